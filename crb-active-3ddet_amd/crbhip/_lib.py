@@ -1,0 +1,99 @@
+"""Loader + ctypes signatures for libcrbhip.so.
+
+Signatures are derived from include/crb_hip.h itself (the single source of truth for the C-ABI), so the
+binding cannot drift from the header: every prototype there must resolve in the shared object.
+"""
+import ctypes
+import os
+import re
+
+import torch  # noqa: F401  (loads libamdhip64 before our library)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+lib_path = os.path.join(_PKG, 'lib', 'libcrbhip.so')
+header_path = os.path.join(os.path.dirname(_PKG), 'include', 'crb_hip.h')
+
+
+class CrbHipError(RuntimeError):
+    pass
+
+
+_ERR = {-1: 'CRB_ERR_ARG', -2: 'CRB_ERR_WORKSPACE', -3: 'CRB_ERR_LAUNCH', -4: 'CRB_ERR_UNSUPPORTED'}
+
+_CT = {'int': ctypes.c_int, 'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float,
+       'double': ctypes.c_double, 'uint32_t': ctypes.c_uint32, 'void': None}
+
+
+def parse_header(path=header_path):
+    """-> {name: (restype, [argtypes])} for every prototype in the header"""
+    src = open(path).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    src = re.sub(r'//[^\n]*', '', src)
+    protos = {}
+    for m in re.finditer(r'\b(int|int64_t|void|float)\s+(crb_\w+)\s*\(([^)]*)\)\s*;', src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        argtypes = []
+        if args and args != 'void':
+            for a in args.split(','):
+                a = a.strip()
+                if '*' in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    base = a.replace('const', '').split()[0]
+                    argtypes.append(_CT[base])
+        protos[name] = (_CT[ret], argtypes)
+    return protos
+
+
+def _load():
+    if not os.path.exists(lib_path):
+        raise CrbHipError(
+            f'{lib_path} not found: build it with `make -C crb-active-3ddet_amd/csrc` '
+            f'(or __graft_entry__.build()). The HIP extension is mandatory; there is no CPU fallback.')
+    L = ctypes.CDLL(lib_path, mode=ctypes.RTLD_GLOBAL)
+    for name, (ret, argtypes) in parse_header().items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise CrbHipError(f'{lib_path} does not export {name} declared in include/crb_hip.h') from e
+        fn.restype = ret
+        fn.argtypes = argtypes
+    return L
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise CrbHipError(f'{what} failed: {_ERR.get(rc, rc)}')
+
+
+def ptr(t):
+    """device (or host) pointer of a contiguous tensor, None -> NULL"""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise CrbHipError('C-ABI needs contiguous tensors')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def cur_stream(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise CrbHipError('libcrbhip ops need device tensors: the HIP path has no CPU fallback')
+
+
+def host_i32x3(v):
+    a = (ctypes.c_int32 * 3)(*[int(x) for x in v])
+    return a
+
+
+def host_f32x3(v):
+    a = (ctypes.c_float * 3)(*[float(x) for x in v])
+    return a

@@ -1,0 +1,219 @@
+"""Host side of the HIP sparse-convolution path (C-ABI: crb_sparse_*, crb_subm_*, crb_spconv_*, crb_pairs_*)."""
+import torch
+
+from ._lib import lib, check, ptr, cur_stream, require_cuda, host_i32x3, CrbHipError
+
+
+def _triple(v):
+    if isinstance(v, (list, tuple)):
+        assert len(v) == 3
+        return [int(x) for x in v]
+    return [int(v)] * 3
+
+
+def conv_out_shape(shape, ksize, stride, padding):
+    return [(int(s) + 2 * p - k) // st + 1 for s, k, st, p in zip(shape, ksize, stride, padding)]
+
+
+class Rulebook(object):
+    """Indice data of one sparse conv (shared by layers with the same indice_key).
+
+    nbr   (n_out,K) i32 : input row feeding output row through offset o, or -1   (forward table)
+    nbr_t (n_in,K)  i32 : output row fed by input row through offset o, or -1    (dgrad table; None for SubM,
+                          whose table is its own transpose under o -> K-1-o)
+    pairs : (pair_in, pair_out, pair_start) built lazily for wgrad
+    """
+
+    def __init__(self, nbr, nbr_t, n_in, n_out, ksize, stride, padding, subm, in_shape, out_shape, out_coords):
+        self.nbr, self.nbr_t = nbr, nbr_t
+        self.n_in, self.n_out = n_in, n_out
+        self.ksize, self.stride, self.padding = ksize, stride, padding
+        self.K = ksize[0] * ksize[1] * ksize[2]
+        self.subm = subm
+        self.in_shape, self.out_shape = in_shape, out_shape
+        self.out_coords = out_coords
+        self.in_coords = None
+        self._pairs = None
+        self._pairs_t = None
+
+    def pairs(self):
+        if self._pairs is None:
+            self._pairs = _pairs_from_nbr(self.nbr, self.n_out, self.K)
+        return self._pairs
+
+    def pairs_t(self):
+        """pairs of the transposed conv (inverse conv): 'in' = rows of this conv's output"""
+        if self._pairs_t is None:
+            self._pairs_t = _pairs_from_nbr(self.nbr_t, self.n_in, self.K)
+        return self._pairs_t
+
+
+def _pairs_from_nbr(nbr, n_rows, K):
+    dev = nbr.device
+    cap = max(n_rows * K, 1)
+    pin = torch.empty((cap,), dtype=torch.int32, device=dev)
+    pout = torch.empty((cap,), dtype=torch.int32, device=dev)
+    pstart = torch.empty((K + 1,), dtype=torch.int32, device=dev)
+    wsb = lib.crb_pairs_workspace_bytes(n_rows, K)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    check(lib.crb_pairs_from_nbr(ptr(nbr), n_rows, K, ptr(pin), ptr(pout), ptr(pstart), ptr(ws), wsb, cur_stream(dev)),
+          'crb_pairs_from_nbr')
+    return pin, pout, pstart
+
+
+def build_hash(coords, shape):
+    require_cuda(coords)
+    n = coords.shape[0]
+    cap = lib.crb_hash_capacity_for(n)
+    hkeys = torch.empty((cap,), dtype=torch.int64, device=coords.device)
+    hvals = torch.empty((cap,), dtype=torch.int32, device=coords.device)
+    check(lib.crb_sparse_hash_build(ptr(coords), n, host_i32x3(shape), ptr(hkeys), ptr(hvals), cap,
+                                    cur_stream(coords.device)), 'crb_sparse_hash_build')
+    return hkeys, hvals, cap
+
+
+def subm_rulebook(coords, shape, ksize):
+    """coords (N,4) i32 cuda contiguous [b,z,y,x]"""
+    require_cuda(coords)
+    assert coords.dtype == torch.int32 and coords.is_contiguous()
+    ksize = _triple(ksize)
+    n = coords.shape[0]
+    K = ksize[0] * ksize[1] * ksize[2]
+    hkeys, hvals, cap = build_hash(coords, shape)
+    nbr = torch.empty((n, K), dtype=torch.int32, device=coords.device)
+    check(lib.crb_subm_rulebook(ptr(coords), n, host_i32x3(shape), host_i32x3(ksize), ptr(hkeys), ptr(hvals), cap,
+                                ptr(nbr), cur_stream(coords.device)), 'crb_subm_rulebook')
+    rb = Rulebook(nbr, None, n, n, ksize, [1, 1, 1], [k // 2 for k in ksize], True, list(shape), list(shape), coords)
+    rb.in_coords = coords
+    return rb
+
+
+def spconv_rulebook(coords, shape, batch_size, ksize, stride, padding):
+    require_cuda(coords)
+    assert coords.dtype == torch.int32 and coords.is_contiguous()
+    ksize, stride, padding = _triple(ksize), _triple(stride), _triple(padding)
+    dev = coords.device
+    n = coords.shape[0]
+    K = ksize[0] * ksize[1] * ksize[2]
+    out_shape = conv_out_shape(shape, ksize, stride, padding)
+    if min(out_shape) <= 0:
+        raise CrbHipError(f'sparse conv output shape {out_shape} is empty')
+    oshape_c = host_i32x3(out_shape)
+    words = lib.crb_spconv_bitmap_words(batch_size, oshape_c)
+    bitmap = torch.empty((words,), dtype=torch.int32, device=dev)
+    prefix = torch.empty((words,), dtype=torch.int32, device=dev)
+    scan_tmp = torch.empty((words // 2048 + 2,), dtype=torch.int32, device=dev)
+    max_out = min(max(n * K, 1), batch_size * out_shape[0] * out_shape[1] * out_shape[2])
+    # upper bound used for the coordinate buffer: an input site feeds at most prod(ceil(k/s)) outputs
+    fan = 1
+    for k, s in zip(ksize, stride):
+        fan *= (k + s - 1) // s
+    max_out = min(max_out, max(n * fan, 1))
+    out_coords = torch.empty((max_out, 4), dtype=torch.int32, device=dev)
+    n_out_dev = torch.empty((1,), dtype=torch.int32, device=dev)
+    st = cur_stream(dev)
+    check(lib.crb_spconv_out_coords(ptr(coords), n, batch_size, host_i32x3(ksize), host_i32x3(stride),
+                                    host_i32x3(padding), oshape_c, ptr(bitmap), ptr(prefix), ptr(scan_tmp),
+                                    ptr(out_coords), max_out, ptr(n_out_dev), st), 'crb_spconv_out_coords')
+    n_out = int(n_out_dev.item())      # sync: the output row count sizes every later buffer
+    assert n_out <= max_out
+    out_coords = out_coords[:n_out]
+    nbr = torch.empty((n_out, K), dtype=torch.int32, device=dev)
+    nbr_t = torch.empty((n, K), dtype=torch.int32, device=dev)
+    check(lib.crb_spconv_rulebook(ptr(coords), n, batch_size, host_i32x3(ksize), host_i32x3(stride),
+                                  host_i32x3(padding), oshape_c, ptr(bitmap), ptr(prefix), n_out, ptr(nbr), ptr(nbr_t),
+                                  st), 'crb_spconv_rulebook')
+    rb = Rulebook(nbr, nbr_t, n, n_out, ksize, stride, padding, False, list(shape), out_shape, out_coords)
+    rb.in_coords = coords
+    return rb
+
+
+def _conv_forward_raw(x, w_kio, nbr, n_out):
+    """x (n_in,cin), w (K,cin,cout), nbr (n_out,K) -> (n_out,cout)"""
+    K, cin, cout = w_kio.shape
+    if not lib.crb_sparse_conv_supported(cin, cout):
+        raise CrbHipError(f'sparse conv channel pair ({cin},{cout}) has no gfx950 kernel instance')
+    y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    check(lib.crb_sparse_conv_forward(ptr(x), ptr(w_kio), ptr(nbr), ptr(y), n_out, K, cin, cout, cur_stream(x.device)),
+          'crb_sparse_conv_forward')
+    return y
+
+
+def _conv_wgrad_raw(x, dy, pairs, K):
+    cin, cout = x.shape[1], dy.shape[1]
+    pin, pout, pstart = pairs
+    dw = torch.empty((K, cin, cout), dtype=torch.float32, device=x.device)
+    wsb = lib.crb_sparse_conv_wgrad_workspace_bytes(K, cin, cout)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+    check(lib.crb_sparse_conv_wgrad(ptr(x), ptr(dy), ptr(pin), ptr(pout), ptr(pstart), ptr(dw), K, cin, cout, ptr(ws),
+                                    wsb, cur_stream(x.device)), 'crb_sparse_conv_wgrad')
+    return dw
+
+
+class SparseConvFunction(torch.autograd.Function):
+    """y = sum_o x[nbr[:,o]] @ w[o]   (w in (K,Cin,Cout) layout; `inverse` runs the transposed rulebook)"""
+
+    @staticmethod
+    def forward(ctx, x, w_kio, rb, inverse):
+        require_cuda(x, w_kio)
+        x = x.contiguous().float()
+        w_kio = w_kio.contiguous().float()
+        if inverse:
+            table, n_out = rb.nbr_t, rb.n_in
+        else:
+            table, n_out = rb.nbr, rb.n_out
+        ctx.rb, ctx.inverse = rb, inverse
+        ctx.save_for_backward(x, w_kio)
+        return _conv_forward_raw(x, w_kio, table, n_out)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        rb, inverse = ctx.rb, ctx.inverse
+        dy = dy.contiguous().float()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if rb.subm:
+                wd = w.flip(0).transpose(1, 2).contiguous()      # Wd[o] = W[K-1-o]^T
+                dx = _conv_forward_raw(dy, wd, rb.nbr, rb.n_in)
+            else:
+                wd = w.transpose(1, 2).contiguous()
+                table, n_in = (rb.nbr, rb.n_out) if inverse else (rb.nbr_t, rb.n_in)
+                dx = _conv_forward_raw(dy, wd, table, n_in)
+        if ctx.needs_input_grad[1]:
+            pairs = rb.pairs_t() if inverse else rb.pairs()
+            dw = _conv_wgrad_raw(x, dy, pairs, rb.K)
+        return dx, dw, None, None
+
+
+def sparse_conv(x, w_kio, rb, inverse=False):
+    return SparseConvFunction.apply(x, w_kio, rb, inverse)
+
+
+class ToDenseFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, coords, batch_size, shape):
+        require_cuda(feat, coords)
+        feat = feat.contiguous().float()
+        n, C = feat.shape
+        D, H, W = [int(v) for v in shape]
+        out = torch.empty((batch_size, C, D, H, W), dtype=torch.float32, device=feat.device)
+        check(lib.crb_sparse_to_dense(ptr(feat), ptr(coords), ptr(out), n, batch_size, C, D, H, W, 1,
+                                      cur_stream(feat.device)), 'crb_sparse_to_dense')
+        ctx.save_for_backward(coords)
+        ctx.meta = (n, batch_size, C, D, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (coords,) = ctx.saved_tensors
+        n, B, C, D, H, W = ctx.meta
+        g = g.contiguous().float()
+        df = torch.empty((n, C), dtype=torch.float32, device=g.device)
+        check(lib.crb_dense_to_sparse(ptr(g), ptr(coords), ptr(df), n, B, C, D, H, W, cur_stream(g.device)),
+              'crb_dense_to_sparse')
+        return df, None, None, None
+
+
+def to_dense(feat, coords, batch_size, shape):
+    return ToDenseFunction.apply(feat, coords, batch_size, shape)

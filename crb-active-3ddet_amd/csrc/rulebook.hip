@@ -1,0 +1,271 @@
+// Sparse-conv "rulebook" construction for gfx950 (row a4 of SURVEY §8).
+//
+// Replaces the indice-pair generation inside spconv.pytorch SubMConv3d / SparseConv3d as configured by
+// the reference at pcdet/models/backbones_3d/spconv_backbone.py:77-117 (third-party spconv-cu113 v2.1.21,
+// absent from the reference tree; semantics restated in SURVEY Appendix A).
+//
+// Data layout in HBM (all int32, device):
+//   coords  (N,4)   [b,z,y,x]
+//   nbr     (N_out,K)  output-stationary table: nbr[i][o] = input row feeding output i through kernel
+//                      offset o = (kz*KH+ky)*KW+kx, or -1
+//   nbr_t   (N_in,K)   the transposed table (for dgrad of strided convs): nbr_t[j][o] = output row or -1
+//   pairs   pair_in/pair_out (P) sorted by (o, out row) + pair_start (K+1): the classic rulebook, used by wgrad
+// Site -> row lookup is an open-addressing hash on the 64-bit linear site index. The output set of a
+// strided conv is de-duplicated AND ordered through a bitmap over the output volume (rank = popcount
+// prefix), which makes the output row order canonical: ascending linear index (b,z,y,x).
+#include "crb_common.h"
+#include "../../include/crb_hip.h"
+
+namespace {
+
+struct Shape3 { int d, h, w; };
+
+__device__ __forceinline__ int64_t lin_index(int b, int z, int y, int x, Shape3 s) {
+  return (((int64_t)b * s.d + z) * s.h + y) * (int64_t)s.w + x;
+}
+
+__global__ __launch_bounds__(256) void hash_build_kernel(const int* __restrict__ coords, int n, Shape3 s,
+                                                         long long* __restrict__ hkeys, int* __restrict__ hvals,
+                                                         uint32_t hmask) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int4 c = *reinterpret_cast<const int4*>(coords + (int64_t)i * 4);
+  uint32_t slot = crb_hash_insert(hkeys, hmask, lin_index(c.x, c.y, c.z, c.w, s));
+  // duplicate coordinates: the smallest row wins (deterministic)
+  atomicMin(&hvals[slot], i);
+}
+
+struct ConvGeom {
+  int kd, kh, kw;
+  int sd, sh, sw;
+  int pd, ph, pw;
+};
+
+// SubM: one thread per (row, offset)
+__global__ __launch_bounds__(256) void subm_nbr_kernel(const int* __restrict__ coords, int n, Shape3 s, ConvGeom g,
+                                                       const long long* __restrict__ hkeys,
+                                                       const int* __restrict__ hvals, uint32_t hmask,
+                                                       int* __restrict__ nbr) {
+  const int K = g.kd * g.kh * g.kw;
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)n * K) return;
+  int i = (int)(t / K);
+  int o = (int)(t - (int64_t)i * K);
+  int kx = o % g.kw, ky = (o / g.kw) % g.kh, kz = o / (g.kw * g.kh);
+  int4 c = *reinterpret_cast<const int4*>(coords + (int64_t)i * 4);
+  int z = c.y + kz - g.kd / 2, y = c.z + ky - g.kh / 2, x = c.w + kx - g.kw / 2;
+  int r = -1;
+  if (z >= 0 && z < s.d && y >= 0 && y < s.h && x >= 0 && x < s.w) {
+    uint32_t slot = crb_hash_find(hkeys, hmask, lin_index(c.x, z, y, x, s));
+    if (slot != 0xffffffffu) r = hvals[slot];
+  }
+  nbr[t] = r;
+}
+
+// strided conv, pass 1: mark every output site reached by (input row, offset) in the bitmap
+__global__ __launch_bounds__(256) void spconv_mark_kernel(const int* __restrict__ coords, int n, ConvGeom g,
+                                                          Shape3 so, uint32_t* __restrict__ bitmap) {
+  const int K = g.kd * g.kh * g.kw;
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)n * K) return;
+  int j = (int)(t / K);
+  int o = (int)(t - (int64_t)j * K);
+  int kx = o % g.kw, ky = (o / g.kw) % g.kh, kz = o / (g.kw * g.kh);
+  int4 c = *reinterpret_cast<const int4*>(coords + (int64_t)j * 4);
+  int tz = c.y + g.pd - kz, ty = c.z + g.ph - ky, tx = c.w + g.pw - kx;
+  if (tz < 0 || ty < 0 || tx < 0) return;
+  if (tz % g.sd || ty % g.sh || tx % g.sw) return;
+  int oz = tz / g.sd, oy = ty / g.sh, ox = tx / g.sw;
+  if (oz >= so.d || oy >= so.h || ox >= so.w) return;
+  int64_t lin = lin_index(c.x, oz, oy, ox, so);
+  atomicOr(&bitmap[lin >> 5], 1u << (lin & 31));
+}
+
+struct PopcF {
+  const uint32_t* bm;
+  __device__ int operator()(int64_t i) const { return __popc(bm[i]); }
+};
+struct PrefixW {
+  int* prefix;
+  __device__ void operator()(int64_t i, int ex, int) const { prefix[i] = ex; }
+};
+
+// pass 2: expand bitmap words into sorted output coordinates
+__global__ __launch_bounds__(256) void spconv_emit_coords_kernel(const uint32_t* __restrict__ bitmap,
+                                                                 const int* __restrict__ prefix, int64_t nwords,
+                                                                 Shape3 so, int max_out, int* __restrict__ out_coords) {
+  int64_t wi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (wi >= nwords) return;
+  uint32_t m = bitmap[wi];
+  int r = prefix[wi];
+  while (m) {
+    int bit = __ffs(m) - 1;
+    m &= m - 1;
+    if (r < max_out) {
+      int64_t lin = wi * 32 + bit;
+      int x = (int)(lin % so.w); lin /= so.w;
+      int y = (int)(lin % so.h); lin /= so.h;
+      int z = (int)(lin % so.d); lin /= so.d;
+      *reinterpret_cast<int4*>(out_coords + (int64_t)r * 4) = make_int4((int)lin, z, y, x);
+    }
+    ++r;
+  }
+}
+
+// pass 3: per (input row, offset) find the output row (bitmap rank) and fill both tables
+__global__ __launch_bounds__(256) void spconv_nbr_kernel(const int* __restrict__ coords, int n, ConvGeom g, Shape3 so,
+                                                         const uint32_t* __restrict__ bitmap,
+                                                         const int* __restrict__ prefix, int n_out,
+                                                         int* __restrict__ nbr /* (n_out,K) pre-filled -1 */,
+                                                         int* __restrict__ nbr_t /* (n,K) */) {
+  const int K = g.kd * g.kh * g.kw;
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)n * K) return;
+  int j = (int)(t / K);
+  int o = (int)(t - (int64_t)j * K);
+  int kx = o % g.kw, ky = (o / g.kw) % g.kh, kz = o / (g.kw * g.kh);
+  int4 c = *reinterpret_cast<const int4*>(coords + (int64_t)j * 4);
+  int tz = c.y + g.pd - kz, ty = c.z + g.ph - ky, tx = c.w + g.pw - kx;
+  int r = -1;
+  if (tz >= 0 && ty >= 0 && tx >= 0 && !(tz % g.sd) && !(ty % g.sh) && !(tx % g.sw)) {
+    int oz = tz / g.sd, oy = ty / g.sh, ox = tx / g.sw;
+    if (oz < so.d && oy < so.h && ox < so.w) {
+      int64_t lin = lin_index(c.x, oz, oy, ox, so);
+      uint32_t word = bitmap[lin >> 5];
+      r = prefix[lin >> 5] + __popc(word & ((1u << (lin & 31)) - 1u));
+      if (r >= n_out) r = -1;
+    }
+  }
+  nbr_t[t] = r;
+  if (r >= 0) nbr[(int64_t)r * K + o] = j;   // unique writer: (out site, offset) determines the input site
+}
+
+// pair lists: flattened offset-major index f = o*n_out + i
+struct PairFlag {
+  const int* nbr; int n_out; int K;
+  __device__ int operator()(int64_t f) const {
+    int o = (int)(f / n_out); int i = (int)(f - (int64_t)o * n_out);
+    return nbr[(int64_t)i * K + o] >= 0 ? 1 : 0;
+  }
+};
+struct PairWrite {
+  const int* nbr; int n_out; int K; int* pin; int* pout; int* pstart;
+  __device__ void operator()(int64_t f, int ex, int v) const {
+    int o = (int)(f / n_out); int i = (int)(f - (int64_t)o * n_out);
+    if (i == 0) pstart[o] = ex;
+    if (v) { pin[ex] = nbr[(int64_t)i * K + o]; pout[ex] = i; }
+  }
+};
+
+__global__ void fill_i32_kernel(int* p, int64_t n, int v) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+extern "C" int64_t crb_hash_capacity_for(int64_t n) { return crb_hash_capacity(n); }
+
+extern "C" int crb_sparse_hash_build(const int32_t* coords, int64_t n, const int32_t* shape_dhw,
+                                     int64_t* hkeys, int32_t* hvals, int64_t capacity, void* stream) {
+  if (n < 0 || capacity < 2 * n || (capacity & (capacity - 1))) return CRB_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  CRB_HIP(hipMemsetAsync(hkeys, 0xff, (size_t)capacity * 8, st));
+  CRB_HIP(hipMemsetAsync(hvals, 0x7f, (size_t)capacity * 4, st));
+  if (n == 0) return CRB_OK;
+  Shape3 s{shape_dhw[0], shape_dhw[1], shape_dhw[2]};
+  hipLaunchKernelGGL(hash_build_kernel, dim3(crb_cdiv(n, 256)), dim3(256), 0, st, coords, (int)n, s,
+                     (long long*)hkeys, hvals, (uint32_t)(capacity - 1));
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_subm_rulebook(const int32_t* coords, int64_t n, const int32_t* shape_dhw, const int32_t* ksize,
+                                 const int64_t* hkeys, const int32_t* hvals, int64_t capacity,
+                                 int32_t* nbr, void* stream) {
+  if (n < 0 || (capacity & (capacity - 1))) return CRB_ERR_ARG;
+  if (n == 0) return CRB_OK;
+  if (!(ksize[0] & 1) || !(ksize[1] & 1) || !(ksize[2] & 1)) return CRB_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  Shape3 s{shape_dhw[0], shape_dhw[1], shape_dhw[2]};
+  ConvGeom g{ksize[0], ksize[1], ksize[2], 1, 1, 1, ksize[0] / 2, ksize[1] / 2, ksize[2] / 2};
+  const int K = g.kd * g.kh * g.kw;
+  hipLaunchKernelGGL(subm_nbr_kernel, dim3(crb_cdiv(n * K, 256)), dim3(256), 0, st, coords, (int)n, s, g,
+                     (const long long*)hkeys, hvals, (uint32_t)(capacity - 1), nbr);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int64_t crb_spconv_bitmap_words(int B, const int32_t* out_shape_dhw) {
+  int64_t sites = (int64_t)B * out_shape_dhw[0] * out_shape_dhw[1] * out_shape_dhw[2];
+  return (sites + 31) / 32;
+}
+
+extern "C" int64_t crb_spconv_out_coords_workspace_bytes(int B, const int32_t* out_shape_dhw) {
+  int64_t words = crb_spconv_bitmap_words(B, out_shape_dhw);
+  return crb_align_up(words * 4, 256) * 2 + crb_align_up((int64_t)crb_scan_num_tiles(words) * 4, 256) + 1024;
+}
+
+// Stage 1 of a strided conv: output active set. bitmap/prefix (words each) stay alive for stage 2.
+extern "C" int crb_spconv_out_coords(const int32_t* coords, int64_t n, int B, const int32_t* ksize,
+                                     const int32_t* stride, const int32_t* padding, const int32_t* out_shape_dhw,
+                                     uint32_t* bitmap, int32_t* prefix, int32_t* scan_tmp,
+                                     int32_t* out_coords, int64_t max_out, int32_t* n_out_dev, void* stream) {
+  if (n < 0 || B <= 0) return CRB_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  Shape3 so{out_shape_dhw[0], out_shape_dhw[1], out_shape_dhw[2]};
+  ConvGeom g{ksize[0], ksize[1], ksize[2], stride[0], stride[1], stride[2], padding[0], padding[1], padding[2]};
+  const int K = g.kd * g.kh * g.kw;
+  const int64_t words = crb_spconv_bitmap_words(B, out_shape_dhw);
+  CRB_HIP(hipMemsetAsync(bitmap, 0, (size_t)words * 4, st));
+  if (n > 0)
+    hipLaunchKernelGGL(spconv_mark_kernel, dim3(crb_cdiv(n * K, 256)), dim3(256), 0, st, coords, (int)n, g, so, bitmap);
+  PopcF f{bitmap};
+  PrefixW w{prefix};
+  int rc = crb_device_excl_scan(f, w, words, scan_tmp, n_out_dev, st);
+  if (rc != CRB_OK) return rc;
+  hipLaunchKernelGGL(spconv_emit_coords_kernel, dim3(crb_cdiv(words, 256)), dim3(256), 0, st, bitmap, prefix, words,
+                     so, (int)(max_out > 0x7fffffff ? 0x7fffffff : max_out), out_coords);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+// Stage 2: both neighbour tables.
+extern "C" int crb_spconv_rulebook(const int32_t* coords, int64_t n, int B, const int32_t* ksize,
+                                   const int32_t* stride, const int32_t* padding, const int32_t* out_shape_dhw,
+                                   const uint32_t* bitmap, const int32_t* prefix, int64_t n_out,
+                                   int32_t* nbr, int32_t* nbr_t, void* stream) {
+  if (n < 0 || n_out < 0) return CRB_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  Shape3 so{out_shape_dhw[0], out_shape_dhw[1], out_shape_dhw[2]};
+  ConvGeom g{ksize[0], ksize[1], ksize[2], stride[0], stride[1], stride[2], padding[0], padding[1], padding[2]};
+  const int K = g.kd * g.kh * g.kw;
+  if (n_out > 0)
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(crb_cdiv(n_out * K, 256)), dim3(256), 0, st, nbr, n_out * K, -1);
+  if (n > 0)
+    hipLaunchKernelGGL(spconv_nbr_kernel, dim3(crb_cdiv(n * K, 256)), dim3(256), 0, st, coords, (int)n, g, so, bitmap,
+                       prefix, (int)n_out, nbr, nbr_t);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int64_t crb_pairs_workspace_bytes(int64_t n_out, int K) {
+  return crb_align_up((int64_t)crb_scan_num_tiles(n_out * K) * 4, 256) + 256;
+}
+
+// Classic rulebook (pair lists sorted by (offset, output row)) from the output-stationary table.
+// pair_in/pair_out need n_out*K entries of capacity (P is only known on the device: pair_start[K]).
+extern "C" int crb_pairs_from_nbr(const int32_t* nbr, int64_t n_out, int K, int32_t* pair_in, int32_t* pair_out,
+                                  int32_t* pair_start /* K+1 */, void* workspace, int64_t workspace_bytes,
+                                  void* stream) {
+  if (n_out < 0 || K <= 0) return CRB_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (n_out == 0) { CRB_HIP(hipMemsetAsync(pair_start, 0, sizeof(int) * (K + 1), st)); return CRB_OK; }
+  if (n_out * K > 0x7fffffffLL) return CRB_ERR_ARG;
+  CrbArena a(workspace, (size_t)workspace_bytes);
+  int* tiles = a.take<int>(crb_scan_num_tiles(n_out * K));
+  if (!a.ok) return CRB_ERR_WORKSPACE;
+  PairFlag f{nbr, (int)n_out, K};
+  PairWrite w{nbr, (int)n_out, K, pair_in, pair_out, pair_start};
+  return crb_device_excl_scan(f, w, n_out * K, tiles, pair_start + K, st);
+}

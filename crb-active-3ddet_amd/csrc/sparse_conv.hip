@@ -1,0 +1,298 @@
+// Sparse 3D convolution arithmetic for gfx950 (row a4 of SURVEY §8): output-stationary gather-GEMM
+// forward / dgrad on the f32 MFMA (v_mfma_f32_16x16x4_f32, exact f32), pair-list wgrad.
+//
+// Replaces the gather -> GEMM -> scatter-add inside spconv.pytorch SubMConv3d / SparseConv3d (third-party
+// spconv-cu113 v2.1.21) as instantiated by pcdet/models/backbones_3d/spconv_backbone.py:77-117,148-157.
+//
+// Forward:  Y[i,:] = sum_o X[nbr[i][o],:] @ W[o]          W is (K, Cin, Cout) f32, contiguous
+// dgrad  :  the same kernel on the transposed table with W[o]^T (host passes both)
+// wgrad  :  dW[o] = sum_{pairs p of offset o} X[pin[p],:]^T (x) dY[pout[p],:]
+//
+// Tile shape: one 256-thread workgroup = 4 waves x 16 output rows. Lane l of a wave owns A row i = l&15 and
+// k-group g = l>>4 of the 16x16x4 MFMA. A lane reads a float4 of its gathered row (16 s + 4 g .. +3), i.e. the
+// k index is permuted (k' = 16 s + 4 g + t for MFMA t) — the same permutation indexes W in LDS, so the sum is
+// unchanged up to f32 summation order. W[o] is staged in LDS once per workgroup and offset (row stride Cout+4
+// keeps the two 16-lane halves of a ds_read_b32 group on different banks).
+// Offsets for which no row of the workgroup (resp. wave) has a neighbour are skipped.
+// blockIdx is remapped so that consecutive row tiles land on the same XCD (private L2 per XCD).
+#include "crb_common.h"
+#include "../../include/crb_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ int xcd_remap(int b, int nblocks) {
+  // hardware round-robins block b to XCD b%8; give every XCD a contiguous chunk of tiles
+  const int per = (nblocks + 7) >> 3;
+  int t = (b & 7) * per + (b >> 3);
+  return t;
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                              const int* __restrict__ nbr, float* __restrict__ Y,
+                                                              int n_out, int K, int ntiles) {
+  constexpr int NB = COUT / 16;          // 16-wide output column blocks
+  constexpr int WS = COUT + 4;           // padded LDS row stride of W[o]
+  constexpr int KSTEPS = (CIN + 3) / 4;  // MFMA k-steps
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* w_lds = reinterpret_cast<float*>(smem);                   // CINP * WS floats
+  constexpr int CINP = KSTEPS * 4;
+  int* nbr_lds = reinterpret_cast<int*>(smem + sizeof(float) * CINP * WS);  // 64 * K ints
+  __shared__ unsigned wg_mask_sh[4];
+
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  if (tile >= ntiles) return;
+  const int row0 = tile * 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int li = lane & 15;
+  const int g = lane >> 4;
+
+  // stage the 64 x K slice of the neighbour table (contiguous in HBM)
+  const int rows_here = min(64, n_out - row0);
+  for (int t = threadIdx.x; t < 64 * K; t += 256) {
+    int r = t / K;
+    nbr_lds[t] = (r < rows_here) ? nbr[(int64_t)row0 * K + t] : -1;
+  }
+  __syncthreads();
+  // per-wave / per-workgroup offset masks (K <= 32)
+  unsigned wmask = 0;
+  {
+    const int myrow = wave * 16 + li;
+    for (int o = 0; o < K; ++o) {
+      bool has = nbr_lds[myrow * K + o] >= 0;
+      if (__ballot(has)) wmask |= (1u << o);
+    }
+    if (lane == 0) wg_mask_sh[wave] = wmask;
+  }
+  __syncthreads();
+  const unsigned wgmask = wg_mask_sh[0] | wg_mask_sh[1] | wg_mask_sh[2] | wg_mask_sh[3];
+
+  f32x4 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int o = 0; o < K; ++o) {
+    if (!((wgmask >> o) & 1u)) continue;   // workgroup-uniform
+    __syncthreads();                       // everyone is done with the previous W[o]
+    {
+      const float* wsrc = W + (int64_t)o * CIN * COUT;
+      if constexpr ((COUT % 4) == 0) {
+        for (int t = threadIdx.x; t < CINP * (COUT / 4); t += 256) {
+          int k = t / (COUT / 4), c4 = t - k * (COUT / 4);
+          f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (k < CIN) v = *reinterpret_cast<const f32x4*>(wsrc + k * COUT + c4 * 4);
+          *reinterpret_cast<f32x4*>(w_lds + k * WS + c4 * 4) = v;
+        }
+      }
+    }
+    __syncthreads();
+    if (!((wmask >> o) & 1u)) continue;    // wave-uniform
+    const int r = nbr_lds[(wave * 16 + li) * K + o];
+    if constexpr (CIN >= 16) {
+#pragma unroll
+      for (int s = 0; s < CIN / 16; ++s) {
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (r >= 0) a = *reinterpret_cast<const f32x4*>(X + (int64_t)r * CIN + 16 * s + 4 * g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float* wrow = w_lds + (16 * s + 4 * g + t) * WS + li;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], wrow[nb * 16], acc[nb], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        const int k = 4 * s + g;
+        float a = 0.f;
+        if (r >= 0 && k < CIN) a = X[(int64_t)r * CIN + k];
+        const float* wrow = w_lds + k * WS + li;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wrow[nb * 16], acc[nb], 0, 0, 0);
+      }
+    }
+  }
+
+  // C/D layout of 16x16: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int row = row0 + wave * 16 + g * 4 + rg;
+      if (row < n_out) Y[(int64_t)row * COUT + nb * 16 + li] = acc[nb][rg];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad: grid (K, S). Workgroup (o, s) reduces its slice of offset o's pairs into a (CIN x COUT) partial.
+// Waves are arranged (ci-wave, pair-slice): WCI waves along Cin (each CIPW 16-row blocks), 4/WCI pair slices.
+// ---------------------------------------------------------------------------------------------------
+template <int CIN, int COUT>
+struct WgradCfg {
+  static constexpr int NCI = (CIN + 15) / 16;
+  static constexpr int CIPW = NCI >= 4 ? NCI / 4 : 1;   // ci blocks per wave
+  static constexpr int WCI = NCI / CIPW;                 // waves along ci (1,2,4)
+  static constexpr int SLICES = 4 / WCI;                 // pair slices per workgroup
+  static constexpr int NB = COUT / 16;
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                                const int* __restrict__ pin, const int* __restrict__ pout,
+                                                                const int* __restrict__ pstart,
+                                                                float* __restrict__ partial /* (S,K,CIN,COUT) */,
+                                                                int K) {
+  using C = WgradCfg<CIN, COUT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);   // SLICES>1: (SLICES-1) * CINP16 * COUT floats
+  const int o = blockIdx.x, S = gridDim.y, sidx = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int wci = wave % C::WCI, slice = wave / C::WCI;
+  const int p0 = pstart[o], p1 = pstart[o + 1];
+  const int np = p1 - p0;
+  // pairs are cut into groups of 4; group q belongs to workgroup (q % S) and slice ((q / S) % SLICES)
+  const int ngroups = (np + 3) >> 2;
+
+  f32x4 acc[C::CIPW][C::NB];
+#pragma unroll
+  for (int a = 0; a < C::CIPW; ++a)
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb) acc[a][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int q = sidx + S * slice; q < ngroups; q += S * C::SLICES) {
+    const int p = p0 + q * 4 + g;
+    const bool valid = p < p1;
+    const int ji = valid ? pin[p] : 0;
+    const int io = valid ? pout[p] : 0;
+    float b[C::NB];
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb) b[nb] = valid ? dY[(int64_t)io * COUT + nb * 16 + li] : 0.f;
+#pragma unroll
+    for (int a = 0; a < C::CIPW; ++a) {
+      const int ci = (wci * C::CIPW + a) * 16 + li;
+      float av = (valid && ci < CIN) ? X[(int64_t)ji * CIN + ci] : 0.f;
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb)
+        acc[a][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nb], acc[a][nb], 0, 0, 0);
+    }
+  }
+
+  // reduce pair slices through LDS (fixed order), slice 0 writes the partial
+  constexpr int CINP16 = C::NCI * 16;
+  if constexpr (C::SLICES > 1) {
+    if (slice > 0) {
+#pragma unroll
+      for (int a = 0; a < C::CIPW; ++a)
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int ci = (wci * C::CIPW + a) * 16 + g * 4 + rg;
+            red[((slice - 1) * CINP16 + ci) * COUT + nb * 16 + li] = acc[a][nb][rg];
+          }
+    }
+    __syncthreads();
+  }
+  if (slice == 0) {
+    float* dst = partial + ((int64_t)sidx * K + o) * CIN * COUT;
+#pragma unroll
+    for (int a = 0; a < C::CIPW; ++a)
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int ci = (wci * C::CIPW + a) * 16 + g * 4 + rg;
+          float v = acc[a][nb][rg];
+          if constexpr (C::SLICES > 1) {
+#pragma unroll
+            for (int sl = 1; sl < C::SLICES; ++sl) v += red[((sl - 1) * CINP16 + ci) * COUT + nb * 16 + li];
+          }
+          if (ci < CIN) dst[ci * COUT + nb * 16 + li] = v;
+        }
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW,
+                                                           int64_t elems, int S) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= elems) return;
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += partial[(int64_t)k * elems + i];
+  dW[i] = s;
+}
+
+template <int CIN, int COUT>
+int launch_fwd(const float* X, const float* W, const int* nbr, float* Y, int64_t n_out, int K, hipStream_t st) {
+  constexpr int KSTEPS = (CIN + 3) / 4;
+  const int ntiles = crb_cdiv(n_out, 64);
+  const int grid = ((ntiles + 7) / 8) * 8;
+  size_t lds = sizeof(float) * KSTEPS * 4 * (COUT + 4) + sizeof(int) * 64 * K;
+  hipLaunchKernelGGL((sparse_conv_fwd_kernel<CIN, COUT>), dim3(grid), dim3(256), lds, st, X, W, nbr, Y, (int)n_out, K,
+                     ntiles);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+template <int CIN, int COUT>
+int launch_wgrad(const float* X, const float* dY, const int* pin, const int* pout, const int* pstart, float* dW,
+                 float* partial, int K, int S, hipStream_t st) {
+  using C = WgradCfg<CIN, COUT>;
+  size_t lds = C::SLICES > 1 ? sizeof(float) * (C::SLICES - 1) * C::NCI * 16 * COUT : 0;
+  hipLaunchKernelGGL((sparse_conv_wgrad_kernel<CIN, COUT>), dim3(K, S), dim3(256), lds, st, X, dY, pin, pout, pstart,
+                     partial, K);
+  const int64_t elems = (int64_t)K * CIN * COUT;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(crb_cdiv(elems, 256)), dim3(256), 0, st, partial, dW, elems, S);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+}  // namespace
+
+#define CRB_CONV_SHAPES(X_) \
+  X_(4, 16) X_(5, 16) X_(16, 16) X_(16, 32) X_(32, 16) X_(32, 32) X_(32, 64) X_(64, 32) X_(64, 64) X_(64, 128) \
+  X_(128, 64) X_(128, 128)
+
+extern "C" int crb_sparse_conv_supported(int cin, int cout) {
+#define X_(a, b) if (cin == a && cout == b) return 1;
+  CRB_CONV_SHAPES(X_)
+#undef X_
+  return 0;
+}
+
+extern "C" int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, float* Y, int64_t n_out,
+                                       int K, int cin, int cout, void* stream) {
+  if (n_out < 0 || K <= 0 || K > 32) return CRB_ERR_ARG;
+  if (n_out == 0) return CRB_OK;
+  hipStream_t st = (hipStream_t)stream;
+#define X_(a, b) if (cin == a && cout == b) return launch_fwd<a, b>(X, W, nbr, Y, n_out, K, st);
+  CRB_CONV_SHAPES(X_)
+#undef X_
+  return CRB_ERR_UNSUPPORTED;
+}
+
+extern "C" int crb_sparse_conv_wgrad_splits(void) { return 48; }
+
+extern "C" int64_t crb_sparse_conv_wgrad_workspace_bytes(int K, int cin, int cout) {
+  return (int64_t)crb_sparse_conv_wgrad_splits() * K * cin * cout * 4 + 256;
+}
+
+extern "C" int crb_sparse_conv_wgrad(const float* X, const float* dY, const int32_t* pair_in, const int32_t* pair_out,
+                                     const int32_t* pair_start, float* dW, int K, int cin, int cout,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+  if (K <= 0) return CRB_ERR_ARG;
+  if (workspace_bytes < crb_sparse_conv_wgrad_workspace_bytes(K, cin, cout) - 256 || !workspace) return CRB_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int S = crb_sparse_conv_wgrad_splits();
+#define X_(a, b) \
+  if (cin == a && cout == b) return launch_wgrad<a, b>(X, dY, pair_in, pair_out, pair_start, dW, (float*)workspace, K, S, st);
+  CRB_CONV_SHAPES(X_)
+#undef X_
+  return CRB_ERR_UNSUPPORTED;
+}

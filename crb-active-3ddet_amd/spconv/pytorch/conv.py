@@ -1,0 +1,160 @@
+"""Sparse convolution layers (host mirror of spconv.pytorch.conv) over the gfx950 gather-GEMM kernels.
+
+Parameter layout follows spconv 2.x: weight (Cout, kd, kh, kw, Cin) — the layout the reference's checkpoint
+loader adapts to (pcdet/models/detectors/detector3d_template.py:455-484)."""
+import math
+
+import torch
+from torch import nn
+from torch.nn import init
+
+from crbhip import sparse as _sp
+from .core import SparseConvTensor
+from .modules import SparseModule
+
+
+def _ntuple(v, n):
+    if isinstance(v, (list, tuple)):
+        assert len(v) == n
+        return [int(x) for x in v]
+    return [int(v)] * n
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None,
+                 algo=None, fp32_accum=None, name=None):
+        super().__init__()
+        assert groups == 1, 'groups > 1 is not on the reference hot path'
+        assert ndim in (2, 3)
+        self.ndim = ndim
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _ntuple(kernel_size, ndim)
+        self.stride = _ntuple(stride, ndim)
+        self.padding = _ntuple(padding, ndim)
+        self.dilation = _ntuple(dilation, ndim)
+        assert all(d == 1 for d in self.dilation), 'dilation != 1 is not on the reference hot path'
+        assert not transposed, 'SparseConvTranspose is not on the reference hot path'
+        self.subm, self.inverse, self.transposed = subm, inverse, transposed
+        self.indice_key = indice_key
+        self.conv1x1 = all(k == 1 for k in self.kernel_size) and all(s == 1 for s in self.stride)
+        self.weight = nn.Parameter(torch.empty(out_channels, *self.kernel_size, in_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def extra_repr(self):
+        return (f'{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, '
+                f'padding={self.padding}, subm={self.subm}, inverse={self.inverse}, indice_key={self.indice_key}')
+
+    def reset_parameters(self):
+        # kaiming-uniform like torch.nn.Conv* / spconv: fan_in = Cin * prod(k)
+        fan_in = self.in_channels
+        for k in self.kernel_size:
+            fan_in *= k
+        gain = math.sqrt(2.0 / (1 + 5.0))           # a = sqrt(5)
+        bound = gain * math.sqrt(3.0 / fan_in)
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if self.bias is not None:
+                b = 1.0 / math.sqrt(fan_in)
+                init.uniform_(self.bias, -b, b)
+
+    def _k3(self, v, fill):
+        return ([fill] + list(v)) if self.ndim == 2 else list(v)
+
+    def weight_kio(self):
+        """(Cout,k..,Cin) -> (K,Cin,Cout) contiguous; differentiable"""
+        w = self.weight
+        K = 1
+        for k in self.kernel_size:
+            K *= k
+        return w.reshape(self.out_channels, K, self.in_channels).permute(1, 2, 0).contiguous()
+
+    def forward(self, input):
+        assert isinstance(input, SparseConvTensor)
+        feats, indices = input.features, input.indices
+        ndim = self.ndim
+        spatial_shape = input.spatial_shape
+        if ndim == 2:
+            idx3 = torch.cat([indices[:, :1], torch.zeros_like(indices[:, :1]), indices[:, 1:]], dim=1).contiguous()
+            shape3 = [1] + list(spatial_shape)
+        else:
+            idx3, shape3 = indices, list(spatial_shape)
+        ks, st, pd = self._k3(self.kernel_size, 1), self._k3(self.stride, 1), self._k3(self.padding, 0)
+
+        if self.conv1x1 and not self.inverse:
+            out = torch.mm(feats, self.weight.view(self.out_channels, self.in_channels).t())
+            if self.bias is not None:
+                out = out + self.bias
+            return input.replace_feature(out)
+
+        datas = input.find_indice_pair(self.indice_key)
+        if self.inverse:
+            assert datas is not None and self.indice_key is not None, 'inverse conv needs the indice_key of a SparseConv'
+            rb = datas
+            assert not rb.subm
+            out_feats = _sp.sparse_conv(feats, self.weight_kio(), rb, True)
+            out_indices3, out_shape3 = rb.in_coords, rb.in_shape
+        else:
+            if datas is not None and self.subm:
+                rb = datas
+                assert rb.n_in == feats.shape[0], 'indice_key reused on a tensor with a different active set'
+            elif datas is not None and not self.subm:
+                rb = datas
+                assert rb.n_in == feats.shape[0]
+            else:
+                if self.subm:
+                    rb = _sp.subm_rulebook(idx3, shape3, ks)
+                else:
+                    rb = _sp.spconv_rulebook(idx3, shape3, input.batch_size, ks, st, pd)
+                if self.indice_key is not None:
+                    input.indice_dict[self.indice_key] = rb
+            out_feats = _sp.sparse_conv(feats, self.weight_kio(), rb, False)
+            out_indices3, out_shape3 = (idx3, shape3) if self.subm else (rb.out_coords, rb.out_shape)
+        if self.bias is not None:
+            out_feats = out_feats + self.bias
+        if ndim == 2:
+            out_indices = out_indices3[:, [0, 2, 3]].contiguous()
+            out_shape = out_shape3[1:]
+        else:
+            out_indices, out_shape = out_indices3, out_shape3
+        out = SparseConvTensor(out_feats, out_indices, out_shape, input.batch_size, input.grid, input.voxel_num,
+                               input.indice_dict, input.benchmark)
+        return out
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, algo=None, fp32_accum=None, name=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, True,
+                         indice_key=indice_key)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, algo=None, fp32_accum=None, name=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         indice_key=indice_key)
+
+
+class SparseInverseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True, algo=None, fp32_accum=None,
+                 name=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True, indice_key=indice_key)
+
+
+class SubMConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, algo=None, fp32_accum=None, name=None):
+        super().__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, True,
+                         indice_key=indice_key)
+
+
+class SparseConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, algo=None, fp32_accum=None, name=None):
+        super().__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         indice_key=indice_key)

@@ -1,0 +1,115 @@
+/*
+ * libcrbhip.so — C-ABI of the MI355X (gfx950) hot path of CRB-active-3Ddet.
+ *
+ * Every entry point: plain device pointers + sizes, caller-owned outputs AND workspace, launches on the
+ * hipStream_t passed as `void* stream`, never synchronises unless stated, returns 0 or a negative
+ * CRB_ERR_* code (never exit()). No torch / pybind types cross this boundary.
+ *
+ * Each declaration cites the reference interface (file:line under the upstream tree) it replaces.
+ * The Python host side (crb-active-3ddet_amd/crbhip/_lib.py) binds these with ctypes; INTEGRATION.md
+ * shows the stub a pcdet maintainer would add.
+ */
+#ifndef CRB_HIP_H
+#define CRB_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRB_OK 0
+#define CRB_ERR_ARG (-1)
+#define CRB_ERR_WORKSPACE (-2)
+#define CRB_ERR_LAUNCH (-3)
+#define CRB_ERR_UNSUPPORTED (-4)
+
+/* ABI version of this header; bumped on any signature change. */
+int crb_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * a1/a2/a3  VoxelGenerator (+ collate + MeanVFE)
+ * replaces: spconv.utils.Point2VoxelCPU3d.point_to_voxel as called from
+ *           pcdet/datasets/processor/data_processor.py:44-60 (VoxelGeneratorWrapper.generate),
+ *           the voxel concat / batch-index pad of pcdet/datasets/dataset.py:160-229 (collate_batch),
+ *           and pcdet/models/backbones_3d/vfe/mean_vfe.py:14-31 (MeanVFE.forward) when mean_features != NULL.
+ *
+ * points          (n_points, num_features) f32, frames concatenated, xyz first
+ * frame_offsets   (B+1) i32 device, frame b owns points [off[b], off[b+1])
+ * range_min_xyz / voxel_size_xyz / grid_xyz : HOST arrays of 3
+ * outputs sized for cap = min(B*max_voxels, n_points) rows:
+ *   voxels (cap, max_points, num_features) f32 or NULL; coords (cap,4) i32 [b,z,y,x];
+ *   num_points (cap) i32; mean_features (cap, num_features) f32 or NULL;
+ *   num_voxels_out (B+1) i32 device: per-frame kept voxel count, [B] = total rows written.
+ * Rows beyond the total are left untouched.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t crb_voxelize_workspace_bytes(int64_t n_points, int B, int max_voxels, int max_points);
+int crb_voxelize(const float* points, int64_t n_points, int num_features,
+                 const int32_t* frame_offsets, int B,
+                 const float* range_min_xyz, const float* voxel_size_xyz, const int32_t* grid_xyz,
+                 int max_voxels, int max_points,
+                 float* voxels, int32_t* coords, int32_t* num_points, float* mean_features,
+                 int32_t* num_voxels_out,
+                 void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a4  Sparse 3D convolution: rulebooks + gather-GEMM fwd / dgrad / wgrad
+ * replaces: spconv.pytorch.SubMConv3d / SparseConv3d / SparseConvTensor (third-party spconv-cu113 v2.1.21,
+ *           not vendored) as used by pcdet/models/backbones_3d/spconv_backbone.py:8-27,77-117,141-157 and
+ *           pcdet/utils/spconv_utils.py:3-34.
+ *
+ * coords (N,4) i32 [b,z,y,x]; shape_dhw = spatial shape [D,H,W] (HOST int32[3]); ksize/stride/padding HOST int32[3].
+ * Kernel offset index o = (kz*KH + ky)*KW + kx; weights are (K, Cin, Cout) f32 contiguous.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t crb_hash_capacity_for(int64_t n);   /* power of two >= 2n */
+/* site -> row hash; hkeys (capacity) i64, hvals (capacity) i32 */
+int crb_sparse_hash_build(const int32_t* coords, int64_t n, const int32_t* shape_dhw,
+                          int64_t* hkeys, int32_t* hvals, int64_t capacity, void* stream);
+/* SubM: nbr (n,K) i32, nbr[i][o] = row of site coords[i] + (o - centre), or -1 */
+int crb_subm_rulebook(const int32_t* coords, int64_t n, const int32_t* shape_dhw, const int32_t* ksize,
+                      const int64_t* hkeys, const int32_t* hvals, int64_t capacity,
+                      int32_t* nbr, void* stream);
+/* strided conv stage 1: output active set, rows in ascending (b,z,y,x) order.
+ * bitmap/prefix: crb_spconv_bitmap_words() u32/i32 words each, kept alive for stage 2;
+ * scan_tmp: crb_spconv_out_coords_workspace_bytes() is an upper bound for bitmap+prefix+scan_tmp together.
+ * n_out_dev: device i32 scalar (caller reads it back to size the outputs of stage 2). */
+int64_t crb_spconv_bitmap_words(int B, const int32_t* out_shape_dhw);
+int64_t crb_spconv_out_coords_workspace_bytes(int B, const int32_t* out_shape_dhw);
+int crb_spconv_out_coords(const int32_t* coords, int64_t n, int B, const int32_t* ksize,
+                          const int32_t* stride, const int32_t* padding, const int32_t* out_shape_dhw,
+                          uint32_t* bitmap, int32_t* prefix, int32_t* scan_tmp,
+                          int32_t* out_coords, int64_t max_out, int32_t* n_out_dev, void* stream);
+/* strided conv stage 2: nbr (n_out,K) and its transpose nbr_t (n,K) */
+int crb_spconv_rulebook(const int32_t* coords, int64_t n, int B, const int32_t* ksize,
+                        const int32_t* stride, const int32_t* padding, const int32_t* out_shape_dhw,
+                        const uint32_t* bitmap, const int32_t* prefix, int64_t n_out,
+                        int32_t* nbr, int32_t* nbr_t, void* stream);
+/* classic pair lists sorted by (offset, output row); pair_in/pair_out capacity n_out*K, pair_start (K+1) */
+int64_t crb_pairs_workspace_bytes(int64_t n_out, int K);
+int crb_pairs_from_nbr(const int32_t* nbr, int64_t n_out, int K, int32_t* pair_in, int32_t* pair_out,
+                       int32_t* pair_start, void* workspace, int64_t workspace_bytes, void* stream);
+/* Y (n_out,cout) = sum_o X[nbr[:,o]] @ W[o]; also used for dgrad with the transposed table / weights */
+int crb_sparse_conv_supported(int cin, int cout);
+int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, float* Y, int64_t n_out,
+                            int K, int cin, int cout, void* stream);
+/* dW (K,cin,cout) = sum over pairs X[pin]^T dY[pout] */
+int crb_sparse_conv_wgrad_splits(void);
+int64_t crb_sparse_conv_wgrad_workspace_bytes(int K, int cin, int cout);
+int crb_sparse_conv_wgrad(const float* X, const float* dY, const int32_t* pair_in, const int32_t* pair_out,
+                          const int32_t* pair_start, float* dW, int K, int cin, int cout,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a6  SparseConvTensor.dense() and its backward
+ * replaces: spconv SparseConvTensor.dense() as used by
+ *           pcdet/models/backbones_2d/map_to_bev/height_compression.py:20-24.
+ * out (B,C,D,H,W) f32. zero_fill != 0 clears `out` first.
+ * ---------------------------------------------------------------------------------------------- */
+int crb_sparse_to_dense(const float* feat, const int32_t* coords, float* out, int64_t n, int B, int C,
+                        int D, int H, int W, int zero_fill, void* stream);
+int crb_dense_to_sparse(const float* dense, const int32_t* coords, float* feat, int64_t n, int B, int C,
+                        int D, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRB_HIP_H */

@@ -1,0 +1,168 @@
+"""ORACLE — test infrastructure only.
+
+CPU restatements (plain C via ctypes + numpy) of the reference algorithms on the hot path. Only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import this package; the product
+path (crb-active-3ddet_amd/) never does. Each function cites the reference file:line it follows in the
+C source next to it. See DESIGN.md §Oracle for what pins each piece.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, 'liboracle.so')
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith('_oracle.c')]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+        subprocess.check_call(['make', '-C', _HERE, '-s', 'liboracle.so'])
+
+
+def _lib():
+    global _L
+    try:
+        return _L
+    except NameError:
+        pass
+    build()
+    _L = ctypes.CDLL(_SO)
+    return _L
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _arr3(v, dt=np.int32):
+    return np.ascontiguousarray(np.asarray(v).reshape(3), dtype=dt)
+
+
+# ------------------------------------------------------------------ voxelizer
+def voxelize_frame(points, range_min_xyz, voxel_size_xyz, grid_xyz, max_voxels, max_points):
+    """-> voxels (M,max_points,C), coords (M,3)[z,y,x], num_points (M)"""
+    L = _lib()
+    pts = _f32(points)
+    n, C = pts.shape
+    voxels = np.empty((max_voxels, max_points, C), np.float32)
+    coords = np.zeros((max_voxels, 3), np.int32)
+    npts = np.zeros((max_voxels,), np.int32)
+    L.oracle_voxelize_frame.restype = ctypes.c_int
+    m = L.oracle_voxelize_frame(_p(pts), ctypes.c_int(n), ctypes.c_int(C), _p(_arr3(range_min_xyz, np.float32)),
+                                _p(_arr3(voxel_size_xyz, np.float32)), _p(_arr3(grid_xyz)), ctypes.c_int(max_voxels),
+                                ctypes.c_int(max_points), _p(voxels), _p(coords), _p(npts))
+    assert m >= 0
+    return voxels[:m].copy(), coords[:m].copy(), npts[:m].copy()
+
+
+def voxelize_batch(points, frame_offsets, range_min_xyz, voxel_size_xyz, grid_xyz, max_voxels, max_points):
+    """collate like pcdet/datasets/dataset.py:160-229: coords (M,4) [b,z,y,x]"""
+    vs, cs, ns, counts = [], [], [], []
+    for b in range(len(frame_offsets) - 1):
+        v, c, k = voxelize_frame(points[frame_offsets[b]:frame_offsets[b + 1]], range_min_xyz, voxel_size_xyz, grid_xyz,
+                                 max_voxels, max_points)
+        vs.append(v)
+        cs.append(np.concatenate([np.full((len(c), 1), b, np.int32), c], axis=1))
+        ns.append(k)
+        counts.append(len(c))
+    return np.concatenate(vs), np.concatenate(cs), np.concatenate(ns), np.asarray(counts, np.int32)
+
+
+def mean_vfe(voxels, num_points):
+    L = _lib()
+    v = _f32(voxels)
+    M, T, C = v.shape
+    out = np.empty((M, C), np.float32)
+    L.oracle_mean_vfe(_p(v), _p(_i32(num_points)), ctypes.c_int(M), ctypes.c_int(T), ctypes.c_int(C), _p(out))
+    return out
+
+
+# ------------------------------------------------------------------ sparse conv
+def subm_nbr(coords, shape_dhw, ksize):
+    L = _lib()
+    c = _i32(coords)
+    ks = _arr3(ksize)
+    K = int(ks.prod())
+    nbr = np.empty((len(c), K), np.int32)
+    L.oracle_subm_nbr(_p(c), ctypes.c_int(len(c)), _p(_arr3(shape_dhw)), _p(ks), _p(nbr))
+    return nbr
+
+
+def conv_out_shape(shape_dhw, ksize, stride, padding):
+    return [(int(s) + 2 * int(p) - int(k)) // int(st) + 1 for s, k, st, p in zip(shape_dhw, ksize, stride, padding)]
+
+
+def spconv_out(coords, shape_dhw, ksize, stride, padding):
+    """-> out_coords (n_out,4) ascending (b,z,y,x), out_shape"""
+    L = _lib()
+    c = _i32(coords)
+    ks, st, pd = _arr3(ksize), _arr3(stride), _arr3(padding)
+    oshape = _arr3(conv_out_shape(shape_dhw, ks, st, pd))
+    cap = max(1, len(c) * int(ks.prod()))
+    out = np.empty((cap, 4), np.int32)
+    L.oracle_spconv_out.restype = ctypes.c_int
+    n_out = L.oracle_spconv_out(_p(c), ctypes.c_int(len(c)), _p(ks), _p(st), _p(pd), _p(oshape), _p(out),
+                                ctypes.c_int(cap))
+    return out[:n_out].copy(), [int(v) for v in oshape]
+
+
+def spconv_nbr(coords, shape_dhw, out_coords, ksize, stride, padding):
+    L = _lib()
+    c, oc = _i32(coords), _i32(out_coords)
+    ks, st, pd = _arr3(ksize), _arr3(stride), _arr3(padding)
+    nbr = np.empty((len(oc), int(ks.prod())), np.int32)
+    L.oracle_spconv_nbr(_p(c), ctypes.c_int(len(c)), _p(_arr3(shape_dhw)), _p(oc), ctypes.c_int(len(oc)), _p(ks), _p(st),
+                        _p(pd), _p(nbr))
+    return nbr
+
+
+def conv_fwd(X, W, nbr):
+    """X (n_in,cin), W (K,cin,cout), nbr (n_out,K) -> Y (n_out,cout)"""
+    L = _lib()
+    X, W, nbr = _f32(X), _f32(W), _i32(nbr)
+    K, cin, cout = W.shape
+    Y = np.empty((len(nbr), cout), np.float32)
+    L.oracle_conv_fwd(_p(X), _p(W), _p(nbr), _p(Y), ctypes.c_int(len(nbr)), ctypes.c_int(K), ctypes.c_int(cin),
+                      ctypes.c_int(cout))
+    return Y
+
+
+def conv_dgrad(dY, W, nbr, n_in):
+    L = _lib()
+    dY, W, nbr = _f32(dY), _f32(W), _i32(nbr)
+    K, cin, cout = W.shape
+    dX = np.empty((n_in, cin), np.float32)
+    L.oracle_conv_dgrad(_p(dY), _p(W), _p(nbr), _p(dX), ctypes.c_int(n_in), ctypes.c_int(len(nbr)), ctypes.c_int(K),
+                        ctypes.c_int(cin), ctypes.c_int(cout))
+    return dX
+
+
+def conv_wgrad(X, dY, nbr, K):
+    L = _lib()
+    X, dY, nbr = _f32(X), _f32(dY), _i32(nbr)
+    cin, cout = X.shape[1], dY.shape[1]
+    dW = np.empty((K, cin, cout), np.float32)
+    L.oracle_conv_wgrad(_p(X), _p(dY), _p(nbr), _p(dW), ctypes.c_int(len(nbr)), ctypes.c_int(K), ctypes.c_int(cin),
+                        ctypes.c_int(cout))
+    return dW
+
+
+def dense(feat, coords, B, shape_dhw):
+    L = _lib()
+    f, c = _f32(feat), _i32(coords)
+    C = f.shape[1]
+    D, H, W = [int(v) for v in shape_dhw]
+    out = np.empty((B, C, D, H, W), np.float32)
+    L.oracle_dense(_p(f), _p(c), _p(out), ctypes.c_int(len(c)), ctypes.c_int(B), ctypes.c_int(C), ctypes.c_int(D),
+                   ctypes.c_int(H), ctypes.c_int(W))
+    return out

@@ -1,0 +1,40 @@
+"""CPU: the C-ABI library loads and exports every symbol include/crb_hip.h declares (no compute calls)."""
+import ctypes
+import os
+
+
+def test_header_symbols_exported():
+    import crbhip
+    protos = crbhip.parse_header()
+    assert len(protos) >= 19
+    L = ctypes.CDLL(crbhip.lib_path)
+    for name in protos:
+        assert hasattr(L, name), name
+
+
+def test_abi_version_and_pure_host_queries():
+    import crbhip
+    assert crbhip.lib.crb_abi_version() >= 1
+    assert crbhip.lib.crb_hash_capacity_for(1000) == 2048
+    assert crbhip.lib.crb_voxelize_workspace_bytes(20000, 1, 16000, 5) > 0
+    assert crbhip.lib.crb_sparse_conv_supported(64, 64) == 1
+    assert crbhip.lib.crb_sparse_conv_supported(7, 9) == 0
+
+
+def test_header_has_no_torch_types():
+    import crbhip
+    import re
+    src = open(crbhip.header_path).read()
+    code = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    assert 'at::' not in code and 'torch' not in code and 'Tensor' not in code
+
+
+def test_missing_gpu_fails_loudly():
+    """product ops refuse CPU tensors instead of silently falling back"""
+    import pytest
+    import torch
+    import crbhip
+    from crbhip import voxel
+    with pytest.raises(crbhip.CrbHipError):
+        voxel.voxelize(torch.zeros(10, 4), torch.tensor([0, 10], dtype=torch.int32), [0, -40, -3, 70.4, 40, 1],
+                       [0.05, 0.05, 0.1], 100, 5)
