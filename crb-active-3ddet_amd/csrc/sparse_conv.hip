@@ -33,8 +33,8 @@ template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                               const int* __restrict__ nbr, float* __restrict__ Y,
                                                               int n_out, int K, int ntiles) {
-  constexpr int NB = COUT / 16;          // 16-wide output column blocks
-  constexpr int WS = COUT + 4;           // padded LDS row stride of W[o]
+  constexpr int NB = (COUT + 15) / 16;   // 16-wide output column blocks (last one masked when COUT % 16)
+  constexpr int WS = NB * 16 + 4;        // padded LDS row stride of W[o]
   constexpr int KSTEPS = (CIN + 3) / 4;  // MFMA k-steps
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* w_lds = reinterpret_cast<float*>(smem);                   // CINP * WS floats
@@ -79,12 +79,18 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
     __syncthreads();                       // everyone is done with the previous W[o]
     {
       const float* wsrc = W + (int64_t)o * CIN * COUT;
-      if constexpr ((COUT % 4) == 0) {
+      if constexpr ((COUT % 16) == 0) {
         for (int t = threadIdx.x; t < CINP * (COUT / 4); t += 256) {
           int k = t / (COUT / 4), c4 = t - k * (COUT / 4);
           f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
           if (k < CIN) v = *reinterpret_cast<const f32x4*>(wsrc + k * COUT + c4 * 4);
           *reinterpret_cast<f32x4*>(w_lds + k * WS + c4 * 4) = v;
+        }
+      }
+      if constexpr ((COUT % 16) != 0) {   // narrow outputs (dgrad into 4/5 point features): scalar, zero padded
+        for (int t = threadIdx.x; t < CINP * NB * 16; t += 256) {
+          int k = t / (NB * 16), c = t - k * (NB * 16);
+          w_lds[k * WS + c] = (k < CIN && c < COUT) ? wsrc[k * COUT + c] : 0.f;
         }
       }
     }
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       const int row = row0 + wave * 16 + g * 4 + rg;
-      if (row < n_out) Y[(int64_t)row * COUT + nb * 16 + li] = acc[nb][rg];
+      if (row < n_out && nb * 16 + li < COUT) Y[(int64_t)row * COUT + nb * 16 + li] = acc[nb][rg];
     }
   }
 }
@@ -139,7 +145,7 @@ struct WgradCfg {
   static constexpr int CIPW = NCI >= 4 ? NCI / 4 : 1;   // ci blocks per wave
   static constexpr int WCI = NCI / CIPW;                 // waves along ci (1,2,4)
   static constexpr int SLICES = 4 / WCI;                 // pair slices per workgroup
-  static constexpr int NB = COUT / 16;
+  static constexpr int NB = (COUT + 15) / 16;
 };
 
 template <int CIN, int COUT>
@@ -173,7 +179,8 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __r
     const int io = valid ? pout[p] : 0;
     float b[C::NB];
 #pragma unroll
-    for (int nb = 0; nb < C::NB; ++nb) b[nb] = valid ? dY[(int64_t)io * COUT + nb * 16 + li] : 0.f;
+    for (int nb = 0; nb < C::NB; ++nb)
+      b[nb] = (valid && nb * 16 + li < COUT) ? dY[(int64_t)io * COUT + nb * 16 + li] : 0.f;
 #pragma unroll
     for (int a = 0; a < C::CIPW; ++a) {
       const int ci = (wci * C::CIPW + a) * 16 + li;
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __r
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
             const int ci = (wci * C::CIPW + a) * 16 + g * 4 + rg;
-            red[((slice - 1) * CINP16 + ci) * COUT + nb * 16 + li] = acc[a][nb][rg];
+            red[((slice - 1) * CINP16 + ci) * (C::NB * 16) + nb * 16 + li] = acc[a][nb][rg];
           }
     }
     __syncthreads();
@@ -212,9 +219,9 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __r
           float v = acc[a][nb][rg];
           if constexpr (C::SLICES > 1) {
 #pragma unroll
-            for (int sl = 1; sl < C::SLICES; ++sl) v += red[((sl - 1) * CINP16 + ci) * COUT + nb * 16 + li];
+            for (int sl = 1; sl < C::SLICES; ++sl) v += red[((sl - 1) * CINP16 + ci) * (C::NB * 16) + nb * 16 + li];
           }
-          if (ci < CIN) dst[ci * COUT + nb * 16 + li] = v;
+          if (ci < CIN && nb * 16 + li < COUT) dst[ci * COUT + nb * 16 + li] = v;
         }
   }
 }
@@ -233,7 +240,7 @@ int launch_fwd(const float* X, const float* W, const int* nbr, float* Y, int64_t
   constexpr int KSTEPS = (CIN + 3) / 4;
   const int ntiles = crb_cdiv(n_out, 64);
   const int grid = ((ntiles + 7) / 8) * 8;
-  size_t lds = sizeof(float) * KSTEPS * 4 * (COUT + 4) + sizeof(int) * 64 * K;
+  size_t lds = sizeof(float) * KSTEPS * 4 * (((COUT + 15) / 16) * 16 + 4) + sizeof(int) * 64 * K;
   hipLaunchKernelGGL((sparse_conv_fwd_kernel<CIN, COUT>), dim3(grid), dim3(256), lds, st, X, W, nbr, Y, (int)n_out, K,
                      ntiles);
   CRB_CHECK_LAUNCH();
@@ -244,7 +251,7 @@ template <int CIN, int COUT>
 int launch_wgrad(const float* X, const float* dY, const int* pin, const int* pout, const int* pstart, float* dW,
                  float* partial, int K, int S, hipStream_t st) {
   using C = WgradCfg<CIN, COUT>;
-  size_t lds = C::SLICES > 1 ? sizeof(float) * (C::SLICES - 1) * C::NCI * 16 * COUT : 0;
+  size_t lds = C::SLICES > 1 ? sizeof(float) * (C::SLICES - 1) * C::NCI * 16 * C::NB * 16 : 0;
   hipLaunchKernelGGL((sparse_conv_wgrad_kernel<CIN, COUT>), dim3(K, S), dim3(256), lds, st, X, dY, pin, pout, pstart,
                      partial, K);
   const int64_t elems = (int64_t)K * CIN * COUT;
@@ -256,7 +263,7 @@ int launch_wgrad(const float* X, const float* dY, const int* pin, const int* pou
 }  // namespace
 
 #define CRB_CONV_SHAPES(X_) \
-  X_(4, 16) X_(5, 16) X_(16, 16) X_(16, 32) X_(32, 16) X_(32, 32) X_(32, 64) X_(64, 32) X_(64, 64) X_(64, 128) \
+  X_(4, 16) X_(5, 16) X_(16, 4) X_(16, 5) X_(16, 16) X_(16, 32) X_(32, 16) X_(32, 32) X_(32, 64) X_(64, 32) X_(64, 64) X_(64, 128) \
   X_(128, 64) X_(128, 128)
 
 extern "C" int crb_sparse_conv_supported(int cin, int cout) {

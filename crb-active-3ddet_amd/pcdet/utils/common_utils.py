@@ -1,0 +1,111 @@
+"""Pure-torch geometry / bookkeeping helpers with the reference's names (pcdet/utils/common_utils.py)."""
+import logging
+import os
+import random
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def check_numpy_to_torch(x):
+    if isinstance(x, np.ndarray):
+        return torch.from_numpy(x).float(), True
+    return x, False
+
+
+def limit_period(val, offset=0.5, period=np.pi):
+    """val - floor(val/period + offset)*period   (common_utils.py:24-27)"""
+    val, is_numpy = check_numpy_to_torch(val)
+    ans = val - torch.floor(val / period + offset) * period
+    return ans.numpy() if is_numpy else ans
+
+
+def rotate_points_along_z(points, angle):
+    """points (B,N,3+C), angle (B) -> rotated about +z (common_utils.py:37-60)"""
+    points, is_numpy = check_numpy_to_torch(points)
+    angle, _ = check_numpy_to_torch(angle)
+    c, s = torch.cos(angle), torch.sin(angle)
+    zeros, ones = torch.zeros_like(angle), torch.ones_like(angle)
+    rot = torch.stack((c, s, zeros, -s, c, zeros, zeros, zeros, ones), dim=1).view(-1, 3, 3).float()
+    xyz = torch.matmul(points[:, :, 0:3], rot)
+    out = torch.cat((xyz, points[:, :, 3:]), dim=-1)
+    return out.numpy() if is_numpy else out
+
+
+def mask_points_by_range(points, limit_range):
+    return (points[:, 0] >= limit_range[0]) & (points[:, 0] <= limit_range[3]) & \
+           (points[:, 1] >= limit_range[1]) & (points[:, 1] <= limit_range[4])
+
+
+def get_voxel_centers(voxel_coords, downsample_times, voxel_size, point_cloud_range):
+    """voxel_coords (N,3) [z,y,x] -> centers (N,3) xyz (common_utils.py:63-80)"""
+    assert voxel_coords.shape[1] == 3
+    centers = voxel_coords[:, [2, 1, 0]].float()
+    vs = torch.tensor(voxel_size, device=centers.device).float() * downsample_times
+    pc_min = torch.tensor(point_cloud_range[0:3], device=centers.device).float()
+    return (centers + 0.5) * vs + pc_min
+
+
+def create_logger(log_file=None, rank=0, log_level=logging.INFO):
+    logger = logging.getLogger(__name__)
+    logger.setLevel(log_level if rank == 0 else 'ERROR')
+    fmt = logging.Formatter('%(asctime)s  %(levelname)5s  %(message)s')
+    console = logging.StreamHandler()
+    console.setLevel(log_level if rank == 0 else 'ERROR')
+    console.setFormatter(fmt)
+    logger.addHandler(console)
+    if log_file is not None:
+        fh = logging.FileHandler(filename=log_file)
+        fh.setLevel(log_level if rank == 0 else 'ERROR')
+        fh.setFormatter(fmt)
+        logger.addHandler(fh)
+    logger.propagate = False
+    return logger
+
+
+def set_random_seed(seed):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    torch.backends.cudnn.deterministic = True
+    torch.backends.cudnn.benchmark = False
+
+
+def keep_arrays_by_name(gt_names, used_classes):
+    inds = [i for i, x in enumerate(gt_names) if x in used_classes]
+    return np.array(inds, dtype=np.int64)
+
+
+def init_dist_pytorch(tcp_port, local_rank, backend='nccl'):
+    """one process per GPU; backend 'nccl' is RCCL on ROCm (common_utils.py:159-175)"""
+    num_gpus = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % max(num_gpus, 1))
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, init_method='tcp://127.0.0.1:%d' % tcp_port,
+                                rank=local_rank, world_size=num_gpus)
+    return num_gpus, dist.get_rank()
+
+
+def get_dist_info(return_gpu_per_machine=False):
+    if dist.is_available() and dist.is_initialized():
+        rank, world_size = dist.get_rank(), dist.get_world_size()
+    else:
+        rank, world_size = 0, 1
+    if return_gpu_per_machine:
+        return rank, world_size, max(torch.cuda.device_count(), 1)
+    return rank, world_size
+
+
+class AverageMeter(object):
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
