@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""bench.py — SECOND fwd+bwd (+optimizer) on synthetic KITTI 20k-point clouds, one process per GPU.
+
+Contract (see task statement): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
+torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE in the env). Rank 0 prints ONE JSON line.
+
+A "step" = one pass of the hot path over one batch of 16 frames per GPU (BASELINE.json configs[1]):
+HIP voxelize(+mean) -> 12 sparse convs (HIP rulebooks + MFMA gather-GEMM) + BN/ReLU -> HIP dense scatter ->
+BEV backbone (MIOpen) -> anchor head -> batched target assignment -> losses -> backward (HIP dgrad/wgrad) ->
+grad-clip -> Adam. Inputs are resident in HBM before the timed region. N>1: DDP over RCCL, weak scaling.
+
+Extra objects on the JSON line: `roofline` (dominant hand-written kernel: subm gather-GEMM, HIP events on the launch
+stream inside the timed region, algorithmic bytes per SURVEY §8d) and `cpu_baseline` (oracle CPU port on a bounded
+sample; rank 0, N=1 only)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'crb-active-3ddet_amd'))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=16, help='frames per GPU')
+    ap.add_argument('--points', type=int, default=20000)
+    ap.add_argument('--kind', default='kitti', choices=['kitti', 'waymo'])
+    ap.add_argument('--pool', type=int, default=2, help='distinct resident batches cycled through')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-frames', type=int, default=1)
+    return ap.parse_args()
+
+
+def make_batches(args, rank, device):
+    from pcdet.datasets.synthetic import kitti_batch
+    batches = []
+    for k in range(args.pool):
+        first = 1000 * rank + k * args.batch
+        pts, off, gt = kitti_batch(first, args.batch, args.points, waymo=(args.kind == 'waymo'))
+        bidx = np.repeat(np.arange(args.batch, dtype=np.float32), np.diff(off))
+        pts5 = np.concatenate([bidx[:, None], pts], axis=1)
+        batches.append({
+            'points': torch.from_numpy(pts5).to(device),
+            'point_frame_offsets': torch.from_numpy(off).to(device),
+            'gt_boxes': torch.from_numpy(gt).to(device),
+            'batch_size': args.batch,
+        })
+    return batches
+
+
+def roofline_from_profile(prof):
+    """dominant subm gather-GEMM instance by total time; algorithmic bytes per SURVEY §8d:
+    B_alg = 4 N_in C_in + 4 N_out C_out + 8 P + 4 K C_in C_out"""
+    agg = {}
+    for kind, cin, cout, K, n_in, n_out, tab, e0, e1 in prof:
+        if kind not in ('subm_fwd', 'subm_dgrad'):
+            continue
+        ms = e0.elapsed_time(e1)
+        key = ('subm_gather_gemm', cin, cout)
+        a = agg.setdefault(key, {'ms': 0.0, 'n': 0, 'bytes': 0.0, 'flops': 0.0, 'pairs': {}})
+        pid = tab.data_ptr()
+        if pid not in a['pairs']:
+            a['pairs'][pid] = int((tab >= 0).sum().item())
+        P = a['pairs'][pid]
+        a['ms'] += ms
+        a['n'] += 1
+        a['bytes'] += 4.0 * n_in * cin + 4.0 * n_out * cout + 8.0 * P + 4.0 * K * cin * cout
+        a['flops'] += 2.0 * P * cin * cout
+    if not agg:
+        return None, {}
+    key = max(agg, key=lambda k: agg[k]['ms'])
+    a = agg[key]
+    gbs = a['bytes'] / (a['ms'] * 1e-3) / 1e9
+    table = {'%s_%dx%d' % k: {'launches': v['n'], 'avg_us': 1e3 * v['ms'] / v['n'],
+                              'GBps_alg': v['bytes'] / (v['ms'] * 1e-3) / 1e9,
+                              'TFLOPs': v['flops'] / (v['ms'] * 1e-3) / 1e12} for k, v in agg.items()}
+    roof = {'bound': 'hbm', 'kernel': 'sparse_conv_fwd_kernel<%d,%d> (subm gather-GEMM fwd+dgrad)' % (key[1], key[2]),
+            'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+            'traffic': None, 'avg_launch_us': round(1e3 * a['ms'] / a['n'], 2),
+            'alg_bytes_per_launch': round(a['bytes'] / a['n']), 'launches': a['n'],
+            'achieved_tflops_f32': round(a['flops'] / (a['ms'] * 1e-3) / 1e12, 2)}
+    return roof, table
+
+
+def cpu_baseline(args):
+    from pcdet.datasets import SyntheticDataset
+    from pcdet.datasets.synthetic import kitti_batch
+    from pcdet.model_cfgs import second_cfg
+    from pcdet.models import build_network
+    from oracle.second_cpu import second_step_cpu
+    # bounded sample: a few frames on at most 32 host threads (256-thread runs of this small problem are slower:
+    # the first bench run took 152 s for 2 frames on 256 threads vs 8 s/frame on 8)
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    os.environ['OMP_NUM_THREADS'] = str(cores)
+    try:
+        import ctypes
+        ctypes.CDLL('libgomp.so.1').omp_set_num_threads(cores)
+    except OSError:
+        pass
+    torch.manual_seed(0)
+    ds = SyntheticDataset(num_frames=4, kind=args.kind, n_points=args.points)
+    m = build_network(second_cfg(args.kind).MODEL, 3, ds)
+    m.train()
+    pts, off, gt = kitti_batch(0, args.cpu_frames, args.points, waymo=(args.kind == 'waymo'))
+    t0 = time.time()
+    second_step_cpu(m, pts, off, gt, max_voxels=ds.max_num_voxels['train'])
+    dt = time.time() - t0
+    return {'value': round(args.cpu_frames / dt, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d synthetic %s frames x %d pts, one SECOND fwd+bwd step (oracle C voxelizer + sparse conv '
+                      'fwd/dgrad/wgrad with OpenMP, stock torch CPU for BEV/head/loss), %.1f s' %
+                      (args.cpu_frames, args.kind, args.points, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=device)    # RCCL over xGMI
+
+    from crbhip import sparse as sp
+    from pcdet.datasets import SyntheticDataset
+    from pcdet.model_cfgs import second_cfg
+    from pcdet.models import build_network
+
+    torch.manual_seed(0)
+    ds = SyntheticDataset(num_frames=args.batch, kind=args.kind, n_points=args.points)
+    model = build_network(second_cfg(args.kind).MODEL, 3, ds).to(device)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=3e-3, weight_decay=0.01, betas=(0.9, 0.99))
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True)
+    batches = make_batches(args, rank, device)
+
+    def step(i):
+        b = dict(batches[i % len(batches)])
+        opt.zero_grad(set_to_none=True)
+        ret, tb, _ = net(b)
+        loss = ret['loss'].mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    prof = [] if rank == 0 else None
+    sp.PROFILE = prof
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    sp.PROFILE = None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    frames = args.batch * world * args.steps
+    out = {
+        'metric': 'frames/s SECOND fwd+bwd, KITTI 20k-pt clouds' if args.kind == 'kitti' else
+                  'frames/s SECOND fwd+bwd, Waymo-shaped 160k-pt clouds',
+        'value': round(frames / dt, 3), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'SECOND (VoxelBackBone8x + BaseBEVBackbone + AnchorHeadSingle) fwd+bwd+AdamW on '
+                               'synthetic %s clouds, %d pts/frame, bs=%d per GPU, HIP voxelize + subm/strided '
+                               'gather-GEMM (BASELINE configs[1])' % (args.kind, args.points, args.batch),
+                   'global_batch': args.batch * world, 'points_per_frame': args.points,
+                   'parallelism': 'dp%d' % world, 'optimizer': 'AdamW in the timed region',
+                   'final_loss': round(float(loss.item()), 4)},
+    }
+    if rank == 0:
+        roof, table = roofline_from_profile(prof)
+        out['roofline'] = roof
+        out['kernel_table'] = table
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

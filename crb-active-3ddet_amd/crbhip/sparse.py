@@ -128,25 +128,44 @@ def spconv_rulebook(coords, shape, batch_size, ksize, stride, padding):
     return rb
 
 
-def _conv_forward_raw(x, w_kio, nbr, n_out):
+# When set to a list, every gather-GEMM launch appends (kind, cin, cout, K, n_in, n_out, nbr, ev0, ev1): HIP events on
+# the launch stream (torch's current stream IS the stream handed to the C-ABI), read back by bench.py for the roofline.
+PROFILE = None
+
+
+def _conv_forward_raw(x, w_kio, nbr, n_out, kind='fwd'):
     """x (n_in,cin), w (K,cin,cout), nbr (n_out,K) -> (n_out,cout)"""
     K, cin, cout = w_kio.shape
     if not lib.crb_sparse_conv_supported(cin, cout):
         raise CrbHipError(f'sparse conv channel pair ({cin},{cout}) has no gfx950 kernel instance')
     y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(lib.crb_sparse_conv_forward(ptr(x), ptr(w_kio), ptr(nbr), ptr(y), n_out, K, cin, cout, cur_stream(x.device)),
           'crb_sparse_conv_forward')
+    if prof is not None:
+        ev1.record()
+        prof.append((kind, cin, cout, K, x.shape[0], n_out, nbr, ev0, ev1))
     return y
 
 
-def _conv_wgrad_raw(x, dy, pairs, K):
+def _conv_wgrad_raw(x, dy, pairs, K, kind='wgrad'):
     cin, cout = x.shape[1], dy.shape[1]
     pin, pout, pstart = pairs
     dw = torch.empty((K, cin, cout), dtype=torch.float32, device=x.device)
     wsb = lib.crb_sparse_conv_wgrad_workspace_bytes(K, cin, cout)
     ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(lib.crb_sparse_conv_wgrad(ptr(x), ptr(dy), ptr(pin), ptr(pout), ptr(pstart), ptr(dw), K, cin, cout, ptr(ws),
                                     wsb, cur_stream(x.device)), 'crb_sparse_conv_wgrad')
+    if prof is not None:
+        ev1.record()
+        prof.append((kind, cin, cout, K, x.shape[0], dy.shape[0], pstart, ev0, ev1))
     return dw
 
 
@@ -164,7 +183,7 @@ class SparseConvFunction(torch.autograd.Function):
             table, n_out = rb.nbr, rb.n_out
         ctx.rb, ctx.inverse = rb, inverse
         ctx.save_for_backward(x, w_kio)
-        return _conv_forward_raw(x, w_kio, table, n_out)
+        return _conv_forward_raw(x, w_kio, table, n_out, ('subm' if rb.subm else 'spconv') + '_fwd')
 
     @staticmethod
     def backward(ctx, dy):
@@ -175,14 +194,14 @@ class SparseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if rb.subm:
                 wd = w.flip(0).transpose(1, 2).contiguous()      # Wd[o] = W[K-1-o]^T
-                dx = _conv_forward_raw(dy, wd, rb.nbr, rb.n_in)
+                dx = _conv_forward_raw(dy, wd, rb.nbr, rb.n_in, 'subm_dgrad')
             else:
                 wd = w.transpose(1, 2).contiguous()
                 table, n_in = (rb.nbr, rb.n_out) if inverse else (rb.nbr_t, rb.n_in)
-                dx = _conv_forward_raw(dy, wd, table, n_in)
+                dx = _conv_forward_raw(dy, wd, table, n_in, 'spconv_dgrad')
         if ctx.needs_input_grad[1]:
             pairs = rb.pairs_t() if inverse else rb.pairs()
-            dw = _conv_wgrad_raw(x, dy, pairs, rb.K)
+            dw = _conv_wgrad_raw(x, dy, pairs, rb.K, ('subm' if rb.subm else 'spconv') + '_wgrad')
         return dx, dw, None, None
 
 

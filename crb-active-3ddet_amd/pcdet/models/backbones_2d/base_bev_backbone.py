@@ -1,0 +1,60 @@
+"""BaseBEVBackbone (pcdet/models/backbones_2d/base_bev_backbone.py:6-112): dense 2-D convs; stays on the stock
+PyTorch-ROCm / MIOpen path (not a hand-written kernel). Same module tree => same state_dict keys."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+def _bn(c):
+    return nn.BatchNorm2d(c, eps=1e-3, momentum=0.01)
+
+
+class BaseBEVBackbone(nn.Module):
+    def __init__(self, model_cfg, input_channels):
+        super().__init__()
+        self.model_cfg = model_cfg
+        layer_nums = list(model_cfg.get('LAYER_NUMS', None) or [])
+        layer_strides = list(model_cfg.get('LAYER_STRIDES', None) or [])
+        num_filters = list(model_cfg.get('NUM_FILTERS', None) or [])
+        assert len(layer_nums) == len(layer_strides) == len(num_filters)
+        upsample_strides = list(model_cfg.get('UPSAMPLE_STRIDES', None) or [])
+        num_upsample_filters = list(model_cfg.get('NUM_UPSAMPLE_FILTERS', None) or [])
+        assert len(upsample_strides) == len(num_upsample_filters)
+        c_in_list = [input_channels] + num_filters[:-1]
+        self.blocks = nn.ModuleList()
+        self.deblocks = nn.ModuleList()
+        for idx, (c_in, c_out, n, s) in enumerate(zip(c_in_list, num_filters, layer_nums, layer_strides)):
+            layers = [nn.ZeroPad2d(1), nn.Conv2d(c_in, c_out, kernel_size=3, stride=s, padding=0, bias=False),
+                      _bn(c_out), nn.ReLU()]
+            for _ in range(n):
+                layers += [nn.Conv2d(c_out, c_out, kernel_size=3, padding=1, bias=False), _bn(c_out), nn.ReLU()]
+            self.blocks.append(nn.Sequential(*layers))
+            if upsample_strides:
+                us, uc = upsample_strides[idx], num_upsample_filters[idx]
+                if us >= 1:
+                    up = nn.ConvTranspose2d(c_out, uc, us, stride=us, bias=False)
+                else:
+                    ds = int(np.round(1 / us))
+                    up = nn.Conv2d(c_out, uc, ds, stride=ds, bias=False)
+                self.deblocks.append(nn.Sequential(up, _bn(uc), nn.ReLU()))
+        c_in = sum(num_upsample_filters)
+        if len(upsample_strides) > len(layer_nums):
+            self.deblocks.append(nn.Sequential(
+                nn.ConvTranspose2d(c_in, c_in, upsample_strides[-1], stride=upsample_strides[-1], bias=False),
+                _bn(c_in), nn.ReLU()))
+        self.num_bev_features = c_in
+
+    def forward(self, data_dict):
+        spatial_features = data_dict['spatial_features']
+        ups = []
+        x = spatial_features
+        for i, blk in enumerate(self.blocks):
+            x = blk(x)
+            stride = int(spatial_features.shape[2] / x.shape[2])
+            data_dict['spatial_features_%dx' % stride] = x
+            ups.append(self.deblocks[i](x) if len(self.deblocks) > 0 else x)
+        x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
+        if len(self.deblocks) > len(self.blocks):
+            x = self.deblocks[-1](x)
+        data_dict['spatial_features_2d'] = x
+        return data_dict

@@ -1,0 +1,169 @@
+"""AnchorHeadTemplate (pcdet/models/dense_heads/anchor_head_template.py:11-285): anchors, target assignment, RPN losses
+and box decoding. Differences from the reference are host-side only: anchors are registered as non-persistent buffers
+(no .cuda() in the constructor, anchor_head_template.py:31) and the loss path never calls .item() — tb_dict values are
+detached 0-dim tensors (float()-convertible) so a training step stays free of host synchronisation."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ...utils import box_coder_utils, common_utils, loss_utils
+from .target_assigner.anchor_generator import AnchorGenerator
+from .target_assigner.axis_aligned_target_assigner import AxisAlignedTargetAssigner
+
+
+class AnchorHeadTemplate(nn.Module):
+    def __init__(self, model_cfg, num_class, class_names, grid_size, point_cloud_range, predict_boxes_when_training):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_class = num_class
+        self.class_names = class_names
+        self.predict_boxes_when_training = predict_boxes_when_training
+        self.use_multihead = self.model_cfg.get('USE_MULTIHEAD', False)
+
+        anchor_target_cfg = self.model_cfg.TARGET_ASSIGNER_CONFIG
+        self.box_coder = getattr(box_coder_utils, anchor_target_cfg.BOX_CODER)(
+            num_dir_bins=anchor_target_cfg.get('NUM_DIR_BINS', 6), **anchor_target_cfg.get('BOX_CODER_CONFIG', {}))
+
+        anchors, self.num_anchors_per_location = self.generate_anchors(
+            self.model_cfg.ANCHOR_GENERATOR_CONFIG, grid_size=grid_size, point_cloud_range=point_cloud_range,
+            anchor_ndim=self.box_coder.code_size)
+        self._n_anchor_sets = len(anchors)
+        for i, a in enumerate(anchors):
+            self.register_buffer('_anchors_%d' % i, a, persistent=False)
+        self.target_assigner = self.get_target_assigner(anchor_target_cfg)
+        self.forward_ret_dict = {}
+        self.build_losses(self.model_cfg.LOSS_CONFIG)
+
+    @property
+    def anchors(self):
+        return [getattr(self, '_anchors_%d' % i) for i in range(self._n_anchor_sets)]
+
+    @staticmethod
+    def generate_anchors(anchor_generator_cfg, grid_size, point_cloud_range, anchor_ndim=7):
+        gen = AnchorGenerator(anchor_range=point_cloud_range, anchor_generator_config=anchor_generator_cfg)
+        gs = np.asarray(grid_size)
+        feature_map_size = [gs[:2] // c['feature_map_stride'] for c in anchor_generator_cfg]
+        anchors_list, per_loc = gen.generate_anchors(feature_map_size)
+        if anchor_ndim != 7:
+            anchors_list = [torch.cat((a, a.new_zeros([*a.shape[:-1], anchor_ndim - 7])), dim=-1)
+                            for a in anchors_list]
+        return anchors_list, per_loc
+
+    def get_target_assigner(self, anchor_target_cfg):
+        if anchor_target_cfg.NAME != 'AxisAlignedTargetAssigner':
+            raise NotImplementedError(anchor_target_cfg.NAME)
+        return AxisAlignedTargetAssigner(model_cfg=self.model_cfg, class_names=self.class_names,
+                                         box_coder=self.box_coder, match_height=anchor_target_cfg.MATCH_HEIGHT)
+
+    def build_losses(self, losses_cfg):
+        self.add_module('cls_loss_func', loss_utils.SigmoidFocalClassificationLoss(alpha=0.25, gamma=2.0))
+        reg_name = losses_cfg.get('REG_LOSS_TYPE', None) or 'WeightedSmoothL1Loss'
+        self.add_module('reg_loss_func',
+                        getattr(loss_utils, reg_name)(code_weights=losses_cfg.LOSS_WEIGHTS['code_weights']))
+        self.add_module('dir_loss_func', loss_utils.WeightedCrossEntropyLoss())
+
+    def assign_targets(self, gt_boxes):
+        return self.target_assigner.assign_targets(self.anchors, gt_boxes)
+
+    def _flat_anchors(self):
+        return torch.cat(self.anchors, dim=-3)
+
+    def get_cls_layer_loss(self, new_data=None, reduce=True):
+        src = self.forward_ret_dict if new_data is None else new_data
+        cls_preds, box_cls_labels = src['cls_preds'], src['box_cls_labels']
+        B = int(cls_preds.shape[0])
+        cared = box_cls_labels >= 0
+        positives = box_cls_labels > 0
+        negatives = box_cls_labels == 0
+        cls_weights = (negatives * 1.0 + 1.0 * positives).float()
+        pos_normalizer = positives.sum(1, keepdim=True).float()
+        cls_weights = cls_weights / torch.clamp(pos_normalizer, min=1.0)
+        if self.num_class == 1:
+            box_cls_labels = torch.where(positives, torch.ones_like(box_cls_labels), box_cls_labels)
+        cls_targets = (box_cls_labels * cared.type_as(box_cls_labels)).long()
+        one_hot = torch.zeros(*cls_targets.shape, self.num_class + 1, dtype=cls_preds.dtype, device=cls_preds.device)
+        one_hot.scatter_(-1, cls_targets.unsqueeze(-1), 1.0)
+        loss_src = self.cls_loss_func(cls_preds.view(B, -1, self.num_class), one_hot[..., 1:], weights=cls_weights)
+        cls_loss = loss_src.sum() / B if reduce else loss_src.sum(-1).sum(-1)
+        cls_loss = cls_loss * self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS['cls_weight']
+        return cls_loss, {'rpn_loss_cls': (cls_loss if reduce else cls_loss[0]).detach()}
+
+    @staticmethod
+    def add_sin_difference(boxes1, boxes2, dim=6):
+        assert dim != -1
+        a, b = boxes1[..., dim:dim + 1], boxes2[..., dim:dim + 1]
+        enc1 = torch.sin(a) * torch.cos(b)
+        enc2 = torch.cos(a) * torch.sin(b)
+        boxes1 = torch.cat([boxes1[..., :dim], enc1, boxes1[..., dim + 1:]], dim=-1)
+        boxes2 = torch.cat([boxes2[..., :dim], enc2, boxes2[..., dim + 1:]], dim=-1)
+        return boxes1, boxes2
+
+    @staticmethod
+    def get_direction_target(anchors, reg_targets, one_hot=True, dir_offset=0, num_bins=2):
+        B = reg_targets.shape[0]
+        anchors = anchors.view(B, -1, anchors.shape[-1])
+        rot_gt = reg_targets[..., 6] + anchors[..., 6]
+        offset_rot = common_utils.limit_period(rot_gt - dir_offset, 0, 2 * np.pi)
+        dir_cls = torch.clamp(torch.floor(offset_rot / (2 * np.pi / num_bins)).long(), min=0, max=num_bins - 1)
+        if one_hot:
+            t = torch.zeros(*dir_cls.shape, num_bins, dtype=anchors.dtype, device=dir_cls.device)
+            t.scatter_(-1, dir_cls.unsqueeze(-1), 1.0)
+            return t
+        return dir_cls
+
+    def get_box_reg_layer_loss(self, reduce=True):
+        d = self.forward_ret_dict
+        box_preds, dir_preds = d['box_preds'], d.get('dir_cls_preds', None)
+        reg_targets, labels = d['box_reg_targets'], d['box_cls_labels']
+        B = int(box_preds.shape[0])
+        positives = labels > 0
+        reg_weights = positives.float()
+        reg_weights = reg_weights / torch.clamp(positives.sum(1, keepdim=True).float(), min=1.0)
+        anchors = self._flat_anchors()
+        anchors = anchors.view(1, -1, anchors.shape[-1]).expand(B, -1, -1)
+        box_preds = box_preds.view(B, -1, box_preds.shape[-1] // self.num_anchors_per_location)
+        p_sin, t_sin = self.add_sin_difference(box_preds, reg_targets)
+        loc_src = self.reg_loss_func(p_sin, t_sin, weights=reg_weights)
+        loc_loss = loc_src.sum() / B if reduce else loc_src.sum(-1).sum(-1)
+        loc_loss = loc_loss * self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS['loc_weight']
+        box_loss = loc_loss
+        tb = {'rpn_loss_loc': (loc_loss if reduce else loc_loss[0]).detach()}
+        if dir_preds is not None:
+            dir_targets = self.get_direction_target(anchors, reg_targets, dir_offset=self.model_cfg.DIR_OFFSET,
+                                                    num_bins=self.model_cfg.NUM_DIR_BINS)
+            dir_logits = dir_preds.view(B, -1, self.model_cfg.NUM_DIR_BINS)
+            w = positives.type_as(dir_logits)
+            w = w / torch.clamp(w.sum(-1, keepdim=True), min=1.0)
+            dir_loss = self.dir_loss_func(dir_logits, dir_targets, weights=w)
+            dir_loss = dir_loss.sum() / B if reduce else dir_loss.sum(-1).sum(-1)
+            dir_loss = dir_loss * self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS['dir_weight']
+            box_loss = box_loss + dir_loss
+            tb['rpn_loss_dir'] = (dir_loss if reduce else dir_loss[0]).detach()
+        return box_loss, tb
+
+    def get_loss(self, reduce=True):
+        cls_loss, tb = self.get_cls_layer_loss(reduce=reduce)
+        box_loss, tb_box = self.get_box_reg_layer_loss(reduce=reduce)
+        tb.update(tb_box)
+        rpn_loss = cls_loss + box_loss
+        tb['rpn_loss'] = (rpn_loss if reduce else rpn_loss[0]).detach()
+        return rpn_loss, tb
+
+    def generate_predicted_boxes(self, batch_size, cls_preds, box_preds, dir_cls_preds=None):
+        """cls (B,H,W,C1), box (B,H,W,C2), dir (B,H,W,C3) -> (B,A,num_class), (B,A,7+C)  (anchor_head_template.py:238-285)"""
+        anchors = self._flat_anchors()
+        A = anchors.view(-1, anchors.shape[-1]).shape[0]
+        batch_anchors = anchors.view(1, -1, anchors.shape[-1]).expand(batch_size, -1, -1)
+        batch_cls_preds = cls_preds.view(batch_size, A, -1).float()
+        batch_box_preds = self.box_coder.decode_torch(box_preds.view(batch_size, A, -1), batch_anchors)
+        if dir_cls_preds is not None:
+            dir_offset, dir_limit_offset = self.model_cfg.DIR_OFFSET, self.model_cfg.DIR_LIMIT_OFFSET
+            dir_labels = torch.max(dir_cls_preds.view(batch_size, A, -1), dim=-1)[1]
+            period = 2 * np.pi / self.model_cfg.NUM_DIR_BINS
+            dir_rot = common_utils.limit_period(batch_box_preds[..., 6] - dir_offset, dir_limit_offset, period)
+            rot = dir_rot + dir_offset + period * dir_labels.to(batch_box_preds.dtype)
+            batch_box_preds = torch.cat([batch_box_preds[..., :6], rot.unsqueeze(-1), batch_box_preds[..., 7:]], dim=-1)
+        return batch_cls_preds, batch_box_preds
+
+    def forward(self, **kwargs):
+        raise NotImplementedError

@@ -109,6 +109,25 @@ int crb_sparse_to_dense(const float* feat, const int32_t* coords, float* out, in
 int crb_dense_to_sparse(const float* dense, const int32_t* coords, float* feat, int64_t n, int B, int C,
                         int D, int H, int W, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * a13/a14  rotated BEV overlap / IoU / 3-D IoU and NMS
+ * replaces: the pybind surface of pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp:11-17
+ *   boxes_overlap_bev_gpu (iou3d_nms.cpp:46-66)  -> crb_boxes_pairwise(mode 0)
+ *   boxes_iou_bev_gpu     (iou3d_nms.cpp:68-88)  -> crb_boxes_pairwise(mode 1)
+ *   boxes_iou3d_gpu       (iou3d_nms_utils.py:48-81, fused) -> crb_boxes_pairwise(mode 2)
+ *   nms_gpu / nms_normal_gpu (iou3d_nms.cpp:90-185: device mask + D2H + host greedy scan) -> crb_nms_batched
+ * boxes are (n,7) f32 [x,y,z,dx,dy,dz,heading]; out (na,nb) f32.
+ * crb_nms_batched: boxes_sorted (B,nmax,7) already in descending score order, counts (B) i32 device or NULL (= nmax
+ * everywhere); keep (B,max_keep) i32 indices into the sorted order, -1 padded; num_keep (B) i32. Greedy scan runs on
+ * the device; no synchronisation. workspace >= crb_nms_workspace_bytes(B,nmax).
+ * ---------------------------------------------------------------------------------------------- */
+int crb_boxes_pairwise(const float* boxes_a, int64_t na, const float* boxes_b, int64_t nb, float* out,
+                       int mode, void* stream);
+int64_t crb_nms_workspace_bytes(int B, int64_t nmax);
+int crb_nms_batched(const float* boxes_sorted, const int32_t* counts, int B, int64_t nmax, float thresh,
+                    int rotated, int max_keep, int32_t* keep, int32_t* num_keep, void* workspace,
+                    int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

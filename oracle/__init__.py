@@ -166,3 +166,46 @@ def dense(feat, coords, B, shape_dhw):
     L.oracle_dense(_p(f), _p(c), _p(out), ctypes.c_int(len(c)), ctypes.c_int(B), ctypes.c_int(C), ctypes.c_int(D),
                    ctypes.c_int(H), ctypes.c_int(W))
     return out
+
+
+# ------------------------------------------------------------------ rotated IoU / NMS
+def boxes_pairwise(boxes_a, boxes_b, mode):
+    """mode 0: BEV overlap area, 1: BEV IoU, 2: 3-D IoU"""
+    L = _lib()
+    a, b = _f32(boxes_a), _f32(boxes_b)
+    out = np.zeros((len(a), len(b)), np.float32)
+    L.oracle_boxes_pairwise(_p(a), ctypes.c_int(len(a)), _p(b), ctypes.c_int(len(b)), _p(out), ctypes.c_int(mode))
+    return out
+
+
+def nms(boxes_sorted, thresh, rotated=True):
+    """greedy NMS over boxes already in descending score order -> kept indices"""
+    L = _lib()
+    b = _f32(boxes_sorted)
+    keep = np.zeros((max(len(b), 1),), np.int32)
+    L.oracle_nms.restype = ctypes.c_int
+    n = L.oracle_nms(_p(b), ctypes.c_int(len(b)), ctypes.c_float(thresh), ctypes.c_int(1 if rotated else 0), _p(keep))
+    return keep[:n].copy()
+
+
+# ------------------------------------------------------------------ oracle/_ref : the reference's own compiled code
+_REF_IOU = os.path.join(_HERE, '_ref', 'libiou3d_ref.so')
+
+
+def have_ref_iou3d():
+    return os.path.exists(_REF_IOU)
+
+
+def ref_boxes_iou_bev(boxes_a, boxes_b):
+    """the reference's boxes_iou_bev_cpu (pcdet/ops/iou3d_nms/src/iou3d_cpu.cpp:232-252) compiled from its own source
+    by oracle/build_ref.sh"""
+    import torch  # noqa: F401  (libtorch must be resident before the shim loads)
+    global _RL
+    try:
+        L = _RL
+    except NameError:
+        L = _RL = ctypes.CDLL(_REF_IOU)
+    a, b = _f32(boxes_a), _f32(boxes_b)
+    out = np.zeros((len(a), len(b)), np.float32)
+    L.ref_boxes_iou_bev_cpu(_p(a), ctypes.c_int(len(a)), _p(b), ctypes.c_int(len(b)), _p(out))
+    return out

@@ -154,15 +154,17 @@ void oracle_conv_fwd(const float* X, const float* W, const int* nbr, float* Y, i
   }
 }
 
-/* dX (n_in,cin) by scattering dY through the same table: dX[nbr[i][o]] += dY[i] W[o]^T */
+/* dX (n_in,cin) by scattering dY through the same table: dX[nbr[i][o]] += dY[i] W[o]^T.
+ * For a fixed offset the map i -> nbr[i][o] is injective, so the inner loop over i is race free. */
 void oracle_conv_dgrad(const float* dY, const float* W, const int* nbr, float* dX, int n_in, int n_out, int K, int cin,
                        int cout) {
   double* acc = (double*)calloc((size_t)(n_in > 0 ? n_in : 1) * cin, sizeof(double));
-  for (int i = 0; i < n_out; ++i)
-    for (int o = 0; o < K; ++o) {
+  for (int o = 0; o < K; ++o) {
+    const float* w = W + (size_t)o * cin * cout;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n_out; ++i) {
       int j = nbr[(size_t)i * K + o];
       if (j < 0) continue;
-      const float* w = W + (size_t)o * cin * cout;
       const float* g = dY + (size_t)i * cout;
       for (int k = 0; k < cin; ++k) {
         double s = 0.0;
@@ -170,23 +172,26 @@ void oracle_conv_dgrad(const float* dY, const float* W, const int* nbr, float* d
         acc[(size_t)j * cin + k] += s;
       }
     }
+  }
   for (size_t t = 0; t < (size_t)n_in * cin; ++t) dX[t] = (float)acc[t];
   free(acc);
 }
 
-/* dW (K,cin,cout) */
+/* dW (K,cin,cout); offsets are independent -> parallel over o */
 void oracle_conv_wgrad(const float* X, const float* dY, const int* nbr, float* dW, int n_out, int K, int cin, int cout) {
   double* acc = (double*)calloc((size_t)K * cin * cout, sizeof(double));
-  for (int i = 0; i < n_out; ++i)
-    for (int o = 0; o < K; ++o) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int o = 0; o < K; ++o) {
+    double* a = acc + (size_t)o * cin * cout;
+    for (int i = 0; i < n_out; ++i) {
       int j = nbr[(size_t)i * K + o];
       if (j < 0) continue;
       const float* x = X + (size_t)j * cin;
       const float* g = dY + (size_t)i * cout;
-      double* a = acc + (size_t)o * cin * cout;
       for (int k = 0; k < cin; ++k)
         for (int c = 0; c < cout; ++c) a[(size_t)k * cout + c] += (double)x[k] * (double)g[c];
     }
+  }
   for (size_t t = 0; t < (size_t)K * cin * cout; ++t) dW[t] = (float)acc[t];
   free(acc);
 }

@@ -1,0 +1,243 @@
+"""Generate golden vectors by importing the importable half of the reference (SURVEY §8c stub recipe).
+
+Runs ONLY in the authoring container (needs /root/reference); the .npz files it writes are committed and are the only
+thing that travels.  Usage:  python tests/golden/make_goldens.py
+Nothing from the reference is copied: the script imports its modules, feeds seeded inputs, stores inputs + outputs."""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class EasyDict(dict):
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        d = dict(d or {})
+        d.update(kw)
+        for k, v in d.items():
+            self[k] = v
+
+    def __setitem__(self, k, v):
+        if isinstance(v, dict) and not isinstance(v, EasyDict):
+            v = EasyDict(v)
+        elif isinstance(v, list):
+            v = [EasyDict(x) if isinstance(x, dict) else x for x in v]
+        super().__setitem__(k, v)
+
+    __setattr__ = __setitem__
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+def import_reference():
+    assert os.path.isdir(REF), 'reference tree not mounted'
+    sys.path.insert(0, REF)
+    _stub('pcdet.version', __version__='0.5.2+ref')
+    _stub('easydict', EasyDict=EasyDict)
+    for n in ('SharedArray', 'wandb', 'tensorboardX', 'kornia'):
+        _stub(n)
+    _passthrough = lambda *a, **k: (a[0] if (len(a) == 1 and callable(a[0]) and not k) else (lambda f: f))
+    nb = _stub('numba', jit=_passthrough, njit=_passthrough)
+    nb.cuda = _stub('numba.cuda', jit=_passthrough)
+    _stub('tensorboardX', SummaryWriter=object)
+    sk = _stub('skimage')
+    sk.transform = _stub('skimage.transform')
+    _stub('skimage.io')
+    sp = _stub('spconv')
+    spp = _stub('spconv.pytorch', SparseModule=torch.nn.Module, SparseSequential=torch.nn.Sequential)
+    spp.conv = _stub('spconv.pytorch.conv', SparseConvolution=torch.nn.Module)
+    sp.pytorch = spp
+    for ext in ('pcdet.ops.iou3d_nms.iou3d_nms_cuda', 'pcdet.ops.roiaware_pool3d.roiaware_pool3d_cuda',
+                'pcdet.ops.roipoint_pool3d.roipoint_pool3d_cuda',
+                'pcdet.ops.pointnet2.pointnet2_stack.pointnet2_stack_cuda',
+                'pcdet.ops.pointnet2.pointnet2_batch.pointnet2_batch_cuda'):
+        _stub(ext)
+    # the reference calls .cuda() in constructors; run them on the CPU
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def small_head_cfg():
+    def anc(cls, size, bottom, m, u):
+        return {'class_name': cls, 'anchor_sizes': [size], 'anchor_rotations': [0, 1.57],
+                'anchor_bottom_heights': [bottom], 'align_center': False, 'feature_map_stride': 8,
+                'matched_threshold': m, 'unmatched_threshold': u}
+    return EasyDict({
+        'NAME': 'AnchorHeadSingle', 'CLASS_AGNOSTIC': False, 'USE_DIRECTION_CLASSIFIER': True,
+        'DIR_OFFSET': 0.78539, 'DIR_LIMIT_OFFSET': 0.0, 'NUM_DIR_BINS': 2,
+        'ANCHOR_GENERATOR_CONFIG': [anc('Car', [3.9, 1.6, 1.56], -1.78, 0.6, 0.45),
+                                    anc('Pedestrian', [0.8, 0.6, 1.73], -0.6, 0.5, 0.35),
+                                    anc('Cyclist', [1.76, 0.6, 1.73], -0.6, 0.5, 0.35)],
+        'TARGET_ASSIGNER_CONFIG': {'NAME': 'AxisAlignedTargetAssigner', 'POS_FRACTION': -1.0, 'SAMPLE_SIZE': 512,
+                                   'NORM_BY_NUM_EXAMPLES': False, 'MATCH_HEIGHT': False, 'BOX_CODER': 'ResidualCoder'},
+        'LOSS_CONFIG': {'LOSS_WEIGHTS': {'cls_weight': 1.0, 'loc_weight': 2.0, 'dir_weight': 0.2,
+                                         'code_weights': [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]}},
+    })
+
+
+def rand_gt(rng, B, G, rng_xy):
+    sizes = {1: (3.9, 1.6, 1.56), 2: (0.8, 0.6, 1.73), 3: (1.76, 0.6, 1.73)}
+    gt = np.zeros((B, G, 8), np.float32)
+    for b in range(B):
+        n = G if b % 2 == 0 else G - 3          # ragged: trailing zero rows
+        for g in range(n):
+            c = int(rng.integers(1, 4))
+            s = np.array(sizes[c]) * rng.uniform(0.85, 1.15, 3)
+            gt[b, g] = [rng.uniform(*rng_xy[0]), rng.uniform(*rng_xy[1]), -1.0 + rng.uniform(-0.3, 0.3), *s,
+                        rng.uniform(-np.pi, np.pi), c]
+    return gt
+
+
+def gen_utils(out):
+    from pcdet.utils import box_coder_utils, box_utils, common_utils, loss_utils
+    rng = np.random.default_rng(1)
+    boxes = rand_gt(rng, 1, 40, ((0, 70), (-40, 40)))[0, :, :7]
+    anchors = boxes + rng.normal(0, 0.3, boxes.shape).astype(np.float32)
+    anchors[:, 3:6] = np.abs(anchors[:, 3:6]) + 0.1
+    coder = box_coder_utils.ResidualCoder()
+    enc = coder.encode_torch(torch.from_numpy(boxes.copy()), torch.from_numpy(anchors.copy()))
+    dec = coder.decode_torch(enc, torch.from_numpy(anchors.copy()))
+    out['coder_boxes'], out['coder_anchors'], out['coder_enc'], out['coder_dec'] = boxes, anchors, _np(enc), _np(dec)
+    val = rng.uniform(-20, 20, 200).astype(np.float32)
+    out['lp_val'] = val
+    out['lp_a'] = _np(common_utils.limit_period(torch.from_numpy(val), offset=0.5, period=np.pi))
+    out['lp_b'] = _np(common_utils.limit_period(torch.from_numpy(val), offset=0.0, period=2 * np.pi))
+    pts = rng.normal(size=(3, 17, 5)).astype(np.float32)
+    ang = rng.uniform(-4, 4, 3).astype(np.float32)
+    out['rot_pts'], out['rot_ang'] = pts, ang
+    out['rot_out'] = _np(common_utils.rotate_points_along_z(torch.from_numpy(pts), torch.from_numpy(ang)))
+    b2 = rand_gt(rng, 1, 30, ((0, 30), (-15, 15)))[0, :, :7]
+    out['iou_a'], out['iou_b'] = boxes, b2
+    out['iou_nearest_bev'] = _np(box_utils.boxes3d_nearest_bev_iou(torch.from_numpy(boxes), torch.from_numpy(b2)))
+    out['corners'] = _np(box_utils.boxes_to_corners_3d(torch.from_numpy(boxes)))
+    # losses
+    x = rng.normal(0, 2, (2, 50, 3)).astype(np.float32)
+    t = (rng.uniform(size=(2, 50, 3)) < 0.2).astype(np.float32)
+    w = rng.uniform(0, 1, (2, 50)).astype(np.float32)
+    out['focal_x'], out['focal_t'], out['focal_w'] = x, t, w
+    out['focal_out'] = _np(loss_utils.SigmoidFocalClassificationLoss(alpha=0.25, gamma=2.0)(
+        torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(w)))
+    p = rng.normal(0, 1, (2, 50, 7)).astype(np.float32)
+    q = rng.normal(0, 1, (2, 50, 7)).astype(np.float32)
+    q[0, 3, 2] = np.nan
+    out['sl1_p'], out['sl1_q'] = p, q
+    out['sl1_out'] = _np(loss_utils.WeightedSmoothL1Loss(code_weights=[1, 1, 1, 1, 1, 1, 2.0])(
+        torch.from_numpy(p), torch.from_numpy(q), torch.from_numpy(w)))
+    logits = rng.normal(0, 1, (2, 50, 2)).astype(np.float32)
+    oh = np.eye(2, dtype=np.float32)[rng.integers(0, 2, (2, 50))]
+    out['ce_x'], out['ce_t'] = logits, oh
+    out['ce_out'] = _np(loss_utils.WeightedCrossEntropyLoss()(torch.from_numpy(logits), torch.from_numpy(oh),
+                                                               torch.from_numpy(w)))
+    out['corner_loss'] = _np(loss_utils.get_corner_loss_lidar(torch.from_numpy(boxes[:30]), torch.from_numpy(b2)))
+
+
+def gen_head(out):
+    """AnchorHeadSingle on a reduced grid (feature map 22x20): anchors, targets, losses + grads, decoded boxes"""
+    from pcdet.models.dense_heads.anchor_head_single import AnchorHeadSingle
+    rng = np.random.default_rng(2)
+    pc_range = np.array([0, -8, -3, 17.6, 8, 1], np.float32)
+    grid = np.array([176, 160, 40], np.int64)
+    torch.manual_seed(3)
+    head = AnchorHeadSingle(small_head_cfg(), input_channels=24, num_class=3,
+                            class_names=['Car', 'Pedestrian', 'Cyclist'], grid_size=grid, point_cloud_range=pc_range,
+                            predict_boxes_when_training=True)
+    head.train()
+    B = 3
+    gt = rand_gt(rng, B, 9, ((0.5, 17), (-7.5, 7.5)))
+    gt[2] = 0                                   # a frame without any box
+    feats = torch.from_numpy(rng.normal(0, 1, (B, 24, 20, 22)).astype(np.float32)).requires_grad_(True)
+    dd = head({'spatial_features_2d': feats, 'gt_boxes': torch.from_numpy(gt.copy()), 'batch_size': B})
+    loss, tb = head.get_loss()
+    loss.backward()
+    out['head_state'] = {k: _np(v) for k, v in head.state_dict().items()}
+    out['head_feats'], out['head_gt'] = _np(feats), gt
+    out['head_anchors'] = np.stack([_np(a) for a in head.anchors])
+    fr = head.forward_ret_dict
+    out['head_labels'] = _np(fr['box_cls_labels']).astype(np.int8)
+    out['head_reg_targets'] = _np(fr['box_reg_targets'])
+    out['head_reg_weights'] = _np(fr['reg_weights'])
+    out['head_loss'] = np.array([float(loss), tb['rpn_loss_cls'], tb['rpn_loss_loc'], tb['rpn_loss_dir']], np.float64)
+    out['head_feats_grad'] = _np(feats.grad)
+    out['head_batch_cls_preds'] = _np(dd['batch_cls_preds'])
+    out['head_batch_box_preds'] = _np(dd['batch_box_preds'])
+    # full-size anchors: a strided sample + column sums
+    from pcdet.models.dense_heads.target_assigner.anchor_generator import AnchorGenerator
+    cfgs = small_head_cfg().ANCHOR_GENERATOR_CONFIG
+    ag = AnchorGenerator(anchor_range=np.array([0, -40, -3, 70.4, 40, 1], np.float32), anchor_generator_config=cfgs)
+    al, per = ag.generate_anchors([np.array([176, 200])] * 3)
+    out['anchors_full_shape'] = np.array(al[0].shape)
+    flat = torch.stack(al).reshape(3, -1, 7)
+    out['anchors_full_sample'] = _np(flat[:, ::997])
+    out['anchors_full_colsum'] = _np(flat.double().sum(1))
+
+
+def gen_bev(out):
+    from pcdet.models.backbones_2d.base_bev_backbone import BaseBEVBackbone
+    from pcdet.models.backbones_3d.vfe.mean_vfe import MeanVFE
+    cfg = EasyDict({'LAYER_NUMS': [2, 1], 'LAYER_STRIDES': [1, 2], 'NUM_FILTERS': [8, 16], 'UPSAMPLE_STRIDES': [1, 2],
+                    'NUM_UPSAMPLE_FILTERS': [8, 8]})
+    torch.manual_seed(4)
+    m = BaseBEVBackbone(cfg, input_channels=6)
+    m.train()
+    rng = np.random.default_rng(5)
+    x = rng.normal(0, 1, (2, 6, 20, 24)).astype(np.float32)
+    y = m({'spatial_features': torch.from_numpy(x)})['spatial_features_2d']
+    out['bev_state'] = {k: _np(v) for k, v in m.state_dict().items()}
+    out['bev_x'], out['bev_y'] = x, _np(y)
+    v = rng.normal(0, 1, (50, 5, 4)).astype(np.float32)
+    n = rng.integers(0, 6, 50).astype(np.float32)
+    for i in range(50):
+        v[i, int(n[i]):] = 0
+    vfe = MeanVFE(EasyDict({}), 4)
+    out['vfe_v'], out['vfe_n'] = v, n
+    out['vfe_out'] = _np(vfe({'voxels': torch.from_numpy(v), 'voxel_num_points': torch.from_numpy(n)})['voxel_features'])
+
+
+def save(name, d):
+    flat = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            for k2, v2 in v.items():
+                flat[k + '/' + k2] = v2
+        else:
+            flat[k] = v
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **flat)
+    print(name, '%.1f KB' % (os.path.getsize(path) / 1024))
+
+
+if __name__ == '__main__':
+    import_reference()
+    for name, fn in (('ref_utils.npz', gen_utils), ('ref_anchor_head.npz', gen_head), ('ref_bev_vfe.npz', gen_bev)):
+        d = {}
+        fn(d)
+        save(name, d)
+
+
+# ref_iou3d.npz is produced from oracle/_ref (the reference's iou3d_cpu.cpp compiled by oracle/build_ref.sh):
+#   python - <<'PY'
+#   import numpy as np, oracle; from boxes_synth import detection_boxes
+#   rng = np.random.default_rng(123); a,_ = detection_boxes(rng,160); b,_ = detection_boxes(rng,120)
+#   b[:40] = a[:40] + rng.normal(0,0.15,(40,7)).astype(np.float32)
+#   np.savez_compressed('tests/golden/ref_iou3d.npz', a=a, b=b, iou=oracle.ref_boxes_iou_bev(a,b))
+#   PY

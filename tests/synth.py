@@ -1,114 +1,3 @@
-"""Seeded synthetic inputs shared by tests, smoke() and bench.py.
-KITTI-shaped LiDAR clouds: 64 beams, +-45 deg azimuth, ground plane + random walls + boxes, cropped to the KITTI range
-and resampled to exactly n points. Pure numpy so the CPU box and the GPU box generate identical data."""
-import numpy as np
-
-KITTI_RANGE = [0.0, -40.0, -3.0, 70.4, 40.0, 1.0]
-KITTI_VOXEL = [0.05, 0.05, 0.1]
-WAYMO_RANGE = [-75.2, -75.2, -2.0, 75.2, 75.2, 4.0]
-WAYMO_VOXEL = [0.1, 0.1, 0.15]
-CLASS_SIZES = {1: (3.9, 1.6, 1.56), 2: (0.8, 0.6, 1.73), 3: (1.76, 0.6, 1.73)}   # second.yaml:41,51,61
-
-
-def _boxes(rng, n_car, n_ped, n_cyc, xr, yr, ground_z):
-    out = []
-    for cls, cnt in ((1, n_car), (2, n_ped), (3, n_cyc)):
-        dx, dy, dz = CLASS_SIZES[cls]
-        for _ in range(cnt):
-            x = rng.uniform(*xr)
-            y = rng.uniform(*yr)
-            yaw = rng.uniform(-np.pi, np.pi)
-            out.append([x, y, ground_z + dz / 2, dx, dy, dz, yaw, cls])
-    return np.asarray(out, dtype=np.float32)
-
-
-def _ray_box(o, d, box):
-    """nearest positive ray/box hit distance (inf if none); o (3,), d (n,3)"""
-    cx, cy, cz, dx, dy, dz, yaw = box[:7]
-    c, s = np.cos(-yaw), np.sin(-yaw)
-    R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=np.float64)
-    ol = R @ (o - np.array([cx, cy, cz]))
-    dl = d @ R.T
-    h = np.array([dx, dy, dz]) / 2
-    with np.errstate(divide='ignore', invalid='ignore'):
-        t1 = (-h - ol) / dl
-        t2 = (h - ol) / dl
-    tmin = np.nanmax(np.minimum(t1, t2), axis=1)
-    tmax = np.nanmin(np.maximum(t1, t2), axis=1)
-    hit = (tmax >= tmin) & (tmax > 0)
-    return np.where(hit, np.maximum(tmin, 0.0), np.inf)
-
-
-def kitti_frame(frame_idx, n_points=20000, waymo=False):
-    """-> points (n,4|5) f32, gt_boxes (G,8) f32 [x,y,z,dx,dy,dz,yaw,cls]"""
-    rng = np.random.default_rng(np.random.PCG64(20230501 + int(frame_idx)))
-    if waymo:
-        rngx = WAYMO_RANGE
-        az_lo, az_hi, n_az = -np.pi, np.pi, 2650
-        boxes = _boxes(rng, 18, 6, 6, (-65, 65), (-65, 65), -1.73)
-        nfeat = 5
-    else:
-        rngx = KITTI_RANGE
-        az_lo, az_hi, n_az = -np.pi / 4, np.pi / 4, 512
-        boxes = _boxes(rng, 6, 3, 3, (5, 65), (-30, 30), -1.73)
-        nfeat = 4
-    elev = np.deg2rad(np.linspace(-24.8, 2.0, 64))
-    az = rng.uniform(az_lo, az_hi, n_az)
-    wall = np.where(rng.uniform(size=n_az) < 0.5, rng.uniform(8, 70, n_az), np.inf)
-    E, A = np.meshgrid(elev, az, indexing='ij')
-    d = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], axis=-1).reshape(-1, 3)
-    o = np.zeros(3)
-    with np.errstate(divide='ignore'):
-        t_ground = np.where(d[:, 2] < 0, -1.73 / d[:, 2], np.inf)
-    t_wall = np.tile(wall[None, :], (64, 1)).reshape(-1) / np.maximum(np.cos(E).reshape(-1), 1e-6)
-    t = np.minimum(t_ground, t_wall)
-    for b in boxes:
-        t = np.minimum(t, _ray_box(o, d, b.astype(np.float64)))
-    ok = np.isfinite(t) & (t < 120)
-    t = t[ok] + rng.normal(0, 0.02, ok.sum())
-    pts = d[ok] * t[:, None]
-    m = ((pts[:, 0] >= rngx[0]) & (pts[:, 0] < rngx[3]) & (pts[:, 1] >= rngx[1]) & (pts[:, 1] < rngx[4]) &
-         (pts[:, 2] >= rngx[2]) & (pts[:, 2] < rngx[5]))
-    pts = pts[m]
-    if len(pts) == 0:
-        pts = np.zeros((1, 3))
-    sel = rng.choice(len(pts), size=n_points, replace=len(pts) < n_points)
-    pts = pts[sel]
-    if len(sel) > len(np.unique(sel)):          # duplicated samples get a little jitter
-        pts = pts + rng.normal(0, 0.01, pts.shape)
-    feats = [rng.uniform(0, 1, (n_points, 1))]
-    if nfeat == 5:
-        feats.append(rng.uniform(0, 1.5, (n_points, 1)))
-    out = np.concatenate([pts] + feats, axis=1).astype(np.float32)
-    return out, boxes
-
-
-def kitti_batch(first_frame, batch_size, n_points=20000, waymo=False):
-    """-> points (B*n, C) f32, frame_offsets (B+1) i32, gt_boxes (B,G,8) f32"""
-    ps, bs = [], []
-    for i in range(batch_size):
-        p, b = kitti_frame(first_frame + i, n_points, waymo)
-        ps.append(p)
-        bs.append(b)
-    off = np.concatenate([[0], np.cumsum([len(p) for p in ps])]).astype(np.int32)
-    return np.concatenate(ps), off, np.stack(bs)
-
-
-def random_sparse_coords(rng, n, batch_size, shape_dhw, clustered=True):
-    """unique active sites (n,4) i32 [b,z,y,x], in random row order"""
-    D, H, W = shape_dhw
-    if clustered:
-        centers = np.stack([rng.integers(0, batch_size, 64), rng.integers(0, D, 64), rng.integers(0, H, 64),
-                            rng.integers(0, W, 64)], axis=1)
-        c = centers[rng.integers(0, 64, n * 2)]
-        off = np.round(rng.normal(0, 2.5, (n * 2, 3))).astype(np.int64)
-        pts = np.concatenate([c[:, :1], c[:, 1:] + off], axis=1)
-        ok = ((pts[:, 1] >= 0) & (pts[:, 1] < D) & (pts[:, 2] >= 0) & (pts[:, 2] < H) & (pts[:, 3] >= 0) &
-              (pts[:, 3] < W))
-        pts = pts[ok]
-    else:
-        pts = np.stack([rng.integers(0, batch_size, n * 2), rng.integers(0, D, n * 2), rng.integers(0, H, n * 2),
-                        rng.integers(0, W, n * 2)], axis=1)
-    _, first = np.unique(pts, axis=0, return_index=True)
-    pts = pts[np.sort(first)][:n]
-    return np.ascontiguousarray(pts.astype(np.int32))
+"""seeded synthetic inputs — the generator itself lives in the package so bench.py / smoke() share it"""
+from pcdet.datasets.synthetic import *  # noqa: F401,F403
+from pcdet.datasets.synthetic import kitti_frame, kitti_batch, random_sparse_coords  # noqa: F401
