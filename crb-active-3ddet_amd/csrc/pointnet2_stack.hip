@@ -1,0 +1,338 @@
+// PointNet++ "stack" ops for gfx950 (rows a16-a18 of SURVEY §8): farthest point sampling, ball query, grouping
+// (+grad), three-NN, three-interpolate (+grad).
+//
+// Replaces pcdet/ops/pointnet2/pointnet2_stack/src/{sampling_gpu.cu:25-140, ball_query_gpu.cu:16-66,
+// group_points_gpu.cu:15-102, interpolate_gpu.cu:16-172} (pybind surface pointnet2_api.cpp:12-31).
+//
+// Layout ("stacked"): xyz (N1+N2+..,3) f32 with *_batch_cnt (B) i32; indices are int32.
+//
+// MI355X design notes
+//  * ball query: ONE WAVE per query centre. The 64 lanes test 64 consecutive candidate points per step (coalesced
+//    12-B rows), a ballot + popcount prefix places the hits in index order, and the wave stops as soon as nsample hits
+//    exist — the reference's per-thread serial scan order (ball_query_gpu.cu:47-64) is reproduced exactly, 64 points
+//    per step.
+//  * FPS: one 1024-thread workgroup per frame with every point of the frame held in registers for the whole run;
+//    each round is a register-only distance update + a wave arg-max by __shfl_xor on a packed 64-bit key + ONE LDS
+//    exchange between the 16 waves (2 barriers per round instead of the reference's 11). The packed key encodes the
+//    reference's tie rule exactly (first max per strided thread, then the lower-position operand of its LDS tree).
+//  * grouping: one workgroup per centre tile, rows read coalesced along C, the (C,nsample) slab transposed through LDS
+//    so the (M,C,nsample) output is written contiguously; the gradient scatters with channel-contiguous atomics.
+#include "crb_common.h"
+#include "../../include/crb_hip.h"
+
+namespace {
+
+// which batch element does stacked row `i` belong to; also returns the start row of that element in `other_cnt`
+__device__ __forceinline__ int locate_batch(const int* __restrict__ cnt, int B, int i, const int* __restrict__ other_cnt,
+                                            int* other_start) {
+  int b = 0, acc = cnt[0], os = 0;
+  for (int k = 1; k < B; ++k) {
+    if (i < acc) break;
+    acc += cnt[k];
+    os += other_cnt[k - 1];
+    b = k;
+  }
+  *other_start = os;
+  return b;
+}
+
+// ------------------------------------------------------------------------------------------------ ball query
+__global__ __launch_bounds__(256) void ball_query_kernel(int B, int M, float radius, int nsample,
+                                                         const float* __restrict__ new_xyz,
+                                                         const int* __restrict__ new_cnt, const float* __restrict__ xyz,
+                                                         const int* __restrict__ xyz_cnt, int* __restrict__ idx) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= M) return;
+  int start;
+  const int b = locate_batch(new_cnt, B, q, xyz_cnt, &start);
+  const int n = xyz_cnt[b];
+  const float* p = xyz + (int64_t)start * 3;
+  const float r2 = radius * radius;
+  const float qx = new_xyz[(int64_t)q * 3 + 0], qy = new_xyz[(int64_t)q * 3 + 1], qz = new_xyz[(int64_t)q * 3 + 2];
+  int* out = idx + (int64_t)q * nsample;
+  int cnt = 0;
+  int first = -1;
+  for (int k0 = 0; k0 < n && cnt < nsample; k0 += 64) {
+    const int k = k0 + lane;
+    bool hit = false;
+    if (k < n) {
+      float x = p[k * 3 + 0], y = p[k * 3 + 1], z = p[k * 3 + 2];
+      float d2 = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z);
+      hit = d2 < r2;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (m == 0ULL) continue;
+    if (first < 0) first = k0 + (__ffsll((long long)m) - 1);
+    const int pos = cnt + __popcll(m & ((1ULL << lane) - 1ULL));
+    if (hit && pos < nsample) out[pos] = k;
+    cnt += __popcll(m);
+  }
+  if (cnt > nsample) cnt = nsample;
+  // pad with the first hit (the reference pre-fills every slot with it), or flag an empty ball with -1 in slot 0
+  for (int l = cnt + lane; l < nsample; l += 64) out[l] = (first >= 0) ? first : 0;
+  if (first < 0 && lane == 0) out[0] = -1;
+}
+
+// ------------------------------------------------------------------------------------------------ grouping
+// out (M, C, ns) ; one workgroup per centre; LDS slab (ns, C+1)
+__global__ __launch_bounds__(256) void group_points_kernel(int B, int M, int C, int ns, const float* __restrict__ feat,
+                                                           const int* __restrict__ feat_cnt, const int* __restrict__ idx,
+                                                           const int* __restrict__ idx_cnt, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* slab = reinterpret_cast<float*>(smem);
+  const int m = blockIdx.x;
+  int start;
+  locate_batch(idx_cnt, B, m, feat_cnt, &start);
+  const int CP = C + 1;
+  for (int t = threadIdx.x; t < ns * C; t += 256) {
+    int s = t / C, c = t - s * C;
+    int row = start + idx[(int64_t)m * ns + s];
+    slab[s * CP + c] = feat[(int64_t)row * C + c];
+  }
+  __syncthreads();
+  float* o = out + (int64_t)m * C * ns;
+  for (int t = threadIdx.x; t < ns * C; t += 256) {
+    int c = t / ns, s = t - c * ns;
+    o[t] = slab[s * CP + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void group_points_grad_kernel(int B, int M, int C, int ns,
+                                                                const float* __restrict__ grad_out,
+                                                                const int* __restrict__ idx,
+                                                                const int* __restrict__ idx_cnt,
+                                                                const int* __restrict__ feat_cnt,
+                                                                float* __restrict__ grad_feat) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* slab = reinterpret_cast<float*>(smem);
+  const int m = blockIdx.x;
+  int start;
+  locate_batch(idx_cnt, B, m, feat_cnt, &start);
+  const int CP = C + 1;
+  const float* g = grad_out + (int64_t)m * C * ns;
+  for (int t = threadIdx.x; t < ns * C; t += 256) {
+    int c = t / ns, s = t - c * ns;
+    slab[s * CP + c] = g[t];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < ns * C; t += 256) {
+    int s = t / C, c = t - s * C;
+    int row = start + idx[(int64_t)m * ns + s];
+    atomicAdd(&grad_feat[(int64_t)row * C + c], slab[s * CP + c]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ FPS
+// Tie rule of the reference (sampling_gpu.cu:49-139) as a strict total order on candidates k:
+//   larger running distance first; then smaller bit-reversed (k mod bs) (its LDS tree keeps the lower-position operand
+//   on ties); then smaller k (each strided thread keeps its first maximum). bs = min(2^floor(log2 n), 1024).
+constexpr int FPS_THREADS = 1024;
+constexpr int FPS_MAX_PER_THREAD = 40;    // up to 40960 points per frame held in registers
+
+template <int PPT>
+__global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, int log2bs, const float* __restrict__ xyz_all,
+                                                          int* __restrict__ out_all) {
+  __shared__ unsigned long long wave_best[16];
+  __shared__ float sel_xyz[3];
+  const float* xyz = xyz_all + (int64_t)blockIdx.x * n * 3;
+  int* out = out_all + (int64_t)blockIdx.x * m;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float px[PPT], py[PPT], pz[PPT], dist[PPT];
+  unsigned tie[PPT];
+  const unsigned bsmask = (1u << log2bs) - 1u;
+#pragma unroll
+  for (int t = 0; t < PPT; ++t) {
+    const int k = tid + t * FPS_THREADS;
+    if (k < n) {
+      px[t] = xyz[k * 3 + 0]; py[t] = xyz[k * 3 + 1]; pz[t] = xyz[k * 3 + 2];
+      unsigned v = (unsigned)k & bsmask;
+      unsigned br = log2bs ? (__brev(v) >> (32 - log2bs)) : 0u;
+      tie[t] = 0xffffffffu - ((br << 20) | (unsigned)k);      // larger = preferred
+    } else {
+      px[t] = py[t] = pz[t] = 0.f; tie[t] = 0u;
+    }
+    dist[t] = 1e10f;
+  }
+  if (tid == 0) { out[0] = 0; sel_xyz[0] = xyz[0]; sel_xyz[1] = xyz[1]; sel_xyz[2] = xyz[2]; }
+  __syncthreads();
+  for (int j = 1; j < m; ++j) {
+    const float x1 = sel_xyz[0], y1 = sel_xyz[1], z1 = sel_xyz[2];
+    unsigned long long best = 0ULL;
+#pragma unroll
+    for (int t = 0; t < PPT; ++t) {
+      const int k = tid + t * FPS_THREADS;
+      if (k < n) {
+        float dx = px[t] - x1, dy = py[t] - y1, dz = pz[t] - z1;
+        float d = dx * dx + dy * dy + dz * dz;
+        float d2 = fminf(d, dist[t]);
+        dist[t] = d2;
+        unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | tie[t];
+        best = key > best ? key : best;
+      }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+      unsigned long long o = __shfl_xor(best, s, 64);
+      best = o > best ? o : best;
+    }
+    if (lane == 0) wave_best[wave] = best;
+    __syncthreads();
+    unsigned long long b2 = wave_best[lane & 15];
+#pragma unroll
+    for (int s = 8; s > 0; s >>= 1) {
+      unsigned long long o = __shfl_xor(b2, s, 64);
+      b2 = o > b2 ? o : b2;
+    }
+    const int sel = (int)((0xffffffffu - (unsigned)(b2 & 0xffffffffULL)) & 0xfffffu);
+    if (tid == 0) {
+      out[j] = sel;
+      sel_xyz[0] = xyz[sel * 3 + 0]; sel_xyz[1] = xyz[sel * 3 + 1]; sel_xyz[2] = xyz[sel * 3 + 2];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ three NN / interp
+__global__ __launch_bounds__(256) void three_nn_kernel(int B, int N, const float* __restrict__ unknown,
+                                                       const int* __restrict__ unknown_cnt,
+                                                       const float* __restrict__ known, const int* __restrict__ known_cnt,
+                                                       float* __restrict__ dist2, int* __restrict__ idx) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  int start;
+  const int b = locate_batch(unknown_cnt, B, i, known_cnt, &start);
+  const int n = known_cnt[b];
+  const float ux = unknown[(int64_t)i * 3 + 0], uy = unknown[(int64_t)i * 3 + 1], uz = unknown[(int64_t)i * 3 + 2];
+  const float* kp = known + (int64_t)start * 3;
+  double b1 = 1e40, b2 = 1e40, b3 = 1e40;      // the reference compares in double (interpolate_gpu.cu:51)
+  int i1 = 0, i2 = 0, i3 = 0;
+  for (int k = 0; k < n; ++k) {
+    float x = kp[k * 3 + 0], y = kp[k * 3 + 1], z = kp[k * 3 + 2];
+    float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+    if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k; }
+    else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = k; }
+    else if (d < b3) { b3 = d; i3 = k; }
+  }
+  dist2[(int64_t)i * 3 + 0] = (float)b1; dist2[(int64_t)i * 3 + 1] = (float)b2; dist2[(int64_t)i * 3 + 2] = (float)b3;
+  idx[(int64_t)i * 3 + 0] = i1 + start; idx[(int64_t)i * 3 + 1] = i2 + start; idx[(int64_t)i * 3 + 2] = i3 + start;
+}
+
+__global__ __launch_bounds__(256) void three_interp_kernel(int N, int C, const float* __restrict__ feat,
+                                                           const int* __restrict__ idx, const float* __restrict__ w,
+                                                           float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)N * C) return;
+  const int i = (int)(t / C), c = (int)(t - (int64_t)i * C);
+  const int* id = idx + (int64_t)i * 3;
+  const float* ww = w + (int64_t)i * 3;
+  out[t] = ww[0] * feat[(int64_t)id[0] * C + c] + ww[1] * feat[(int64_t)id[1] * C + c] +
+           ww[2] * feat[(int64_t)id[2] * C + c];
+}
+
+__global__ __launch_bounds__(256) void three_interp_grad_kernel(int N, int C, const float* __restrict__ grad_out,
+                                                                const int* __restrict__ idx, const float* __restrict__ w,
+                                                                float* __restrict__ grad_feat) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)N * C) return;
+  const int i = (int)(t / C), c = (int)(t - (int64_t)i * C);
+  const int* id = idx + (int64_t)i * 3;
+  const float* ww = w + (int64_t)i * 3;
+  const float g = grad_out[t];
+  atomicAdd(&grad_feat[(int64_t)id[0] * C + c], g * ww[0]);
+  atomicAdd(&grad_feat[(int64_t)id[1] * C + c], g * ww[1]);
+  atomicAdd(&grad_feat[(int64_t)id[2] * C + c], g * ww[2]);
+}
+
+template <int PPT>
+void launch_fps(int B, int n, int m, int log2bs, const float* xyz, int* out, hipStream_t st) {
+  hipLaunchKernelGGL((fps_kernel<PPT>), dim3(B), dim3(FPS_THREADS), 0, st, n, m, log2bs, xyz, out);
+}
+
+}  // namespace
+
+extern "C" int crb_ball_query_stack(int B, int64_t M, float radius, int nsample, const float* new_xyz,
+                                    const int32_t* new_xyz_batch_cnt, const float* xyz, const int32_t* xyz_batch_cnt,
+                                    int32_t* idx, void* stream) {
+  if (B <= 0 || M < 0 || nsample <= 0) return CRB_ERR_ARG;
+  if (M == 0) return CRB_OK;
+  hipLaunchKernelGGL(ball_query_kernel, dim3(crb_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, B, (int)M, radius,
+                     nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_group_points_stack(int B, int64_t M, int C, int nsample, const float* features,
+                                      const int32_t* features_batch_cnt, const int32_t* idx,
+                                      const int32_t* idx_batch_cnt, float* out, void* stream) {
+  if (B <= 0 || M < 0 || C <= 0 || nsample <= 0) return CRB_ERR_ARG;
+  if (M == 0) return CRB_OK;
+  size_t lds = sizeof(float) * (size_t)nsample * (C + 1);
+  if (lds > 64 * 1024) return CRB_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(group_points_kernel, dim3((unsigned)M), dim3(256), lds, (hipStream_t)stream, B, (int)M, C, nsample,
+                     features, features_batch_cnt, idx, idx_batch_cnt, out);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_group_points_grad_stack(int B, int64_t M, int C, int nsample, const float* grad_out,
+                                           const int32_t* idx, const int32_t* idx_batch_cnt,
+                                           const int32_t* features_batch_cnt, float* grad_features /* pre-zeroed */,
+                                           void* stream) {
+  if (B <= 0 || M < 0 || C <= 0 || nsample <= 0) return CRB_ERR_ARG;
+  if (M == 0) return CRB_OK;
+  size_t lds = sizeof(float) * (size_t)nsample * (C + 1);
+  if (lds > 64 * 1024) return CRB_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(group_points_grad_kernel, dim3((unsigned)M), dim3(256), lds, (hipStream_t)stream, B, (int)M, C,
+                     nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_farthest_point_sample(int B, int n, int m, const float* xyz, int32_t* out_idx, void* stream) {
+  if (B <= 0 || n <= 0 || m < 0) return CRB_ERR_ARG;
+  if (m == 0) return CRB_OK;
+  if (n > FPS_THREADS * FPS_MAX_PER_THREAD || n >= (1 << 20)) return CRB_ERR_UNSUPPORTED;
+  int log2bs = 0;
+  while ((2 << log2bs) <= n && log2bs < 10) ++log2bs;       // bs = min(2^floor(log2 n), 1024)
+  hipStream_t st = (hipStream_t)stream;
+  const int ppt = (n + FPS_THREADS - 1) / FPS_THREADS;
+  if (ppt <= 4) launch_fps<4>(B, n, m, log2bs, xyz, out_idx, st);
+  else if (ppt <= 8) launch_fps<8>(B, n, m, log2bs, xyz, out_idx, st);
+  else if (ppt <= 20) launch_fps<20>(B, n, m, log2bs, xyz, out_idx, st);
+  else launch_fps<40>(B, n, m, log2bs, xyz, out_idx, st);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_three_nn_stack(int B, int64_t N, const float* unknown, const int32_t* unknown_batch_cnt,
+                                  const float* known, const int32_t* known_batch_cnt, float* dist2, int32_t* idx,
+                                  void* stream) {
+  if (B <= 0 || N < 0) return CRB_ERR_ARG;
+  if (N == 0) return CRB_OK;
+  hipLaunchKernelGGL(three_nn_kernel, dim3(crb_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, B, (int)N, unknown,
+                     unknown_batch_cnt, known, known_batch_cnt, dist2, idx);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_three_interpolate_stack(int64_t N, int C, const float* features, const int32_t* idx,
+                                           const float* weight, float* out, void* stream) {
+  if (N < 0 || C <= 0) return CRB_ERR_ARG;
+  if (N == 0) return CRB_OK;
+  hipLaunchKernelGGL(three_interp_kernel, dim3(crb_cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, (int)N, C,
+                     features, idx, weight, out);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_three_interpolate_grad_stack(int64_t N, int C, const float* grad_out, const int32_t* idx,
+                                                const float* weight, float* grad_features /* pre-zeroed */,
+                                                void* stream) {
+  if (N < 0 || C <= 0) return CRB_ERR_ARG;
+  if (N == 0) return CRB_OK;
+  hipLaunchKernelGGL(three_interp_grad_kernel, dim3(crb_cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, (int)N, C,
+                     grad_out, idx, weight, grad_features);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}

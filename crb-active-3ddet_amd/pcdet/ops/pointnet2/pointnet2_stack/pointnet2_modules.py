@@ -1,0 +1,64 @@
+"""StackSAModuleMSG / build_local_aggregation_module (pointnet2_modules.py:10-112): multi-scale set abstraction on
+stacked batches: ball query + grouping (HIP) -> shared 1x1 MLP (+BN+ReLU) -> max over the neighbourhood."""
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import pointnet2_utils
+
+
+def build_local_aggregation_module(input_channels, config):
+    name = config.get('NAME', 'StackSAModuleMSG')
+    if name != 'StackSAModuleMSG':
+        raise NotImplementedError(name + ' (VectorPool is PV-RCNN++ only: out of scope, SURVEY §2.1 row 4)')
+    mlps = [[input_channels] + list(m) for m in config.MLPS]
+    layer = StackSAModuleMSG(radii=config.POOL_RADIUS, nsamples=config.NSAMPLE, mlps=mlps, use_xyz=True,
+                             pool_method='max_pool')
+    return layer, sum(m[-1] for m in mlps)
+
+
+class StackSAModuleMSG(nn.Module):
+    def __init__(self, *, radii: List[float], nsamples: List[int], mlps: List[List[int]], use_xyz: bool = True,
+                 pool_method='max_pool'):
+        super().__init__()
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        for radius, nsample, spec in zip(radii, nsamples, mlps):
+            self.groupers.append(pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz))
+            spec = list(spec)
+            if use_xyz:
+                spec[0] += 3
+            layers = []
+            for c_in, c_out in zip(spec[:-1], spec[1:]):
+                layers += [nn.Conv2d(c_in, c_out, kernel_size=1, bias=False), nn.BatchNorm2d(c_out), nn.ReLU()]
+            self.mlps.append(nn.Sequential(*layers))
+        self.pool_method = pool_method
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            if isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1.0)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None, empty_voxel_set_zeros=True):
+        """xyz (N,3), features (N,C), new_xyz (M,3) -> new_xyz, new_features (M, sum C_out)"""
+        outs = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            grouped, _ = grouper(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features)     # (M, C, ns)
+            x = mlp(grouped.permute(1, 0, 2).unsqueeze(0))                                      # (1, C', M, ns)
+            if self.pool_method == 'max_pool':
+                x = F.max_pool2d(x, kernel_size=[1, x.size(3)]).squeeze(-1)
+            elif self.pool_method == 'avg_pool':
+                x = F.avg_pool2d(x, kernel_size=[1, x.size(3)]).squeeze(-1)
+            else:
+                raise NotImplementedError
+            outs.append(x.squeeze(0).permute(1, 0))
+        return new_xyz, torch.cat(outs, dim=1)

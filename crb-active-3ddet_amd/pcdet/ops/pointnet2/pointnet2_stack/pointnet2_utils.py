@@ -1,0 +1,171 @@
+"""pcdet.ops.pointnet2.pointnet2_stack.pointnet2_utils (reference: pointnet2_utils.py:8-299) over csrc/pointnet2_stack.hip.
+Same callables: ball_query, grouping_operation, QueryAndGroup, farthest_point_sample, stack_farthest_point_sample,
+three_nn, three_interpolate."""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from crbhip import lib, check, ptr, cur_stream, require_cuda
+
+
+def _i32(t):
+    return t.to(torch.int32).contiguous()
+
+
+class BallQuery(Function):
+    @staticmethod
+    def forward(ctx, radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt):
+        """xyz (N,3), xyz_batch_cnt (B), new_xyz (M,3), new_xyz_batch_cnt (B) -> idx (M,nsample) int32, empty (M) bool"""
+        require_cuda(xyz, new_xyz)
+        assert new_xyz.is_contiguous() and xyz.is_contiguous()
+        B, M = xyz_batch_cnt.shape[0], new_xyz.shape[0]
+        idx = torch.empty((M, nsample), dtype=torch.int32, device=xyz.device)
+        check(lib.crb_ball_query_stack(B, M, float(radius), int(nsample), ptr(new_xyz), ptr(_i32(new_xyz_batch_cnt)),
+                                       ptr(xyz), ptr(_i32(xyz_batch_cnt)), ptr(idx), cur_stream(xyz.device)),
+              'crb_ball_query_stack')
+        empty_ball_mask = (idx[:, 0] == -1)
+        idx = torch.where(empty_ball_mask[:, None], torch.zeros_like(idx), idx)
+        ctx.mark_non_differentiable(idx, empty_ball_mask)
+        return idx, empty_ball_mask
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None, None, None, None, None
+
+
+ball_query = BallQuery.apply
+
+
+class GroupingOperation(Function):
+    @staticmethod
+    def forward(ctx, features, features_batch_cnt, idx, idx_batch_cnt):
+        """features (N,C), idx (M,nsample) -> (M,C,nsample)"""
+        require_cuda(features, idx)
+        assert features.is_contiguous() and idx.is_contiguous()
+        M, nsample = idx.shape
+        N, C = features.shape
+        B = idx_batch_cnt.shape[0]
+        fcnt, icnt = _i32(features_batch_cnt), _i32(idx_batch_cnt)
+        out = torch.empty((M, C, nsample), dtype=torch.float32, device=features.device)
+        check(lib.crb_group_points_stack(B, M, C, nsample, ptr(features), ptr(fcnt), ptr(idx), ptr(icnt), ptr(out),
+                                         cur_stream(features.device)), 'crb_group_points_stack')
+        ctx.for_backwards = (B, N, idx, fcnt, icnt)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        B, N, idx, fcnt, icnt = ctx.for_backwards
+        M, C, nsample = grad_out.shape
+        g = grad_out.contiguous().float()
+        grad_features = torch.zeros((N, C), dtype=torch.float32, device=g.device)
+        check(lib.crb_group_points_grad_stack(B, M, C, nsample, ptr(g), ptr(idx), ptr(icnt), ptr(fcnt),
+                                              ptr(grad_features), cur_stream(g.device)), 'crb_group_points_grad_stack')
+        return grad_features, None, None, None
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class QueryAndGroup(nn.Module):
+    def __init__(self, radius: float, nsample: int, use_xyz: bool = True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None):
+        """-> new_features (M, 3+C, nsample), idx (M, nsample)   (pointnet2_utils.py:107-155)"""
+        idx, empty = ball_query(self.radius, self.nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+        grouped_xyz = grouping_operation(xyz, xyz_batch_cnt, idx, new_xyz_batch_cnt) - new_xyz.unsqueeze(-1)
+        keep = (~empty).view(-1, 1, 1).to(grouped_xyz.dtype)
+        grouped_xyz = grouped_xyz * keep
+        if features is not None:
+            grouped_features = grouping_operation(features, xyz_batch_cnt, idx, new_xyz_batch_cnt) * keep
+            new_features = torch.cat([grouped_xyz, grouped_features], dim=1) if self.use_xyz else grouped_features
+        else:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            new_features = grouped_xyz
+        return new_features, idx
+
+
+class FarthestPointSampling(Function):
+    @staticmethod
+    def forward(ctx, xyz, npoint):
+        """xyz (B,N,3) -> (B,npoint) int32"""
+        require_cuda(xyz)
+        assert xyz.is_contiguous()
+        B, N, _ = xyz.shape
+        out = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+        check(lib.crb_farthest_point_sample(B, N, int(npoint), ptr(xyz), ptr(out), cur_stream(xyz.device)),
+              'crb_farthest_point_sample')
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None
+
+
+farthest_point_sample = furthest_point_sample = FarthestPointSampling.apply
+
+
+def stack_farthest_point_sample(xyz, xyz_batch_cnt, npoint):
+    """stacked xyz (N,3) with per-frame counts -> concatenated LOCAL indices (sum npoint) (pointnet2_utils.py:187-221).
+    Frames are sampled one launch each (frames of different length cannot share the register-resident kernel)."""
+    B = len(xyz_batch_cnt)
+    cnt = [int(v) for v in xyz_batch_cnt.tolist()]
+    if not isinstance(npoint, (list, tuple, torch.Tensor)):
+        npoint = [npoint] * B
+    npoint = [int(v) for v in (npoint.tolist() if isinstance(npoint, torch.Tensor) else npoint)]
+    outs, s = [], 0
+    for b in range(B):
+        outs.append(farthest_point_sample(xyz[s:s + cnt[b]].unsqueeze(0).contiguous(), npoint[b]).view(-1))
+        s += cnt[b]
+    return torch.cat(outs)
+
+
+class ThreeNN(Function):
+    @staticmethod
+    def forward(ctx, unknown, unknown_batch_cnt, known, known_batch_cnt):
+        require_cuda(unknown, known)
+        assert unknown.dim() == 2 and unknown.shape[1] == 3 and known.dim() == 2 and known.shape[1] == 3
+        N = unknown.shape[0]
+        dist2 = torch.empty((N, 3), dtype=torch.float32, device=unknown.device)
+        idx = torch.empty((N, 3), dtype=torch.int32, device=unknown.device)
+        check(lib.crb_three_nn_stack(len(unknown_batch_cnt), N, ptr(unknown.contiguous()), ptr(_i32(unknown_batch_cnt)),
+                                     ptr(known.contiguous()), ptr(_i32(known_batch_cnt)), ptr(dist2), ptr(idx),
+                                     cur_stream(unknown.device)), 'crb_three_nn_stack')
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None, None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    @staticmethod
+    def forward(ctx, features, idx, weight):
+        """features (M,C), idx (N,3), weight (N,3) -> (N,C)"""
+        require_cuda(features, idx, weight)
+        assert idx.shape[0] == weight.shape[0] and idx.shape[1] == weight.shape[1] == 3
+        f, i, w = features.contiguous().float(), idx.contiguous(), weight.contiguous().float()
+        ctx.three_interpolate_for_backward = (i, w, f.shape[0])
+        out = torch.empty((i.shape[0], f.shape[1]), dtype=torch.float32, device=f.device)
+        check(lib.crb_three_interpolate_stack(i.shape[0], f.shape[1], ptr(f), ptr(i), ptr(w), ptr(out),
+                                              cur_stream(f.device)), 'crb_three_interpolate_stack')
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight, M = ctx.three_interpolate_for_backward
+        g = grad_out.contiguous().float()
+        grad_features = torch.zeros((M, g.shape[1]), dtype=torch.float32, device=g.device)
+        check(lib.crb_three_interpolate_grad_stack(g.shape[0], g.shape[1], ptr(g), ptr(idx), ptr(weight),
+                                                   ptr(grad_features), cur_stream(g.device)),
+              'crb_three_interpolate_grad_stack')
+        return grad_features, None, None
+
+
+three_interpolate = ThreeInterpolate.apply

@@ -128,6 +128,52 @@ int crb_nms_batched(const float* boxes_sorted, const int32_t* counts, int B, int
                     int rotated, int max_keep, int32_t* keep, int32_t* num_keep, void* workspace,
                     int64_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * a16-a18  PointNet++ stack ops
+ * replaces: the pybind surface of pcdet/ops/pointnet2/pointnet2_stack/src/pointnet2_api.cpp:12-31
+ *   ball_query_wrapper (ball_query.cpp:31-47), group_points_wrapper / group_points_grad_wrapper
+ *   (group_points.cpp), farthest_point_sampling_wrapper (sampling.cpp), three_nn_wrapper,
+ *   three_interpolate_wrapper / three_interpolate_grad_wrapper (interpolate.cpp).
+ * Stacked layout: xyz (N1+N2+..,3) f32 + *_batch_cnt (B) i32 on the device; idx int32.
+ * ball query: idx (M,nsample): hits in scan order, padded with the first hit; empty ball: idx[m][0] = -1, rest 0.
+ * grad kernels accumulate with atomics into PRE-ZEROED outputs.
+ * ---------------------------------------------------------------------------------------------- */
+int crb_ball_query_stack(int B, int64_t M, float radius, int nsample, const float* new_xyz,
+                         const int32_t* new_xyz_batch_cnt, const float* xyz, const int32_t* xyz_batch_cnt,
+                         int32_t* idx, void* stream);
+int crb_group_points_stack(int B, int64_t M, int C, int nsample, const float* features,
+                           const int32_t* features_batch_cnt, const int32_t* idx,
+                           const int32_t* idx_batch_cnt, float* out, void* stream);
+int crb_group_points_grad_stack(int B, int64_t M, int C, int nsample, const float* grad_out,
+                                const int32_t* idx, const int32_t* idx_batch_cnt,
+                                const int32_t* features_batch_cnt, float* grad_features, void* stream);
+/* xyz (B,n,3) -> out_idx (B,m); first pick is index 0; ties resolved like the reference kernel (see source) */
+int crb_farthest_point_sample(int B, int n, int m, const float* xyz, int32_t* out_idx, void* stream);
+int crb_three_nn_stack(int B, int64_t N, const float* unknown, const int32_t* unknown_batch_cnt,
+                       const float* known, const int32_t* known_batch_cnt, float* dist2, int32_t* idx,
+                       void* stream);
+int crb_three_interpolate_stack(int64_t N, int C, const float* features, const int32_t* idx,
+                                const float* weight, float* out, void* stream);
+int crb_three_interpolate_grad_stack(int64_t N, int C, const float* grad_out, const int32_t* idx,
+                                     const float* weight, float* grad_features, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a15  points-in-boxes and RoI-aware pooling
+ * replaces: pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:172-177 (points_in_boxes_gpu :94-119, forward :46-70,
+ *           backward :72-92).  boxes (B,T,7), pts (B,M,3) -> box_idx_of_points (B,M) i32, -1 = background.
+ * pool: rois (N,7), pts (P,3), pts_feature (P,C); pts_idx_of_voxels (N,ox,oy,oz,max_pts) i32 and pooled_features
+ * (N,ox,oy,oz,C) must be zero-filled by the caller; argmax (N,ox,oy,oz,C) i32. pool_method 0 = max, 1 = avg.
+ * ---------------------------------------------------------------------------------------------- */
+int crb_points_in_boxes(int B, int T, int M, const float* boxes, const float* pts, int32_t* box_idx_of_points,
+                        void* stream);
+int crb_roiaware_pool3d_forward(int N, int P, int C, int max_pts_each_voxel, int out_x, int out_y, int out_z,
+                                const float* rois, const float* pts, const float* pts_feature,
+                                int32_t* argmax, int32_t* pts_idx_of_voxels, float* pooled_features,
+                                int pool_method, void* stream);
+int crb_roiaware_pool3d_backward(int N, int C, int max_pts_each_voxel, int out_x, int out_y, int out_z,
+                                 const int32_t* pts_idx_of_voxels, const int32_t* argmax,
+                                 const float* grad_out, float* grad_in, int pool_method, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
