@@ -209,3 +209,95 @@ def ref_boxes_iou_bev(boxes_a, boxes_b):
     out = np.zeros((len(a), len(b)), np.float32)
     L.ref_boxes_iou_bev_cpu(_p(a), ctypes.c_int(len(a)), _p(b), ctypes.c_int(len(b)), _p(out))
     return out
+
+
+# ------------------------------------------------------------------ PointNet++ stack ops, points-in-boxes, RoI-aware pool
+def _ci(v):
+    return ctypes.c_int(int(v))
+
+
+def ball_query(radius, nsample, xyz, xyz_cnt, new_xyz, new_cnt):
+    """-> idx (M,nsample) as written by the kernel (empty ball: [-1,0,0,..])"""
+    L = _lib()
+    xyz, new_xyz, xyz_cnt, new_cnt = _f32(xyz), _f32(new_xyz), _i32(xyz_cnt), _i32(new_cnt)
+    idx = np.zeros((len(new_xyz), nsample), np.int32)
+    L.oracle_ball_query(_ci(len(xyz_cnt)), _ci(len(new_xyz)), ctypes.c_float(radius), _ci(nsample), _p(new_xyz),
+                        _p(new_cnt), _p(xyz), _p(xyz_cnt), _p(idx))
+    return idx
+
+
+def group_points(feat, feat_cnt, idx, idx_cnt):
+    L = _lib()
+    feat, idx, feat_cnt, idx_cnt = _f32(feat), _i32(idx), _i32(feat_cnt), _i32(idx_cnt)
+    M, ns = idx.shape
+    C = feat.shape[1]
+    out = np.empty((M, C, ns), np.float32)
+    L.oracle_group_points(_ci(len(idx_cnt)), _ci(M), _ci(C), _ci(ns), _p(feat), _p(feat_cnt), _p(idx), _p(idx_cnt), _p(out))
+    return out
+
+
+def group_points_grad(grad_out, idx, idx_cnt, feat_cnt, N):
+    L = _lib()
+    g, idx, feat_cnt, idx_cnt = _f32(grad_out), _i32(idx), _i32(feat_cnt), _i32(idx_cnt)
+    M, C, ns = g.shape
+    out = np.empty((N, C), np.float32)
+    L.oracle_group_points_grad(_ci(len(idx_cnt)), _ci(M), _ci(C), _ci(N), _ci(ns), _p(g), _p(idx), _p(idx_cnt),
+                               _p(feat_cnt), _p(out))
+    return out
+
+
+def fps(xyz, m):
+    """xyz (B,n,3) -> (B,m) int32"""
+    L = _lib()
+    xyz = _f32(xyz)
+    B, n, _ = xyz.shape
+    out = np.zeros((B, m), np.int32)
+    L.oracle_fps(_ci(B), _ci(n), _ci(m), _p(xyz), _p(out))
+    return out
+
+
+def three_nn(unknown, unknown_cnt, known, known_cnt):
+    L = _lib()
+    u, k, uc, kc = _f32(unknown), _f32(known), _i32(unknown_cnt), _i32(known_cnt)
+    d2 = np.empty((len(u), 3), np.float32)
+    idx = np.empty((len(u), 3), np.int32)
+    L.oracle_three_nn(_ci(len(uc)), _ci(len(u)), _p(u), _p(uc), _p(k), _p(kc), _p(d2), _p(idx))
+    return d2, idx
+
+
+def three_interpolate(feat, idx, w):
+    L = _lib()
+    f, i, w = _f32(feat), _i32(idx), _f32(w)
+    out = np.empty((len(i), f.shape[1]), np.float32)
+    L.oracle_three_interpolate(_ci(len(i)), _ci(f.shape[1]), _p(f), _p(i), _p(w), _p(out))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, w, M):
+    L = _lib()
+    g, i, w = _f32(grad_out), _i32(idx), _f32(w)
+    out = np.empty((M, g.shape[1]), np.float32)
+    L.oracle_three_interpolate_grad(_ci(len(i)), _ci(g.shape[1]), _ci(M), _p(g), _p(i), _p(w), _p(out))
+    return out
+
+
+def points_in_boxes(points, boxes):
+    """points (B,M,3), boxes (B,T,7) -> (B,M) int32"""
+    L = _lib()
+    p, b = _f32(points), _f32(boxes)
+    out = np.empty(p.shape[:2], np.int32)
+    L.oracle_points_in_boxes(_ci(p.shape[0]), _ci(b.shape[1]), _ci(p.shape[1]), _p(b), _p(p), _p(out))
+    return out
+
+
+def roiaware_pool(rois, pts, feat, out_size, max_pts, method):
+    L = _lib()
+    r, p, f = _f32(rois), _f32(pts), _f32(feat)
+    ox, oy, oz = out_size
+    N, C = len(r), f.shape[1]
+    argmax = np.empty((N, ox, oy, oz, C), np.int32)
+    pts_idx = np.empty((N, ox, oy, oz, max_pts), np.int32)
+    pooled = np.empty((N, ox, oy, oz, C), np.float32)
+    L.oracle_roiaware_pool(_ci(N), _ci(len(p)), _ci(C), _ci(max_pts), _ci(ox), _ci(oy), _ci(oz), _p(r), _p(p), _p(f),
+                           _p(argmax), _p(pts_idx), _p(pooled), _ci(method))
+    return pooled, argmax, pts_idx

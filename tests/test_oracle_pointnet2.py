@@ -1,0 +1,73 @@
+"""CPU: sanity pins for oracle/pointnet2_oracle.c with independent numpy formulations (the reference has no tests for
+these kernels: parity is otherwise unpinned, see the oracle header)."""
+import numpy as np
+
+import oracle
+from boxes_synth import detection_boxes
+
+
+def test_ball_query_vs_numpy_bruteforce():
+    rng = np.random.default_rng(0)
+    xyz = rng.uniform(-5, 5, (700, 3)).astype(np.float32)
+    new = rng.uniform(-5, 5, (90, 3)).astype(np.float32)
+    xc, nc = np.array([300, 400], np.int32), np.array([40, 50], np.int32)
+    idx = oracle.ball_query(1.2, 16, xyz, xc, new, nc)
+    for q in range(90):
+        b = 0 if q < 40 else 1
+        s = 0 if b == 0 else 300
+        p = xyz[s:s + xc[b]]
+        d2 = ((new[q, 0] - p[:, 0]) * (new[q, 0] - p[:, 0]) + (new[q, 1] - p[:, 1]) * (new[q, 1] - p[:, 1]) +
+              (new[q, 2] - p[:, 2]) * (new[q, 2] - p[:, 2]))
+        hits = np.nonzero(d2 < np.float32(1.2) * np.float32(1.2))[0][:16]
+        if len(hits) == 0:
+            assert idx[q, 0] == -1 and (idx[q, 1:] == 0).all()
+        else:
+            exp = np.full(16, hits[0])
+            exp[:len(hits)] = hits
+            np.testing.assert_array_equal(idx[q], exp)
+
+
+def test_fps_matches_simple_definition_when_no_ties():
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(2, 1500, 3)).astype(np.float32)
+    out = oracle.fps(x, 64)
+    for b in range(2):
+        d = np.full(1500, 1e10, np.float32)
+        cur, exp = 0, [0]
+        for _ in range(63):
+            diff = x[b] - x[b, cur]
+            dd = diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1] + diff[:, 2] * diff[:, 2]
+            d = np.minimum(d, dd)
+            cur = int(np.argmax(d))
+            exp.append(cur)
+        np.testing.assert_array_equal(out[b], exp)
+
+
+def test_points_in_boxes_vs_numpy():
+    rng = np.random.default_rng(2)
+    boxes, _ = detection_boxes(rng, 60)
+    pts = (boxes[rng.integers(0, 60, 4000), :3] + rng.normal(0, 1.0, (4000, 3))).astype(np.float32)
+    got = oracle.points_in_boxes(pts[None], boxes[None])[0]
+    c, s = np.cos(-boxes[:, 6].astype(np.float64)), np.sin(-boxes[:, 6].astype(np.float64))
+    sx = pts[:, None, 0].astype(np.float64) - boxes[None, :, 0]
+    sy = pts[:, None, 1].astype(np.float64) - boxes[None, :, 1]
+    lx, ly = sx * c - sy * s, sx * s + sy * c
+    inside = (np.abs(pts[:, None, 2] - boxes[None, :, 2]) <= boxes[None, :, 5] / 2) & \
+             (np.abs(lx) < boxes[None, :, 3] / 2 + 1e-5) & (np.abs(ly) < boxes[None, :, 4] / 2 + 1e-5)
+    exp = np.where(inside.any(1), inside.argmax(1), -1)
+    # float vs double rotation can differ for points within ~1e-5 of a face: allow a handful
+    assert (got != exp).sum() <= 3
+    assert (got >= 0).sum() > 500
+
+
+def test_group_and_interpolate_roundtrip():
+    rng = np.random.default_rng(3)
+    feat = rng.normal(size=(50, 6)).astype(np.float32)
+    idx = rng.integers(0, 25, (30, 4)).astype(np.int32)
+    out = oracle.group_points(feat, [25, 25], idx, [10, 20])
+    assert out.shape == (30, 6, 4)
+    np.testing.assert_array_equal(out[12, :, 2], feat[25 + idx[12, 2]])
+    g = oracle.group_points_grad(np.ones_like(out), idx, [10, 20], [25, 25], 50)
+    assert abs(g.sum() - out.size) < 1e-3
+    d2, nn = oracle.three_nn(feat[:, :3], [25, 25], feat[:, 3:], [25, 25])
+    assert (nn[:25] < 25).all() and (nn[25:] >= 25).all() and (np.diff(d2, axis=1) >= 0).all()

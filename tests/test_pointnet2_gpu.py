@@ -1,0 +1,142 @@
+"""GPU parity: PointNet++ stack ops, points-in-boxes, RoI-aware pool (HIP through the C-ABI / pcdet.ops mirrors) vs the
+oracle. Index outputs bit-exact; gathered features bit-exact; atomically accumulated gradients within 1e-5 relative."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from boxes_synth import detection_boxes
+from synth import kitti_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_ball_query_and_grouping(dev):
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as U
+    pts, off, _ = kitti_batch(0, 3, n_points=6000)
+    xyz = np.ascontiguousarray(pts[:, :3])
+    xc = np.diff(off).astype(np.int32)
+    rng = np.random.default_rng(0)
+    new = np.concatenate([xyz[off[b]:off[b + 1]][rng.choice(6000, 500, replace=False)] for b in range(3)])
+    new[::17] += 50.0                       # some empty balls
+    nc = np.array([500, 500, 500], np.int32)
+    feat = rng.normal(size=(len(xyz), 19)).astype(np.float32)
+    for radius, ns in ((0.4, 16), (0.8, 32), (4.8, 16)):
+        idx, empty = U.ball_query(radius, ns, _t(xyz, dev), _t(xc, dev), _t(new, dev), _t(nc, dev))
+        ref = oracle.ball_query(radius, ns, xyz, xc, new, nc)
+        ref_empty = ref[:, 0] == -1
+        ref[ref_empty] = 0
+        np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+        np.testing.assert_array_equal(empty.cpu().numpy(), ref_empty)
+        assert ref_empty.sum() >= 80
+        f = _t(feat, dev).requires_grad_(True)
+        g = U.grouping_operation(f, _t(xc, dev), idx, _t(nc, dev))
+        np.testing.assert_array_equal(g.detach().cpu().numpy(), oracle.group_points(feat, xc, ref, nc))
+        go = rng.normal(size=tuple(g.shape)).astype(np.float32)
+        g.backward(_t(go, dev))
+        np.testing.assert_allclose(f.grad.cpu().numpy(), oracle.group_points_grad(go, ref, nc, xc, len(xyz)),
+                                   rtol=1e-5, atol=1e-5)
+    qg = U.QueryAndGroup(0.8, 16, use_xyz=True)
+    nf, idx = qg(_t(xyz, dev), _t(xc, dev), _t(new, dev), _t(nc, dev), _t(feat, dev))
+    assert nf.shape == (1500, 22, 16)
+    assert float(nf[::17].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('n,m', [(20000, 2048), (4096, 512), (1000, 100), (777, 64), (37, 10)])
+def test_fps(dev, n, m):
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as U
+    pts, off, _ = kitti_batch(5, 2, n_points=n)
+    xyz = np.ascontiguousarray(pts[:, :3].reshape(2, n, 3))
+    out = U.farthest_point_sample(_t(xyz, dev), m)
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle.fps(xyz, m))
+
+
+def test_fps_tie_rule_with_duplicate_points(dev):
+    """duplicated points create exact distance ties: the HIP kernel must resolve them like the reference's LDS tree"""
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as U
+    rng = np.random.default_rng(4)
+    base = rng.normal(size=(300, 3)).astype(np.float32)
+    xyz = np.concatenate([base, base, base[:150]])[rng.permutation(750)][None]
+    out = U.farthest_point_sample(_t(xyz, dev), 200)
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle.fps(xyz, 200))
+    xyz2 = np.concatenate([base] * 8)[None]          # n = 2400 > 1024 threads, every point 8 times
+    out2 = U.farthest_point_sample(_t(xyz2, dev), 64)
+    np.testing.assert_array_equal(out2.cpu().numpy(), oracle.fps(xyz2, 64))
+
+
+def test_three_nn_and_interpolate(dev):
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as U
+    rng = np.random.default_rng(6)
+    unknown = rng.uniform(-10, 10, (3000, 3)).astype(np.float32)
+    known = rng.uniform(-10, 10, (700, 3)).astype(np.float32)
+    uc, kc = np.array([1000, 2000], np.int32), np.array([300, 400], np.int32)
+    dist, idx = U.three_nn(_t(unknown, dev), _t(uc, dev), _t(known, dev), _t(kc, dev))
+    d2, ridx = oracle.three_nn(unknown, uc, known, kc)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    np.testing.assert_allclose(dist.cpu().numpy(), np.sqrt(d2), rtol=1e-6)
+    feat = rng.normal(size=(700, 33)).astype(np.float32)
+    w = rng.uniform(0, 1, (3000, 3)).astype(np.float32)
+    f = _t(feat, dev).requires_grad_(True)
+    out = U.three_interpolate(f, idx, _t(w, dev))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), oracle.three_interpolate(feat, ridx, w), rtol=1e-6, atol=1e-6)
+    go = rng.normal(size=(3000, 33)).astype(np.float32)
+    out.backward(_t(go, dev))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), oracle.three_interpolate_grad(go, ridx, w, 700), rtol=1e-4,
+                               atol=1e-4)
+
+
+def test_points_in_boxes(dev):
+    from pcdet.ops.roiaware_pool3d import roiaware_pool3d_utils as R
+    pts, off, gt = kitti_batch(3, 4)
+    xyz = np.ascontiguousarray(pts[:, :3].reshape(4, 20000, 3))
+    rng = np.random.default_rng(1)
+    boxes = np.stack([np.concatenate([gt[b, :, :7], detection_boxes(rng, 300)[0]]) for b in range(4)])
+    got = R.points_in_boxes_gpu(_t(xyz, dev), _t(boxes, dev)).cpu().numpy()
+    ref = oracle.points_in_boxes(xyz, boxes)
+    np.testing.assert_array_equal(got, ref)
+    assert (ref >= 0).sum() > 1000 and (ref == -1).sum() > 1000
+    m = R.points_in_boxes_cpu(xyz[0, :500], boxes[0, :20])
+    assert m.shape == (20, 500)
+    # empty box list
+    e = R.points_in_boxes_gpu(_t(xyz[:1], dev), torch.zeros((1, 0, 7), device=dev))
+    assert (e == -1).all()
+
+
+@pytest.mark.parametrize('method', ['max', 'avg'])
+def test_roiaware_pool(dev, method):
+    from pcdet.ops.roiaware_pool3d import roiaware_pool3d_utils as R
+    pts, off, gt = kitti_batch(9, 1)
+    xyz = np.ascontiguousarray(pts[:, :3])
+    rng = np.random.default_rng(2)
+    rois = gt[0, :, :7].copy()
+    rois[:, 3:6] *= 1.5
+    feat = rng.normal(size=(len(xyz), 16)).astype(np.float32)
+    pool = R.RoIAwarePool3d(out_size=6, max_pts_each_voxel=8)       # small cap: exercises "first max_pts-1 in order"
+    f = _t(feat, dev).requires_grad_(True)
+    out = pool(_t(rois, dev), _t(xyz, dev), f, pool_method=method)
+    ref, argmax, pidx = oracle.roiaware_pool(rois, xyz, feat, (6, 6, 6), 8, 0 if method == 'max' else 1)
+    if method == 'max':
+        np.testing.assert_array_equal(out.detach().cpu().numpy(), ref)
+    else:
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+    assert (pidx[..., 0] == 7).any() and (pidx[..., 0] > 0).sum() > 50
+    go = rng.normal(size=tuple(out.shape)).astype(np.float32)
+    out.backward(_t(go, dev))
+    g = np.zeros_like(feat, dtype=np.float64)
+    N = len(rois)
+    for bi in range(N):
+        for cell in range(216):
+            v = pidx[bi].reshape(216, 8)[cell]
+            for c in range(16):
+                if method == 'max':
+                    am = argmax[bi].reshape(216, 16)[cell, c]
+                    if am >= 0:
+                        g[am, c] += go[bi].reshape(216, 16)[cell, c]
+                else:
+                    for k in range(1, v[0] + 1):
+                        g[v[k], c] += go[bi].reshape(216, 16)[cell, c] / max(v[0], 1)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), g, rtol=1e-4, atol=1e-5)
