@@ -56,3 +56,68 @@ def second_cfg(kind='kitti'):
                          'WEIGHT_DECAY': 0.01, 'MOMENTUM': 0.9, 'MOMS': [0.95, 0.85], 'PCT_START': 0.4,
                          'DIV_FACTOR': 10, 'GRAD_NORM_CLIP': 10},
     })
+
+
+def pv_rcnn_cfg(kind='kitti'):
+    """values of tools/cfgs/active-kitti_models/pv_rcnn_active_crb.yaml"""
+    assert kind == 'kitti'
+    sa = lambda f, mlp, r, ns: {'DOWNSAMPLE_FACTOR': f, 'MLPS': [list(mlp), list(mlp)], 'POOL_RADIUS': list(r),
+                                'NSAMPLE': list(ns)}
+    return EasyDict({
+        'CLASS_NAMES': ['Car', 'Pedestrian', 'Cyclist'],
+        'DATA_CONFIG': {'DATASET': 'KittiDataset'},
+        'MODEL': {
+            'NAME': 'PVRCNN',
+            'VFE': {'NAME': 'MeanVFE'},
+            'BACKBONE_3D': {'NAME': 'VoxelBackBone8x'},
+            'MAP_TO_BEV': {'NAME': 'HeightCompression', 'NUM_BEV_FEATURES': 256},
+            'BACKBONE_2D': dict(_BEV),
+            'DENSE_HEAD': _dense_head(KITTI_ANCHORS),
+            'PFE': {
+                'NAME': 'VoxelSetAbstraction', 'POINT_SOURCE': 'raw_points', 'NUM_KEYPOINTS': 2048,
+                'NUM_OUTPUT_FEATURES': 128, 'SAMPLE_METHOD': 'FPS',
+                'FEATURES_SOURCE': ['bev', 'x_conv1', 'x_conv2', 'x_conv3', 'x_conv4', 'raw_points'],
+                'SA_LAYER': {
+                    'raw_points': {'MLPS': [[16, 16], [16, 16]], 'POOL_RADIUS': [0.4, 0.8], 'NSAMPLE': [16, 16]},
+                    'x_conv1': sa(1, (16, 16), (0.4, 0.8), (16, 16)),
+                    'x_conv2': sa(2, (32, 32), (0.8, 1.2), (16, 32)),
+                    'x_conv3': sa(4, (64, 64), (1.2, 2.4), (16, 32)),
+                    'x_conv4': sa(8, (64, 64), (2.4, 4.8), (16, 32)),
+                }},
+            'POINT_HEAD': {
+                'NAME': 'PointHeadSimple', 'CLS_FC': [256, 256], 'CLASS_AGNOSTIC': True,
+                'USE_POINT_FEATURES_BEFORE_FUSION': True, 'NUM_KEYPOINTS': 2048,
+                'TARGET_CONFIG': {'GT_EXTRA_WIDTH': [0.2, 0.2, 0.2]},
+                'LOSS_CONFIG': {'LOSS_REG': 'smooth-l1', 'LOSS_WEIGHTS': {'point_cls_weight': 1.0}}},
+            'ROI_HEAD': {
+                'NAME': 'PVRCNNHead', 'CLASS_AGNOSTIC': True, 'SAMPLING_ROUND': 5, 'SHARED_FC': [256, 256],
+                'CLS_FC': [256, 256], 'REG_FC': [256, 256], 'DP_RATIO': 0.3,
+                'NMS_CONFIG': {
+                    'TRAIN': {'NMS_TYPE': 'nms_gpu', 'MULTI_CLASSES_NMS': False, 'NMS_PRE_MAXSIZE': 9000,
+                              'NMS_POST_MAXSIZE': 512, 'NMS_THRESH': 0.8},
+                    'TEST': {'NMS_TYPE': 'nms_gpu', 'MULTI_CLASSES_NMS': False, 'NMS_PRE_MAXSIZE': 1024,
+                             'NMS_POST_MAXSIZE': 128, 'NMS_THRESH': 0.7}},
+                'ROI_GRID_POOL': {'GRID_SIZE': 6, 'MLPS': [[64, 64], [64, 64]], 'POOL_RADIUS': [0.8, 1.6],
+                                  'NSAMPLE': [16, 16], 'POOL_METHOD': 'max_pool'},
+                'TARGET_CONFIG': {'BOX_CODER': 'ResidualCoder', 'ROI_PER_IMAGE': 128, 'FG_RATIO': 0.5,
+                                  'SAMPLE_ROI_BY_EACH_CLASS': True, 'CLS_SCORE_TYPE': 'roi_iou', 'CLS_FG_THRESH': 0.75,
+                                  'CLS_BG_THRESH': 0.25, 'CLS_BG_THRESH_LO': 0.1, 'HARD_BG_RATIO': 0.8,
+                                  'REG_FG_THRESH': 0.55},
+                'LOSS_CONFIG': {'CLS_LOSS': 'BinaryCrossEntropy', 'REG_LOSS': 'smooth-l1',
+                                'CORNER_LOSS_REGULARIZATION': True,
+                                'LOSS_WEIGHTS': {'rcnn_cls_weight': 1.0, 'rcnn_reg_weight': 1.0,
+                                                 'rcnn_corner_weight': 1.0,
+                                                 'code_weights': [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]}}},
+            'POST_PROCESSING': {
+                'RECALL_THRESH_LIST': [0.3, 0.5, 0.7], 'SCORE_THRESH': 0.1, 'OUTPUT_RAW_SCORE': False,
+                'EVAL_METRIC': 'kitti',
+                'NMS_CONFIG': {'MULTI_CLASSES_NMS': False, 'NMS_TYPE': 'nms_gpu', 'NMS_THRESH': 0.1,
+                               'NMS_PRE_MAXSIZE': 4096, 'NMS_POST_MAXSIZE': 500}},
+        },
+        'OPTIMIZATION': {'OPTIMIZER': 'adam_onecycle', 'LR': 0.01, 'WEIGHT_DECAY': 0.01, 'MOMENTUM': 0.9,
+                         'MOMS': [0.95, 0.85], 'PCT_START': 0.4, 'DIV_FACTOR': 10, 'GRAD_NORM_CLIP': 10},
+        'ACTIVE_TRAIN': {'METHOD': 'crb', 'AGGREGATION': 'mean', 'PRE_TRAIN_SAMPLE_NUMS': 100,
+                         'PRE_TRAIN_EPOCH_NUMS': 40, 'TRAIN_RESUME': True, 'SELECT_NUMS': 100,
+                         'SELECT_LABEL_EPOCH_INTERVAL': 40, 'TOTAL_BUDGET_NUMS': 600,
+                         'ACTIVE_CONFIG': {'K1': 5, 'K2': 3, 'BANDWIDTH': 5, 'CLUSTERING': 'kmeans++'}},
+    })

@@ -1,0 +1,121 @@
+"""PVRCNNHead (pcdet/models/roi_heads/pvrcnn_head.py:9-242): RoI-grid pooling of keypoint features (HIP ball query +
+grouping), shared FC, class / box branches, MC-dropout passes in eval (SAMPLING_ROUND)."""
+import torch
+import torch.nn as nn
+
+from ...ops.pointnet2.pointnet2_stack import pointnet2_modules as pointnet2_stack_modules
+from ...utils import common_utils
+from .roi_head_template import RoIHeadTemplate
+
+
+class PVRCNNHead(RoIHeadTemplate):
+    def __init__(self, input_channels, model_cfg, num_class=1, **kwargs):
+        super().__init__(num_class=num_class, model_cfg=model_cfg)
+        self.model_cfg = model_cfg
+        self.roi_grid_pool_layer, num_c_out = pointnet2_stack_modules.build_local_aggregation_module(
+            input_channels=input_channels, config=self.model_cfg.ROI_GRID_POOL)
+        G = self.model_cfg.ROI_GRID_POOL.GRID_SIZE
+        pre = G * G * G * num_c_out
+        shared = []
+        n_fc = len(self.model_cfg.SHARED_FC)
+        for k, c in enumerate(self.model_cfg.SHARED_FC):
+            shared += [nn.Conv1d(pre, c, kernel_size=1, bias=False), nn.BatchNorm1d(c), nn.ReLU()]
+            pre = c
+            if k != n_fc - 1 and self.model_cfg.DP_RATIO > 0:
+                shared.append(nn.Dropout(self.model_cfg.DP_RATIO))
+        self.shared_fc_layer = nn.Sequential(*shared)
+        self.cls_layers = self.make_fc_layers(input_channels=pre, output_channels=self.num_class,
+                                              fc_list=self.model_cfg.CLS_FC)
+        self.reg_layers = self.make_fc_layers(input_channels=pre, output_channels=self.box_coder.code_size * self.num_class,
+                                              fc_list=self.model_cfg.REG_FC)
+        if model_cfg.get('LOSS_NET', None):
+            raise NotImplementedError('LossNet (LLAL baseline) is out of scope, SURVEY §2.1 row 11')
+        self.init_weights(weight_init='xavier')
+
+    def init_weights(self, weight_init='xavier'):
+        init = {'kaiming': nn.init.kaiming_normal_, 'xavier': nn.init.xavier_normal_, 'normal': nn.init.normal_}[weight_init]
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Conv1d)):
+                if weight_init == 'normal':
+                    init(m.weight, mean=0, std=0.001)
+                else:
+                    init(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        nn.init.normal_(self.reg_layers[-1].weight, mean=0, std=0.001)
+
+    def roi_grid_pool(self, batch_dict):
+        """rois (B,N,7), keypoints -> (B*N, G^3, C)"""
+        batch_size = batch_dict['batch_size']
+        rois = batch_dict['rois']
+        point_coords = batch_dict['point_coords']
+        point_features = batch_dict['point_features'] * batch_dict['point_cls_scores'].view(-1, 1)
+        G = self.model_cfg.ROI_GRID_POOL.GRID_SIZE
+        grid_pts, _ = self.get_global_grid_points_of_roi(rois, grid_size=G)
+        grid_pts = grid_pts.view(batch_size, -1, 3)
+        xyz = point_coords[:, 1:4]
+        xyz_batch_cnt = torch.bincount(point_coords[:, 0].long(), minlength=batch_size).int()
+        new_xyz = grid_pts.view(-1, 3)
+        new_xyz_batch_cnt = xyz_batch_cnt.new_full((batch_size,), grid_pts.shape[1])
+        _, pooled = self.roi_grid_pool_layer(xyz=xyz.contiguous(), xyz_batch_cnt=xyz_batch_cnt, new_xyz=new_xyz.contiguous(),
+                                             new_xyz_batch_cnt=new_xyz_batch_cnt, features=point_features.contiguous())
+        return pooled.view(-1, G ** 3, pooled.shape[-1])
+
+    def get_global_grid_points_of_roi(self, rois, grid_size):
+        rois = rois.view(-1, rois.shape[-1])
+        n = rois.shape[0]
+        local = self.get_dense_grid_points(rois, n, grid_size)
+        glob = common_utils.rotate_points_along_z(local.clone(), rois[:, 6]).squeeze(dim=1)
+        glob = glob + rois[:, 0:3].unsqueeze(dim=1)
+        return glob, local
+
+    @staticmethod
+    def get_dense_grid_points(rois, batch_size_rcnn, grid_size):
+        g = torch.arange(grid_size, device=rois.device)
+        dense_idx = torch.stack(torch.meshgrid(g, g, g, indexing='ij'), dim=-1).view(1, -1, 3).float()   # x,y,z fastest z
+        size = rois.view(batch_size_rcnn, -1)[:, 3:6].unsqueeze(1)
+        return (dense_idx + 0.5) / grid_size * size - size / 2
+
+    def _heads(self, pooled_flat):
+        shared = self.shared_fc_layer(pooled_flat)
+        rcnn_cls = self.cls_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
+        rcnn_reg = self.reg_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
+        return shared, rcnn_cls, rcnn_reg
+
+    def forward(self, batch_dict):
+        targets_dict = self.proposal_layer(batch_dict,
+                                           nms_config=self.model_cfg.NMS_CONFIG['TRAIN' if self.training else 'TEST'])
+        if self.training:
+            targets_dict = batch_dict.get('roi_targets_dict', None)
+            if targets_dict is None:
+                targets_dict = self.assign_targets(batch_dict)
+                batch_dict['rois'] = targets_dict['rois']
+                batch_dict['roi_labels'] = targets_dict['roi_labels']
+        pooled = self.roi_grid_pool(batch_dict)                                   # (BN, G^3, C)
+        n = pooled.shape[0]
+        pooled_flat = pooled.permute(0, 2, 1).contiguous().view(n, -1, 1)          # (BN, C*G^3, 1)
+        shared, rcnn_cls, rcnn_reg = self._heads(pooled_flat)
+        if not self.training:
+            rounds = self.model_cfg.get('SAMPLING_ROUND', None)
+            if rounds:
+                cls_list, reg_list = [rcnn_cls], [rcnn_reg]
+                for _ in range(rounds - 1):
+                    shared, rcnn_cls, rcnn_reg = self._heads(pooled_flat)
+                    cls_list.append(rcnn_cls)
+                    reg_list.append(rcnn_reg)
+                batch_dict['rcnn_cls'] = torch.stack(cls_list, 0)
+                batch_dict['rcnn_reg'] = torch.stack(reg_list, 0)
+            elif self.model_cfg.get('EMBEDDING_REQUIRED', None):
+                batch_dict['shared_features'] = shared
+            batch_cls_preds, batch_box_preds = self.generate_predicted_boxes(
+                batch_size=batch_dict['batch_size'], rois=batch_dict['rois'], cls_preds=rcnn_cls, box_preds=rcnn_reg)
+            batch_dict['batch_cls_preds'] = batch_cls_preds
+            batch_dict['batch_box_preds'] = batch_box_preds
+            batch_dict['cls_preds_normalized'] = False
+        else:
+            targets_dict['rcnn_cls'] = rcnn_cls
+            targets_dict['rcnn_reg'] = rcnn_reg
+            self.forward_ret_dict = targets_dict
+            batch_dict['rcnn_cls'] = rcnn_cls
+            batch_dict['rcnn_reg'] = rcnn_reg
+        return batch_dict

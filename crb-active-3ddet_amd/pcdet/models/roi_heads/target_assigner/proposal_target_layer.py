@@ -1,0 +1,119 @@
+"""ProposalTargetLayer (pcdet/models/roi_heads/target_assigner/proposal_target_layer.py:8-228): RoI sampling for the
+second stage, batched over frames and free of host synchronisation.
+
+Same sampling rule as the reference (fg >= min(REG_FG_THRESH, CLS_FG_THRESH), hard bg in [CLS_BG_THRESH_LO, REG_FG_THRESH),
+easy bg below, FG_RATIO / HARD_BG_RATIO quotas, fg without replacement, bg with replacement); the random draws come
+from a torch.Generator (device RNG) or from injected uniforms instead of np.random / CPU torch.randint
+(proposal_target_layer.py:134,171,175) — the reference's CPU RNG stream is not reproduced."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ....ops.iou3d_nms import iou3d_nms_utils
+
+
+class ProposalTargetLayer(nn.Module):
+    def __init__(self, roi_sampler_cfg):
+        super().__init__()
+        self.roi_sampler_cfg = roi_sampler_cfg
+        self.generator = None          # optional torch.Generator for reproducible draws
+
+    def forward(self, batch_dict, uniforms=None):
+        cfg = self.roi_sampler_cfg
+        rois, gt_of_rois, ious, scores, labels = self.sample_rois_for_rcnn(batch_dict, uniforms)
+        reg_valid_mask = (ious > cfg.REG_FG_THRESH).long()
+        if cfg.CLS_SCORE_TYPE == 'cls':
+            cls_labels = (ious > cfg.CLS_FG_THRESH).long()
+            ignore = (ious > cfg.CLS_BG_THRESH) & (ious < cfg.CLS_FG_THRESH)
+            cls_labels = torch.where(ignore, torch.full_like(cls_labels, -1), cls_labels)
+        elif cfg.CLS_SCORE_TYPE == 'roi_iou':
+            fg = ious > cfg.CLS_FG_THRESH
+            bg = ious < cfg.CLS_BG_THRESH
+            soft = (ious - cfg.CLS_BG_THRESH) / (cfg.CLS_FG_THRESH - cfg.CLS_BG_THRESH)
+            cls_labels = torch.where(fg, torch.ones_like(ious), torch.where(bg, torch.zeros_like(ious), soft))
+        else:
+            raise NotImplementedError
+        return {'rois': rois, 'gt_of_rois': gt_of_rois, 'gt_iou_of_rois': ious, 'roi_scores': scores,
+                'roi_labels': labels, 'reg_valid_mask': reg_valid_mask, 'rcnn_cls_labels': cls_labels}
+
+    # ------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def max_iou_with_same_class_batched(rois, roi_labels, gt_boxes):
+        """rois (B,R,7), roi_labels (B,R) long, gt_boxes (B,G,8) zero padded -> max_overlaps (B,R), gt_assignment (B,R).
+        Batched form of get_max_iou_with_same_class (proposal_target_layer.py:195-228): IoU3D only against ground truths
+        of the RoI's own class; RoIs without a same-class gt get overlap 0 and assignment 0."""
+        B, R, _ = rois.shape
+        G = gt_boxes.shape[1]
+        nonzero = gt_boxes[..., :-1].sum(-1) != 0
+        idx = torch.arange(G, device=rois.device).view(1, G)
+        last = torch.where(nonzero, idx, torch.zeros_like(idx)).max(dim=1, keepdim=True)[0]
+        valid = idx <= last
+        iou = iou3d_nms_utils.boxes_iou3d_gpu(rois.reshape(B * R, 7)[:, 0:7], gt_boxes.reshape(B * G, -1)[:, 0:7])
+        iou = iou.view(B, R, B, G)[torch.arange(B), :, torch.arange(B)]                     # (B,R,G) block diagonal
+        same = (roi_labels[:, :, None] == gt_boxes[:, None, :, -1].long()) & valid[:, None, :]
+        iou = torch.where(same, iou, iou.new_full((), -1.0))
+        mx, arg = iou.max(dim=2)
+        none = mx < 0
+        return torch.where(none, torch.zeros_like(mx), mx), torch.where(none, torch.zeros_like(arg), arg)
+
+    def sample_rois_for_rcnn(self, batch_dict, uniforms=None):
+        cfg = self.roi_sampler_cfg
+        rois, roi_scores, roi_labels, gt_boxes = (batch_dict['rois'], batch_dict['roi_scores'], batch_dict['roi_labels'],
+                                                  batch_dict['gt_boxes'])
+        B = rois.shape[0]
+        if cfg.get('SAMPLE_ROI_BY_EACH_CLASS', False):
+            max_overlaps, gt_assignment = self.max_iou_with_same_class_batched(rois, roi_labels, gt_boxes)
+        else:
+            G = gt_boxes.shape[1]
+            iou = iou3d_nms_utils.boxes_iou3d_gpu(rois.reshape(-1, rois.shape[-1])[:, 0:7],
+                                                  gt_boxes.reshape(B * G, -1)[:, 0:7])
+            iou = iou.view(B, -1, B, G)[torch.arange(B), :, torch.arange(B)]
+            max_overlaps, gt_assignment = iou.max(dim=2)
+        sampled = self.subsample_rois_batched(max_overlaps, uniforms)                     # (B, ROI_PER_IMAGE)
+        g = lambda t: torch.gather(t, 1, sampled)
+        batch_rois = torch.gather(rois, 1, sampled[..., None].expand(-1, -1, rois.shape[-1]))
+        assign = g(gt_assignment)
+        batch_gt = torch.gather(gt_boxes, 1, assign[..., None].expand(-1, -1, gt_boxes.shape[-1]))
+        return batch_rois, batch_gt, g(max_overlaps), g(roi_scores), g(roi_labels)
+
+    def subsample_rois_batched(self, max_overlaps, uniforms=None):
+        """max_overlaps (B,R) -> sampled indices (B, ROI_PER_IMAGE), ordered [fg..., hard bg..., easy bg...]"""
+        cfg = self.roi_sampler_cfg
+        B, R = max_overlaps.shape
+        P = cfg.ROI_PER_IMAGE
+        dev = max_overlaps.device
+        fg_quota = int(np.round(cfg.FG_RATIO * P))
+        fg_thresh = min(cfg.REG_FG_THRESH, cfg.CLS_FG_THRESH)
+        fg = max_overlaps >= fg_thresh
+        easy = max_overlaps < cfg.CLS_BG_THRESH_LO
+        hard = (max_overlaps < cfg.REG_FG_THRESH) & (max_overlaps >= cfg.CLS_BG_THRESH_LO)
+        if uniforms is None:
+            u_perm = torch.rand((B, R), device=dev, generator=self.generator)
+            u_slot = torch.rand((B, P), device=dev, generator=self.generator)
+        else:
+            u_perm, u_slot = uniforms
+        n_fg, n_hard, n_easy = fg.sum(1), hard.sum(1), easy.sum(1)
+        n_bg = n_hard + n_easy
+        # members of each set first (stable), fg additionally in random order
+        fg_order = torch.argsort(torch.where(fg, u_perm, u_perm + 2.0), dim=1)            # random permutation of fg first
+        hard_order = torch.argsort((~hard).to(torch.int8), dim=1, stable=True)
+        easy_order = torch.argsort((~easy).to(torch.int8), dim=1, stable=True)
+        # quotas
+        fg_take = torch.where(n_bg > 0, torch.clamp(n_fg, max=fg_quota), torch.full_like(n_fg, P))
+        fg_take = torch.where(n_fg > 0, fg_take, torch.zeros_like(fg_take))
+        bg_take = P - fg_take
+        hard_take = torch.where(n_easy > 0, torch.minimum((bg_take.float() * cfg.HARD_BG_RATIO).long(), n_hard), bg_take)
+        hard_take = torch.where(n_hard > 0, hard_take, torch.zeros_like(hard_take))
+        slot = torch.arange(P, device=dev).view(1, P)
+        in_fg = slot < fg_take[:, None]
+        in_hard = (~in_fg) & (slot < (fg_take + hard_take)[:, None])
+        # fg slots: without replacement while n_fg >= fg_take (bg exists), with replacement when fg fills every slot
+        fg_pos = torch.where((n_bg > 0)[:, None], slot.expand(B, P),
+                             (u_slot * n_fg.clamp(min=1)[:, None].float()).floor().long())
+        fg_pos = fg_pos.clamp(max=R - 1)
+        fg_idx = torch.gather(fg_order, 1, torch.minimum(fg_pos, (n_fg.clamp(min=1) - 1)[:, None]))
+        hard_pos = (u_slot * n_hard.clamp(min=1)[:, None].float()).floor().long()
+        hard_idx = torch.gather(hard_order, 1, torch.minimum(hard_pos, (n_hard.clamp(min=1) - 1)[:, None]))
+        easy_pos = (u_slot * n_easy.clamp(min=1)[:, None].float()).floor().long()
+        easy_idx = torch.gather(easy_order, 1, torch.minimum(easy_pos, (n_easy.clamp(min=1) - 1)[:, None]))
+        return torch.where(in_fg, fg_idx, torch.where(in_hard, hard_idx, easy_idx))

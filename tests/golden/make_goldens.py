@@ -213,6 +213,107 @@ def gen_bev(out):
     out['vfe_out'] = _np(vfe({'voxels': torch.from_numpy(v), 'voxel_num_points': torch.from_numpy(n)})['voxel_features'])
 
 
+
+def gen_roi_head(out):
+    """second-stage pieces of PV-RCNN from the reference (CPU): canonical target transform, soft cls labels, losses +
+    grads, box decoding, FC stack in eval mode, same-class IoU assignment (IoU3D supplied by oracle/_ref-pinned C code)"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))          # repo root for `oracle`
+    sys.path.insert(0, os.path.dirname(OUT))
+    import oracle
+    from boxes_synth import detection_boxes
+    from pcdet.config import cfg as ref_cfg
+    ref_cfg.CLASS_NAMES = ['Car', 'Pedestrian', 'Cyclist']
+    from pcdet.ops.iou3d_nms import iou3d_nms_utils
+    iou3d_nms_utils.boxes_iou3d_gpu = lambda a, b: torch.from_numpy(oracle.boxes_pairwise(a.numpy(), b.numpy(), 2))
+    from pcdet.models.roi_heads.pvrcnn_head import PVRCNNHead
+    head_cfg = EasyDict({
+        'NAME': 'PVRCNNHead', 'CLASS_AGNOSTIC': True, 'SAMPLING_ROUND': 5, 'SHARED_FC': [32, 32], 'CLS_FC': [32, 32],
+        'REG_FC': [32, 32], 'DP_RATIO': 0.3,
+        'NMS_CONFIG': {'TRAIN': {'NMS_TYPE': 'nms_gpu', 'MULTI_CLASSES_NMS': False, 'NMS_PRE_MAXSIZE': 9000,
+                                 'NMS_POST_MAXSIZE': 512, 'NMS_THRESH': 0.8},
+                       'TEST': {'NMS_TYPE': 'nms_gpu', 'MULTI_CLASSES_NMS': False, 'NMS_PRE_MAXSIZE': 1024,
+                                'NMS_POST_MAXSIZE': 128, 'NMS_THRESH': 0.7}},
+        'ROI_GRID_POOL': {'GRID_SIZE': 2, 'MLPS': [[8, 8], [8, 8]], 'POOL_RADIUS': [0.8, 1.6], 'NSAMPLE': [16, 16],
+                          'POOL_METHOD': 'max_pool'},
+        'TARGET_CONFIG': {'BOX_CODER': 'ResidualCoder', 'ROI_PER_IMAGE': 128, 'FG_RATIO': 0.5,
+                          'SAMPLE_ROI_BY_EACH_CLASS': True, 'CLS_SCORE_TYPE': 'roi_iou', 'CLS_FG_THRESH': 0.75,
+                          'CLS_BG_THRESH': 0.25, 'CLS_BG_THRESH_LO': 0.1, 'HARD_BG_RATIO': 0.8, 'REG_FG_THRESH': 0.55},
+        'LOSS_CONFIG': {'CLS_LOSS': 'BinaryCrossEntropy', 'REG_LOSS': 'smooth-l1', 'CORNER_LOSS_REGULARIZATION': True,
+                        'LOSS_WEIGHTS': {'rcnn_cls_weight': 1.0, 'rcnn_reg_weight': 1.0, 'rcnn_corner_weight': 1.0,
+                                         'code_weights': [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]}}})
+    torch.manual_seed(11)
+    head = PVRCNNHead(input_channels=12, model_cfg=head_cfg, num_class=1)
+    rng = np.random.default_rng(12)
+    B, R = 2, 128
+    gtb = np.zeros((B, 9, 8), np.float32)
+    rois = np.zeros((B, R, 7), np.float32)
+    for b in range(B):
+        g, _ = detection_boxes(rng, 9 if b == 0 else 6, n_obj=9, spread=0.0)
+        gtb[b, :len(g), :7] = g
+        gtb[b, :len(g), 7] = rng.integers(1, 4, len(g))
+        k = rng.integers(0, len(g), R)
+        rois[b] = g[k] + rng.normal(0, 0.25, (R, 7)).astype(np.float32) * np.array([1, 1, .3, .3, .3, .3, .5], np.float32)
+    roi_labels = rng.integers(1, 4, (B, R)).astype(np.int64)
+    # (e) same-class max IoU
+    mo, ga = [], []
+    for b in range(B):
+        n_gt = 9 if b == 0 else 6
+        m, a = head.proposal_target_layer.get_max_iou_with_same_class(
+            rois=torch.from_numpy(rois[b]), roi_labels=torch.from_numpy(roi_labels[b]),
+            gt_boxes=torch.from_numpy(gtb[b, :n_gt, :7]), gt_labels=torch.from_numpy(gtb[b, :n_gt, 7]).long())
+        mo.append(_np(m)); ga.append(_np(a))
+    out['roi_rois'], out['roi_gt'], out['roi_labels'] = rois, gtb, roi_labels
+    out['roi_max_overlaps'], out['roi_gt_assignment'] = np.stack(mo), np.stack(ga)
+    # (d) labels from IoUs with the sampler bypassed
+    ious = torch.from_numpy(np.stack(mo))
+    gt_of = torch.from_numpy(np.stack([gtb[b][ga[b]] for b in range(B)]))
+    ptl = head.proposal_target_layer
+    ptl.sample_rois_for_rcnn = lambda batch_dict: (torch.from_numpy(rois), gt_of.clone(), ious,
+                                                   torch.zeros(B, R), torch.from_numpy(roi_labels))
+    head.train()
+    td = head.assign_targets({'batch_size': B})
+    out['roi_reg_valid_mask'] = _np(td['reg_valid_mask'])
+    out['roi_cls_labels'] = _np(td['rcnn_cls_labels'])
+    out['roi_gt_of_rois'] = _np(td['gt_of_rois'])
+    out['roi_gt_of_rois_src'] = _np(td['gt_of_rois_src'])
+    # (b) losses + grads
+    rcnn_cls = torch.from_numpy(rng.normal(0, 1, (B * R, 1)).astype(np.float32)).requires_grad_(True)
+    rcnn_reg = torch.from_numpy(rng.normal(0, 0.3, (B * R, 7)).astype(np.float32)).requires_grad_(True)
+    td['rcnn_cls'], td['rcnn_reg'] = rcnn_cls, rcnn_reg
+    head.forward_ret_dict = td
+    loss, tb = head.get_loss()
+    loss.backward()
+    out['roi_rcnn_cls'], out['roi_rcnn_reg'] = _np(rcnn_cls), _np(rcnn_reg)
+    out['roi_loss'] = np.array([float(loss), tb['rcnn_loss_cls'], tb['rcnn_loss_reg'], tb['rcnn_loss_corner']])
+    out['roi_cls_grad'], out['roi_reg_grad'] = _np(rcnn_cls.grad), _np(rcnn_reg.grad)
+    out['roi_rcnn_reg_gt'] = _np(td['rcnn_reg_gt'])
+    # CRB branch of the two losses (crb_sampling.py:194-196)
+    hyp_cls = torch.from_numpy(rng.uniform(0, 1, (R, 1)).astype(np.float32))
+    hyp_reg = torch.from_numpy(rng.normal(0, 0.3, (R, 7)).astype(np.float32))
+    c1 = rcnn_cls[:R].detach().clone().requires_grad_(True)
+    r1 = rcnn_reg[:R].detach().clone().requires_grad_(True)
+    cls_loss, _ = head.get_box_cls_layer_loss({'rcnn_cls': c1, 'rcnn_cls_labels': hyp_cls})
+    reg_loss = head.get_box_reg_layer_loss({'rcnn_reg': r1, 'reg_sample_targets': hyp_reg})
+    (cls_loss + reg_loss.mean()).backward()
+    out['crb_hyp_cls'], out['crb_hyp_reg'] = _np(hyp_cls), _np(hyp_reg)
+    out['crb_loss'] = np.array([float(cls_loss), float(reg_loss.mean())])
+    out['crb_cls_grad'], out['crb_reg_grad'] = _np(c1.grad), _np(r1.grad)
+    # (c) decoding
+    bc, bb = head.generate_predicted_boxes(B, torch.from_numpy(rois), rcnn_cls.detach(), rcnn_reg.detach())
+    out['roi_decoded'] = _np(bb)
+    # (f) FC stack, eval mode
+    head.eval()
+    pooled = torch.from_numpy(rng.normal(0, 1, (B * R, 8, 16)).astype(np.float32))
+    flat = pooled.permute(0, 2, 1).contiguous().view(B * R, -1, 2, 2, 2).view(B * R, -1, 1)
+    shared = head.shared_fc_layer(flat)
+    out['fc_state'] = {k: _np(v) for k, v in head.state_dict().items() if not k.startswith('roi_grid_pool_layer')}
+    out['fc_pooled'] = _np(pooled)
+    out['fc_cls'] = _np(head.cls_layers(shared).transpose(1, 2).contiguous().squeeze(1))
+    out['fc_reg'] = _np(head.reg_layers(shared).transpose(1, 2).contiguous().squeeze(1))
+    g, l = head.get_global_grid_points_of_roi(torch.from_numpy(rois), 2)
+    out['grid_global'] = _np(g)
+
+
 def save(name, d):
     flat = {}
     for k, v in d.items():
@@ -228,7 +329,10 @@ def save(name, d):
 
 if __name__ == '__main__':
     import_reference()
-    for name, fn in (('ref_utils.npz', gen_utils), ('ref_anchor_head.npz', gen_head), ('ref_bev_vfe.npz', gen_bev)):
+    only = sys.argv[1:] 
+    for name, fn in (('ref_utils.npz', gen_utils), ('ref_anchor_head.npz', gen_head), ('ref_bev_vfe.npz', gen_bev), ('ref_roi_head.npz', gen_roi_head)):
+        if only and name not in only:
+            continue
         d = {}
         fn(d)
         save(name, d)
