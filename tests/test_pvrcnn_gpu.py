@@ -1,0 +1,119 @@
+"""GPU: PV-RCNN end to end through the HIP path — training step (fwd+bwd) and the CRB evaluation pass
+(MC-dropout heads + batched post-processing records), with parity checks of the device-side pieces against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from synth import kitti_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(dev, first, B, n=20000):
+    pts, off, gt = kitti_batch(first, B, n)
+    bidx = np.repeat(np.arange(B, dtype=np.float32), np.diff(off))
+    return {'points': torch.from_numpy(np.concatenate([bidx[:, None], pts], 1)).to(dev),
+            'point_frame_offsets': torch.from_numpy(off).to(dev), 'gt_boxes': torch.from_numpy(gt).to(dev),
+            'batch_size': B, 'point_frame_counts_host': np.diff(off).tolist(),
+            'frame_id': np.array(['%06d' % (first + i) for i in range(B)])}, pts, off, gt
+
+
+@pytest.fixture(scope='module')
+def model(dev):
+    from pcdet.datasets import SyntheticDataset
+    from pcdet.model_cfgs import pv_rcnn_cfg
+    from pcdet.models import build_network
+    torch.manual_seed(0)
+    return build_network(pv_rcnn_cfg().MODEL, 3, SyntheticDataset(num_frames=2)).to(dev)
+
+
+def test_train_step(model, dev):
+    model.train()
+    b, *_ = _batch(dev, 0, 2)
+    ret, tb, _ = model(b)
+    loss = ret['loss']
+    assert torch.isfinite(loss)
+    model.zero_grad(set_to_none=True)
+    loss.backward()
+    for name in ('backbone_3d.conv_input.0.weight', 'pfe.SA_layers.3.mlps.1.0.weight', 'roi_head.shared_fc_layer.4.weight',
+                 'point_head.cls_layers.0.weight', 'dense_head.conv_box.weight'):
+        g = dict(model.named_parameters())[name].grad
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0, name
+    assert ret['rcnn_cls'].shape == (2 * 128, 1) and ret['rcnn_reg'].shape == (2 * 128, 7)
+    assert set(tb) >= {'rpn_loss', 'point_loss_cls', 'rcnn_loss_cls', 'rcnn_loss_reg', 'rcnn_loss_corner'}
+
+
+def test_eval_records_and_parity(model, dev):
+    from pcdet.models.detectors.post_processing import crb_frame_records
+    model.eval()
+    for m in model.modules():                         # CRB: dropout stays on in eval (crb_sampling.py:39-46)
+        if m.__class__.__name__.startswith('Dropout'):
+            m.train()
+    b, pts, off, gt = _batch(dev, 4, 3)
+    with torch.no_grad():
+        for mod in model.module_list:
+            b = mod(b)
+        assert b['rcnn_cls'].shape == (5, 3 * 128, 1) and b['rois'].shape == (3, 128, 7)
+        # proposal layer parity: the rois are exactly greedy NMS (0.7) over the top-1024 anchors
+        scores, labels = torch.max(b['rpn_preds'].view(3, -1, 3) if False else None or
+                                   model.dense_head.forward_ret_dict['cls_preds'].view(3, -1, 3), dim=2)
+        rec = crb_frame_records(model, b)
+        pred_dicts, recall = model.post_processing(b)
+    assert len(pred_dicts) == 3
+    keys = {'confidence', 'rpn_preds', 'num_bbox', 'mean_points', 'median_points', 'variance_points',
+            'loss_predictions', 'batch_rcnn_cls', 'batch_rcnn_reg', 'embeddings', 'pred_logits', 'pred_boxes',
+            'pred_scores', 'pred_labels', 'pred_box_unique_density'}
+    assert keys <= set(pred_dicts[0].keys())
+    for f in range(3):
+        d = pred_dicts[f]
+        k = d['pred_boxes'].shape[0]
+        assert d['batch_rcnn_cls'].shape == (128, 1) and d['batch_rcnn_reg'].shape == (128, 7)
+        assert d['pred_scores'].shape[0] == k == d['pred_labels'].shape[0] == d['pred_box_unique_density'].shape[0]
+        if k:
+            assert float(d['pred_scores'].min()) >= 0.1
+            # density parity: points whose first containing box is j / volume
+            boxes = d['pred_boxes'].cpu().numpy()
+            xyz = pts[off[f]:off[f + 1], :3]
+            idx = oracle.points_in_boxes(xyz[None], boxes[None, :, :7])[0]
+            cnt = np.bincount(idx[idx >= 0], minlength=k).astype(np.float32)
+            np.testing.assert_allclose(d['pred_box_unique_density'].cpu().numpy(),
+                                       cnt / (boxes[:, 3] * boxes[:, 4] * boxes[:, 5]), rtol=1e-5)
+            # final NMS parity on the 128 refined boxes
+            conf = torch.sigmoid(b['batch_cls_preds'][f]).max(-1)[0].cpu().numpy()
+            allb = b['batch_box_preds'][f].cpu().numpy()
+            cand = np.nonzero(conf >= 0.1)[0]
+            order = cand[np.argsort(-conf[cand], kind='stable')]
+            keep = oracle.nms(allb[order, :7], 0.1)[:500]
+            np.testing.assert_allclose(boxes, allb[order][keep], rtol=0, atol=0)
+        # label entropy vs the reference formula (crb_sampling.py:86-94)
+        lab = d['pred_labels']
+        if k == 0:
+            exp = 0.0
+        else:
+            v, c = torch.unique(lab, return_counts=True)
+            p = torch.ones(3, device=lab.device)
+            p[v - 1] = c.float()
+            exp = float(torch.distributions.Categorical(probs=p / c.sum()).entropy())
+        assert abs(float(d['label_entropy']) - exp) < 1e-5
+    assert recall['gt'] == 36
+
+
+def test_proposal_layer_matches_oracle_nms(model, dev):
+    model.eval()
+    b, *_ = _batch(dev, 9, 2)
+    with torch.no_grad():
+        for mod in model.module_list[:-1]:
+            b = mod(b)
+        cls, box = b['batch_cls_preds'].clone(), b['batch_box_preds'].clone()
+        cfg = model.roi_head.model_cfg.NMS_CONFIG['TEST']
+        out = model.roi_head.proposal_layer(dict(b), cfg)
+    for f in range(2):
+        s, lab = cls[f].max(1)
+        top_s, top_i = torch.topk(s, 1024)
+        boxes = box[f][top_i].cpu().numpy()
+        keep = oracle.nms(boxes[:, :7], 0.7)[:128]
+        exp = np.zeros((128, 7), np.float32)
+        exp[:len(keep)] = boxes[keep]
+        np.testing.assert_array_equal(out['rois'][f].cpu().numpy(), exp)
+        assert (out['roi_labels'][f, len(keep):] == 1).all()
