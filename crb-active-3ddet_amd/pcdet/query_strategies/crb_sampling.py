@@ -1,0 +1,151 @@
+"""CRBSampling (pcdet/query_strategies/crb_sampling.py:20-342) on the MI355X path.
+
+Stage 1  concise label sampling: every rank scores its rank-strided shard of the unlabeled pool with the eval model +
+         MC dropout; per-frame records stay on the device as fixed-stride rows and are all-gathered over RCCL, so every
+         rank ranks the WHOLE pool (the reference ranks only its own sampler shard, SURVEY finding 6).
+Stage 2  representative prototypes: the K1*N frames are sharded across ranks; per frame one bs=1 training-mode
+         forward/backward gives the gradient of roi_head.shared_fc_layer[4].weight (exactly the reference's per-sample
+         semantics: single-frame BatchNorm statistics, dropout on); embeddings are all-gathered and sklearn
+         kmeans_plusplus(random_state=0) picks K2*N prototypes (kept for parity).
+Stage 3  greedy density balancing: one HIP launch pair (crb_density_greedy) instead of ~74k CPU KDE fits."""
+import time
+
+import numpy as np
+import torch
+
+from ..models import load_data_to_gpu
+from ..models.detectors.post_processing import crb_frame_records
+from . import scoring
+from .strategy import Strategy
+
+
+class CRBSampling(Strategy):
+    def __init__(self, model, labelled_loader, unlabelled_loader, rank, active_label_dir, cfg):
+        super().__init__(model, labelled_loader, unlabelled_loader, rank, active_label_dir, cfg)
+        ac = cfg.ACTIVE_TRAIN.ACTIVE_CONFIG
+        self.k1 = getattr(ac, 'K1', 5)
+        self.k2 = getattr(ac, 'K2', 3)
+        # the reference reads the misspelt key 'BANDWDITH' (crb_sampling.py:31) so the YAML's BANDWIDTH never applies
+        # and the bandwidth is always 5; keep that behaviour
+        self.bandwidth = getattr(ac, 'BANDWDITH', 5)
+        self.prototype = getattr(ac, 'CLUSTERING', 'kmeans++')
+        self.alpha = 0.95
+        self.timings = {}
+
+    @staticmethod
+    def enable_dropout(model):
+        n = 0
+        for m in model.modules():
+            if m.__class__.__name__.startswith('Dropout'):
+                n += 1
+                m.train()
+        return n
+
+    def _world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+
+    # ---------------------------------------------------------------- stage 1
+    @torch.no_grad()
+    def score_pool(self, frame_indices, batch_size):
+        """-> (len(frame_indices), REC_STRIDE) device tensor of per-frame records, GT statistics recorded on the way"""
+        ds = self.unlabelled_set
+        model = self.model
+        model.eval()
+        self.enable_dropout(model)
+        rows = []
+        for s in range(0, len(frame_indices), batch_size):
+            chunk = frame_indices[s:s + batch_size]
+            batch = ds.collate_batch([ds[i] for i in chunk])
+            batch['point_frame_counts_host'] = np.diff(batch['point_frame_offsets']).tolist()
+            load_data_to_gpu(batch)
+            batch['point_frame_offsets'] = batch['point_frame_offsets'].int()
+            for mod in model.module_list:
+                batch = mod(batch)
+            rows.append(scoring.pack_records(crb_frame_records(model, batch)))
+        return torch.cat(rows, 0)
+
+    # ---------------------------------------------------------------- stage 2
+    def grad_embeddings(self, frame_indices, records):
+        """per-frame gradient of roi_head.shared_fc_layer[4].weight under the stage-1 hypothetical labels
+        (crb_sampling.py:174-212). -> (len(frame_indices), 65536) device tensor"""
+        ds = self.unlabelled_set
+        model = self.model
+        rec = scoring.unpack_records(records)
+        model.train()
+        was_training = getattr(ds, 'training', True)
+        out = []
+        w = model.roi_head.shared_fc_layer[4].weight
+        for k, i in enumerate(frame_indices):
+            batch = ds.collate_batch([ds[i]])
+            batch['point_frame_counts_host'] = np.diff(batch['point_frame_offsets']).tolist()
+            load_data_to_gpu(batch)
+            batch['point_frame_offsets'] = batch['point_frame_offsets'].int()
+            ret, _, _ = model(batch)
+            cls_loss, _ = model.roi_head.get_box_cls_layer_loss({'rcnn_cls': ret['rcnn_cls'],
+                                                                 'rcnn_cls_labels': rec['rcnn_cls'][k]})
+            reg_loss = model.roi_head.get_box_reg_layer_loss({'rcnn_reg': ret['rcnn_reg'],
+                                                              'reg_sample_targets': rec['rcnn_reg'][k]})
+            loss = cls_loss + reg_loss.mean()
+            model.zero_grad(set_to_none=True)
+            loss.backward()
+            out.append(w.grad.detach().reshape(-1).clone())
+        ds.training = was_training
+        return torch.stack(out, 0) if out else torch.zeros((0, w.numel()), device=w.device)
+
+    # ---------------------------------------------------------------- stage 3
+    def density_balance(self, cand_records, all_records, select_nums, num_class):
+        a = scoring.unpack_records(all_records)
+        valid = torch.arange(scoring.MAX_BOX, device=all_records.device)[None, :] < a['num'][:, None]
+        xaxis, prior = scoring.density_prior(a['density'][valid], a['labels'][valid], num_class, self.alpha)
+        c = scoring.unpack_records(cand_records)
+        cvalid = torch.arange(scoring.MAX_BOX, device=cand_records.device)[None, :] < c['num'][:, None]
+        labels = torch.where(cvalid, c['labels'], torch.zeros_like(c['labels'])).int()
+        order, scores = scoring.density_greedy(c['density'], labels, xaxis, prior, self.bandwidth, select_nums)
+        return order, scores
+
+    # ---------------------------------------------------------------- query
+    def query(self, leave_pbar=True, cur_epoch=None):
+        rank, world = self._world()
+        ds = self.unlabelled_set
+        frame_ids = [p[0] for p in self.pairs]
+        n = len(frame_ids)
+        select_nums = self.cfg.ACTIVE_TRAIN.SELECT_NUMS
+        num_class = len(self.labelled_loader.dataset.class_names)
+        bs = self.unlabelled_loader.batch_size or 1
+        t0 = time.time()
+        # Stage 1
+        mine, per = scoring.shard_indices(n, rank, world)
+        local = self.score_pool(mine, bs)
+        records = scoring.all_gather_rows(local, n, world)
+        torch.cuda.synchronize()
+        self.timings['stage1_s'] = time.time() - t0
+        entropy = records[:, 0]
+        k1n = min(int(self.k1 * select_nums), n)
+        # sort ascending (stable) then take from the end, like sorted(dict.items())[::-1][:K1*N] (crb_sampling.py:118-121)
+        order = torch.argsort(entropy, stable=True).flip(0)[:k1n].cpu().tolist()
+        # the reference then walks self.pairs in dataset order (:134-137)
+        stage2_idx = sorted(order)
+        # Stage 2
+        t1 = time.time()
+        mine2, _ = scoring.shard_indices(len(stage2_idx), rank, world)
+        emb_local = self.grad_embeddings([stage2_idx[j] for j in mine2], records[[stage2_idx[j] for j in mine2]])
+        emb = scoring.all_gather_rows(emb_local, len(stage2_idx), world)
+        k2n = min(int(select_nums * self.k2), len(stage2_idx))
+        if self.prototype != 'kmeans++':
+            raise NotImplementedError(self.prototype)
+        from sklearn.cluster import kmeans_plusplus
+        _, sel = kmeans_plusplus(emb.cpu().numpy(), n_clusters=k2n, random_state=0)
+        cand_idx = [stage2_idx[i] for i in sel]
+        torch.cuda.synchronize()
+        self.timings['stage2_s'] = time.time() - t1
+        # Stage 3
+        t2 = time.time()
+        order3, _ = self.density_balance(records[cand_idx], records, min(select_nums, len(cand_idx)), num_class)
+        picked = [cand_idx[i] for i in order3.cpu().tolist() if i >= 0]
+        self.timings['stage3_s'] = time.time() - t2
+        self.model.eval()
+        self.last_records = records
+        return [frame_ids[i] for i in picked]

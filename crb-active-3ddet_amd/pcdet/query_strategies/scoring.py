@@ -1,0 +1,97 @@
+"""Device-side CRB scoring primitives shared by the strategies (MI355X redesign of the hot loops of
+pcdet/query_strategies/crb_sampling.py): fixed-stride per-frame records, frame sharding + RCCL all-gather, the stage-3
+density prior and the HIP greedy selection."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from crbhip import lib, check, ptr, cur_stream, require_cuda
+
+MAX_BOX = 128                                      # TEST NMS_POST_MAXSIZE: at most 128 RoIs reach post-processing
+REC_STRIDE = 2 + 3 * MAX_BOX + 7 * MAX_BOX         # entropy | n_box | labels | density | rcnn_cls | rcnn_reg
+
+
+def pack_records(rec):
+    """crb_frame_records(...) dict -> (B, REC_STRIDE) f32 (SURVEY §8e record layout)"""
+    B = rec['entropy'].shape[0]
+    P = rec['pred_labels'].shape[1]
+    assert P <= MAX_BOX
+    out = torch.zeros((B, REC_STRIDE), dtype=torch.float32, device=rec['entropy'].device)
+    out[:, 0] = rec['entropy']
+    out[:, 1] = rec['num'].float()
+    out[:, 2:2 + P] = rec['pred_labels'].float()
+    out[:, 2 + MAX_BOX:2 + MAX_BOX + P] = rec['density']
+    o = 2 + 2 * MAX_BOX
+    if rec['batch_rcnn_cls'] is not None:
+        R = rec['batch_rcnn_cls'].shape[1]
+        out[:, o:o + R] = rec['batch_rcnn_cls'].reshape(B, R)
+        out[:, o + MAX_BOX:o + MAX_BOX + 7 * R] = rec['batch_rcnn_reg'].reshape(B, 7 * R)
+    return out
+
+
+def unpack_records(records):
+    """(F, REC_STRIDE) -> dict of views"""
+    o = 2 + 2 * MAX_BOX
+    return {'entropy': records[:, 0], 'num': records[:, 1].long(), 'labels': records[:, 2:2 + MAX_BOX].long(),
+            'density': records[:, 2 + MAX_BOX:o], 'rcnn_cls': records[:, o:o + MAX_BOX].unsqueeze(-1),
+            'rcnn_reg': records[:, o + MAX_BOX:].reshape(-1, MAX_BOX, 7)}
+
+
+def shard_indices(n, rank, world):
+    """rank-strided shard with wrap-around padding — the reference's eval DistributedSampler
+    (pcdet/datasets/__init__.py:37-46) — -> (indices of this rank, per-rank count)"""
+    per = (n + world - 1) // world
+    total = per * world
+    idx = list(range(n)) + list(range(total - n))
+    return idx[rank:total:world], per
+
+
+def all_gather_rows(local, n_total, world, backend_device=None):
+    """local (per, S) rows of this rank (rank-strided shard) -> (n_total, S) rows in dataset order, on every rank.
+    One all_gather_into_tensor (RCCL over xGMI on the GPU node; gloo in the CPU tests)."""
+    if world == 1:
+        return local[:n_total]
+    per = local.shape[0]
+    gathered = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, local.contiguous())
+    # gathered[r*per + k] = global index k*world + r  -> interleave back and drop the wrap-around padding
+    out = gathered.view(world, per, *local.shape[1:]).transpose(0, 1).reshape(world * per, *local.shape[1:])
+    return out[:n_total]
+
+
+def density_prior(density_all, label_all, num_class, alpha=0.95):
+    """per-class evaluation axis and uniform prior over the central `alpha` density interval
+    (crb_sampling.py:250-260). -> xaxis (C,400) f64, prior (C,400) f64 numpy"""
+    xaxis = np.zeros((num_class, 400), np.float64)
+    prior = np.zeros((num_class, 400), np.float64)
+    for c in range(num_class):
+        d = torch.sort(density_all[label_all == (c + 1)])[0]
+        n = d.numel()
+        if n == 0:
+            raise ValueError('class %d has no predicted box in the pool (the reference indexes an empty tensor here)' % (c + 1))
+        gmax = int(d[-1])
+        ghigh = int(d[int(alpha * n)])
+        glow = int(d[-int(alpha * n)])
+        xaxis[c] = np.linspace(-50, gmax + 50, 400)
+        scale = ghigh - glow
+        with np.errstate(divide='ignore', invalid='ignore'):
+            prior[c] = np.where((xaxis[c] >= glow) & (xaxis[c] <= ghigh), 1.0 / scale, 0.0) if scale > 0 else np.nan
+    return xaxis, prior
+
+
+def density_greedy(densities, labels, xaxis, prior, bandwidth, select_nums):
+    """densities (N,D) f32 cuda, labels (N,D) i32 cuda (0 = padding) -> order (select_nums) int32 cuda, scores f64"""
+    require_cuda(densities, labels)
+    dev = densities.device
+    N, D = densities.shape
+    C = xaxis.shape[0]
+    xa = torch.from_numpy(np.ascontiguousarray(xaxis)).to(dev)
+    pr = torch.from_numpy(np.ascontiguousarray(prior)).to(dev)
+    order = torch.empty((select_nums,), dtype=torch.int32, device=dev)
+    scores = torch.empty((select_nums,), dtype=torch.float64, device=dev)
+    wsb = lib.crb_density_greedy_workspace_bytes(N, C)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    check(lib.crb_density_greedy(ptr(densities.contiguous().float()), ptr(labels.contiguous().int()), N, D, C, ptr(xa),
+                                 ptr(pr), float(bandwidth), int(select_nums), ptr(order), ptr(scores), ptr(ws), wsb,
+                                 cur_stream(dev)), 'crb_density_greedy')
+    return order, scores

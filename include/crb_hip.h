@@ -174,6 +174,21 @@ int crb_roiaware_pool3d_backward(int N, int C, int max_pts_each_voxel, int out_x
                                  const int32_t* pts_idx_of_voxels, const int32_t* argmax,
                                  const float* grad_out, float* grad_in, int pool_method, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * a28  CRB stage 3: greedy point-cloud-density balancing
+ * replaces: the sklearn KernelDensity / scipy.stats.entropy triple loop of
+ *           pcdet/query_strategies/crb_sampling.py:276-331 (SELECT_NUMS x candidates x classes KDE fits on the CPU).
+ * densities (n_candidates,dmax) f32 / labels (n_candidates,dmax) i32 (1..num_class, 0 = padding): predicted-box point
+ * densities of the K2*N candidate frames in candidate order; xaxis/prior (num_class,400) f64 device: evaluation axis
+ * and (un-normalised) uniform prior per class; order (select_nums) i32: picked candidate indices, first pick = 0,
+ * -1 padded; best_scores (select_nums) f64 or NULL. f64 arithmetic. No synchronisation.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t crb_density_greedy_workspace_bytes(int n_candidates, int num_class);
+int crb_density_greedy(const float* densities, const int32_t* labels, int n_candidates, int dmax,
+                       int num_class, const double* xaxis, const double* prior, double bandwidth,
+                       int select_nums, int32_t* order, double* best_scores, void* workspace,
+                       int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
