@@ -68,7 +68,10 @@ def density_prior(density_all, label_all, num_class, alpha=0.95):
         d = torch.sort(density_all[label_all == (c + 1)])[0]
         n = d.numel()
         if n == 0:
-            raise ValueError('class %d has no predicted box in the pool (the reference indexes an empty tensor here)' % (c + 1))
+            # no predicted box of this class anywhere in the pool: the reference indexes an empty tensor and crashes
+            # (crb_sampling.py:255-258); here the class simply never contributes (every candidate has 0 boxes of it)
+            xaxis[c] = np.linspace(-50, 50, 400)
+            continue
         gmax = int(d[-1])
         ghigh = int(d[int(alpha * n)])
         glow = int(d[-int(alpha * n)])
