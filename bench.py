@@ -39,7 +39,9 @@ def parse():
     ap.add_argument('--kind', default='kitti', choices=['kitti', 'waymo'])
     ap.add_argument('--pool', type=int, default=2, help='distinct resident batches cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-frames', type=int, default=1)
+    ap.add_argument('--cpu-frames', type=int, default=8)
+    ap.add_argument('--scoring-frames', type=int, default=32,
+                    help='frames per GPU for the CRB stage-1 scoring measurement (0 = skip)')
     return ap.parse_args()
 
 
@@ -70,6 +72,7 @@ def roofline_from_profile(prof):
         ms = e0.elapsed_time(e1)
         key = ('subm_gather_gemm', cin, cout)
         a = agg.setdefault(key, {'ms': 0.0, 'n': 0, 'bytes': 0.0, 'flops': 0.0, 'pairs': {}})
+        tab = tab if not isinstance(tab, tuple) else tab[0]
         pid = tab.data_ptr()
         if pid not in a['pairs']:
             a['pairs'][pid] = int((tab >= 0).sum().item())
@@ -122,6 +125,65 @@ def cpu_baseline(args):
             'sample': '%d synthetic %s frames x %d pts, one SECOND fwd+bwd step (oracle C voxelizer + sparse conv '
                       'fwd/dgrad/wgrad with OpenMP, stock torch CPU for BEV/head/loss), %.1f s' %
                       (args.cpu_frames, args.kind, args.points, dt)}
+
+
+def crb_scoring_bench(args, rank, world, device):
+    """CRB stage-1 acquisition scoring throughput: PV-RCNN eval forward with 5 MC-dropout head passes, batched
+    post-processing records (final NMS, box point densities, label entropy) for a shard of `scoring_frames` frames per
+    rank, then the RCCL all-gather of the fixed-stride records. Inputs resident in HBM; random-init weights."""
+    from pcdet.datasets.synthetic import kitti_batch
+    from pcdet.datasets import SyntheticDataset
+    from pcdet.model_cfgs import pv_rcnn_cfg
+    from pcdet.models import build_network
+    from pcdet.models.detectors.post_processing import crb_frame_records
+    from pcdet.query_strategies import scoring
+    torch.manual_seed(0)
+    cfg = pv_rcnn_cfg()
+    model = build_network(cfg.MODEL, 3, SyntheticDataset(num_frames=2)).to(device)
+    model.eval()
+    for m in model.modules():
+        if m.__class__.__name__.startswith('Dropout'):
+            m.train()
+    bs = 16
+    nb = max(1, args.scoring_frames // bs)
+    batches = []
+    for k in range(nb):
+        pts, off, gt = kitti_batch(5000 + 1000 * rank + k * bs, bs, args.points)
+        bidx = np.repeat(np.arange(bs, dtype=np.float32), np.diff(off))
+        batches.append({'points': torch.from_numpy(np.concatenate([bidx[:, None], pts], 1)).to(device),
+                        'point_frame_offsets': torch.from_numpy(off).to(device),
+                        'gt_boxes': torch.from_numpy(gt).to(device), 'batch_size': bs,
+                        'point_frame_counts_host': np.diff(off).tolist()})
+
+    def run():
+        rows = []
+        with torch.no_grad():
+            for b in batches:
+                b = dict(b)
+                for mod in model.module_list:
+                    b = mod(b)
+                rows.append(scoring.pack_records(crb_frame_records(model, b)))
+        local = torch.cat(rows, 0)
+        return scoring.all_gather_rows(local, local.shape[0] * world, world)
+
+    run()                                   # warm-up (MIOpen solver search, allocator)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    rec = run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    frames = nb * bs * world
+    return {'metric': 'frames/s CRB stage-1 acquisition scoring (PV-RCNN eval, 5 MC-dropout passes, records + all-gather)',
+            'value': round(frames / dt, 3), 'unit': 'frames/s', 'frames': frames, 'seconds': round(dt, 3),
+            'record_bytes_per_frame': 4 * scoring.REC_STRIDE, 'boxes_kept_total': int(rec[:, 1].sum().item())}
 
 
 def main():
@@ -197,7 +259,11 @@ def main():
                    'parallelism': 'dp%d' % world, 'optimizer': 'AdamW in the timed region',
                    'final_loss': round(float(loss.item()), 4)},
     }
+    del opt, net, model, batches
+    torch.cuda.empty_cache()
+    score = crb_scoring_bench(args, rank, world, device) if args.scoring_frames > 0 else None
     if rank == 0:
+        out['crb_scoring'] = score
         roof, table = roofline_from_profile(prof)
         out['roofline'] = roof
         out['kernel_table'] = table

@@ -35,6 +35,15 @@ class Rulebook(object):
         self.in_coords = None
         self._pairs = None
         self._pairs_t = None
+        self._sorted = {}
+
+    def sorted_table(self, which):
+        """('nbr' | 'nbr_t') -> (table rows in neighbour-mask order, perm int32): the layout the gather-GEMM kernel
+        consumes (rows of a wave share their set of active kernel offsets)"""
+        if which not in self._sorted:
+            table = self.nbr if which == 'nbr' else self.nbr_t
+            self._sorted[which] = _mask_sort(table, self.K)
+        return self._sorted[which]
 
     def pairs(self):
         if self._pairs is None:
@@ -46,6 +55,22 @@ class Rulebook(object):
         if self._pairs_t is None:
             self._pairs_t = _pairs_from_nbr(self.nbr_t, self.n_in, self.K)
         return self._pairs_t
+
+
+MASK_SORT = True      # set False to run the kernel on the natural row order (A/B measurements)
+
+
+def _mask_sort(table, K):
+    n = table.shape[0]
+    dev = table.device
+    if n == 0 or not MASK_SORT:
+        return table, None
+    mask = torch.empty((n,), dtype=torch.int32, device=dev)
+    check(lib.crb_nbr_masks(ptr(table), n, K, ptr(mask), cur_stream(dev)), 'crb_nbr_masks')
+    perm = torch.sort(mask, stable=True)[1].to(torch.int32)
+    out = torch.empty_like(table)
+    check(lib.crb_nbr_permute(ptr(table), ptr(perm), n, K, ptr(out), cur_stream(dev)), 'crb_nbr_permute')
+    return out, perm
 
 
 def _pairs_from_nbr(nbr, n_rows, K):
@@ -133,8 +158,9 @@ def spconv_rulebook(coords, shape, batch_size, ksize, stride, padding):
 PROFILE = None
 
 
-def _conv_forward_raw(x, w_kio, nbr, n_out, kind='fwd'):
-    """x (n_in,cin), w (K,cin,cout), nbr (n_out,K) -> (n_out,cout)"""
+def _conv_forward_raw(x, w_kio, table, n_out, kind='fwd'):
+    """x (n_in,cin), w (K,cin,cout), table = (nbr rows in kernel order (n_out,K), perm or None) -> (n_out,cout)"""
+    nbr, perm = table
     K, cin, cout = w_kio.shape
     if not lib.crb_sparse_conv_supported(cin, cout):
         raise CrbHipError(f'sparse conv channel pair ({cin},{cout}) has no gfx950 kernel instance')
@@ -143,7 +169,8 @@ def _conv_forward_raw(x, w_kio, nbr, n_out, kind='fwd'):
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(lib.crb_sparse_conv_forward(ptr(x), ptr(w_kio), ptr(nbr), ptr(y), n_out, K, cin, cout, cur_stream(x.device)),
+    check(lib.crb_sparse_conv_forward(ptr(x), ptr(w_kio), ptr(nbr), ptr(perm), ptr(y), n_out, K, cin, cout,
+                                      cur_stream(x.device)),
           'crb_sparse_conv_forward')
     if prof is not None:
         ev1.record()
@@ -178,9 +205,9 @@ class SparseConvFunction(torch.autograd.Function):
         x = x.contiguous().float()
         w_kio = w_kio.contiguous().float()
         if inverse:
-            table, n_out = rb.nbr_t, rb.n_in
+            table, n_out = rb.sorted_table('nbr_t'), rb.n_in
         else:
-            table, n_out = rb.nbr, rb.n_out
+            table, n_out = rb.sorted_table('nbr'), rb.n_out
         ctx.rb, ctx.inverse = rb, inverse
         ctx.save_for_backward(x, w_kio)
         return _conv_forward_raw(x, w_kio, table, n_out, ('subm' if rb.subm else 'spconv') + '_fwd')
@@ -194,10 +221,10 @@ class SparseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if rb.subm:
                 wd = w.flip(0).transpose(1, 2).contiguous()      # Wd[o] = W[K-1-o]^T
-                dx = _conv_forward_raw(dy, wd, rb.nbr, rb.n_in, 'subm_dgrad')
+                dx = _conv_forward_raw(dy, wd, rb.sorted_table('nbr'), rb.n_in, 'subm_dgrad')
             else:
                 wd = w.transpose(1, 2).contiguous()
-                table, n_in = (rb.nbr, rb.n_out) if inverse else (rb.nbr_t, rb.n_in)
+                table, n_in = (rb.sorted_table('nbr'), rb.n_out) if inverse else (rb.sorted_table('nbr_t'), rb.n_in)
                 dx = _conv_forward_raw(dy, wd, table, n_in, 'spconv_dgrad')
         if ctx.needs_input_grad[1]:
             pairs = rb.pairs_t() if inverse else rb.pairs()

@@ -29,17 +29,50 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) {
   return t;
 }
 
+// A-operand fragment of one gathered row for all k-steps of a lane
+template <int CIN>
+struct AFrag {
+  static constexpr int NV = CIN >= 16 ? CIN / 16 : (CIN + 3) / 4;
+  f32x4 v[NV];     // CIN >= 16: float4 per 16-channel step; CIN < 16: one scalar per k-step in .x
+};
+
+template <int CIN>
+__device__ __forceinline__ void load_afrag(AFrag<CIN>& a, const float* __restrict__ X, int r, int g) {
+  if constexpr (CIN >= 16) {
+#pragma unroll
+    for (int s = 0; s < CIN / 16; ++s) {
+      a.v[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (r >= 0) a.v[s] = *reinterpret_cast<const f32x4*>(X + (int64_t)r * CIN + 16 * s + 4 * g);
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < (CIN + 3) / 4; ++s) {
+      const int k = 4 * s + g;
+      a.v[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (r >= 0 && k < CIN) a.v[s][0] = X[(int64_t)r * CIN + k];
+    }
+  }
+}
+
+// rows of a tile are taken through `perm` (rows sorted by their neighbour bit-mask so that the 16 rows of a wave share
+// the same set of active offsets: the dense-over-offsets MFMA waste drops from ~55-70 % to ~12-15 %); perm == nullptr
+// means identity. W[o] is double buffered in LDS: the next active offset's weights are fetched global->registers before
+// the MFMA block and written to the other buffer after it (one barrier per active offset); the next offset's gathered
+// rows are prefetched into registers the same way.
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
-                                                              const int* __restrict__ nbr, float* __restrict__ Y,
-                                                              int n_out, int K, int ntiles) {
+                                                              const int* __restrict__ nbr, const int* __restrict__ perm,
+                                                              float* __restrict__ Y, int n_out, int K, int ntiles) {
   constexpr int NB = (COUT + 15) / 16;   // 16-wide output column blocks (last one masked when COUT % 16)
   constexpr int WS = NB * 16 + 4;        // padded LDS row stride of W[o]
   constexpr int KSTEPS = (CIN + 3) / 4;  // MFMA k-steps
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* w_lds = reinterpret_cast<float*>(smem);                   // CINP * WS floats
   constexpr int CINP = KSTEPS * 4;
-  int* nbr_lds = reinterpret_cast<int*>(smem + sizeof(float) * CINP * WS);  // 64 * K ints
+  constexpr int WELEMS = CINP * NB * 16;            // staged elements of one W[o] (padding columns excluded)
+  constexpr int WPT = (WELEMS + 255) / 256;         // per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* w_lds0 = reinterpret_cast<float*>(smem);
+  float* w_lds1 = w_lds0 + CINP * WS;
+  int* nbr_lds = reinterpret_cast<int*>(smem + 2 * sizeof(float) * CINP * WS);  // 64 * K ints
   __shared__ unsigned wg_mask_sh[4];
 
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -50,14 +83,12 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
   const int li = lane & 15;
   const int g = lane >> 4;
 
-  // stage the 64 x K slice of the neighbour table (contiguous in HBM)
   const int rows_here = min(64, n_out - row0);
   for (int t = threadIdx.x; t < 64 * K; t += 256) {
     int r = t / K;
     nbr_lds[t] = (r < rows_here) ? nbr[(int64_t)row0 * K + t] : -1;
   }
   __syncthreads();
-  // per-wave / per-workgroup offset masks (K <= 32)
   unsigned wmask = 0;
   {
     const int myrow = wave * 16 + li;
@@ -68,71 +99,107 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
     if (lane == 0) wg_mask_sh[wave] = wmask;
   }
   __syncthreads();
-  const unsigned wgmask = wg_mask_sh[0] | wg_mask_sh[1] | wg_mask_sh[2] | wg_mask_sh[3];
+  unsigned todo = wg_mask_sh[0] | wg_mask_sh[1] | wg_mask_sh[2] | wg_mask_sh[3];
 
   f32x4 acc[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int o = 0; o < K; ++o) {
-    if (!((wgmask >> o) & 1u)) continue;   // workgroup-uniform
-    __syncthreads();                       // everyone is done with the previous W[o]
-    {
-      const float* wsrc = W + (int64_t)o * CIN * COUT;
-      if constexpr ((COUT % 16) == 0) {
-        for (int t = threadIdx.x; t < CINP * (COUT / 4); t += 256) {
-          int k = t / (COUT / 4), c4 = t - k * (COUT / 4);
-          f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (k < CIN) v = *reinterpret_cast<const f32x4*>(wsrc + k * COUT + c4 * 4);
-          *reinterpret_cast<f32x4*>(w_lds + k * WS + c4 * 4) = v;
-        }
-      }
-      if constexpr ((COUT % 16) != 0) {   // narrow outputs (dgrad into 4/5 point features): scalar, zero padded
-        for (int t = threadIdx.x; t < CINP * NB * 16; t += 256) {
-          int k = t / (NB * 16), c = t - k * (NB * 16);
-          w_lds[k * WS + c] = (k < CIN && c < COUT) ? wsrc[k * COUT + c] : 0.f;
-        }
-      }
+  // W staging helpers: thread t owns elements e = t + 256*j of the (CINP x NB*16) block
+  float wreg[WPT];
+  auto w_fetch = [&](int o) {
+    const float* wsrc = W + (int64_t)o * CIN * COUT;
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      const int k = e / (NB * 16), c = e - k * (NB * 16);
+      wreg[j] = (e < WELEMS && k < CIN && c < COUT) ? wsrc[k * COUT + c] : 0.f;
     }
-    __syncthreads();
-    if (!((wmask >> o) & 1u)) continue;    // wave-uniform
-    const int r = nbr_lds[(wave * 16 + li) * K + o];
-    if constexpr (CIN >= 16) {
+  };
+  auto w_store = [&](float* dst) {
 #pragma unroll
-      for (int s = 0; s < CIN / 16; ++s) {
-        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (r >= 0) a = *reinterpret_cast<const f32x4*>(X + (int64_t)r * CIN + 16 * s + 4 * g);
+    for (int j = 0; j < WPT; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      const int k = e / (NB * 16), c = e - k * (NB * 16);
+      if (e < WELEMS) dst[k * WS + c] = wreg[j];
+    }
+  };
+
+  int cur = todo ? __ffs(todo) - 1 : -1;
+  if (cur >= 0) { w_fetch(cur); w_store(w_lds0); }
+  AFrag<CIN> a_cur, a_nxt;
+  unsigned wtodo = wmask;
+  {
+    const int o0 = wtodo ? __ffs(wtodo) - 1 : -1;
+    load_afrag<CIN>(a_cur, X, o0 >= 0 ? nbr_lds[(wave * 16 + li) * K + o0] : -1, g);
+  }
+  __syncthreads();
+  int buf = 0;
+  while (cur >= 0) {
+    todo &= todo - 1;
+    const int nxt = todo ? __ffs(todo) - 1 : -1;
+    if (nxt >= 0) w_fetch(nxt);                         // global -> registers, lands during the MFMA block
+    const float* wl = buf ? w_lds1 : w_lds0;
+    if ((wmask >> cur) & 1u) {                          // wave-uniform
+      wtodo &= wtodo - 1;
+      const int on = wtodo ? __ffs(wtodo) - 1 : -1;     // this wave's next active offset: prefetch its rows
+      load_afrag<CIN>(a_nxt, X, on >= 0 ? nbr_lds[(wave * 16 + li) * K + on] : -1, g);
+      if constexpr (CIN >= 16) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float* wrow = w_lds + (16 * s + 4 * g + t) * WS + li;
+        for (int s = 0; s < CIN / 16; ++s) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float* wrow = wl + (16 * s + 4 * g + t) * WS + li;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.v[s][t], wrow[nb * 16], acc[nb], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+          const float* wrow = wl + (4 * s + g) * WS + li;
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], wrow[nb * 16], acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.v[s][0], wrow[nb * 16], acc[nb], 0, 0, 0);
         }
       }
-    } else {
-#pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) {
-        const int k = 4 * s + g;
-        float a = 0.f;
-        if (r >= 0 && k < CIN) a = X[(int64_t)r * CIN + k];
-        const float* wrow = w_lds + k * WS + li;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wrow[nb * 16], acc[nb], 0, 0, 0);
-      }
+      a_cur = a_nxt;
     }
+    if (nxt >= 0) w_store(buf ? w_lds0 : w_lds1);
+    __syncthreads();
+    buf ^= 1;
+    cur = nxt;
   }
 
   // C/D layout of 16x16: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
+  for (int rg = 0; rg < 4; ++rg) {
+    const int srow = row0 + wave * 16 + g * 4 + rg;
+    if (srow < n_out) {
+      const int row = perm ? perm[srow] : srow;
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int row = row0 + wave * 16 + g * 4 + rg;
-      if (row < n_out && nb * 16 + li < COUT) Y[(int64_t)row * COUT + nb * 16 + li] = acc[nb][rg];
+      for (int nb = 0; nb < NB; ++nb)
+        if (nb * 16 + li < COUT) Y[(int64_t)row * COUT + nb * 16 + li] = acc[nb][rg];
     }
   }
+}
+
+// one 32-bit neighbour mask per row (bit o set <=> nbr[row][o] >= 0); sort key for the row permutation
+__global__ __launch_bounds__(256) void nbr_mask_kernel(const int* __restrict__ nbr, int n, int K, int* __restrict__ mask) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  unsigned m = 0;
+  for (int o = 0; o < K; ++o) m |= (nbr[(int64_t)i * K + o] >= 0 ? 1u : 0u) << o;
+  mask[i] = (int)m;
+}
+
+__global__ __launch_bounds__(256) void nbr_permute_kernel(const int* __restrict__ nbr, const int* __restrict__ perm,
+                                                          int n, int K, int* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)n * K) return;
+  const int i = (int)(t / K), o = (int)(t - (int64_t)i * K);
+  out[t] = nbr[(int64_t)perm[i] * K + o];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -236,13 +303,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 template <int CIN, int COUT>
-int launch_fwd(const float* X, const float* W, const int* nbr, float* Y, int64_t n_out, int K, hipStream_t st) {
+int launch_fwd(const float* X, const float* W, const int* nbr, const int* perm, float* Y, int64_t n_out, int K,
+               hipStream_t st) {
   constexpr int KSTEPS = (CIN + 3) / 4;
   const int ntiles = crb_cdiv(n_out, 64);
   const int grid = ((ntiles + 7) / 8) * 8;
-  size_t lds = sizeof(float) * KSTEPS * 4 * (((COUT + 15) / 16) * 16 + 4) + sizeof(int) * 64 * K;
-  hipLaunchKernelGGL((sparse_conv_fwd_kernel<CIN, COUT>), dim3(grid), dim3(256), lds, st, X, W, nbr, Y, (int)n_out, K,
-                     ntiles);
+  size_t lds = 2 * sizeof(float) * KSTEPS * 4 * (((COUT + 15) / 16) * 16 + 4) + sizeof(int) * 64 * K;
+  hipLaunchKernelGGL((sparse_conv_fwd_kernel<CIN, COUT>), dim3(grid), dim3(256), lds, st, X, W, nbr, perm, Y, (int)n_out,
+                     K, ntiles);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
@@ -273,12 +341,30 @@ extern "C" int crb_sparse_conv_supported(int cin, int cout) {
   return 0;
 }
 
-extern "C" int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, float* Y, int64_t n_out,
-                                       int K, int cin, int cout, void* stream) {
+extern "C" int crb_nbr_masks(const int32_t* nbr, int64_t n, int K, int32_t* mask, void* stream) {
+  if (n < 0 || K <= 0 || K > 32) return CRB_ERR_ARG;
+  if (n == 0) return CRB_OK;
+  hipLaunchKernelGGL(nbr_mask_kernel, dim3(crb_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, nbr, (int)n, K, mask);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_nbr_permute(const int32_t* nbr, const int32_t* perm, int64_t n, int K, int32_t* nbr_sorted,
+                               void* stream) {
+  if (n < 0 || K <= 0) return CRB_ERR_ARG;
+  if (n == 0) return CRB_OK;
+  hipLaunchKernelGGL(nbr_permute_kernel, dim3(crb_cdiv(n * K, 256)), dim3(256), 0, (hipStream_t)stream, nbr, perm,
+                     (int)n, K, nbr_sorted);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, const int32_t* perm, float* Y,
+                                       int64_t n_out, int K, int cin, int cout, void* stream) {
   if (n_out < 0 || K <= 0 || K > 32) return CRB_ERR_ARG;
   if (n_out == 0) return CRB_OK;
   hipStream_t st = (hipStream_t)stream;
-#define X_(a, b) if (cin == a && cout == b) return launch_fwd<a, b>(X, W, nbr, Y, n_out, K, st);
+#define X_(a, b) if (cin == a && cout == b) return launch_fwd<a, b>(X, W, nbr, perm, Y, n_out, K, st);
   CRB_CONV_SHAPES(X_)
 #undef X_
   return CRB_ERR_UNSUPPORTED;

@@ -87,10 +87,15 @@ int crb_spconv_rulebook(const int32_t* coords, int64_t n, int B, const int32_t* 
 int64_t crb_pairs_workspace_bytes(int64_t n_out, int K);
 int crb_pairs_from_nbr(const int32_t* nbr, int64_t n_out, int K, int32_t* pair_in, int32_t* pair_out,
                        int32_t* pair_start, void* workspace, int64_t workspace_bytes, void* stream);
-/* Y (n_out,cout) = sum_o X[nbr[:,o]] @ W[o]; also used for dgrad with the transposed table / weights */
+/* Y (n_out,cout) = sum_o X[nbr[:,o]] @ W[o]; also used for dgrad with the transposed table / weights.
+ * Optional row permutation: when perm != NULL, `nbr` holds the table rows in permuted order (nbr_sorted[s] =
+ * nbr[perm[s]]) and the result of sorted row s is written to Y[perm[s]]. Sorting rows by their neighbour bit-mask
+ * (crb_nbr_masks -> sort -> crb_nbr_permute) lets a wave skip every kernel offset none of its 16 rows uses. */
 int crb_sparse_conv_supported(int cin, int cout);
-int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, float* Y, int64_t n_out,
-                            int K, int cin, int cout, void* stream);
+int crb_nbr_masks(const int32_t* nbr, int64_t n, int K, int32_t* mask, void* stream);
+int crb_nbr_permute(const int32_t* nbr, const int32_t* perm, int64_t n, int K, int32_t* nbr_sorted, void* stream);
+int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, const int32_t* perm, float* Y,
+                            int64_t n_out, int K, int cin, int cout, void* stream);
 /* dW (K,cin,cout) = sum over pairs X[pin]^T dY[pout] */
 int crb_sparse_conv_wgrad_splits(void);
 int64_t crb_sparse_conv_wgrad_workspace_bytes(int K, int cin, int cout);
