@@ -64,10 +64,13 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
                                                               const int* __restrict__ nbr, const int* __restrict__ perm,
                                                               float* __restrict__ Y, int n_out, int K, int ntiles) {
   constexpr int NB = (COUT + 15) / 16;   // 16-wide output column blocks (last one masked when COUT % 16)
-  constexpr int WS = NB * 16 + 4;        // padded LDS row stride of W[o]
+  // LDS layout of W[o]: [k][li][nb] (column nb*16+li stored at li*NB+nb), row stride NB*16 floats, unpadded: a lane's
+  // NB column-block values of one k are contiguous -> one ds_read_b128 (b64/b32 for NB=2/1) instead of NB ds_read_b32,
+  // and with a 256-B row the 4 k-groups of a wave (rows k, k+4, ...) land on disjoint 16-B slots: conflict free.
+  constexpr int WS = NB * 16;
   constexpr int KSTEPS = (CIN + 3) / 4;  // MFMA k-steps
   constexpr int CINP = KSTEPS * 4;
-  constexpr int WELEMS = CINP * NB * 16;            // staged elements of one W[o] (padding columns excluded)
+  constexpr int WELEMS = CINP * NB * 16;            // staged elements of one W[o]
   constexpr int WPT = (WELEMS + 255) / 256;         // per thread
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* w_lds0 = reinterpret_cast<float*>(smem);
@@ -107,21 +110,24 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
 
   // W staging helpers: thread t owns elements e = t + 256*j of the (CINP x NB*16) block
   float wreg[WPT];
+  // element e = (k, li, nb) in LDS order; consecutive threads take consecutive li for a fixed nb so the global reads
+  // of a wave stay contiguous 64-B runs and each thread's NB values of one (k, li) are adjacent registers
   auto w_fetch = [&](int o) {
     const float* wsrc = W + (int64_t)o * CIN * COUT;
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
-      const int e = threadIdx.x + 256 * j;
-      const int k = e / (NB * 16), c = e - k * (NB * 16);
-      wreg[j] = (e < WELEMS && k < CIN && c < COUT) ? wsrc[k * COUT + c] : 0.f;
+      const int q = (threadIdx.x + 256 * (j / NB));          // (k, li) pair index
+      const int nb = j % NB;
+      const int k = q >> 4, l = q & 15, c = nb * 16 + l;
+      wreg[j] = (q < CINP * 16 && k < CIN && c < COUT) ? wsrc[k * COUT + c] : 0.f;
     }
   };
   auto w_store = [&](float* dst) {
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
-      const int e = threadIdx.x + 256 * j;
-      const int k = e / (NB * 16), c = e - k * (NB * 16);
-      if (e < WELEMS) dst[k * WS + c] = wreg[j];
+      const int q = (threadIdx.x + 256 * (j / NB));
+      const int nb = j % NB;
+      if (q < CINP * 16) dst[(q >> 4) * WS + (q & 15) * NB + nb] = wreg[j];
     }
   };
 
@@ -145,23 +151,37 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
       const int on = wtodo ? __ffs(wtodo) - 1 : -1;     // this wave's next active offset: prefetch its rows
       load_afrag<CIN>(a_nxt, X, on >= 0 ? nbr_lds[(wave * 16 + li) * K + on] : -1, g);
       if constexpr (CIN >= 16) {
-#pragma unroll
-        for (int s = 0; s < CIN / 16; ++s) {
+        // B fragments of one 16-channel step are read (vector LDS reads) one step ahead of their MFMAs
+        float bcur[4][NB], bnxt[4][NB];
+        auto load_b = [&](float (&b)[4][NB], int s) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const float* wrow = wl + (16 * s + 4 * g + t) * WS + li;
+            const float* src = wl + (16 * s + 4 * g + t) * WS + li * NB;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) b[t][nb] = src[nb];
+          }
+        };
+        load_b(bcur, 0);
+#pragma unroll
+        for (int s = 0; s < CIN / 16; ++s) {
+          if (s + 1 < CIN / 16) load_b(bnxt, s + 1);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-              acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.v[s][t], wrow[nb * 16], acc[nb], 0, 0, 0);
-          }
+              acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.v[s][t], bcur[t][nb], acc[nb], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bcur[t][nb] = bnxt[t][nb];
         }
       } else {
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
-          const float* wrow = wl + (4 * s + g) * WS + li;
+          const float* src = wl + (4 * s + g) * WS + li * NB;
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.v[s][0], wrow[nb * 16], acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.v[s][0], src[nb], acc[nb], 0, 0, 0);
         }
       }
       a_cur = a_nxt;
@@ -230,8 +250,6 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __r
   const int wci = wave % C::WCI, slice = wave / C::WCI;
   const int p0 = pstart[o], p1 = pstart[o + 1];
   const int np = p1 - p0;
-  // pairs are cut into groups of 4; group q belongs to workgroup (q % S) and slice ((q / S) % SLICES)
-  const int ngroups = (np + 3) >> 2;
 
   f32x4 acc[C::CIPW][C::NB];
 #pragma unroll
@@ -239,23 +257,46 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __r
 #pragma unroll
     for (int nb = 0; nb < C::NB; ++nb) acc[a][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int q = sidx + S * slice; q < ngroups; q += S * C::SLICES) {
-    const int p = p0 + q * 4 + g;
-    const bool valid = p < p1;
-    const int ji = valid ? pin[p] : 0;
-    const int io = valid ? pout[p] : 0;
-    float b[C::NB];
+  // Each iteration covers 16 consecutive pairs (4 MFMA k-steps); blocks of 16 pairs are dealt round-robin to
+  // (workgroup, slice). All index loads, then all feature loads of the block are issued before the MFMAs, and the next
+  // block's indices are prefetched — the loop is latency-bound otherwise (dependent idx -> row -> MFMA chains).
+  const int nblocks = (np + 15) >> 4;
+  const int bstride = S * C::SLICES;
+  int blk = sidx + S * slice;
+  int ji[4], io[4];
+  bool vld[4];
+  auto load_idx = [&](int b) {
 #pragma unroll
-    for (int nb = 0; nb < C::NB; ++nb)
-      b[nb] = (valid && nb * 16 + li < COUT) ? dY[(int64_t)io * COUT + nb * 16 + li] : 0.f;
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + b * 16 + u * 4 + g;
+      vld[u] = (b < nblocks) && (p < p1);
+      ji[u] = vld[u] ? pin[p] : 0;
+      io[u] = vld[u] ? pout[p] : 0;
+    }
+  };
+  load_idx(blk);
+  for (; blk < nblocks; blk += bstride) {
+    float bv[4][C::NB];
+    float av[4][C::CIPW];
 #pragma unroll
-    for (int a = 0; a < C::CIPW; ++a) {
-      const int ci = (wci * C::CIPW + a) * 16 + li;
-      float av = (valid && ci < CIN) ? X[(int64_t)ji * CIN + ci] : 0.f;
+    for (int u = 0; u < 4; ++u) {
 #pragma unroll
       for (int nb = 0; nb < C::NB; ++nb)
-        acc[a][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nb], acc[a][nb], 0, 0, 0);
+        bv[u][nb] = (vld[u] && nb * 16 + li < COUT) ? dY[(int64_t)io[u] * COUT + nb * 16 + li] : 0.f;
+#pragma unroll
+      for (int a = 0; a < C::CIPW; ++a) {
+        const int ci = (wci * C::CIPW + a) * 16 + li;
+        av[u][a] = (vld[u] && ci < CIN) ? X[(int64_t)ji[u] * CIN + ci] : 0.f;
+      }
     }
+    load_idx(blk + bstride);                 // indices of the next block fly during the MFMAs
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int a = 0; a < C::CIPW; ++a)
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb)
+          acc[a][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][a], bv[u][nb], acc[a][nb], 0, 0, 0);
   }
 
   // reduce pair slices through LDS (fixed order), slice 0 writes the partial
@@ -308,7 +349,7 @@ int launch_fwd(const float* X, const float* W, const int* nbr, const int* perm, 
   constexpr int KSTEPS = (CIN + 3) / 4;
   const int ntiles = crb_cdiv(n_out, 64);
   const int grid = ((ntiles + 7) / 8) * 8;
-  size_t lds = 2 * sizeof(float) * KSTEPS * 4 * (((COUT + 15) / 16) * 16 + 4) + sizeof(int) * 64 * K;
+  size_t lds = 2 * sizeof(float) * KSTEPS * 4 * (((COUT + 15) / 16) * 16) + sizeof(int) * 64 * K;
   hipLaunchKernelGGL((sparse_conv_fwd_kernel<CIN, COUT>), dim3(grid), dim3(256), lds, st, X, W, nbr, perm, Y, (int)n_out,
                      K, ntiles);
   CRB_CHECK_LAUNCH();

@@ -1,0 +1,68 @@
+"""GPU: SECOND end to end through the HIP path — KITTI config vs the CPU oracle step, Waymo-shaped config
+(5 point features, 150k-voxel cap, BASELINE configs[4] shapes), VoxelResBackBone8x, reference-layout (pre-voxelized) batches."""
+import numpy as np
+import pytest
+import torch
+
+from synth import kitti_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev_batch(dev, pts, off, gt):
+    B = len(off) - 1
+    bidx = np.repeat(np.arange(B, dtype=np.float32), np.diff(off))
+    return {'points': torch.from_numpy(np.concatenate([bidx[:, None], pts], 1)).to(dev),
+            'point_frame_offsets': torch.from_numpy(off).to(dev), 'gt_boxes': torch.from_numpy(gt).to(dev),
+            'batch_size': B}
+
+
+def test_second_kitti_step_matches_cpu_oracle(dev):
+    import __graft_entry__ as ge
+    ge.smoke()
+
+
+def test_second_waymo_shape(dev):
+    from pcdet.datasets import SyntheticDataset
+    from pcdet.model_cfgs import second_cfg
+    from pcdet.models import build_network
+    torch.manual_seed(0)
+    ds = SyntheticDataset(num_frames=2, kind='waymo', n_points=160000)
+    model = build_network(second_cfg('waymo').MODEL, 3, ds).to(dev)
+    model.train()
+    pts, off, gt = kitti_batch(0, 2, 160000, waymo=True)
+    ret, tb, _ = model(_dev_batch(dev, pts, off, gt))
+    ret['loss'].backward()
+    assert torch.isfinite(ret['loss'])
+    assert model.backbone_3d.sparse_shape == [41, 1504, 1504]
+    g = model.backbone_3d.conv_input[0].weight.grad
+    assert g.shape == (16, 3, 3, 3, 5) and torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    assert model.dense_head.forward_ret_dict['cls_preds'].shape == (2, 188, 188, 18)
+
+
+def test_res_backbone_and_reference_layout_batch(dev):
+    """VoxelResBackBone8x + the reference batch layout: voxels / voxel_coords / voxel_num_points
+    produced per frame by VoxelGeneratorWrapper and collated like DatasetTemplate.collate_batch"""
+    from pcdet.datasets import SyntheticDataset
+    from pcdet.model_cfgs import second_cfg
+    from pcdet.models import build_network, load_data_to_gpu
+    torch.manual_seed(0)
+    cfg = second_cfg()
+    cfg.MODEL.BACKBONE_3D.NAME = 'VoxelResBackBone8x'
+    ds = SyntheticDataset(num_frames=2, device_voxelize=False)
+    model = build_network(cfg.MODEL, 3, ds).to(dev)
+    model.train()
+    batch = ds.collate_batch([ds[0], ds[1]])
+    assert batch['voxels'].shape[1:] == (5, 4) and batch['voxel_coords'].shape[1] == 4
+    load_data_to_gpu(batch)
+    ret, tb, _ = model(batch)
+    ret['loss'].backward()
+    assert torch.isfinite(ret['loss'])
+    w = model.backbone_3d.conv4[1].conv1
+    assert w.weight.shape == (128, 3, 3, 3, 128) and w.bias is not None and torch.isfinite(w.weight.grad).all()
+    # the device-voxelized path yields the same voxel features as the reference-layout path
+    pts, off, gt = kitti_batch(0, 2)
+    b2 = model.vfe(_dev_batch(dev, pts, off, gt))
+    b1 = model.vfe(dict(batch))
+    torch.testing.assert_close(b1['voxel_features'], b2['voxel_features'], rtol=1e-6, atol=1e-6)
+    assert torch.equal(b1['voxel_coords'].int(), b2['voxel_coords'])

@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the sparse-conv kernels on the real SECOND bs=16 geometry (levels 1..4 of VoxelBackBone8x).
+Prints per (level, Cin, Cout): rows, pairs, time, algorithmic GB/s (SURVEY §8d bytes), f32 TFLOP/s for fwd and wgrad.
+Usage: python tools/bench_sparse_conv.py [--batch 16] [--iters 50] [--no-sort]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'crb-active-3ddet_amd'))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--iters', type=int, default=50)
+    ap.add_argument('--no-sort', action='store_true')
+    ap.add_argument('--levels', default='1,2,3,4')
+    args = ap.parse_args()
+    from crbhip import sparse, voxel
+    from pcdet.datasets.synthetic import kitti_batch, KITTI_RANGE, KITTI_VOXEL
+    if args.no_sort:
+        sparse.MASK_SORT = False
+    dev = torch.device('cuda', 0)
+    pts, off, _ = kitti_batch(0, args.batch)
+    r = voxel.voxelize(torch.from_numpy(pts).to(dev), torch.from_numpy(off).to(dev), KITTI_RANGE, KITTI_VOXEL, 16000, 5,
+                       want_voxels=False, want_mean=True)
+    coords, shape = r['coords'], [41, 1600, 1408]
+    geo = [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1))]
+    chans = {1: (16, 16), 2: (32, 32), 3: (64, 64), 4: (64, 64)}
+    levels = [int(v) for v in args.levels.split(',')]
+    for lvl in range(1, 5):
+        if lvl > 1:
+            ks, st, pd = geo[lvl - 2]
+            rbs = sparse.spconv_rulebook(coords, shape, args.batch, ks, st, pd)
+            coords, shape = rbs.out_coords.contiguous(), rbs.out_shape
+        if lvl not in levels:
+            continue
+        rb = sparse.subm_rulebook(coords, shape, [3, 3, 3])
+        cin, cout = chans[lvl]
+        n = rb.n_out
+        P = int((rb.nbr >= 0).sum())
+        x = torch.randn(n, cin, device=dev)
+        dy = torch.randn(n, cout, device=dev)
+        w = torch.randn(27, cin, cout, device=dev) / 10
+        table = rb.sorted_table('nbr')
+        pairs = rb.pairs()
+
+        def timeit(fn):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / args.iters * 1e3      # us
+
+        t_f = timeit(lambda: sparse._conv_forward_raw(x, w, table, n))
+        t_w = timeit(lambda: sparse._conv_wgrad_raw(x, dy, pairs, 27))
+        balg = 4.0 * n * cin + 4.0 * n * cout + 8.0 * P + 4.0 * 27 * cin * cout
+        fl = 2.0 * P * cin * cout
+        print('L%d subm %dx%d N=%d P=%d (%.2f/row) | fwd %.1f us  %.0f GB/s alg (%.1f%% of 8TB/s)  %.1f TF | '
+              'wgrad %.1f us %.1f TF' % (lvl, cin, cout, n, P, P / n, t_f, balg / t_f / 1e3, balg / t_f / 1e3 / 80,
+                                        fl / t_f / 1e6, t_w, fl / t_w / 1e6), flush=True)
+
+
+if __name__ == '__main__':
+    main()
