@@ -58,6 +58,10 @@ class Rulebook(object):
 
 
 MASK_SORT = True      # set False to run the kernel on the natural row order (A/B measurements)
+# rows are sorted by neighbour mask inside chunks of this many consecutive rows: a global sort maximises MFMA skipping
+# (0.89 vs 0.80 useful/issued) but scatters each tile's gathers over the whole feature map (L2 misses); chunks keep the
+# spatial locality of the row order
+MASK_SORT_CHUNK = int(__import__('os').environ.get('CRB_MASK_SORT_CHUNK', '4096'))
 
 
 def _mask_sort(table, K):
@@ -67,7 +71,11 @@ def _mask_sort(table, K):
         return table, None
     mask = torch.empty((n,), dtype=torch.int32, device=dev)
     check(lib.crb_nbr_masks(ptr(table), n, K, ptr(mask), cur_stream(dev)), 'crb_nbr_masks')
-    perm = torch.sort(mask, stable=True)[1].to(torch.int32)
+    if MASK_SORT_CHUNK > 0:
+        key = (torch.arange(n, device=dev, dtype=torch.int64) // MASK_SORT_CHUNK) * (1 << 32) + mask.long()
+    else:
+        key = mask
+    perm = torch.sort(key, stable=True)[1].to(torch.int32)
     out = torch.empty_like(table)
     check(lib.crb_nbr_permute(ptr(table), ptr(perm), n, K, ptr(out), cur_stream(dev)), 'crb_nbr_permute')
     return out, perm
@@ -156,6 +164,7 @@ def spconv_rulebook(coords, shape, batch_size, ksize, stride, padding):
 # When set to a list, every gather-GEMM launch appends (kind, cin, cout, K, n_in, n_out, nbr, ev0, ev1): HIP events on
 # the launch stream (torch's current stream IS the stream handed to the C-ABI), read back by bench.py for the roofline.
 PROFILE = None
+CONV_VARIANT = int(__import__('os').environ.get('CRB_CONV_VARIANT', '0'))    # 0 = LDS-staged kernel; 1/2 = direct kernel
 
 
 def _conv_forward_raw(x, w_kio, table, n_out, kind='fwd'):
@@ -169,9 +178,15 @@ def _conv_forward_raw(x, w_kio, table, n_out, kind='fwd'):
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(lib.crb_sparse_conv_forward(ptr(x), ptr(w_kio), ptr(nbr), ptr(perm), ptr(y), n_out, K, cin, cout,
-                                      cur_stream(x.device)),
-          'crb_sparse_conv_forward')
+    if CONV_VARIANT and cin == cout and cin in (16, 32, 64):
+        scratch = torch.empty_like(w_kio)
+        check(lib.crb_sparse_conv_forward_variant(ptr(x), ptr(w_kio), ptr(nbr), ptr(perm), ptr(y), n_out, K, cin, cout,
+                                                  CONV_VARIANT, ptr(scratch), cur_stream(x.device)),
+              'crb_sparse_conv_forward_variant')
+    else:
+        check(lib.crb_sparse_conv_forward(ptr(x), ptr(w_kio), ptr(nbr), ptr(perm), ptr(y), n_out, K, cin, cout,
+                                          cur_stream(x.device)),
+              'crb_sparse_conv_forward')
     if prof is not None:
         ev1.record()
         prof.append((kind, cin, cout, K, x.shape[0], n_out, nbr, ev0, ev1))

@@ -205,6 +205,102 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Variant "direct": no LDS staging of W and no workgroup barriers. W is pre-arranged in MFMA fragment order
+// Wf[o][k][li][nb] (column nb*16+li at li*NB+nb) so that a lane's NB values of one k are one 16-B global load and a
+// wave's load of one (s,t) is a contiguous 1-KiB run; the 16 KiB of one W[o] stay L1/L2 resident across the waves of a
+// CU. Every wave walks its OWN active offsets (mask-sorted rows), SUBT 16-row sub-tiles per wave share each B load.
+template <int CIN, int COUT, int SUBT>
+__global__ __launch_bounds__(256) void sparse_conv_fwd_direct_kernel(const float* __restrict__ X,
+                                                                     const float* __restrict__ Wf,
+                                                                     const int* __restrict__ nbr,
+                                                                     const int* __restrict__ perm, float* __restrict__ Y,
+                                                                     int n_out, int K, int nwtiles) {
+  static_assert(CIN >= 16 && COUT % 16 == 0, "direct variant covers the wide layers");
+  constexpr int NB = COUT / 16;
+  constexpr int ROWS = 16 * SUBT;
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int wtile = xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  if (wtile >= nwtiles) return;
+  const int row0 = wtile * ROWS;
+
+  int nrow[SUBT];                      // this lane's A row (li) of each sub-tile, index into nbr
+  unsigned wmask = 0;
+#pragma unroll
+  for (int u = 0; u < SUBT; ++u) nrow[u] = row0 + u * 16 + li;
+  for (int o = 0; o < K; ++o) {
+    bool has = false;
+#pragma unroll
+    for (int u = 0; u < SUBT; ++u) has |= (nrow[u] < n_out) && (nbr[(int64_t)nrow[u] * K + o] >= 0);
+    if (__ballot(has)) wmask |= (1u << o);
+  }
+  f32x4 acc[SUBT][NB];
+#pragma unroll
+  for (int u = 0; u < SUBT; ++u)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[u][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  AFrag<CIN> a_cur[SUBT], a_nxt[SUBT];
+  auto load_a = [&](AFrag<CIN> (&a)[SUBT], int o) {
+#pragma unroll
+    for (int u = 0; u < SUBT; ++u) {
+      int r = -1;
+      if (o >= 0 && nrow[u] < n_out) r = nbr[(int64_t)nrow[u] * K + o];
+      load_afrag<CIN>(a[u], X, r, g);
+    }
+  };
+  unsigned todo = wmask;
+  int cur = todo ? __ffs(todo) - 1 : -1;
+  load_a(a_cur, cur);
+  while (cur >= 0) {
+    todo &= todo - 1;
+    const int nxt = todo ? __ffs(todo) - 1 : -1;
+    load_a(a_nxt, nxt);
+    const float* wo = Wf + (int64_t)cur * CIN * COUT + li * NB;
+#pragma unroll
+    for (int s = 0; s < CIN / 16; ++s) {
+      float b[4][NB];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b[t][nb] = wo[(16 * s + 4 * g + t) * COUT + nb];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < SUBT; ++u)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[u][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u].v[s][t], b[t][nb], acc[u][nb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < SUBT; ++u) a_cur[u] = a_nxt[u];
+    cur = nxt;
+  }
+#pragma unroll
+  for (int u = 0; u < SUBT; ++u)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int srow = row0 + u * 16 + g * 4 + rg;
+      if (srow < n_out) {
+        const int row = perm ? perm[srow] : srow;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) Y[(int64_t)row * COUT + nb * 16 + li] = acc[u][nb][rg];
+      }
+    }
+}
+
+// (K,Cin,Cout) -> fragment order [o][k][li][nb]
+__global__ __launch_bounds__(256) void w_to_frag_kernel(const float* __restrict__ W, float* __restrict__ Wf, int64_t total,
+                                                        int cout) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int c = (int)(t % cout);
+  const int64_t ok = t / cout;
+  const int nbn = cout / 16;
+  Wf[ok * cout + (c & 15) * nbn + (c >> 4)] = W[t];
+}
+
 // one 32-bit neighbour mask per row (bit o set <=> nbr[row][o] >= 0); sort key for the row permutation
 __global__ __launch_bounds__(256) void nbr_mask_kernel(const int* __restrict__ nbr, int n, int K, int* __restrict__ mask) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -244,7 +340,12 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __r
   using C = WgradCfg<CIN, COUT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = reinterpret_cast<float*>(smem);   // SLICES>1: (SLICES-1) * CINP16 * COUT floats
-  const int o = blockIdx.x, S = gridDim.y, sidx = blockIdx.y;
+  // 1-D grid of K*S blocks. Block b runs on XCD b%8 (observed round-robin): all K offsets of one pair split are
+  // given to the SAME XCD and adjacent launch slots, so the X / dY rows of that split are re-read from one L2
+  // (offset o of split s touches the same output rows and their neighbours as offset o' of split s).
+  const int S = (int)gridDim.x / K;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int o = slot % K, sidx = (slot / K) * 8 + xcd;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int wci = wave % C::WCI, slice = wave / C::WCI;
@@ -260,9 +361,12 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __r
   // Each iteration covers 16 consecutive pairs (4 MFMA k-steps); blocks of 16 pairs are dealt round-robin to
   // (workgroup, slice). All index loads, then all feature loads of the block are issued before the MFMAs, and the next
   // block's indices are prefetched — the loop is latency-bound otherwise (dependent idx -> row -> MFMA chains).
-  const int nblocks = (np + 15) >> 4;
-  const int bstride = S * C::SLICES;
-  int blk = sidx + S * slice;
+  const int nblocks_all = (np + 15) >> 4;
+  const int per_split = (nblocks_all + S - 1) / S;              // contiguous range of 16-pair blocks per split
+  const int blk_lo = sidx * per_split;
+  const int nblocks = min(nblocks_all, blk_lo + per_split);
+  const int bstride = C::SLICES;
+  int blk = blk_lo + slice;
   int ji[4], io[4];
   bool vld[4];
   auto load_idx = [&](int b) {
@@ -361,10 +465,24 @@ int launch_wgrad(const float* X, const float* dY, const int* pin, const int* pou
                  float* partial, int K, int S, hipStream_t st) {
   using C = WgradCfg<CIN, COUT>;
   size_t lds = C::SLICES > 1 ? sizeof(float) * (C::SLICES - 1) * C::NCI * 16 * C::NB * 16 : 0;
-  hipLaunchKernelGGL((sparse_conv_wgrad_kernel<CIN, COUT>), dim3(K, S), dim3(256), lds, st, X, dY, pin, pout, pstart,
+  hipLaunchKernelGGL((sparse_conv_wgrad_kernel<CIN, COUT>), dim3(K * S), dim3(256), lds, st, X, dY, pin, pout, pstart,
                      partial, K);
   const int64_t elems = (int64_t)K * CIN * COUT;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(crb_cdiv(elems, 256)), dim3(256), 0, st, partial, dW, elems, S);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+template <int CIN, int COUT, int SUBT>
+int launch_fwd_direct(const float* X, const float* W, const int* nbr, const int* perm, float* Y, int64_t n_out, int K,
+                      float* wfrag, hipStream_t st) {
+  const int64_t total = (int64_t)K * CIN * COUT;
+  hipLaunchKernelGGL(w_to_frag_kernel, dim3(crb_cdiv(total, 256)), dim3(256), 0, st, W, wfrag, total, COUT);
+  const int nwtiles = crb_cdiv(n_out, 16 * SUBT);
+  const int nwg = crb_cdiv(nwtiles, 4);
+  const int grid = ((nwg + 7) / 8) * 8;
+  hipLaunchKernelGGL((sparse_conv_fwd_direct_kernel<CIN, COUT, SUBT>), dim3(grid), dim3(256), 0, st, X, wfrag, nbr, perm,
+                     Y, (int)n_out, K, nwtiles);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
@@ -400,6 +518,23 @@ extern "C" int crb_nbr_permute(const int32_t* nbr, const int32_t* perm, int64_t 
   return CRB_OK;
 }
 
+// experimental variants (A/B measurements): 1/2 = direct kernel with 1/2 sub-tiles per wave; needs a K*cin*cout scratch
+extern "C" int crb_sparse_conv_forward_variant(const float* X, const float* W, const int32_t* nbr, const int32_t* perm,
+                                               float* Y, int64_t n_out, int K, int cin, int cout, int variant,
+                                               float* wfrag_scratch, void* stream) {
+  if (n_out < 0 || K <= 0 || K > 32 || !wfrag_scratch) return CRB_ERR_ARG;
+  if (n_out == 0) return CRB_OK;
+  hipStream_t st = (hipStream_t)stream;
+#define V_(a, b)                                                                                                    \
+  if (cin == a && cout == b) {                                                                                      \
+    if (variant == 1) return launch_fwd_direct<a, b, 1>(X, W, nbr, perm, Y, n_out, K, wfrag_scratch, st);            \
+    if (variant == 2) return launch_fwd_direct<a, b, 2>(X, W, nbr, perm, Y, n_out, K, wfrag_scratch, st);            \
+  }
+  V_(16, 16) V_(32, 32) V_(64, 64)
+#undef V_
+  return CRB_ERR_UNSUPPORTED;
+}
+
 extern "C" int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, const int32_t* perm, float* Y,
                                        int64_t n_out, int K, int cin, int cout, void* stream) {
   if (n_out < 0 || K <= 0 || K > 32) return CRB_ERR_ARG;
@@ -411,7 +546,7 @@ extern "C" int crb_sparse_conv_forward(const float* X, const float* W, const int
   return CRB_ERR_UNSUPPORTED;
 }
 
-extern "C" int crb_sparse_conv_wgrad_splits(void) { return 48; }
+extern "C" int crb_sparse_conv_wgrad_splits(void) { return 96; }   // multiple of 8 (XCD mapping)
 
 extern "C" int64_t crb_sparse_conv_wgrad_workspace_bytes(int K, int cin, int cout) {
   return (int64_t)crb_sparse_conv_wgrad_splits() * K * cin * cout * 4 + 256;

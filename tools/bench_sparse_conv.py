@@ -18,11 +18,14 @@ def main():
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--no-sort', action='store_true')
     ap.add_argument('--levels', default='1,2,3,4')
+    ap.add_argument('--chunk', type=int, default=None)
     args = ap.parse_args()
     from crbhip import sparse, voxel
     from pcdet.datasets.synthetic import kitti_batch, KITTI_RANGE, KITTI_VOXEL
     if args.no_sort:
         sparse.MASK_SORT = False
+    if args.chunk is not None:
+        sparse.MASK_SORT_CHUNK = args.chunk
     dev = torch.device('cuda', 0)
     pts, off, _ = kitti_batch(0, args.batch)
     r = voxel.voxelize(torch.from_numpy(pts).to(dev), torch.from_numpy(off).to(dev), KITTI_RANGE, KITTI_VOXEL, 16000, 5,
@@ -61,12 +64,21 @@ def main():
             return e0.elapsed_time(e1) / args.iters * 1e3      # us
 
         t_f = timeit(lambda: sparse._conv_forward_raw(x, w, table, n))
+        ref = sparse._conv_forward_raw(x, w, table, n)
+        tv = {}
+        for v in (1, 2):
+            sparse.CONV_VARIANT = v
+            tv[v] = timeit(lambda: sparse._conv_forward_raw(x, w, table, n))
+            err = float((sparse._conv_forward_raw(x, w, table, n) - ref).abs().max())
+            tv[v] = (tv[v], err)
+        sparse.CONV_VARIANT = 0
         t_w = timeit(lambda: sparse._conv_wgrad_raw(x, dy, pairs, 27))
         balg = 4.0 * n * cin + 4.0 * n * cout + 8.0 * P + 4.0 * 27 * cin * cout
         fl = 2.0 * P * cin * cout
         print('L%d subm %dx%d N=%d P=%d (%.2f/row) | fwd %.1f us  %.0f GB/s alg (%.1f%% of 8TB/s)  %.1f TF | '
-              'wgrad %.1f us %.1f TF' % (lvl, cin, cout, n, P, P / n, t_f, balg / t_f / 1e3, balg / t_f / 1e3 / 80,
-                                        fl / t_f / 1e6, t_w, fl / t_w / 1e6), flush=True)
+              'wgrad %.1f us %.1f TF | direct1 %.1f us (err %.1e) direct2 %.1f us (err %.1e)' % (
+                  lvl, cin, cout, n, P, P / n, t_f, balg / t_f / 1e3, balg / t_f / 1e3 / 80, fl / t_f / 1e6, t_w,
+                  fl / t_w / 1e6, tv[1][0], tv[1][1], tv[2][0], tv[2][1]), flush=True)
 
 
 if __name__ == '__main__':
