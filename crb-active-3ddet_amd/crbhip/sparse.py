@@ -164,7 +164,6 @@ def spconv_rulebook(coords, shape, batch_size, ksize, stride, padding):
 # When set to a list, every gather-GEMM launch appends (kind, cin, cout, K, n_in, n_out, nbr, ev0, ev1): HIP events on
 # the launch stream (torch's current stream IS the stream handed to the C-ABI), read back by bench.py for the roofline.
 PROFILE = None
-CONV_VARIANT = int(__import__('os').environ.get('CRB_CONV_VARIANT', '0'))    # 0 = LDS-staged kernel; 1/2 = direct kernel
 
 
 def _conv_forward_raw(x, w_kio, table, n_out, kind='fwd'):
@@ -178,15 +177,9 @@ def _conv_forward_raw(x, w_kio, table, n_out, kind='fwd'):
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    if CONV_VARIANT and cin == cout and cin in (16, 32, 64):
-        scratch = torch.empty_like(w_kio)
-        check(lib.crb_sparse_conv_forward_variant(ptr(x), ptr(w_kio), ptr(nbr), ptr(perm), ptr(y), n_out, K, cin, cout,
-                                                  CONV_VARIANT, ptr(scratch), cur_stream(x.device)),
-              'crb_sparse_conv_forward_variant')
-    else:
-        check(lib.crb_sparse_conv_forward(ptr(x), ptr(w_kio), ptr(nbr), ptr(perm), ptr(y), n_out, K, cin, cout,
-                                          cur_stream(x.device)),
-              'crb_sparse_conv_forward')
+    check(lib.crb_sparse_conv_forward(ptr(x), ptr(w_kio), ptr(nbr), ptr(perm), ptr(y), n_out, K, cin, cout,
+                                      cur_stream(x.device)),
+          'crb_sparse_conv_forward')
     if prof is not None:
         ev1.record()
         prof.append((kind, cin, cout, K, x.shape[0], n_out, nbr, ev0, ev1))

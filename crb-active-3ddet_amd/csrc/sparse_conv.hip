@@ -54,12 +54,15 @@ __device__ __forceinline__ void load_afrag(AFrag<CIN>& a, const float* __restric
   }
 }
 
-// rows of a tile are taken through `perm` (rows sorted by their neighbour bit-mask so that the 16 rows of a wave share
-// the same set of active offsets: the dense-over-offsets MFMA waste drops from ~55-70 % to ~12-15 %); perm == nullptr
-// means identity. W[o] is double buffered in LDS: the next active offset's weights are fetched global->registers before
-// the MFMA block and written to the other buffer after it (one barrier per active offset); the next offset's gathered
-// rows are prefetched into registers the same way.
-template <int CIN, int COUT>
+// rows of a tile are taken through `perm` (rows sorted by their neighbour bit-mask inside chunks, so that the 16 rows
+// of a sub-tile share the same set of active offsets: the dense-over-offsets MFMA waste drops from ~55-70 % to ~15-20 %);
+// perm == nullptr means identity.
+// A workgroup covers 64*SUBT rows: wave w owns SUBT sub-tiles of 16 rows. One staging of W[o] (double buffered in LDS:
+// fetched global->registers before the MFMA block, written to the other buffer after it, one barrier per active offset)
+// now serves 64*SUBT rows — at SUBT=1 the W traffic through the vector-memory pipe (12 active offsets x 16 KiB per 64
+// rows at C=64) exceeded the row gathers themselves. The next (offset, sub-tile)'s gathered rows are prefetched into
+// registers while the current one runs on the MFMA pipe.
+template <int CIN, int COUT, int SUBT>
 __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                               const int* __restrict__ nbr, const int* __restrict__ perm,
                                                               float* __restrict__ Y, int n_out, int K, int ntiles) {
@@ -72,46 +75,54 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
   constexpr int CINP = KSTEPS * 4;
   constexpr int WELEMS = CINP * NB * 16;            // staged elements of one W[o]
   constexpr int WPT = (WELEMS + 255) / 256;         // per thread
+  constexpr int TROWS = 64 * SUBT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* w_lds0 = reinterpret_cast<float*>(smem);
   float* w_lds1 = w_lds0 + CINP * WS;
-  int* nbr_lds = reinterpret_cast<int*>(smem + 2 * sizeof(float) * CINP * WS);  // 64 * K ints
+  int* nbr_lds = reinterpret_cast<int*>(smem + 2 * sizeof(float) * CINP * WS);  // TROWS * K ints
   __shared__ unsigned wg_mask_sh[4];
 
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   if (tile >= ntiles) return;
-  const int row0 = tile * 64;
+  const int row0 = tile * TROWS;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int li = lane & 15;
   const int g = lane >> 4;
 
-  const int rows_here = min(64, n_out - row0);
-  for (int t = threadIdx.x; t < 64 * K; t += 256) {
+  const int rows_here = min(TROWS, n_out - row0);
+  for (int t = threadIdx.x; t < TROWS * K; t += 256) {
     int r = t / K;
     nbr_lds[t] = (r < rows_here) ? nbr[(int64_t)row0 * K + t] : -1;
   }
   __syncthreads();
+  // per sub-tile offset masks (K <= 32); sub-tile u of wave w holds tile rows (w*SUBT + u)*16 ..
+  unsigned sm[SUBT];
   unsigned wmask = 0;
-  {
-    const int myrow = wave * 16 + li;
+#pragma unroll
+  for (int u = 0; u < SUBT; ++u) {
+    const int myrow = (wave * SUBT + u) * 16 + li;
+    unsigned m = 0;
     for (int o = 0; o < K; ++o) {
       bool has = nbr_lds[myrow * K + o] >= 0;
-      if (__ballot(has)) wmask |= (1u << o);
+      if (__ballot(has)) m |= (1u << o);
     }
-    if (lane == 0) wg_mask_sh[wave] = wmask;
+    sm[u] = m;
+    wmask |= m;
   }
+  if (lane == 0) wg_mask_sh[wave] = wmask;
   __syncthreads();
   unsigned todo = wg_mask_sh[0] | wg_mask_sh[1] | wg_mask_sh[2] | wg_mask_sh[3];
 
-  f32x4 acc[NB];
+  f32x4 acc[SUBT][NB];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < SUBT; ++u)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[u][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // W staging helpers: thread t owns elements e = t + 256*j of the (CINP x NB*16) block
+  // W staging helpers: element e = (k, li, nb) in LDS order; consecutive threads take consecutive li for a fixed nb so
+  // the global reads of a wave stay contiguous 64-B runs and each thread's NB values of one (k, li) are adjacent
   float wreg[WPT];
-  // element e = (k, li, nb) in LDS order; consecutive threads take consecutive li for a fixed nb so the global reads
-  // of a wave stay contiguous 64-B runs and each thread's NB values of one (k, li) are adjacent registers
   auto w_fetch = [&](int o) {
     const float* wsrc = W + (int64_t)o * CIN * COUT;
 #pragma unroll
@@ -131,14 +142,27 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
     }
   };
 
+  // this wave's work list is the (offset, sub-tile) pairs with sm[u] bit o set, walked offset-major
+  auto next_pair = [&](int& o, int& u) {       // advance to the next active pair after (o,u); o = K when exhausted
+    while (o < K) {
+      ++u;
+      if (u >= SUBT) { u = 0; ++o; if (o >= K) return; }
+      bool act = false;
+#pragma unroll
+      for (int v = 0; v < SUBT; ++v) act |= (v == u) && ((sm[v] >> o) & 1u);
+      if (act) return;
+    }
+  };
+  auto row_of = [&](int o, int u) -> int {
+    return (o < K) ? nbr_lds[((wave * SUBT + u) * 16 + li) * K + o] : -1;
+  };
+
   int cur = todo ? __ffs(todo) - 1 : -1;
   if (cur >= 0) { w_fetch(cur); w_store(w_lds0); }
+  int po = -1, pu = SUBT - 1;                 // prefetch cursor
+  next_pair(po, pu);
   AFrag<CIN> a_cur, a_nxt;
-  unsigned wtodo = wmask;
-  {
-    const int o0 = wtodo ? __ffs(wtodo) - 1 : -1;
-    load_afrag<CIN>(a_cur, X, o0 >= 0 ? nbr_lds[(wave * 16 + li) * K + o0] : -1, g);
-  }
+  load_afrag<CIN>(a_cur, X, row_of(po, pu), g);
   __syncthreads();
   int buf = 0;
   while (cur >= 0) {
@@ -146,34 +170,27 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
     const int nxt = todo ? __ffs(todo) - 1 : -1;
     if (nxt >= 0) w_fetch(nxt);                         // global -> registers, lands during the MFMA block
     const float* wl = buf ? w_lds1 : w_lds0;
-    if ((wmask >> cur) & 1u) {                          // wave-uniform
-      wtodo &= wtodo - 1;
-      const int on = wtodo ? __ffs(wtodo) - 1 : -1;     // this wave's next active offset: prefetch its rows
-      load_afrag<CIN>(a_nxt, X, on >= 0 ? nbr_lds[(wave * 16 + li) * K + on] : -1, g);
+#pragma unroll
+    for (int u = 0; u < SUBT; ++u) {
+      if (!((sm[u] >> cur) & 1u)) continue;             // wave-uniform
+      // (po,pu) == (cur,u) here by construction; fetch the following pair's rows before the MFMAs
+      next_pair(po, pu);
+      load_afrag<CIN>(a_nxt, X, row_of(po, pu), g);
       if constexpr (CIN >= 16) {
-        // B fragments of one 16-channel step are read (vector LDS reads) one step ahead of their MFMAs
-        float bcur[4][NB], bnxt[4][NB];
-        auto load_b = [&](float (&b)[4][NB], int s) {
+#pragma unroll
+        for (int s = 0; s < CIN / 16; ++s) {
+          float b[4][NB];
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const float* src = wl + (16 * s + 4 * g + t) * WS + li * NB;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) b[t][nb] = src[nb];
           }
-        };
-        load_b(bcur, 0);
-#pragma unroll
-        for (int s = 0; s < CIN / 16; ++s) {
-          if (s + 1 < CIN / 16) load_b(bnxt, s + 1);
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-              acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.v[s][t], bcur[t][nb], acc[nb], 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) bcur[t][nb] = bnxt[t][nb];
+              acc[u][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.v[s][t], b[t][nb], acc[u][nb], 0, 0, 0);
         }
       } else {
 #pragma unroll
@@ -181,7 +198,7 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
           const float* src = wl + (4 * s + g) * WS + li * NB;
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.v[s][0], src[nb], acc[nb], 0, 0, 0);
+            acc[u][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.v[s][0], src[nb], acc[u][nb], 0, 0, 0);
         }
       }
       a_cur = a_nxt;
@@ -194,111 +211,17 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
 
   // C/D layout of 16x16: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) {
-    const int srow = row0 + wave * 16 + g * 4 + rg;
-    if (srow < n_out) {
-      const int row = perm ? perm[srow] : srow;
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-        if (nb * 16 + li < COUT) Y[(int64_t)row * COUT + nb * 16 + li] = acc[nb][rg];
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Variant "direct": no LDS staging of W and no workgroup barriers. W is pre-arranged in MFMA fragment order
-// Wf[o][k][li][nb] (column nb*16+li at li*NB+nb) so that a lane's NB values of one k are one 16-B global load and a
-// wave's load of one (s,t) is a contiguous 1-KiB run; the 16 KiB of one W[o] stay L1/L2 resident across the waves of a
-// CU. Every wave walks its OWN active offsets (mask-sorted rows), SUBT 16-row sub-tiles per wave share each B load.
-template <int CIN, int COUT, int SUBT>
-__global__ __launch_bounds__(256) void sparse_conv_fwd_direct_kernel(const float* __restrict__ X,
-                                                                     const float* __restrict__ Wf,
-                                                                     const int* __restrict__ nbr,
-                                                                     const int* __restrict__ perm, float* __restrict__ Y,
-                                                                     int n_out, int K, int nwtiles) {
-  static_assert(CIN >= 16 && COUT % 16 == 0, "direct variant covers the wide layers");
-  constexpr int NB = COUT / 16;
-  constexpr int ROWS = 16 * SUBT;
-  const int lane = threadIdx.x & 63;
-  const int li = lane & 15, g = lane >> 4;
-  const int wtile = xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
-  if (wtile >= nwtiles) return;
-  const int row0 = wtile * ROWS;
-
-  int nrow[SUBT];                      // this lane's A row (li) of each sub-tile, index into nbr
-  unsigned wmask = 0;
-#pragma unroll
-  for (int u = 0; u < SUBT; ++u) nrow[u] = row0 + u * 16 + li;
-  for (int o = 0; o < K; ++o) {
-    bool has = false;
-#pragma unroll
-    for (int u = 0; u < SUBT; ++u) has |= (nrow[u] < n_out) && (nbr[(int64_t)nrow[u] * K + o] >= 0);
-    if (__ballot(has)) wmask |= (1u << o);
-  }
-  f32x4 acc[SUBT][NB];
-#pragma unroll
-  for (int u = 0; u < SUBT; ++u)
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[u][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  AFrag<CIN> a_cur[SUBT], a_nxt[SUBT];
-  auto load_a = [&](AFrag<CIN> (&a)[SUBT], int o) {
-#pragma unroll
-    for (int u = 0; u < SUBT; ++u) {
-      int r = -1;
-      if (o >= 0 && nrow[u] < n_out) r = nbr[(int64_t)nrow[u] * K + o];
-      load_afrag<CIN>(a[u], X, r, g);
-    }
-  };
-  unsigned todo = wmask;
-  int cur = todo ? __ffs(todo) - 1 : -1;
-  load_a(a_cur, cur);
-  while (cur >= 0) {
-    todo &= todo - 1;
-    const int nxt = todo ? __ffs(todo) - 1 : -1;
-    load_a(a_nxt, nxt);
-    const float* wo = Wf + (int64_t)cur * CIN * COUT + li * NB;
-#pragma unroll
-    for (int s = 0; s < CIN / 16; ++s) {
-      float b[4][NB];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) b[t][nb] = wo[(16 * s + 4 * g + t) * COUT + nb];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int u = 0; u < SUBT; ++u)
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            acc[u][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u].v[s][t], b[t][nb], acc[u][nb], 0, 0, 0);
-    }
-#pragma unroll
-    for (int u = 0; u < SUBT; ++u) a_cur[u] = a_nxt[u];
-    cur = nxt;
-  }
-#pragma unroll
   for (int u = 0; u < SUBT; ++u)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      const int srow = row0 + u * 16 + g * 4 + rg;
+      const int srow = row0 + (wave * SUBT + u) * 16 + g * 4 + rg;
       if (srow < n_out) {
         const int row = perm ? perm[srow] : srow;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) Y[(int64_t)row * COUT + nb * 16 + li] = acc[u][nb][rg];
+        for (int nb = 0; nb < NB; ++nb)
+          if (nb * 16 + li < COUT) Y[(int64_t)row * COUT + nb * 16 + li] = acc[u][nb][rg];
       }
     }
-}
-
-// (K,Cin,Cout) -> fragment order [o][k][li][nb]
-__global__ __launch_bounds__(256) void w_to_frag_kernel(const float* __restrict__ W, float* __restrict__ Wf, int64_t total,
-                                                        int cout) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= total) return;
-  const int c = (int)(t % cout);
-  const int64_t ok = t / cout;
-  const int nbn = cout / 16;
-  Wf[ok * cout + (c & 15) * nbn + (c >> 4)] = W[t];
 }
 
 // one 32-bit neighbour mask per row (bit o set <=> nbr[row][o] >= 0); sort key for the row permutation
@@ -447,17 +370,36 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   dW[i] = s;
 }
 
+static int g_subt_override = 0;     // 0 = heuristic; 1/2/4 force (A/B measurements)
+
+template <int CIN, int COUT, int SUBT>
+int launch_fwd_subt(const float* X, const float* W, const int* nbr, const int* perm, float* Y, int64_t n_out, int K,
+                    hipStream_t st) {
+  constexpr int KSTEPS = (CIN + 3) / 4;
+  const int ntiles = crb_cdiv(n_out, 64 * SUBT);
+  const int grid = ((ntiles + 7) / 8) * 8;
+  size_t lds = 2 * sizeof(float) * KSTEPS * 4 * (((COUT + 15) / 16) * 16) + sizeof(int) * 64 * SUBT * K;
+  hipLaunchKernelGGL((sparse_conv_fwd_kernel<CIN, COUT, SUBT>), dim3(grid), dim3(256), lds, st, X, W, nbr, perm, Y,
+                     (int)n_out, K, ntiles);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
 template <int CIN, int COUT>
 int launch_fwd(const float* X, const float* W, const int* nbr, const int* perm, float* Y, int64_t n_out, int K,
                hipStream_t st) {
-  constexpr int KSTEPS = (CIN + 3) / 4;
-  const int ntiles = crb_cdiv(n_out, 64);
-  const int grid = ((ntiles + 7) / 8) * 8;
-  size_t lds = 2 * sizeof(float) * KSTEPS * 4 * (((COUT + 15) / 16) * 16) + sizeof(int) * 64 * K;
-  hipLaunchKernelGGL((sparse_conv_fwd_kernel<CIN, COUT>), dim3(grid), dim3(256), lds, st, X, W, nbr, perm, Y, (int)n_out,
-                     K, ntiles);
-  CRB_CHECK_LAUNCH();
-  return CRB_OK;
+  // rows per workgroup: as many as keep >= ~3 workgroups per CU (256 CUs); wide layers gain most from W reuse
+  int subt = 1;
+  if constexpr (CIN >= 32 && COUT <= 64) {
+    if (n_out >= 64 * 4 * 768) subt = 4;
+    else if (n_out >= 64 * 2 * 768) subt = 2;
+  }
+  if (g_subt_override) subt = g_subt_override;
+  if constexpr (CIN >= 16 && COUT <= 64) {
+    if (subt == 4) return launch_fwd_subt<CIN, COUT, 4>(X, W, nbr, perm, Y, n_out, K, st);
+    if (subt == 2) return launch_fwd_subt<CIN, COUT, 2>(X, W, nbr, perm, Y, n_out, K, st);
+  }
+  return launch_fwd_subt<CIN, COUT, 1>(X, W, nbr, perm, Y, n_out, K, st);
 }
 
 template <int CIN, int COUT>
@@ -473,20 +415,6 @@ int launch_wgrad(const float* X, const float* dY, const int* pin, const int* pou
   return CRB_OK;
 }
 
-template <int CIN, int COUT, int SUBT>
-int launch_fwd_direct(const float* X, const float* W, const int* nbr, const int* perm, float* Y, int64_t n_out, int K,
-                      float* wfrag, hipStream_t st) {
-  const int64_t total = (int64_t)K * CIN * COUT;
-  hipLaunchKernelGGL(w_to_frag_kernel, dim3(crb_cdiv(total, 256)), dim3(256), 0, st, W, wfrag, total, COUT);
-  const int nwtiles = crb_cdiv(n_out, 16 * SUBT);
-  const int nwg = crb_cdiv(nwtiles, 4);
-  const int grid = ((nwg + 7) / 8) * 8;
-  hipLaunchKernelGGL((sparse_conv_fwd_direct_kernel<CIN, COUT, SUBT>), dim3(grid), dim3(256), 0, st, X, wfrag, nbr, perm,
-                     Y, (int)n_out, K, nwtiles);
-  CRB_CHECK_LAUNCH();
-  return CRB_OK;
-}
-
 }  // namespace
 
 #define CRB_CONV_SHAPES(X_) \
@@ -498,6 +426,11 @@ extern "C" int crb_sparse_conv_supported(int cin, int cout) {
   CRB_CONV_SHAPES(X_)
 #undef X_
   return 0;
+}
+
+extern "C" int crb_sparse_conv_set_subtiles(int subt) {
+  g_subt_override = (subt == 1 || subt == 2 || subt == 4) ? subt : 0;
+  return CRB_OK;
 }
 
 extern "C" int crb_nbr_masks(const int32_t* nbr, int64_t n, int K, int32_t* mask, void* stream) {
@@ -516,23 +449,6 @@ extern "C" int crb_nbr_permute(const int32_t* nbr, const int32_t* perm, int64_t 
                      (int)n, K, nbr_sorted);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
-}
-
-// experimental variants (A/B measurements): 1/2 = direct kernel with 1/2 sub-tiles per wave; needs a K*cin*cout scratch
-extern "C" int crb_sparse_conv_forward_variant(const float* X, const float* W, const int32_t* nbr, const int32_t* perm,
-                                               float* Y, int64_t n_out, int K, int cin, int cout, int variant,
-                                               float* wfrag_scratch, void* stream) {
-  if (n_out < 0 || K <= 0 || K > 32 || !wfrag_scratch) return CRB_ERR_ARG;
-  if (n_out == 0) return CRB_OK;
-  hipStream_t st = (hipStream_t)stream;
-#define V_(a, b)                                                                                                    \
-  if (cin == a && cout == b) {                                                                                      \
-    if (variant == 1) return launch_fwd_direct<a, b, 1>(X, W, nbr, perm, Y, n_out, K, wfrag_scratch, st);            \
-    if (variant == 2) return launch_fwd_direct<a, b, 2>(X, W, nbr, perm, Y, n_out, K, wfrag_scratch, st);            \
-  }
-  V_(16, 16) V_(32, 32) V_(64, 64)
-#undef V_
-  return CRB_ERR_UNSUPPORTED;
 }
 
 extern "C" int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, const int32_t* perm, float* Y,

@@ -96,11 +96,8 @@ int crb_nbr_masks(const int32_t* nbr, int64_t n, int K, int32_t* mask, void* str
 int crb_nbr_permute(const int32_t* nbr, const int32_t* perm, int64_t n, int K, int32_t* nbr_sorted, void* stream);
 int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, const int32_t* perm, float* Y,
                             int64_t n_out, int K, int cin, int cout, void* stream);
-/* experimental kernel variants for A/B measurements (same result): variant 1/2 = barrier-free "direct" kernel with 1/2
- * sub-tiles per wave; wfrag_scratch: K*cin*cout floats */
-int crb_sparse_conv_forward_variant(const float* X, const float* W, const int32_t* nbr, const int32_t* perm,
-                                    float* Y, int64_t n_out, int K, int cin, int cout, int variant,
-                                    float* wfrag_scratch, void* stream);
+/* tuning knob for measurements: rows per workgroup = 64*subt (0 = built-in heuristic) */
+int crb_sparse_conv_set_subtiles(int subt);
 /* dW (K,cin,cout) = sum over pairs X[pin]^T dY[pout] */
 int crb_sparse_conv_wgrad_splits(void);
 int64_t crb_sparse_conv_wgrad_workspace_bytes(int K, int cin, int cout);

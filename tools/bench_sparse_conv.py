@@ -63,22 +63,20 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / args.iters * 1e3      # us
 
+        from crbhip import lib
+        ts = {}
+        for st_ in (1, 2, 4):
+            lib.crb_sparse_conv_set_subtiles(st_)
+            ts[st_] = timeit(lambda: sparse._conv_forward_raw(x, w, table, n))
+        lib.crb_sparse_conv_set_subtiles(0)
         t_f = timeit(lambda: sparse._conv_forward_raw(x, w, table, n))
-        ref = sparse._conv_forward_raw(x, w, table, n)
-        tv = {}
-        for v in (1, 2):
-            sparse.CONV_VARIANT = v
-            tv[v] = timeit(lambda: sparse._conv_forward_raw(x, w, table, n))
-            err = float((sparse._conv_forward_raw(x, w, table, n) - ref).abs().max())
-            tv[v] = (tv[v], err)
-        sparse.CONV_VARIANT = 0
         t_w = timeit(lambda: sparse._conv_wgrad_raw(x, dy, pairs, 27))
         balg = 4.0 * n * cin + 4.0 * n * cout + 8.0 * P + 4.0 * 27 * cin * cout
         fl = 2.0 * P * cin * cout
         print('L%d subm %dx%d N=%d P=%d (%.2f/row) | fwd %.1f us  %.0f GB/s alg (%.1f%% of 8TB/s)  %.1f TF | '
-              'wgrad %.1f us %.1f TF | direct1 %.1f us (err %.1e) direct2 %.1f us (err %.1e)' % (
+              'wgrad %.1f us %.1f TF' % (
                   lvl, cin, cout, n, P, P / n, t_f, balg / t_f / 1e3, balg / t_f / 1e3 / 80, fl / t_f / 1e6, t_w,
-                  fl / t_w / 1e6, tv[1][0], tv[1][1], tv[2][0], tv[2][1]), flush=True)
+                  fl / t_w / 1e6), 'subt1/2/4 %.1f %.1f %.1f us' % (ts[1], ts[2], ts[4]), flush=True)
 
 
 if __name__ == '__main__':
