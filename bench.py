@@ -39,6 +39,7 @@ def parse():
     ap.add_argument('--kind', default='kitti', choices=['kitti', 'waymo'])
     ap.add_argument('--pool', type=int, default=2, help='distinct resident batches cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--nchw', action='store_true', help='A/B: NCHW memory format for the dense BEV part')
     ap.add_argument('--cpu-frames', type=int, default=8)
     ap.add_argument('--scoring-frames', type=int, default=32,
                     help='frames per GPU for the CRB stage-1 scoring measurement (0 = skip)')
@@ -204,6 +205,9 @@ def main():
     from pcdet.model_cfgs import second_cfg
     from pcdet.models import build_network
 
+    if args.nchw:
+        from pcdet.models.backbones_2d.map_to_bev import height_compression
+        height_compression.CHANNELS_LAST = False
     torch.manual_seed(0)
     ds = SyntheticDataset(num_frames=args.batch, kind=args.kind, n_points=args.points)
     model = build_network(second_cfg(args.kind).MODEL, 3, ds).to(device)

@@ -71,11 +71,16 @@ def _mask_sort(table, K):
         return table, None
     mask = torch.empty((n,), dtype=torch.int32, device=dev)
     check(lib.crb_nbr_masks(ptr(table), n, K, ptr(mask), cur_stream(dev)), 'crb_nbr_masks')
-    if MASK_SORT_CHUNK > 0:
-        key = (torch.arange(n, device=dev, dtype=torch.int64) // MASK_SORT_CHUNK) * (1 << 32) + mask.long()
+    if MASK_SORT_CHUNK == lib.crb_mask_sort_chunk_rows():
+        perm = torch.empty((n,), dtype=torch.int32, device=dev)            # one LDS bitonic-sort workgroup per chunk
+        check(lib.crb_mask_sort_chunks(ptr(mask), n, ptr(perm), cur_stream(dev)), 'crb_mask_sort_chunks')
     else:
-        key = mask
-    perm = torch.sort(key, stable=True)[1].to(torch.int32)
+        if MASK_SORT_CHUNK > 0:
+            key = (torch.arange(n, device=dev, dtype=torch.int64) // MASK_SORT_CHUNK) * (1 << 32) + \
+                (mask.long() & 0xffffffff)
+        else:
+            key = mask.long() & 0xffffffff
+        perm = torch.sort(key, stable=True)[1].to(torch.int32)
     out = torch.empty_like(table)
     check(lib.crb_nbr_permute(ptr(table), ptr(perm), n, K, ptr(out), cur_stream(dev)), 'crb_nbr_permute')
     return out, perm
@@ -271,3 +276,41 @@ class ToDenseFunction(torch.autograd.Function):
 
 def to_dense(feat, coords, batch_size, shape):
     return ToDenseFunction.apply(feat, coords, batch_size, shape)
+
+
+class ToBEVChannelsLastFunction(torch.autograd.Function):
+    """HeightCompression in one step: (N,C) sparse rows -> (B, C*D, H, W) tensor in channels_last memory format"""
+
+    @staticmethod
+    def forward(ctx, feat, coords, batch_size, shape):
+        require_cuda(feat, coords)
+        feat = feat.contiguous().float()
+        n, C = feat.shape
+        D, H, W = [int(v) for v in shape]
+        out = torch.empty((batch_size, C * D, H, W), dtype=torch.float32, device=feat.device,
+                          memory_format=torch.channels_last)
+        check(lib.crb_sparse_to_dense_nhwc(ptr(feat), ptr(coords), ctypes_ptr(out), n, batch_size, C, D, H, W, 1,
+                                           cur_stream(feat.device)), 'crb_sparse_to_dense_nhwc')
+        ctx.save_for_backward(coords)
+        ctx.meta = (n, batch_size, C, D, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (coords,) = ctx.saved_tensors
+        n, B, C, D, H, W = ctx.meta
+        g = g.float().contiguous(memory_format=torch.channels_last)
+        df = torch.empty((n, C), dtype=torch.float32, device=g.device)
+        check(lib.crb_dense_to_sparse_nhwc(ctypes_ptr(g), ptr(coords), ptr(df), n, B, C, D, H, W, cur_stream(g.device)),
+              'crb_dense_to_sparse_nhwc')
+        return df, None, None, None
+
+
+def ctypes_ptr(t):
+    """data pointer of a tensor that is dense in SOME memory format (channels_last tensors are not .is_contiguous())"""
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def to_bev_channels_last(feat, coords, batch_size, shape):
+    return ToBEVChannelsLastFunction.apply(feat, coords, batch_size, shape)

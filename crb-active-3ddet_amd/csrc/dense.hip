@@ -67,7 +67,54 @@ __global__ __launch_bounds__(256) void dense_gather_kernel(const float* __restri
   }
 }
 
+// channels-last BEV layout (B, H, W, C*D), channel index c*D + z: what MIOpen's NHWC igemm kernels consume without the
+// NCHW<->NHWC transposes it otherwise inserts around them. One thread per (row, c): reads run along c, the C values of a
+// row land in one (C*D)-float span.
+__global__ __launch_bounds__(256) void dense_scatter_nhwc_kernel(const float* __restrict__ feat, const int* __restrict__ coords,
+                                                                 float* __restrict__ out, int64_t total, int C, int D, int H,
+                                                                 int W) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int64_t r = t / C;
+  const int c = (int)(t - r * C);
+  const int4 q = *reinterpret_cast<const int4*>(coords + r * 4);
+  out[((((int64_t)q.x * H + q.z) * W + q.w) * C + c) * D + q.y] = feat[t];
+}
+
+__global__ __launch_bounds__(256) void dense_gather_nhwc_kernel(const float* __restrict__ dense, const int* __restrict__ coords,
+                                                                float* __restrict__ feat, int64_t total, int C, int D, int H,
+                                                                int W) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int64_t r = t / C;
+  const int c = (int)(t - r * C);
+  const int4 q = *reinterpret_cast<const int4*>(coords + r * 4);
+  feat[t] = dense[((((int64_t)q.x * H + q.z) * W + q.w) * C + c) * D + q.y];
+}
+
 }  // namespace
+
+extern "C" int crb_sparse_to_dense_nhwc(const float* feat, const int32_t* coords, float* out, int64_t n, int B, int C,
+                                        int D, int H, int W, int zero_fill, void* stream) {
+  if (n < 0 || B <= 0 || C <= 0) return CRB_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (zero_fill) CRB_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C * D * H * W, st));
+  if (n == 0) return CRB_OK;
+  hipLaunchKernelGGL(dense_scatter_nhwc_kernel, dim3(crb_cdiv(n * C, 256)), dim3(256), 0, st, feat, coords, out, n * C, C,
+                     D, H, W);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_dense_to_sparse_nhwc(const float* dense, const int32_t* coords, float* feat, int64_t n, int B, int C,
+                                        int D, int H, int W, void* stream) {
+  if (n < 0 || B <= 0 || C <= 0) return CRB_ERR_ARG;
+  if (n == 0) return CRB_OK;
+  hipLaunchKernelGGL(dense_gather_nhwc_kernel, dim3(crb_cdiv(n * C, 256)), dim3(256), 0, (hipStream_t)stream, dense,
+                     coords, feat, n * C, C, D, H, W);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
 
 extern "C" int crb_sparse_to_dense(const float* feat, const int32_t* coords, float* out, int64_t n, int B, int C,
                                    int D, int H, int W, int zero_fill, void* stream) {

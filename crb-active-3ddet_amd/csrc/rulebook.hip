@@ -141,13 +141,23 @@ __global__ __launch_bounds__(256) void spconv_nbr_kernel(const int* __restrict__
 }
 
 // pair lists: flattened offset-major index f = o*n_out + i
+// flags are read from the per-row neighbour bit-mask (coalesced along rows for a fixed offset); reading nbr[i*K+o]
+// directly in offset-major order is a stride-K access and made this scan the most expensive rulebook kernel
 struct PairFlag {
-  const int* nbr; int n_out; int K;
+  const unsigned* mask; int n_out;
   __device__ int operator()(int64_t f) const {
     int o = (int)(f / n_out); int i = (int)(f - (int64_t)o * n_out);
-    return nbr[(int64_t)i * K + o] >= 0 ? 1 : 0;
+    return (int)((mask[i] >> o) & 1u);
   }
 };
+
+__global__ __launch_bounds__(256) void row_mask_kernel(const int* __restrict__ nbr, int n, int K, unsigned* __restrict__ mask) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  unsigned m = 0;
+  for (int o = 0; o < K; ++o) m |= (nbr[(int64_t)i * K + o] >= 0 ? 1u : 0u) << o;
+  mask[i] = m;
+}
 struct PairWrite {
   const int* nbr; int n_out; int K; int* pin; int* pout; int* pstart;
   __device__ void operator()(int64_t f, int ex, int v) const {
@@ -162,7 +172,49 @@ __global__ void fill_i32_kernel(int* p, int64_t n, int v) {
   if (i < n) p[i] = v;
 }
 
+// Sort the rows of every chunk of SORT_CHUNK consecutive rows by their neighbour mask (stable: ties keep row order).
+// One 1024-thread workgroup per chunk; bitonic network on 64-bit (mask << 32 | local index) keys in LDS.
+constexpr int SORT_CHUNK = 4096;
+
+__global__ __launch_bounds__(1024) void mask_sort_chunks_kernel(const int* __restrict__ mask, int n, int* __restrict__ perm) {
+  __shared__ unsigned long long key[SORT_CHUNK];
+  const int base = blockIdx.x * SORT_CHUNK;
+  for (int t = threadIdx.x; t < SORT_CHUNK; t += 1024) {
+    const int i = base + t;
+    key[t] = (i < n) ? (((unsigned long long)(unsigned)mask[i] << 32) | (unsigned)t) : ~0ULL;
+  }
+  __syncthreads();
+  for (int k = 2; k <= SORT_CHUNK; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < SORT_CHUNK / 2; t += 1024) {
+        // t-th compare-exchange of this stage: partners (i, i^j) with i the one whose bit j is clear
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int p = i | j;
+        const bool up = (i & k) == 0;
+        const unsigned long long a = key[i], b = key[p];
+        if ((a > b) == up) { key[i] = b; key[p] = a; }
+      }
+      __syncthreads();
+    }
+  for (int t = threadIdx.x; t < SORT_CHUNK; t += 1024) {
+    const int i = base + t;
+    if (i < n) perm[i] = base + (int)(key[t] & 0xffffffffULL);
+  }
+}
+
 }  // namespace
+
+extern "C" int crb_mask_sort_chunk_rows(void) { return SORT_CHUNK; }
+
+// perm (n) i32: row permutation that sorts every chunk of crb_mask_sort_chunk_rows() consecutive rows by mask (stable)
+extern "C" int crb_mask_sort_chunks(const int32_t* mask, int64_t n, int32_t* perm, void* stream) {
+  if (n < 0) return CRB_ERR_ARG;
+  if (n == 0) return CRB_OK;
+  hipLaunchKernelGGL(mask_sort_chunks_kernel, dim3(crb_cdiv(n, SORT_CHUNK)), dim3(1024), 0, (hipStream_t)stream, mask,
+                     (int)n, perm);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
 
 extern "C" int64_t crb_hash_capacity_for(int64_t n) { return crb_hash_capacity(n); }
 
@@ -250,7 +302,7 @@ extern "C" int crb_spconv_rulebook(const int32_t* coords, int64_t n, int B, cons
 }
 
 extern "C" int64_t crb_pairs_workspace_bytes(int64_t n_out, int K) {
-  return crb_align_up((int64_t)crb_scan_num_tiles(n_out * K) * 4, 256) + 256;
+  return crb_align_up((int64_t)crb_scan_num_tiles(n_out * K) * 4, 256) + crb_align_up(n_out * 4, 256) + 256;
 }
 
 // Classic rulebook (pair lists sorted by (offset, output row)) from the output-stationary table.
@@ -264,8 +316,11 @@ extern "C" int crb_pairs_from_nbr(const int32_t* nbr, int64_t n_out, int K, int3
   if (n_out * K > 0x7fffffffLL) return CRB_ERR_ARG;
   CrbArena a(workspace, (size_t)workspace_bytes);
   int* tiles = a.take<int>(crb_scan_num_tiles(n_out * K));
+  unsigned* mask = a.take<unsigned>(n_out);
   if (!a.ok) return CRB_ERR_WORKSPACE;
-  PairFlag f{nbr, (int)n_out, K};
+  if (K > 32) return CRB_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(row_mask_kernel, dim3(crb_cdiv(n_out, 256)), dim3(256), 0, st, nbr, (int)n_out, K, mask);
+  PairFlag f{mask, (int)n_out};
   PairWrite w{nbr, (int)n_out, K, pair_in, pair_out, pair_start};
   return crb_device_excl_scan(f, w, n_out * K, tiles, pair_start + K, st);
 }

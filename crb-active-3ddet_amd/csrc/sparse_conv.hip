@@ -388,13 +388,10 @@ int launch_fwd_subt(const float* X, const float* W, const int* nbr, const int* p
 template <int CIN, int COUT>
 int launch_fwd(const float* X, const float* W, const int* nbr, const int* perm, float* Y, int64_t n_out, int K,
                hipStream_t st) {
-  // rows per workgroup: as many as keep >= ~3 workgroups per CU (256 CUs); wide layers gain most from W reuse
-  int subt = 1;
-  if constexpr (CIN >= 32 && COUT <= 64) {
-    if (n_out >= 64 * 4 * 768) subt = 4;
-    else if (n_out >= 64 * 2 * 768) subt = 2;
-  }
-  if (g_subt_override) subt = g_subt_override;
+  // rows per workgroup = 64*subt. Measured on the SECOND bs=16 geometry (tools/bench_sparse_conv.py): subt 1/2/4 =
+  // 221/258/343 us at C=64, 96/115/160 us at C=32 — the kernel is latency-, not W-traffic-bound, so more, smaller
+  // workgroups win. subt > 1 stays available for measurements only.
+  int subt = g_subt_override ? g_subt_override : 1;
   if constexpr (CIN >= 16 && COUT <= 64) {
     if (subt == 4) return launch_fwd_subt<CIN, COUT, 4>(X, W, nbr, perm, Y, n_out, K, st);
     if (subt == 2) return launch_fwd_subt<CIN, COUT, 2>(X, W, nbr, perm, Y, n_out, K, st);

@@ -48,6 +48,13 @@ class Detector3DTemplate(nn.Module):
         for name in self.module_topology:
             module, info = getattr(self, 'build_%s' % name)(model_info_dict=info)
             self.add_module(name, module)
+        from ..backbones_2d.map_to_bev import height_compression
+        if height_compression.CHANNELS_LAST:
+            import torch as _torch
+            for name in ('backbone_2d', 'dense_head'):      # the dense 2-D part runs NHWC end to end
+                m = getattr(self, name, None)
+                if m is not None:
+                    m.to(memory_format=_torch.channels_last)
         return info['module_list']
 
     def build_vfe(self, model_info_dict):

@@ -93,6 +93,9 @@ int crb_pairs_from_nbr(const int32_t* nbr, int64_t n_out, int K, int32_t* pair_i
  * (crb_nbr_masks -> sort -> crb_nbr_permute) lets a wave skip every kernel offset none of its 16 rows uses. */
 int crb_sparse_conv_supported(int cin, int cout);
 int crb_nbr_masks(const int32_t* nbr, int64_t n, int K, int32_t* mask, void* stream);
+/* stable sort of the rows of every chunk of crb_mask_sort_chunk_rows() consecutive rows by mask -> perm (n) */
+int crb_mask_sort_chunk_rows(void);
+int crb_mask_sort_chunks(const int32_t* mask, int64_t n, int32_t* perm, void* stream);
 int crb_nbr_permute(const int32_t* nbr, const int32_t* perm, int64_t n, int K, int32_t* nbr_sorted, void* stream);
 int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, const int32_t* perm, float* Y,
                             int64_t n_out, int K, int cin, int cout, void* stream);
@@ -115,6 +118,12 @@ int crb_sparse_to_dense(const float* feat, const int32_t* coords, float* out, in
                         int D, int H, int W, int zero_fill, void* stream);
 int crb_dense_to_sparse(const float* dense, const int32_t* coords, float* feat, int64_t n, int B, int C,
                         int D, int H, int W, void* stream);
+/* same, BEV channels-last memory: out is (B, H, W, C*D) with channel index c*D + z — the layout of a
+ * torch (B, C*D, H, W) tensor in channels_last format, i.e. HeightCompression's view without NCHW<->NHWC transposes */
+int crb_sparse_to_dense_nhwc(const float* feat, const int32_t* coords, float* out, int64_t n, int B, int C,
+                             int D, int H, int W, int zero_fill, void* stream);
+int crb_dense_to_sparse_nhwc(const float* dense, const int32_t* coords, float* feat, int64_t n, int B, int C,
+                             int D, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a13/a14  rotated BEV overlap / IoU / 3-D IoU and NMS

@@ -194,3 +194,37 @@ def test_spconv_module_api_backbone_chain(dev):
                                          'spconv_down2'}
     d = x.dense()
     assert d.shape == (2, 128, 2, 200, 176)
+
+
+def test_chunk_mask_sort_is_a_stable_sort_per_chunk(dev):
+    """the LDS bitonic chunk sort equals a stable sort by (chunk, unsigned mask) — the gather-GEMM result does not depend
+    on it, the MFMA skipping efficiency does"""
+    from crbhip import lib, check, ptr, cur_stream
+    rng = np.random.default_rng(3)
+    for n in (1, 100, 4096, 4097, 50000):
+        mask = rng.integers(0, 1 << 27, n).astype(np.int32)
+        mask[rng.random(n) < 0.5] = 7                         # many ties
+        m = _t(mask, dev)
+        perm = torch.empty(n, dtype=torch.int32, device=dev)
+        check(lib.crb_mask_sort_chunks(ptr(m), n, ptr(perm), cur_stream(dev)), 'sort')
+        chunk = lib.crb_mask_sort_chunk_rows()
+        key = (np.arange(n) // chunk).astype(np.int64) * (1 << 32) + mask.astype(np.int64)
+        np.testing.assert_array_equal(perm.cpu().numpy(), np.argsort(key, kind='stable'))
+
+
+def test_bev_channels_last_scatter_equals_dense_view(dev):
+    from crbhip import sparse
+    rng = np.random.default_rng(6)
+    shape = [2, 200, 176]
+    coords = random_sparse_coords(rng, 7000, 3, shape)
+    F_ = rng.normal(size=(len(coords), 128)).astype(np.float32)
+    f1 = _t(F_, dev).requires_grad_(True)
+    f2 = _t(F_, dev).requires_grad_(True)
+    a = sparse.to_bev_channels_last(f1, _t(coords, dev), 3, shape)
+    b = sparse.to_dense(f2, _t(coords, dev), 3, shape).view(3, 256, 200, 176)
+    assert a.is_contiguous(memory_format=torch.channels_last) and a.shape == b.shape
+    assert torch.equal(a, b)
+    g = torch.randn_like(b)
+    a.backward(g)
+    b.backward(g)
+    assert torch.equal(f1.grad, f2.grad)
