@@ -1,0 +1,187 @@
+// Fused BatchNorm1d (+ReLU) over the rows of a sparse tensor (row a5 of SURVEY §8).
+// Replaces the separate nn.BatchNorm1d(eps=1e-3, momentum=0.01) + nn.ReLU passes that follow every sparse conv in
+// pcdet/models/backbones_3d/spconv_backbone.py:21-25,73 (stats pass, normalise pass, ReLU pass forward; ReLU backward,
+// BN reduce, BN apply backward): here forward = 1 stats pass + 1 apply pass, backward = 1 reduce pass + 1 apply pass.
+//   forward : mean_c, var_c (biased) over rows;  z = relu(gamma * (x - mean) * rsqrt(var + eps) + beta)
+//   backward: d = dz * [z > 0]; dbeta = sum d; dgamma = sum d * xhat;  dx = gamma * invstd * (d - dbeta/N - xhat * dgamma/N)
+// Layout: x (N, C) row-major, C in {16, 32, 64, 128, ...} (multiple of 4). A 256-thread workgroup is (256/TC) row lanes x TC
+// channel lanes (TC = min(C,256)/4 float4 columns); per-block partials are reduced in double by a second tiny kernel
+// (fixed order: deterministic).
+#include "crb_common.h"
+#include "../../include/crb_hip.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 2048;
+
+// partial[(blk * 2 + which) * C + c]; which 0: sum a, 1: sum b
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int64_t n, int C, int relu, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f4* red = reinterpret_cast<f4*>(smem);               // 2 * 256 f4
+  const int c4n = C >> 2;                              // float4 columns
+  const int tc = threadIdx.x % c4n, tr = threadIdx.x / c4n;
+  const int rlanes = 256 / c4n;
+  const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+  const int64_t r1 = min(n, r0 + ROWS_PER_BLOCK);
+  f4 a = (f4){0, 0, 0, 0}, b = (f4){0, 0, 0, 0};
+  f4 mu, is, ga, be;
+  if (BWD) {
+    mu = *reinterpret_cast<const f4*>(mean + tc * 4);
+    is = *reinterpret_cast<const f4*>(invstd + tc * 4);
+    ga = *reinterpret_cast<const f4*>(gamma + tc * 4);
+    be = *reinterpret_cast<const f4*>(beta + tc * 4);
+  }
+  if (tr < rlanes)
+    for (int64_t r = r0 + tr; r < r1; r += rlanes) {
+      const f4 v = *reinterpret_cast<const f4*>(x + r * C + tc * 4);
+      if (!BWD) {
+        a += v;
+        b += v * v;
+      } else {
+        const f4 xh = (v - mu) * is;
+        f4 d = *reinterpret_cast<const f4*>(dz + r * C + tc * 4);
+        if (relu) {
+          const f4 z = ga * xh + be;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) d[k] = z[k] > 0.f ? d[k] : 0.f;
+        }
+        a += d;
+        b += d * xh;
+      }
+    }
+  red[threadIdx.x] = a;
+  red[256 + threadIdx.x] = b;
+  __syncthreads();
+  if (tr == 0) {
+    for (int k = 1; k < rlanes; ++k) { a += red[k * c4n + tc]; b += red[256 + k * c4n + tc]; }
+    *reinterpret_cast<f4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * C + tc * 4) = a;
+    *reinterpret_cast<f4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * C + tc * 4) = b;
+  }
+}
+
+// forward finalize: mean, biased var, invstd ; backward finalize: dbeta, dgamma
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int64_t n, float eps, int bwd,
+                                   float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < nblk; ++k) {
+    a += (double)partial[((int64_t)k * 2 + 0) * C + c];
+    b += (double)partial[((int64_t)k * 2 + 1) * C + c];
+  }
+  if (!bwd) {
+    const double m = a / (double)n;
+    double v = b / (double)n - m * m;
+    if (v < 0.0) v = 0.0;
+    o0[c] = (float)m;
+    o1[c] = (float)v;
+    o2[c] = (float)(1.0 / sqrt(v + (double)eps));
+  } else {
+    o0[c] = (float)a;      // dbeta
+    o1[c] = (float)b;      // dgamma
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ z, int64_t total4,
+                                                       int C, int relu) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total4) return;
+  const int c = (int)((t * 4) % C);
+  const f4 v = *reinterpret_cast<const f4*>(x + t * 4);
+  const f4 mu = *reinterpret_cast<const f4*>(mean + c), is = *reinterpret_cast<const f4*>(invstd + c);
+  const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
+  f4 o = ga * ((v - mu) * is) + be;
+  if (relu) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = o[k] > 0.f ? o[k] : 0.f;
+  }
+  *reinterpret_cast<f4*>(z + t * 4) = o;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ dbeta, const float* __restrict__ dgamma,
+                                                           float* __restrict__ dx, int64_t total4, int C, float inv_n,
+                                                           int relu) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total4) return;
+  const int c = (int)((t * 4) % C);
+  const f4 v = *reinterpret_cast<const f4*>(x + t * 4);
+  f4 d = *reinterpret_cast<const f4*>(dz + t * 4);
+  const f4 mu = *reinterpret_cast<const f4*>(mean + c), is = *reinterpret_cast<const f4*>(invstd + c);
+  const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
+  const f4 db = *reinterpret_cast<const f4*>(dbeta + c), dg = *reinterpret_cast<const f4*>(dgamma + c);
+  const f4 xh = (v - mu) * is;
+  if (relu) {
+    const f4 z = ga * xh + be;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = z[k] > 0.f ? d[k] : 0.f;
+  }
+  *reinterpret_cast<f4*>(dx + t * 4) = ga * is * (d - db * inv_n - xh * (dg * inv_n));
+}
+
+}  // namespace
+
+static inline int bn_blocks(int64_t n) { return crb_cdiv(n, ROWS_PER_BLOCK); }
+
+extern "C" int64_t crb_bn_workspace_bytes(int64_t n, int C) { return (int64_t)bn_blocks(n) * 2 * C * 4 + 256; }
+
+// training forward. mean/var/invstd (C) out. z may alias x? no: x is kept for backward.
+extern "C" int crb_bn_relu_forward(const float* x, int64_t n, int C, const float* gamma, const float* beta, float eps,
+                                   int relu, float* z, float* mean, float* var, float* invstd, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+  if (n <= 0 || C <= 0 || (C & 3) || C > 1024 || (256 % (C >> 2) && (C >> 2) < 256)) return CRB_ERR_ARG;
+  if (workspace_bytes < crb_bn_workspace_bytes(n, C) - 256 || !workspace) return CRB_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = bn_blocks(n);
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(nblk), dim3(256), 2 * 256 * 16, st, x, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, n, C, relu, partial);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 64)), dim3(64), 0, st, partial, nblk, C, n, eps, 0, mean, var,
+                     invstd);
+  const int64_t total4 = n * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, z,
+                     total4, C, relu);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+// inference forward with given statistics (mean, invstd)
+extern "C" int crb_bn_relu_apply(const float* x, int64_t n, int C, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, int relu, float* z, void* stream) {
+  if (n < 0 || C <= 0 || (C & 3)) return CRB_ERR_ARG;
+  if (n == 0) return CRB_OK;
+  const int64_t total4 = n * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd,
+                     gamma, beta, z, total4, C, relu);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_bn_relu_backward(const float* x, const float* dz, int64_t n, int C, const float* mean,
+                                    const float* invstd, const float* gamma, const float* beta, int relu, float* dx,
+                                    float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (n <= 0 || C <= 0 || (C & 3) || C > 1024 || (256 % (C >> 2) && (C >> 2) < 256)) return CRB_ERR_ARG;
+  if (workspace_bytes < crb_bn_workspace_bytes(n, C) - 256 || !workspace) return CRB_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = bn_blocks(n);
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL(bn_partial_kernel<true>, dim3(nblk), dim3(256), 2 * 256 * 16, st, x, dz, mean, invstd, gamma, beta, n,
+                     C, relu, partial);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 64)), dim3(64), 0, st, partial, nblk, C, n, 0.f, 1, dbeta, dgamma,
+                     (float*)nullptr);
+  const int64_t total4 = n * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, dz, mean, invstd, gamma, beta,
+                     dbeta, dgamma, dx, total4, C, 1.0f / (float)n, relu);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}

@@ -4,7 +4,11 @@ from collections import OrderedDict
 
 from torch import nn
 
+from crbhip import bnrelu as _bnrelu
 from .core import SparseConvTensor
+
+FUSE_BN_RELU = True      # run BatchNorm1d -> ReLU pairs that follow a sparse conv as one fused HIP op (same modules,
+                         # same parameters / buffers / state_dict; set False for the plain torch path)
 
 
 class SparseModule(nn.Module):
@@ -51,14 +55,23 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for k, module in self._modules.items():
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            module = mods[i]
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
                 input = module(input)
+            elif isinstance(input, SparseConvTensor):
+                if input.indices.shape[0] != 0:
+                    feats = input.features
+                    if (FUSE_BN_RELU and isinstance(module, nn.BatchNorm1d) and i + 1 < len(mods) and
+                            isinstance(mods[i + 1], nn.ReLU) and _bnrelu.supported(feats, module)):
+                        input = input.replace_feature(_bnrelu.bn_relu(feats, module, relu=True))
+                        i += 1                      # the ReLU module was consumed by the fused op
+                    else:
+                        input = input.replace_feature(module(feats))
             else:
-                if isinstance(input, SparseConvTensor):
-                    if input.indices.shape[0] != 0:
-                        input = input.replace_feature(module(input.features))
-                else:
-                    input = module(input)
+                input = module(input)
+            i += 1
         return input

@@ -228,3 +228,35 @@ def test_bev_channels_last_scatter_equals_dense_view(dev):
     a.backward(g)
     b.backward(g)
     assert torch.equal(f1.grad, f2.grad)
+
+
+@pytest.mark.parametrize('C,n', [(16, 50000), (32, 4097), (64, 2), (128, 30000)])
+def test_fused_bn_relu_matches_torch(dev, C, n):
+    """fused BatchNorm1d+ReLU (crb_bn_relu_*) vs nn.BatchNorm1d(eps=1e-3, momentum=0.01) + nn.ReLU: outputs, input /
+    affine grads and the running statistics; rtol 1e-4 (two-pass float vs torch's Welford)"""
+    from crbhip import bnrelu
+    torch.manual_seed(C + n)
+    x = (torch.randn(n, C, device=dev) * 3 + 1.5)
+    dz = torch.randn(n, C, device=dev)
+    bn_a = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).to(dev)
+    bn_b = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).to(dev)
+    with torch.no_grad():
+        bn_a.weight.uniform_(0.5, 1.5)
+        bn_a.bias.uniform_(-0.5, 0.5)
+        bn_b.load_state_dict(bn_a.state_dict())
+    xa = x.clone().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    za = bnrelu.bn_relu(xa, bn_a, relu=True)
+    zb = torch.relu(bn_b(xb))
+    torch.testing.assert_close(za, zb, rtol=1e-4, atol=1e-4)
+    za.backward(dz)
+    zb.backward(dz)
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(bn_a.weight.grad, bn_b.weight.grad, rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(bn_a.bias.grad, bn_b.bias.grad, rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(bn_a.running_mean, bn_b.running_mean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(bn_a.running_var, bn_b.running_var, rtol=1e-4, atol=1e-5)
+    assert int(bn_a.num_batches_tracked) == 1
+    bn_a.eval(); bn_b.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(bnrelu.bn_relu(x, bn_a), torch.relu(bn_b(x)), rtol=1e-5, atol=1e-5)
