@@ -21,7 +21,7 @@ class CrbHipError(RuntimeError):
 
 _ERR = {-1: 'CRB_ERR_ARG', -2: 'CRB_ERR_WORKSPACE', -3: 'CRB_ERR_LAUNCH', -4: 'CRB_ERR_UNSUPPORTED'}
 
-_CT = {'int': ctypes.c_int, 'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float,
+_CT = {'uint8_t': ctypes.c_uint8, 'int': ctypes.c_int, 'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float,
        'double': ctypes.c_double, 'uint32_t': ctypes.c_uint32, 'void': None}
 
 

@@ -13,7 +13,10 @@ Only the POS_FRACTION < 0 (no sampling) branch used by every shipped SECOND / PV
 import numpy as np
 import torch
 
+from crbhip import lib, check, ptr, cur_stream
 from ....utils import box_utils
+
+FUSED = True      # use the two-launch HIP assigner (crb_assign_targets) for device tensors; False = batched torch ops
 
 
 class AxisAlignedTargetAssigner(object):
@@ -38,6 +41,8 @@ class AxisAlignedTargetAssigner(object):
         """all_anchors: [(nz,ny,nx,S,R,7) per class]; gt (B,G,8) zero padded, last column class id 1..C
         -> box_cls_labels (B,A) int32, box_reg_targets (B,A,code), reg_weights (B,A); A ordered (z,y,x,class,size,rot)"""
         gt = gt_boxes_with_classes
+        if FUSED and gt.is_cuda and self.box_coder.code_size == 7 and not self.norm_by_num_examples:
+            return self.assign_targets_fused(all_anchors, gt)
         B, G = gt.shape[0], gt.shape[1]
         gt_boxes, gt_cls = gt[..., :-1], gt[..., -1]
         # valid = everything up to the last non-zero row (axis_aligned_target_assigner.py:54-58; row 0 always kept)
@@ -61,6 +66,52 @@ class AxisAlignedTargetAssigner(object):
             'box_reg_targets': torch.cat(targets_l, dim=-2).view(B, -1, self.box_coder.code_size),
             'reg_weights': torch.cat(weights_l, dim=-1).view(B, -1),
         }
+
+    def _fused_constants(self, all_anchors):
+        key = (all_anchors[0].device, all_anchors[0].data_ptr())
+        if getattr(self, '_fused_key', None) != key:
+            dev = all_anchors[0].device
+            flat = torch.cat(all_anchors, dim=-3)                       # (nz,ny,nx, sum S, R, 7)
+            per = [a.shape[3] * a.shape[4] for a in all_anchors]
+            ids = [int(np.nonzero(self.class_names == n)[0][0]) + 1 for n in self.anchor_class_names]
+            pattern = torch.tensor(sum([[i] * (a.shape[4]) * a.shape[3] for i, a in zip(ids, all_anchors)], []),
+                                   dtype=torch.int32)
+            # flattened order is (.., class*size, rot): class id of slot s = ids[s // R] for equal R per class
+            R = all_anchors[0].shape[4]
+            slots = torch.tensor(sum([[i] * a.shape[3] for i, a in zip(ids, all_anchors)], []), dtype=torch.int32)
+            cls_of = slots.repeat_interleave(R)                          # (sum S * R)
+            A = flat.numel() // 7
+            anchor_cls = cls_of.repeat(A // cls_of.numel()).to(dev)
+            nmax = max(ids) + 1
+            m = torch.zeros(nmax, dtype=torch.float32)
+            u = torch.zeros(nmax, dtype=torch.float32)
+            for i, n in zip(ids, self.anchor_class_names):
+                m[i] = self.matched_thresholds[n]
+                u[i] = self.unmatched_thresholds[n]
+            self._fused = (flat.reshape(-1, 7).contiguous(), anchor_cls.contiguous(), m.to(dev), u.to(dev))
+            self._fused_key = key
+        return self._fused
+
+    def assign_targets_fused(self, all_anchors, gt):
+        """same outputs as the batched torch path, two HIP launches (csrc/target_assign.hip)"""
+        anchors, anchor_cls, m, u = self._fused_constants(all_anchors)
+        B, G = gt.shape[0], gt.shape[1]
+        A = anchors.shape[0]
+        dev = gt.device
+        gtc = gt.contiguous().float()
+        nonzero = gtc[..., :-1].sum(-1) != 0
+        idx = torch.arange(G, device=dev).view(1, G)
+        last = torch.where(nonzero, idx, torch.zeros_like(idx)).max(dim=1, keepdim=True)[0]
+        valid = (idx <= last).to(torch.uint8).contiguous()
+        labels = torch.empty((B, A), dtype=torch.int32, device=dev)
+        targets = torch.empty((B, A, 7), dtype=torch.float32, device=dev)
+        weights = torch.empty((B, A), dtype=torch.float32, device=dev)
+        wsb = lib.crb_assign_targets_workspace_bytes(B, A, G)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        check(lib.crb_assign_targets(ptr(anchors), ptr(anchor_cls), A, ptr(gtc), ptr(valid), B, G, ptr(m), ptr(u),
+                                     ptr(labels), ptr(targets), ptr(weights), ptr(ws), wsb, cur_stream(dev)),
+              'crb_assign_targets')
+        return {'box_cls_labels': labels, 'box_reg_targets': targets, 'reg_weights': weights}
 
     def assign_targets_batched(self, anchors, gt_boxes, gt_mask, class_id, matched_threshold, unmatched_threshold):
         """anchors (A,7); gt_boxes (B,G,7); gt_mask (B,G) -> labels (B,A) i32, targets (B,A,code), reg_weights (B,A)"""

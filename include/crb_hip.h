@@ -222,6 +222,21 @@ int crb_bn_relu_backward(const float* x, const float* dz, int64_t n, int C, cons
                          const float* invstd, const float* gamma, const float* beta, int relu, float* dx,
                          float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * a10  anchor target assignment (nearest-BEV IoU + thresholds + residual box encoding)
+ * replaces: AxisAlignedTargetAssigner.assign_targets (pcdet/models/dense_heads/target_assigner/
+ *           axis_aligned_target_assigner.py:36-210), box_utils.boxes3d_nearest_bev_iou (pcdet/utils/box_utils.py:272-298),
+ *           ResidualCoder.encode_torch (pcdet/utils/box_coder_utils.py:13-43); POS_FRACTION < 0 branch, single head.
+ * anchors (A,7) in the head's flattened order with anchor_cls (A) i32 (1-based class); gt_boxes (B,G,8) zero padded,
+ * gt_valid (B,G) u8; matched_thr / unmatched_thr: device f32 arrays indexed by class id (entry 0 unused).
+ * out: labels (B,A) i32 {-1,0,class}, reg_targets (B,A,7), reg_weights (B,A).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t crb_assign_targets_workspace_bytes(int B, int A, int G);
+int crb_assign_targets(const float* anchors, const int32_t* anchor_cls, int A, const float* gt_boxes,
+                       const uint8_t* gt_valid, int B, int G, const float* matched_thr,
+                       const float* unmatched_thr, int32_t* labels, float* reg_targets, float* reg_weights,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
