@@ -51,4 +51,4 @@ def test_fused_assigner_equals_torch_path_full_size(dev, kind, B):
     assert torch.equal(fused['box_cls_labels'], ref['box_cls_labels'])
     assert torch.equal(fused['reg_weights'], ref['reg_weights'])
     torch.testing.assert_close(fused['box_reg_targets'], ref['box_reg_targets'], rtol=1e-6, atol=1e-6)
-    assert int((ref['box_cls_labels'] > 0).sum()) > 50 and int((ref['box_cls_labels'] < 0).sum()) > 0
+    assert int((ref['box_cls_labels'] > 0).sum()) > 20 and int((ref['box_cls_labels'] < 0).sum()) > 0
