@@ -194,11 +194,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    ndev = torch.cuda.device_count()
+    dev_idx = local_rank % ndev          # one process per GPU; the modulo only matters for the single-GPU gloo dry run
+    torch.cuda.set_device(dev_idx)
+    device = torch.device('cuda', dev_idx)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=device)    # RCCL over xGMI
+        backend = os.environ.get('CRB_DIST_BACKEND', 'nccl')          # 'nccl' = RCCL over xGMI
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     from crbhip import sparse as sp
     from pcdet.datasets import SyntheticDataset
@@ -215,7 +221,7 @@ def main():
     opt = torch.optim.AdamW(model.parameters(), lr=3e-3, weight_decay=0.01, betas=(0.9, 0.99))
     net = model
     if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True)
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_idx], gradient_as_bucket_view=True)
     batches = make_batches(args, rank, device)
 
     def step(i):

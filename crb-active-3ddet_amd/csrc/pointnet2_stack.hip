@@ -128,9 +128,12 @@ __global__ __launch_bounds__(256) void group_points_grad_kernel(int B, int M, in
 //   larger running distance first; then smaller bit-reversed (k mod bs) (its LDS tree keeps the lower-position operand
 //   on ties); then smaller k (each strided thread keeps its first maximum). bs = min(2^floor(log2 n), 1024).
 constexpr int FPS_THREADS = 1024;
-constexpr int FPS_MAX_PER_THREAD = 40;    // up to 40960 points per frame held in registers
+constexpr int FPS_MAX_PER_THREAD = 80;    // up to 81920 points per frame
 
-template <int PPT>
+// REGS: point coordinates live in registers for the whole run (n <= 20480); otherwise they are re-read (coalesced, L2
+// resident) every round and only the running distances stay in registers. The tie key is built once per thread per
+// round from its best index (a per-point key array spilled the 128-VGPR budget of a 1024-thread workgroup).
+template <int PPT, bool REGS>
 __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, int log2bs, const float* __restrict__ xyz_all,
                                                           int* __restrict__ out_all) {
   __shared__ unsigned long long wave_best[16];
@@ -138,19 +141,14 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, int log2
   const float* xyz = xyz_all + (int64_t)blockIdx.x * n * 3;
   int* out = out_all + (int64_t)blockIdx.x * m;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float px[PPT], py[PPT], pz[PPT], dist[PPT];
-  unsigned tie[PPT];
+  float px[REGS ? PPT : 1], py[REGS ? PPT : 1], pz[REGS ? PPT : 1], dist[PPT];
   const unsigned bsmask = (1u << log2bs) - 1u;
 #pragma unroll
   for (int t = 0; t < PPT; ++t) {
     const int k = tid + t * FPS_THREADS;
-    if (k < n) {
-      px[t] = xyz[k * 3 + 0]; py[t] = xyz[k * 3 + 1]; pz[t] = xyz[k * 3 + 2];
-      unsigned v = (unsigned)k & bsmask;
-      unsigned br = log2bs ? (__brev(v) >> (32 - log2bs)) : 0u;
-      tie[t] = 0xffffffffu - ((br << 20) | (unsigned)k);      // larger = preferred
-    } else {
-      px[t] = py[t] = pz[t] = 0.f; tie[t] = 0u;
+    if (REGS) {
+      const bool in = k < n;
+      px[t] = in ? xyz[k * 3 + 0] : 0.f; py[t] = in ? xyz[k * 3 + 1] : 0.f; pz[t] = in ? xyz[k * 3 + 2] : 0.f;
     }
     dist[t] = 1e10f;
   }
@@ -158,18 +156,27 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, int log2
   __syncthreads();
   for (int j = 1; j < m; ++j) {
     const float x1 = sel_xyz[0], y1 = sel_xyz[1], z1 = sel_xyz[2];
-    unsigned long long best = 0ULL;
+    float bestd = -1.f;
+    int bestk = 0;
 #pragma unroll
     for (int t = 0; t < PPT; ++t) {
       const int k = tid + t * FPS_THREADS;
       if (k < n) {
-        float dx = px[t] - x1, dy = py[t] - y1, dz = pz[t] - z1;
-        float d = dx * dx + dy * dy + dz * dz;
-        float d2 = fminf(d, dist[t]);
+        float x2, y2, z2;
+        if (REGS) { x2 = px[t]; y2 = py[t]; z2 = pz[t]; }
+        else { x2 = xyz[k * 3 + 0]; y2 = xyz[k * 3 + 1]; z2 = xyz[k * 3 + 2]; }
+        const float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+        const float d = dx * dx + dy * dy + dz * dz;
+        const float d2 = fminf(d, dist[t]);
         dist[t] = d2;
-        unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | tie[t];
-        best = key > best ? key : best;
+        if (d2 > bestd) { bestd = d2; bestk = k; }     // strict: the first maximum of the strided thread wins
       }
+    }
+    unsigned long long best = 0ULL;
+    if (bestd >= 0.f) {
+      const unsigned v = (unsigned)bestk & bsmask;
+      const unsigned br = log2bs ? (__brev(v) >> (32 - log2bs)) : 0u;
+      best = ((unsigned long long)__float_as_uint(bestd) << 32) | (0xffffffffu - ((br << 20) | (unsigned)bestk));
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) {
@@ -244,9 +251,9 @@ __global__ __launch_bounds__(256) void three_interp_grad_kernel(int N, int C, co
   atomicAdd(&grad_feat[(int64_t)id[2] * C + c], g * ww[2]);
 }
 
-template <int PPT>
+template <int PPT, bool REGS>
 void launch_fps(int B, int n, int m, int log2bs, const float* xyz, int* out, hipStream_t st) {
-  hipLaunchKernelGGL((fps_kernel<PPT>), dim3(B), dim3(FPS_THREADS), 0, st, n, m, log2bs, xyz, out);
+  hipLaunchKernelGGL((fps_kernel<PPT, REGS>), dim3(B), dim3(FPS_THREADS), 0, st, n, m, log2bs, xyz, out);
 }
 
 }  // namespace
@@ -297,10 +304,11 @@ extern "C" int crb_farthest_point_sample(int B, int n, int m, const float* xyz, 
   while ((2 << log2bs) <= n && log2bs < 10) ++log2bs;       // bs = min(2^floor(log2 n), 1024)
   hipStream_t st = (hipStream_t)stream;
   const int ppt = (n + FPS_THREADS - 1) / FPS_THREADS;
-  if (ppt <= 4) launch_fps<4>(B, n, m, log2bs, xyz, out_idx, st);
-  else if (ppt <= 8) launch_fps<8>(B, n, m, log2bs, xyz, out_idx, st);
-  else if (ppt <= 20) launch_fps<20>(B, n, m, log2bs, xyz, out_idx, st);
-  else launch_fps<40>(B, n, m, log2bs, xyz, out_idx, st);
+  if (ppt <= 4) launch_fps<4, true>(B, n, m, log2bs, xyz, out_idx, st);
+  else if (ppt <= 8) launch_fps<8, true>(B, n, m, log2bs, xyz, out_idx, st);
+  else if (ppt <= 20) launch_fps<20, true>(B, n, m, log2bs, xyz, out_idx, st);
+  else if (ppt <= 40) launch_fps<40, false>(B, n, m, log2bs, xyz, out_idx, st);
+  else launch_fps<80, false>(B, n, m, log2bs, xyz, out_idx, st);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

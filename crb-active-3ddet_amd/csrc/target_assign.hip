@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ a
                                                      float* __restrict__ reg_weights) {
   __shared__ Aligned sg[MAXG];
   __shared__ int scls[MAXG];
-  __shared__ int smax[MAXG];
+  __shared__ int smax[MAXG];       // pass 1: this block's running max per gt; pass 2: the global max
   __shared__ int has_cls[8];
   const int b = blockIdx.y;
   const float* fg = gt + (int64_t)b * G * 8;
@@ -69,26 +69,34 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ a
     const int c = gvalid[(int64_t)b * G + g] ? (int)q[7] : 0;
     scls[g] = c;
     if (c > 0 && c < 8) has_cls[c] = 1;
-    if (PASS == 2) smax[g] = g2a_max[(int64_t)b * G + g];
+    smax[g] = (PASS == 2) ? g2a_max[(int64_t)b * G + g] : 0;
   }
   __syncthreads();
   const int a = blockIdx.x * 256 + threadIdx.x;
-  if (a >= A) return;
-  const float* an = anchors + (int64_t)a * 7;
-  const int cls = anchor_cls[a];
+  const bool live = a < A;
+  if (PASS == 2 && !live) return;
+  const float* an = anchors + (int64_t)(live ? a : 0) * 7;
+  const int cls = anchor_cls[live ? a : 0];
   const Aligned ab = aligned_bev(an[0], an[1], an[3], an[4], an[6]);
   const int64_t o = (int64_t)b * A + a;
   if (PASS == 1) {
-    float best = -1.f;
-    int arg = 0;
-    for (int g = 0; g < G; ++g) {
-      if (scls[g] != cls) continue;
-      const float v = iou_aligned(ab, sg[g]);
-      if (v > best) { best = v; arg = g; }
-      atomicMax(&g2a_max[(int64_t)b * G + g], __float_as_int(v));
+    // per-gt best overlap: LDS max per block first (only non-zero overlaps matter: the table starts at 0), then one
+    // global atomic per (block, gt) — one global atomic per (anchor, gt) serialised 70k threads on ~12 addresses
+    if (live) {
+      float best = -1.f;
+      int arg = 0;
+      for (int g = 0; g < G; ++g) {
+        if (scls[g] != cls) continue;
+        const float v = iou_aligned(ab, sg[g]);
+        if (v > best) { best = v; arg = g; }
+        if (v > 0.f) atomicMax(&smax[g], __float_as_int(v));
+      }
+      best_gt[o] = arg;
+      best_iou[o] = best;
     }
-    best_gt[o] = arg;
-    best_iou[o] = best;
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += 256)
+      if (smax[g] > 0) atomicMax(&g2a_max[(int64_t)b * G + g], smax[g]);
   } else {
     const float best = best_iou[o];
     const int arg = best_gt[o];

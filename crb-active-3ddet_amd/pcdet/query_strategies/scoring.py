@@ -53,7 +53,12 @@ def all_gather_rows(local, n_total, world, backend_device=None):
         return local[:n_total]
     per = local.shape[0]
     gathered = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(gathered, local.contiguous())
+    if local.is_cuda and dist.get_backend() == 'gloo':       # gloo dry runs on GPU tensors: gather through the host
+        g = torch.empty(gathered.shape, dtype=local.dtype)
+        dist.all_gather_into_tensor(g, local.contiguous().cpu())
+        gathered.copy_(g)
+    else:
+        dist.all_gather_into_tensor(gathered, local.contiguous())
     # gathered[r*per + k] = global index k*world + r  -> interleave back and drop the wrap-around padding
     out = gathered.view(world, per, *local.shape[1:]).transpose(0, 1).reshape(world * per, *local.shape[1:])
     return out[:n_total]

@@ -10,6 +10,8 @@ from collections import defaultdict
 
 
 def main(path, K, marker='vox_insert'):
+    import os
+    marker = os.environ.get('PROF_MARKER', marker)
     rows = list(csv.DictReader(open(path)))
     key_s = 'Start_Timestamp' if 'Start_Timestamp' in rows[0] else 'Start'
     key_e = 'End_Timestamp' if 'End_Timestamp' in rows[0] else 'End'
