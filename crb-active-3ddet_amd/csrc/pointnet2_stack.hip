@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void group_points_grad_kernel(int B, int M, in
 //   larger running distance first; then smaller bit-reversed (k mod bs) (its LDS tree keeps the lower-position operand
 //   on ties); then smaller k (each strided thread keeps its first maximum). bs = min(2^floor(log2 n), 1024).
 constexpr int FPS_THREADS = 1024;
-constexpr int FPS_MAX_PER_THREAD = 80;    // up to 81920 points per frame
+constexpr int FPS_REG_MAX_PER_THREAD = 40;    // up to 40960 points per frame with register-resident distances
 
 // REGS: point coordinates live in registers for the whole run (n <= 20480); otherwise they are re-read (coalesced, L2
 // resident) every round and only the running distances stay in registers. The tie key is built once per thread per
@@ -251,6 +251,57 @@ __global__ __launch_bounds__(256) void three_interp_grad_kernel(int N, int C, co
   atomicAdd(&grad_feat[(int64_t)id[2] * C + c], g * ww[2]);
 }
 
+// any n: running distances in a caller-provided (B,n) buffer, coordinates re-read every round
+__global__ __launch_bounds__(FPS_THREADS) void fps_large_kernel(int n, int m, int log2bs, const float* __restrict__ xyz_all,
+                                                                float* __restrict__ temp_all, int* __restrict__ out_all) {
+  __shared__ unsigned long long wave_best[16];
+  __shared__ float sel_xyz[3];
+  const float* xyz = xyz_all + (int64_t)blockIdx.x * n * 3;
+  float* dist = temp_all + (int64_t)blockIdx.x * n;
+  int* out = out_all + (int64_t)blockIdx.x * m;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned bsmask = (1u << log2bs) - 1u;
+  for (int k = tid; k < n; k += FPS_THREADS) dist[k] = 1e10f;
+  if (tid == 0) { out[0] = 0; sel_xyz[0] = xyz[0]; sel_xyz[1] = xyz[1]; sel_xyz[2] = xyz[2]; }
+  __syncthreads();
+  for (int j = 1; j < m; ++j) {
+    const float x1 = sel_xyz[0], y1 = sel_xyz[1], z1 = sel_xyz[2];
+    float bestd = -1.f;
+    int bestk = 0;
+    for (int k = tid; k < n; k += FPS_THREADS) {
+      const float dx = xyz[k * 3 + 0] - x1, dy = xyz[k * 3 + 1] - y1, dz = xyz[k * 3 + 2] - z1;
+      const float d2 = fminf(dx * dx + dy * dy + dz * dz, dist[k]);
+      dist[k] = d2;
+      if (d2 > bestd) { bestd = d2; bestk = k; }
+    }
+    unsigned long long best = 0ULL;
+    if (bestd >= 0.f) {
+      const unsigned v = (unsigned)bestk & bsmask;
+      const unsigned br = log2bs ? (__brev(v) >> (32 - log2bs)) : 0u;
+      best = ((unsigned long long)__float_as_uint(bestd) << 32) | (0xffffffffu - ((br << 20) | (unsigned)bestk));
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+      unsigned long long o = __shfl_xor(best, s, 64);
+      best = o > best ? o : best;
+    }
+    if (lane == 0) wave_best[wave] = best;
+    __syncthreads();
+    unsigned long long b2 = wave_best[lane & 15];
+#pragma unroll
+    for (int s = 8; s > 0; s >>= 1) {
+      unsigned long long o = __shfl_xor(b2, s, 64);
+      b2 = o > b2 ? o : b2;
+    }
+    const int sel = (int)((0xffffffffu - (unsigned)(b2 & 0xffffffffULL)) & 0xfffffu);
+    if (tid == 0) {
+      out[j] = sel;
+      sel_xyz[0] = xyz[sel * 3 + 0]; sel_xyz[1] = xyz[sel * 3 + 1]; sel_xyz[2] = xyz[sel * 3 + 2];
+    }
+    __syncthreads();
+  }
+}
+
 template <int PPT, bool REGS>
 void launch_fps(int B, int n, int m, int log2bs, const float* xyz, int* out, hipStream_t st) {
   hipLaunchKernelGGL((fps_kernel<PPT, REGS>), dim3(B), dim3(FPS_THREADS), 0, st, n, m, log2bs, xyz, out);
@@ -296,10 +347,12 @@ extern "C" int crb_group_points_grad_stack(int B, int64_t M, int C, int nsample,
   return CRB_OK;
 }
 
-extern "C" int crb_farthest_point_sample(int B, int n, int m, const float* xyz, int32_t* out_idx, void* stream) {
+extern "C" int crb_farthest_point_sample(int B, int n, int m, const float* xyz, float* temp, int32_t* out_idx,
+                                         void* stream) {
   if (B <= 0 || n <= 0 || m < 0) return CRB_ERR_ARG;
   if (m == 0) return CRB_OK;
-  if (n > FPS_THREADS * FPS_MAX_PER_THREAD || n >= (1 << 20)) return CRB_ERR_UNSUPPORTED;
+  if (n >= (1 << 20)) return CRB_ERR_UNSUPPORTED;
+  if (n > FPS_THREADS * FPS_REG_MAX_PER_THREAD && !temp) return CRB_ERR_WORKSPACE;
   int log2bs = 0;
   while ((2 << log2bs) <= n && log2bs < 10) ++log2bs;       // bs = min(2^floor(log2 n), 1024)
   hipStream_t st = (hipStream_t)stream;
@@ -308,7 +361,7 @@ extern "C" int crb_farthest_point_sample(int B, int n, int m, const float* xyz, 
   else if (ppt <= 8) launch_fps<8, true>(B, n, m, log2bs, xyz, out_idx, st);
   else if (ppt <= 20) launch_fps<20, true>(B, n, m, log2bs, xyz, out_idx, st);
   else if (ppt <= 40) launch_fps<40, false>(B, n, m, log2bs, xyz, out_idx, st);
-  else launch_fps<80, false>(B, n, m, log2bs, xyz, out_idx, st);
+  else hipLaunchKernelGGL(fps_large_kernel, dim3(B), dim3(FPS_THREADS), 0, st, n, m, log2bs, xyz, temp, out_idx);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

@@ -94,7 +94,8 @@ class FarthestPointSampling(Function):
         assert xyz.is_contiguous()
         B, N, _ = xyz.shape
         out = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
-        check(lib.crb_farthest_point_sample(B, N, int(npoint), ptr(xyz), ptr(out), cur_stream(xyz.device)),
+        temp = torch.empty((B, N), dtype=torch.float32, device=xyz.device) if N > 40960 else None
+        check(lib.crb_farthest_point_sample(B, N, int(npoint), ptr(xyz), ptr(temp), ptr(out), cur_stream(xyz.device)),
               'crb_farthest_point_sample')
         ctx.mark_non_differentiable(out)
         return out

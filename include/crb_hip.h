@@ -163,8 +163,10 @@ int crb_group_points_stack(int B, int64_t M, int C, int nsample, const float* fe
 int crb_group_points_grad_stack(int B, int64_t M, int C, int nsample, const float* grad_out,
                                 const int32_t* idx, const int32_t* idx_batch_cnt,
                                 const int32_t* features_batch_cnt, float* grad_features, void* stream);
-/* xyz (B,n,3) -> out_idx (B,m); first pick is index 0; ties resolved like the reference kernel (see source) */
-int crb_farthest_point_sample(int B, int n, int m, const float* xyz, int32_t* out_idx, void* stream);
+/* xyz (B,n,3) -> out_idx (B,m); first pick is index 0; ties resolved like the reference kernel (see source).
+ * temp: (B,n) f32 scratch for the running distances (the reference's `temp` argument); only needed for n > 40960
+ * (below that the distances stay in registers) and may be NULL otherwise. */
+int crb_farthest_point_sample(int B, int n, int m, const float* xyz, float* temp, int32_t* out_idx, void* stream);
 int crb_three_nn_stack(int B, int64_t N, const float* unknown, const int32_t* unknown_batch_cnt,
                        const float* known, const int32_t* known_batch_cnt, float* dist2, int32_t* idx,
                        void* stream);

@@ -46,7 +46,7 @@ def test_ball_query_and_grouping(dev):
     assert float(nf[::17].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize('n,m', [(20000, 2048), (4096, 512), (1000, 100), (777, 64), (37, 10)])
+@pytest.mark.parametrize('n,m', [(20000, 2048), (4096, 512), (1000, 100), (777, 64), (37, 10), (30000, 300), (50000, 200)])
 def test_fps(dev, n, m):
     from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as U
     pts, off, _ = kitti_batch(5, 2, n_points=n)
@@ -140,3 +140,30 @@ def test_roiaware_pool(dev, method):
                     for k in range(1, v[0] + 1):
                         g[v[k], c] += go[bi].reshape(216, 16)[cell, c] / max(v[0], 1)
     np.testing.assert_allclose(f.grad.cpu().numpy(), g, rtol=1e-4, atol=1e-5)
+
+
+def test_sa_module_eval_bn_folding_equals_module_path(dev):
+    from pcdet.config import EasyDict
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_modules as M
+    torch.manual_seed(0)
+    layer, c_out = M.build_local_aggregation_module(
+        12, EasyDict({'MLPS': [[16, 16], [16, 32]], 'POOL_RADIUS': [0.8, 1.6], 'NSAMPLE': [16, 16]}))
+    layer = layer.to(dev)
+    for m in layer.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 2.0)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    layer.eval()
+    xyz = torch.rand(3000, 3, device=dev) * 10
+    feat = torch.randn(3000, 12, device=dev)
+    new = xyz[::7].contiguous()
+    cnt = torch.tensor([3000], dtype=torch.int32, device=dev)
+    ncnt = torch.tensor([new.shape[0]], dtype=torch.int32, device=dev)
+    with torch.no_grad():
+        _, a = layer(xyz, cnt, new, ncnt, feat)            # folded path
+    with torch.enable_grad():
+        _, b = layer(xyz, cnt, new, ncnt, feat)            # module path
+    assert a.shape == (new.shape[0], c_out)
+    torch.testing.assert_close(a, b.detach(), rtol=1e-4, atol=1e-5)
