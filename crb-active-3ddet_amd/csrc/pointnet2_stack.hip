@@ -123,6 +123,91 @@ __global__ __launch_bounds__(256) void group_points_grad_kernel(int B, int M, in
   }
 }
 
+// ------------------------------------------------------------------------------------------------ fused QueryAndGroup
+// out (3+C, M, ns) channel-major = the (1, 3+C, M, ns) NCHW tensor the shared MLP consumes:
+//   c < 3 : xyz[nbr] - new_xyz   ;   c >= 3 : features[nbr][c-3]   ; all zero for an empty ball
+// One launch replaces group(xyz), the centre subtraction, two mask multiplies, group(features), the concat and the
+// (M,C,ns)->(1,C,M,ns) permute copy of QueryAndGroup + StackSAModuleMSG.forward (pointnet2_utils.py:129-155,
+// pointnet2_modules.py:90-97) — seven passes over a GB-sized tensor at the RoI-grid pooling shapes.
+// A 256-thread workgroup owns 64 consecutive (query, sample) pairs: rows are read coalesced along the channel axis into an
+// LDS slab and written back 64-wide along the pair axis.
+__global__ __launch_bounds__(256) void query_group_kernel(int B, int64_t MP /* M*ns */, int C, int ns,
+                                                          const float* __restrict__ xyz, const int* __restrict__ xyz_cnt,
+                                                          const float* __restrict__ feat, const float* __restrict__ new_xyz,
+                                                          const int* __restrict__ new_cnt, const int* __restrict__ idx,
+                                                          const unsigned char* __restrict__ empty, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* slab = reinterpret_cast<float*>(smem);            // 64 x (CT+1)
+  __shared__ int srow[64];
+  __shared__ int sm[64];
+  const int CT = C + 3, CP = CT + 1;
+  const int64_t p0 = (int64_t)blockIdx.x * 64;
+  if (threadIdx.x < 64) {
+    const int64_t p = p0 + threadIdx.x;
+    int row = -1, m = 0;
+    if (p < MP) {
+      m = (int)(p / ns);
+      if (!empty[m]) {
+        int start;
+        locate_batch(new_cnt, B, m, xyz_cnt, &start);
+        row = start + idx[p];
+      }
+    }
+    srow[threadIdx.x] = row;
+    sm[threadIdx.x] = m;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * CT; e += 256) {
+    const int pl = e / CT, c = e - pl * CT;
+    const int row = srow[pl];
+    float v = 0.f;
+    if (row >= 0) v = (c < 3) ? xyz[(int64_t)row * 3 + c] - new_xyz[(int64_t)sm[pl] * 3 + c] : feat[(int64_t)row * C + c - 3];
+    slab[pl * CP + c] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * CT; e += 256) {
+    const int c = e >> 6, pl = e & 63;
+    if (p0 + pl < MP) out[(int64_t)c * MP + p0 + pl] = slab[pl * CP + c];
+  }
+}
+
+// grad_feat[row][c-3] += grad_out[c][p] for non-empty balls (c >= 3)
+__global__ __launch_bounds__(256) void query_group_grad_kernel(int B, int64_t MP, int C, int ns,
+                                                               const int* __restrict__ xyz_cnt,
+                                                               const int* __restrict__ new_cnt, const int* __restrict__ idx,
+                                                               const unsigned char* __restrict__ empty,
+                                                               const float* __restrict__ grad_out,
+                                                               float* __restrict__ grad_feat) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* slab = reinterpret_cast<float*>(smem);            // 64 x (C+1)
+  __shared__ int srow[64];
+  const int CP = C + 1;
+  const int64_t p0 = (int64_t)blockIdx.x * 64;
+  if (threadIdx.x < 64) {
+    const int64_t p = p0 + threadIdx.x;
+    int row = -1;
+    if (p < MP) {
+      const int m = (int)(p / ns);
+      if (!empty[m]) {
+        int start;
+        locate_batch(new_cnt, B, m, xyz_cnt, &start);
+        row = start + idx[p];
+      }
+    }
+    srow[threadIdx.x] = row;
+  }
+  for (int e = threadIdx.x; e < 64 * C; e += 256) {
+    const int c = e >> 6, pl = e & 63;
+    slab[pl * CP + c] = (p0 + pl < MP) ? grad_out[(int64_t)(c + 3) * MP + p0 + pl] : 0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * C; e += 256) {
+    const int pl = e / C, c = e - pl * C;
+    const int row = srow[pl];
+    if (row >= 0) atomicAdd(&grad_feat[(int64_t)row * C + c], slab[pl * CP + c]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ FPS
 // Tie rule of the reference (sampling_gpu.cu:49-139) as a strict total order on candidates k:
 //   larger running distance first; then smaller bit-reversed (k mod bs) (its LDS tree keeps the lower-position operand
@@ -343,6 +428,36 @@ extern "C" int crb_group_points_grad_stack(int B, int64_t M, int C, int nsample,
   if (lds > 64 * 1024) return CRB_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(group_points_grad_kernel, dim3((unsigned)M), dim3(256), lds, (hipStream_t)stream, B, (int)M, C,
                      nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_query_group_stack(int B, int64_t M, int C, int nsample, const float* xyz,
+                                     const int32_t* xyz_batch_cnt, const float* features, const float* new_xyz,
+                                     const int32_t* new_xyz_batch_cnt, const int32_t* idx, const uint8_t* empty_mask,
+                                     float* out, void* stream) {
+  if (B <= 0 || M < 0 || C < 0 || nsample <= 0) return CRB_ERR_ARG;
+  if (M == 0) return CRB_OK;
+  const size_t lds = sizeof(float) * 64 * (C + 4);
+  if (lds > 64 * 1024) return CRB_ERR_UNSUPPORTED;
+  const int64_t MP = M * nsample;
+  hipLaunchKernelGGL(query_group_kernel, dim3(crb_cdiv(MP, 64)), dim3(256), lds, (hipStream_t)stream, B, MP, C, nsample,
+                     xyz, xyz_batch_cnt, features, new_xyz, new_xyz_batch_cnt, idx, empty_mask, out);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_query_group_grad_stack(int B, int64_t M, int C, int nsample, const int32_t* xyz_batch_cnt,
+                                          const int32_t* new_xyz_batch_cnt, const int32_t* idx,
+                                          const uint8_t* empty_mask, const float* grad_out,
+                                          float* grad_features /* pre-zeroed */, void* stream) {
+  if (B <= 0 || M < 0 || C <= 0 || nsample <= 0) return CRB_ERR_ARG;
+  if (M == 0) return CRB_OK;
+  const size_t lds = sizeof(float) * 64 * (C + 1);
+  if (lds > 64 * 1024) return CRB_ERR_UNSUPPORTED;
+  const int64_t MP = M * nsample;
+  hipLaunchKernelGGL(query_group_grad_kernel, dim3(crb_cdiv(MP, 64)), dim3(256), lds, (hipStream_t)stream, B, MP, C,
+                     nsample, xyz_batch_cnt, new_xyz_batch_cnt, idx, empty_mask, grad_out, grad_features);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

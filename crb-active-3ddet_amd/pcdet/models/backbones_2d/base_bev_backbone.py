@@ -44,10 +44,50 @@ class BaseBEVBackbone(nn.Module):
                 _bn(c_in), nn.ReLU()))
         self.num_bev_features = c_in
 
+    @staticmethod
+    def _run_folded(seq, x):
+        """inference only: every (Conv2d | ConvTranspose2d) -> BatchNorm2d -> ReLU triple runs as one convolution with the
+        BN affine folded into its weights and bias (same values up to f32 rounding); MIOpen's inference BN pass over the
+        288 MB BEV tensors was the largest single item of the CRB scoring profile"""
+        mods = list(seq)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) and i + 2 < len(mods) + 1 and \
+                    isinstance(mods[i + 1], nn.BatchNorm2d):
+                bn = mods[i + 1]
+                scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+                shift = bn.bias - bn.running_mean * scale
+                if m.bias is not None:
+                    shift = shift + m.bias * scale
+                if isinstance(m, nn.Conv2d):
+                    x = torch.nn.functional.conv2d(x, m.weight * scale.view(-1, 1, 1, 1), shift, m.stride, m.padding,
+                                                   m.dilation, m.groups)
+                else:
+                    x = torch.nn.functional.conv_transpose2d(x, m.weight * scale.view(1, -1, 1, 1), shift, m.stride,
+                                                             m.padding, m.output_padding, m.groups, m.dilation)
+                i += 2
+                if i < len(mods) and isinstance(mods[i], nn.ReLU):
+                    x = torch.relu_(x)
+                    i += 1
+            else:
+                x = m(x)
+                i += 1
+        return x
+
     def forward(self, data_dict):
         spatial_features = data_dict['spatial_features']
         ups = []
         x = spatial_features
+        if not self.training and not torch.is_grad_enabled():
+            for i, blk in enumerate(self.blocks):
+                x = self._run_folded(blk, x)
+                ups.append(self._run_folded(self.deblocks[i], x) if len(self.deblocks) > 0 else x)
+            x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
+            if len(self.deblocks) > len(self.blocks):
+                x = self._run_folded(self.deblocks[-1], x)
+            data_dict['spatial_features_2d'] = x
+            return data_dict
         for i, blk in enumerate(self.blocks):
             x = blk(x)
             stride = int(spatial_features.shape[2] / x.shape[2])

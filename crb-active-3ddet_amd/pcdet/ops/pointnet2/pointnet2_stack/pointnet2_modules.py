@@ -9,6 +9,9 @@ import torch.nn.functional as F
 from . import pointnet2_utils
 
 
+FUSED_GROUP = True     # one HIP launch builds the (1, 3+C, M, ns) MLP input (False: QueryAndGroup + permute copy)
+
+
 def build_local_aggregation_module(input_channels, config):
     name = config.get('NAME', 'StackSAModuleMSG')
     if name != 'StackSAModuleMSG':
@@ -70,11 +73,16 @@ class StackSAModuleMSG(nn.Module):
         """xyz (N,3), features (N,C), new_xyz (M,3) -> new_xyz, new_features (M, sum C_out)"""
         outs = []
         for grouper, mlp in zip(self.groupers, self.mlps):
-            grouped, _ = grouper(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features)     # (M, C, ns)
-            if not self.training and not torch.is_grad_enabled():
-                x = self._mlp_eval_folded(mlp, grouped.permute(1, 0, 2).unsqueeze(0))
+            if FUSED_GROUP and features is not None and grouper.use_xyz and xyz.is_cuda:
+                x_in, _ = pointnet2_utils.query_and_group_fused(grouper.radius, grouper.nsample, xyz, xyz_batch_cnt,
+                                                                new_xyz, new_xyz_batch_cnt, features)   # (1, 3+C, M, ns)
             else:
-                x = mlp(grouped.permute(1, 0, 2).unsqueeze(0))                                  # (1, C', M, ns)
+                grouped, _ = grouper(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features)  # (M, C, ns)
+                x_in = grouped.permute(1, 0, 2).unsqueeze(0)
+            if not self.training and not torch.is_grad_enabled():
+                x = self._mlp_eval_folded(mlp, x_in)
+            else:
+                x = mlp(x_in)                                                                   # (1, C', M, ns)
             if self.pool_method == 'max_pool':
                 x = F.max_pool2d(x, kernel_size=[1, x.size(3)]).squeeze(-1)
             elif self.pool_method == 'avg_pool':

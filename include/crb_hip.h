@@ -163,6 +163,17 @@ int crb_group_points_stack(int B, int64_t M, int C, int nsample, const float* fe
 int crb_group_points_grad_stack(int B, int64_t M, int C, int nsample, const float* grad_out,
                                 const int32_t* idx, const int32_t* idx_batch_cnt,
                                 const int32_t* features_batch_cnt, float* grad_features, void* stream);
+/* fused QueryAndGroup (pointnet2_utils.py:107-155) in the layout the shared MLP consumes: out (3+C, M, nsample) =
+ * [xyz[nbr]-new_xyz ; features[nbr]] per (query, sample), zero for empty balls (empty_mask (M) u8). idx as returned by
+ * crb_ball_query_stack after the empty fix-up. grad: features only, atomics into a pre-zeroed (N,C) buffer. */
+int crb_query_group_stack(int B, int64_t M, int C, int nsample, const float* xyz,
+                          const int32_t* xyz_batch_cnt, const float* features, const float* new_xyz,
+                          const int32_t* new_xyz_batch_cnt, const int32_t* idx, const uint8_t* empty_mask,
+                          float* out, void* stream);
+int crb_query_group_grad_stack(int B, int64_t M, int C, int nsample, const int32_t* xyz_batch_cnt,
+                               const int32_t* new_xyz_batch_cnt, const int32_t* idx,
+                               const uint8_t* empty_mask, const float* grad_out,
+                               float* grad_features, void* stream);
 /* xyz (B,n,3) -> out_idx (B,m); first pick is index 0; ties resolved like the reference kernel (see source).
  * temp: (B,n) f32 scratch for the running distances (the reference's `temp` argument); only needed for n > 40960
  * (below that the distances stay in registers) and may be NULL otherwise. */

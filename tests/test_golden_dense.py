@@ -126,3 +126,24 @@ def test_bev_backbone_and_mean_vfe_match_reference():
     np.testing.assert_allclose(out.numpy(), g['vfe_out'], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(out.numpy(), __import__('oracle').mean_vfe(g['vfe_v'], g['vfe_n'].astype(np.int32)),
                                rtol=1e-6, atol=1e-7)
+
+
+def test_bev_backbone_eval_folding_equals_module_path():
+    from pcdet.config import EasyDict
+    from pcdet.models.backbones_2d import BaseBEVBackbone
+    cfg = EasyDict({'LAYER_NUMS': [2, 1], 'LAYER_STRIDES': [1, 2], 'NUM_FILTERS': [8, 16], 'UPSAMPLE_STRIDES': [1, 2],
+                    'NUM_UPSAMPLE_FILTERS': [8, 8]})
+    torch.manual_seed(0)
+    m = BaseBEVBackbone(cfg, input_channels=6)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.3)
+            mod.running_var.uniform_(0.5, 2.0)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.2)
+    m.eval()
+    x = torch.randn(2, 6, 20, 24)
+    with torch.no_grad():
+        a = m({'spatial_features': x})['spatial_features_2d']
+    b = m({'spatial_features': x})['spatial_features_2d']          # grad enabled -> module path
+    np.testing.assert_allclose(a.numpy(), b.detach().numpy(), rtol=1e-4, atol=1e-5)

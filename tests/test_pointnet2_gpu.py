@@ -167,3 +167,25 @@ def test_sa_module_eval_bn_folding_equals_module_path(dev):
         _, b = layer(xyz, cnt, new, ncnt, feat)            # module path
     assert a.shape == (new.shape[0], c_out)
     torch.testing.assert_close(a, b.detach(), rtol=1e-4, atol=1e-5)
+
+
+def test_fused_query_group_equals_query_and_group(dev):
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as U
+    pts, off, _ = kitti_batch(2, 2, n_points=5000)
+    xyz = _t(np.ascontiguousarray(pts[:, :3]), dev)
+    xc = _t(np.diff(off).astype(np.int32), dev)
+    rng = np.random.default_rng(1)
+    sel = np.concatenate([rng.choice(5000, 300, replace=False), 5000 + rng.choice(5000, 200, replace=False)])
+    new = xyz[torch.from_numpy(sel).to(dev)].contiguous()
+    new[::9] += 40.0
+    nc = torch.tensor([300, 200], dtype=torch.int32, device=dev)
+    f1 = torch.randn(10000, 21, device=dev, requires_grad=True)
+    f2 = f1.detach().clone().requires_grad_(True)
+    a, idx_a = U.query_and_group_fused(0.9, 16, xyz, xc, new, nc, f1)
+    b, idx_b = U.QueryAndGroup(0.9, 16, use_xyz=True)(xyz, xc, new, nc, f2)
+    assert torch.equal(idx_a, idx_b)
+    assert torch.equal(a, b.permute(1, 0, 2).unsqueeze(0))
+    g = torch.randn_like(a)
+    a.backward(g)
+    b.backward(g[0].permute(1, 0, 2))
+    torch.testing.assert_close(f1.grad, f2.grad, rtol=1e-5, atol=1e-5)
