@@ -82,6 +82,42 @@ class PVRCNNHead(RoIHeadTemplate):
         rcnn_reg = self.reg_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
         return shared, rcnn_cls, rcnn_reg
 
+    # ---- inference fast path (same values up to f32 rounding) -------------------------------------------------------
+    @staticmethod
+    def _run_folded(mods, x):
+        """Conv1d(k=1) -> BatchNorm1d(eval) pairs as one folded conv; ReLU / Dropout modules run as they are (Dropout
+        stays stochastic when the CRB strategy switched it to train mode)"""
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Conv1d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d):
+                bn = mods[i + 1]
+                scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+                shift = bn.bias - bn.running_mean * scale
+                if m.bias is not None:
+                    shift = shift + m.bias * scale
+                x = torch.nn.functional.conv1d(x, m.weight * scale.view(-1, 1, 1), shift)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+    def _heads_eval(self, pooled_flat, rounds):
+        """MC-dropout passes of pvrcnn_head.py:187-202. Everything before the first Dropout of shared_fc_layer is
+        deterministic in eval mode, so the 27648->256 layer (7 M MACs per RoI) runs once instead of `rounds` times."""
+        mods = list(self.shared_fc_layer)
+        first_dp = next((k for k, m in enumerate(mods) if isinstance(m, nn.Dropout)), len(mods))
+        prefix = self._run_folded(mods[:first_dp], pooled_flat)
+        cls_l, reg_l = list(self.cls_layers), list(self.reg_layers)
+        out = []
+        for _ in range(max(1, rounds)):
+            shared = self._run_folded(mods[first_dp:], prefix)
+            rcnn_cls = self._run_folded(cls_l, shared).transpose(1, 2).contiguous().squeeze(dim=1)
+            rcnn_reg = self._run_folded(reg_l, shared).transpose(1, 2).contiguous().squeeze(dim=1)
+            out.append((shared, rcnn_cls, rcnn_reg))
+        return out
+
     def forward(self, batch_dict):
         targets_dict = self.proposal_layer(batch_dict,
                                            nms_config=self.model_cfg.NMS_CONFIG['TRAIN' if self.training else 'TEST'])
@@ -94,15 +130,25 @@ class PVRCNNHead(RoIHeadTemplate):
         pooled = self.roi_grid_pool(batch_dict)                                   # (BN, G^3, C)
         n = pooled.shape[0]
         pooled_flat = pooled.permute(0, 2, 1).contiguous().view(n, -1, 1)          # (BN, C*G^3, 1)
-        shared, rcnn_cls, rcnn_reg = self._heads(pooled_flat)
+        fast = (not self.training) and (not torch.is_grad_enabled()) and \
+            not any(m.training for m in self.modules() if isinstance(m, nn.BatchNorm1d))
+        if fast:
+            rounds = self.model_cfg.get('SAMPLING_ROUND', None) or 1
+            passes = self._heads_eval(pooled_flat, rounds)
+            shared, rcnn_cls, rcnn_reg = passes[-1]
+        else:
+            shared, rcnn_cls, rcnn_reg = self._heads(pooled_flat)
         if not self.training:
             rounds = self.model_cfg.get('SAMPLING_ROUND', None)
             if rounds:
-                cls_list, reg_list = [rcnn_cls], [rcnn_reg]
-                for _ in range(rounds - 1):
-                    shared, rcnn_cls, rcnn_reg = self._heads(pooled_flat)
-                    cls_list.append(rcnn_cls)
-                    reg_list.append(rcnn_reg)
+                if fast:
+                    cls_list, reg_list = [p[1] for p in passes], [p[2] for p in passes]
+                else:
+                    cls_list, reg_list = [rcnn_cls], [rcnn_reg]
+                    for _ in range(rounds - 1):
+                        shared, rcnn_cls, rcnn_reg = self._heads(pooled_flat)
+                        cls_list.append(rcnn_cls)
+                        reg_list.append(rcnn_reg)
                 batch_dict['rcnn_cls'] = torch.stack(cls_list, 0)
                 batch_dict['rcnn_reg'] = torch.stack(reg_list, 0)
             elif self.model_cfg.get('EMBEDDING_REQUIRED', None):

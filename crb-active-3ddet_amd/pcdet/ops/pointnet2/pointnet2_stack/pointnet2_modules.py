@@ -9,6 +9,7 @@ import torch.nn.functional as F
 from . import pointnet2_utils
 
 
+FUSED_SA_EVAL = True   # inference: group + 2-layer MLP + max in one HIP kernel (crb_sa_mlp2_max_stack)
 FUSED_GROUP = True     # one HIP launch builds the (1, 3+C, M, ns) MLP input (False: QueryAndGroup + permute copy)
 
 
@@ -69,8 +70,45 @@ class StackSAModuleMSG(nn.Module):
             i += 3
         return x
 
+    @staticmethod
+    def _folded_pair(mlp):
+        """[(w (Cout,Cin), b (Cout))] x 2 of a Conv-BN-ReLU-Conv-BN-ReLU stack with eval BN folded, or None"""
+        mods = list(mlp)
+        if len(mods) != 6:
+            return None
+        out = []
+        for conv, bn in ((mods[0], mods[1]), (mods[3], mods[4])):
+            if not isinstance(conv, nn.Conv2d) or not isinstance(bn, nn.BatchNorm2d) or bn.training:
+                return None
+            scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+            b = bn.bias - bn.running_mean * scale
+            if conv.bias is not None:
+                b = b + conv.bias * scale
+            out.append((conv.weight.flatten(1) * scale.view(-1, 1), b))
+        return out
+
+    def _forward_fused_eval(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features):
+        folded = [self._folded_pair(m) for m in self.mlps]
+        if any(f is None or not pointnet2_utils.sa_mlp2_max_supported(f[0][0].shape[0], f[1][0].shape[0])
+               for f in folded):
+            return None
+        widths = [f[1][0].shape[0] for f in folded]
+        out = torch.empty((new_xyz.shape[0], sum(widths)), dtype=torch.float32, device=xyz.device)
+        col = 0
+        for grouper, f, w in zip(self.groupers, folded, widths):
+            pointnet2_utils.sa_mlp2_max(grouper.radius, grouper.nsample, xyz, xyz_batch_cnt, new_xyz,
+                                        new_xyz_batch_cnt, features, f[0][0], f[0][1], f[1][0], f[1][1],
+                                        out[:, col:col + w])
+            col += w
+        return out
+
     def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None, empty_voxel_set_zeros=True):
         """xyz (N,3), features (N,C), new_xyz (M,3) -> new_xyz, new_features (M, sum C_out)"""
+        if FUSED_SA_EVAL and not self.training and not torch.is_grad_enabled() and features is not None \
+                and xyz.is_cuda and self.pool_method == 'max_pool' and all(g.use_xyz for g in self.groupers):
+            fused = self._forward_fused_eval(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features)
+            if fused is not None:
+                return new_xyz, fused
         outs = []
         for grouper, mlp in zip(self.groupers, self.mlps):
             if FUSED_GROUP and features is not None and grouper.use_xyz and xyz.is_cuda:

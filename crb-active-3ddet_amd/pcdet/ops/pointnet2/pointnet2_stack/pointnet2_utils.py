@@ -1,6 +1,8 @@
 """pcdet.ops.pointnet2.pointnet2_stack.pointnet2_utils (reference: pointnet2_utils.py:8-299) over csrc/pointnet2_stack.hip.
 Same callables: ball_query, grouping_operation, QueryAndGroup, farthest_point_sample, stack_farthest_point_sample,
 three_nn, three_interpolate."""
+import ctypes
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -118,6 +120,33 @@ def query_and_group_fused(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_
     """-> (1, 3+C, M, nsample), idx (M, nsample)"""
     idx, empty = ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
     return FusedQueryGroup.apply(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx, empty), idx
+
+
+def sa_mlp2_max_supported(h1, h2):
+    return bool(lib.crb_sa_mlp2_max_supported(int(h1), int(h2)))
+
+
+@torch.no_grad()
+def sa_mlp2_max(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, w1, b1, w2, b2, out):
+    """inference-only ball query -> group -> relu(W1 . + b1) -> relu(W2 . + b2) -> max over samples, written into `out`
+    ((M, h2) view, may be a column slice of a wider row-major buffer). w1 (h1, 3+C) / w2 (h2, h1) are the BN-folded 1x1 conv
+    weights of one StackSAModuleMSG scale (pointnet2_modules.py:73-112)."""
+    require_cuda(xyz, new_xyz, features, out)
+    idx, empty = ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+    h1, h2 = w1.shape[0], w2.shape[0]
+    M = new_xyz.shape[0]
+    assert out.shape == (M, h2) and out.stride(1) == 1
+    P = features.contiguous() @ w1[:, 3:].t()                      # (N, h1): layer 1 per SOURCE point, not per pair
+    w1x = w1[:, :3].t().contiguous()
+    w2t = w2.t().contiguous()
+    xc, nc = _i32(xyz_batch_cnt), _i32(new_xyz_batch_cnt)
+    em = empty.to(torch.uint8)
+    check(lib.crb_sa_mlp2_max_stack(len(xyz_batch_cnt), M, int(nsample), h1, h2, ptr(xyz.contiguous()), ptr(xc), ptr(P),
+                                    ptr(new_xyz.contiguous()), ptr(nc), ptr(idx), ptr(em), ptr(w1x),
+                                    ptr(b1.contiguous()), ptr(w2t), ptr(b2.contiguous()), ctypes.c_void_p(out.data_ptr()),
+                                    out.stride(0),
+                                    cur_stream(xyz.device)), 'crb_sa_mlp2_max_stack')
+    return out
 
 
 class FarthestPointSampling(Function):

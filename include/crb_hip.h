@@ -174,6 +174,17 @@ int crb_query_group_grad_stack(int B, int64_t M, int C, int nsample, const int32
                                const int32_t* new_xyz_batch_cnt, const int32_t* idx,
                                const uint8_t* empty_mask, const float* grad_out,
                                float* grad_features, void* stream);
+/* inference-only fused set abstraction: replaces the body of StackSAModuleMSG.forward
+ * (pointnet2_modules.py:73-112: QueryAndGroup -> 2 x [Conv2d 1x1 + BatchNorm2d + ReLU] -> max_pool2d over nsample) for one
+ * radius. BN is folded by the caller; layer 1 is split as W1 [dxyz ; f] = W1x dxyz + P[row], P = features @ W1f^T (N,h1).
+ * W1x (3,h1), b1 (h1), W2 (h1,h2) [k][n], b2 (h2); idx / empty_mask as for crb_query_group_stack; writes
+ * out[m*out_stride + n], n < h2 (out may point into a wider (M, sum h2) buffer). h1,h2 in {16,32,64}. */
+int crb_sa_mlp2_max_supported(int h1, int h2);
+int crb_sa_mlp2_max_stack(int B, int64_t M, int nsample, int h1, int h2, const float* xyz,
+                          const int32_t* xyz_batch_cnt, const float* P, const float* new_xyz,
+                          const int32_t* new_xyz_batch_cnt, const int32_t* idx, const uint8_t* empty_mask,
+                          const float* W1x, const float* b1, const float* W2, const float* b2, float* out,
+                          int out_stride, void* stream);
 /* xyz (B,n,3) -> out_idx (B,m); first pick is index 0; ties resolved like the reference kernel (see source).
  * temp: (B,n) f32 scratch for the running distances (the reference's `temp` argument); only needed for n > 40960
  * (below that the distances stay in registers) and may be NULL otherwise. */

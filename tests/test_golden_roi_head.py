@@ -123,3 +123,20 @@ def test_roi_subsampling_rule():
     assert int(((s[0] < 0.55) & (s[0] >= 0.1)).sum()) == min(int(64 * 0.8), n_hard0)
     assert (s[1] < 0.1).all() and (s[2] >= 0.55).all() and (s[4] >= 0.1).all() and (s[4] < 0.55).all()
     assert int((s[3] >= 0.55).sum()) == 5 and int(((s[3] < 0.55) & (s[3] >= 0.1)).sum()) == 123
+
+
+def test_eval_fast_path_equals_module_path(head):
+    """folded Conv1d+BN and the once-only first FC layer give the same logits as the plain module path (dropout off)"""
+    g = np.load(G)
+    sd = {k[len('fc_state/'):]: _t(g[k]) for k in g.files if k.startswith('fc_state/')}
+    head.load_state_dict(sd, strict=False)
+    head.eval()
+    pooled = _t(g['fc_pooled'])
+    flat = pooled.permute(0, 2, 1).contiguous().view(pooled.shape[0], -1, 1)
+    with torch.no_grad():
+        passes = head._heads_eval(flat, 3)
+        _, cls, reg = head._heads(flat)
+    for _, c, r in passes:
+        np.testing.assert_allclose(c.numpy(), cls.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(r.numpy(), reg.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(passes[0][1].numpy(), g['fc_cls'], rtol=1e-4, atol=1e-5)     # and the reference golden

@@ -38,8 +38,9 @@ def test_ball_query_and_grouping(dev):
         np.testing.assert_array_equal(g.detach().cpu().numpy(), oracle.group_points(feat, xc, ref, nc))
         go = rng.normal(size=tuple(g.shape)).astype(np.float32)
         g.backward(_t(go, dev))
+        # float atomics: the order of the (up to a few hundred) addends per source point differs from the oracle's
         np.testing.assert_allclose(f.grad.cpu().numpy(), oracle.group_points_grad(go, ref, nc, xc, len(xyz)),
-                                   rtol=1e-5, atol=1e-5)
+                                   rtol=1e-4, atol=1e-4)
     qg = U.QueryAndGroup(0.8, 16, use_xyz=True)
     nf, idx = qg(_t(xyz, dev), _t(xc, dev), _t(new, dev), _t(nc, dev), _t(feat, dev))
     assert nf.shape == (1500, 22, 16)
@@ -167,6 +168,48 @@ def test_sa_module_eval_bn_folding_equals_module_path(dev):
         _, b = layer(xyz, cnt, new, ncnt, feat)            # module path
     assert a.shape == (new.shape[0], c_out)
     torch.testing.assert_close(a, b.detach(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('c_in,mlps,nsamples', [(128, [[64, 64], [64, 64]], [16, 16]), (5, [[32, 32], [16, 64]], [24, 7]),
+                                                (1, [[16, 16], [64, 32]], [16, 40])])
+def test_fused_sa_eval_kernel_equals_module_path(dev, c_in, mlps, nsamples):
+    """crb_sa_mlp2_max_stack (group + MLP + max in one launch) against the Conv2d/BatchNorm2d/max_pool2d module path:
+    two frames, empty balls, nsample below / above / not a multiple of the 16-row MFMA tile. fp32, rtol 1e-4."""
+    from pcdet.config import EasyDict
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_modules as M
+    torch.manual_seed(3)
+    layer, c_out = M.build_local_aggregation_module(
+        c_in, EasyDict({'MLPS': mlps, 'POOL_RADIUS': [0.8, 1.6], 'NSAMPLE': nsamples}))
+    layer = layer.to(dev)
+    for m in layer.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 2.0)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    layer.eval()
+    pts, off, _ = kitti_batch(2, 5, n_points=6000)
+    xyz = _t(np.ascontiguousarray(pts[:, :3]), dev)
+    xc = _t(np.diff(off).astype(np.int32), dev)
+    rng = np.random.default_rng(2)
+    sel = np.concatenate([rng.choice(6000, 700, replace=False), 6000 + rng.choice(6000, 401, replace=False)])
+    new = xyz[torch.from_numpy(sel).to(dev)].contiguous()
+    new[::5] += 55.0                                        # empty balls
+    nc = torch.tensor([700, 401], dtype=torch.int32, device=dev)
+    feat = torch.randn(12000, c_in, device=dev)
+    with torch.no_grad():
+        _, a = layer(xyz, xc, new, nc, feat)                # fused kernel
+        M.FUSED_SA_EVAL = False
+        try:
+            _, c = layer(xyz, xc, new, nc, feat)            # folded convs
+        finally:
+            M.FUSED_SA_EVAL = True
+    with torch.enable_grad():
+        _, b = layer(xyz, xc, new, nc, feat)                # module path
+    assert a.shape == (1101, c_out)
+    torch.testing.assert_close(a, b.detach(), rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(c, b.detach(), rtol=1e-4, atol=2e-5)
+    assert float(a[::5].std(dim=0).max()) == 0.0            # empty balls: one constant row
 
 
 def test_fused_query_group_equals_query_and_group(dev):
