@@ -27,6 +27,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense f32-input MFMA (exact f32), the dtype this path computes in
 
 
 def parse():
@@ -90,11 +91,25 @@ def roofline_from_profile(prof):
     table = {'%s_%dx%d' % k: {'launches': v['n'], 'avg_us': 1e3 * v['ms'] / v['n'],
                               'GBps_alg': v['bytes'] / (v['ms'] * 1e-3) / 1e9,
                               'TFLOPs': v['flops'] / (v['ms'] * 1e-3) / 1e12} for k, v in agg.items()}
-    roof = {'bound': 'hbm', 'kernel': 'sparse_conv_fwd_kernel<%d,%d> (subm gather-GEMM fwd+dgrad)' % (key[1], key[2]),
-            'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
-            'traffic': None, 'avg_launch_us': round(1e3 * a['ms'] / a['n'], 2),
-            'alg_bytes_per_launch': round(a['bytes'] / a['n']), 'launches': a['n'],
-            'achieved_tflops_f32': round(a['flops'] / (a['ms'] * 1e-3) / 1e12, 2)}
+    tfs = a['flops'] / (a['ms'] * 1e-3) / 1e12
+    # which roof binds: the algorithmic bytes at 8 TB/s or the algorithmic flops on the exact-f32 MFMA
+    # (v_mfma_f32_16x16x4_f32, 157.3 TF dense, MI355X_MICROARCH.md). At C=64 the intensity is ~117 flop/B against a
+    # machine balance of 19.7, so the f32 gather-GEMM is MFMA-bound; the HBM fraction is reported beside it.
+    t_hbm = a['bytes'] / (HBM_PEAK_GBS * 1e9)
+    t_mfma = a['flops'] / (MFMA_F32_PEAK_TF * 1e12)
+    kern = 'sparse_conv_fwd_kernel<%d,%d> (subm gather-GEMM fwd+dgrad)' % (key[1], key[2])
+    common = {'traffic': None, 'avg_launch_us': round(1e3 * a['ms'] / a['n'], 2), 'launches': a['n'],
+              'alg_bytes_per_launch': round(a['bytes'] / a['n']), 'alg_flops_per_launch': round(a['flops'] / a['n']),
+              'hbm_GBps_alg': round(gbs, 1), 'hbm_frac': round(gbs / HBM_PEAK_GBS, 4),
+              'mfma_f32_TFLOPs': round(tfs, 2), 'mfma_f32_frac': round(tfs / MFMA_F32_PEAK_TF, 4),
+              'roof_us': {'hbm': round(1e6 * t_hbm / a['n'], 2), 'mfma_f32': round(1e6 * t_mfma / a['n'], 2)}}
+    if t_mfma > t_hbm:
+        roof = {'bound': 'mfma', 'kernel': kern, 'achieved': round(tfs, 2), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
+                'frac': round(tfs / MFMA_F32_PEAK_TF, 4)}
+    else:
+        roof = {'bound': 'hbm', 'kernel': kern, 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(gbs / HBM_PEAK_GBS, 4)}
+    roof.update(common)
     return roof, table
 
 

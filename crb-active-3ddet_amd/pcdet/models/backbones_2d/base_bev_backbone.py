@@ -4,6 +4,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ...utils.fold_utils import fold_conv_bn
+
 
 def _bn(c):
     return nn.BatchNorm2d(c, eps=1e-3, momentum=0.01)
@@ -55,17 +57,12 @@ class BaseBEVBackbone(nn.Module):
             m = mods[i]
             if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) and i + 2 < len(mods) + 1 and \
                     isinstance(mods[i + 1], nn.BatchNorm2d):
-                bn = mods[i + 1]
-                scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-                shift = bn.bias - bn.running_mean * scale
-                if m.bias is not None:
-                    shift = shift + m.bias * scale
+                w, shift = fold_conv_bn(m, mods[i + 1])
                 if isinstance(m, nn.Conv2d):
-                    x = torch.nn.functional.conv2d(x, m.weight * scale.view(-1, 1, 1, 1), shift, m.stride, m.padding,
-                                                   m.dilation, m.groups)
+                    x = torch.nn.functional.conv2d(x, w, shift, m.stride, m.padding, m.dilation, m.groups)
                 else:
-                    x = torch.nn.functional.conv_transpose2d(x, m.weight * scale.view(1, -1, 1, 1), shift, m.stride,
-                                                             m.padding, m.output_padding, m.groups, m.dilation)
+                    x = torch.nn.functional.conv_transpose2d(x, w, shift, m.stride, m.padding, m.output_padding,
+                                                             m.groups, m.dilation)
                 i += 2
                 if i < len(mods) and isinstance(mods[i], nn.ReLU):
                     x = torch.relu_(x)

@@ -136,8 +136,37 @@ class VoxelSetAbstraction(nn.Module):
                                    new_xyz_batch_cnt=new_xyz_batch_cnt, features=xyz_features.contiguous())
         return pooled
 
+    PREFETCH_KEYPOINTS = True
+
+    def prefetch_keypoints(self, batch_dict):
+        """Start farthest-point sampling on a side HIP stream as soon as the raw points exist. FPS is a sequential
+        2048-round selection that keeps one workgroup per frame busy for ~5 ms and depends on nothing but the points, so
+        it runs under the 3-D / BEV backbones (which use the other 240 CUs) instead of after them. The detector calls
+        this before its module loop; forward() joins the stream."""
+        pts = batch_dict.get('points', None)
+        if not self.PREFETCH_KEYPOINTS or pts is None or not pts.is_cuda or self.model_cfg.POINT_SOURCE != 'raw_points':
+            return
+        main = torch.cuda.current_stream(pts.device)
+        side = getattr(self, '_kp_stream', None)
+        if side is None or side.device != pts.device:
+            side = self._kp_stream = torch.cuda.Stream(device=pts.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            kp = self.get_sampled_points(batch_dict)
+            done = torch.cuda.Event()
+            done.record(side)
+        pts.record_stream(side)
+        batch_dict['_keypoints_prefetched'] = (kp, done)
+
     def forward(self, batch_dict):
-        keypoints = self.get_sampled_points(batch_dict)
+        pre = batch_dict.pop('_keypoints_prefetched', None)
+        if pre is not None:
+            keypoints, done = pre
+            cur = torch.cuda.current_stream(keypoints.device)
+            cur.wait_event(done)
+            keypoints.record_stream(cur)
+        else:
+            keypoints = self.get_sampled_points(batch_dict)
         batch_size = batch_dict['batch_size']
         feats = []
         if 'bev' in self.model_cfg.FEATURES_SOURCE:

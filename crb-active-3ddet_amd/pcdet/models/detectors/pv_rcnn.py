@@ -8,6 +8,8 @@ class PVRCNN(Detector3DTemplate):
         self.module_list = self.build_networks()
 
     def forward(self, batch_dict):
+        if getattr(self, 'pfe', None) is not None and hasattr(self.pfe, 'prefetch_keypoints'):
+            self.pfe.prefetch_keypoints(batch_dict)          # FPS on a side stream, joined inside the PFE
         for cur_module in self.module_list:
             batch_dict = cur_module(batch_dict)
         if self.training:

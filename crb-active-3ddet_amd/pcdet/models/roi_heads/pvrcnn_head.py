@@ -5,6 +5,7 @@ import torch.nn as nn
 
 from ...ops.pointnet2.pointnet2_stack import pointnet2_modules as pointnet2_stack_modules
 from ...utils import common_utils
+from ...utils.fold_utils import fold_conv_bn
 from .roi_head_template import RoIHeadTemplate
 
 
@@ -91,12 +92,8 @@ class PVRCNNHead(RoIHeadTemplate):
         while i < len(mods):
             m = mods[i]
             if isinstance(m, nn.Conv1d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d):
-                bn = mods[i + 1]
-                scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-                shift = bn.bias - bn.running_mean * scale
-                if m.bias is not None:
-                    shift = shift + m.bias * scale
-                x = torch.nn.functional.conv1d(x, m.weight * scale.view(-1, 1, 1), shift)
+                w, shift = fold_conv_bn(m, mods[i + 1])
+                x = torch.nn.functional.conv1d(x, w, shift)
                 i += 2
             else:
                 x = m(x)

@@ -7,6 +7,17 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import pointnet2_utils
+from ....utils.fold_utils import fold_conv_bn
+
+
+def _split_first_layer(w, b):
+    """(h1, 3+C, 1, 1) -> W1x (3, h1), W1f^T (C, h1), b1: the operand layout of crb_sa_mlp2_max_stack"""
+    w = w.flatten(1)
+    return w[:, :3].t().contiguous(), w[:, 3:].t().contiguous(), b.contiguous()
+
+
+def _transpose_second_layer(w, b):
+    return w.flatten(1).t().contiguous(), b.contiguous()
 
 
 FUSED_SA_EVAL = True   # inference: group + 2-layer MLP + max in one HIP kernel (crb_sa_mlp2_max_stack)
@@ -60,45 +71,34 @@ class StackSAModuleMSG(nn.Module):
         mods = list(mlp)
         i = 0
         while i < len(mods):
-            conv, bn = mods[i], mods[i + 1]
-            scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-            w = conv.weight * scale.view(-1, 1, 1, 1)
-            b = bn.bias - bn.running_mean * scale
-            if conv.bias is not None:
-                b = b + conv.bias * scale
+            w, b = fold_conv_bn(mods[i], mods[i + 1])
             x = F.relu(F.conv2d(x, w, b), inplace=True)
             i += 3
         return x
 
     @staticmethod
     def _folded_pair(mlp):
-        """[(w (Cout,Cin), b (Cout))] x 2 of a Conv-BN-ReLU-Conv-BN-ReLU stack with eval BN folded, or None"""
+        """kernel operands of a Conv-BN-ReLU-Conv-BN-ReLU stack with eval BN folded (cached on the convs), or None"""
         mods = list(mlp)
         if len(mods) != 6:
             return None
-        out = []
         for conv, bn in ((mods[0], mods[1]), (mods[3], mods[4])):
             if not isinstance(conv, nn.Conv2d) or not isinstance(bn, nn.BatchNorm2d) or bn.training:
                 return None
-            scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-            b = bn.bias - bn.running_mean * scale
-            if conv.bias is not None:
-                b = b + conv.bias * scale
-            out.append((conv.weight.flatten(1) * scale.view(-1, 1), b))
-        return out
+        w1x, w1f_t, b1 = fold_conv_bn(mods[0], mods[1], _split_first_layer)
+        w2t, b2 = fold_conv_bn(mods[3], mods[4], _transpose_second_layer)
+        return w1x, w1f_t, b1, w2t, b2
 
     def _forward_fused_eval(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features):
         folded = [self._folded_pair(m) for m in self.mlps]
-        if any(f is None or not pointnet2_utils.sa_mlp2_max_supported(f[0][0].shape[0], f[1][0].shape[0])
-               for f in folded):
+        if any(f is None or not pointnet2_utils.sa_mlp2_max_supported(f[3].shape[0], f[3].shape[1]) for f in folded):
             return None
-        widths = [f[1][0].shape[0] for f in folded]
+        widths = [f[3].shape[1] for f in folded]
         out = torch.empty((new_xyz.shape[0], sum(widths)), dtype=torch.float32, device=xyz.device)
         col = 0
         for grouper, f, w in zip(self.groupers, folded, widths):
             pointnet2_utils.sa_mlp2_max(grouper.radius, grouper.nsample, xyz, xyz_batch_cnt, new_xyz,
-                                        new_xyz_batch_cnt, features, f[0][0], f[0][1], f[1][0], f[1][1],
-                                        out[:, col:col + w])
+                                        new_xyz_batch_cnt, features, *f, out[:, col:col + w])
             col += w
         return out
 

@@ -127,25 +127,22 @@ def sa_mlp2_max_supported(h1, h2):
 
 
 @torch.no_grad()
-def sa_mlp2_max(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, w1, b1, w2, b2, out):
+def sa_mlp2_max(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, w1x, w1f_t, b1, w2t, b2, out):
     """inference-only ball query -> group -> relu(W1 . + b1) -> relu(W2 . + b2) -> max over samples, written into `out`
-    ((M, h2) view, may be a column slice of a wider row-major buffer). w1 (h1, 3+C) / w2 (h2, h1) are the BN-folded 1x1 conv
-    weights of one StackSAModuleMSG scale (pointnet2_modules.py:73-112)."""
+    ((M, h2) view, may be a column slice of a wider row-major buffer). Operands are the BN-folded 1x1 conv weights of one
+    StackSAModuleMSG scale (pointnet2_modules.py:73-112): w1x (3,h1), w1f_t (C,h1), b1 (h1), w2t (h1,h2), b2 (h2)."""
     require_cuda(xyz, new_xyz, features, out)
     idx, empty = ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
-    h1, h2 = w1.shape[0], w2.shape[0]
+    h1, h2 = w2t.shape
     M = new_xyz.shape[0]
     assert out.shape == (M, h2) and out.stride(1) == 1
-    P = features.contiguous() @ w1[:, 3:].t()                      # (N, h1): layer 1 per SOURCE point, not per pair
-    w1x = w1[:, :3].t().contiguous()
-    w2t = w2.t().contiguous()
+    P = features.contiguous() @ w1f_t                              # (N, h1): layer 1 per SOURCE point, not per pair
     xc, nc = _i32(xyz_batch_cnt), _i32(new_xyz_batch_cnt)
-    em = empty.to(torch.uint8)
+    em = empty.view(torch.uint8) if empty.dtype == torch.bool else empty.to(torch.uint8)
     check(lib.crb_sa_mlp2_max_stack(len(xyz_batch_cnt), M, int(nsample), h1, h2, ptr(xyz.contiguous()), ptr(xc), ptr(P),
-                                    ptr(new_xyz.contiguous()), ptr(nc), ptr(idx), ptr(em), ptr(w1x),
-                                    ptr(b1.contiguous()), ptr(w2t), ptr(b2.contiguous()), ctypes.c_void_p(out.data_ptr()),
-                                    out.stride(0),
-                                    cur_stream(xyz.device)), 'crb_sa_mlp2_max_stack')
+                                    ptr(new_xyz.contiguous()), ptr(nc), ptr(idx), ptr(em), ptr(w1x), ptr(b1), ptr(w2t),
+                                    ptr(b2), ctypes.c_void_p(out.data_ptr()), out.stride(0), cur_stream(xyz.device)),
+          'crb_sa_mlp2_max_stack')
     return out
 
 
