@@ -172,7 +172,8 @@ __global__ void fill_i32_kernel(int* p, int64_t n, int v) {
   if (i < n) p[i] = v;
 }
 
-// Sort the rows of every chunk of SORT_CHUNK consecutive rows by their neighbour mask (stable: ties keep row order).
+// Sort the rows of every chunk of SORT_CHUNK consecutive rows by their neighbour mask, descending (stable: ties keep row
+// order).
 // One 1024-thread workgroup per chunk; bitonic network on 64-bit (mask << 32 | local index) keys in LDS.
 constexpr int SORT_CHUNK = 4096;
 
@@ -181,7 +182,9 @@ __global__ __launch_bounds__(1024) void mask_sort_chunks_kernel(const int* __res
   const int base = blockIdx.x * SORT_CHUNK;
   for (int t = threadIdx.x; t < SORT_CHUNK; t += 1024) {
     const int i = base + t;
-    key[t] = (i < n) ? (((unsigned long long)(unsigned)mask[i] << 32) | (unsigned)t) : ~0ULL;
+    // descending mask order: the rows with the most neighbours (longest-running tiles) come first inside every chunk, so
+    // the last tiles a launch dispatches are light ones (no heavy-tile tail); equal masks stay adjacent either way
+    key[t] = (i < n) ? (((unsigned long long)(~(unsigned)mask[i]) << 32) | (unsigned)t) : ~0ULL;
   }
   __syncthreads();
   for (int k = 2; k <= SORT_CHUNK; k <<= 1)

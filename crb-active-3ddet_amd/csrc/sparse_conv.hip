@@ -224,6 +224,181 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// v2 of the forward kernel for CIN % 16 == 0 (one 16-row tile per wave). Same tiling, LDS layout and arithmetic order as
+// above, restructured after reading the ISA of v1 (tools/pmc_sparse_conv.sh: 39 % of wave cycles parked in s_waitcnt,
+// MFMA pipe 51 % busy): the `a_cur = a_nxt` register copies made the compiler wait for the just-issued gather in the
+// middle of every MFMA block. Here the two A fragments ping-pong (two copies of the MFMA block, wave-uniform branch), so a
+// prefetched row is first touched one phase later, and the W operands of k-group s+1 are read from LDS under the MFMAs of
+// group s. Measured on the SECOND bs=16 geometry (tools/bench_sparse_conv.py, v1 -> v2): 97.5 -> 85.7 us at C=32, 218 ->
+// 203 us (L3) / 167 -> 153 us (L4) at C=64; with all 27 neighbours present 436 -> 363 us = 117 TF (75 % of the f32 MFMA
+// peak). A third variant that split the OUTPUT COLUMNS over the 4 waves (identical work per wave, A tile shared through
+// LDS, 2 barriers per phase) was correct but slower (238 us L3, 95 TF dense) and is not kept. What remains on real tables
+// is per-phase latency: time fits 25 us + 12.6 us x (offsets in the workgroup union), i.e. a phase costs the same whether 4
+// or 1 of its tiles are active — the W[o] global->LDS hand-off and its barrier set a floor the MFMA work does not fill.
+// ---------------------------------------------------------------------------------------------------
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                               const int* __restrict__ nbr, const int* __restrict__ perm,
+                                                               float* __restrict__ Y, int n_out, int K, int ntiles) {
+  static_assert(CIN % 16 == 0 && COUT % 16 == 0, "v2 needs whole float4 k-groups and unmasked column blocks");
+  constexpr int NB = (COUT + 15) / 16;
+  constexpr int WS = NB * 16;
+  constexpr int KS = CIN / 16;                      // k-groups of 16 channels (4 MFMA k-steps each)
+  constexpr int WELEMS = CIN * NB * 16;
+  constexpr int WPT = (WELEMS + 255) / 256;
+  constexpr bool BDB = NB <= 2;                     // double-buffer the B operands while they fit in registers
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* w_lds0 = reinterpret_cast<float*>(smem);
+  float* w_lds1 = w_lds0 + CIN * WS;
+  int* nbr_lds = reinterpret_cast<int*>(smem + 2 * sizeof(float) * CIN * WS);   // 64 * K ints
+  __shared__ unsigned wg_mask_sh[4];
+
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  if (tile >= ntiles) return;
+  const int row0 = tile * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+  const int rows_here = min(64, n_out - row0);
+  for (int t = threadIdx.x; t < 64 * K; t += 256) nbr_lds[t] = (t / K < rows_here) ? nbr[(int64_t)row0 * K + t] : -1;
+  __syncthreads();
+  const int* my_nbr = nbr_lds + (wave * 16 + li) * K;
+  unsigned sm = 0;
+  for (int o = 0; o < K; ++o)
+    if (__ballot(my_nbr[o] >= 0)) sm |= 1u << o;
+  sm = __builtin_amdgcn_readfirstlane(sm);
+  if (lane == 0) wg_mask_sh[wave] = sm;
+  __syncthreads();
+  unsigned todo = wg_mask_sh[0] | wg_mask_sh[1] | wg_mask_sh[2] | wg_mask_sh[3];
+
+  f32x4 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float wreg[WPT];
+  auto w_fetch = [&](int o) {
+    const float* wsrc = W + (int64_t)o * CIN * COUT;
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+      const int q = threadIdx.x + 256 * (j / NB);
+      const int nb = j % NB;
+      const int k = q >> 4, l = q & 15, c = nb * 16 + l;
+      wreg[j] = wsrc[k * COUT + c];                  // CIN*16 is a multiple of 256: no tail predicate
+    }
+  };
+  auto w_store = [&](float* dst) {
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+      const int q = threadIdx.x + 256 * (j / NB);
+      const int nb = j % NB;
+      dst[(q >> 4) * WS + (q & 15) * NB + nb] = wreg[j];
+    }
+  };
+  // Loads are issued unconditionally (invalid rows read row 0 and are zeroed by a select at use): every path through a
+  // phase then issues the same number of VMEM loads, so the compiler's in-order vmcnt bookkeeping can leave the prefetch
+  // outstanding across the phase instead of draining it at the next control-flow join.
+  auto load_a = [&](f32x4 (&a)[KS], const float* xbase, int r) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(xbase + (int64_t)(r < 0 ? 0 : r) * CIN + 4 * g);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) a[s] = src[4 * s];
+  };
+  auto load_b = [&](float (&b)[4][NB], const float* wl, int s) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float* src = wl + (16 * s + 4 * g + t) * WS + li * NB;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) b[t][nb] = src[nb];
+    }
+  };
+  auto mfma_block = [&](const f32x4 (&a)[KS], bool valid, const float* wl) {
+    if constexpr (BDB) {
+      float b[2][4][NB];
+      load_b(b[0], wl, 0);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        if (s + 1 < KS) load_b(b[(s + 1) & 1], wl, s + 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float av = valid ? a[s][t] : 0.f;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[s & 1][t][nb], acc[nb], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        float b[4][NB];
+        load_b(b, wl, s);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float av = valid ? a[s][t] : 0.f;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[t][nb], acc[nb], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  int cur = todo ? __ffs(todo) - 1 : -1;
+  if (cur >= 0) { w_fetch(cur); w_store(w_lds0); }
+  // `mine`: this wave's offsets not yet multiplied, ascending. The lowest one (p) is the pending item, resident in a0
+  // (ph == 0) or a1; every phase (re)loads p's successor q into the other fragment, whether or not the wave takes part in
+  // the phase, and a phase that consumes p flips ph.
+  unsigned mine = sm;
+  f32x4 a0[KS], a1[KS];
+  int r0, r1 = -1;
+  {
+    const int o = mine ? __ffs(mine) - 1 : -1;
+    r0 = o >= 0 ? my_nbr[o] : -1;
+    load_a(a0, X, r0);
+  }
+  __syncthreads();
+  int buf = 0;
+  bool ph = false;
+  while (cur >= 0) {
+    todo &= todo - 1;
+    const int nxt = todo ? __ffs(todo) - 1 : -1;
+    w_fetch(nxt >= 0 ? nxt : cur);                   // unconditional (the last phase re-reads its own W, unused)
+    const float* wl = buf ? w_lds1 : w_lds0;
+    const bool has = (sm >> cur) & 1u;               // wave-uniform; then cur is the lowest set bit of `mine`
+    const unsigned rest = mine & (mine - 1);
+    const int oq = rest ? __ffs(rest) - 1 : -1;
+    const int rq = oq >= 0 ? my_nbr[oq] : -1;
+    // the row index is laundered per arm: otherwise the compiler hoists the (identical) loads above the branch into a
+    // temporary and copies it into a0/a1 after the MFMA block, which re-introduces the wait this structure removes
+    if (!ph) {
+      int rr = rq;
+      asm volatile("" : "+v"(rr));
+      load_a(a1, X, rr);
+      r1 = rq;
+      if (has) mfma_block(a0, r0 >= 0, wl);
+    } else {
+      int rr = rq;
+      asm volatile("" : "+v"(rr));
+      load_a(a0, X, rr);
+      r0 = rq;
+      if (has) mfma_block(a1, r1 >= 0, wl);
+    }
+    if (has) { mine = rest; ph = !ph; }
+    w_store(buf ? w_lds0 : w_lds1);
+    __syncthreads();
+    buf ^= 1;
+    cur = nxt;
+  }
+
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    const int srow = row0 + wave * 16 + g * 4 + rg;
+    if (srow < n_out) {
+      const int row = perm ? perm[srow] : srow;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        if (nb * 16 + li < COUT) Y[(int64_t)row * COUT + nb * 16 + li] = acc[nb][rg];
+    }
+  }
+}
+
 // one 32-bit neighbour mask per row (bit o set <=> nbr[row][o] >= 0); sort key for the row permutation
 __global__ __launch_bounds__(256) void nbr_mask_kernel(const int* __restrict__ nbr, int n, int K, int* __restrict__ mask) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -391,7 +566,18 @@ int launch_fwd(const float* X, const float* W, const int* nbr, const int* perm, 
   // rows per workgroup = 64*subt. Measured on the SECOND bs=16 geometry (tools/bench_sparse_conv.py): subt 1/2/4 =
   // 221/258/343 us at C=64, 96/115/160 us at C=32 — the kernel is latency-, not W-traffic-bound, so more, smaller
   // workgroups win. subt > 1 stays available for measurements only.
-  int subt = g_subt_override ? g_subt_override : 1;
+  int subt = (g_subt_override == 2 || g_subt_override == 4) ? g_subt_override : 1;
+  if constexpr (CIN % 16 == 0 && COUT % 16 == 0 && CIN <= 64) {
+    if (g_subt_override == 0 || g_subt_override == 8) {   // v2 (row-split waves, ping-pong A fragments)
+      const int ntiles = crb_cdiv(n_out, 64);
+      const int grid = ((ntiles + 7) / 8) * 8;
+      size_t lds = 2 * sizeof(float) * CIN * (((COUT + 15) / 16) * 16) + sizeof(int) * 64 * K;
+      hipLaunchKernelGGL((sparse_conv_fwd2_kernel<CIN, COUT>), dim3(grid), dim3(256), lds, st, X, W, nbr, perm, Y,
+                         (int)n_out, K, ntiles);
+      CRB_CHECK_LAUNCH();
+      return CRB_OK;
+    }
+  }
   if constexpr (CIN >= 16 && COUT <= 64) {
     if (subt == 4) return launch_fwd_subt<CIN, COUT, 4>(X, W, nbr, perm, Y, n_out, K, st);
     if (subt == 2) return launch_fwd_subt<CIN, COUT, 2>(X, W, nbr, perm, Y, n_out, K, st);
@@ -426,7 +612,8 @@ extern "C" int crb_sparse_conv_supported(int cin, int cout) {
 }
 
 extern "C" int crb_sparse_conv_set_subtiles(int subt) {
-  g_subt_override = (subt == 1 || subt == 2 || subt == 4) ? subt : 0;
+  // 0 = default (v2 where the shape allows, else v1); 1,2,4 = v1 with that many row tiles per wave; 8 = v2 (A/B runs)
+  g_subt_override = (subt == 1 || subt == 2 || subt == 4 || subt == 8) ? subt : 0;
   return CRB_OK;
 }
 

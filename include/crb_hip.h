@@ -93,13 +93,15 @@ int crb_pairs_from_nbr(const int32_t* nbr, int64_t n_out, int K, int32_t* pair_i
  * (crb_nbr_masks -> sort -> crb_nbr_permute) lets a wave skip every kernel offset none of its 16 rows uses. */
 int crb_sparse_conv_supported(int cin, int cout);
 int crb_nbr_masks(const int32_t* nbr, int64_t n, int K, int32_t* mask, void* stream);
-/* stable sort of the rows of every chunk of crb_mask_sort_chunk_rows() consecutive rows by mask -> perm (n) */
+/* stable sort of the rows of every chunk of crb_mask_sort_chunk_rows() consecutive rows by mask, DESCENDING (rows with the
+ * most neighbours first) -> perm (n) */
 int crb_mask_sort_chunk_rows(void);
 int crb_mask_sort_chunks(const int32_t* mask, int64_t n, int32_t* perm, void* stream);
 int crb_nbr_permute(const int32_t* nbr, const int32_t* perm, int64_t n, int K, int32_t* nbr_sorted, void* stream);
 int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, const int32_t* perm, float* Y,
                             int64_t n_out, int K, int cin, int cout, void* stream);
-/* tuning knob for measurements: rows per workgroup = 64*subt (0 = built-in heuristic) */
+/* kernel-variant knob for A/B measurements only: 0 = default (v2 kernel where Cin,Cout are multiples of 16 and Cin <= 64,
+ * else v1); 1|2|4 = v1 with 64*subt rows per workgroup; 8 = v2. Results are identical up to f32 summation order. */
 int crb_sparse_conv_set_subtiles(int subt);
 /* dW (K,cin,cout) = sum over pairs X[pin]^T dY[pout] */
 int crb_sparse_conv_wgrad_splits(void);

@@ -197,8 +197,8 @@ def test_spconv_module_api_backbone_chain(dev):
 
 
 def test_chunk_mask_sort_is_a_stable_sort_per_chunk(dev):
-    """the LDS bitonic chunk sort equals a stable sort by (chunk, unsigned mask) — the gather-GEMM result does not depend
-    on it, the MFMA skipping efficiency does"""
+    """the LDS bitonic chunk sort equals a stable sort by (chunk, unsigned mask DESCENDING: heaviest tiles first) — the
+    gather-GEMM result does not depend on it, the MFMA skipping efficiency and the launch tail do"""
     from crbhip import lib, check, ptr, cur_stream
     rng = np.random.default_rng(3)
     for n in (1, 100, 4096, 4097, 50000):
@@ -208,7 +208,7 @@ def test_chunk_mask_sort_is_a_stable_sort_per_chunk(dev):
         perm = torch.empty(n, dtype=torch.int32, device=dev)
         check(lib.crb_mask_sort_chunks(ptr(m), n, ptr(perm), cur_stream(dev)), 'sort')
         chunk = lib.crb_mask_sort_chunk_rows()
-        key = (np.arange(n) // chunk).astype(np.int64) * (1 << 32) + mask.astype(np.int64)
+        key = (np.arange(n) // chunk).astype(np.int64) * (1 << 32) + ((~mask.astype(np.int64)) & 0xffffffff)
         np.testing.assert_array_equal(perm.cpu().numpy(), np.argsort(key, kind='stable'))
 
 

@@ -19,6 +19,9 @@ def main():
     ap.add_argument('--no-sort', action='store_true')
     ap.add_argument('--levels', default='1,2,3,4')
     ap.add_argument('--chunk', type=int, default=None)
+    ap.add_argument('--dense-random', action='store_true', help='all 27 neighbours present, rows drawn at random inside +-4096 rows (real-table-like locality)')
+    ap.add_argument('--dense-k', type=int, default=27, help='with --dense: only the first k offsets are present in every row')
+    ap.add_argument('--dense', action='store_true', help='synthetic table with all 27 neighbours present (no skip imbalance)')
     args = ap.parse_args()
     from crbhip import sparse, voxel
     from pcdet.datasets.synthetic import kitti_batch, KITTI_RANGE, KITTI_VOXEL
@@ -50,6 +53,22 @@ def main():
         w = torch.randn(27, cin, cout, device=dev) / 10
         table = rb.sorted_table('nbr')
         pairs = rb.pairs()
+        if args.dense_random:
+            g = torch.Generator(device=dev).manual_seed(0)
+            ar = torch.arange(n, device=dev, dtype=torch.int64).view(-1, 1)
+            jit = torch.randint(-4096, 4096, (n, 27), device=dev, generator=g)
+            dense_nbr = ((ar + jit) % n).to(torch.int32).contiguous()
+            if args.dense_k < 27:
+                dense_nbr[:, args.dense_k:] = -1
+            table = (dense_nbr, None)
+            P = min(27, args.dense_k) * n
+        if args.dense:
+            ar = torch.arange(n, device=dev, dtype=torch.int64).view(-1, 1)
+            dense_nbr = ((ar + torch.arange(27, device=dev, dtype=torch.int64).view(1, -1) * 97) % n).to(torch.int32).contiguous()
+            if args.dense_k < 27:
+                dense_nbr[:, args.dense_k:] = -1
+            table = (dense_nbr, None)
+            P = min(27, args.dense_k) * n
 
         def timeit(fn):
             for _ in range(5):
@@ -65,7 +84,7 @@ def main():
 
         from crbhip import lib
         ts = {}
-        for st_ in (1, 2, 4):
+        for st_ in (1, 2, 8):                                     # v1 (1 / 2 row tiles per wave), v2
             lib.crb_sparse_conv_set_subtiles(st_)
             ts[st_] = timeit(lambda: sparse._conv_forward_raw(x, w, table, n))
         lib.crb_sparse_conv_set_subtiles(0)
@@ -76,7 +95,7 @@ def main():
         print('L%d subm %dx%d N=%d P=%d (%.2f/row) | fwd %.1f us  %.0f GB/s alg (%.1f%% of 8TB/s)  %.1f TF | '
               'wgrad %.1f us %.1f TF' % (
                   lvl, cin, cout, n, P, P / n, t_f, balg / t_f / 1e3, balg / t_f / 1e3 / 80, fl / t_f / 1e6, t_w,
-                  fl / t_w / 1e6), 'subt1/2/4 %.1f %.1f %.1f us' % (ts[1], ts[2], ts[4]), flush=True)
+                  fl / t_w / 1e6), 'v1/v1x2/v2 %.1f %.1f %.1f us' % (ts[1], ts[2], ts[8]), flush=True)
 
 
 if __name__ == '__main__':

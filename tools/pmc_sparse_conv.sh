@@ -1,27 +1,34 @@
+# PMC passes for the subm gather-GEMM forward (level-3 geometry of SECOND bs=16). Separate passes (SQ / FETCH_SIZE /
+# WRITE_SIZE), counters only (+ --kernel-trace), instrumentation limited to the conv kernel, every pass under `timeout`.
+# usage (GPU box): bash tools/pmc_sparse_conv.sh [level] ; writes gpurun_out/pmc_sparse_conv_L<level>.txt
+LEVEL=${1:-3}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_sparse_conv_L$LEVEL.txt
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/pmc1 -o p -- python $GRAFT_REPO_ROOT/tools/bench_sparse_conv.py --levels 3 --iters 3 > /tmp/pmc1.log 2>&1
-python - <<'PY'
-import csv, glob, collections
-f = glob.glob('/tmp/pmc1/*counter_collection.csv')
+: > $OUT
+run_pass () {   # name, counters...
+  name=$1; shift
+  rm -rf /tmp/pmc_$name
+  timeout 240 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "sparse_conv_fwd_kernel" --output-format csv \
+      -d /tmp/pmc_$name -o p -- python $GRAFT_REPO_ROOT/tools/pmc_driver.py $LEVEL 3 > /tmp/pmc_$name.log 2>&1
+  echo "== pass $name rc=$? : $@" >> $OUT
+  grep -a PMC_DRIVER /tmp/pmc_$name.log >> $OUT
+  python - $name >> $OUT <<'PY'
+import csv, glob, collections, sys
+f = glob.glob('/tmp/pmc_%s/**/*counter_collection.csv' % sys.argv[1], recursive=True)
+if not f:
+    print('no counter file'); sys.exit(0)
 rows = list(csv.DictReader(open(f[0])))
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+agg = collections.defaultdict(float); n = collections.Counter()
 for r in rows:
-    k = r['Kernel_Name'][:70]
-    agg[k][r['Counter_Name']] += float(r['Counter_Value'])
-for k, v in agg.items():
-    if 'sparse_conv' in k:
-        print(k, {c: '%.3g' % x for c, x in v.items()})
+    if 'sparse_conv_fwd' in r['Kernel_Name']:
+        agg[r['Counter_Name']] += float(r['Counter_Value']); n[r['Counter_Name']] += 1
+for c, x in agg.items():
+    print('%-28s %.6g per launch (%d launches)' % (c, x / n[c], n[c]))
 PY
-rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d /tmp/pmc2 -o p -- python $GRAFT_REPO_ROOT/tools/bench_sparse_conv.py --levels 3 --iters 3 > /tmp/pmc2.log 2>&1
-python - <<'PY'
-import csv, glob, collections
-f = glob.glob('/tmp/pmc2/*counter_collection.csv')
-rows = list(csv.DictReader(open(f[0])))
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
-for r in rows:
-    k = r['Kernel_Name'][:70]
-    agg[k][r['Counter_Name']] += float(r['Counter_Value']); n[(k, r['Counter_Name'])] += 1
-for k, v in agg.items():
-    if 'sparse_conv' in k:
-        print(k, {c: '%.4g per launch' % (x / n[(k, c)]) for c, x in v.items()})
-PY
+}
+run_pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS
+run_pass sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM
+run_pass fetch FETCH_SIZE
+run_pass write WRITE_SIZE
+run_pass tcc TCC_HIT_sum TCC_MISS_sum
+cat $OUT
