@@ -65,7 +65,15 @@ def _load():
 lib = _load()
 
 
+# Tensors whose address went into the argument list of the call being assembled. `ptr(x.contiguous())` or `ptr(_i32(cnt))`
+# may be handed a temporary: without a reference it is freed the moment ptr() returns and the caching allocator can give
+# the same block to the next temporary of the SAME argument list. They are released once the launch call has returned
+# (check()); from then on stream order protects the memory like any other torch tensor.
+_keepalive = []
+
+
 def check(rc, what):
+    _keepalive.clear()
     if rc != 0:
         raise CrbHipError(f'{what} failed: {_ERR.get(rc, rc)}')
 
@@ -76,6 +84,9 @@ def ptr(t):
         return None
     if not t.is_contiguous():
         raise CrbHipError('C-ABI needs contiguous tensors')
+    if len(_keepalive) > 256:                      # ptr() used outside a check(...) call: stay bounded
+        del _keepalive[:128]
+    _keepalive.append(t)
     return ctypes.c_void_p(t.data_ptr())
 
 

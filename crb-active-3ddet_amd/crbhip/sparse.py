@@ -57,6 +57,7 @@ class Rulebook(object):
         return self._pairs_t
 
 
+TILE_LPT = True       # 64-row tiles of the sorted table dispatched heaviest first (crb_tile_lpt_perm)
 MASK_SORT = True      # set False to run the kernel on the natural row order (A/B measurements)
 # rows are sorted by neighbour mask inside chunks of this many consecutive rows: a global sort maximises MFMA skipping
 # (0.89 vs 0.80 useful/issued) but scatters each tile's gathers over the whole feature map (L2 misses); chunks keep the
@@ -81,6 +82,13 @@ def _mask_sort(table, K):
         else:
             key = mask.long() & 0xffffffff
         perm = torch.sort(key, stable=True)[1].to(torch.int32)
+    if TILE_LPT and n >= 128:
+        wsb = lib.crb_tile_lpt_workspace_bytes(n)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        perm2 = torch.empty_like(perm)
+        check(lib.crb_tile_lpt_perm(ptr(mask), ptr(perm), n, ptr(perm2), ptr(ws), wsb, cur_stream(dev)),
+              'crb_tile_lpt_perm')
+        perm = perm2
     out = torch.empty_like(table)
     check(lib.crb_nbr_permute(ptr(table), ptr(perm), n, K, ptr(out), cur_stream(dev)), 'crb_nbr_permute')
     return out, perm

@@ -205,6 +205,50 @@ __global__ __launch_bounds__(1024) void mask_sort_chunks_kernel(const int* __res
   }
 }
 
+// ---- heaviest-tile-first order of the 64-row tiles of a mask-sorted table -------------------------------------------
+// A gather-GEMM workgroup runs one phase per kernel offset present in ANY of its 64 rows (1..27 phases), so tile run times
+// differ by more than an order of magnitude; dispatched in table order the last tiles of a launch can be 27-phase ones and
+// most CUs idle behind them. The table is cut into 8 contiguous ranges of tiles, one per XCD (workgroup b runs on XCD b % 8
+// and takes tile (b % 8) * per + b / 8, see xcd_remap in sparse_conv.hip): a range keeps its rows — and with them the L2
+// footprint of its gathers — on one XCD, and INSIDE each range the tiles are ranked heaviest first by popcount of the OR of
+// their row masks (33-bin counting sort per range, two tiny launches). The order among equally heavy tiles is arbitrary
+// (atomics) — results do not depend on it, every tile writes its own rows.
+constexpr int LPT_RANGES = 8;
+
+__global__ __launch_bounds__(256) void tile_weight_kernel(const int* __restrict__ mask, const int* __restrict__ perm,
+                                                          int ntiles, int per, int* __restrict__ weight,
+                                                          int* __restrict__ hist) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= ntiles) return;
+  const int lane = threadIdx.x & 63;
+  const unsigned m = (unsigned)mask[perm[(int64_t)t * 64 + lane]];
+  int w = 0;
+  for (int b = 0; b < 32; ++b) w += __ballot((m >> b) & 1u) != 0ULL;      // bits present in any of the 64 rows
+  if (lane == 0) {
+    weight[t] = w;
+    atomicAdd(&hist[(t / per) * 64 + w], 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void tile_place_kernel(const int* __restrict__ weight, const int* __restrict__ hist,
+                                                         int* __restrict__ cursor, int ntiles, int per,
+                                                         int* __restrict__ order) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= ntiles) return;
+  const int w = weight[t], r = t / per;
+  int base = r * per;
+  for (int b = 32; b > w; --b) base += hist[r * 64 + b];
+  order[base + atomicAdd(&cursor[r * 64 + w], 1)] = t;
+}
+
+__global__ __launch_bounds__(256) void tile_perm_kernel(const int* __restrict__ perm, const int* __restrict__ order,
+                                                        int n, int ntiles, int* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int t = i >> 6;
+  out[i] = t < ntiles ? perm[(order[t] << 6) + (i & 63)] : perm[i];
+}
+
 }  // namespace
 
 extern "C" int crb_mask_sort_chunk_rows(void) { return SORT_CHUNK; }
@@ -326,4 +370,35 @@ extern "C" int crb_pairs_from_nbr(const int32_t* nbr, int64_t n_out, int K, int3
   PairFlag f{mask, (int)n_out};
   PairWrite w{nbr, (int)n_out, K, pair_in, pair_out, pair_start};
   return crb_device_excl_scan(f, w, n_out * K, tiles, pair_start + K, st);
+}
+
+extern "C" int64_t crb_tile_lpt_workspace_bytes(int64_t n) { return (2 * LPT_RANGES * 64 + 2 * (n / 64 + 1)) * 4; }
+
+extern "C" int crb_tile_lpt_ranges(void) { return LPT_RANGES; }
+
+// perm_out = perm_in with the full 64-row tiles of each of the crb_tile_lpt_ranges() contiguous tile ranges re-ordered
+// heaviest first (weight = number of kernel offsets present in any row of the tile); the trailing partial tile stays last.
+// Range length = ceil(ceil(n/64) / ranges) tiles — the split xcd_remap uses. mask (n) is indexed by ORIGINAL row.
+extern "C" int crb_tile_lpt_perm(const int32_t* mask, const int32_t* perm_in, int64_t n, int32_t* perm_out,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+  if (n < 0 || n >= (1LL << 31)) return CRB_ERR_ARG;
+  if (n == 0) return CRB_OK;
+  if (!workspace || workspace_bytes < crb_tile_lpt_workspace_bytes(n)) return CRB_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int ntiles = (int)(n / 64);                               // full tiles
+  const int per = (int)((crb_cdiv(n, 64) + LPT_RANGES - 1) / LPT_RANGES);
+  int* hist = (int*)workspace;                                    // [range][64 bins] (0..32 used)
+  int* cursor = hist + LPT_RANGES * 64;
+  int* weight = cursor + LPT_RANGES * 64;
+  int* order = weight + ntiles + 1;
+  CRB_HIP(hipMemsetAsync(hist, 0, 2 * LPT_RANGES * 64 * 4, st));
+  if (ntiles > 0) {
+    hipLaunchKernelGGL(tile_weight_kernel, dim3(crb_cdiv(ntiles, 4)), dim3(256), 0, st, mask, perm_in, ntiles, per, weight,
+                       hist);
+    hipLaunchKernelGGL(tile_place_kernel, dim3(crb_cdiv(ntiles, 256)), dim3(256), 0, st, weight, hist, cursor, ntiles, per,
+                       order);
+  }
+  hipLaunchKernelGGL(tile_perm_kernel, dim3(crb_cdiv(n, 256)), dim3(256), 0, st, perm_in, order, (int)n, ntiles, perm_out);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
 }

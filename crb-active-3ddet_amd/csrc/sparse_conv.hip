@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
 // is per-phase latency: time fits 25 us + 12.6 us x (offsets in the workgroup union), i.e. a phase costs the same whether 4
 // or 1 of its tiles are active — the W[o] global->LDS hand-off and its barrier set a floor the MFMA work does not fill.
 // ---------------------------------------------------------------------------------------------------
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool NOMFMA = false, bool REMAP = true>
 __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                                const int* __restrict__ nbr, const int* __restrict__ perm,
                                                                float* __restrict__ Y, int n_out, int K, int ntiles) {
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
   int* nbr_lds = reinterpret_cast<int*>(smem + 2 * sizeof(float) * CIN * WS);   // 64 * K ints
   __shared__ unsigned wg_mask_sh[4];
 
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   if (tile >= ntiles) return;
   const int row0 = tile * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
@@ -310,7 +310,10 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
     }
   };
   auto mfma_block = [&](const f32x4 (&a)[KS], bool valid, const float* wl) {
-    if constexpr (BDB) {
+    if constexpr (NOMFMA) {                          // measurement build: staging chain only (result is garbage)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) acc[0][0] += valid ? a[s][0] + wl[(16 * s + 4 * g) * WS + li * NB] : 0.f;
+    } else if constexpr (BDB) {
       float b[2][4][NB];
       load_b(b[0], wl, 0);
 #pragma unroll
@@ -342,49 +345,40 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
 
   int cur = todo ? __ffs(todo) - 1 : -1;
   if (cur >= 0) { w_fetch(cur); w_store(w_lds0); }
-  // `mine`: this wave's offsets not yet multiplied, ascending. The lowest one (p) is the pending item, resident in a0
-  // (ph == 0) or a1; every phase (re)loads p's successor q into the other fragment, whether or not the wave takes part in
-  // the phase, and a phase that consumes p flips ph.
-  unsigned mine = sm;
+  // Phases are unrolled by two so the two A fragments alternate statically: phase `cur` multiplies fragment a0 while the
+  // rows of the workgroup's NEXT offset are fetched into a1, then the roles swap. Every wave prefetches for every phase of
+  // the workgroup (also for offsets its own tile lacks: those rows are -1 -> row 0, never multiplied), so all paths issue
+  // the same loads and only the MFMA block itself sits under the wave-uniform `has` branch.
   f32x4 a0[KS], a1[KS];
-  int r0, r1 = -1;
-  {
-    const int o = mine ? __ffs(mine) - 1 : -1;
-    r0 = o >= 0 ? my_nbr[o] : -1;
-    load_a(a0, X, r0);
-  }
+  int r0 = cur >= 0 ? my_nbr[cur] : -1, r1 = -1;
+  load_a(a0, X, r0);
   __syncthreads();
-  int buf = 0;
-  bool ph = false;
   while (cur >= 0) {
-    todo &= todo - 1;
-    const int nxt = todo ? __ffs(todo) - 1 : -1;
-    w_fetch(nxt >= 0 ? nxt : cur);                   // unconditional (the last phase re-reads its own W, unused)
-    const float* wl = buf ? w_lds1 : w_lds0;
-    const bool has = (sm >> cur) & 1u;               // wave-uniform; then cur is the lowest set bit of `mine`
-    const unsigned rest = mine & (mine - 1);
-    const int oq = rest ? __ffs(rest) - 1 : -1;
-    const int rq = oq >= 0 ? my_nbr[oq] : -1;
-    // the row index is laundered per arm: otherwise the compiler hoists the (identical) loads above the branch into a
-    // temporary and copies it into a0/a1 after the MFMA block, which re-introduces the wait this structure removes
-    if (!ph) {
-      int rr = rq;
-      asm volatile("" : "+v"(rr));
-      load_a(a1, X, rr);
-      r1 = rq;
-      if (has) mfma_block(a0, r0 >= 0, wl);
-    } else {
-      int rr = rq;
-      asm volatile("" : "+v"(rr));
-      load_a(a0, X, rr);
-      r0 = rq;
-      if (has) mfma_block(a1, r1 >= 0, wl);
+    {                                                // even phase: W in w_lds0, A in a0
+      todo &= todo - 1;
+      const int nxt = todo ? __ffs(todo) - 1 : -1;
+      const int oq = nxt >= 0 ? nxt : cur;           // the last phase re-fetches its own offset (unused)
+      w_fetch(oq);
+      r1 = my_nbr[oq];
+      load_a(a1, X, r1);
+      if ((sm >> cur) & 1u) mfma_block(a0, r0 >= 0, w_lds0);
+      w_store(w_lds1);
+      __syncthreads();
+      cur = nxt;
     }
-    if (has) { mine = rest; ph = !ph; }
-    w_store(buf ? w_lds0 : w_lds1);
-    __syncthreads();
-    buf ^= 1;
-    cur = nxt;
+    if (cur < 0) break;
+    {                                                // odd phase: W in w_lds1, A in a1
+      todo &= todo - 1;
+      const int nxt = todo ? __ffs(todo) - 1 : -1;
+      const int oq = nxt >= 0 ? nxt : cur;
+      w_fetch(oq);
+      r0 = my_nbr[oq];
+      load_a(a0, X, r0);
+      if ((sm >> cur) & 1u) mfma_block(a1, r1 >= 0, w_lds1);
+      w_store(w_lds0);
+      __syncthreads();
+      cur = nxt;
+    }
   }
 
 #pragma unroll
@@ -568,10 +562,24 @@ int launch_fwd(const float* X, const float* W, const int* nbr, const int* perm, 
   // workgroups win. subt > 1 stays available for measurements only.
   int subt = (g_subt_override == 2 || g_subt_override == 4) ? g_subt_override : 1;
   if constexpr (CIN % 16 == 0 && COUT % 16 == 0 && CIN <= 64) {
-    if (g_subt_override == 0 || g_subt_override == 8) {   // v2 (row-split waves, ping-pong A fragments)
+    if (g_subt_override == 0 || g_subt_override == 8 || g_subt_override == 9 || g_subt_override == 16) {   // v2
       const int ntiles = crb_cdiv(n_out, 64);
       const int grid = ((ntiles + 7) / 8) * 8;
       size_t lds = 2 * sizeof(float) * CIN * (((COUT + 15) / 16) * 16) + sizeof(int) * 64 * K;
+      if constexpr (CIN == 64 && COUT == 64) {
+        if (g_subt_override == 16) {                 // measurement: tiles in blockIdx order (no XCD-contiguous remap)
+          hipLaunchKernelGGL((sparse_conv_fwd2_kernel<CIN, COUT, false, false>), dim3(grid), dim3(256), lds, st, X, W, nbr,
+                             perm, Y, (int)n_out, K, ntiles);
+          CRB_CHECK_LAUNCH();
+          return CRB_OK;
+        }
+        if (g_subt_override == 9) {                  // staging-only measurement variant (wrong results by design)
+          hipLaunchKernelGGL((sparse_conv_fwd2_kernel<CIN, COUT, true>), dim3(grid), dim3(256), lds, st, X, W, nbr, perm,
+                             Y, (int)n_out, K, ntiles);
+          CRB_CHECK_LAUNCH();
+          return CRB_OK;
+        }
+      }
       hipLaunchKernelGGL((sparse_conv_fwd2_kernel<CIN, COUT>), dim3(grid), dim3(256), lds, st, X, W, nbr, perm, Y,
                          (int)n_out, K, ntiles);
       CRB_CHECK_LAUNCH();
@@ -613,7 +621,7 @@ extern "C" int crb_sparse_conv_supported(int cin, int cout) {
 
 extern "C" int crb_sparse_conv_set_subtiles(int subt) {
   // 0 = default (v2 where the shape allows, else v1); 1,2,4 = v1 with that many row tiles per wave; 8 = v2 (A/B runs)
-  g_subt_override = (subt == 1 || subt == 2 || subt == 4 || subt == 8) ? subt : 0;
+  g_subt_override = (subt == 1 || subt == 2 || subt == 4 || subt == 8 || subt == 9 || subt == 16) ? subt : 0;
   return CRB_OK;
 }
 

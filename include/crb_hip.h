@@ -97,6 +97,15 @@ int crb_nbr_masks(const int32_t* nbr, int64_t n, int K, int32_t* mask, void* str
  * most neighbours first) -> perm (n) */
 int crb_mask_sort_chunk_rows(void);
 int crb_mask_sort_chunks(const int32_t* mask, int64_t n, int32_t* perm, void* stream);
+/* perm_out = perm_in with the full 64-row tiles of each of crb_tile_lpt_ranges() contiguous tile ranges (one per XCD, the
+ * split the gather-GEMM's workgroup->tile map uses) re-ordered heaviest first; weight = kernel offsets present in any row
+ * of the tile = phases its workgroup will run. A launch then ends on light tiles instead of idling behind 27-phase ones,
+ * and a range's gathers stay in one XCD's L2. mask as written by crb_nbr_masks (indexed by original row). The order among
+ * equal weights is arbitrary; the trailing partial tile stays last. */
+int crb_tile_lpt_ranges(void);
+int64_t crb_tile_lpt_workspace_bytes(int64_t n);
+int crb_tile_lpt_perm(const int32_t* mask, const int32_t* perm_in, int64_t n, int32_t* perm_out, void* workspace,
+                      int64_t workspace_bytes, void* stream);
 int crb_nbr_permute(const int32_t* nbr, const int32_t* perm, int64_t n, int K, int32_t* nbr_sorted, void* stream);
 int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, const int32_t* perm, float* Y,
                             int64_t n_out, int K, int cin, int cout, void* stream);

@@ -38,3 +38,22 @@ def test_missing_gpu_fails_loudly():
     with pytest.raises(crbhip.CrbHipError):
         voxel.voxelize(torch.zeros(10, 4), torch.tensor([0, 10], dtype=torch.int32), [0, -40, -3, 70.4, 40, 1],
                        [0.05, 0.05, 0.1], 100, 5)
+
+
+def test_ptr_keeps_temporaries_alive_until_check():
+    """`ptr(t.contiguous())` may receive a temporary; _lib keeps it referenced until check() so that the allocator cannot
+    hand its block to the next temporary of the same argument list"""
+    import gc
+    import weakref
+    import torch
+    from crbhip import _lib
+    t = torch.arange(12).view(3, 4).t()                     # non-contiguous -> .contiguous() makes a temporary
+    tmp = t.contiguous()
+    ref = weakref.ref(tmp)
+    p = _lib.ptr(tmp)
+    del tmp
+    gc.collect()
+    assert ref() is not None and p.value == ref().data_ptr()
+    _lib.check(0, 'noop')
+    gc.collect()
+    assert ref() is None

@@ -212,6 +212,38 @@ def test_chunk_mask_sort_is_a_stable_sort_per_chunk(dev):
         np.testing.assert_array_equal(perm.cpu().numpy(), np.argsort(key, kind='stable'))
 
 
+def test_tile_lpt_perm_orders_whole_tiles_heaviest_first(dev):
+    """crb_tile_lpt_perm: output = input perm with its full 64-row tiles moved as units INSIDE their range (8 contiguous
+    ranges of ceil(ceil(n/64)/8) tiles), tile weights (popcount of the OR of the tile's row masks) non-increasing within a
+    range, trailing partial tile untouched"""
+    from crbhip import lib, check, ptr, cur_stream
+    rng = np.random.default_rng(5)
+    R = lib.crb_tile_lpt_ranges()
+    for n in (64, 130, 4096 + 17, 30000):
+        mask = (rng.integers(0, 1 << 27, n) & rng.integers(0, 1 << 27, n) & rng.integers(0, 1 << 27, n)).astype(np.int32)
+        mask[rng.random(n) < 0.6] = 0                         # spread the tile weights
+        perm = np.argsort(mask, kind='stable').astype(np.int32)
+        out = torch.empty(n, dtype=torch.int32, device=dev)
+        wsb = lib.crb_tile_lpt_workspace_bytes(n)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        m_d, p_d = _t(mask, dev), _t(perm, dev)               # named: a temporary would be freed (and reused) after ptr()
+        check(lib.crb_tile_lpt_perm(ptr(m_d), ptr(p_d), n, ptr(out), ptr(ws), wsb, cur_stream(dev)), 'lpt')
+        o = out.cpu().numpy()
+        T = n // 64
+        per = -(-(-(-n // 64)) // R)
+        np.testing.assert_array_equal(o[T * 64:], perm[T * 64:])
+
+        def weight(rows):
+            return bin(int(np.bitwise_or.reduce(mask[rows].astype(np.int64) & 0xffffffff))).count('1')
+        for r in range(R):
+            t0, t1 = min(r * per, T), min((r + 1) * per, T)
+            tin = sorted(tuple(perm[64 * t:64 * t + 64]) for t in range(t0, t1))
+            tout = [tuple(o[64 * t:64 * t + 64]) for t in range(t0, t1)]
+            assert sorted(tout) == tin, (n, r)
+            w = [weight(np.array(t)) for t in tout]
+            assert all(a >= b for a, b in zip(w, w[1:])), (n, r, w)
+
+
 def test_bev_channels_last_scatter_equals_dense_view(dev):
     from crbhip import sparse
     rng = np.random.default_rng(6)

@@ -17,6 +17,7 @@ def main():
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--no-sort', action='store_true')
+    ap.add_argument('--no-lpt', action='store_true')
     ap.add_argument('--levels', default='1,2,3,4')
     ap.add_argument('--chunk', type=int, default=None)
     ap.add_argument('--dense-random', action='store_true', help='all 27 neighbours present, rows drawn at random inside +-4096 rows (real-table-like locality)')
@@ -27,6 +28,8 @@ def main():
     from pcdet.datasets.synthetic import kitti_batch, KITTI_RANGE, KITTI_VOXEL
     if args.no_sort:
         sparse.MASK_SORT = False
+    if args.no_lpt:
+        sparse.TILE_LPT = False
     if args.chunk is not None:
         sparse.MASK_SORT_CHUNK = args.chunk
     dev = torch.device('cuda', 0)
@@ -84,7 +87,7 @@ def main():
 
         from crbhip import lib
         ts = {}
-        for st_ in (1, 2, 8):                                     # v1 (1 / 2 row tiles per wave), v2
+        for st_ in (1, 16, 8):                                     # v1 (1 / 2 row tiles per wave), v2
             lib.crb_sparse_conv_set_subtiles(st_)
             ts[st_] = timeit(lambda: sparse._conv_forward_raw(x, w, table, n))
         lib.crb_sparse_conv_set_subtiles(0)
@@ -95,7 +98,7 @@ def main():
         print('L%d subm %dx%d N=%d P=%d (%.2f/row) | fwd %.1f us  %.0f GB/s alg (%.1f%% of 8TB/s)  %.1f TF | '
               'wgrad %.1f us %.1f TF' % (
                   lvl, cin, cout, n, P, P / n, t_f, balg / t_f / 1e3, balg / t_f / 1e3 / 80, fl / t_f / 1e6, t_w,
-                  fl / t_w / 1e6), 'v1/v1x2/v2 %.1f %.1f %.1f us' % (ts[1], ts[2], ts[8]), flush=True)
+                  fl / t_w / 1e6), 'v1/v2-noremap/v2 %.1f %.1f %.1f us' % (ts[1], ts[16], ts[8]), flush=True)
 
 
 if __name__ == '__main__':
