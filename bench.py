@@ -64,6 +64,18 @@ def make_batches(args, rank, device):
     return batches
 
 
+def pmc_traffic(cin, cout):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (bench.py cannot collect counters on itself:
+    they come from `bash tools/pmc_sparse_conv.sh`, summarised in profiles/r01_pmc_sparse_conv_fwd.json); None if the
+    summary is for another kernel instance"""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_sparse_conv_fwd.json')
+    try:
+        d = json.load(open(path))
+    except OSError:
+        return None
+    return d['traffic_bytes_per_launch_bench_mix'] if '<%d,%d>' % (cin, cout) in d.get('kernel', '') else None
+
+
 def roofline_from_profile(prof):
     """dominant subm gather-GEMM instance by total time; algorithmic bytes per SURVEY §8d:
     B_alg = 4 N_in C_in + 4 N_out C_out + 8 P + 4 K C_in C_out"""
@@ -97,8 +109,8 @@ def roofline_from_profile(prof):
     # machine balance of 19.7, so the f32 gather-GEMM is MFMA-bound; the HBM fraction is reported beside it.
     t_hbm = a['bytes'] / (HBM_PEAK_GBS * 1e9)
     t_mfma = a['flops'] / (MFMA_F32_PEAK_TF * 1e12)
-    kern = 'sparse_conv_fwd_kernel<%d,%d> (subm gather-GEMM fwd+dgrad)' % (key[1], key[2])
-    common = {'traffic': None, 'avg_launch_us': round(1e3 * a['ms'] / a['n'], 2), 'launches': a['n'],
+    kern = 'sparse_conv_fwd2_kernel<%d,%d> (subm gather-GEMM fwd+dgrad)' % (key[1], key[2])
+    common = {'traffic': pmc_traffic(key[1], key[2]), 'avg_launch_us': round(1e3 * a['ms'] / a['n'], 2), 'launches': a['n'],
               'alg_bytes_per_launch': round(a['bytes'] / a['n']), 'alg_flops_per_launch': round(a['flops'] / a['n']),
               'hbm_GBps_alg': round(gbs, 1), 'hbm_frac': round(gbs / HBM_PEAK_GBS, 4),
               'mfma_f32_TFLOPs': round(tfs, 2), 'mfma_f32_frac': round(tfs / MFMA_F32_PEAK_TF, 4),

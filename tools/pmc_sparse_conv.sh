@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 run_pass () {   # name, counters...
   name=$1; shift
   rm -rf /tmp/pmc_$name
-  timeout 240 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "sparse_conv_fwd_kernel" --output-format csv \
+  timeout 240 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "sparse_conv_fwd" --output-format csv \
       -d /tmp/pmc_$name -o p -- python $GRAFT_REPO_ROOT/tools/pmc_driver.py $LEVEL 3 > /tmp/pmc_$name.log 2>&1
   echo "== pass $name rc=$? : $@" >> $OUT
   grep -a PMC_DRIVER /tmp/pmc_$name.log >> $OUT
@@ -20,7 +20,7 @@ if not f:
 rows = list(csv.DictReader(open(f[0])))
 agg = collections.defaultdict(float); n = collections.Counter()
 for r in rows:
-    if 'sparse_conv_fwd' in r['Kernel_Name']:
+    if "sparse_conv_fwd" in r["Kernel_Name"]:
         agg[r['Counter_Name']] += float(r['Counter_Value']); n[r['Counter_Name']] += 1
 for c, x in agg.items():
     print('%-28s %.6g per launch (%d launches)' % (c, x / n[c], n[c]))
