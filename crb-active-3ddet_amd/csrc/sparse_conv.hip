@@ -423,26 +423,53 @@ struct WgradCfg {
   static constexpr int NB = (COUT + 15) / 16;
 };
 
+// plan (ints, written by wgrad_plan_kernel): [0] = 16-pair blocks per workgroup, [1] = workgroups in use,
+// [2 + o] = first workgroup of offset o (o = 0..K). Every workgroup gets the same number of pairs of ONE offset: the centre
+// offset of a SubM conv holds N pairs, a corner offset a few thousand — with a fixed number of splits per offset the centre
+// workgroups ran 3x longer than the average and the launch ended on them.
+__global__ __launch_bounds__(64) void wgrad_plan_kernel(const int* __restrict__ pstart, int K, int target,
+                                                        int* __restrict__ plan) {
+  const int o = threadIdx.x;
+  const int nb16 = o < K ? (pstart[o + 1] - pstart[o] + 15) >> 4 : 0;
+  int total = nb16;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
+  int cb = (total + target - 1) / target;
+  cb = cb < 1 ? 1 : cb;
+  const int nwg = (nb16 + cb - 1) / cb;
+  int incl = nwg;                                   // inclusive prefix over lanes
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(incl, d);
+    if (o >= d) incl += v;
+  }
+  if (o <= K) plan[2 + o] = incl - nwg;             // lane K: nwg = 0 -> total
+  if (o == 0) plan[0] = cb;
+  if (o == K) plan[1] = incl;
+}
+
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                                 const int* __restrict__ pin, const int* __restrict__ pout,
-                                                                const int* __restrict__ pstart,
-                                                                float* __restrict__ partial /* (S,K,CIN,COUT) */,
+                                                                const int* __restrict__ pstart, const int* __restrict__ plan,
+                                                                float* __restrict__ partial /* (workgroup,CIN,COUT) */,
                                                                 int K) {
   using C = WgradCfg<CIN, COUT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = reinterpret_cast<float*>(smem);   // SLICES>1: (SLICES-1) * CINP16 * COUT floats
-  // 1-D grid of K*S blocks. Block b runs on XCD b%8 (observed round-robin): all K offsets of one pair split are
-  // given to the SAME XCD and adjacent launch slots, so the X / dY rows of that split are re-read from one L2
-  // (offset o of split s touches the same output rows and their neighbours as offset o' of split s).
-  const int S = (int)gridDim.x / K;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int o = slot % K, sidx = (slot / K) * 8 + xcd;
+  // consecutive workgroups (= consecutive pair ranges of one offset, touching neighbouring rows) share an XCD and its L2
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  if (wg >= plan[1]) return;
+  const int cb = plan[0];
+  int o = 0;
+  for (int k = 1; k < K; ++k)
+    if (plan[2 + k] <= wg) o = k;                  // starts are non-decreasing; empty offsets share their successor's start
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int wci = wave % C::WCI, slice = wave / C::WCI;
   const int p0 = pstart[o], p1 = pstart[o + 1];
-  const int np = p1 - p0;
+  const int blk_lo = (wg - plan[2 + o]) * cb;
+  const int nblocks = min((p1 - p0 + 15) >> 4, blk_lo + cb);
 
   f32x4 acc[C::CIPW][C::NB];
 #pragma unroll
@@ -450,49 +477,68 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __r
 #pragma unroll
     for (int nb = 0; nb < C::NB; ++nb) acc[a][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // Each iteration covers 16 consecutive pairs (4 MFMA k-steps); blocks of 16 pairs are dealt round-robin to
-  // (workgroup, slice). All index loads, then all feature loads of the block are issued before the MFMAs, and the next
-  // block's indices are prefetched — the loop is latency-bound otherwise (dependent idx -> row -> MFMA chains).
-  const int nblocks_all = (np + 15) >> 4;
-  const int per_split = (nblocks_all + S - 1) / S;              // contiguous range of 16-pair blocks per split
-  const int blk_lo = sidx * per_split;
-  const int nblocks = min(nblocks_all, blk_lo + per_split);
-  const int bstride = C::SLICES;
-  int blk = blk_lo + slice;
-  int ji[4], io[4];
-  bool vld[4];
-  auto load_idx = [&](int b) {
+  // Each step covers 16 consecutive pairs (4 MFMA k-steps); steps are dealt round-robin to the pair slices of the
+  // workgroup. Software pipeline, statically double-buffered (two copies of the body): pair indices two steps ahead, the
+  // gathered X / dY values one step ahead, MFMAs on the current step. All loads are unconditional (clamped address, value
+  // zeroed by a select at use) so that every path issues the same number of VMEM loads and nothing drains early.
+  struct Idx { int ji[4], io[4]; };
+  struct Feat { float av[4][C::CIPW], bv[4][C::NB]; };
+  auto load_idx = [&](Idx& x, int b) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int p = p0 + b * 16 + u * 4 + g;
-      vld[u] = (b < nblocks) && (p < p1);
-      ji[u] = vld[u] ? pin[p] : 0;
-      io[u] = vld[u] ? pout[p] : 0;
+      int p = p0 + b * 16 + u * 4 + g;
+      p = p < p1 ? p : p1 - 1;                     // p1 > p0 for every workgroup in use
+      x.ji[u] = pin[p];
+      x.io[u] = pout[p];
     }
   };
-  load_idx(blk);
-  for (; blk < nblocks; blk += bstride) {
-    float bv[4][C::NB];
-    float av[4][C::CIPW];
+  auto load_feat = [&](Feat& f, const Idx& x) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
 #pragma unroll
-      for (int nb = 0; nb < C::NB; ++nb)
-        bv[u][nb] = (vld[u] && nb * 16 + li < COUT) ? dY[(int64_t)io[u] * COUT + nb * 16 + li] : 0.f;
+      for (int nb = 0; nb < C::NB; ++nb) {
+        const int c = nb * 16 + li;
+        f.bv[u][nb] = dY[(int64_t)x.io[u] * COUT + (c < COUT ? c : COUT - 1)];
+      }
 #pragma unroll
       for (int a = 0; a < C::CIPW; ++a) {
         const int ci = (wci * C::CIPW + a) * 16 + li;
-        av[u][a] = (vld[u] && ci < CIN) ? X[(int64_t)ji[u] * CIN + ci] : 0.f;
+        f.av[u][a] = X[(int64_t)x.ji[u] * CIN + (ci < CIN ? ci : CIN - 1)];
       }
     }
-    load_idx(blk + bstride);                 // indices of the next block fly during the MFMAs
+  };
+  auto mfma_step = [&](const Feat& f, int b) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 4; ++u) {
+      const bool v = (b < nblocks) && (p0 + b * 16 + u * 4 + g < p1);
 #pragma unroll
-      for (int a = 0; a < C::CIPW; ++a)
+      for (int a = 0; a < C::CIPW; ++a) {
+        const float av = (v && (wci * C::CIPW + a) * 16 + li < CIN) ? f.av[u][a] : 0.f;
 #pragma unroll
-        for (int nb = 0; nb < C::NB; ++nb)
-          acc[a][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][a], bv[u][nb], acc[a][nb], 0, 0, 0);
+        for (int nb = 0; nb < C::NB; ++nb) {
+          const float bv = (nb * 16 + li < COUT) ? f.bv[u][nb] : 0.f;
+          acc[a][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[a][nb], 0, 0, 0);
+        }
+      }
+    }
+  };
+  constexpr int BS = C::SLICES;
+  int blk = blk_lo + slice;
+  Idx i0, i1;
+  Feat f0, f1;
+  load_idx(i0, blk);
+  load_feat(f0, i0);
+  load_idx(i1, blk + BS);
+  while (blk < nblocks) {
+    load_feat(f1, i1);
+    load_idx(i0, blk + 2 * BS);
+    mfma_step(f0, blk);
+    blk += BS;
+    if (blk >= nblocks) break;
+    load_feat(f0, i0);
+    load_idx(i1, blk + 2 * BS);
+    mfma_step(f1, blk);
+    blk += BS;
   }
 
   // reduce pair slices through LDS (fixed order), slice 0 writes the partial
@@ -512,7 +558,7 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __r
     __syncthreads();
   }
   if (slice == 0) {
-    float* dst = partial + ((int64_t)sidx * K + o) * CIN * COUT;
+    float* dst = partial + (int64_t)wg * CIN * COUT;
 #pragma unroll
     for (int a = 0; a < C::CIPW; ++a)
 #pragma unroll
@@ -530,13 +576,26 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __r
   }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW,
-                                                           int64_t elems, int S) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= elems) return;
+// dW[o] = sum of the partials of offset o's workgroups. A 256-thread workgroup owns 32 consecutive elements of one offset;
+// 8 thread groups stride over the partials, then a fixed-shape LDS tree adds the 8 sums (same association every run).
+// The centre offset of a SubM conv has hundreds of partials: a serial per-element loop took longer than the wgrad itself
+// at C = 16.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, const int* __restrict__ plan,
+                                                           float* __restrict__ dW, int K, int per /* CIN*COUT */) {
+  __shared__ float sh[8][32];
+  const int chunks = (per + 31) >> 5;
+  const int o = blockIdx.x / chunks, e = (blockIdx.x - o * chunks) * 32 + (threadIdx.x & 31);
+  const int part = threadIdx.x >> 5;
+  const int w0 = plan[2 + o], w1 = plan[3 + o];
   float s = 0.f;
-  for (int k = 0; k < S; ++k) s += partial[(int64_t)k * elems + i];
-  dW[i] = s;
+  if (e < per)
+    for (int w = w0 + part; w < w1; w += 8) s += partial[(int64_t)w * per + e];
+  sh[part][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (part == 0 && e < per) {
+    const int l = threadIdx.x & 31;
+    dW[(int64_t)o * per + e] = ((sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l])) + ((sh[4][l] + sh[5][l]) + (sh[6][l] + sh[7][l]));
+  }
 }
 
 static int g_subt_override = 0;     // 0 = heuristic; 1/2/4 force (A/B measurements)
@@ -595,13 +654,15 @@ int launch_fwd(const float* X, const float* W, const int* nbr, const int* perm, 
 
 template <int CIN, int COUT>
 int launch_wgrad(const float* X, const float* dY, const int* pin, const int* pout, const int* pstart, float* dW,
-                 float* partial, int K, int S, hipStream_t st) {
+                 float* partial, int* plan, int K, int S, hipStream_t st) {
   using C = WgradCfg<CIN, COUT>;
   size_t lds = C::SLICES > 1 ? sizeof(float) * (C::SLICES - 1) * C::NCI * 16 * C::NB * 16 : 0;
-  hipLaunchKernelGGL((sparse_conv_wgrad_kernel<CIN, COUT>), dim3(K * S), dim3(256), lds, st, X, dY, pin, pout, pstart,
-                     partial, K);
-  const int64_t elems = (int64_t)K * CIN * COUT;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(crb_cdiv(elems, 256)), dim3(256), 0, st, partial, dW, elems, S);
+  const int maxwg = K * S;                                   // partial slots; the plan aims at maxwg - K workgroups
+  hipLaunchKernelGGL(wgrad_plan_kernel, dim3(1), dim3(64), 0, st, pstart, K, maxwg - K, plan);
+  hipLaunchKernelGGL((sparse_conv_wgrad_kernel<CIN, COUT>), dim3(((maxwg + 7) / 8) * 8), dim3(256), lds, st, X, dY, pin,
+                     pout, pstart, plan, partial, K);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(K * ((CIN * COUT + 31) / 32)), dim3(256), 0, st, partial, plan, dW, K,
+                     CIN * COUT);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
@@ -663,12 +724,14 @@ extern "C" int64_t crb_sparse_conv_wgrad_workspace_bytes(int K, int cin, int cou
 extern "C" int crb_sparse_conv_wgrad(const float* X, const float* dY, const int32_t* pair_in, const int32_t* pair_out,
                                      const int32_t* pair_start, float* dW, int K, int cin, int cout,
                                      void* workspace, int64_t workspace_bytes, void* stream) {
-  if (K <= 0) return CRB_ERR_ARG;
-  if (workspace_bytes < crb_sparse_conv_wgrad_workspace_bytes(K, cin, cout) - 256 || !workspace) return CRB_ERR_WORKSPACE;
+  if (K <= 0 || K > 32) return CRB_ERR_ARG;
+  if (workspace_bytes < crb_sparse_conv_wgrad_workspace_bytes(K, cin, cout) || !workspace) return CRB_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int S = crb_sparse_conv_wgrad_splits();
-#define X_(a, b) \
-  if (cin == a && cout == b) return launch_wgrad<a, b>(X, dY, pair_in, pair_out, pair_start, dW, (float*)workspace, K, S, st);
+#define X_(a, b)                                                                                              \
+  if (cin == a && cout == b)                                                                                  \
+    return launch_wgrad<a, b>(X, dY, pair_in, pair_out, pair_start, dW, (float*)workspace,                     \
+                              (int*)((char*)workspace + (int64_t)S * K * cin * cout * 4), K, S, st);
   CRB_CONV_SHAPES(X_)
 #undef X_
   return CRB_ERR_UNSUPPORTED;
