@@ -417,10 +417,15 @@ __global__ __launch_bounds__(256) void nbr_permute_kernel(const int* __restrict_
 template <int CIN, int COUT>
 struct WgradCfg {
   static constexpr int NCI = (CIN + 15) / 16;
-  static constexpr int CIPW = NCI >= 4 ? NCI / 4 : 1;   // ci blocks per wave
+  static constexpr int NB = (COUT + 15) / 16;
+  // ci blocks per wave. With the Cin rows split over the 4 waves every wave re-loads the same dY rows (20 loads per 16
+  // MFMAs at C = 64); a wave that keeps more of the Cin x Cout tile and takes its own pair slice instead loads each value
+  // once but pays in accumulator registers. Measured (L2 / L3 geometry, us): 32x32 CIPW 1 / 2 = 109 / 99;
+  // 64x64 CIPW 1 / 2 / 4 = 265 / 289 / 494 (occupancy collapses with 32-64 accumulator VGPRs) -> whole tile only up to 32x32.
+  static constexpr int TILES = NCI * NB;
+  static constexpr int CIPW = TILES <= 4 ? NCI : (NCI >= 4 ? NCI / 4 : 1);
   static constexpr int WCI = NCI / CIPW;                 // waves along ci (1,2,4)
   static constexpr int SLICES = 4 / WCI;                 // pair slices per workgroup
-  static constexpr int NB = (COUT + 15) / 16;
 };
 
 // plan (ints, written by wgrad_plan_kernel): [0] = 16-pair blocks per workgroup, [1] = workgroups in use,
