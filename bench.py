@@ -188,6 +188,7 @@ def crb_scoring_bench(args, rank, world, device):
         with torch.no_grad():
             for b in batches:
                 b = dict(b)
+                model.pfe.prefetch_keypoints(b)          # as PVRCNN.forward does: FPS on a side stream
                 for mod in model.module_list:
                     b = mod(b)
                 rows.append(scoring.pack_records(crb_frame_records(model, b)))
