@@ -6,8 +6,39 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from crbhip import bnrelu
+
 from . import pointnet2_utils
 from ....utils.fold_utils import fold_conv_bn
+
+
+class _LinearRows(torch.autograd.Function):
+    """y = x @ w^T for a tall (pairs, Cin) matrix. The weight gradient dy^T x reduces over millions of rows into a 64 x 131
+    tile: as one GEMM it gets a handful of workgroups (3 ms per call at the RoI-grid shape); here the rows are cut into 256
+    slices multiplied as one batched GEMM and summed."""
+    SLICES = 256
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ w if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            R, S = x.shape[0], _LinearRows.SLICES
+            if R >= 64 * S:
+                r0 = (R // S) * S
+                dw = torch.bmm(dy[:r0].view(S, r0 // S, -1).transpose(1, 2), x[:r0].view(S, r0 // S, -1)).sum(0)
+                if r0 < R:
+                    dw = dw + dy[r0:].t() @ x[r0:]
+            else:
+                dw = dy.t() @ x
+        return dx, dw
 
 
 def _split_first_layer(w, b):
@@ -21,6 +52,7 @@ def _transpose_second_layer(w, b):
 
 
 FUSED_SA_EVAL = True   # inference: group + 2-layer MLP + max in one HIP kernel (crb_sa_mlp2_max_stack)
+ROWS_TRAIN = True      # training: row-major grouped matrix -> GEMM + fused BN/ReLU row kernels -> max (no MIOpen BN2d / transposes)
 FUSED_GROUP = True     # one HIP launch builds the (1, 3+C, M, ns) MLP input (False: QueryAndGroup + permute copy)
 
 
@@ -102,6 +134,21 @@ class StackSAModuleMSG(nn.Module):
             col += w
         return out
 
+    @staticmethod
+    def _rows_ok(mlp, features):
+        mods = list(mlp)
+        if len(mods) % 3:
+            return False
+        x = features.new_empty((2, 4))
+        for i in range(0, len(mods), 3):
+            conv, bn, act = mods[i], mods[i + 1], mods[i + 2]
+            if not (isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and isinstance(bn, nn.BatchNorm2d)
+                    and isinstance(act, nn.ReLU)):
+                return False
+            if not bnrelu.supported(x.new_empty((2, conv.out_channels)), bn):
+                return False
+        return True
+
     def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None, empty_voxel_set_zeros=True):
         """xyz (N,3), features (N,C), new_xyz (M,3) -> new_xyz, new_features (M, sum C_out)"""
         if FUSED_SA_EVAL and not self.training and not torch.is_grad_enabled() and features is not None \
@@ -110,6 +157,21 @@ class StackSAModuleMSG(nn.Module):
             if fused is not None:
                 return new_xyz, fused
         outs = []
+        if ROWS_TRAIN and features is not None and xyz.is_cuda and self.pool_method == 'max_pool' \
+                and all(g.use_xyz for g in self.groupers) and all(self._rows_ok(m, features) for m in self.mlps):
+            M = new_xyz.shape[0]
+            for grouper, mlp in zip(self.groupers, self.mlps):
+                x, _ = pointnet2_utils.query_and_group_rows(grouper.radius, grouper.nsample, xyz, xyz_batch_cnt, new_xyz,
+                                                            new_xyz_batch_cnt, features)          # (M*ns, 3+C)
+                mods = list(mlp)
+                for i in range(0, len(mods), 3):
+                    conv, bn = mods[i], mods[i + 1]
+                    x = _LinearRows.apply(x, conv.weight.flatten(1))
+                    if conv.bias is not None:
+                        x = x + conv.bias
+                    x = bnrelu.bn_relu(x, bn, relu=True)
+                outs.append(x.view(M, grouper.nsample, x.shape[1]).max(dim=1).values)
+            return new_xyz, torch.cat(outs, dim=1)
         for grouper, mlp in zip(self.groupers, self.mlps):
             if FUSED_GROUP and features is not None and grouper.use_xyz and xyz.is_cuda:
                 x_in, _ = pointnet2_utils.query_and_group_fused(grouper.radius, grouper.nsample, xyz, xyz_batch_cnt,

@@ -122,6 +122,41 @@ def query_and_group_fused(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_
     return FusedQueryGroup.apply(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx, empty), idx
 
 
+class FusedQueryGroupRows(Function):
+    """ball-query result -> (M*nsample, 3+C) row-major matrix [xyz[nbr]-new_xyz ; features[nbr]] (one HIP launch)"""
+
+    @staticmethod
+    def forward(ctx, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx, empty):
+        require_cuda(xyz, new_xyz, features, idx)
+        M, ns = idx.shape
+        N, C = features.shape
+        B = xyz_batch_cnt.shape[0]
+        xc, nc = _i32(xyz_batch_cnt), _i32(new_xyz_batch_cnt)
+        em = empty.to(torch.uint8).contiguous()
+        out = torch.empty((M * ns, 3 + C), dtype=torch.float32, device=xyz.device)
+        check(lib.crb_query_group_rows_stack(B, M, C, ns, ptr(xyz.contiguous()), ptr(xc),
+                                             ptr(features.contiguous().float()), ptr(new_xyz.contiguous()), ptr(nc),
+                                             ptr(idx.contiguous()), ptr(em), ptr(out), cur_stream(xyz.device)),
+              'crb_query_group_rows_stack')
+        ctx.meta = (B, M, C, ns, N, xc, nc, idx, em)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, M, C, ns, N, xc, nc, idx, em = ctx.meta
+        g = g.contiguous().float()
+        gf = torch.zeros((N, C), dtype=torch.float32, device=g.device)
+        check(lib.crb_query_group_rows_grad_stack(B, M, C, ns, ptr(xc), ptr(nc), ptr(idx), ptr(em), ptr(g), ptr(gf),
+                                                  cur_stream(g.device)), 'crb_query_group_rows_grad_stack')
+        return None, None, None, None, gf, None, None
+
+
+def query_and_group_rows(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features):
+    """-> (M*nsample, 3+C), idx (M, nsample)"""
+    idx, empty = ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+    return FusedQueryGroupRows.apply(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx, empty), idx
+
+
 def sa_mlp2_max_supported(h1, h2):
     return bool(lib.crb_sa_mlp2_max_supported(int(h1), int(h2)))
 

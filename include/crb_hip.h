@@ -185,6 +185,17 @@ int crb_query_group_grad_stack(int B, int64_t M, int C, int nsample, const int32
                                const int32_t* new_xyz_batch_cnt, const int32_t* idx,
                                const uint8_t* empty_mask, const float* grad_out,
                                float* grad_features, void* stream);
+/* the same grouping in row-major layout, out (M*nsample, 3+C): the training path runs the shared MLP as GEMMs + fused
+ * BatchNorm/ReLU row kernels on it. The grad kernel pre-sums pairs that share a source row inside a workgroup (ball-query
+ * padding repeats the first hit) before its atomics. */
+int crb_query_group_rows_stack(int B, int64_t M, int C, int nsample, const float* xyz,
+                               const int32_t* xyz_batch_cnt, const float* features, const float* new_xyz,
+                               const int32_t* new_xyz_batch_cnt, const int32_t* idx, const uint8_t* empty_mask,
+                               float* out, void* stream);
+int crb_query_group_rows_grad_stack(int B, int64_t M, int C, int nsample, const int32_t* xyz_batch_cnt,
+                                    const int32_t* new_xyz_batch_cnt, const int32_t* idx,
+                                    const uint8_t* empty_mask, const float* grad_out, float* grad_features,
+                                    void* stream);
 /* inference-only fused set abstraction: replaces the body of StackSAModuleMSG.forward
  * (pointnet2_modules.py:73-112: QueryAndGroup -> 2 x [Conv2d 1x1 + BatchNorm2d + ReLU] -> max_pool2d over nsample) for one
  * radius. BN is folded by the caller; layer 1 is split as W1 [dxyz ; f] = W1x dxyz + P[row], P = features @ W1f^T (N,h1).

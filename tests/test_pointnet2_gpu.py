@@ -212,6 +212,46 @@ def test_fused_sa_eval_kernel_equals_module_path(dev, c_in, mlps, nsamples):
     assert float(a[::5].std(dim=0).max()) == 0.0            # empty balls: one constant row
 
 
+def test_sa_module_rows_training_path_equals_module_path(dev):
+    """training: row-major grouping + F.linear + fused BN/ReLU row kernels + max == Conv2d/BatchNorm2d/max_pool2d modules:
+    outputs (1e-4), grads w.r.t. features (1e-3) and every parameter (5e-3), running statistics (1e-4). fp32."""
+    import copy
+    from pcdet.config import EasyDict
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_modules as M
+    torch.manual_seed(4)
+    layer, c_out = M.build_local_aggregation_module(
+        20, EasyDict({'MLPS': [[32, 32], [64, 64]], 'POOL_RADIUS': [0.8, 1.6], 'NSAMPLE': [16, 16]}))
+    layer = layer.to(dev).train()
+    ref = copy.deepcopy(layer)
+    pts, off, _ = kitti_batch(2, 7, n_points=6000)
+    xyz = _t(np.ascontiguousarray(pts[:, :3]), dev)
+    xc = _t(np.diff(off).astype(np.int32), dev)
+    rng = np.random.default_rng(2)
+    sel = np.concatenate([rng.choice(6000, 500, replace=False), 6000 + rng.choice(6000, 300, replace=False)])
+    new = xyz[torch.from_numpy(sel).to(dev)].contiguous()
+    new[::6] += 55.0
+    nc = torch.tensor([500, 300], dtype=torch.int32, device=dev)
+    f1 = torch.randn(12000, 20, device=dev, requires_grad=True)
+    f2 = f1.detach().clone().requires_grad_(True)
+    go = torch.randn(800, c_out, device=dev)
+    assert M.ROWS_TRAIN
+    _, a = layer(xyz, xc, new, nc, f1)
+    a.backward(go)
+    M.ROWS_TRAIN = False
+    try:
+        _, b = ref(xyz, xc, new, nc, f2)
+        b.backward(go)
+    finally:
+        M.ROWS_TRAIN = True
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(f1.grad, f2.grad, rtol=1e-3, atol=1e-4)
+    for (n1, p1), (n2, p2) in zip(layer.named_parameters(), ref.named_parameters()):
+        # parameter grads are sums over M*ns = 12.8k rows taken in a different association (GEMM vs conv, BN reductions)
+        torch.testing.assert_close(p1.grad, p2.grad, rtol=5e-3, atol=1e-3, msg=lambda m, n1=n1: n1 + ': ' + m)
+    for (n1, b1), (n2, b2) in zip(layer.named_buffers(), ref.named_buffers()):
+        torch.testing.assert_close(b1.float(), b2.float(), rtol=1e-4, atol=1e-5, msg=lambda m, n1=n1: n1 + ': ' + m)
+
+
 def test_fused_query_group_equals_query_and_group(dev):
     from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as U
     pts, off, _ = kitti_batch(2, 2, n_points=5000)
