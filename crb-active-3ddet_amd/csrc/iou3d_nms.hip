@@ -185,9 +185,29 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   for (int k = 0; k < 7; ++k) a[k] = fb[(int64_t)i * 7 + k];
   unsigned long long t = 0;
   const int start = (row_blk == col_blk) ? threadIdx.x + 1 : 0;
-  for (int j = start; j < col_size; ++j) {
-    float iou = ROTATED ? iou_bev_rot(a, cb + j * 7) : iou_bev_normal(a, cb + j * 7);
-    if (iou > thresh) t |= 1ULL << j;
+  if constexpr (ROTATED) {
+    // Two passes. (1) cheap reject with circumscribed circles: boxes whose BEV centres are farther apart than the sum of
+    // their half-diagonals (+1e-4 relative slack) cannot intersect, the reference's polygon clipping finds no vertex for
+    // them and returns overlap 0 -> IoU 0 -> never above a positive threshold. (2) the rotated-overlap arithmetic only for
+    // the survivors: a wave runs max-over-lanes(survivors) iterations instead of 64 (proposals are score-sorted, i.e.
+    // spatially random: typically a handful of the 64 columns are near a given row box).
+    const float ra = 0.5f * sqrtf(a[3] * a[3] + a[4] * a[4]);
+    unsigned long long cand = 0;
+    for (int j = start; j < col_size; ++j) {
+      const float* b = cb + j * 7;
+      const float rb = 0.5f * sqrtf(b[3] * b[3] + b[4] * b[4]);
+      const float dx = a[0] - b[0], dy = a[1] - b[1], rs = ra + rb;
+      if (dx * dx + dy * dy <= rs * rs * 1.0001f + 1e-6f) cand |= 1ULL << j;
+    }
+    if (!(thresh > 0.f)) cand = (col_size >= 64 ? ~0ULL : ((1ULL << col_size) - 1ULL)) & (~0ULL << start);  // degenerate threshold: test everything
+    while (cand) {
+      const int j = __ffsll((long long)cand) - 1;
+      cand &= cand - 1;
+      if (iou_bev_rot(a, cb + j * 7) > thresh) t |= 1ULL << j;
+    }
+  } else {
+    for (int j = start; j < col_size; ++j)
+      if (iou_bev_normal(a, cb + j * 7) > thresh) t |= 1ULL << j;
   }
   mask[((int64_t)f * nmax + i) * col_blocks + col_blk] = t;
 }
