@@ -75,3 +75,36 @@ def test_crb_query_end_to_end_small_pool(dev):
     e = build_strategy('entropy', model, build_synthetic_dataloader(lab, 2), build_synthetic_dataloader(pool, 4), 0,
                        '/tmp', cfg).query(cur_epoch=0)
     assert len(e) == 3
+
+
+def test_stage2_pruned_backward_equals_full_backward(dev):
+    """grad_embeddings: d loss / d shared_fc_layer[4].weight through autograd.grad on that weight only == the reference's
+    full loss.backward() followed by reading .grad (same RNG state for RoI sampling / dropout in both runs)"""
+    from pcdet.datasets import SyntheticDataset, build_synthetic_dataloader
+    from pcdet.model_cfgs import pv_rcnn_cfg
+    from pcdet.models import build_network
+    from pcdet.query_strategies import build_strategy
+    cfg = pv_rcnn_cfg()
+    torch.manual_seed(0)
+    pool = SyntheticDataset(num_frames=6, first_frame=700)
+    model = build_network(cfg.MODEL, 3, pool).to(dev)
+    strat = build_strategy('crb', model, build_synthetic_dataloader(SyntheticDataset(num_frames=2), 2),
+                           build_synthetic_dataloader(pool, 2), 0, '/tmp', cfg)
+    idx = [1, 4]
+    model.eval()
+    for m in model.modules():
+        if m.__class__.__name__.startswith('Dropout'):
+            m.train()
+    with torch.no_grad():
+        records = strat.score_pool(idx, 2)
+
+    def run(pruned):
+        strat.PRUNED_BACKWARD = pruned
+        torch.manual_seed(11)
+        gen = getattr(model.roi_head.proposal_target_layer, 'generator', None)
+        if gen is not None:
+            gen.manual_seed(11)
+        return strat.grad_embeddings(idx, records)
+    a, b = run(True), run(False)
+    assert a.shape == (2, 256 * 256) and float(a.abs().sum()) > 0
+    torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
