@@ -234,6 +234,8 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
+    if os.environ.get('CRB_MIOPEN_FIND', '0') == '1':
+        torch.backends.cudnn.benchmark = True       # MIOpen find mode: benchmark the applicable solvers per conv shape
     from crbhip import sparse as sp
     from pcdet.datasets import SyntheticDataset
     from pcdet.model_cfgs import second_cfg

@@ -110,6 +110,49 @@ def test_strided_conv_fwd_bwd(dev, cin, cout, ks, st, pd):
     _close(w.grad.cpu().numpy(), oracle.conv_wgrad(X, dY, nbr, K))
 
 
+@pytest.mark.parametrize('level,cin,cout', [(1, 16, 16), (2, 32, 32), (3, 64, 64)])
+def test_full_size_linearity_and_adjoint_identity(dev, level, cin, cout):
+    """BASELINE configs[1] size (16 frames x 20k points, SubM level 1-3 of VoxelBackBone8x: 190-280k active sites), where
+    the CPU oracle would take minutes: size-independent properties instead.
+      linearity   conv(a x1 + b x2) = a conv(x1) + b conv(x2)
+      adjoint     <conv(x), dy> = <x, dgrad(dy)> = <W, wgrad(x, dy)>      (fwd, dgrad and wgrad describe ONE bilinear map)
+      row order   the mask-sorted / heaviest-first table and the natural-order table give the same rows"""
+    from crbhip import sparse, voxel
+    pts, off, _ = kitti_batch(0, 16)
+    r = voxel.voxelize(_t(pts, dev), _t(off, dev), KITTI_RANGE, KITTI_VOXEL, 16000, 5, want_voxels=False, want_mean=True)
+    coords, shape = r['coords'], [41, 1600, 1408]
+    geo = [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1))]
+    for lvl in range(2, level + 1):
+        rbs = sparse.spconv_rulebook(coords, shape, 16, *geo[lvl - 2])
+        coords, shape = rbs.out_coords.contiguous(), rbs.out_shape
+    rb = sparse.subm_rulebook(coords, shape, [3, 3, 3])
+    n = rb.n_out
+    assert n > 150000
+    g = torch.Generator(device=dev).manual_seed(level)
+    x1 = torch.randn(n, cin, device=dev, generator=g)
+    x2 = torch.randn(n, cin, device=dev, generator=g)
+    w = (torch.randn(27, cin, cout, device=dev, generator=g) / cin ** 0.5).requires_grad_(True)
+    dy = torch.randn(n, cout, device=dev, generator=g)
+    y1, y2 = sparse.sparse_conv(x1, w, rb), sparse.sparse_conv(x2, w, rb)
+    y12 = sparse.sparse_conv(0.7 * x1 - 1.3 * x2, w, rb)
+    torch.testing.assert_close(y12, 0.7 * y1 - 1.3 * y2, rtol=1e-4, atol=1e-4)
+    x = x1.clone().requires_grad_(True)
+    y = sparse.sparse_conv(x, w, rb)
+    y.backward(dy)
+    a = float((y.detach().double() * dy.double()).sum())
+    b = float((x.detach().double() * x.grad.double()).sum())
+    c = float((w.detach().double() * w.grad.double()).sum())
+    scale = float(y.detach().double().norm() * dy.double().norm())
+    assert abs(a - b) <= 1e-5 * scale and abs(a - c) <= 1e-5 * scale, (a, b, c, scale)
+    sparse.MASK_SORT = False
+    try:
+        rb2 = sparse.subm_rulebook(coords, shape, [3, 3, 3])
+        y_nat = sparse.sparse_conv(x1, w.detach(), rb2)
+    finally:
+        sparse.MASK_SORT = True
+    assert torch.equal(y_nat, y1.detach())          # same per-row arithmetic, only the row -> workgroup map differs
+
+
 def test_dense_scatter_and_backward(dev):
     from crbhip import sparse
     rng = np.random.default_rng(5)
