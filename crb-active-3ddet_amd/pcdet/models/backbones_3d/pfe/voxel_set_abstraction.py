@@ -29,7 +29,7 @@ def bilinear_interpolate_torch(im, x, y):
 
 
 def _batch_counts(bs_idx, batch_size):
-    return torch.bincount(bs_idx.long(), minlength=batch_size).int()
+    return common_utils.batch_counts(bs_idx, batch_size)
 
 
 class VoxelSetAbstraction(nn.Module):

@@ -11,6 +11,7 @@ all-gathers."""
 import torch
 
 from ...ops.iou3d_nms import iou3d_nms_utils
+from ...utils import common_utils
 from ...ops.roiaware_pool3d import roiaware_pool3d_utils
 
 
@@ -18,7 +19,7 @@ def _frame_points(batch_dict, batch_size):
     """points (N,1+C) frame-sorted -> dense (B,M,3) with far-away padding, counts (B)"""
     pts = batch_dict['points']
     bidx = pts[:, 0].long()
-    counts = torch.bincount(bidx, minlength=batch_size)
+    counts = common_utils.batch_counts(bidx, batch_size).long()
     M = int(pts.shape[0] // batch_size)
     if pts.shape[0] == M * batch_size and 'point_frame_counts_host' in batch_dict and \
             len(set(batch_dict['point_frame_counts_host'])) == 1:

@@ -55,7 +55,7 @@ class PVRCNNHead(RoIHeadTemplate):
         grid_pts, _ = self.get_global_grid_points_of_roi(rois, grid_size=G)
         grid_pts = grid_pts.view(batch_size, -1, 3)
         xyz = point_coords[:, 1:4]
-        xyz_batch_cnt = torch.bincount(point_coords[:, 0].long(), minlength=batch_size).int()
+        xyz_batch_cnt = common_utils.batch_counts(point_coords[:, 0], batch_size)
         new_xyz = grid_pts.view(-1, 3)
         new_xyz_batch_cnt = xyz_batch_cnt.new_full((batch_size,), grid_pts.shape[1])
         _, pooled = self.roi_grid_pool_layer(xyz=xyz.contiguous(), xyz_batch_cnt=xyz_batch_cnt, new_xyz=new_xyz.contiguous(),

@@ -71,6 +71,20 @@ class CRBSampling(Strategy):
 
     PRUNED_BACKWARD = True
 
+    def frame_loss(self, i, rcnn_cls_labels, reg_sample_targets):
+        """bs=1 training-mode pass of pool frame i and the RoI-head loss against the stage-1 hypothetical labels
+        (crb_sampling.py:174-196)"""
+        ds, model = self.unlabelled_set, self.model
+        batch = ds.collate_batch([ds[i]])
+        batch['point_frame_counts_host'] = np.diff(batch['point_frame_offsets']).tolist()
+        load_data_to_gpu(batch)
+        batch['point_frame_offsets'] = batch['point_frame_offsets'].int()
+        ret, _, _ = model(batch)
+        cls_loss, _ = model.roi_head.get_box_cls_layer_loss({'rcnn_cls': ret['rcnn_cls'], 'rcnn_cls_labels': rcnn_cls_labels})
+        reg_loss = model.roi_head.get_box_reg_layer_loss({'rcnn_reg': ret['rcnn_reg'],
+                                                          'reg_sample_targets': reg_sample_targets})
+        return cls_loss + reg_loss.mean()
+
     # ---------------------------------------------------------------- stage 2
     def grad_embeddings(self, frame_indices, records):
         """per-frame gradient of roi_head.shared_fc_layer[4].weight under the stage-1 hypothetical labels
@@ -83,21 +97,12 @@ class CRBSampling(Strategy):
         out = []
         w = model.roi_head.shared_fc_layer[4].weight
         for k, i in enumerate(frame_indices):
-            batch = ds.collate_batch([ds[i]])
-            batch['point_frame_counts_host'] = np.diff(batch['point_frame_offsets']).tolist()
-            load_data_to_gpu(batch)
-            batch['point_frame_offsets'] = batch['point_frame_offsets'].int()
-            ret, _, _ = model(batch)
-            cls_loss, _ = model.roi_head.get_box_cls_layer_loss({'rcnn_cls': ret['rcnn_cls'],
-                                                                 'rcnn_cls_labels': rec['rcnn_cls'][k]})
-            reg_loss = model.roi_head.get_box_reg_layer_loss({'rcnn_reg': ret['rcnn_reg'],
-                                                              'reg_sample_targets': rec['rcnn_reg'][k]})
-            loss = cls_loss + reg_loss.mean()
+            loss = self.frame_loss(i, rec['rcnn_cls'][k], rec['rcnn_reg'][k])
             if self.PRUNED_BACKWARD:
                 # the embedding is d loss / d shared_fc_layer[4].weight only: autograd walks loss -> cls/reg layers -> FC stack
                 # and stops there; the reference's loss.backward() (crb_sampling.py:197) also back-propagates through the RoI
                 # grid pooling, the PFE and both backbones and throws those gradients away (model.zero_grad() on the next
-                # frame). Same value, ~2/3 of the per-frame work gone.
+                # frame). Same value, most of the backward work gone.
                 g, = torch.autograd.grad(loss, w)
                 out.append(g.detach().reshape(-1))
             else:

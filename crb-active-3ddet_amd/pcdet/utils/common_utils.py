@@ -42,9 +42,31 @@ def get_voxel_centers(voxel_coords, downsample_times, voxel_size, point_cloud_ra
     """voxel_coords (N,3) [z,y,x] -> centers (N,3) xyz (common_utils.py:63-80)"""
     assert voxel_coords.shape[1] == 3
     centers = voxel_coords[:, [2, 1, 0]].float()
-    vs = torch.tensor(voxel_size, device=centers.device).float() * downsample_times
-    pc_min = torch.tensor(point_cloud_range[0:3], device=centers.device).float()
+    vs = device_constant(voxel_size, centers.device) * downsample_times
+    pc_min = device_constant(point_cloud_range[0:3], centers.device)
     return (centers + 0.5) * vs + pc_min
+
+
+_CONSTS = {}
+
+
+def device_constant(values, device):
+    """small f32 constant vector resident on `device` (cached: a torch.tensor(list, device=cuda) per call is a blocking
+    pageable H2D copy, i.e. a host sync in the middle of the forward)"""
+    key = (str(device), tuple(float(v) for v in values))
+    t = _CONSTS.get(key)
+    if t is None:
+        if len(_CONSTS) > 256:
+            _CONSTS.clear()
+        t = _CONSTS[key] = torch.tensor(key[1], dtype=torch.float32, device=device)
+    return t
+
+
+def batch_counts(bs_idx, batch_size):
+    """rows per frame of a stacked tensor whose batch index column is bs_idx -> (B) int32. scatter_add instead of
+    torch.bincount: bincount reads back the maximum to size its output, a device->host sync per call."""
+    out = torch.zeros((batch_size,), dtype=torch.int32, device=bs_idx.device)
+    return out.scatter_add_(0, bs_idx.long(), torch.ones_like(bs_idx, dtype=torch.int32))
 
 
 def create_logger(log_file=None, rank=0, log_level=logging.INFO):
