@@ -68,3 +68,15 @@ def bn_relu(x, bn, relu=True):
     check(lib.crb_bn_relu_apply(ptr(x), n, C, ptr(bn.running_mean.contiguous()), ptr(invstd), ptr(bn.weight.contiguous()),
                                 ptr(bn.bias.contiguous()), int(relu), ptr(z), cur_stream(x.device)), 'crb_bn_relu_apply')
     return z
+
+
+@torch.no_grad()
+def bn_apply_(x, bn, relu=True):
+    """in-place inference BatchNorm(+ReLU) on (N, C) rows from the running statistics: one read + one write of x"""
+    require_cuda(x)
+    n, C = x.shape
+    assert x.is_contiguous()
+    invstd = torch.rsqrt(bn.running_var + bn.eps)
+    check(lib.crb_bn_relu_apply(ptr(x), n, C, ptr(bn.running_mean.contiguous()), ptr(invstd), ptr(bn.weight.contiguous()),
+                                ptr(bn.bias.contiguous()), int(relu), ptr(x), cur_stream(x.device)), 'crb_bn_relu_apply')
+    return x

@@ -4,6 +4,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from crbhip import bnrelu
+
 from ...utils.fold_utils import fold_conv_bn
 
 
@@ -48,25 +50,38 @@ class BaseBEVBackbone(nn.Module):
 
     @staticmethod
     def _run_folded(seq, x):
-        """inference only: every (Conv2d | ConvTranspose2d) -> BatchNorm2d -> ReLU triple runs as one convolution with the
-        BN affine folded into its weights and bias (same values up to f32 rounding); MIOpen's inference BN pass over the
-        288 MB BEV tensors was the largest single item of the CRB scoring profile"""
+        """inference only: every (Conv2d | ConvTranspose2d) -> BatchNorm2d -> ReLU triple runs as the convolution followed by
+        ONE elementwise pass. channels_last CUDA tensors: the conv output viewed as (N*H*W, C) rows goes through
+        crb_bn_relu_apply (scale/shift from the running statistics + ReLU, in place) — with the BN folded into the conv
+        weights PyTorch still launches a separate bias-add and a separate ReLU pass over the 288 MB BEV tensors. Other
+        tensors: BN folded into the weights (same values up to f32 rounding)."""
         mods = list(seq)
         i = 0
         while i < len(mods):
             m = mods[i]
-            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) and i + 2 < len(mods) + 1 and \
-                    isinstance(mods[i + 1], nn.BatchNorm2d):
-                w, shift = fold_conv_bn(m, mods[i + 1])
-                if isinstance(m, nn.Conv2d):
-                    x = torch.nn.functional.conv2d(x, w, shift, m.stride, m.padding, m.dilation, m.groups)
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
+                bn = mods[i + 1]
+                relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                rows_ok = x.is_cuda and x.is_contiguous(memory_format=torch.channels_last) and m.bias is None
+                if rows_ok:
+                    y = m(x)
+                    rows_ok = y.is_contiguous(memory_format=torch.channels_last) and \
+                        bnrelu.supported(y.new_empty((2, y.shape[1])), bn)
+                if rows_ok:
+                    n, c, h, w_ = y.shape
+                    rows = y.permute(0, 2, 3, 1).reshape(n * h * w_, c)          # a view of the NHWC storage
+                    z = bnrelu.bn_apply_(rows, bn, relu)
+                    x = z.view(n, h, w_, c).permute(0, 3, 1, 2)
                 else:
-                    x = torch.nn.functional.conv_transpose2d(x, w, shift, m.stride, m.padding, m.output_padding,
-                                                             m.groups, m.dilation)
-                i += 2
-                if i < len(mods) and isinstance(mods[i], nn.ReLU):
-                    x = torch.relu_(x)
-                    i += 1
+                    w, shift = fold_conv_bn(m, bn)
+                    if isinstance(m, nn.Conv2d):
+                        x = torch.nn.functional.conv2d(x, w, shift, m.stride, m.padding, m.dilation, m.groups)
+                    else:
+                        x = torch.nn.functional.conv_transpose2d(x, w, shift, m.stride, m.padding, m.output_padding,
+                                                                 m.groups, m.dilation)
+                    if relu:
+                        x = torch.relu_(x)
+                i += 3 if relu else 2
             else:
                 x = m(x)
                 i += 1

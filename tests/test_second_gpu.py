@@ -66,3 +66,26 @@ def test_res_backbone_and_reference_layout_batch(dev):
     b1 = model.vfe(dict(batch))
     torch.testing.assert_close(b1['voxel_features'], b2['voxel_features'], rtol=1e-6, atol=1e-6)
     assert torch.equal(b1['voxel_coords'].int(), b2['voxel_coords'])
+
+
+def test_bev_backbone_eval_rows_path_equals_module_path(dev):
+    """inference: conv + in-place crb_bn_relu_apply on the NHWC rows == Conv2d/BatchNorm2d/ReLU modules (channels_last)"""
+    from pcdet.config import EasyDict
+    from pcdet.models.backbones_2d import BaseBEVBackbone
+    cfg = EasyDict({'LAYER_NUMS': [2, 2], 'LAYER_STRIDES': [1, 2], 'NUM_FILTERS': [64, 128], 'UPSAMPLE_STRIDES': [1, 2],
+                    'NUM_UPSAMPLE_FILTERS': [128, 128]})
+    torch.manual_seed(0)
+    m = BaseBEVBackbone(cfg, input_channels=64).to(dev)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.3)
+            mod.running_var.uniform_(0.5, 2.0)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.2)
+    m = m.eval().to(memory_format=torch.channels_last)
+    x = torch.randn(3, 64, 40, 48, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        a = m({'spatial_features': x})['spatial_features_2d']
+    b = m({'spatial_features': x})['spatial_features_2d']          # grad enabled -> module path
+    assert a.shape == b.shape == (3, 256, 40, 48)
+    torch.testing.assert_close(a, b.detach(), rtol=1e-4, atol=1e-4)
