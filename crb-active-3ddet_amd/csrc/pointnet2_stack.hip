@@ -74,6 +74,62 @@ __global__ __launch_bounds__(256) void ball_query_kernel(int B, int M, float rad
   if (first < 0 && lane == 0) out[0] = -1;
 }
 
+// Two radii in ONE scan of the frame's points (StackSAModuleMSG always queries the same centres with two radii): the
+// distance of a candidate is computed once and tested against both; the scan stops when both lists are full. Writes the
+// index lists already in the form the grouping kernels consume (empty ball -> all zeros) plus the empty flags, so the three
+// torch launches of the reference's fix-up (pointnet2_utils.py:36-38) disappear as well.
+__global__ __launch_bounds__(256) void ball_query2_kernel(int B, int M, float ra, int nsa, float rb, int nsb,
+                                                          const float* __restrict__ new_xyz, const int* __restrict__ new_cnt,
+                                                          const float* __restrict__ xyz, const int* __restrict__ xyz_cnt,
+                                                          int* __restrict__ idx_a, int* __restrict__ idx_b,
+                                                          unsigned char* __restrict__ empty_a,
+                                                          unsigned char* __restrict__ empty_b) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= M) return;
+  int start;
+  const int b = locate_batch(new_cnt, B, q, xyz_cnt, &start);
+  const int n = xyz_cnt[b];
+  const float* p = xyz + (int64_t)start * 3;
+  const float ra2 = ra * ra, rb2 = rb * rb;
+  const float qx = new_xyz[(int64_t)q * 3 + 0], qy = new_xyz[(int64_t)q * 3 + 1], qz = new_xyz[(int64_t)q * 3 + 2];
+  int* oa = idx_a + (int64_t)q * nsa;
+  int* ob = idx_b + (int64_t)q * nsb;
+  int ca = 0, cb = 0, fa = -1, fb = -1;
+  for (int k0 = 0; k0 < n && (ca < nsa || cb < nsb); k0 += 64) {
+    const int k = k0 + lane;
+    bool ha = false, hb = false;
+    if (k < n) {
+      float x = p[k * 3 + 0], y = p[k * 3 + 1], z = p[k * 3 + 2];
+      float d2 = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z);
+      ha = d2 < ra2;
+      hb = d2 < rb2;
+    }
+    const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+    if (ma != 0ULL && ca < nsa) {
+      if (fa < 0) fa = k0 + (__ffsll((long long)ma) - 1);
+      const int pos = ca + __popcll(ma & below);
+      if (ha && pos < nsa) oa[pos] = k;
+      ca += __popcll(ma);
+    }
+    if (mb != 0ULL && cb < nsb) {
+      if (fb < 0) fb = k0 + (__ffsll((long long)mb) - 1);
+      const int pos = cb + __popcll(mb & below);
+      if (hb && pos < nsb) ob[pos] = k;
+      cb += __popcll(mb);
+    }
+  }
+  ca = ca > nsa ? nsa : ca;
+  cb = cb > nsb ? nsb : cb;
+  for (int l = ca + lane; l < nsa; l += 64) oa[l] = (fa >= 0) ? fa : 0;
+  for (int l = cb + lane; l < nsb; l += 64) ob[l] = (fb >= 0) ? fb : 0;
+  if (lane == 0) {
+    empty_a[q] = fa < 0;
+    empty_b[q] = fb < 0;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ grouping
 // out (M, C, ns) ; one workgroup per centre; LDS slab (ns, C+1)
 __global__ __launch_bounds__(256) void group_points_kernel(int B, int M, int C, int ns, const float* __restrict__ feat,
@@ -496,6 +552,19 @@ extern "C" int crb_ball_query_stack(int B, int64_t M, float radius, int nsample,
   if (M == 0) return CRB_OK;
   hipLaunchKernelGGL(ball_query_kernel, dim3(crb_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, B, (int)M, radius,
                      nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_ball_query2_stack(int B, int64_t M, float radius_a, int nsample_a, float radius_b, int nsample_b,
+                                     const float* new_xyz, const int32_t* new_xyz_batch_cnt, const float* xyz,
+                                     const int32_t* xyz_batch_cnt, int32_t* idx_a, int32_t* idx_b, uint8_t* empty_a,
+                                     uint8_t* empty_b, void* stream) {
+  if (B <= 0 || M < 0 || nsample_a <= 0 || nsample_b <= 0 || M >= (1LL << 31)) return CRB_ERR_ARG;
+  if (M == 0) return CRB_OK;
+  hipLaunchKernelGGL(ball_query2_kernel, dim3(crb_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, B, (int)M, radius_a,
+                     nsample_a, radius_b, nsample_b, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx_a, idx_b, empty_a,
+                     empty_b);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

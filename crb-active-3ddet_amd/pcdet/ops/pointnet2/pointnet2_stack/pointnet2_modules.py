@@ -128,11 +128,20 @@ class StackSAModuleMSG(nn.Module):
         widths = [f[3].shape[1] for f in folded]
         out = torch.empty((new_xyz.shape[0], sum(widths)), dtype=torch.float32, device=xyz.device)
         col = 0
-        for grouper, f, w in zip(self.groupers, folded, widths):
+        balls = self._balls(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+        for grouper, f, w, ball in zip(self.groupers, folded, widths, balls):
             pointnet2_utils.sa_mlp2_max(grouper.radius, grouper.nsample, xyz, xyz_batch_cnt, new_xyz,
-                                        new_xyz_batch_cnt, features, *f, out[:, col:col + w])
+                                        new_xyz_batch_cnt, features, *f, out[:, col:col + w], ball=ball)
             col += w
         return out
+
+    def _balls(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt):
+        """ball queries of all scales; two scales share one scan of the points (crb_ball_query2_stack)"""
+        gs = list(self.groupers)
+        if len(gs) == 2:
+            return pointnet2_utils.ball_query_pair(gs[0].radius, gs[0].nsample, gs[1].radius, gs[1].nsample, xyz,
+                                                   xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+        return [None] * len(gs)
 
     @staticmethod
     def _rows_ok(mlp, features):
@@ -160,9 +169,10 @@ class StackSAModuleMSG(nn.Module):
         if ROWS_TRAIN and features is not None and xyz.is_cuda and self.pool_method == 'max_pool' \
                 and all(g.use_xyz for g in self.groupers) and all(self._rows_ok(m, features) for m in self.mlps):
             M = new_xyz.shape[0]
-            for grouper, mlp in zip(self.groupers, self.mlps):
+            balls = self._balls(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+            for grouper, mlp, ball in zip(self.groupers, self.mlps, balls):
                 x, _ = pointnet2_utils.query_and_group_rows(grouper.radius, grouper.nsample, xyz, xyz_batch_cnt, new_xyz,
-                                                            new_xyz_batch_cnt, features)          # (M*ns, 3+C)
+                                                            new_xyz_batch_cnt, features, ball=ball)   # (M*ns, 3+C)
                 mods = list(mlp)
                 for i in range(0, len(mods), 3):
                     conv, bn = mods[i], mods[i + 1]

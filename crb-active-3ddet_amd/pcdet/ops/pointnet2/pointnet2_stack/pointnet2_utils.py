@@ -38,6 +38,23 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+@torch.no_grad()
+def ball_query_pair(radius_a, nsample_a, radius_b, nsample_b, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt):
+    """both radii of a StackSAModuleMSG in one scan -> ((idx_a, empty_a), (idx_b, empty_b)), the same values as two
+    ball_query calls (idx int32 with empty balls zeroed, empty as uint8)"""
+    require_cuda(xyz, new_xyz)
+    xyz, new_xyz = xyz.contiguous(), new_xyz.contiguous()
+    B, M, dev = xyz_batch_cnt.shape[0], new_xyz.shape[0], xyz.device
+    ia = torch.empty((M, nsample_a), dtype=torch.int32, device=dev)
+    ib = torch.empty((M, nsample_b), dtype=torch.int32, device=dev)
+    ea = torch.empty((M,), dtype=torch.uint8, device=dev)
+    eb = torch.empty((M,), dtype=torch.uint8, device=dev)
+    check(lib.crb_ball_query2_stack(B, M, float(radius_a), int(nsample_a), float(radius_b), int(nsample_b), ptr(new_xyz),
+                                    ptr(_i32(new_xyz_batch_cnt)), ptr(xyz), ptr(_i32(xyz_batch_cnt)), ptr(ia), ptr(ib),
+                                    ptr(ea), ptr(eb), cur_stream(dev)), 'crb_ball_query2_stack')
+    return (ia, ea), (ib, eb)
+
+
 class GroupingOperation(Function):
     @staticmethod
     def forward(ctx, features, features_batch_cnt, idx, idx_batch_cnt):
@@ -151,9 +168,9 @@ class FusedQueryGroupRows(Function):
         return None, None, None, None, gf, None, None
 
 
-def query_and_group_rows(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features):
-    """-> (M*nsample, 3+C), idx (M, nsample)"""
-    idx, empty = ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+def query_and_group_rows(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, ball=None):
+    """-> (M*nsample, 3+C), idx (M, nsample); `ball` = (idx, empty) from ball_query_pair skips the query"""
+    idx, empty = ball if ball is not None else ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
     return FusedQueryGroupRows.apply(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx, empty), idx
 
 
@@ -162,12 +179,13 @@ def sa_mlp2_max_supported(h1, h2):
 
 
 @torch.no_grad()
-def sa_mlp2_max(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, w1x, w1f_t, b1, w2t, b2, out):
+def sa_mlp2_max(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, w1x, w1f_t, b1, w2t, b2, out,
+                ball=None):
     """inference-only ball query -> group -> relu(W1 . + b1) -> relu(W2 . + b2) -> max over samples, written into `out`
     ((M, h2) view, may be a column slice of a wider row-major buffer). Operands are the BN-folded 1x1 conv weights of one
     StackSAModuleMSG scale (pointnet2_modules.py:73-112): w1x (3,h1), w1f_t (C,h1), b1 (h1), w2t (h1,h2), b2 (h2)."""
     require_cuda(xyz, new_xyz, features, out)
-    idx, empty = ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+    idx, empty = ball if ball is not None else ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
     h1, h2 = w2t.shape
     M = new_xyz.shape[0]
     assert out.shape == (M, h2) and out.stride(1) == 1

@@ -168,6 +168,13 @@ int crb_nms_batched(const float* boxes_sorted, const int32_t* counts, int B, int
 int crb_ball_query_stack(int B, int64_t M, float radius, int nsample, const float* new_xyz,
                          const int32_t* new_xyz_batch_cnt, const float* xyz, const int32_t* xyz_batch_cnt,
                          int32_t* idx, void* stream);
+/* two radii, same centres, one scan. idx_a (M,nsample_a) / idx_b (M,nsample_b) already in the grouping kernels' form (an
+ * empty ball is all zeros, flagged in empty_a / empty_b (M) u8): replaces two ball_query_wrapper calls plus the Python
+ * fix-up `empty = idx[:,0]==-1; idx[empty]=0` (pointnet2_utils.py:31-38) */
+int crb_ball_query2_stack(int B, int64_t M, float radius_a, int nsample_a, float radius_b, int nsample_b,
+                          const float* new_xyz, const int32_t* new_xyz_batch_cnt, const float* xyz,
+                          const int32_t* xyz_batch_cnt, int32_t* idx_a, int32_t* idx_b, uint8_t* empty_a,
+                          uint8_t* empty_b, void* stream);
 int crb_group_points_stack(int B, int64_t M, int C, int nsample, const float* features,
                            const int32_t* features_batch_cnt, const int32_t* idx,
                            const int32_t* idx_batch_cnt, float* out, void* stream);

@@ -47,6 +47,26 @@ def test_ball_query_and_grouping(dev):
     assert float(nf[::17].abs().sum()) == 0.0
 
 
+def test_ball_query_pair_equals_two_queries(dev):
+    """crb_ball_query2_stack (both radii in one scan) == two crb_ball_query_stack calls + the reference's empty fix-up"""
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as U
+    pts, off, _ = kitti_batch(3, 3, n_points=7000)
+    xyz = _t(np.ascontiguousarray(pts[:, :3]), dev)
+    xc = _t(np.diff(off).astype(np.int32), dev)
+    rng = np.random.default_rng(9)
+    new = torch.cat([xyz[off[b]:off[b + 1]][torch.from_numpy(rng.choice(7000, 400, replace=False)).to(dev)]
+                     for b in range(3)]).contiguous()
+    new[::11] += 60.0
+    nc = torch.tensor([400, 400, 400], dtype=torch.int32, device=dev)
+    for (ra, na, rb, nb) in ((0.4, 16, 0.8, 16), (2.4, 16, 4.8, 32), (1.6, 24, 0.8, 7)):
+        (ia, ea), (ib, eb) = U.ball_query_pair(ra, na, rb, nb, xyz, xc, new, nc)
+        ja, fa = U.ball_query(ra, na, xyz, xc, new, nc)
+        jb, fb = U.ball_query(rb, nb, xyz, xc, new, nc)
+        assert torch.equal(ia, ja) and torch.equal(ib, jb)
+        assert torch.equal(ea.bool(), fa) and torch.equal(eb.bool(), fb)
+        assert int(fa.sum()) >= 100
+
+
 @pytest.mark.parametrize('n,m', [(20000, 2048), (4096, 512), (1000, 100), (777, 64), (37, 10), (30000, 300), (50000, 200)])
 def test_fps(dev, n, m):
     from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as U
