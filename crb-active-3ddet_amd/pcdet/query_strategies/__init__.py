@@ -1,13 +1,23 @@
-"""pcdet.query_strategies factory (pcdet/query_strategies/__init__.py:12-29). Only the strategies on the CRB hot path
-are provided; the other baselines are out of scope."""
+"""pcdet.query_strategies factory (pcdet/query_strategies/__init__.py:12-29). `llal` needs the loss-prediction module of
+the LLAL detector variant (`pv_rcnn_llal`, not on the SECOND / PV-RCNN / CRB path) and is not provided."""
+from .badge_sampling import BadgeSampling
+from .bald_sampling import BALDSampling
+from .confidence_sampling import ConfidenceSampling
+from .coreset_sampling import CoresetSampling
 from .crb_sampling import CRBSampling
 from .entropy_sampling import EntropySampling
+from .montecarlo_sampling import MonteCarloSampling
 from .random_sampling import RandomSampling
 from .strategy import Strategy  # noqa: F401
 
 __factory = {
     'random': RandomSampling,
     'entropy': EntropySampling,
+    'confidence': ConfidenceSampling,
+    'bald': BALDSampling,
+    'montecarlo': MonteCarloSampling,
+    'coreset': CoresetSampling,
+    'badge': BadgeSampling,
     'crb': CRBSampling,
 }
 

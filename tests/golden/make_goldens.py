@@ -314,6 +314,28 @@ def gen_roi_head(out):
     out['grid_global'] = _np(g)
 
 
+def gen_strategies(out):
+    """arithmetic of the baseline query strategies, run through the reference's own methods"""
+    from pcdet.query_strategies.coreset_sampling import CoresetSampling
+    import torch.nn.functional as F
+    rng = np.random.default_rng(5)
+    me = CoresetSampling.__new__(CoresetSampling)               # furthest_first / pairwise only touch their arguments
+    X = torch.from_numpy(rng.normal(size=(23, 6, 5)).astype(np.float32))
+    X[7] = X[3]                                                 # a duplicate row: ties in the arg-max
+    S = torch.from_numpy(rng.normal(size=(4, 6, 5)).astype(np.float32) + 0.5)
+    out['cs_X'], out['cs_S'] = _np(X), _np(S)
+    out['cs_dist'] = _np(me.pairwise_squared_distances(X, S))
+    out['cs_pick'] = np.array([int(i) for i in me.furthest_first(X.clone(), S.clone(), 9)], np.int64)
+    # confidence / BALD value of a frame and the selection rule (confidence_sampling.py:44-66)
+    logits = [torch.from_numpy(rng.normal(size=(int(k), 3)).astype(np.float32) * 2) for k in (5, 1, 12, 7, 3, 9)]
+    vals = [(-(F.softmax(l, dim=1) * F.log_softmax(l, dim=1)).sum(dim=1)).mean() for l in logits]
+    sel = dict(sorted({i: v for i, v in enumerate(vals)}.items(), key=lambda item: item[1]))
+    out['ent_logits'] = np.concatenate([_np(l) for l in logits])
+    out['ent_counts'] = np.array([len(l) for l in logits], np.int64)
+    out['ent_vals'] = np.array([float(v) for v in vals], np.float32)
+    out['ent_selected'] = np.array(list(sel.keys())[len(sel) - 3:], np.int64)
+
+
 def save(name, d):
     flat = {}
     for k, v in d.items():
@@ -330,7 +352,8 @@ def save(name, d):
 if __name__ == '__main__':
     import_reference()
     only = sys.argv[1:] 
-    for name, fn in (('ref_utils.npz', gen_utils), ('ref_anchor_head.npz', gen_head), ('ref_bev_vfe.npz', gen_bev), ('ref_roi_head.npz', gen_roi_head)):
+    for name, fn in (('ref_utils.npz', gen_utils), ('ref_anchor_head.npz', gen_head), ('ref_bev_vfe.npz', gen_bev), ('ref_roi_head.npz', gen_roi_head),
+                     ('ref_strategies.npz', gen_strategies)):
         if only and name not in only:
             continue
         d = {}

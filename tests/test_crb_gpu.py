@@ -113,3 +113,56 @@ def test_stage2_pruned_backward_equals_full_backward(dev):
         torch.testing.assert_close(g, w.grad, rtol=1e-5, atol=1e-6 * float(g.abs().max()))
     emb = strat.grad_embeddings(idx, records)
     assert emb.shape == (2, 256 * 256) and torch.isfinite(emb).all()
+
+
+def test_baseline_strategies_end_to_end_small_pool(dev):
+    """confidence / bald / montecarlo / coreset / badge on a 10-frame pool through the HIP detector: N distinct pool frames
+    each; the scalar strategies' pick equals the selection rule applied to the values they computed"""
+    from pcdet.datasets import SyntheticDataset, build_synthetic_dataloader
+    from pcdet.model_cfgs import pv_rcnn_cfg
+    from pcdet.models import build_network
+    from pcdet.query_strategies import build_strategy
+    pool = SyntheticDataset(num_frames=10, first_frame=300)
+    lab = SyntheticDataset(num_frames=4, first_frame=0)
+
+    def make(embedding):
+        cfg = pv_rcnn_cfg()
+        cfg.ACTIVE_TRAIN.SELECT_NUMS = 3
+        if embedding:       # pv_rcnn_active_coreset.yaml: EMBEDDING_REQUIRED instead of the MC-dropout SAMPLING_ROUND
+            cfg.MODEL.ROI_HEAD.pop('SAMPLING_ROUND', None)
+            cfg.MODEL.ROI_HEAD.EMBEDDING_REQUIRED = True
+        torch.manual_seed(0)
+        model = build_network(cfg.MODEL, 3, pool).to(dev)
+        with torch.no_grad():
+            model.roi_head.cls_layers[-1].bias.fill_(1.0)
+        return cfg, model
+    models = {False: make(False), True: make(True)}
+    # a random-init RPN puts its top-128 proposals 20 m away from any point: RoI pooling then sees only empty balls and every
+    # frame gets the same all-zero embedding. Give the embedding model proposals on the objects (jittered GT boxes).
+    emb_head = models[True][1].roi_head
+    orig_proposal_layer = emb_head.proposal_layer
+
+    def gt_proposals(batch_dict, nms_config):
+        batch_dict = orig_proposal_layer(batch_dict, nms_config=nms_config)
+        gt = batch_dict['gt_boxes'][..., :7]
+        reps = -(-batch_dict['rois'].shape[1] // gt.shape[1])
+        rois = gt.repeat(1, reps, 1)[:, :batch_dict['rois'].shape[1]].clone()
+        rois[..., :3] += 0.2 * torch.randn_like(rois[..., :3])
+        batch_dict['rois'] = rois
+        return batch_dict
+    emb_head.proposal_layer = gt_proposals
+    for name in ('confidence', 'bald', 'montecarlo', 'coreset', 'badge'):
+        cfg, model = models[name == 'coreset']
+        strat = build_strategy(name, model, build_synthetic_dataloader(lab, 2), build_synthetic_dataloader(pool, 4), 0,
+                               '/tmp', cfg)
+        picked = strat.query(cur_epoch=0)
+        assert len(picked) == 3 and len(set(picked)) == 3 and set(picked) <= set(pool.sample_id_list), (name, picked)
+        if hasattr(strat, 'last_values'):
+            v = strat.last_values.cpu().numpy()
+            assert v.shape == (10,)
+            want = [pool.sample_id_list[i] for i in np.argsort(v, kind='stable')[-3:]]
+            assert picked == want, (name, picked, want)
+        if name == 'badge':
+            assert strat.last_embeddings.shape == (10, model.dense_head.conv_cls.weight.numel())
+            assert float(strat.last_embeddings.abs().sum()) > 0
+        assert len(strat.bbox_records) == 10                     # save_points bookkeeping of the eval pass
