@@ -48,3 +48,17 @@ def boxes3d_lidar_to_aligned_bev_boxes(boxes3d):
 def boxes3d_nearest_bev_iou(boxes_a, boxes_b):
     """(..,N,7),(..,M,7) -> (..,N,M) (box_utils.py:286-298)"""
     return boxes_iou_normal(boxes3d_lidar_to_aligned_bev_boxes(boxes_a), boxes3d_lidar_to_aligned_bev_boxes(boxes_b))
+
+
+def mask_boxes_outside_range_numpy(boxes, limit_range, min_num_corners=1):
+    """boxes (N,7+) numpy -> (N) bool: boxes with at least min_num_corners corners inside limit_range (box_utils.py:56-72)"""
+    import numpy as np
+    if boxes.shape[1] > 7:
+        boxes = boxes[:, 0:7]
+    if boxes.shape[0] == 0:
+        return np.zeros((0,), dtype=bool)
+    corners = boxes_to_corners_3d(boxes)
+    corners = corners.numpy() if hasattr(corners, 'numpy') else np.asarray(corners)
+    lr = np.asarray(limit_range, dtype=np.float32)
+    mask = ((corners >= lr[0:3]) & (corners <= lr[3:6])).all(axis=2)
+    return mask.sum(axis=1) >= min_num_corners

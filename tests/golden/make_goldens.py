@@ -336,6 +336,24 @@ def gen_strategies(out):
     out['ent_selected'] = np.array(list(sel.keys())[len(sel) - 3:], np.int64)
 
 
+def gen_data_processor(out):
+    """DataProcessor.mask_points_and_boxes_outside_range through the reference's own class (train mode, shuffle off)"""
+    from pcdet.datasets.processor.data_processor import DataProcessor
+    rng = np.random.default_rng(21)
+    pcr = np.array([0, -40, -3, 70.4, 40, 1], dtype=np.float32)
+    cfgs = [EasyDict({'NAME': 'mask_points_and_boxes_outside_range', 'REMOVE_OUTSIDE_BOXES': True}),
+            EasyDict({'NAME': 'shuffle_points', 'SHUFFLE_ENABLED': EasyDict({'train': False, 'test': False})}),
+            EasyDict({'NAME': 'transform_points_to_voxels_placeholder', 'VOXEL_SIZE': [0.05, 0.05, 0.1]})]
+    dp = DataProcessor(cfgs, point_cloud_range=pcr, training=True, num_point_features=4)
+    pts = rng.uniform([-8, -48, -4, 0], [78, 48, 2, 1], size=(3000, 4)).astype(np.float32)
+    gt = np.concatenate([rng.uniform([-5, -45, -2], [76, 45, 0], size=(14, 3)), rng.uniform(1.0, 4.5, size=(14, 3)),
+                         rng.uniform(-3.1, 3.1, size=(14, 1)), rng.integers(1, 4, size=(14, 1))], 1).astype(np.float32)
+    d = dp.forward({'points': pts.copy(), 'gt_boxes': gt.copy(), 'use_lead_xyz': True})
+    out['dp_points_in'], out['dp_gt_in'] = pts, gt
+    out['dp_points_out'], out['dp_gt_out'] = d['points'], d['gt_boxes']
+    out['dp_grid_size'] = dp.grid_size
+
+
 def save(name, d):
     flat = {}
     for k, v in d.items():
@@ -353,7 +371,7 @@ if __name__ == '__main__':
     import_reference()
     only = sys.argv[1:] 
     for name, fn in (('ref_utils.npz', gen_utils), ('ref_anchor_head.npz', gen_head), ('ref_bev_vfe.npz', gen_bev), ('ref_roi_head.npz', gen_roi_head),
-                     ('ref_strategies.npz', gen_strategies)):
+                     ('ref_strategies.npz', gen_strategies), ('ref_data_processor.npz', gen_data_processor)):
         if only and name not in only:
             continue
         d = {}

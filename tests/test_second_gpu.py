@@ -89,3 +89,48 @@ def test_bev_backbone_eval_rows_path_equals_module_path(dev):
     b = m({'spatial_features': x})['spatial_features_2d']          # grad enabled -> module path
     assert a.shape == b.shape == (3, 256, 40, 48)
     torch.testing.assert_close(a, b.detach(), rtol=1e-4, atol=1e-4)
+
+
+def test_device_data_processor_feeds_second(dev):
+    """raw per-frame points -> DeviceDataProcessor (mask + concatenate on the GPU) -> MeanVFE device
+    voxeliser -> SECOND training step. With shuffle off the voxel set / per-voxel mean equal the host DataProcessor +
+    VoxelGeneratorWrapper route (same first-point order)."""
+    from pcdet.config import EasyDict
+    from pcdet.datasets import SyntheticDataset
+    from pcdet.datasets.processor.data_processor import DataProcessor, DeviceDataProcessor
+    from pcdet.datasets.synthetic import kitti_frame
+    from pcdet.model_cfgs import second_cfg
+    from pcdet.models import build_network
+    pcr = [0, -40, -3, 70.4, 40, 1]
+    cfgs = [EasyDict({'NAME': 'mask_points_and_boxes_outside_range', 'REMOVE_OUTSIDE_BOXES': True}),
+            EasyDict({'NAME': 'shuffle_points', 'SHUFFLE_ENABLED': EasyDict({'train': False, 'test': False})}),
+            EasyDict({'NAME': 'transform_points_to_voxels', 'VOXEL_SIZE': [0.05, 0.05, 0.1], 'MAX_POINTS_PER_VOXEL': 5,
+                      'MAX_NUMBER_OF_VOXELS': EasyDict({'train': 16000, 'test': 40000})})]
+    rng = np.random.default_rng(0)
+    frames, gts = [], []
+    for f in range(3):
+        p, g = kitti_frame(40 + f, 20000)
+        p = np.concatenate([p, rng.uniform([-20, -60, -3, 0], [90, 60, 1, 1], (500, 4)).astype(np.float32)])   # outliers
+        frames.append(p)
+        gts.append(g)
+    dp = DeviceDataProcessor(cfgs, pcr, True, 4, device=dev)
+    batch = dp.process_batch(frames, gts, ['a', 'b', 'c'])
+    assert batch['points'].is_cuda and batch['points'].shape[1] == 5
+    torch.manual_seed(0)
+    model = build_network(second_cfg('kitti').MODEL, 3, SyntheticDataset(num_frames=3)).to(dev).train()
+    b2 = dict(batch)
+    ret, tb, _ = model(b2)
+    assert torch.isfinite(ret['loss'])
+    ret['loss'].backward()
+    coords = b2['voxel_coords'].cpu().numpy()
+    feats = b2['voxel_features'].cpu().numpy()
+    host = DataProcessor(cfgs, pcr, training=True, num_point_features=4)
+    start = 0
+    for k, (p, g) in enumerate(zip(frames, gts)):
+        d = host.forward({'points': p.copy(), 'gt_boxes': g.copy(), 'use_lead_xyz': True})
+        m = int((coords[:, 0] == k).sum())
+        np.testing.assert_array_equal(coords[start:start + m, 1:], d['voxel_coords'])
+        mean = d['voxels'].sum(1) / np.maximum(d['voxel_num_points'], 1)[:, None]
+        np.testing.assert_allclose(feats[start:start + m], mean, rtol=1e-5, atol=1e-5)
+        start += m
+    assert start == len(coords)
