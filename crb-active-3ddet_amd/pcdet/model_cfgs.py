@@ -59,8 +59,27 @@ def second_cfg(kind='kitti'):
 
 
 def pv_rcnn_cfg(kind='kitti'):
-    """values of tools/cfgs/active-kitti_models/pv_rcnn_active_crb.yaml"""
-    assert kind == 'kitti'
+    """values of tools/cfgs/active-kitti_models/pv_rcnn_active_crb.yaml; kind='waymo': the differences of
+    tools/cfgs/active-waymo_models/pv_rcnn_active_crb.yaml applied on top (anchors, 4096 keypoints, bev/x_conv3/x_conv4/
+    raw_points feature sources, NMS sizes and thresholds, K1=3 / K2=2 / SELECT_NUMS=400)"""
+    assert kind in ('kitti', 'waymo')
+    if kind == 'waymo':
+        c = pv_rcnn_cfg('kitti')
+        c.CLASS_NAMES = ['Vehicle', 'Pedestrian', 'Cyclist']
+        c.DATA_CONFIG.DATASET = 'WaymoDataset'
+        m = c.MODEL
+        m.DENSE_HEAD = EasyDict(_dense_head(WAYMO_ANCHORS))
+        m.PFE.NUM_KEYPOINTS = 4096
+        m.PFE.FEATURES_SOURCE = ['bev', 'x_conv3', 'x_conv4', 'raw_points']
+        m.POINT_HEAD.NUM_KEYPOINTS = 4096
+        m.ROI_HEAD.NMS_CONFIG.TEST.NMS_PRE_MAXSIZE = 4096
+        m.ROI_HEAD.NMS_CONFIG.TEST.NMS_THRESH = 0.85
+        m.POST_PROCESSING.EVAL_METRIC = 'waymo'
+        m.POST_PROCESSING.NMS_CONFIG.NMS_THRESH = 0.7
+        c.OPTIMIZATION.WEIGHT_DECAY = 0.001
+        c.ACTIVE_TRAIN.update({'PRE_TRAIN_SAMPLE_NUMS': 400, 'SELECT_NUMS': 400, 'TOTAL_BUDGET_NUMS': 2000})
+        c.ACTIVE_TRAIN.ACTIVE_CONFIG.update({'K1': 3, 'K2': 2})
+        return c
     sa = lambda f, mlp, r, ns: {'DOWNSAMPLE_FACTOR': f, 'MLPS': [list(mlp), list(mlp)], 'POOL_RADIUS': list(r),
                                 'NSAMPLE': list(ns)}
     return EasyDict({

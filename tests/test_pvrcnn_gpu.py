@@ -117,3 +117,40 @@ def test_proposal_layer_matches_oracle_nms(model, dev):
         exp[:len(keep)] = boxes[keep]
         np.testing.assert_array_equal(out['rois'][f].cpu().numpy(), exp)
         assert (out['roi_labels'][f, len(keep):] == 1).all()
+
+
+def test_waymo_pvrcnn_config_train_and_eval(dev):
+    """the Waymo PV-RCNN CRB configuration (160k-pt clouds, 5 point features, 4096 keypoints from the
+    large-n FPS kernel, bev/x_conv3/x_conv4/raw_points sources) through one training step and one CRB scoring pass"""
+    from pcdet.datasets import SyntheticDataset
+    from pcdet.model_cfgs import pv_rcnn_cfg
+    from pcdet.models import build_network
+    from pcdet.models.detectors.post_processing import crb_frame_records
+    from pcdet.query_strategies import scoring
+    cfg = pv_rcnn_cfg('waymo')
+    torch.manual_seed(0)
+    ds = SyntheticDataset(num_frames=2, kind='waymo', n_points=160000)
+    model = build_network(cfg.MODEL, 3, ds).to(dev)
+    pts, off, gt = kitti_batch(0, 2, 160000, waymo=True)
+    bidx = np.repeat(np.arange(2, dtype=np.float32), np.diff(off))
+    base = {'points': torch.from_numpy(np.concatenate([bidx[:, None], pts], 1)).to(dev),
+            'point_frame_offsets': torch.from_numpy(off).to(dev), 'gt_boxes': torch.from_numpy(gt).to(dev),
+            'batch_size': 2, 'point_frame_counts_host': np.diff(off).tolist()}
+    model.train()
+    ret, tb, _ = model(dict(base))
+    assert torch.isfinite(ret['loss'])
+    ret['loss'].backward()
+    assert model.pfe.model_cfg.NUM_KEYPOINTS == 4096 and ret['rcnn_cls'].shape == (2 * 128, 1)
+    g = model.roi_head.shared_fc_layer[4].weight.grad
+    assert g is not None and torch.isfinite(g).all()
+    model.eval()
+    for m in model.modules():
+        if m.__class__.__name__.startswith('Dropout'):
+            m.train()
+    with torch.no_grad():
+        b = dict(base)
+        for mod in model.module_list:
+            b = mod(b)
+        assert b['point_coords'].shape == (2 * 4096, 4) and b['rcnn_cls'].shape == (5, 2 * 128, 1)
+        rows = scoring.pack_records(crb_frame_records(model, b))
+    assert rows.shape == (2, scoring.REC_STRIDE) and torch.isfinite(rows).all()
