@@ -14,21 +14,28 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int ROWS_PER_BLOCK = 2048;
+// rows per statistics workgroup: sized so that a launch has ~4096 workgroups (a fixed 2048 rows gave 94 workgroups for the
+// 190k-row sparse tensors — a third of the CUs idle — and 275 for the dense BEV rows), never fewer than 128 rows
+static inline int bn_rows_per_block(int64_t n) {
+  int64_t r = (n + 4095) / 4096;
+  r = r < 128 ? 128 : (r > 2048 ? 2048 : r);
+  return (int)r;
+}
 
 // partial[(blk * 2 + which) * C + c]; which 0: sum a, 1: sum b
 template <bool BWD>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         int64_t n, int C, int relu, float* __restrict__ partial) {
+                                                         int64_t n, int C, int relu, int rows_per_block,
+                                                         float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f4* red = reinterpret_cast<f4*>(smem);               // 2 * 256 f4
   const int c4n = C >> 2;                              // float4 columns
   const int tc = threadIdx.x % c4n, tr = threadIdx.x / c4n;
   const int rlanes = 256 / c4n;
-  const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
-  const int64_t r1 = min(n, r0 + ROWS_PER_BLOCK);
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(n, r0 + rows_per_block);
   f4 a = (f4){0, 0, 0, 0}, b = (f4){0, 0, 0, 0};
   f4 mu, is, ga, be;
   if (BWD) {
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 }  // namespace
 
-static inline int bn_blocks(int64_t n) { return crb_cdiv(n, ROWS_PER_BLOCK); }
+static inline int bn_blocks(int64_t n) { return crb_cdiv(n, bn_rows_per_block(n)); }
 
 extern "C" int64_t crb_bn_workspace_bytes(int64_t n, int C) { return (int64_t)bn_blocks(n) * 2 * C * 4 + 256; }
 
@@ -156,7 +163,7 @@ extern "C" int crb_bn_relu_forward(const float* x, int64_t n, int C, const float
   const int nblk = bn_blocks(n);
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(nblk), dim3(256), 2 * 256 * 16, st, x, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, n, C, relu, partial);
+                     nullptr, nullptr, n, C, relu, bn_rows_per_block(n), partial);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 16)), dim3(256), 0, st, partial, nblk, C, n, eps, 0, mean, var,
                      invstd);
   const int64_t total4 = n * C / 4;
@@ -187,7 +194,7 @@ extern "C" int crb_bn_relu_backward(const float* x, const float* dz, int64_t n, 
   const int nblk = bn_blocks(n);
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(bn_partial_kernel<true>, dim3(nblk), dim3(256), 2 * 256 * 16, st, x, dz, mean, invstd, gamma, beta, n,
-                     C, relu, partial);
+                     C, relu, bn_rows_per_block(n), partial);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 16)), dim3(256), 0, st, partial, nblk, C, n, 0.f, 1, dbeta, dgamma,
                      (float*)nullptr);
   const int64_t total4 = n * C / 4;
