@@ -9,6 +9,9 @@ from crbhip import bnrelu
 from ...utils.fold_utils import fold_conv_bn
 
 
+ROWS_TRAIN = True      # BatchNorm2d+ReLU pairs through the fused row kernels when the activations are channels_last
+
+
 def _bn(c):
     return nn.BatchNorm2d(c, eps=1e-3, momentum=0.01)
 
@@ -87,6 +90,29 @@ class BaseBEVBackbone(nn.Module):
                 i += 1
         return x
 
+    @staticmethod
+    def _run_rows_train(seq, x):
+        """training / grad-enabled path on channels_last CUDA tensors: the BatchNorm2d -> ReLU pairs run as the fused row
+        kernels on the (N*H*W, C) view of the NHWC storage (crb_bn_relu_forward / _backward: statistics pass + apply pass
+        forward, reduce + apply pass backward with the ReLU mask recomputed) instead of MIOpen BatchNorm2d plus separate
+        ReLU forward / backward passes over the 288 MB BEV tensors."""
+        mods = list(seq)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(m, nn.BatchNorm2d) and isinstance(nxt, nn.ReLU) and \
+                    x.is_contiguous(memory_format=torch.channels_last) and \
+                    bnrelu.supported(x.new_empty((2, x.shape[1])), m):
+                n, c, h, w_ = x.shape
+                rows = x.permute(0, 2, 3, 1).reshape(n * h * w_, c)
+                x = bnrelu.bn_relu(rows, m, relu=True).view(n, h, w_, c).permute(0, 3, 1, 2)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
+
     def forward(self, data_dict):
         spatial_features = data_dict['spatial_features']
         ups = []
@@ -100,11 +126,13 @@ class BaseBEVBackbone(nn.Module):
                 x = self._run_folded(self.deblocks[-1], x)
             data_dict['spatial_features_2d'] = x
             return data_dict
+        run = self._run_rows_train if (ROWS_TRAIN and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last)) \
+            else (lambda seq, t: seq(t))
         for i, blk in enumerate(self.blocks):
-            x = blk(x)
+            x = run(blk, x)
             stride = int(spatial_features.shape[2] / x.shape[2])
             data_dict['spatial_features_%dx' % stride] = x
-            ups.append(self.deblocks[i](x) if len(self.deblocks) > 0 else x)
+            ups.append(run(self.deblocks[i], x) if len(self.deblocks) > 0 else x)
         x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
         if len(self.deblocks) > len(self.blocks):
             x = self.deblocks[-1](x)

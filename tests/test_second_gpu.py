@@ -134,3 +134,43 @@ def test_device_data_processor_feeds_second(dev):
         np.testing.assert_allclose(feats[start:start + m], mean, rtol=1e-5, atol=1e-5)
         start += m
     assert start == len(coords)
+
+
+def test_bev_backbone_training_rows_path_equals_module_path(dev):
+    """training: BatchNorm2d+ReLU pairs through the fused row kernels on the NHWC view == the nn modules (outputs, input /
+    parameter grads, running statistics)"""
+    import copy
+    from pcdet.config import EasyDict
+    from pcdet.models.backbones_2d import BaseBEVBackbone, base_bev_backbone as B
+    cfg = EasyDict({'LAYER_NUMS': [2, 2], 'LAYER_STRIDES': [1, 2], 'NUM_FILTERS': [64, 128], 'UPSAMPLE_STRIDES': [1, 2],
+                    'NUM_UPSAMPLE_FILTERS': [128, 128]})
+    torch.manual_seed(0)
+    m = BaseBEVBackbone(cfg, input_channels=64).to(dev).train().to(memory_format=torch.channels_last)
+    ref = copy.deepcopy(m)
+    x1 = torch.randn(3, 64, 40, 48, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    go = torch.randn(3, 256, 40, 48, device=dev).contiguous(memory_format=torch.channels_last)
+    assert B.ROWS_TRAIN
+    a = m({'spatial_features': x1})['spatial_features_2d']
+    a.backward(go)
+    B.ROWS_TRAIN = False
+    try:
+        b = ref({'spatial_features': x2})['spatial_features_2d']
+        b.backward(go)
+    finally:
+        B.ROWS_TRAIN = True
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+
+    def same_up_to_relu_flips(g1, g2, what):
+        # a pre-activation within rounding of 0 may land on different sides in the two runs (f32 sums in another order): that
+        # ONE flipped ReLU gate changes the gradient of every input element in its 9x9 receptive field. Typical: 2-3 gates of
+        # 3.7 M. So: the bulk must agree to f32 accuracy, the total deviation must stay tiny.
+        d = (g1 - g2).abs()
+        assert float(d.median()) < 1e-5 * max(1.0, float(g2.abs().max())), what
+        assert float((d > 1e-3 * (1 + g2.abs())).float().mean()) < 0.05, what
+        assert float(d.norm() / g2.norm()) < 3e-2, what
+    same_up_to_relu_flips(x1.grad, x2.grad, 'input grad')
+    for (n1, p1), (_, p2) in zip(m.named_parameters(), ref.named_parameters()):
+        same_up_to_relu_flips(p1.grad, p2.grad, n1)
+    for (n1, b1), (_, b2) in zip(m.named_buffers(), ref.named_buffers()):
+        torch.testing.assert_close(b1.float(), b2.float(), rtol=1e-4, atol=1e-5, msg=lambda s, n1=n1: n1 + ': ' + s)
