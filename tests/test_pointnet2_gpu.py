@@ -268,9 +268,9 @@ def test_sa_module_rows_training_path_equals_module_path(dev):
     def same_up_to_relu_flips(g1, g2, what):
         # sums over M*ns = 12.8k rows in another association (GEMM vs conv, BN reductions); a pre-activation within rounding
         # of 0 may also land on different sides of the ReLU in the two paths and change a handful of entries
-        d = (g1 - g2).abs()
-        assert float(d.median()) < 1e-4 * max(1.0, float(g2.abs().max())), what
-        assert float((d > 5e-3 * (1 + g2.abs())).float().mean()) < 0.02, what
+        d, scale = (g1 - g2).abs(), max(1.0, float(g2.abs().max()))
+        assert float(d.median()) < 1e-3 * scale, what
+        assert float((d > 5e-3 * scale).float().mean()) < 0.02, what
         assert float(d.norm() / g2.norm().clamp_min(1e-12)) < 2e-2, what
     same_up_to_relu_flips(f1.grad, f2.grad, 'feature grad')
     for (n1, p1), (n2, p2) in zip(layer.named_parameters(), ref.named_parameters()):
