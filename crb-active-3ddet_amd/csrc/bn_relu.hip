@@ -14,11 +14,12 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-// rows per statistics workgroup: sized so that a launch has ~4096 workgroups (a fixed 2048 rows gave 94 workgroups for the
-// 190k-row sparse tensors — a third of the CUs idle — and 275 for the dense BEV rows), never fewer than 128 rows
+// rows per statistics workgroup: sized so that a launch has ~1024 workgroups = 4 per CU (a fixed 2048 rows gave 94
+// workgroups for the 190k-row sparse tensors — a third of the CUs idle — and 275 for the dense BEV rows; 4096 workgroups
+// made the finalize pass, which walks all partials, the most expensive BN kernel of the step), never fewer than 128 rows
 static inline int bn_rows_per_block(int64_t n) {
-  int64_t r = (n + 4095) / 4096;
-  r = r < 128 ? 128 : (r > 2048 ? 2048 : r);
+  int64_t r = (n + 1023) / 1024;
+  r = r < 128 ? 128 : r;
   return (int)r;
 }
 
@@ -73,18 +74,17 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 }
 
 // forward finalize: mean, biased var, invstd ; backward finalize: dbeta, dgamma.
-// 256 threads = 16 channels x 16 strided slices of the per-block partials, summed in double and combined through LDS in a
-// fixed order (deterministic). One thread per channel walking all partials took 174 us at the RoI-grid shape of PV-RCNN
-// (7 M rows -> 3456 partials).
+// 256 threads = 8 channels x 32 strided slices of the per-block partials, summed in double and combined through LDS in a
+// fixed order (deterministic).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int64_t n,
                                                           float eps, int bwd, float* __restrict__ o0,
                                                           float* __restrict__ o1, float* __restrict__ o2) {
-  __shared__ double sa[16][16], sb[16][16];
-  const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  __shared__ double sa[32][8], sb[32][8];
+  const int cl = threadIdx.x & 7, part = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
   double a = 0.0, b = 0.0;
   if (c < C)
-    for (int k = part; k < nblk; k += 16) {
+    for (int k = part; k < nblk; k += 32) {
       a += (double)partial[((int64_t)k * 2 + 0) * C + c];
       b += (double)partial[((int64_t)k * 2 + 1) * C + c];
     }
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   sb[part][cl] = b;
   __syncthreads();
   if (part != 0 || c >= C) return;
-  for (int k = 1; k < 16; ++k) { a += sa[k][cl]; b += sb[k][cl]; }
+  for (int k = 1; k < 32; ++k) { a += sa[k][cl]; b += sb[k][cl]; }
   if (!bwd) {
     const double m = a / (double)n;
     double v = b / (double)n - m * m;
@@ -164,7 +164,7 @@ extern "C" int crb_bn_relu_forward(const float* x, int64_t n, int C, const float
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(nblk), dim3(256), 2 * 256 * 16, st, x, nullptr, nullptr, nullptr,
                      nullptr, nullptr, n, C, relu, bn_rows_per_block(n), partial);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 16)), dim3(256), 0, st, partial, nblk, C, n, eps, 0, mean, var,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, eps, 0, mean, var,
                      invstd);
   const int64_t total4 = n * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, z,
@@ -195,7 +195,7 @@ extern "C" int crb_bn_relu_backward(const float* x, const float* dz, int64_t n, 
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(bn_partial_kernel<true>, dim3(nblk), dim3(256), 2 * 256 * 16, st, x, dz, mean, invstd, gamma, beta, n,
                      C, relu, bn_rows_per_block(n), partial);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 16)), dim3(256), 0, st, partial, nblk, C, n, 0.f, 1, dbeta, dgamma,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, 0.f, 1, dbeta, dgamma,
                      (float*)nullptr);
   const int64_t total4 = n * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, dz, mean, invstd, gamma, beta,
