@@ -4,6 +4,9 @@ import torch
 from ._lib import lib, check, ptr, cur_stream, require_cuda
 
 
+FUSE_RUNNING = __import__('os').environ.get('CRB_BN_FUSE_RUNNING', '1') == '1'
+
+
 def supported(x, bn):
     C = x.shape[1]
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 2 and C % 4 == 0 and
@@ -12,7 +15,7 @@ def supported(x, bn):
 
 class _BNReLUTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu):
+    def forward(ctx, x, gamma, beta, eps, relu, running_mean=None, running_var=None, momentum=0.0):
         require_cuda(x, gamma, beta)
         x = x.contiguous()
         n, C = x.shape
@@ -25,7 +28,8 @@ class _BNReLUTrain(torch.autograd.Function):
         ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
         g, b = gamma.contiguous().float(), beta.contiguous().float()
         check(lib.crb_bn_relu_forward(ptr(x), n, C, ptr(g), ptr(b), float(eps), int(relu), ptr(z), ptr(mean), ptr(var),
-                                      ptr(invstd), ptr(ws), wsb, cur_stream(dev)), 'crb_bn_relu_forward')
+                                      ptr(invstd), ptr(running_mean), ptr(running_var), float(momentum), ptr(ws), wsb,
+                                      cur_stream(dev)), 'crb_bn_relu_forward')
         ctx.save_for_backward(x, mean, invstd, g, b)
         ctx.relu = int(relu)
         ctx.mark_non_differentiable(mean, var)
@@ -44,7 +48,7 @@ class _BNReLUTrain(torch.autograd.Function):
         ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
         check(lib.crb_bn_relu_backward(ptr(x), ptr(dz), n, C, ptr(mean), ptr(invstd), ptr(g), ptr(b), ctx.relu, ptr(dx),
                                        ptr(dgamma), ptr(dbeta), ptr(ws), wsb, cur_stream(dev)), 'crb_bn_relu_backward')
-        return dx, dgamma, dbeta, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None
 
 
 def bn_relu(x, bn, relu=True):
@@ -52,9 +56,16 @@ def bn_relu(x, bn, relu=True):
     (momentum, unbiased running variance, num_batches_tracked)."""
     n, C = x.shape
     if bn.training:
-        z, mean, var = _BNReLUTrain.apply(x, bn.weight, bn.bias, bn.eps, relu)
         with torch.no_grad():
             bn.num_batches_tracked += 1
+        if FUSE_RUNNING and bn.momentum is not None and bn.running_mean.is_contiguous() and \
+                bn.running_var.is_contiguous():
+            # the running statistics are updated inside the finalize launch of the forward
+            z, mean, var = _BNReLUTrain.apply(x, bn.weight, bn.bias, bn.eps, relu, bn.running_mean, bn.running_var,
+                                              float(bn.momentum))
+            return z
+        z, mean, var = _BNReLUTrain.apply(x, bn.weight, bn.bias, bn.eps, relu)
+        with torch.no_grad():                      # cumulative moving average (momentum=None): factor known on the host
             m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
             bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
             bn.running_var.mul_(1 - m).add_(var, alpha=m * n / (n - 1))

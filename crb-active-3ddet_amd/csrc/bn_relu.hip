@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 // fixed order (deterministic).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int64_t n,
                                                           float eps, int bwd, float* __restrict__ o0,
-                                                          float* __restrict__ o1, float* __restrict__ o2) {
+                                                          float* __restrict__ o1, float* __restrict__ o2,
+                                                          float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float momentum) {
   __shared__ double sa[32][8], sb[32][8];
   const int cl = threadIdx.x & 7, part = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cl;
@@ -100,6 +102,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     o0[c] = (float)m;
     o1[c] = (float)v;
     o2[c] = (float)(1.0 / sqrt(v + (double)eps));
+    if (running_mean) {                  // nn.BatchNorm: running = (1 - m) * running + m * batch (variance unbiased)
+      const float unbiased = (float)(n > 1 ? v * ((double)n / (double)(n - 1)) : v);
+      running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * (float)m;
+      running_var[c] = running_var[c] * (1.f - momentum) + momentum * unbiased;
+    }
   } else {
     o0[c] = (float)a;      // dbeta
     o1[c] = (float)b;      // dgamma
@@ -155,8 +162,9 @@ extern "C" int64_t crb_bn_workspace_bytes(int64_t n, int C) { return (int64_t)bn
 
 // training forward. mean/var/invstd (C) out. z may alias x? no: x is kept for backward.
 extern "C" int crb_bn_relu_forward(const float* x, int64_t n, int C, const float* gamma, const float* beta, float eps,
-                                   int relu, float* z, float* mean, float* var, float* invstd, void* workspace,
-                                   int64_t workspace_bytes, void* stream) {
+                                   int relu, float* z, float* mean, float* var, float* invstd, float* running_mean,
+                                   float* running_var, float momentum, void* workspace, int64_t workspace_bytes,
+                                   void* stream) {
   if (n <= 0 || C <= 0 || (C & 3) || C > 1024 || (256 % (C >> 2) && (C >> 2) < 256)) return CRB_ERR_ARG;
   if (workspace_bytes < crb_bn_workspace_bytes(n, C) - 256 || !workspace) return CRB_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -165,7 +173,7 @@ extern "C" int crb_bn_relu_forward(const float* x, int64_t n, int C, const float
   hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(nblk), dim3(256), 2 * 256 * 16, st, x, nullptr, nullptr, nullptr,
                      nullptr, nullptr, n, C, relu, bn_rows_per_block(n), partial);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, eps, 0, mean, var,
-                     invstd);
+                     invstd, running_mean, running_var, momentum);
   const int64_t total4 = n * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, z,
                      total4, C, relu);
@@ -196,7 +204,7 @@ extern "C" int crb_bn_relu_backward(const float* x, const float* dz, int64_t n, 
   hipLaunchKernelGGL(bn_partial_kernel<true>, dim3(nblk), dim3(256), 2 * 256 * 16, st, x, dz, mean, invstd, gamma, beta, n,
                      C, relu, bn_rows_per_block(n), partial);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, 0.f, 1, dbeta, dgamma,
-                     (float*)nullptr);
+                     (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f);
   const int64_t total4 = n * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, dz, mean, invstd, gamma, beta,
                      dbeta, dgamma, dx, total4, C, 1.0f / (float)n, relu);

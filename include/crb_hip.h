@@ -263,12 +263,13 @@ int crb_density_greedy(const float* densities, const int32_t* labels, int n_cand
  * replaces: nn.BatchNorm1d(eps=1e-3, momentum=0.01) + nn.ReLU after every sparse conv
  *           (pcdet/models/backbones_3d/spconv_backbone.py:21-25,73). x,z,dx,dz (n,C) f32, C % 4 == 0 and
  *           (C/4) divides 256 (C = 16,32,64,128,...). Training forward returns batch mean / biased var / invstd;
- *           the running-statistics update stays on the host side (two axpy on C floats).
+ *           running_mean / running_var (nullable) are updated in the same launch: r = (1-momentum) r + momentum batch,
+ *           variance unbiased (n/(n-1)), as nn.BatchNorm does.
  * ---------------------------------------------------------------------------------------------- */
 int64_t crb_bn_workspace_bytes(int64_t n, int C);
 int crb_bn_relu_forward(const float* x, int64_t n, int C, const float* gamma, const float* beta, float eps,
-                        int relu, float* z, float* mean, float* var, float* invstd, void* workspace,
-                        int64_t workspace_bytes, void* stream);
+                        int relu, float* z, float* mean, float* var, float* invstd, float* running_mean,
+                        float* running_var, float momentum, void* workspace, int64_t workspace_bytes, void* stream);
 int crb_bn_relu_apply(const float* x, int64_t n, int C, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int relu, float* z, void* stream);
 int crb_bn_relu_backward(const float* x, const float* dz, int64_t n, int C, const float* mean,
