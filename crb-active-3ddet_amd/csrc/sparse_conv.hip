@@ -237,7 +237,11 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
 // is per-phase latency: time fits 25 us + 12.6 us x (offsets in the workgroup union), i.e. a phase costs the same whether 4
 // or 1 of its tiles are active — the W[o] global->LDS hand-off and its barrier set a floor the MFMA work does not fill.
 // ---------------------------------------------------------------------------------------------------
-template <int CIN, int COUT, bool NOMFMA = false, bool REMAP = true>
+// cycle accounting of the measurement build (TIMING): [0] waves, [1] total, [2] prologue, [3] load issue, [4] MFMA block,
+// [5] W store (incl. its vmcnt wait), [6] barrier wait, [7] epilogue, [8] phases, [9] phases with MFMA work
+__device__ unsigned long long g_fwd2_timing[16];
+
+template <int CIN, int COUT, bool NOMFMA = false, bool REMAP = true, bool TIMING = false>
 __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                                const int* __restrict__ nbr, const int* __restrict__ perm,
                                                                float* __restrict__ Y, int n_out, int K, int ntiles) {
@@ -256,15 +260,37 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
 
   const int tile = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   if (tile >= ntiles) return;
+  unsigned long long tk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_begin = TIMING ? __builtin_readcyclecounter() : 0ULL;
+  unsigned long long t_mark = t_begin;
+  auto lap = [&](int slot) {
+    if constexpr (TIMING) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      tk[slot] += now - t_mark;
+      t_mark = now;
+    }
+  };
   const int row0 = tile * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
-  const int rows_here = min(64, n_out - row0);
-  for (int t = threadIdx.x; t < 64 * K; t += 256) nbr_lds[t] = (t / K < rows_here) ? nbr[(int64_t)row0 * K + t] : -1;
+  // Prologue and epilogue run in the issue shadows of the other resident workgroups' MFMAs (s_memtime accounting,
+  // tools/time_gather_gemm_regions.py: 31 % + 21 % of a wave's lifetime on the real tables), so they are kept short in
+  // INSTRUCTIONS: the 64 x K table is copied without a division per element, a wave derives its tile's offset mask from
+  // ceil(K/4) LDS reads per lane + an OR butterfly (not K reads + K ballots), and the output-row indirection perm[] is
+  // fetched here, long before the final stores need it.
+  const int lim = min(64, n_out - row0) * K;
+  for (int t = threadIdx.x; t < 64 * K; t += 256) nbr_lds[t] = (t < lim) ? nbr[(int64_t)row0 * K + t] : -1;
+  int out_row[4];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    const int srow = row0 + wave * 16 + g * 4 + rg;
+    out_row[rg] = srow < n_out ? (perm ? perm[srow] : srow) : -1;
+  }
   __syncthreads();
   const int* my_nbr = nbr_lds + (wave * 16 + li) * K;
   unsigned sm = 0;
-  for (int o = 0; o < K; ++o)
-    if (__ballot(my_nbr[o] >= 0)) sm |= 1u << o;
+  for (int o = g; o < K; o += 4) sm |= (my_nbr[o] >= 0 ? 1u : 0u) << o;      // lane (li, g): offsets g, g+4, ...
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) sm |= (unsigned)__shfl_xor((int)sm, d);
   sm = __builtin_amdgcn_readfirstlane(sm);
   if (lane == 0) wg_mask_sh[wave] = sm;
   __syncthreads();
@@ -353,6 +379,7 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
   int r0 = cur >= 0 ? my_nbr[cur] : -1, r1 = -1;
   load_a(a0, X, r0);
   __syncthreads();
+  lap(2);
   while (cur >= 0) {
     {                                                // even phase: W in w_lds0, A in a0
       todo &= todo - 1;
@@ -361,9 +388,14 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
       w_fetch(oq);
       r1 = my_nbr[oq];
       load_a(a1, X, r1);
-      if ((sm >> cur) & 1u) mfma_block(a0, r0 >= 0, w_lds0);
+      lap(3);
+      if ((sm >> cur) & 1u) { mfma_block(a0, r0 >= 0, w_lds0); tk[9] += 1; }
+      lap(4);
       w_store(w_lds1);
+      lap(5);
       __syncthreads();
+      lap(6);
+      tk[8] += 1;
       cur = nxt;
     }
     if (cur < 0) break;
@@ -374,21 +406,32 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
       w_fetch(oq);
       r0 = my_nbr[oq];
       load_a(a0, X, r0);
-      if ((sm >> cur) & 1u) mfma_block(a1, r1 >= 0, w_lds1);
+      lap(3);
+      if ((sm >> cur) & 1u) { mfma_block(a1, r1 >= 0, w_lds1); tk[9] += 1; }
+      lap(4);
       w_store(w_lds0);
+      lap(5);
       __syncthreads();
+      lap(6);
+      tk[8] += 1;
       cur = nxt;
     }
   }
 
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) {
-    const int srow = row0 + wave * 16 + g * 4 + rg;
-    if (srow < n_out) {
-      const int row = perm ? perm[srow] : srow;
+    if (out_row[rg] >= 0) {
+      float* dst = Y + (int64_t)out_row[rg] * COUT + li;
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-        if (nb * 16 + li < COUT) Y[(int64_t)row * COUT + nb * 16 + li] = acc[nb][rg];
+      for (int nb = 0; nb < NB; ++nb) dst[nb * 16] = acc[nb][rg];
+    }
+  }
+  if constexpr (TIMING) {
+    lap(7);
+    if (lane == 0) {
+      atomicAdd(&g_fwd2_timing[0], 1ULL);
+      atomicAdd(&g_fwd2_timing[1], __builtin_readcyclecounter() - t_begin);
+      for (int k = 2; k < 10; ++k) atomicAdd(&g_fwd2_timing[k], tk[k]);
     }
   }
 }
@@ -626,7 +669,8 @@ int launch_fwd(const float* X, const float* W, const int* nbr, const int* perm, 
   // workgroups win. subt > 1 stays available for measurements only.
   int subt = (g_subt_override == 2 || g_subt_override == 4) ? g_subt_override : 1;
   if constexpr (CIN % 16 == 0 && COUT % 16 == 0 && CIN <= 64) {
-    if (g_subt_override == 0 || g_subt_override == 8 || g_subt_override == 9 || g_subt_override == 16) {   // v2
+    if (g_subt_override == 0 || g_subt_override == 8 || g_subt_override == 9 || g_subt_override == 16 ||
+        g_subt_override == 32) {   // v2
       const int ntiles = crb_cdiv(n_out, 64);
       const int grid = ((ntiles + 7) / 8) * 8;
       size_t lds = 2 * sizeof(float) * CIN * (((COUT + 15) / 16) * 16) + sizeof(int) * 64 * K;
@@ -634,6 +678,12 @@ int launch_fwd(const float* X, const float* W, const int* nbr, const int* perm, 
         if (g_subt_override == 16) {                 // measurement: tiles in blockIdx order (no XCD-contiguous remap)
           hipLaunchKernelGGL((sparse_conv_fwd2_kernel<CIN, COUT, false, false>), dim3(grid), dim3(256), lds, st, X, W, nbr,
                              perm, Y, (int)n_out, K, ntiles);
+          CRB_CHECK_LAUNCH();
+          return CRB_OK;
+        }
+        if (g_subt_override == 32) {                 // measurement: per-region cycle accounting (crb_sparse_conv_timing)
+          hipLaunchKernelGGL((sparse_conv_fwd2_kernel<CIN, COUT, false, true, true>), dim3(grid), dim3(256), lds, st, X, W,
+                             nbr, perm, Y, (int)n_out, K, ntiles);
           CRB_CHECK_LAUNCH();
           return CRB_OK;
         }
@@ -687,7 +737,17 @@ extern "C" int crb_sparse_conv_supported(int cin, int cout) {
 
 extern "C" int crb_sparse_conv_set_subtiles(int subt) {
   // 0 = default (v2 where the shape allows, else v1); 1,2,4 = v1 with that many row tiles per wave; 8 = v2 (A/B runs)
-  g_subt_override = (subt == 1 || subt == 2 || subt == 4 || subt == 8 || subt == 9 || subt == 16) ? subt : 0;
+  g_subt_override = (subt == 1 || subt == 2 || subt == 4 || subt == 8 || subt == 9 || subt == 16 || subt == 32) ? subt : 0;
+  return CRB_OK;
+}
+
+// measurement builds only: read (and clear) the cycle counters accumulated by set_subtiles(32) launches of the 64x64 kernel
+extern "C" int crb_sparse_conv_timing(uint64_t* out16_host) {
+  unsigned long long h[16];
+  CRB_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fwd2_timing), sizeof(h)));
+  for (int k = 0; k < 16; ++k) out16_host[k] = h[k];
+  unsigned long long z[16] = {0};
+  CRB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fwd2_timing), z, sizeof(z)));
   return CRB_OK;
 }
 
