@@ -238,7 +238,9 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
 // or 1 of its tiles are active — the W[o] global->LDS hand-off and its barrier set a floor the MFMA work does not fill.
 // ---------------------------------------------------------------------------------------------------
 // cycle accounting of the measurement build (TIMING): [0] waves, [1] total, [2] prologue, [3] load issue, [4] MFMA block,
-// [5] W store (incl. its vmcnt wait), [6] barrier wait, [7] epilogue, [8] phases, [9] phases with MFMA work
+// [5] W store (incl. its vmcnt wait), [6] barrier wait, [7] epilogue, [8] phases, [9] phases with MFMA work,
+// [10] W fetch issue, [11] row-index LDS read ([3] is then the gather issue only), [12] wait at phase start until the
+// gather prefetched one phase earlier has landed (explicit vmcnt(0), measurement build only)
 __device__ unsigned long long g_fwd2_timing[16];
 
 template <int CIN, int COUT, bool NOMFMA = false, bool REMAP = true, bool TIMING = false>
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
 
   const int tile = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   if (tile >= ntiles) return;
-  unsigned long long tk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tk[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_begin = TIMING ? __builtin_readcyclecounter() : 0ULL;
   unsigned long long t_mark = t_begin;
   auto lap = [&](int slot) {
@@ -385,8 +387,11 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
       todo &= todo - 1;
       const int nxt = todo ? __ffs(todo) - 1 : -1;
       const int oq = nxt >= 0 ? nxt : cur;           // the last phase re-fetches its own offset (unused)
+      if constexpr (TIMING) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lap(12); }
       w_fetch(oq);
+      lap(10);
       r1 = my_nbr[oq];
+      if constexpr (TIMING) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); lap(11); }
       load_a(a1, X, r1);
       lap(3);
       if ((sm >> cur) & 1u) { mfma_block(a0, r0 >= 0, w_lds0); tk[9] += 1; }
@@ -403,8 +408,11 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
       todo &= todo - 1;
       const int nxt = todo ? __ffs(todo) - 1 : -1;
       const int oq = nxt >= 0 ? nxt : cur;
+      if constexpr (TIMING) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lap(12); }
       w_fetch(oq);
+      lap(10);
       r0 = my_nbr[oq];
+      if constexpr (TIMING) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); lap(11); }
       load_a(a0, X, r0);
       lap(3);
       if ((sm >> cur) & 1u) { mfma_block(a1, r1 >= 0, w_lds1); tk[9] += 1; }
@@ -431,7 +439,7 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
     if (lane == 0) {
       atomicAdd(&g_fwd2_timing[0], 1ULL);
       atomicAdd(&g_fwd2_timing[1], __builtin_readcyclecounter() - t_begin);
-      for (int k = 2; k < 10; ++k) atomicAdd(&g_fwd2_timing[k], tk[k]);
+      for (int k = 2; k < 13; ++k) atomicAdd(&g_fwd2_timing[k], tk[k]);
     }
   }
 }

@@ -114,7 +114,8 @@ int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, 
 int crb_sparse_conv_set_subtiles(int subt);
 /* measurement builds: after launches under crb_sparse_conv_set_subtiles(32) (64x64 kernel with s_memtime accounting), copy the
  * 16 accumulated counters to host memory and clear them: [0] waves [1] total cycles [2] prologue [3] load issue [4] MFMA
- * block [5] W store [6] barrier wait [7] epilogue [8] phases [9] phases with MFMA work. Synchronises the device. */
+ * block [5] W store [6] barrier wait [7] epilogue [8] phases [9] phases with MFMA work [10] W fetch issue [11] row-index
+ * LDS read [12] wait for the previous phase's gather prefetch. Synchronises the device. */
 int crb_sparse_conv_timing(uint64_t* out16_host);
 /* dW (K,cin,cout) = sum over pairs X[pin]^T dY[pout] */
 int crb_sparse_conv_wgrad_splits(void);
