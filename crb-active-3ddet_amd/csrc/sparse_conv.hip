@@ -240,7 +240,9 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
 // cycle accounting of the measurement build (TIMING): [0] waves, [1] total, [2] prologue, [3] load issue, [4] MFMA block,
 // [5] W store (incl. its vmcnt wait), [6] barrier wait, [7] epilogue, [8] phases, [9] phases with MFMA work,
 // [10] W fetch issue, [11] row-index LDS read ([3] is then the gather issue only), [12] wait at phase start until the
-// gather prefetched one phase earlier has landed (explicit vmcnt(0), measurement build only)
+// gather prefetched one phase earlier has landed (explicit vmcnt(0), measurement build only), [13] prologue part 1: table
+// copy + perm loads up to the first barrier, [14] part 2: masks up to the second barrier ([2] is then part 3: first W[o]
+// fetch + store + first gather issue + barrier)
 __device__ unsigned long long g_fwd2_timing[16];
 
 template <int CIN, int COUT, bool NOMFMA = false, bool REMAP = true, bool TIMING = false>
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
 
   const int tile = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   if (tile >= ntiles) return;
-  unsigned long long tk[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_begin = TIMING ? __builtin_readcyclecounter() : 0ULL;
   unsigned long long t_mark = t_begin;
   auto lap = [&](int slot) {
@@ -288,6 +290,7 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
     out_row[rg] = srow < n_out ? (perm ? perm[srow] : srow) : -1;
   }
   __syncthreads();
+  lap(13);
   const int* my_nbr = nbr_lds + (wave * 16 + li) * K;
   unsigned sm = 0;
   for (int o = g; o < K; o += 4) sm |= (my_nbr[o] >= 0 ? 1u : 0u) << o;      // lane (li, g): offsets g, g+4, ...
@@ -296,6 +299,7 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
   sm = __builtin_amdgcn_readfirstlane(sm);
   if (lane == 0) wg_mask_sh[wave] = sm;
   __syncthreads();
+  lap(14);
   unsigned todo = wg_mask_sh[0] | wg_mask_sh[1] | wg_mask_sh[2] | wg_mask_sh[3];
 
   f32x4 acc[NB];
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
     if (lane == 0) {
       atomicAdd(&g_fwd2_timing[0], 1ULL);
       atomicAdd(&g_fwd2_timing[1], __builtin_readcyclecounter() - t_begin);
-      for (int k = 2; k < 13; ++k) atomicAdd(&g_fwd2_timing[k], tk[k]);
+      for (int k = 2; k < 15; ++k) atomicAdd(&g_fwd2_timing[k], tk[k]);
     }
   }
 }

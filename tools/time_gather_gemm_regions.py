@@ -9,8 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'crb-active-3ddet_amd'))
 import torch  # noqa: E402
 
-NAMES = ['waves', 'total', 'prologue', 'gather issue', 'MFMA block', 'W store(+vmcnt)', 'barrier wait', 'epilogue', 'phases',
-         'phases with MFMA', 'W fetch issue', 'row index (LDS)', 'prefetch landed?']
+NAMES = ['waves', 'total', 'prologue 3: first W', 'gather issue', 'MFMA block', 'W store(+vmcnt)', 'barrier wait', 'epilogue', 'phases',
+         'phases with MFMA', 'W fetch issue', 'row index (LDS)', 'prefetch landed?', 'prologue 1: table', 'prologue 2: masks']
 
 
 def main():
@@ -48,7 +48,7 @@ def main():
             waves = max(v[0], 1)
             print('== %s: %d waves, %.1f phases/wave (%.1f with MFMA work), %.0f cycles/wave (s_memtime ticks = shader cycles)'
                   % (name, waves // 3, v[8] / waves, v[9] / waves, v[1] / waves))
-            for k in (2, 12, 10, 11, 3, 4, 5, 6, 7):
+            for k in (13, 14, 2, 12, 10, 11, 3, 4, 5, 6, 7):
                 print('   %-18s %8.0f cycles/wave  %5.1f %%   %7.0f per phase' % (NAMES[k], v[k] / waves, 100.0 * v[k] / v[1],
                                                                                 v[k] / max(v[8], 1)))
 
