@@ -792,10 +792,18 @@ extern "C" int crb_sparse_conv_forward(const float* X, const float* W, const int
   return CRB_ERR_UNSUPPORTED;
 }
 
-extern "C" int crb_sparse_conv_wgrad_splits(void) { return 96; }   // multiple of 8 (XCD mapping)
+static int g_wgrad_splits = 96;   // workgroups per kernel offset the plan aims at (multiple of 8: XCD mapping)
+extern "C" int crb_sparse_conv_wgrad_splits(void) { return g_wgrad_splits; }
+// 16x16 tiles: the partial reduction costs as much as the MFMA work, fewer and larger workgroups win (sweep on the SECOND
+// bs=16 geometry: 32 / 96 / 256 workgroups per offset = 39 / 52 / 95 us at C=16, 292 / 264 / 259 us at C=64)
+static inline int wgrad_splits_for(int cin, int cout) { return (cin * cout <= 256 && g_wgrad_splits == 96) ? 32 : g_wgrad_splits; }
+extern "C" int crb_sparse_conv_set_wgrad_splits(int s) {      // A/B measurements; 0 restores the default
+  g_wgrad_splits = (s >= 8 && s <= 1024 && s % 8 == 0) ? s : 96;
+  return CRB_OK;
+}
 
 extern "C" int64_t crb_sparse_conv_wgrad_workspace_bytes(int K, int cin, int cout) {
-  return (int64_t)crb_sparse_conv_wgrad_splits() * K * cin * cout * 4 + 256;
+  return (int64_t)wgrad_splits_for(cin, cout) * K * cin * cout * 4 + 256;
 }
 
 extern "C" int crb_sparse_conv_wgrad(const float* X, const float* dY, const int32_t* pair_in, const int32_t* pair_out,
@@ -804,7 +812,7 @@ extern "C" int crb_sparse_conv_wgrad(const float* X, const float* dY, const int3
   if (K <= 0 || K > 32) return CRB_ERR_ARG;
   if (workspace_bytes < crb_sparse_conv_wgrad_workspace_bytes(K, cin, cout) || !workspace) return CRB_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  const int S = crb_sparse_conv_wgrad_splits();
+  const int S = wgrad_splits_for(cin, cout);
 #define X_(a, b)                                                                                              \
   if (cin == a && cout == b)                                                                                  \
     return launch_wgrad<a, b>(X, dY, pair_in, pair_out, pair_start, dW, (float*)workspace,                     \
