@@ -154,3 +154,48 @@ def test_waymo_pvrcnn_config_train_and_eval(dev):
         assert b['point_coords'].shape == (2 * 4096, 4) and b['rcnn_cls'].shape == (5, 2 * 128, 1)
         rows = scoring.pack_records(crb_frame_records(model, b))
     assert rows.shape == (2, scoring.REC_STRIDE) and torch.isfinite(rows).all()
+
+
+def test_ragged_batch_train_and_scoring(model, dev):
+    """frames of different length (9k / 20k / 14k points, one of them with fewer points than a dense frame): the per-frame FPS
+    path, the padded per-frame point views of the post-processing and the stacked ops all see ragged offsets"""
+    from pcdet.datasets.synthetic import kitti_frame
+    from pcdet.models.detectors.post_processing import crb_frame_records
+    from pcdet.query_strategies import scoring
+    sizes = [9000, 20000, 14000]
+    frames = [kitti_frame(60 + i, n) for i, n in enumerate(sizes)]
+    pts = np.concatenate([f[0] for f in frames]).astype(np.float32)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    G = max(len(f[1]) for f in frames)
+    gt = np.zeros((3, G, 8), np.float32)
+    for i, f in enumerate(frames):
+        gt[i, :len(f[1])] = f[1]
+    bidx = np.repeat(np.arange(3, dtype=np.float32), sizes)
+    base = {'points': torch.from_numpy(np.concatenate([bidx[:, None], pts], 1)).to(dev),
+            'point_frame_offsets': torch.from_numpy(off).to(dev), 'gt_boxes': torch.from_numpy(gt).to(dev),
+            'batch_size': 3, 'point_frame_counts_host': sizes}
+    model.train()
+    ret, tb, _ = model(dict(base))
+    assert torch.isfinite(ret['loss'])
+    model.zero_grad(set_to_none=True)
+    ret['loss'].backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    model.eval()
+    for m in model.modules():
+        if m.__class__.__name__.startswith('Dropout'):
+            m.train()
+    with torch.no_grad():
+        b = dict(base)
+        model.pfe.prefetch_keypoints(b)
+        for mod in model.module_list:
+            b = mod(b)
+        kp = b['point_coords']
+        assert kp.shape == (3 * 2048, 4)
+        # keypoints of frame k are points of frame k (FPS ran per frame on the ragged segments)
+        for k in range(3):
+            seg = base['points'][off[k]:off[k + 1], 1:4]
+            kk = kp[kp[:, 0] == k][:, 1:4]
+            assert kk.shape[0] == 2048
+            assert bool((kk[:64, None, :] == seg[None, :, :]).all(-1).any(1).all())
+        rows = scoring.pack_records(crb_frame_records(model, b))
+    assert rows.shape == (3, scoring.REC_STRIDE) and torch.isfinite(rows).all()
