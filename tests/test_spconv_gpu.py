@@ -153,6 +153,28 @@ def test_full_size_linearity_and_adjoint_identity(dev, level, cin, cout):
     assert torch.equal(y_nat, y1.detach())          # same per-row arithmetic, only the row -> workgroup map differs
 
 
+def test_conv_results_are_bitwise_reproducible(dev):
+    """forward, dgrad and wgrad twice on fresh rulebooks of the same input: bit-identical. (The heaviest-first tile order is
+    built with atomics and may differ between the two rulebooks; per-row arithmetic does not depend on it. wgrad partials are
+    reduced by a fixed plan and a fixed-shape tree.)"""
+    from crbhip import sparse
+    rng = np.random.default_rng(11)
+    shape = [21, 200, 176]
+    coords = _t(random_sparse_coords(rng, 40000, 4, shape), dev)
+    outs = []
+    for _ in range(2):
+        rb = sparse.subm_rulebook(coords, shape, [3, 3, 3])
+        g = torch.Generator(device=dev).manual_seed(5)
+        x = torch.randn(rb.n_out, 64, device=dev, generator=g).requires_grad_(True)
+        w = (torch.randn(27, 64, 64, device=dev, generator=g) / 8).requires_grad_(True)
+        dy = torch.randn(rb.n_out, 64, device=dev, generator=g)
+        y = sparse.sparse_conv(x, w, rb)
+        y.backward(dy)
+        outs.append((y.detach().clone(), x.grad.clone(), w.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_dense_scatter_and_backward(dev):
     from crbhip import sparse
     rng = np.random.default_rng(5)
