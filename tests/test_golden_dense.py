@@ -147,3 +147,34 @@ def test_bev_backbone_eval_folding_equals_module_path():
         a = m({'spatial_features': x})['spatial_features_2d']
     b = m({'spatial_features': x})['spatial_features_2d']          # grad enabled -> module path
     np.testing.assert_allclose(a.numpy(), b.detach().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_fused_head_convs_equal_three_convs():
+    """AnchorHeadSingle: one conv over the concatenated cls/box/dir filters == the three module convs, outputs and grads"""
+    from pcdet.models.dense_heads import anchor_head_single as A
+    from pcdet.models.dense_heads import AnchorHeadSingle
+    from pcdet.model_cfgs import second_cfg
+    torch.manual_seed(0)
+    cfg = second_cfg('kitti').MODEL.DENSE_HEAD
+    head = AnchorHeadSingle(cfg, input_channels=32, num_class=3, class_names=['Car', 'Pedestrian', 'Cyclist'],
+                            grid_size=np.array([176 * 8, 200 * 8, 40]), point_cloud_range=np.array([0, -40, -3, 70.4, 40, 1.0]),
+                            predict_boxes_when_training=False)
+    head.eval()
+    x1 = torch.randn(2, 32, 200, 176, requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    outs = []
+    for flag, x in ((True, x1), (False, x2)):
+        A.FUSED_HEAD_CONVS = flag
+        head.zero_grad()
+        d = head({'spatial_features_2d': x, 'batch_size': 2})
+        r = head.forward_ret_dict
+        loss = r['cls_preds'].square().sum() + r['box_preds'].sum() * 0.5 + r['dir_cls_preds'].abs().sum()
+        loss.backward()
+        outs.append(([r[k].detach().clone() for k in ('cls_preds', 'box_preds', 'dir_cls_preds')], x.grad.clone(),
+                     [p.grad.clone() for p in head.parameters()]))
+    A.FUSED_HEAD_CONVS = True
+    for a, b in zip(outs[0][0], outs[1][0]):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-5)
+    for a, b in zip(outs[0][2], outs[1][2]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-3)
