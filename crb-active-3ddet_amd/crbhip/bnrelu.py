@@ -27,7 +27,7 @@ class _BNReLUTrain(torch.autograd.Function):
         wsb = lib.crb_bn_workspace_bytes(n, C)
         ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
         g, b = gamma.contiguous().float(), beta.contiguous().float()
-        check(lib.crb_bn_relu_forward(ptr(x), n, C, ptr(g), ptr(b), float(eps), int(relu), ptr(z), ptr(mean), ptr(var),
+        check(lib.crb_bn_relu_forward(ptr(x), n, C, ptr(g), ptr(b), float(eps), int(relu), ptr(z), 0, ptr(mean), ptr(var),
                                       ptr(invstd), ptr(running_mean), ptr(running_var), float(momentum), ptr(ws), wsb,
                                       cur_stream(dev)), 'crb_bn_relu_forward')
         ctx.save_for_backward(x, mean, invstd, g, b)
@@ -46,7 +46,7 @@ class _BNReLUTrain(torch.autograd.Function):
         dbeta = torch.empty_like(dgamma)
         wsb = lib.crb_bn_workspace_bytes(n, C)
         ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
-        check(lib.crb_bn_relu_backward(ptr(x), ptr(dz), n, C, ptr(mean), ptr(invstd), ptr(g), ptr(b), ctx.relu, ptr(dx),
+        check(lib.crb_bn_relu_backward(ptr(x), ptr(dz), 0, n, C, ptr(mean), ptr(invstd), ptr(g), ptr(b), ctx.relu, ptr(dx),
                                        ptr(dgamma), ptr(dbeta), ptr(ws), wsb, cur_stream(dev)), 'crb_bn_relu_backward')
         return dx, dgamma, dbeta, None, None, None, None, None
 
@@ -91,3 +91,72 @@ def bn_apply_(x, bn, relu=True):
     check(lib.crb_bn_relu_apply(ptr(x), n, C, ptr(bn.running_mean.contiguous()), ptr(invstd), ptr(bn.weight.contiguous()),
                                 ptr(bn.bias.contiguous()), int(relu), ptr(x), cur_stream(x.device)), 'crb_bn_relu_apply')
     return x
+
+
+class _BNReLUConcatTrain(torch.autograd.Function):
+    """training BatchNorm+ReLU of several (n, C_i) row matrices written side by side into ONE (n, sum C_i) matrix — the
+    torch.cat of the BEV backbone's up-sampled branches (base_bev_backbone.py:100-104) without the copy: every branch's
+    apply kernel writes its channel slice (row stride sum C_i), the backward reads the slices of the incoming gradient in
+    place. Arguments: relu, then (x, gamma, beta, eps, running_mean, running_var, momentum) per branch."""
+
+    @staticmethod
+    def forward(ctx, relu, *args):
+        import ctypes
+        k = len(args) // 7
+        xs = [args[7 * i].contiguous() for i in range(k)]
+        n, dev = xs[0].shape[0], xs[0].device
+        widths = [x.shape[1] for x in xs]
+        total = sum(widths)
+        out = torch.empty((n, total), dtype=torch.float32, device=dev)
+        saved, col = [], 0
+        for i, x in enumerate(xs):
+            gamma, beta, eps, rm, rv, mom = args[7 * i + 1:7 * i + 7]
+            C = widths[i]
+            mean = torch.empty((C,), dtype=torch.float32, device=dev)
+            var, invstd = torch.empty_like(mean), torch.empty_like(mean)
+            wsb = lib.crb_bn_workspace_bytes(n, C)
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+            g, b = gamma.contiguous().float(), beta.contiguous().float()
+            zptr = ctypes.c_void_p(out.data_ptr() + 4 * col)
+            check(lib.crb_bn_relu_forward(ptr(x), n, C, ptr(g), ptr(b), float(eps), int(relu), zptr, total, ptr(mean),
+                                          ptr(var), ptr(invstd), ptr(rm), ptr(rv), float(mom), ptr(ws), wsb,
+                                          cur_stream(dev)), 'crb_bn_relu_forward')
+            saved += [x, mean, invstd, g, b]
+            col += C
+        ctx.save_for_backward(*saved)
+        ctx.relu, ctx.widths = int(relu), widths
+        return out
+
+    @staticmethod
+    def backward(ctx, dz):
+        import ctypes
+        dz = dz.contiguous().float()
+        n, total = dz.shape
+        saved = ctx.saved_tensors
+        grads, col = [None], 0
+        for i, C in enumerate(ctx.widths):
+            x, mean, invstd, g, b = saved[5 * i:5 * i + 5]
+            dev = x.device
+            dx = torch.empty_like(x)
+            dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+            dbeta = torch.empty_like(dgamma)
+            wsb = lib.crb_bn_workspace_bytes(n, C)
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+            dzp = ctypes.c_void_p(dz.data_ptr() + 4 * col)
+            check(lib.crb_bn_relu_backward(ptr(x), dzp, total, n, C, ptr(mean), ptr(invstd), ptr(g), ptr(b), ctx.relu,
+                                           ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), wsb, cur_stream(dev)),
+                  'crb_bn_relu_backward')
+            grads += [dx, dgamma, dbeta, None, None, None, None]
+            col += C
+        return tuple(grads)
+
+
+def bn_relu_concat(xs, bns, relu=True):
+    """training-mode relu(bn_i(x_i)) for row matrices x_i (n, C_i), concatenated along the channel axis -> (n, sum C_i).
+    Every bn must be in training mode with a momentum (running statistics are updated in the forward launch)."""
+    args = []
+    for x, bn in zip(xs, bns):
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+        args += [x, bn.weight, bn.bias, bn.eps, bn.running_mean, bn.running_var, float(bn.momentum)]
+    return _BNReLUConcatTrain.apply(relu, *args)

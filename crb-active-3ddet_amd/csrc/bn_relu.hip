@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          int64_t n, int C, int relu, int rows_per_block,
-                                                         float* __restrict__ partial) {
+                                                         int64_t ld_dz, float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f4* red = reinterpret_cast<f4*>(smem);               // 2 * 256 f4
   const int c4n = C >> 2;                              // float4 columns
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
         b += v * v;
       } else {
         const f4 xh = (v - mu) * is;
-        f4 d = *reinterpret_cast<const f4*>(dz + r * C + tc * 4);
+        f4 d = *reinterpret_cast<const f4*>(dz + r * ld_dz + tc * 4);
         if (relu) {
           const f4 z = ga * xh + be;
 #pragma unroll
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ z, int64_t total4,
-                                                       int C, int relu) {
+                                                       int C, int relu, int64_t ld_z) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= total4) return;
   const int c = (int)((t * 4) % C);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = o[k] > 0.f ? o[k] : 0.f;
   }
-  *reinterpret_cast<f4*>(z + t * 4) = o;
+  *reinterpret_cast<f4*>(z + ((t * 4) / C) * ld_z + c) = o;      // ld_z == C: the dense case
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dz,
@@ -136,12 +136,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ dbeta, const float* __restrict__ dgamma,
                                                            float* __restrict__ dx, int64_t total4, int C, float inv_n,
-                                                           int relu) {
+                                                           int relu, int64_t ld_dz) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= total4) return;
   const int c = (int)((t * 4) % C);
   const f4 v = *reinterpret_cast<const f4*>(x + t * 4);
-  f4 d = *reinterpret_cast<const f4*>(dz + t * 4);
+  f4 d = *reinterpret_cast<const f4*>(dz + ((t * 4) / C) * ld_dz + c);
   const f4 mu = *reinterpret_cast<const f4*>(mean + c), is = *reinterpret_cast<const f4*>(invstd + c);
   const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
   const f4 db = *reinterpret_cast<const f4*>(dbeta + c), dg = *reinterpret_cast<const f4*>(dgamma + c);
@@ -162,21 +162,23 @@ extern "C" int64_t crb_bn_workspace_bytes(int64_t n, int C) { return (int64_t)bn
 
 // training forward. mean/var/invstd (C) out. z may alias x? no: x is kept for backward.
 extern "C" int crb_bn_relu_forward(const float* x, int64_t n, int C, const float* gamma, const float* beta, float eps,
-                                   int relu, float* z, float* mean, float* var, float* invstd, float* running_mean,
-                                   float* running_var, float momentum, void* workspace, int64_t workspace_bytes,
-                                   void* stream) {
+                                   int relu, float* z, int64_t z_row_stride, float* mean, float* var, float* invstd,
+                                   float* running_mean, float* running_var, float momentum, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+  const int64_t ld_z = z_row_stride > 0 ? z_row_stride : C;
+  if (ld_z < C || (ld_z & 3)) return CRB_ERR_ARG;
   if (n <= 0 || C <= 0 || (C & 3) || C > 1024 || (256 % (C >> 2) && (C >> 2) < 256)) return CRB_ERR_ARG;
   if (workspace_bytes < crb_bn_workspace_bytes(n, C) - 256 || !workspace) return CRB_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = bn_blocks(n);
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(nblk), dim3(256), 2 * 256 * 16, st, x, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, n, C, relu, bn_rows_per_block(n), partial);
+                     nullptr, nullptr, n, C, relu, bn_rows_per_block(n), (int64_t)C, partial);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, eps, 0, mean, var,
                      invstd, running_mean, running_var, momentum);
   const int64_t total4 = n * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, z,
-                     total4, C, relu);
+                     total4, C, relu, ld_z);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
@@ -188,26 +190,28 @@ extern "C" int crb_bn_relu_apply(const float* x, int64_t n, int C, const float* 
   if (n == 0) return CRB_OK;
   const int64_t total4 = n * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd,
-                     gamma, beta, z, total4, C, relu);
+                     gamma, beta, z, total4, C, relu, (int64_t)C);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
 
-extern "C" int crb_bn_relu_backward(const float* x, const float* dz, int64_t n, int C, const float* mean,
+extern "C" int crb_bn_relu_backward(const float* x, const float* dz, int64_t dz_row_stride, int64_t n, int C, const float* mean,
                                     const float* invstd, const float* gamma, const float* beta, int relu, float* dx,
                                     float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, void* stream) {
   if (n <= 0 || C <= 0 || (C & 3) || C > 1024 || (256 % (C >> 2) && (C >> 2) < 256)) return CRB_ERR_ARG;
   if (workspace_bytes < crb_bn_workspace_bytes(n, C) - 256 || !workspace) return CRB_ERR_WORKSPACE;
+  const int64_t ld_dz = dz_row_stride > 0 ? dz_row_stride : C;
+  if (ld_dz < C || (ld_dz & 3)) return CRB_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = bn_blocks(n);
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(bn_partial_kernel<true>, dim3(nblk), dim3(256), 2 * 256 * 16, st, x, dz, mean, invstd, gamma, beta, n,
-                     C, relu, bn_rows_per_block(n), partial);
+                     C, relu, bn_rows_per_block(n), ld_dz, partial);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, 0.f, 1, dbeta, dgamma,
                      (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f);
   const int64_t total4 = n * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, dz, mean, invstd, gamma, beta,
-                     dbeta, dgamma, dx, total4, C, 1.0f / (float)n, relu);
+                     dbeta, dgamma, dx, total4, C, 1.0f / (float)n, relu, ld_dz);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

@@ -113,6 +113,19 @@ class BaseBEVBackbone(nn.Module):
                 i += 1
         return x
 
+    def _can_fuse_concat(self, x):
+        """training + channels_last + every up-sampling branch is [conv, BatchNorm2d(train, momentum), ReLU] with a channel
+        count the row kernels take, and there is no extra deblock after the concat"""
+        if not self.training or len(self.deblocks) != len(self.blocks) or len(self.deblocks) < 2:
+            return False
+        for d in self.deblocks:
+            m = list(d)
+            if len(m) != 3 or not isinstance(m[1], nn.BatchNorm2d) or not isinstance(m[2], nn.ReLU) or \
+                    not m[1].training or m[1].momentum is None or \
+                    not bnrelu.supported(x.new_empty((2, m[1].num_features)), m[1]):
+                return False
+        return x.is_contiguous(memory_format=torch.channels_last)
+
     def forward(self, data_dict):
         spatial_features = data_dict['spatial_features']
         ups = []
@@ -128,11 +141,24 @@ class BaseBEVBackbone(nn.Module):
             return data_dict
         run = self._run_rows_train if (ROWS_TRAIN and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last)) \
             else (lambda seq, t: seq(t))
+        fuse_cat = ROWS_TRAIN and x.is_cuda and self._can_fuse_concat(x)
+        pre = []                                         # deblock conv outputs awaiting their joint BN+ReLU+concat
         for i, blk in enumerate(self.blocks):
             x = run(blk, x)
             stride = int(spatial_features.shape[2] / x.shape[2])
             data_dict['spatial_features_%dx' % stride] = x
-            ups.append(run(self.deblocks[i], x) if len(self.deblocks) > 0 else x)
+            if fuse_cat:
+                pre.append(self.deblocks[i][0](x))       # ConvTranspose2d / Conv2d only
+            else:
+                ups.append(run(self.deblocks[i], x) if len(self.deblocks) > 0 else x)
+        if fuse_cat and all(p.is_contiguous(memory_format=torch.channels_last) and p.shape[2:] == pre[0].shape[2:]
+                            for p in pre):
+            n, _, h, w_ = pre[0].shape
+            rows = [p.permute(0, 2, 3, 1).reshape(n * h * w_, p.shape[1]) for p in pre]
+            cat = bnrelu.bn_relu_concat(rows, [d[1] for d in self.deblocks[:len(pre)]], relu=True)
+            ups = [cat.view(n, h, w_, cat.shape[1]).permute(0, 3, 1, 2)]
+        elif fuse_cat:
+            ups = [d[2](d[1](p)) for d, p in zip(self.deblocks, pre)]
         x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
         if len(self.deblocks) > len(self.blocks):
             x = self.deblocks[-1](x)

@@ -274,11 +274,15 @@ int crb_density_greedy(const float* densities, const int32_t* labels, int n_cand
  * ---------------------------------------------------------------------------------------------- */
 int64_t crb_bn_workspace_bytes(int64_t n, int C);
 int crb_bn_relu_forward(const float* x, int64_t n, int C, const float* gamma, const float* beta, float eps,
-                        int relu, float* z, float* mean, float* var, float* invstd, float* running_mean,
-                        float* running_var, float momentum, void* workspace, int64_t workspace_bytes, void* stream);
+                        int relu, float* z, int64_t z_row_stride, float* mean, float* var, float* invstd,
+                        float* running_mean, float* running_var, float momentum, void* workspace,
+                        int64_t workspace_bytes, void* stream);
 int crb_bn_relu_apply(const float* x, int64_t n, int C, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int relu, float* z, void* stream);
-int crb_bn_relu_backward(const float* x, const float* dz, int64_t n, int C, const float* mean,
+/* z_row_stride / dz_row_stride (floats, 0 = C): z may be a channel slice of a wider row-major buffer (the BEV backbone
+ * writes its two up-sampled branches straight into the concatenated (N*H*W, 512) map, and their backward reads the matching
+ * slices of its gradient: no torch.cat copy, no .contiguous() copies of the gradient slices). */
+int crb_bn_relu_backward(const float* x, const float* dz, int64_t dz_row_stride, int64_t n, int C, const float* mean,
                          const float* invstd, const float* gamma, const float* beta, int relu, float* dx,
                          float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, void* stream);
 
