@@ -62,12 +62,18 @@ class BaseBEVBackbone(nn.Module):
         i = 0
         while i < len(mods):
             m = mods[i]
+            pad = None                                   # ZeroPad2d(p) + Conv2d(padding=0) -> Conv2d(padding=p), no padded copy
+            if isinstance(m, nn.ZeroPad2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.Conv2d):
+                c, pd = mods[i + 1], m.padding
+                if c.padding == (0, 0) and c.padding_mode == 'zeros' and pd[0] == pd[1] and pd[2] == pd[3]:
+                    pad, i, m = (pd[2], pd[0]), i + 1, c
             if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
                 bn = mods[i + 1]
                 relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
                 rows_ok = x.is_cuda and x.is_contiguous(memory_format=torch.channels_last) and m.bias is None
                 if rows_ok:
-                    y = m(x)
+                    y = m(x) if pad is None else torch.nn.functional.conv2d(x, m.weight, None, m.stride, pad, m.dilation,
+                                                                             m.groups)
                     rows_ok = y.is_contiguous(memory_format=torch.channels_last) and \
                         bnrelu.supported(y.new_empty((2, y.shape[1])), bn)
                 if rows_ok:
@@ -78,7 +84,8 @@ class BaseBEVBackbone(nn.Module):
                 else:
                     w, shift = fold_conv_bn(m, bn)
                     if isinstance(m, nn.Conv2d):
-                        x = torch.nn.functional.conv2d(x, w, shift, m.stride, m.padding, m.dilation, m.groups)
+                        x = torch.nn.functional.conv2d(x, w, shift, m.stride, m.padding if pad is None else pad, m.dilation,
+                                                       m.groups)
                     else:
                         x = torch.nn.functional.conv_transpose2d(x, w, shift, m.stride, m.padding, m.output_padding,
                                                                  m.groups, m.dilation)
@@ -86,9 +93,21 @@ class BaseBEVBackbone(nn.Module):
                         x = torch.relu_(x)
                 i += 3 if relu else 2
             else:
-                x = m(x)
+                x = m(x) if pad is None else torch.nn.functional.conv2d(x, m.weight, m.bias, m.stride, pad, m.dilation, m.groups)
                 i += 1
         return x
+
+    @staticmethod
+    def _pad_conv(mods, i, x):
+        """ZeroPad2d(p) followed by Conv2d(padding=0) == the same conv with padding=p: the explicit pad makes a padded copy of
+        the (B,256,200,176) map (and a slice copy in backward). -> (output, modules consumed) or (None, 0)"""
+        m = mods[i]
+        if isinstance(m, nn.ZeroPad2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.Conv2d):
+            c = mods[i + 1]
+            pd = m.padding
+            if c.padding == (0, 0) and c.padding_mode == 'zeros' and pd[0] == pd[1] and pd[2] == pd[3]:
+                return torch.nn.functional.conv2d(x, c.weight, c.bias, c.stride, (pd[2], pd[0]), c.dilation, c.groups), 2
+        return None, 0
 
     @staticmethod
     def _run_rows_train(seq, x):
@@ -101,6 +120,10 @@ class BaseBEVBackbone(nn.Module):
         while i < len(mods):
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < len(mods) else None
+            y, used = BaseBEVBackbone._pad_conv(mods, i, x)
+            if used:
+                x, i = y, i + used
+                continue
             if isinstance(m, nn.BatchNorm2d) and isinstance(nxt, nn.ReLU) and \
                     x.is_contiguous(memory_format=torch.channels_last) and \
                     bnrelu.supported(x.new_empty((2, x.shape[1])), m):
