@@ -77,7 +77,7 @@ def bn_relu(x, bn, relu=True):
     invstd = torch.rsqrt(bn.running_var + bn.eps)
     z = torch.empty_like(x)
     check(lib.crb_bn_relu_apply(ptr(x), n, C, ptr(bn.running_mean.contiguous()), ptr(invstd), ptr(bn.weight.contiguous()),
-                                ptr(bn.bias.contiguous()), int(relu), ptr(z), cur_stream(x.device)), 'crb_bn_relu_apply')
+                                ptr(bn.bias.contiguous()), int(relu), ptr(z), 0, cur_stream(x.device)), 'crb_bn_relu_apply')
     return z
 
 
@@ -89,8 +89,22 @@ def bn_apply_(x, bn, relu=True):
     assert x.is_contiguous()
     invstd = torch.rsqrt(bn.running_var + bn.eps)
     check(lib.crb_bn_relu_apply(ptr(x), n, C, ptr(bn.running_mean.contiguous()), ptr(invstd), ptr(bn.weight.contiguous()),
-                                ptr(bn.bias.contiguous()), int(relu), ptr(x), cur_stream(x.device)), 'crb_bn_relu_apply')
+                                ptr(bn.bias.contiguous()), int(relu), ptr(x), 0, cur_stream(x.device)), 'crb_bn_relu_apply')
     return x
+
+
+@torch.no_grad()
+def bn_apply_into(x, bn, relu, out, col):
+    """inference BatchNorm(+ReLU) of (N, C) rows written into columns [col, col+C) of the row-major (N, W) buffer `out`"""
+    import ctypes
+    require_cuda(x, out)
+    n, C = x.shape
+    assert x.is_contiguous() and out.is_contiguous() and out.shape[0] == n and col + C <= out.shape[1]
+    invstd = torch.rsqrt(bn.running_var + bn.eps)
+    check(lib.crb_bn_relu_apply(ptr(x), n, C, ptr(bn.running_mean.contiguous()), ptr(invstd), ptr(bn.weight.contiguous()),
+                                ptr(bn.bias.contiguous()), int(relu), ctypes.c_void_p(out.data_ptr() + 4 * col),
+                                out.shape[1], cur_stream(x.device)), 'crb_bn_relu_apply')
+    return out
 
 
 class _BNReLUConcatTrain(torch.autograd.Function):

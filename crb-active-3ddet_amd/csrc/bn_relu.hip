@@ -185,12 +185,15 @@ extern "C" int crb_bn_relu_forward(const float* x, int64_t n, int C, const float
 
 // inference forward with given statistics (mean, invstd)
 extern "C" int crb_bn_relu_apply(const float* x, int64_t n, int C, const float* mean, const float* invstd,
-                                 const float* gamma, const float* beta, int relu, float* z, void* stream) {
+                                 const float* gamma, const float* beta, int relu, float* z, int64_t z_row_stride,
+                                 void* stream) {
   if (n < 0 || C <= 0 || (C & 3)) return CRB_ERR_ARG;
+  const int64_t ld_z = z_row_stride > 0 ? z_row_stride : C;
+  if (ld_z < C || (ld_z & 3)) return CRB_ERR_ARG;
   if (n == 0) return CRB_OK;
   const int64_t total4 = n * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd,
-                     gamma, beta, z, total4, C, relu, (int64_t)C);
+                     gamma, beta, z, total4, C, relu, ld_z);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

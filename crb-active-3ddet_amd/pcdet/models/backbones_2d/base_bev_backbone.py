@@ -136,6 +136,16 @@ class BaseBEVBackbone(nn.Module):
                 i += 1
         return x
 
+    def _can_fuse_concat_eval(self, x):
+        if len(self.deblocks) != len(self.blocks) or len(self.deblocks) < 2:
+            return False
+        for d in self.deblocks:
+            m = list(d)
+            if len(m) != 3 or not isinstance(m[1], nn.BatchNorm2d) or not isinstance(m[2], nn.ReLU) or m[0].bias is not None \
+                    or not bnrelu.supported(x.new_empty((2, m[1].num_features)), m[1]):
+                return False
+        return True
+
     def _can_fuse_concat(self, x):
         """training + channels_last + every up-sampling branch is [conv, BatchNorm2d(train, momentum), ReLU] with a channel
         count the row kernels take, and there is no extra deblock after the concat"""
@@ -154,9 +164,26 @@ class BaseBEVBackbone(nn.Module):
         ups = []
         x = spatial_features
         if not self.training and not torch.is_grad_enabled():
+            cat_ok = x.is_cuda and x.is_contiguous(memory_format=torch.channels_last) and self._can_fuse_concat_eval(x)
+            pre = []
             for i, blk in enumerate(self.blocks):
                 x = self._run_folded(blk, x)
-                ups.append(self._run_folded(self.deblocks[i], x) if len(self.deblocks) > 0 else x)
+                if cat_ok:
+                    pre.append(self.deblocks[i][0](x))
+                else:
+                    ups.append(self._run_folded(self.deblocks[i], x) if len(self.deblocks) > 0 else x)
+            if cat_ok and all(p.is_contiguous(memory_format=torch.channels_last) and p.shape[2:] == pre[0].shape[2:]
+                              for p in pre):
+                # the up-sampled branches' BN+ReLU write their channel slices of the concatenated map directly
+                n, _, h, w_ = pre[0].shape
+                cat = torch.empty((n * h * w_, sum(p.shape[1] for p in pre)), dtype=torch.float32, device=x.device)
+                col = 0
+                for d, p in zip(self.deblocks, pre):
+                    bnrelu.bn_apply_into(p.permute(0, 2, 3, 1).reshape(n * h * w_, p.shape[1]), d[1], True, cat, col)
+                    col += p.shape[1]
+                ups = [cat.view(n, h, w_, cat.shape[1]).permute(0, 3, 1, 2)]
+            elif cat_ok:
+                ups = [self._run_folded(nn.Sequential(*list(d)[1:]), p) for d, p in zip(self.deblocks, pre)]
             x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
             if len(self.deblocks) > len(self.blocks):
                 x = self._run_folded(self.deblocks[-1], x)

@@ -278,7 +278,7 @@ int crb_bn_relu_forward(const float* x, int64_t n, int C, const float* gamma, co
                         float* running_mean, float* running_var, float momentum, void* workspace,
                         int64_t workspace_bytes, void* stream);
 int crb_bn_relu_apply(const float* x, int64_t n, int C, const float* mean, const float* invstd,
-                      const float* gamma, const float* beta, int relu, float* z, void* stream);
+                      const float* gamma, const float* beta, int relu, float* z, int64_t z_row_stride, void* stream);
 /* z_row_stride / dz_row_stride (floats, 0 = C): z may be a channel slice of a wider row-major buffer (the BEV backbone
  * writes its two up-sampled branches straight into the concatenated (N*H*W, 512) map, and their backward reads the matching
  * slices of its gradient: no torch.cat copy, no .contiguous() copies of the gradient slices). */
