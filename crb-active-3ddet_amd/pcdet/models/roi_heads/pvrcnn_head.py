@@ -9,6 +9,20 @@ from ...utils.fold_utils import fold_conv_bn
 from .roi_head_template import RoIHeadTemplate
 
 
+_GC_ORDER = {}
+
+
+def _gc_order(c, g3):
+    """fold_conv_bn transform: first FC weight (256, C*G^3, 1) from (c*G^3 + g) to (g*C + c) column order"""
+    key = (c, g3)
+    if key not in _GC_ORDER:
+        def gc_order(w, b, c=c, g3=g3):
+            return w.reshape(w.shape[0], c, g3).permute(0, 2, 1).reshape(w.shape[0], g3 * c).contiguous(), b.contiguous()
+        gc_order.__name__ = 'gc_order_%d_%d' % key
+        _GC_ORDER[key] = gc_order
+    return _GC_ORDER[key]
+
+
 class PVRCNNHead(RoIHeadTemplate):
     def __init__(self, input_channels, model_cfg, num_class=1, **kwargs):
         super().__init__(num_class=num_class, model_cfg=model_cfg)
@@ -100,20 +114,30 @@ class PVRCNNHead(RoIHeadTemplate):
                 i += 1
         return x
 
-    def _heads_eval(self, pooled_flat, rounds):
-        """MC-dropout passes of pvrcnn_head.py:187-202. Everything before the first Dropout of shared_fc_layer is
-        deterministic in eval mode, so the 27648->256 layer (7 M MACs per RoI) runs once instead of `rounds` times."""
+    def _heads_eval(self, pooled, rounds):
+        """MC-dropout passes of pvrcnn_head.py:187-202 on pooled (BN, G^3, C) features.
+        * Everything before the first Dropout of shared_fc_layer is deterministic in eval mode, so the 27648->256 layer
+          (7 M MACs per RoI) runs once instead of `rounds` times. Its weight is re-ordered once (cached) from the reference's
+          channel-major flattening (c*G^3 + g) to the pooled tensor's own (g*C + c) order: no permute().contiguous() copy of
+          the 226 MB pooled tensor.
+        * The `rounds` passes only differ by their dropout masks: they run as ONE batch of rounds*BN rows through the
+          remaining layers (independent masks per row and element, as in `rounds` separate calls)."""
         mods = list(self.shared_fc_layer)
         first_dp = next((k for k, m in enumerate(mods) if isinstance(m, nn.Dropout)), len(mods))
-        prefix = self._run_folded(mods[:first_dp], pooled_flat)
-        cls_l, reg_l = list(self.cls_layers), list(self.reg_layers)
-        out = []
-        for _ in range(max(1, rounds)):
-            shared = self._run_folded(mods[first_dp:], prefix)
-            rcnn_cls = self._run_folded(cls_l, shared).transpose(1, 2).contiguous().squeeze(dim=1)
-            rcnn_reg = self._run_folded(reg_l, shared).transpose(1, 2).contiguous().squeeze(dim=1)
-            out.append((shared, rcnn_cls, rcnn_reg))
-        return out
+        n, g3, c = pooled.shape
+        conv0, bn0 = mods[0], mods[1]
+        if isinstance(conv0, nn.Conv1d) and isinstance(bn0, nn.BatchNorm1d) and conv0.in_channels == g3 * c:
+            w0, b0 = fold_conv_bn(conv0, bn0, _gc_order(c, g3))
+            x = torch.addmm(b0, pooled.reshape(n, g3 * c), w0.t()).unsqueeze(-1)           # (BN, 256, 1)
+            prefix = self._run_folded(mods[2:first_dp], x)
+        else:
+            prefix = self._run_folded(mods[:first_dp], pooled.permute(0, 2, 1).contiguous().view(n, -1, 1))
+        r = max(1, rounds)
+        stacked = prefix.repeat(r, 1, 1) if r > 1 else prefix                             # (r*BN, 256, 1)
+        shared = self._run_folded(mods[first_dp:], stacked)
+        rcnn_cls = self._run_folded(list(self.cls_layers), shared).transpose(1, 2).contiguous().squeeze(dim=1)
+        rcnn_reg = self._run_folded(list(self.reg_layers), shared).transpose(1, 2).contiguous().squeeze(dim=1)
+        return [(shared[k * n:(k + 1) * n], rcnn_cls[k * n:(k + 1) * n], rcnn_reg[k * n:(k + 1) * n]) for k in range(r)]
 
     def forward(self, batch_dict):
         targets_dict = self.proposal_layer(batch_dict,
@@ -131,7 +155,7 @@ class PVRCNNHead(RoIHeadTemplate):
             not any(m.training for m in self.modules() if isinstance(m, nn.BatchNorm1d))
         if fast:
             rounds = self.model_cfg.get('SAMPLING_ROUND', None) or 1
-            passes = self._heads_eval(pooled_flat, rounds)
+            passes = self._heads_eval(pooled, rounds)
             shared, rcnn_cls, rcnn_reg = passes[-1]
         else:
             shared, rcnn_cls, rcnn_reg = self._heads(pooled_flat)

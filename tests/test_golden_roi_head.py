@@ -126,7 +126,8 @@ def test_roi_subsampling_rule():
 
 
 def test_eval_fast_path_equals_module_path(head):
-    """folded Conv1d+BN and the once-only first FC layer give the same logits as the plain module path (dropout off)"""
+    """folded Conv1d+BN, the once-only first FC layer on the un-permuted pooled tensor (re-ordered weight) and the MC passes
+    batched as rows give the same logits as the plain module path (dropout off)"""
     g = np.load(G)
     sd = {k[len('fc_state/'):]: _t(g[k]) for k in g.files if k.startswith('fc_state/')}
     head.load_state_dict(sd, strict=False)
@@ -134,7 +135,7 @@ def test_eval_fast_path_equals_module_path(head):
     pooled = _t(g['fc_pooled'])
     flat = pooled.permute(0, 2, 1).contiguous().view(pooled.shape[0], -1, 1)
     with torch.no_grad():
-        passes = head._heads_eval(flat, 3)
+        passes = head._heads_eval(pooled, 3)             # takes the pooled (BN, G^3, C) tensor itself
         _, cls, reg = head._heads(flat)
     for _, c, r in passes:
         np.testing.assert_allclose(c.numpy(), cls.numpy(), rtol=1e-4, atol=1e-5)
