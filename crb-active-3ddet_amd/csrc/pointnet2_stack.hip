@@ -359,6 +359,123 @@ __global__ __launch_bounds__(256) void query_group_rows_grad_kernel(int B, int64
   }
 }
 
+// First shared-MLP layer of the training path without the grouped matrix. A bias-free 1x1 conv on [xyz_j - c_i ; f_j] is
+//   y[p] = W1x (xyz_j - c_i) + (F W1f^T)[j]:  P = F W1f^T is one small GEMM over the N source points (caller), and this kernel
+// gathers P rows and adds the 3-term offset part: the (pairs, 3+C) matrix (3.7 GB at the RoI-grid shape) and the
+// pairs x (3+C) x H GEMM on it are never formed. rel (pairs,3) keeps xyz_j - c_i for the weight gradient.
+__global__ __launch_bounds__(256) void group_affine_rows_kernel(int B, int64_t MP, int H, int ns,
+                                                                const float* __restrict__ xyz, const int* __restrict__ xyz_cnt,
+                                                                const float* __restrict__ P, const float* __restrict__ new_xyz,
+                                                                const int* __restrict__ new_cnt, const int* __restrict__ idx,
+                                                                const unsigned char* __restrict__ empty,
+                                                                const float* __restrict__ W1x /* (3,H) */,
+                                                                float* __restrict__ out, float* __restrict__ rel) {
+  __shared__ int srow[64];
+  __shared__ float sd[64][3];
+  const int64_t p0 = (int64_t)blockIdx.x * 64;
+  if (threadIdx.x < 64) {
+    const int64_t p = p0 + threadIdx.x;
+    int row = -1;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (p < MP) {
+      const int m = (int)(p / ns);
+      if (!empty[m]) {
+        int start;
+        locate_batch(new_cnt, B, m, xyz_cnt, &start);
+        row = start + idx[p];
+        dx = xyz[(int64_t)row * 3 + 0] - new_xyz[(int64_t)m * 3 + 0];
+        dy = xyz[(int64_t)row * 3 + 1] - new_xyz[(int64_t)m * 3 + 1];
+        dz = xyz[(int64_t)row * 3 + 2] - new_xyz[(int64_t)m * 3 + 2];
+      }
+      rel[p * 3 + 0] = dx; rel[p * 3 + 1] = dy; rel[p * 3 + 2] = dz;
+    }
+    srow[threadIdx.x] = row;
+    sd[threadIdx.x][0] = dx; sd[threadIdx.x][1] = dy; sd[threadIdx.x][2] = dz;
+  }
+  __syncthreads();
+  const int npl = (int)min((int64_t)64, MP - p0);
+  float* dst = out + p0 * H;
+  for (int e = threadIdx.x; e < npl * H; e += 256) {
+    const int pl = e / H, c = e - pl * H;
+    const int row = srow[pl];
+    float v = 0.f;                                           // empty ball: the reference zeroes the whole grouped row
+    if (row >= 0) {
+      v = P[(int64_t)row * H + c];
+      v = fmaf(W1x[c], sd[pl][0], v);
+      v = fmaf(W1x[H + c], sd[pl][1], v);
+      v = fmaf(W1x[2 * H + c], sd[pl][2], v);
+    }
+    dst[e] = v;
+  }
+}
+
+// backward of the kernel above: grad_P[row] += dy[p] (in-slab dedupe as query_group_rows_grad_kernel), and this slab's
+// contribution to dW1x, part[blk][d][c] = sum_p rel[p][d] * dy[p][c] (summed over blocks by the caller: deterministic).
+__global__ __launch_bounds__(256) void group_affine_rows_grad_kernel(int B, int64_t MP, int H, int ns,
+                                                                     const int* __restrict__ xyz_cnt,
+                                                                     const int* __restrict__ new_cnt,
+                                                                     const int* __restrict__ idx,
+                                                                     const unsigned char* __restrict__ empty,
+                                                                     const float* __restrict__ rel,
+                                                                     const float* __restrict__ grad_out,
+                                                                     float* __restrict__ grad_P, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* slab = reinterpret_cast<float*>(smem);            // 64 x H
+  __shared__ int srow[64];
+  __shared__ int first[64];
+  __shared__ float sd[64][3];
+  const int64_t p0 = (int64_t)blockIdx.x * 64;
+  if (threadIdx.x < 64) {
+    const int64_t p = p0 + threadIdx.x;
+    int row = -1;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (p < MP) {
+      const int m = (int)(p / ns);
+      if (!empty[m]) {
+        int start;
+        locate_batch(new_cnt, B, m, xyz_cnt, &start);
+        row = start + idx[p];
+        dx = rel[p * 3 + 0]; dy = rel[p * 3 + 1]; dz = rel[p * 3 + 2];
+      }
+    }
+    srow[threadIdx.x] = row;
+    sd[threadIdx.x][0] = dx; sd[threadIdx.x][1] = dy; sd[threadIdx.x][2] = dz;
+  }
+  const int npl = (int)min((int64_t)64, MP - p0);
+  for (int e = threadIdx.x; e < 64 * H; e += 256) {
+    const int pl = e / H;
+    slab[e] = pl < npl ? grad_out[p0 * H + e] : 0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 3 * H; e += 256) {
+    const int d = e / H, c = e - d * H;
+    float acc = 0.f;
+    for (int pl = 0; pl < 64; ++pl) acc = fmaf(sd[pl][d], slab[pl * H + c], acc);     // empty rows carry rel = 0
+    part[(int64_t)blockIdx.x * 3 * H + e] = acc;
+  }
+  if (threadIdx.x < 64) {
+    const int row = srow[threadIdx.x];
+    int f = threadIdx.x;
+    if (row >= 0)
+      for (int q = 0; q < (int)threadIdx.x; ++q)
+        if (srow[q] == row) { f = q; break; }
+    first[threadIdx.x] = f;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256) {
+    for (int pl = 0; pl < 64; ++pl) {
+      const int f = first[pl];
+      if (f != pl) slab[f * H + c] += slab[pl * H + c];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * H; e += 256) {
+    const int pl = e / H, c = e - pl * H;
+    const int row = srow[pl];
+    if (row >= 0 && first[pl] == pl) atomicAdd(&grad_P[(int64_t)row * H + c], slab[e]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ FPS
 // Tie rule of the reference (sampling_gpu.cu:49-139) as a strict total order on candidates k:
 //   larger running distance first; then smaller bit-reversed (k mod bs) (its LDS tree keeps the lower-position operand
@@ -650,6 +767,37 @@ extern "C" int crb_query_group_rows_grad_stack(int B, int64_t M, int C, int nsam
   const int64_t MP = M * nsample;
   hipLaunchKernelGGL(query_group_rows_grad_kernel, dim3(crb_cdiv(MP, 64)), dim3(256), lds, (hipStream_t)stream, B, MP, C,
                      nsample, xyz_batch_cnt, new_xyz_batch_cnt, idx, empty_mask, grad_out, grad_features);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_group_affine_rows_stack(int B, int64_t M, int H, int nsample, const float* xyz,
+                                           const int32_t* xyz_batch_cnt, const float* P, const float* new_xyz,
+                                           const int32_t* new_xyz_batch_cnt, const int32_t* idx,
+                                           const uint8_t* empty_mask, const float* W1x, float* out, float* rel,
+                                           void* stream) {
+  if (B <= 0 || M < 0 || H <= 0 || nsample <= 0) return CRB_ERR_ARG;
+  if (M == 0) return CRB_OK;
+  const int64_t MP = M * nsample;
+  hipLaunchKernelGGL(group_affine_rows_kernel, dim3(crb_cdiv(MP, 64)), dim3(256), 0, (hipStream_t)stream, B, MP, H, nsample,
+                     xyz, xyz_batch_cnt, P, new_xyz, new_xyz_batch_cnt, idx, empty_mask, W1x, out, rel);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int64_t crb_group_affine_rows_grad_blocks(int64_t M, int nsample) { return crb_cdiv(M * nsample, 64); }
+
+extern "C" int crb_group_affine_rows_grad_stack(int B, int64_t M, int H, int nsample, const int32_t* xyz_batch_cnt,
+                                                const int32_t* new_xyz_batch_cnt, const int32_t* idx,
+                                                const uint8_t* empty_mask, const float* rel, const float* grad_out,
+                                                float* grad_P /* pre-zeroed */, float* part, void* stream) {
+  if (B <= 0 || M < 0 || H <= 0 || nsample <= 0) return CRB_ERR_ARG;
+  if (M == 0) return CRB_OK;
+  const size_t lds = sizeof(float) * 64 * H;
+  if (lds > 64 * 1024) return CRB_ERR_UNSUPPORTED;
+  const int64_t MP = M * nsample;
+  hipLaunchKernelGGL(group_affine_rows_grad_kernel, dim3(crb_cdiv(MP, 64)), dim3(256), lds, (hipStream_t)stream, B, MP, H,
+                     nsample, xyz_batch_cnt, new_xyz_batch_cnt, idx, empty_mask, rel, grad_out, grad_P, part);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

@@ -53,6 +53,7 @@ def _transpose_second_layer(w, b):
 
 FUSED_SA_EVAL = True   # inference: group + 2-layer MLP + max in one HIP kernel (crb_sa_mlp2_max_stack)
 ROWS_TRAIN = True      # training: row-major grouped matrix -> GEMM + fused BN/ReLU row kernels -> max (no MIOpen BN2d / transposes)
+SPLIT_FIRST_LAYER = True   # training rows path: layer 1 = gather of per-source-point products + offset term (no grouped matrix)
 FUSED_GROUP = True     # one HIP launch builds the (1, 3+C, M, ns) MLP input (False: QueryAndGroup + permute copy)
 
 
@@ -171,12 +172,19 @@ class StackSAModuleMSG(nn.Module):
             M = new_xyz.shape[0]
             balls = self._balls(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
             for grouper, mlp, ball in zip(self.groupers, self.mlps, balls):
-                x, _ = pointnet2_utils.query_and_group_rows(grouper.radius, grouper.nsample, xyz, xyz_batch_cnt, new_xyz,
-                                                            new_xyz_batch_cnt, features, ball=ball)   # (M*ns, 3+C)
                 mods = list(mlp)
+                split = SPLIT_FIRST_LAYER and mods[0].bias is None and mods[0].out_channels <= 256
+                if not split:
+                    x, _ = pointnet2_utils.query_and_group_rows(grouper.radius, grouper.nsample, xyz, xyz_batch_cnt,
+                                                                new_xyz, new_xyz_batch_cnt, features, ball=ball)   # (M*ns, 3+C)
                 for i in range(0, len(mods), 3):
                     conv, bn = mods[i], mods[i + 1]
-                    x = _LinearRows.apply(x, conv.weight.flatten(1))
+                    if i == 0 and split:
+                        x = pointnet2_utils.grouped_first_layer_rows(grouper.radius, grouper.nsample, xyz, xyz_batch_cnt,
+                                                                     new_xyz, new_xyz_batch_cnt, features,
+                                                                     conv.weight.flatten(1), ball=ball)    # (M*ns, H)
+                    else:
+                        x = _LinearRows.apply(x, conv.weight.flatten(1))
                     if conv.bias is not None:
                         x = x + conv.bias
                     x = bnrelu.bn_relu(x, bn, relu=True)

@@ -174,6 +174,56 @@ def query_and_group_rows(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_b
     return FusedQueryGroupRows.apply(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx, empty), idx
 
 
+class GroupedFirstLayerRows(Function):
+    """y (M*nsample, H) = [xyz[nbr]-new_xyz ; features[nbr]] @ weight^T without forming the grouped matrix: the feature part of
+    the product is taken per SOURCE point (P = features @ W1f^T, N rows) and gathered (crb_group_affine_rows_stack)."""
+
+    @staticmethod
+    def forward(ctx, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx, empty, weight):
+        require_cuda(xyz, new_xyz, features, idx, weight)
+        M, ns = idx.shape
+        H = weight.shape[0]
+        B = xyz_batch_cnt.shape[0]
+        xc, nc = _i32(xyz_batch_cnt), _i32(new_xyz_batch_cnt)
+        em = empty.to(torch.uint8).contiguous()
+        idx = idx.contiguous()
+        feats = features.contiguous().float()
+        w1x = weight[:, :3].t().contiguous()                  # (3, H)
+        w1f = weight[:, 3:].contiguous()                      # (H, C)
+        P = feats @ w1f.t()
+        xyz_c, new_c = xyz.contiguous(), new_xyz.contiguous()
+        out = torch.empty((M * ns, H), dtype=torch.float32, device=xyz.device)
+        rel = torch.empty((M * ns, 3), dtype=torch.float32, device=xyz.device)
+        check(lib.crb_group_affine_rows_stack(B, M, H, ns, ptr(xyz_c), ptr(xc), ptr(P), ptr(new_c), ptr(nc), ptr(idx),
+                                              ptr(em), ptr(w1x), ptr(out), ptr(rel), cur_stream(xyz.device)),
+              'crb_group_affine_rows_stack')
+        ctx.meta = (B, M, H, ns, xc, nc, idx, em)
+        ctx.save_for_backward(feats, w1f, rel)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, M, H, ns, xc, nc, idx, em = ctx.meta
+        feats, w1f, rel = ctx.saved_tensors
+        g = g.contiguous().float()
+        gP = torch.zeros((feats.shape[0], H), dtype=torch.float32, device=g.device)
+        part = torch.empty((int(lib.crb_group_affine_rows_grad_blocks(M, ns)), 3, H), dtype=torch.float32, device=g.device)
+        check(lib.crb_group_affine_rows_grad_stack(B, M, H, ns, ptr(xc), ptr(nc), ptr(idx), ptr(em), ptr(rel), ptr(g),
+                                                   ptr(gP), ptr(part), cur_stream(g.device)),
+              'crb_group_affine_rows_grad_stack')
+        gf = gP @ w1f if ctx.needs_input_grad[4] else None
+        gw = None
+        if ctx.needs_input_grad[7]:
+            gw = torch.cat([part.sum(0).t(), gP.t() @ feats], dim=1)           # (H, 3+C)
+        return None, None, None, None, gf, None, None, gw
+
+
+def grouped_first_layer_rows(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, weight, ball=None):
+    """first bias-free 1x1 conv of a StackSAModuleMSG scale applied to the ball-query groups -> (M*nsample, H)"""
+    idx, empty = ball if ball is not None else ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+    return GroupedFirstLayerRows.apply(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx, empty, weight)
+
+
 def sa_mlp2_max_supported(h1, h2):
     return bool(lib.crb_sa_mlp2_max_supported(int(h1), int(h2)))
 

@@ -209,6 +209,19 @@ int crb_query_group_rows_grad_stack(int B, int64_t M, int C, int nsample, const 
                                     const int32_t* new_xyz_batch_cnt, const int32_t* idx,
                                     const uint8_t* empty_mask, const float* grad_out, float* grad_features,
                                     void* stream);
+/* training path, first shared-MLP layer without the grouped matrix: for a bias-free 1x1 conv on QueryAndGroup's output
+ * (pointnet2_utils.py:107-155 feeding pointnet2_modules.py:94-97), y[p] = W1x (xyz_j - c_i) + P[j] with P = features @ W1f^T
+ * (N,H) computed by the caller. out (M*nsample, H) row-major, rel (M*nsample, 3) = xyz_j - c_i (0 for empty balls, whose
+ * rows of out are 0 like the reference's zeroed groups). The grad entry accumulates grad_P (N,H, pre-zeroed) and writes
+ * part (crb_group_affine_rows_grad_blocks(M,nsample), 3, H): per-slab pieces of dW1x, summed by the caller. */
+int crb_group_affine_rows_stack(int B, int64_t M, int H, int nsample, const float* xyz, const int32_t* xyz_batch_cnt,
+                                const float* P, const float* new_xyz, const int32_t* new_xyz_batch_cnt,
+                                const int32_t* idx, const uint8_t* empty_mask, const float* W1x, float* out, float* rel,
+                                void* stream);
+int64_t crb_group_affine_rows_grad_blocks(int64_t M, int nsample);
+int crb_group_affine_rows_grad_stack(int B, int64_t M, int H, int nsample, const int32_t* xyz_batch_cnt,
+                                     const int32_t* new_xyz_batch_cnt, const int32_t* idx, const uint8_t* empty_mask,
+                                     const float* rel, const float* grad_out, float* grad_P, float* part, void* stream);
 /* inference-only fused set abstraction: replaces the body of StackSAModuleMSG.forward
  * (pointnet2_modules.py:73-112: QueryAndGroup -> 2 x [Conv2d 1x1 + BatchNorm2d + ReLU] -> max_pool2d over nsample) for one
  * radius. BN is folded by the caller; layer 1 is split as W1 [dxyz ; f] = W1x dxyz + P[row], P = features @ W1f^T (N,h1).

@@ -279,6 +279,39 @@ def test_sa_module_rows_training_path_equals_module_path(dev):
         torch.testing.assert_close(b1.float(), b2.float(), rtol=1e-4, atol=1e-5, msg=lambda m, n1=n1: n1 + ': ' + m)
 
 
+def test_grouped_first_layer_rows_equals_group_then_gemm(dev):
+    """y = [xyz_j - c_i ; f_j] W^T taken as gather(F W1f^T) + W1x (xyz_j - c_i) (no grouped matrix) == grouping followed by the
+    GEMM: values 1e-5, feature / weight gradients 1e-4 relative to their scale (other summation order, fp32)."""
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as U
+    pts, off, _ = kitti_batch(3, 3, n_points=5000)
+    xyz = _t(np.ascontiguousarray(pts[:, :3]), dev)
+    xc = _t(np.diff(off).astype(np.int32), dev)
+    rng = np.random.default_rng(5)
+    sel = np.concatenate([k * 5000 + rng.choice(5000, n, replace=False) for k, n in enumerate((310, 5, 202))])
+    new = xyz[torch.from_numpy(sel).to(dev)].contiguous()
+    new[::7] += 45.0                                         # empty balls
+    nc = torch.tensor([310, 5, 202], dtype=torch.int32, device=dev)
+    torch.manual_seed(0)
+    for C, H, ns in ((21, 24, 16), (128, 64, 16), (7, 32, 5)):
+        f1 = torch.randn(15000, C, device=dev, requires_grad=True)
+        f2 = f1.detach().clone().requires_grad_(True)
+        w1 = (torch.randn(H, 3 + C, device=dev) * 0.2).requires_grad_(True)
+        w2 = w1.detach().clone().requires_grad_(True)
+        ball = U.ball_query(1.1, ns, xyz, xc, new, nc)
+        assert bool(ball[1].any()) and not bool(ball[1].all())
+        a = U.grouped_first_layer_rows(1.1, ns, xyz, xc, new, nc, f1, w1, ball=ball)
+        rows, _ = U.query_and_group_rows(1.1, ns, xyz, xc, new, nc, f2, ball=ball)
+        b = rows @ w2.t()
+        assert a.shape == b.shape == (517 * ns, H)
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+        assert float(a.detach().view(517, ns, H)[ball[1]].abs().max()) == 0.0
+        go = torch.randn_like(a)
+        a.backward(go)
+        b.backward(go)
+        for g1, g2 in ((f1.grad, f2.grad), (w1.grad, w2.grad)):
+            assert float((g1 - g2).abs().max()) < 1e-4 * max(1.0, float(g2.abs().max()))
+
+
 def test_fused_query_group_equals_query_and_group(dev):
     from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as U
     pts, off, _ = kitti_batch(2, 2, n_points=5000)
