@@ -174,3 +174,77 @@ def bn_relu_concat(xs, bns, relu=True):
             bn.num_batches_tracked += 1
         args += [x, bn.weight, bn.bias, bn.eps, bn.running_mean, bn.running_var, float(bn.momentum)]
     return _BNReLUConcatTrain.apply(relu, *args)
+
+
+class _BNReLUMaxConcatTrain(torch.autograd.Function):
+    """training relu(bn_i(x_i)) followed by the max over groups of ns_i consecutive rows, for several (M*ns_i, C_i) row
+    matrices, written side by side into ONE (M, sum C_i) matrix: the BatchNorm2d -> ReLU -> max_pool2d -> torch.cat tail of
+    StackSAModuleMSG.forward (pointnet2_modules.py:96-112). The normalised (M*ns_i, C_i) matrices, the zero-filled gradient
+    of the max and its scatter never exist. Arguments: (x, ns, gamma, beta, eps, running_mean, running_var, momentum) per
+    scale."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        import ctypes
+        k = len(args) // 8
+        xs = [args[8 * i].contiguous() for i in range(k)]
+        nss = [int(args[8 * i + 1]) for i in range(k)]
+        dev = xs[0].device
+        M = xs[0].shape[0] // nss[0]
+        widths = [x.shape[1] for x in xs]
+        total = sum(widths)
+        out = torch.empty((M, total), dtype=torch.float32, device=dev)
+        saved, col = [], 0
+        for i, x in enumerate(xs):
+            gamma, beta, eps, rm, rv, mom = args[8 * i + 2:8 * i + 8]
+            C, ns = widths[i], nss[i]
+            assert x.shape[0] == M * ns
+            mean = torch.empty((C,), dtype=torch.float32, device=dev)
+            var, invstd = torch.empty_like(mean), torch.empty_like(mean)
+            arg = torch.empty((M, C), dtype=torch.int32, device=dev)
+            wsb = lib.crb_bn_workspace_bytes(M * ns, C)
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+            g, b = gamma.contiguous().float(), beta.contiguous().float()
+            zptr = ctypes.c_void_p(out.data_ptr() + 4 * col)
+            check(lib.crb_bn_relu_max_forward(ptr(x), M, ns, C, ptr(g), ptr(b), float(eps), zptr, total, ptr(arg),
+                                              ptr(mean), ptr(var), ptr(invstd), ptr(rm), ptr(rv), float(mom), ptr(ws), wsb,
+                                              cur_stream(dev)), 'crb_bn_relu_max_forward')
+            saved += [x, mean, invstd, g, b, arg]
+            col += C
+        ctx.save_for_backward(*saved)
+        ctx.widths, ctx.nss = widths, nss
+        return out
+
+    @staticmethod
+    def backward(ctx, gz):
+        import ctypes
+        gz = gz.contiguous().float()
+        M, total = gz.shape
+        saved = ctx.saved_tensors
+        grads, col = [], 0
+        for i, (C, ns) in enumerate(zip(ctx.widths, ctx.nss)):
+            x, mean, invstd, g, b, arg = saved[6 * i:6 * i + 6]
+            dev = x.device
+            dx = torch.empty_like(x)
+            dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+            dbeta = torch.empty_like(dgamma)
+            wsb = lib.crb_bn_workspace_bytes(M * ns, C)
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+            gp = ctypes.c_void_p(gz.data_ptr() + 4 * col)
+            check(lib.crb_bn_relu_max_backward(ptr(x), gp, total, ptr(arg), M, ns, C, ptr(mean), ptr(invstd), ptr(g), ptr(b),
+                                               ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), wsb, cur_stream(dev)),
+                  'crb_bn_relu_max_backward')
+            grads += [dx, None, dgamma, dbeta, None, None, None, None]
+            col += C
+        return tuple(grads)
+
+
+def bn_relu_max_concat(xs, nss, bns):
+    """training-mode max over groups of nss[i] rows of relu(bn_i(x_i)), concatenated along the channel axis -> (M, sum C_i);
+    every bn in training mode with a momentum (running statistics are updated in the forward launch)"""
+    args = []
+    for x, ns, bn in zip(xs, nss, bns):
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+        args += [x, int(ns), bn.weight, bn.bias, bn.eps, bn.running_mean, bn.running_var, float(bn.momentum)]
+    return _BNReLUMaxConcatTrain.apply(*args)

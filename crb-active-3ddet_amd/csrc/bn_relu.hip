@@ -154,6 +154,107 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   *reinterpret_cast<f4*>(dx + t * 4) = ga * is * (d - db * inv_n - xh * (dg * inv_n));
 }
 
+// ---- BatchNorm + ReLU + max over groups of `ns` consecutive rows (the tail of a set-abstraction scale in training:
+// pointnet2_modules.py:96-103, BatchNorm2d -> ReLU -> max_pool2d over nsample). The normalised (groups*ns, C) matrix is
+// never written: forward keeps the max and the first row attaining it, backward rebuilds the (one-hot) upstream gradient
+// from them. z is formed exactly as bn_apply_kernel forms it.
+__global__ __launch_bounds__(256) void bn_relu_max_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int64_t groups, int ns, int C,
+                                                          float* __restrict__ zmax, int64_t ld_out, int* __restrict__ arg) {
+  const int c4n = C >> 2;
+  const int tc = threadIdx.x % c4n, tr = threadIdx.x / c4n;
+  const int glanes = 256 / c4n;
+  if (tr >= glanes) return;
+  const int64_t m = (int64_t)blockIdx.x * glanes + tr;
+  if (m >= groups) return;
+  const int c = tc * 4;
+  const f4 mu = *reinterpret_cast<const f4*>(mean + c), is = *reinterpret_cast<const f4*>(invstd + c);
+  const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
+  const float* src = x + m * ns * C + c;
+  f4 best = (f4){-1.f, -1.f, -1.f, -1.f};                   // relu output is >= 0: the first row always replaces it
+  int bi[4] = {0, 0, 0, 0};
+  for (int s = 0; s < ns; ++s) {
+    const f4 v = *reinterpret_cast<const f4*>(src + (int64_t)s * C);
+    f4 o = ga * ((v - mu) * is) + be;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o[k] = o[k] > 0.f ? o[k] : 0.f;
+      if (o[k] > best[k]) { best[k] = o[k]; bi[k] = s; }
+    }
+  }
+  *reinterpret_cast<f4*>(zmax + m * ld_out + c) = best;
+  int* a = arg + m * C + c;
+  a[0] = bi[0]; a[1] = bi[1]; a[2] = bi[2]; a[3] = bi[3];
+}
+
+// backward sums from the groups only: d = g[m][c] where the max is positive; dbeta = sum d, dgamma = sum d * xhat(arg row)
+__global__ __launch_bounds__(256) void bn_max_partial_kernel(const float* __restrict__ x, const float* __restrict__ gz,
+                                                             int64_t ld_g, const int* __restrict__ arg,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int64_t groups, int ns, int C, int groups_per_block,
+                                                             float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f4* red = reinterpret_cast<f4*>(smem);
+  const int c4n = C >> 2;
+  const int tc = threadIdx.x % c4n, tr = threadIdx.x / c4n;
+  const int rlanes = 256 / c4n;
+  const int c = tc * 4;
+  const int64_t m0 = (int64_t)blockIdx.x * groups_per_block;
+  const int64_t m1 = min(groups, m0 + groups_per_block);
+  f4 a = (f4){0, 0, 0, 0}, b = (f4){0, 0, 0, 0};
+  const f4 mu = *reinterpret_cast<const f4*>(mean + c), is = *reinterpret_cast<const f4*>(invstd + c);
+  const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
+  if (tr < rlanes)
+    for (int64_t m = m0 + tr; m < m1; m += rlanes) {
+      const f4 g = *reinterpret_cast<const f4*>(gz + m * ld_g + c);
+      const int* ar = arg + m * C + c;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v = x[(m * ns + ar[k]) * C + c + k];
+        const float xh = (v - mu[k]) * is[k];
+        const float d = (ga[k] * xh + be[k]) > 0.f ? g[k] : 0.f;
+        a[k] += d;
+        b[k] += d * xh;
+      }
+    }
+  red[threadIdx.x] = a;
+  red[256 + threadIdx.x] = b;
+  __syncthreads();
+  if (tr == 0) {
+    for (int k = 1; k < rlanes; ++k) { a += red[k * c4n + tc]; b += red[256 + k * c4n + tc]; }
+    *reinterpret_cast<f4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * C + c) = a;
+    *reinterpret_cast<f4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * C + c) = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_max_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gz,
+                                                               int64_t ld_g, const int* __restrict__ arg,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ dbeta,
+                                                               const float* __restrict__ dgamma, float* __restrict__ dx,
+                                                               int64_t total4, int ns, int C, float inv_n) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total4) return;
+  const int c = (int)((t * 4) % C);
+  const int64_t row = (t * 4) / C, m = row / ns;
+  const int s = (int)(row - m * ns);
+  const f4 v = *reinterpret_cast<const f4*>(x + t * 4);
+  const f4 g = *reinterpret_cast<const f4*>(gz + m * ld_g + c);
+  const int* ar = arg + m * C + c;
+  const f4 mu = *reinterpret_cast<const f4*>(mean + c), is = *reinterpret_cast<const f4*>(invstd + c);
+  const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
+  const f4 db = *reinterpret_cast<const f4*>(dbeta + c), dg = *reinterpret_cast<const f4*>(dgamma + c);
+  const f4 xh = (v - mu) * is;
+  const f4 z = ga * xh + be;
+  f4 d;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) d[k] = (ar[k] == s && z[k] > 0.f) ? g[k] : 0.f;
+  *reinterpret_cast<f4*>(dx + t * 4) = ga * is * (d - db * inv_n - xh * (dg * inv_n));
+}
+
 }  // namespace
 
 static inline int bn_blocks(int64_t n) { return crb_cdiv(n, bn_rows_per_block(n)); }
@@ -215,6 +316,57 @@ extern "C" int crb_bn_relu_backward(const float* x, const float* dz, int64_t dz_
   const int64_t total4 = n * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, dz, mean, invstd, gamma, beta,
                      dbeta, dgamma, dx, total4, C, 1.0f / (float)n, relu, ld_dz);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+// training BatchNorm + ReLU over all groups*ns rows, then max over each group of ns consecutive rows.
+// zmax (groups, out_row_stride >= C) may be a column slice of a wider buffer; arg (groups, C) = first row of the group
+// attaining the max. workspace: crb_bn_workspace_bytes(groups * ns, C).
+extern "C" int crb_bn_relu_max_forward(const float* x, int64_t groups, int ns, int C, const float* gamma, const float* beta,
+                                       float eps, float* zmax, int64_t out_row_stride, int32_t* arg, float* mean, float* var,
+                                       float* invstd, float* running_mean, float* running_var, float momentum,
+                                       void* workspace, int64_t workspace_bytes, void* stream) {
+  const int64_t n = groups * ns;
+  const int64_t ld = out_row_stride > 0 ? out_row_stride : C;
+  if (ld < C || (ld & 3) || ns <= 0) return CRB_ERR_ARG;
+  if (n <= 0 || C <= 0 || (C & 3) || C > 1024 || (256 % (C >> 2) && (C >> 2) < 256)) return CRB_ERR_ARG;
+  if (workspace_bytes < crb_bn_workspace_bytes(n, C) - 256 || !workspace) return CRB_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = bn_blocks(n);
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(nblk), dim3(256), 2 * 256 * 16, st, x, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, n, C, 1, bn_rows_per_block(n), (int64_t)C, partial);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, eps, 0, mean, var,
+                     invstd, running_mean, running_var, momentum);
+  const int glanes = 256 / (C >> 2) > 0 ? 256 / (C >> 2) : 1;
+  hipLaunchKernelGGL(bn_relu_max_kernel, dim3(crb_cdiv(groups, glanes)), dim3(256), 0, st, x, mean, invstd, gamma, beta,
+                     groups, ns, C, zmax, ld, arg);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+// backward of the above: gz (groups, gz_row_stride >= C) is the gradient w.r.t. zmax; dx (groups*ns, C) dense.
+extern "C" int crb_bn_relu_max_backward(const float* x, const float* gz, int64_t gz_row_stride, const int32_t* arg,
+                                        int64_t groups, int ns, int C, const float* mean, const float* invstd,
+                                        const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
+                                        void* workspace, int64_t workspace_bytes, void* stream) {
+  const int64_t n = groups * ns;
+  const int64_t ld = gz_row_stride > 0 ? gz_row_stride : C;
+  if (ld < C || (ld & 3) || ns <= 0) return CRB_ERR_ARG;
+  if (n <= 0 || C <= 0 || (C & 3) || C > 1024 || (256 % (C >> 2) && (C >> 2) < 256)) return CRB_ERR_ARG;
+  if (workspace_bytes < crb_bn_workspace_bytes(n, C) - 256 || !workspace) return CRB_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int gpb = bn_rows_per_block(groups);
+  const int nblk = crb_cdiv(groups, gpb);                       // <= bn_blocks(n): fits the same workspace
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL(bn_max_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * 16, st, x, gz, ld, arg, mean, invstd, gamma,
+                     beta, groups, ns, C, gpb, partial);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, 0.f, 1, dbeta, dgamma,
+                     (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f);
+  const int64_t total4 = n * C / 4;
+  hipLaunchKernelGGL(bn_max_bwd_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, gz, ld, arg, mean, invstd,
+                     gamma, beta, dbeta, dgamma, dx, total4, ns, C, 1.0f / (float)n);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

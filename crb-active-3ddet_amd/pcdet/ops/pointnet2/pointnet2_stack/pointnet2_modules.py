@@ -54,6 +54,7 @@ def _transpose_second_layer(w, b):
 FUSED_SA_EVAL = True   # inference: group + 2-layer MLP + max in one HIP kernel (crb_sa_mlp2_max_stack)
 ROWS_TRAIN = True      # training: row-major grouped matrix -> GEMM + fused BN/ReLU row kernels -> max (no MIOpen BN2d / transposes)
 SPLIT_FIRST_LAYER = True   # training rows path: layer 1 = gather of per-source-point products + offset term (no grouped matrix)
+FUSED_BN_MAX = True        # training rows path: last BatchNorm+ReLU, max over nsample and the concat of the scales in one op
 FUSED_GROUP = True     # one HIP launch builds the (1, 3+C, M, ns) MLP input (False: QueryAndGroup + permute copy)
 
 
@@ -171,6 +172,8 @@ class StackSAModuleMSG(nn.Module):
                 and all(g.use_xyz for g in self.groupers) and all(self._rows_ok(m, features) for m in self.mlps):
             M = new_xyz.shape[0]
             balls = self._balls(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+            fuse_max = FUSED_BN_MAX and self.training and M > 0 and \
+                all(list(m)[-2].training and list(m)[-2].momentum is not None for m in self.mlps)
             for grouper, mlp, ball in zip(self.groupers, self.mlps, balls):
                 mods = list(mlp)
                 split = SPLIT_FIRST_LAYER and mods[0].bias is None and mods[0].out_channels <= 256
@@ -187,8 +190,15 @@ class StackSAModuleMSG(nn.Module):
                         x = _LinearRows.apply(x, conv.weight.flatten(1))
                     if conv.bias is not None:
                         x = x + conv.bias
-                    x = bnrelu.bn_relu(x, bn, relu=True)
-                outs.append(x.view(M, grouper.nsample, x.shape[1]).max(dim=1).values)
+                    if i + 3 < len(mods) or not fuse_max:
+                        x = bnrelu.bn_relu(x, bn, relu=True)
+                if fuse_max:
+                    outs.append(x)                                         # pre-BN rows of the last layer
+                else:
+                    outs.append(x.view(M, grouper.nsample, x.shape[1]).max(dim=1).values)
+            if fuse_max:
+                return new_xyz, bnrelu.bn_relu_max_concat(outs, [g.nsample for g in self.groupers],
+                                                          [list(m)[-2] for m in self.mlps])
             return new_xyz, torch.cat(outs, dim=1)
         for grouper, mlp in zip(self.groupers, self.mlps):
             if FUSED_GROUP and features is not None and grouper.use_xyz and xyz.is_cuda:

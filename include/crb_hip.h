@@ -298,6 +298,19 @@ int crb_bn_relu_apply(const float* x, int64_t n, int C, const float* mean, const
 int crb_bn_relu_backward(const float* x, const float* dz, int64_t dz_row_stride, int64_t n, int C, const float* mean,
                          const float* invstd, const float* gamma, const float* beta, int relu, float* dx,
                          float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, void* stream);
+/* training BatchNorm + ReLU over groups*ns rows followed by the max over every group of ns consecutive rows: the tail of
+ * a StackSAModuleMSG scale (pointnet2_modules.py:96-103: BatchNorm2d, ReLU, F.max_pool2d over nsample) on the row-major
+ * (M*nsample, C) layout. The normalised matrix is not materialised: zmax (groups, out_row_stride; 0 = C) and
+ * arg (groups, C) = first row of the group attaining the max are the outputs; the backward takes the gradient of zmax
+ * (groups, gz_row_stride) and writes the dense dx. workspace: crb_bn_workspace_bytes(groups*ns, C). */
+int crb_bn_relu_max_forward(const float* x, int64_t groups, int ns, int C, const float* gamma, const float* beta, float eps,
+                            float* zmax, int64_t out_row_stride, int32_t* arg, float* mean, float* var, float* invstd,
+                            float* running_mean, float* running_var, float momentum, void* workspace,
+                            int64_t workspace_bytes, void* stream);
+int crb_bn_relu_max_backward(const float* x, const float* gz, int64_t gz_row_stride, const int32_t* arg, int64_t groups,
+                             int ns, int C, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                             float* dx, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a10  anchor target assignment (nearest-BEV IoU + thresholds + residual box encoding)

@@ -327,6 +327,43 @@ def test_bev_channels_last_scatter_equals_dense_view(dev):
     assert torch.equal(f1.grad, f2.grad)
 
 
+def test_fused_bn_relu_max_concat_matches_separate_ops(dev):
+    """BatchNorm+ReLU -> max over groups of ns rows -> concat of two scales as one op (crb_bn_relu_max_*) vs the fused
+    BN+ReLU op followed by torch's view/max/cat: identical values (same expression per element), gradients w.r.t. the rows
+    and the affine parameters (1e-5 of their scale; duplicated rows inside a group tie and may route the gradient to another
+    copy in torch, so the rows are distinct here), identical running statistics."""
+    from crbhip import bnrelu
+    torch.manual_seed(3)
+    M = 3001
+    specs = [(32, 16), (64, 5)]
+    xs = [torch.randn(M * ns, C, device=dev) * 2 + 0.3 for C, ns in specs]
+    xs[0][:16 * 7] = -50.0                                   # groups whose every ReLU output is 0
+    bns_a = [torch.nn.BatchNorm1d(C, eps=1e-5, momentum=0.1).to(dev) for C, _ in specs]
+    bns_b = [torch.nn.BatchNorm1d(C, eps=1e-5, momentum=0.1).to(dev) for C, _ in specs]
+    with torch.no_grad():
+        for a, b in zip(bns_a, bns_b):
+            a.weight.uniform_(-1.0, 1.5)
+            a.bias.uniform_(-0.5, 0.5)
+            b.load_state_dict(a.state_dict())
+    xa = [x.clone().requires_grad_(True) for x in xs]
+    xb = [x.clone().requires_grad_(True) for x in xs]
+    out_a = bnrelu.bn_relu_max_concat(xa, [ns for _, ns in specs], bns_a)
+    out_b = torch.cat([bnrelu.bn_relu(x, bn).view(M, ns, C).max(dim=1).values
+                       for x, bn, (C, ns) in zip(xb, bns_b, specs)], dim=1)
+    assert out_a.shape == (M, 96)
+    assert torch.equal(out_a, out_b)
+    g = torch.randn_like(out_a)
+    out_a.backward(g)
+    out_b.backward(g)
+    for a, b in zip(xa, xb):
+        assert float((a.grad - b.grad).abs().max()) < 1e-5 * max(1.0, float(b.grad.abs().max()))
+    for a, b in zip(bns_a, bns_b):
+        for pa, pb in ((a.weight, b.weight), (a.bias, b.bias)):
+            assert float((pa.grad - pb.grad).abs().max()) < 1e-5 * max(1.0, float(pb.grad.abs().max()))
+        assert torch.equal(a.running_mean, b.running_mean) and torch.equal(a.running_var, b.running_var)
+        assert int(a.num_batches_tracked) == 1
+
+
 @pytest.mark.parametrize('C,n', [(16, 50000), (32, 4097), (64, 2), (128, 30000)])
 def test_fused_bn_relu_matches_torch(dev, C, n):
     """fused BatchNorm1d+ReLU (crb_bn_relu_*) vs nn.BatchNorm1d(eps=1e-3, momentum=0.01) + nn.ReLU: outputs, input /
