@@ -363,7 +363,11 @@ __global__ __launch_bounds__(256) void query_group_rows_grad_kernel(int B, int64
 //   y[p] = W1x (xyz_j - c_i) + (F W1f^T)[j]:  P = F W1f^T is one small GEMM over the N source points (caller), and this kernel
 // gathers P rows and adds the 3-term offset part: the (pairs, 3+C) matrix (3.7 GB at the RoI-grid shape) and the
 // pairs x (3+C) x H GEMM on it are never formed. rel (pairs,3) keeps xyz_j - c_i for the weight gradient.
-__global__ __launch_bounds__(256) void group_affine_rows_kernel(int B, int64_t MP, int H, int ns,
+typedef float gf4 __attribute__((ext_vector_type(4)));
+
+// HT > 0: compile-time H (16/32/64/128), one float4 of an output row per thread; HT = 0: any H, scalar lanes
+template <int HT>
+__global__ __launch_bounds__(256) void group_affine_rows_kernel(int B, int64_t MP, int Hrt, int ns,
                                                                 const float* __restrict__ xyz, const int* __restrict__ xyz_cnt,
                                                                 const float* __restrict__ P, const float* __restrict__ new_xyz,
                                                                 const int* __restrict__ new_cnt, const int* __restrict__ idx,
@@ -394,24 +398,50 @@ __global__ __launch_bounds__(256) void group_affine_rows_kernel(int B, int64_t M
   }
   __syncthreads();
   const int npl = (int)min((int64_t)64, MP - p0);
-  float* dst = out + p0 * H;
-  for (int e = threadIdx.x; e < npl * H; e += 256) {
-    const int pl = e / H, c = e - pl * H;
-    const int row = srow[pl];
-    float v = 0.f;                                           // empty ball: the reference zeroes the whole grouped row
-    if (row >= 0) {
-      v = P[(int64_t)row * H + c];
-      v = fmaf(W1x[c], sd[pl][0], v);
-      v = fmaf(W1x[H + c], sd[pl][1], v);
-      v = fmaf(W1x[2 * H + c], sd[pl][2], v);
+  if (HT > 0) {
+    constexpr int H = HT > 0 ? HT : 4, H4 = H / 4, NPLANE = 256 / H4;
+    float* dst = out + p0 * H;
+    const int c4 = threadIdx.x % H4, plane = threadIdx.x / H4, c = c4 * 4;
+    const gf4 w0 = *reinterpret_cast<const gf4*>(W1x + c), w1 = *reinterpret_cast<const gf4*>(W1x + H + c),
+              w2 = *reinterpret_cast<const gf4*>(W1x + 2 * H + c);
+#pragma unroll
+    for (int i = 0; i < 64 / NPLANE; ++i) {
+      const int pl = plane + i * NPLANE;
+      if (pl >= npl) break;
+      const int row = srow[pl];
+      gf4 v = (gf4){0.f, 0.f, 0.f, 0.f};                     // empty ball: the reference zeroes the whole grouped row
+      if (row >= 0) {
+        v = *reinterpret_cast<const gf4*>(P + (int64_t)row * H + c);
+        const float dx = sd[pl][0], dy = sd[pl][1], dz = sd[pl][2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fmaf(w2[k], dz, fmaf(w1[k], dy, fmaf(w0[k], dx, v[k])));
+      }
+      *reinterpret_cast<gf4*>(dst + pl * H + c) = v;
     }
-    dst[e] = v;
+  } else {
+    const int H = Hrt;
+    float* dst = out + p0 * H;
+    for (int e = threadIdx.x; e < npl * H; e += 256) {
+      const int pl = e / H, c = e - pl * H;
+      const int row = srow[pl];
+      float v = 0.f;
+      if (row >= 0)
+        v = fmaf(W1x[2 * H + c], sd[pl][2], fmaf(W1x[H + c], sd[pl][1], fmaf(W1x[c], sd[pl][0], P[(int64_t)row * H + c])));
+      dst[e] = v;
+    }
   }
 }
 
-// backward of the kernel above: grad_P[row] += dy[p] (in-slab dedupe as query_group_rows_grad_kernel), and this slab's
-// contribution to dW1x, part[blk][d][c] = sum_p rel[p][d] * dy[p][c] (summed over blocks by the caller: deterministic).
-__global__ __launch_bounds__(256) void group_affine_rows_grad_kernel(int B, int64_t MP, int H, int ns,
+// backward of the kernel above: grad_P[row] += dy[p], and this slab's contribution to dW1x,
+// part[blk][d][c] = sum_p rel[p][d] * dy[p][c] (summed over blocks by the caller).
+// A ball query pads its result with its first hit, so most pairs of a 16-pair segment repeat an earlier pair's row: those
+// are folded into the first occurrence inside LDS and only first occurrences issue global atomics, one row of H consecutive
+// floats per H lanes (measured: the global atomics that remain cost < 0.01 ms at the RoI-grid shape; without any folding
+// they cost 1.5 ms).
+// H is a template parameter: with a run-time H the index arithmetic (e / H, e % H per element) made the kernel VALU-bound
+// (~3000 instructions per thread, 2.4 ms at the RoI-grid shape for 1.8 GB of input).
+template <int H>
+__global__ __launch_bounds__(256) void group_affine_rows_grad_kernel(int B, int64_t MP, int ns,
                                                                      const int* __restrict__ xyz_cnt,
                                                                      const int* __restrict__ new_cnt,
                                                                      const int* __restrict__ idx,
@@ -419,8 +449,9 @@ __global__ __launch_bounds__(256) void group_affine_rows_grad_kernel(int B, int6
                                                                      const float* __restrict__ rel,
                                                                      const float* __restrict__ grad_out,
                                                                      float* __restrict__ grad_P, float* __restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* slab = reinterpret_cast<float*>(smem);            // 64 x H
+  constexpr int H4 = H / 4, NPLANE = 256 / H4, NROW = 256 / H < 1 ? 1 : 256 / H;
+  __shared__ __attribute__((aligned(16))) float slab[64 * H];
+  __shared__ float wred[4 * H4 * 12];
   __shared__ int srow[64];
   __shared__ int first[64];
   __shared__ float sd[64][3];
@@ -442,37 +473,99 @@ __global__ __launch_bounds__(256) void group_affine_rows_grad_kernel(int B, int6
     sd[threadIdx.x][0] = dx; sd[threadIdx.x][1] = dy; sd[threadIdx.x][2] = dz;
   }
   const int npl = (int)min((int64_t)64, MP - p0);
-  for (int e = threadIdx.x; e < 64 * H; e += 256) {
-    const int pl = e / H;
-    slab[e] = pl < npl ? grad_out[p0 * H + e] : 0.f;
+  const int c4 = threadIdx.x % H4, plane = threadIdx.x / H4;
+  const gf4* src = reinterpret_cast<const gf4*>(grad_out + p0 * H);
+  gf4* slab4 = reinterpret_cast<gf4*>(slab);
+  gf4 v[64 / NPLANE];
+#pragma unroll
+  for (int i = 0; i < 64 / NPLANE; ++i) {
+    const int pl = plane + i * NPLANE;
+    v[i] = pl < npl ? src[pl * H4 + c4] : (gf4){0.f, 0.f, 0.f, 0.f};
+    slab4[pl * H4 + c4] = v[i];
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < 3 * H; e += 256) {
-    const int d = e / H, c = e - d * H;
-    float acc = 0.f;
-    for (int pl = 0; pl < 64; ++pl) acc = fmaf(sd[pl][d], slab[pl * H + c], acc);     // empty rows carry rel = 0
-    part[(int64_t)blockIdx.x * 3 * H + e] = acc;
+  {                                                          // dW1x piece from the registers (rel = 0 on empty rows)
+    float wacc[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < 64 / NPLANE; ++i) {
+      const int pl = plane + i * NPLANE;
+      const float dx = sd[pl][0], dy = sd[pl][1], dz = sd[pl][2];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        wacc[0][k] = fmaf(dx, v[i][k], wacc[0][k]);
+        wacc[1][k] = fmaf(dy, v[i][k], wacc[1][k]);
+        wacc[2][k] = fmaf(dz, v[i][k], wacc[2][k]);
+      }
+    }
+    // lanes of a wave that share c4 sit H4 apart: butterfly over them, then one (4 waves x H4 x 12) LDS table
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float t = wacc[d][k];
+#pragma unroll
+        for (int off = H4; off < 64; off <<= 1) t += __shfl_xor(t, off);
+        wacc[d][k] = t;
+      }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < H4) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wred[(wave * H4 + lane) * 12 + d * 4 + k] = wacc[d][k];
+    }
   }
-  if (threadIdx.x < 64) {
+  if (threadIdx.x < 64) {                                    // first occurrence of this pair's row in its 16-pair segment
     const int row = srow[threadIdx.x];
     int f = threadIdx.x;
     if (row >= 0)
-      for (int q = 0; q < (int)threadIdx.x; ++q)
+      for (int q = threadIdx.x & ~15; q < (int)threadIdx.x; ++q)
         if (srow[q] == row) { f = q; break; }
     first[threadIdx.x] = f;
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < H; c += 256) {
-    for (int pl = 0; pl < 64; ++pl) {
-      const int f = first[pl];
-      if (f != pl) slab[f * H + c] += slab[pl * H + c];
+  if (threadIdx.x < 3 * H) {
+    const int d = threadIdx.x / H, c = threadIdx.x % H;
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) acc += wred[(w * H4 + (c >> 2)) * 12 + d * 4 + (c & 3)];
+    part[(int64_t)blockIdx.x * 3 * H + threadIdx.x] = acc;
+  }
+  if (3 * H > 256) {                                         // H = 128: 384 outputs
+    for (int e = 256 + threadIdx.x; e < 3 * H; e += 256) {
+      const int d = e / H, c = e % H;
+      float acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) acc += wred[(w * H4 + (c >> 2)) * 12 + d * 4 + (c & 3)];
+      part[(int64_t)blockIdx.x * 3 * H + e] = acc;
     }
   }
+  // fold repeats into their first occurrence: one thread per (segment, channel) walks its 16 pairs; runs of pairs with the
+  // same target (the padded tail of a ball) are summed in a register. (ds_add_f32 from all lanes instead: +1.3 ms at the
+  // RoI-grid shape — the repeats of one ball hit the same addresses from every wave.)
+  for (int e = threadIdx.x; e < 4 * H; e += 256) {
+    const int seg = e / H, c = e % H;
+    int cur = -1;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int pl = 16 * seg; pl < 16 * seg + 16; ++pl) {
+      const int f = first[pl];
+      if (f == pl) continue;
+      if (f != cur) {
+        if (cur >= 0) slab[cur * H + c] += acc;
+        cur = f;
+        acc = 0.f;
+      }
+      acc += slab[pl * H + c];
+    }
+    if (cur >= 0) slab[cur * H + c] += acc;
+  }
   __syncthreads();
-  for (int e = threadIdx.x; e < 64 * H; e += 256) {
-    const int pl = e / H, c = e - pl * H;
+  // one source row per H consecutive lanes
+  const int c = threadIdx.x % H, r0 = threadIdx.x / H;
+  for (int pl = r0; pl < 64; pl += NROW) {
     const int row = srow[pl];
-    if (row >= 0 && first[pl] == pl) atomicAdd(&grad_P[(int64_t)row * H + c], slab[e]);
+    if (row >= 0 && first[pl] == pl) atomicAdd(&grad_P[(int64_t)row * H + c], slab[pl * H + c]);
   }
 }
 
@@ -779,8 +872,17 @@ extern "C" int crb_group_affine_rows_stack(int B, int64_t M, int H, int nsample,
   if (B <= 0 || M < 0 || H <= 0 || nsample <= 0) return CRB_ERR_ARG;
   if (M == 0) return CRB_OK;
   const int64_t MP = M * nsample;
-  hipLaunchKernelGGL(group_affine_rows_kernel, dim3(crb_cdiv(MP, 64)), dim3(256), 0, (hipStream_t)stream, B, MP, H, nsample,
-                     xyz, xyz_batch_cnt, P, new_xyz, new_xyz_batch_cnt, idx, empty_mask, W1x, out, rel);
+  const dim3 grid(crb_cdiv(MP, 64));
+  hipStream_t st = (hipStream_t)stream;
+#define CRB_GAF(HT)                                                                                                    \
+  hipLaunchKernelGGL(group_affine_rows_kernel<HT>, grid, dim3(256), 0, st, B, MP, H, nsample, xyz, xyz_batch_cnt, P,  \
+                     new_xyz, new_xyz_batch_cnt, idx, empty_mask, W1x, out, rel)
+  if (H == 16) CRB_GAF(16);
+  else if (H == 32) CRB_GAF(32);
+  else if (H == 64) CRB_GAF(64);
+  else if (H == 128) CRB_GAF(128);
+  else CRB_GAF(0);
+#undef CRB_GAF
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
@@ -792,12 +894,17 @@ extern "C" int crb_group_affine_rows_grad_stack(int B, int64_t M, int H, int nsa
                                                 const uint8_t* empty_mask, const float* rel, const float* grad_out,
                                                 float* grad_P /* pre-zeroed */, float* part, void* stream) {
   if (B <= 0 || M < 0 || H <= 0 || nsample <= 0) return CRB_ERR_ARG;
+  if (H != 16 && H != 32 && H != 64 && H != 128) return CRB_ERR_UNSUPPORTED;
   if (M == 0) return CRB_OK;
-  const size_t lds = sizeof(float) * 64 * H;
-  if (lds > 64 * 1024) return CRB_ERR_UNSUPPORTED;
   const int64_t MP = M * nsample;
-  hipLaunchKernelGGL(group_affine_rows_grad_kernel, dim3(crb_cdiv(MP, 64)), dim3(256), lds, (hipStream_t)stream, B, MP, H,
-                     nsample, xyz_batch_cnt, new_xyz_batch_cnt, idx, empty_mask, rel, grad_out, grad_P, part);
+  const dim3 grid(crb_cdiv(MP, 64));
+  hipStream_t st = (hipStream_t)stream;
+#define CRB_GA_CASE(HH)                                                                                              \
+  if (H == HH)                                                                                                       \
+    hipLaunchKernelGGL(group_affine_rows_grad_kernel<HH>, grid, dim3(256), 0, st, B, MP, nsample, xyz_batch_cnt,     \
+                       new_xyz_batch_cnt, idx, empty_mask, rel, grad_out, grad_P, part);
+  CRB_GA_CASE(16) CRB_GA_CASE(32) CRB_GA_CASE(64) CRB_GA_CASE(128)
+#undef CRB_GA_CASE
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

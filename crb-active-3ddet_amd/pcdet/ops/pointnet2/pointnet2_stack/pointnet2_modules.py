@@ -176,7 +176,7 @@ class StackSAModuleMSG(nn.Module):
                 all(list(m)[-2].training and list(m)[-2].momentum is not None for m in self.mlps)
             for grouper, mlp, ball in zip(self.groupers, self.mlps, balls):
                 mods = list(mlp)
-                split = SPLIT_FIRST_LAYER and mods[0].bias is None and mods[0].out_channels <= 256
+                split = SPLIT_FIRST_LAYER and mods[0].bias is None and mods[0].out_channels in (16, 32, 64, 128)
                 if not split:
                     x, _ = pointnet2_utils.query_and_group_rows(grouper.radius, grouper.nsample, xyz, xyz_batch_cnt,
                                                                 new_xyz, new_xyz_batch_cnt, features, ball=ball)   # (M*ns, 3+C)

@@ -292,7 +292,7 @@ def test_grouped_first_layer_rows_equals_group_then_gemm(dev):
     new[::7] += 45.0                                         # empty balls
     nc = torch.tensor([310, 5, 202], dtype=torch.int32, device=dev)
     torch.manual_seed(0)
-    for C, H, ns in ((21, 24, 16), (128, 64, 16), (7, 32, 5)):
+    for C, H, ns in ((21, 16, 16), (128, 64, 16), (7, 32, 5), (9, 128, 16)):
         f1 = torch.randn(15000, C, device=dev, requires_grad=True)
         f2 = f1.detach().clone().requires_grad_(True)
         w1 = (torch.randn(H, 3 + C, device=dev) * 0.2).requires_grad_(True)
@@ -310,6 +310,12 @@ def test_grouped_first_layer_rows_equals_group_then_gemm(dev):
         b.backward(go)
         for g1, g2 in ((f1.grad, f2.grad), (w1.grad, w2.grad)):
             assert float((g1 - g2).abs().max()) < 1e-4 * max(1.0, float(g2.abs().max()))
+    with torch.no_grad():                                    # any other width: scalar-lane forward kernel
+        f, w = torch.randn(15000, 10, device=dev), torch.randn(24, 13, device=dev) * 0.2
+        ball = U.ball_query(1.1, 16, xyz, xc, new, nc)
+        a = U.grouped_first_layer_rows(1.1, 16, xyz, xc, new, nc, f, w, ball=ball)
+        b = U.query_and_group_rows(1.1, 16, xyz, xc, new, nc, f, ball=ball)[0] @ w.t()
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
 
 
 def test_fused_query_group_equals_query_and_group(dev):
