@@ -7,9 +7,11 @@ import torch.nn as nn
 from crbhip import bnrelu
 
 from ...utils.fold_utils import fold_conv_bn
+from ...utils.linear_rows import LinearRows, rows_view, rows_to_nchw
 
 
 ROWS_TRAIN = True      # BatchNorm2d+ReLU pairs through the fused row kernels when the activations are channels_last
+ROWS_GEMM = True       # kernel-1 stride-1 up-sampling branch (ConvTranspose2d 1x1) as a row GEMM on the channels_last map
 
 
 def _bn(c):
@@ -136,6 +138,20 @@ class BaseBEVBackbone(nn.Module):
                 i += 1
         return x
 
+    @staticmethod
+    def _up(conv, x):
+        """first module of an up-sampling branch. A kernel-1 stride-1 ConvTranspose2d / Conv2d without bias on a
+        channels_last CUDA map is the GEMM rows @ W (no convolution kernel); everything else runs as the module."""
+        if ROWS_GEMM and x.is_cuda and conv.bias is None and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and \
+                conv.padding == (0, 0) and conv.groups == 1 and conv.dilation == (1, 1):
+            rows = rows_view(x)
+            if rows is not None:
+                w2d = conv.weight[:, :, 0, 0]
+                w2d = w2d.t() if isinstance(conv, nn.ConvTranspose2d) else w2d            # (Cout, Cin)
+                n, _, h, w_ = x.shape
+                return rows_to_nchw(LinearRows.apply(rows, w2d), n, h, w_)
+        return conv(x)
+
     def _can_fuse_concat_eval(self, x):
         if len(self.deblocks) != len(self.blocks) or len(self.deblocks) < 2:
             return False
@@ -169,7 +185,7 @@ class BaseBEVBackbone(nn.Module):
             for i, blk in enumerate(self.blocks):
                 x = self._run_folded(blk, x)
                 if cat_ok:
-                    pre.append(self.deblocks[i][0](x))
+                    pre.append(self._up(self.deblocks[i][0], x))
                 else:
                     ups.append(self._run_folded(self.deblocks[i], x) if len(self.deblocks) > 0 else x)
             if cat_ok and all(p.is_contiguous(memory_format=torch.channels_last) and p.shape[2:] == pre[0].shape[2:]
@@ -198,7 +214,7 @@ class BaseBEVBackbone(nn.Module):
             stride = int(spatial_features.shape[2] / x.shape[2])
             data_dict['spatial_features_%dx' % stride] = x
             if fuse_cat:
-                pre.append(self.deblocks[i][0](x))       # ConvTranspose2d / Conv2d only
+                pre.append(self._up(self.deblocks[i][0], x))       # ConvTranspose2d / Conv2d only
             else:
                 ups.append(run(self.deblocks[i], x) if len(self.deblocks) > 0 else x)
         if fuse_cat and all(p.is_contiguous(memory_format=torch.channels_last) and p.shape[2:] == pre[0].shape[2:]

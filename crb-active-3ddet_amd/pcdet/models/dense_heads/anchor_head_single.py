@@ -3,10 +3,12 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ...utils.linear_rows import LinearRows, rows_view
 from .anchor_head_template import AnchorHeadTemplate
 
 
 FUSED_HEAD_CONVS = True     # cls / box / dir 1x1 convs as one convolution over the concatenated filters
+ROWS_GEMM = True            # ... run as a row GEMM on the channels_last map (utils/linear_rows.py)
 
 
 class AnchorHeadSingle(AnchorHeadTemplate):
@@ -39,7 +41,14 @@ class AnchorHeadSingle(AnchorHeadTemplate):
             heads = [self.conv_cls, self.conv_box] + ([self.conv_dir_cls] if self.conv_dir_cls is not None else [])
             w = torch.cat([h.weight for h in heads], 0)
             b = torch.cat([h.bias for h in heads], 0)
-            y = torch.nn.functional.conv2d(feats, w, b).permute(0, 2, 3, 1)                # (B,H,W,sum C)
+            rows = rows_view(feats) if (ROWS_GEMM and feats.is_cuda) else None
+            if rows is not None:
+                # channels_last: the 1x1 convolution is the GEMM (B*H*W, 512) x (512, sum C); its output rows already are the
+                # (B,H,W,sum C) layout the reference permutes to
+                n, _, h, w_ = feats.shape
+                y = LinearRows.apply(rows, w.flatten(1), b).view(n, h, w_, w.shape[0])
+            else:
+                y = torch.nn.functional.conv2d(feats, w, b).permute(0, 2, 3, 1)            # (B,H,W,sum C)
             outs = torch.split(y, [h.out_channels for h in heads], dim=3)
             cls_preds, box_preds = outs[0].contiguous(), outs[1].contiguous()
             dir_cls_preds = outs[2].contiguous() if self.conv_dir_cls is not None else None

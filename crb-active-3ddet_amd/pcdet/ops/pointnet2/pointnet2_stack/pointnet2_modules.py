@@ -10,35 +10,7 @@ from crbhip import bnrelu
 
 from . import pointnet2_utils
 from ....utils.fold_utils import fold_conv_bn
-
-
-class _LinearRows(torch.autograd.Function):
-    """y = x @ w^T for a tall (pairs, Cin) matrix. The weight gradient dy^T x reduces over millions of rows into a 64 x 131
-    tile: as one GEMM it gets a handful of workgroups (3 ms per call at the RoI-grid shape); here the rows are cut into 256
-    slices multiplied as one batched GEMM and summed."""
-    SLICES = 256
-
-    @staticmethod
-    def forward(ctx, x, w):
-        ctx.save_for_backward(x, w)
-        return x @ w.t()
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        dy = dy.contiguous()
-        dx = dy @ w if ctx.needs_input_grad[0] else None
-        dw = None
-        if ctx.needs_input_grad[1]:
-            R, S = x.shape[0], _LinearRows.SLICES
-            if R >= 64 * S:
-                r0 = (R // S) * S
-                dw = torch.bmm(dy[:r0].view(S, r0 // S, -1).transpose(1, 2), x[:r0].view(S, r0 // S, -1)).sum(0)
-                if r0 < R:
-                    dw = dw + dy[r0:].t() @ x[r0:]
-            else:
-                dw = dy.t() @ x
-        return dx, dw
+from ....utils.linear_rows import LinearRows as _LinearRows
 
 
 def _split_first_layer(w, b):

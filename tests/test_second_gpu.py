@@ -174,3 +174,34 @@ def test_bev_backbone_training_rows_path_equals_module_path(dev):
         same_up_to_relu_flips(p1.grad, p2.grad, n1)
     for (n1, b1), (_, b2) in zip(m.named_buffers(), ref.named_buffers()):
         torch.testing.assert_close(b1.float(), b2.float(), rtol=1e-4, atol=1e-5, msg=lambda s, n1=n1: n1 + ': ' + s)
+
+
+def test_pointwise_conv_as_row_gemm(dev):
+    """1x1 convolutions on channels_last maps as row GEMMs (utils/linear_rows.py): Conv2d with bias (anchor head) and
+    ConvTranspose2d (stride-1 up-sampling branch) — outputs 1e-4, input / weight / bias gradients 1e-3 of their scale
+    (the weight gradient is a sum over 84k rows taken in 256 slices)"""
+    import torch.nn.functional as F
+    from pcdet.utils.linear_rows import LinearRows, rows_view, rows_to_nchw
+    torch.manual_seed(1)
+    x1 = torch.randn(4, 96, 120, 176, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    assert rows_view(torch.randn(2, 8, 4, 4, device=dev)) is None            # NCHW-contiguous: no row view
+    for transposed in (False, True):
+        cout = 72
+        w1 = (torch.randn((96, cout, 1, 1) if transposed else (cout, 96, 1, 1), device=dev) * 0.1).requires_grad_(True)
+        b1 = torch.randn(cout, device=dev).requires_grad_(True) if not transposed else None
+        w2 = w1.detach().clone().requires_grad_(True)
+        b2 = b1.detach().clone().requires_grad_(True) if b1 is not None else None
+        w2d = w1[:, :, 0, 0].t() if transposed else w1[:, :, 0, 0]
+        a = rows_to_nchw(LinearRows.apply(rows_view(x1), w2d, b1), 4, 120, 176)
+        b = F.conv_transpose2d(x2, w2) if transposed else F.conv2d(x2, w2, b2)
+        assert a.shape == b.shape and a.is_contiguous(memory_format=torch.channels_last)
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+        go = torch.randn_like(b)
+        x1.grad = x2.grad = None
+        a.backward(go)
+        b.backward(go)
+        pairs = [(x1.grad, x2.grad), (w1.grad, w2.grad)] + ([(b1.grad, b2.grad)] if b1 is not None else [])
+        for g1, g2 in pairs:
+            assert g1.shape == g2.shape
+            assert float((g1 - g2).abs().max()) < 1e-3 * max(1.0, float(g2.abs().max()))
