@@ -3,7 +3,9 @@
 
 MIOpen's find phase (naive_conv_*, GEMM trials) pollutes whole-process --stats; a training step of this repo launches
 the voxelizer's `vox_insert` kernel exactly once, so the trace is cut at the (last-K)-th vox_insert and only the
-K last steps are aggregated.  Usage: prof_summary.py <kernel_trace.csv> <K> > summary.csv"""
+K last steps are aggregated.  Usage: prof_summary.py <kernel_trace.csv> <K> > summary.csv
+PROF_MARKER=<kernel substring> picks another once-per-step kernel; PROF_SPLIT_GRID=<kernel substring> lists the matching
+kernel once per launch geometry (the subm and the strided layers run the same gather-GEMM instance)."""
 import csv
 import sys
 from collections import defaultdict
@@ -24,9 +26,14 @@ def main(path, K, marker='vox_insert'):
     sel = rows[first:]
     span_ns = int(sel[-1][key_e]) - int(sel[0][key_s])
     agg = defaultdict(lambda: [0, 0])
+    split = os.environ.get('PROF_SPLIT_GRID', '')          # e.g. "sparse_conv_fwd2": one line per launch geometry
+    key_g = next((k for k in ('Grid_Size_X', 'Grid_Size', 'Grid_Size_x') if k in rows[0]), None)
     for r in sel:
         d = int(r[key_e]) - int(r[key_s])
-        a = agg[r[key_n]]
+        name = r[key_n]
+        if split and key_g and split in name:
+            name = '[grid_x=%s] %s' % (r[key_g], name)
+        a = agg[name]
         a[0] += 1
         a[1] += d
     busy = sum(v[1] for v in agg.values())
