@@ -54,17 +54,18 @@ def test_ball_query_pair_equals_two_queries(dev):
     xyz = _t(np.ascontiguousarray(pts[:, :3]), dev)
     xc = _t(np.diff(off).astype(np.int32), dev)
     rng = np.random.default_rng(9)
-    new = torch.cat([xyz[off[b]:off[b + 1]][torch.from_numpy(rng.choice(7000, 400, replace=False)).to(dev)]
-                     for b in range(3)]).contiguous()
+    counts = (397, 3, 399)        # ragged: groups of 8 queries straddle frame boundaries, the last group is short
+    new = torch.cat([xyz[off[b]:off[b + 1]][torch.from_numpy(rng.choice(7000, c, replace=False)).to(dev)]
+                     for b, c in enumerate(counts)]).contiguous()
     new[::11] += 60.0
-    nc = torch.tensor([400, 400, 400], dtype=torch.int32, device=dev)
-    for (ra, na, rb, nb) in ((0.4, 16, 0.8, 16), (2.4, 16, 4.8, 32), (1.6, 24, 0.8, 7)):
+    nc = torch.tensor(counts, dtype=torch.int32, device=dev)
+    for (ra, na, rb, nb) in ((0.4, 16, 0.8, 16), (2.4, 16, 4.8, 32), (1.6, 24, 0.8, 7), (0.9, 5, 0.9, 64)):
         (ia, ea), (ib, eb) = U.ball_query_pair(ra, na, rb, nb, xyz, xc, new, nc)
         ja, fa = U.ball_query(ra, na, xyz, xc, new, nc)
         jb, fb = U.ball_query(rb, nb, xyz, xc, new, nc)
         assert torch.equal(ia, ja) and torch.equal(ib, jb)
         assert torch.equal(ea.bool(), fa) and torch.equal(eb.bool(), fb)
-        assert int(fa.sum()) >= 100
+        assert int(fa.sum()) >= 60
 
 
 @pytest.mark.parametrize('n,m', [(20000, 2048), (4096, 512), (1000, 100), (777, 64), (37, 10), (30000, 300), (50000, 200)])
