@@ -238,12 +238,16 @@ __global__ __launch_bounds__(256) void bn_max_bwd_apply_kernel(const float* __re
                                                                int64_t total4, int ns, int C, float inv_n) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= total4) return;
-  const int c = (int)((t * 4) % C);
-  const int64_t row = (t * 4) / C, m = row / ns;
-  const int s = (int)(row - m * ns);
+  // C/4 divides 256 and 256 is the block size: a thread's column only depends on threadIdx; rows fit 32 bits (host check)
+  const int c4n = C >> 2;
+  const int c = (int)(threadIdx.x % c4n) * 4;
+  const unsigned row = (unsigned)((t * 4) >> (31 - __clz(C)));           // C = 4 * 2^k
+  const unsigned m = row / (unsigned)ns;
+  const int s = (int)(row - m * (unsigned)ns);
   const f4 v = *reinterpret_cast<const f4*>(x + t * 4);
-  const f4 g = *reinterpret_cast<const f4*>(gz + m * ld_g + c);
-  const int* ar = arg + m * C + c;
+  const f4 g = *reinterpret_cast<const f4*>(gz + (int64_t)m * ld_g + c);
+  typedef int i4 __attribute__((ext_vector_type(4)));
+  const i4 ar = *reinterpret_cast<const i4*>(arg + (int64_t)m * C + c);
   const f4 mu = *reinterpret_cast<const f4*>(mean + c), is = *reinterpret_cast<const f4*>(invstd + c);
   const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
   const f4 db = *reinterpret_cast<const f4*>(dbeta + c), dg = *reinterpret_cast<const f4*>(dgamma + c);
@@ -357,6 +361,7 @@ extern "C" int crb_bn_relu_max_backward(const float* x, const float* gz, int64_t
   if (n <= 0 || C <= 0 || (C & 3) || C > 1024 || (256 % (C >> 2) && (C >> 2) < 256)) return CRB_ERR_ARG;
   if (workspace_bytes < crb_bn_workspace_bytes(n, C) - 256 || !workspace) return CRB_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  if (n >= (1LL << 32) || 256 % (C >> 2)) return CRB_ERR_UNSUPPORTED;   // 32-bit row arithmetic in the apply pass
   const int gpb = bn_rows_per_block(groups);
   const int nblk = crb_cdiv(groups, gpb);                       // <= bn_blocks(n): fits the same workspace
   float* partial = (float*)workspace;

@@ -96,8 +96,7 @@ def crb_frame_records(model, batch_dict):
     far[..., 0:3] = torch.where(valid[..., None], pred_boxes[..., 0:3], pred_boxes.new_full((), 1e7))
     idx = roiaware_pool3d_utils.points_in_boxes_gpu(pts, far[..., 0:7].contiguous()).long()      # (B,M)
     P = pred_boxes.shape[1]
-    cnt = torch.zeros((B, P + 1), dtype=torch.float32, device=pts.device)
-    cnt.scatter_add_(1, torch.where(idx >= 0, idx, torch.full_like(idx, P)), torch.ones_like(idx, dtype=torch.float32))
+    cnt = _first_hit_counts(idx, P)
     vol = pred_boxes[..., 3] * pred_boxes[..., 4] * pred_boxes[..., 5]
     density = torch.where(valid, cnt[:, :P] / vol.clamp(min=1e-12), torch.zeros_like(vol))
     num_class = len(model.model_cfg.DENSE_HEAD.ANCHOR_GENERATOR_CONFIG)
@@ -109,6 +108,17 @@ def crb_frame_records(model, batch_dict):
     return {'sel': sel, 'valid': valid, 'num': num, 'pred_boxes': pred_boxes, 'pred_scores': pred_scores,
             'pred_labels': pred_labels, 'pred_logits': pred_logits, 'density': density, 'entropy': ent,
             'batch_rcnn_cls': rcnn_cls, 'batch_rcnn_reg': rcnn_reg, 'confidence': cls_preds}
+
+
+def _first_hit_counts(idx, P):
+    """idx (B,M) = first containing box of every point or -1 -> (B, >=P) float counts per box (columns < P are the boxes).
+    Most points lie in no box: sent to ONE dump bin they serialise on a single atomic address (0.29 ms for 16 x 20k points),
+    so they are spread over 64 dump bins."""
+    B, M = idx.shape
+    dump = P + (torch.arange(M, device=idx.device) & 63)
+    cnt = torch.zeros((B, P + 64), dtype=torch.float32, device=idx.device)
+    cnt.scatter_add_(1, torch.where(idx >= 0, idx, dump.expand(B, M)), torch.ones_like(idx, dtype=torch.float32))
+    return cnt
 
 
 def gt_point_statistics(model, batch_dict):
@@ -127,8 +137,7 @@ def gt_point_statistics(model, batch_dict):
         boxes = gt[..., :7].clone()
         boxes[..., 0:3] = torch.where(m[..., None], boxes[..., 0:3], boxes.new_full((), 1e7))
         idx = roiaware_pool3d_utils.points_in_boxes_gpu(pts, boxes.contiguous()).long()
-        cnt = torch.zeros((B, G + 1), dtype=torch.float32, device=pts.device)
-        cnt.scatter_add_(1, torch.where(idx >= 0, idx, torch.full_like(idx, G)), torch.ones_like(idx, dtype=torch.float32))
+        cnt = _first_hit_counts(idx, G)
         stats[name] = (m.sum(1).cpu(), cnt[:, :G].cpu(), m.cpu())
     for b in range(B):
         num_bbox, mean_p, med_p, var_p = out[b]
