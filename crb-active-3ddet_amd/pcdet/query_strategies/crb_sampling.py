@@ -56,9 +56,7 @@ class CRBSampling(Strategy):
         model.eval()
         self.enable_dropout(model)
         rows = []
-        for s in range(0, len(frame_indices), batch_size):
-            chunk = frame_indices[s:s + batch_size]
-            batch = ds.collate_batch([ds[i] for i in chunk])
+        for batch in self.iter_pool_batches(frame_indices, batch_size):
             batch['point_frame_counts_host'] = np.diff(batch['point_frame_offsets']).tolist()
             load_data_to_gpu(batch)
             batch['point_frame_offsets'] = batch['point_frame_offsets'].int()
@@ -72,11 +70,12 @@ class CRBSampling(Strategy):
     PRUNED_BACKWARD = True
     SKIP_UNUSED_LOSSES = True
 
-    def frame_loss(self, i, rcnn_cls_labels, reg_sample_targets):
-        """bs=1 training-mode pass of pool frame i and the RoI-head loss against the stage-1 hypothetical labels
-        (crb_sampling.py:174-196)"""
+    def frame_loss(self, i, rcnn_cls_labels, reg_sample_targets, batch=None):
+        """bs=1 training-mode pass of pool frame i (or of the already collated host `batch`) and the RoI-head loss against
+        the stage-1 hypothetical labels (crb_sampling.py:174-196)"""
         ds, model = self.unlabelled_set, self.model
-        batch = ds.collate_batch([ds[i]])
+        if batch is None:
+            batch = ds.collate_batch([ds[i]])
         batch['point_frame_counts_host'] = np.diff(batch['point_frame_offsets']).tolist()
         load_data_to_gpu(batch)
         batch['point_frame_offsets'] = batch['point_frame_offsets'].int()
@@ -106,8 +105,8 @@ class CRBSampling(Strategy):
         was_training = getattr(ds, 'training', True)
         out = []
         w = model.roi_head.shared_fc_layer[4].weight
-        for k, i in enumerate(frame_indices):
-            loss = self.frame_loss(i, rec['rcnn_cls'][k], rec['rcnn_reg'][k])
+        for k, (i, batch) in enumerate(zip(frame_indices, self.iter_pool_batches(frame_indices, 1))):
+            loss = self.frame_loss(i, rec['rcnn_cls'][k], rec['rcnn_reg'][k], batch=batch)
             if self.PRUNED_BACKWARD:
                 # the embedding is d loss / d shared_fc_layer[4].weight only: autograd walks loss -> cls/reg layers -> FC stack
                 # and stops there; the reference's loss.backward() (crb_sampling.py:197) also back-propagates through the RoI
@@ -160,11 +159,16 @@ class CRBSampling(Strategy):
         mine2, _ = scoring.shard_indices(len(stage2_idx), rank, world)
         emb_local = self.grad_embeddings([stage2_idx[j] for j in mine2], records[[stage2_idx[j] for j in mine2]])
         emb = scoring.all_gather_rows(emb_local, len(stage2_idx), world)
+        torch.cuda.synchronize()
+        self.timings['stage2_embed_s'] = time.time() - t1
         k2n = min(int(select_nums * self.k2), len(stage2_idx))
-        if self.prototype != 'kmeans++':
+        if self.prototype == 'kmeans++':
+            from sklearn.cluster import kmeans_plusplus
+            _, sel = kmeans_plusplus(emb.cpu().numpy(), n_clusters=k2n, random_state=0)
+        elif self.prototype == 'kmeans++_device':
+            sel = scoring.kmeans_plusplus_device(emb, k2n, random_state=0).cpu().tolist()
+        else:
             raise NotImplementedError(self.prototype)
-        from sklearn.cluster import kmeans_plusplus
-        _, sel = kmeans_plusplus(emb.cpu().numpy(), n_clusters=k2n, random_state=0)
         cand_idx = [stage2_idx[i] for i in sel]
         torch.cuda.synchronize()
         self.timings['stage2_s'] = time.time() - t1

@@ -32,9 +32,13 @@ class PoolEvalStrategy(Strategy):
         return 0, 1
 
     def _batches(self, ds, frame_indices, batch_size):
-        for s in range(0, len(frame_indices), batch_size):
-            chunk = frame_indices[s:s + batch_size]
-            batch = ds.collate_batch([ds[i] for i in chunk])
+        if ds is self.unlabelled_set:
+            host = self.iter_pool_batches(frame_indices, batch_size)        # loader workers read ahead of the GPU
+        else:
+            host = (ds.collate_batch([ds[i] for i in frame_indices[s:s + batch_size]])
+                    for s in range(0, len(frame_indices), batch_size))
+        for k, batch in enumerate(host):
+            chunk = frame_indices[k * batch_size:(k + 1) * batch_size]
             if 'point_frame_offsets' in batch:
                 batch['point_frame_counts_host'] = np.diff(batch['point_frame_offsets']).tolist()
             load_data_to_gpu(batch)

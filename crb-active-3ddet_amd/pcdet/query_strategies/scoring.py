@@ -103,3 +103,58 @@ def density_greedy(densities, labels, xaxis, prior, bandwidth, select_nums):
                                  ptr(pr), float(bandwidth), int(select_nums), ptr(order), ptr(scores), ptr(ws), wsb,
                                  cur_stream(dev)), 'crb_density_greedy')
     return order, scores
+
+
+def kmeans_plusplus_device(X, n_clusters, random_state=0):
+    """k-means++ seeding (the reference's `sklearn.cluster.kmeans_plusplus(X, n_clusters, random_state=0)`,
+    crb_sampling.py:225-229) with the embeddings left on the device.
+
+    Restates sklearn 1.7's `_kmeans_plusplus` for float32 input step by step: the first centre and every trial position come
+    from the SAME numpy RandomState stream (drawn on the host: one `choice`, then `2 + int(log k)` uniforms per centre);
+    squared distances as sklearn's float32 path forms them (`_euclidean_distances_upcast`: -2 x.y + |x|^2 + |y|^2 in
+    float64, rounded to float32, clamped at 0); trial positions by searchsorted on the float64 cumulative sum; the trial with
+    the smallest float32 potential wins. The 500 x 65536 matrix never crosses PCIe and is not re-converted to float64 for
+    each of the 300 centres (10.5 s on the host for K1*N = 500, K2*N = 300).
+    Same picks as sklearn unless two trial potentials of one step tie within float32 summation noise (sums are taken in
+    another order) — selected with ACTIVE_TRAIN.ACTIVE_CONFIG.CLUSTERING = 'kmeans++_device'; 'kmeans++' keeps sklearn itself.
+    -> LongTensor (n_clusters,) of row indices, on X's device"""
+    assert X.dim() == 2 and X.dtype == torch.float32
+    n = X.shape[0]
+    if n < n_clusters:
+        raise ValueError(f'n_samples={n} should be >= n_clusters={n_clusters}.')
+    rs = np.random.RandomState(random_state) if not isinstance(random_state, np.random.RandomState) else random_state
+    n_local = 2 + int(np.log(n_clusters))
+    w = np.ones(n, dtype=np.float32)
+    first = int(rs.choice(n, p=w / w.sum()))
+    U = torch.from_numpy(rs.uniform(size=(max(n_clusters - 1, 0), n_local))).to(X.device)        # float64
+    X64 = X.double()
+    norms = (X64 * X64).sum(1)
+
+    # x.y for a handful of rows against all rows, K = 65536 deep: as one float64 GEMM it gets a few workgroups (10.5 ms per
+    # step on MI355X); cut into S slices of the K axis it is a batched GEMM + a sum over slices (0.09 ms)
+    dim = X.shape[1]
+    S = 64
+    while S > 1 and (dim % S or dim // S < 256):
+        S //= 2
+    Bs = X64.view(n, S, dim // S).permute(1, 2, 0)                         # (S, k, n) view
+
+    def sq_dist(rows):                                    # (t,) indices -> (t, n) float32
+        A = X64[rows].view(-1, S, dim // S).permute(1, 0, 2)               # (S, t, k)
+        d = -2.0 * torch.bmm(A, Bs).sum(0)
+        d += norms[rows][:, None]
+        d += norms[None, :]
+        return d.float().clamp_(min=0)
+
+    picks = torch.empty((n_clusters,), dtype=torch.long, device=X.device)
+    picks[0] = first
+    closest = sq_dist(picks[:1])[0]
+    pot = closest.sum()
+    for c in range(1, n_clusters):
+        rand_vals = U[c - 1] * pot.double()
+        cand = torch.searchsorted(torch.cumsum(closest.double(), 0), rand_vals).clamp_(max=n - 1)
+        dc = torch.minimum(closest[None, :], sq_dist(cand))
+        pots = dc.sum(1)
+        best = torch.argmin(pots)
+        pot, closest = pots[best], dc[best]
+        picks[c] = cand[best]
+    return picks

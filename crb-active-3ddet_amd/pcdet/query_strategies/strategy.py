@@ -24,6 +24,25 @@ class Strategy:
         else:
             self.pairs = list(zip(ds.frame_ids, ds.infos))
 
+    def iter_pool_batches(self, frame_indices, batch_size):
+        """host batches (collated like the loader's) of the given pool frames, in order. Frames are read and collated by as
+        many DataLoader workers as the caller gave `unlabelled_loader` (the reference iterates that loader itself,
+        crb_sampling.py:72-80), so reading / decoding the next frames overlaps the GPU work on the current ones; with
+        num_workers == 0 the frames are read inline."""
+        ds = self.unlabelled_set
+        workers = int(getattr(self.unlabelled_loader, 'num_workers', 0) or 0)
+        if not getattr(ds, 'device_voxelize', True):
+            workers = 0                     # a host-voxelising dataset calls the HIP voxelizer: not from forked workers
+        if workers > 0 and len(frame_indices) > batch_size:
+            from torch.utils.data import DataLoader, Subset
+            loader = DataLoader(Subset(ds, list(frame_indices)), batch_size=batch_size, shuffle=False,
+                                num_workers=min(workers, (len(frame_indices) + batch_size - 1) // batch_size),
+                                collate_fn=ds.collate_batch, pin_memory=False, drop_last=False, prefetch_factor=2)
+            yield from loader
+            return
+        for s in range(0, len(frame_indices), batch_size):
+            yield ds.collate_batch([ds[i] for i in frame_indices[s:s + batch_size]])
+
     def save_points(self, frame_id, batch_dict):
         self.bbox_records[frame_id] = batch_dict['num_bbox']
         self.mean_point_records[frame_id] = batch_dict['mean_points']

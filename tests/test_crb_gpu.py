@@ -75,6 +75,17 @@ def test_crb_query_end_to_end_small_pool(dev):
     e = build_strategy('entropy', model, build_synthetic_dataloader(lab, 2), build_synthetic_dataloader(pool, 4), 0,
                        '/tmp', cfg).query(cur_epoch=0)
     assert len(e) == 3
+    # pool frames read by the loader's worker processes (as the reference's DataLoader does) == read inline
+    w = build_strategy('crb', model, build_synthetic_dataloader(lab, 2), build_synthetic_dataloader(pool, 4, workers=2), 0,
+                       '/tmp', cfg)
+    host_a = list(strat.iter_pool_batches(list(range(3, 14)), 4))
+    host_b = list(w.iter_pool_batches(list(range(3, 14)), 4))
+    assert len(host_a) == len(host_b) == 3
+    for a, b in zip(host_a, host_b):
+        assert list(a['frame_id']) == list(b['frame_id'])
+        np.testing.assert_array_equal(np.asarray(a['points']), np.asarray(b['points']))
+        np.testing.assert_array_equal(np.asarray(a['point_frame_offsets']), np.asarray(b['point_frame_offsets']))
+    assert w.score_pool(list(range(3, 14)), 4).shape == (11, scoring.REC_STRIDE)
 
 
 def test_stage2_pruned_backward_equals_full_backward(dev):
@@ -166,3 +177,15 @@ def test_baseline_strategies_end_to_end_small_pool(dev):
             assert strat.last_embeddings.shape == (10, model.dense_head.conv_cls.weight.numel())
             assert float(strat.last_embeddings.abs().sum()) > 0
         assert len(strat.bbox_records) == 10                     # save_points bookkeeping of the eval pass
+
+
+def test_kmeans_plusplus_device_equals_sklearn_on_gradient_sized_embeddings(dev):
+    """stage-2 prototype selection on the device == sklearn.cluster.kmeans_plusplus(random_state=0) (the reference's call) at
+    the CRB shape class: rows of 65536 floats, heavy-tailed norms like gradient embeddings"""
+    from sklearn.cluster import kmeans_plusplus
+    from pcdet.query_strategies import scoring
+    rng = np.random.default_rng(11)
+    X = (rng.standard_normal((120, 65536)) * np.exp(rng.normal(0, 1.5, size=(120, 1)))).astype(np.float32)
+    _, want = kmeans_plusplus(X, n_clusters=72, random_state=0)
+    got = scoring.kmeans_plusplus_device(torch.from_numpy(X).to(dev), 72, random_state=0).cpu().numpy()
+    np.testing.assert_array_equal(got, want)

@@ -92,3 +92,18 @@ def test_label_entropy_matches_reference_formula():
     for b in range(4):
         exp = crb_oracle.label_entropy(labs[b][valid[b]], 3)
         assert abs(float(got[b]) - exp) < 1e-6
+
+
+@pytest.mark.parametrize('n,d,k,seed', [(200, 512, 60, 0), (500, 4096, 300, 1), (64, 33, 40, 2), (300, 1000, 7, 3)])
+def test_kmeans_plusplus_device_picks_equal_sklearn(n, d, k, seed):
+    """scoring.kmeans_plusplus_device (ACTIVE_TRAIN.ACTIVE_CONFIG.CLUSTERING = 'kmeans++_device') restates sklearn's k-means++ seeding —
+    the library call of the reference (crb_sampling.py:225-229) — with the same RandomState stream: identical picks, in
+    order, on float32 embeddings of very different norms (here on CPU tensors; the GPU test repeats it on the device)"""
+    from sklearn.cluster import kmeans_plusplus
+    from pcdet.query_strategies import scoring
+    rng = np.random.default_rng(seed)
+    X = (rng.standard_normal((n, d)) * rng.uniform(0.1, 3, size=(n, 1))).astype(np.float32)
+    _, want = kmeans_plusplus(X, n_clusters=k, random_state=0)
+    got = scoring.kmeans_plusplus_device(torch.from_numpy(X), k, random_state=0).numpy()
+    np.testing.assert_array_equal(got, want)
+    assert len(set(got.tolist())) == k
