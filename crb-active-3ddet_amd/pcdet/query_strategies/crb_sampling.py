@@ -76,13 +76,15 @@ class CRBSampling(Strategy):
         ds, model = self.unlabelled_set, self.model
         if batch is None:
             batch = ds.collate_batch([ds[i]])
-        batch['point_frame_counts_host'] = np.diff(batch['point_frame_offsets']).tolist()
-        load_data_to_gpu(batch)
-        batch['point_frame_offsets'] = batch['point_frame_offsets'].int()
+        if 'point_frame_counts_host' not in batch:          # host batch; device batches from _frame_batches are complete
+            batch['point_frame_counts_host'] = np.diff(batch['point_frame_offsets']).tolist()
+            load_data_to_gpu(batch)
+            batch['point_frame_offsets'] = batch['point_frame_offsets'].int()
         if self.SKIP_UNUSED_LOSSES and hasattr(model, 'module_list'):
             # the reference calls model(batch) (crb_sampling.py:181), which also evaluates the RPN / point / RCNN training
             # losses against the (absent) ground truth and then ignores them; only the forward pass matters here
-            if getattr(model, 'pfe', None) is not None and hasattr(model.pfe, 'prefetch_keypoints'):
+            if '_keypoints_prefetched' not in batch and getattr(model, 'pfe', None) is not None \
+                    and hasattr(model.pfe, 'prefetch_keypoints'):
                 model.pfe.prefetch_keypoints(batch)
             for mod in model.module_list:
                 batch = mod(batch)
@@ -93,6 +95,58 @@ class CRBSampling(Strategy):
         cls_loss, _ = model.roi_head.get_box_cls_layer_loss({'rcnn_cls': rcnn_cls, 'rcnn_cls_labels': rcnn_cls_labels})
         reg_loss = model.roi_head.get_box_reg_layer_loss({'rcnn_reg': rcnn_reg, 'reg_sample_targets': reg_sample_targets})
         return cls_loss + reg_loss.mean()
+
+    GROUP = 16          # stage 2: frames uploaded and farthest-point-sampled together (the passes stay bs=1)
+
+    def _frame_batches(self, frame_indices):
+        """bs=1 device batches of the given pool frames. Frames travel to the device GROUP at a time and their keypoints are
+        sampled in ONE launch on the side stream (one workgroup per frame, ~5 ms for the whole group): sampled frame by frame
+        the serial 2047-round selection was 5 ms of every 24 ms stage-2 pass."""
+        model = self.model
+        pfe = getattr(model, 'pfe', None)
+
+        def launch(group):                                   # upload + keypoint sampling of a whole group (asynchronous)
+            counts = np.diff(group['point_frame_offsets']).tolist()
+            group['point_frame_counts_host'] = counts
+            if isinstance(group.get('gt_boxes', None), np.ndarray):          # collate pads with all-zero rows
+                group['_gt_counts'] = [int((np.abs(g).sum(-1) > 0).sum()) for g in group['gt_boxes']]
+            load_data_to_gpu(group)
+            if pfe is not None and hasattr(pfe, 'prefetch_keypoints'):
+                pfe.prefetch_keypoints(group)
+            return group
+
+        def frames(group):
+            counts = group['point_frame_counts_host']
+            kp = group.pop('_keypoints_prefetched', None)
+            if kp is not None:
+                torch.cuda.current_stream(kp[0].device).wait_event(kp[1])      # sampled on the side stream
+                kp[0].record_stream(torch.cuda.current_stream(kp[0].device))
+            pts, K = group['points'], (kp[0].shape[0] // len(counts) if kp is not None else 0)
+            start = 0
+            for b, n in enumerate(counts):
+                p = pts[start:start + n].clone()
+                p[:, 0] = 0
+                one = {'points': p, 'batch_size': 1, 'point_frame_counts_host': [n],
+                       'point_frame_offsets': torch.tensor([0, n], dtype=torch.int32, device=p.device),
+                       'frame_id': group['frame_id'][b:b + 1]}
+                if 'gt_boxes' in group:
+                    g = group['gt_boxes'][b:b + 1]
+                    one['gt_boxes'] = g[:, :group['_gt_counts'][b]] if '_gt_counts' in group else g
+                if kp is not None:
+                    k = kp[0][b * K:(b + 1) * K].clone()
+                    k[:, 0] = 0
+                    one['_keypoints_prefetched'] = (k, kp[1])
+                start += n
+                yield one
+
+        prev = None                                          # the next group's sampling runs under this group's passes
+        for group in self.iter_pool_batches(frame_indices, self.GROUP):
+            group = launch(group)
+            if prev is not None:
+                yield from frames(prev)
+            prev = group
+        if prev is not None:
+            yield from frames(prev)
 
     # ---------------------------------------------------------------- stage 2
     def grad_embeddings(self, frame_indices, records):
@@ -105,7 +159,7 @@ class CRBSampling(Strategy):
         was_training = getattr(ds, 'training', True)
         out = []
         w = model.roi_head.shared_fc_layer[4].weight
-        for k, (i, batch) in enumerate(zip(frame_indices, self.iter_pool_batches(frame_indices, 1))):
+        for k, (i, batch) in enumerate(zip(frame_indices, self._frame_batches(frame_indices))):
             loss = self.frame_loss(i, rec['rcnn_cls'][k], rec['rcnn_reg'][k], batch=batch)
             if self.PRUNED_BACKWARD:
                 # the embedding is d loss / d shared_fc_layer[4].weight only: autograd walks loss -> cls/reg layers -> FC stack

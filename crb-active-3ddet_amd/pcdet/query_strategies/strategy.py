@@ -4,6 +4,19 @@ import os
 import pickle
 
 
+class _ListBatchSampler:
+    """batch sampler over an explicit list of index lists, replaced before every pass of a persistent-worker loader"""
+
+    def __init__(self):
+        self.batches = []
+
+    def __iter__(self):
+        return iter(self.batches)
+
+    def __len__(self):
+        return len(self.batches)
+
+
 class Strategy:
     def __init__(self, model, labelled_loader, unlabelled_loader, rank, active_label_dir, cfg):
         self.cfg = cfg
@@ -28,20 +41,26 @@ class Strategy:
         """host batches (collated like the loader's) of the given pool frames, in order. Frames are read and collated by as
         many DataLoader workers as the caller gave `unlabelled_loader` (the reference iterates that loader itself,
         crb_sampling.py:72-80), so reading / decoding the next frames overlaps the GPU work on the current ones; with
-        num_workers == 0 the frames are read inline."""
+        num_workers == 0 the frames are read inline. The worker processes are started once per strategy and reused by every
+        call (stage 1, stage 2, ...): forking them costs 2-3 s each time."""
         ds = self.unlabelled_set
+        frame_indices = list(frame_indices)
         workers = int(getattr(self.unlabelled_loader, 'num_workers', 0) or 0)
         if not getattr(ds, 'device_voxelize', True):
             workers = 0                     # a host-voxelising dataset calls the HIP voxelizer: not from forked workers
-        if workers > 0 and len(frame_indices) > batch_size:
-            from torch.utils.data import DataLoader, Subset
-            loader = DataLoader(Subset(ds, list(frame_indices)), batch_size=batch_size, shuffle=False,
-                                num_workers=min(workers, (len(frame_indices) + batch_size - 1) // batch_size),
-                                collate_fn=ds.collate_batch, pin_memory=False, drop_last=False, prefetch_factor=2)
-            yield from loader
+        batches = [frame_indices[s:s + batch_size] for s in range(0, len(frame_indices), batch_size)]
+        if workers > 0 and len(batches) > 1:
+            if getattr(self, '_pool_loader', None) is None:
+                from torch.utils.data import DataLoader
+                self._pool_batches = _ListBatchSampler()
+                self._pool_loader = DataLoader(ds, batch_sampler=self._pool_batches, num_workers=workers,
+                                               collate_fn=ds.collate_batch, pin_memory=False, prefetch_factor=2,
+                                               persistent_workers=True)
+            self._pool_batches.batches = batches
+            yield from self._pool_loader
             return
-        for s in range(0, len(frame_indices), batch_size):
-            yield ds.collate_batch([ds[i] for i in frame_indices[s:s + batch_size]])
+        for chunk in batches:
+            yield ds.collate_batch([ds[i] for i in chunk])
 
     def save_points(self, frame_id, batch_dict):
         self.bbox_records[frame_id] = batch_dict['num_bbox']

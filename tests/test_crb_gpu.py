@@ -189,3 +189,33 @@ def test_kmeans_plusplus_device_equals_sklearn_on_gradient_sized_embeddings(dev)
     _, want = kmeans_plusplus(X, n_clusters=72, random_state=0)
     got = scoring.kmeans_plusplus_device(torch.from_numpy(X).to(dev), 72, random_state=0).cpu().numpy()
     np.testing.assert_array_equal(got, want)
+
+
+def test_stage2_group_uploaded_frames_equal_single_frame_batches(dev):
+    """stage 2 uploads and farthest-point-samples pool frames a GROUP at a time but still runs bs=1 passes: every per-frame
+    device batch (points, gt boxes without the collate padding, keypoints) equals what the frame collated alone gives"""
+    from pcdet.datasets import SyntheticDataset, build_synthetic_dataloader
+    from pcdet.model_cfgs import pv_rcnn_cfg
+    from pcdet.models import build_network, load_data_to_gpu
+    from pcdet.query_strategies import build_strategy
+    cfg = pv_rcnn_cfg()
+    torch.manual_seed(0)
+    pool = SyntheticDataset(num_frames=8, first_frame=500)
+    model = build_network(cfg.MODEL, 3, pool).to(dev)
+    strat = build_strategy('crb', model, build_synthetic_dataloader(SyntheticDataset(num_frames=2), 2),
+                           build_synthetic_dataloader(pool, 2), 0, '/tmp', cfg)
+    strat.GROUP = 3                                            # 5 frames -> groups of 3 + 2, exercises the look-ahead
+    idx = [6, 0, 3, 4, 7]
+    got = list(strat._frame_batches(idx))
+    assert len(got) == len(idx)
+    for i, one in zip(idx, got):
+        ref = pool.collate_batch([pool[i]])
+        ref['point_frame_counts_host'] = np.diff(ref['point_frame_offsets']).tolist()
+        load_data_to_gpu(ref)
+        assert one['batch_size'] == 1 and list(one['frame_id']) == list(ref['frame_id'])
+        assert torch.equal(one['points'], ref['points'])
+        assert one['gt_boxes'].shape == ref['gt_boxes'].shape and torch.equal(one['gt_boxes'], ref['gt_boxes'])
+        assert one['point_frame_offsets'].tolist() == ref['point_frame_offsets'].int().tolist()
+        kp, done = one['_keypoints_prefetched']
+        torch.cuda.current_stream().wait_event(done)
+        assert torch.equal(kp, model.pfe.get_sampled_points(ref))
