@@ -62,6 +62,21 @@ class Strategy:
         for chunk in batches:
             yield ds.collate_batch([ds[i] for i in chunk])
 
+    def close(self):
+        """stop the pool loader's worker processes (they otherwise live as long as the strategy object)"""
+        loader = getattr(self, '_pool_loader', None)
+        if loader is not None:
+            it = getattr(loader, '_iterator', None)
+            if it is not None and hasattr(it, '_shutdown_workers'):
+                it._shutdown_workers()
+            self._pool_loader = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def save_points(self, frame_id, batch_dict):
         self.bbox_records[frame_id] = batch_dict['num_bbox']
         self.mean_point_records[frame_id] = batch_dict['mean_points']

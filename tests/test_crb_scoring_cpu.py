@@ -107,3 +107,28 @@ def test_kmeans_plusplus_device_picks_equal_sklearn(n, d, k, seed):
     got = scoring.kmeans_plusplus_device(torch.from_numpy(X), k, random_state=0).numpy()
     np.testing.assert_array_equal(got, want)
     assert len(set(got.tolist())) == k
+
+
+def test_pool_batches_from_persistent_loader_workers():
+    """Strategy.iter_pool_batches: frames collated by the unlabelled loader's worker processes (started once, re-used by the
+    next pass with another index list) == frames read inline, in the requested order"""
+    from pcdet.datasets import SyntheticDataset, build_synthetic_dataloader
+    from pcdet.model_cfgs import pv_rcnn_cfg
+    from pcdet.query_strategies.strategy import Strategy
+    ds = SyntheticDataset(num_frames=10, n_points=1500)
+    cfg = pv_rcnn_cfg()
+    inline = Strategy(None, build_synthetic_dataloader(ds, 2), build_synthetic_dataloader(ds, 4), 0, '/tmp', cfg)
+    st = Strategy(None, build_synthetic_dataloader(ds, 2), build_synthetic_dataloader(ds, 4, workers=2), 0, '/tmp', cfg)
+    try:
+        for idx, bs in (([9, 1, 3, 5, 7], 2), ([0, 2, 4, 6], 3), ([8], 4)):
+            a = list(inline.iter_pool_batches(idx, bs))
+            b = list(st.iter_pool_batches(idx, bs))
+            assert len(a) == len(b) == (len(idx) + bs - 1) // bs
+            for x, y in zip(a, b):
+                assert list(x['frame_id']) == list(y['frame_id'])
+                np.testing.assert_array_equal(np.asarray(x['points']), np.asarray(y['points']))
+                np.testing.assert_array_equal(np.asarray(x['gt_boxes']), np.asarray(y['gt_boxes']))
+        assert st._pool_loader is not None                      # workers kept between the passes
+    finally:
+        st.close()
+    assert st._pool_loader is None
