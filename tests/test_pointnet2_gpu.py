@@ -55,6 +55,12 @@ def test_ball_query_pair_equals_two_queries(dev):
     xc = _t(np.diff(off).astype(np.int32), dev)
     rng = np.random.default_rng(9)
     counts = (397, 3, 399)        # ragged: groups of 8 queries straddle frame boundaries, the last group is short
+    _check_ball_query_pair(dev, xyz, xc, off, rng, (402, 0, 397))     # a frame without queries
+    _check_ball_query_pair(dev, xyz, xc, off, rng, counts)
+
+
+def _check_ball_query_pair(dev, xyz, xc, off, rng, counts):
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as U
     new = torch.cat([xyz[off[b]:off[b + 1]][torch.from_numpy(rng.choice(7000, c, replace=False)).to(dev)]
                      for b, c in enumerate(counts)]).contiguous()
     new[::11] += 60.0
@@ -66,6 +72,13 @@ def test_ball_query_pair_equals_two_queries(dev):
         assert torch.equal(ia, ja) and torch.equal(ib, jb)
         assert torch.equal(ea.bool(), fa) and torch.equal(eb.bool(), fb)
         assert int(fa.sum()) >= 60
+        for r, n, got_i, got_e in ((ra, na, ia, ea), (rb, nb, ib, eb)):          # and the oracle (scan order, first-hit padding)
+            ref = oracle.ball_query(r, n, xyz.cpu().numpy(), xc.cpu().numpy(), new.cpu().numpy(),
+                                    np.asarray(counts, dtype=np.int32))
+            ref_empty = ref[:, 0] == -1
+            ref[ref_empty] = 0
+            np.testing.assert_array_equal(got_i.cpu().numpy(), ref)
+            np.testing.assert_array_equal(got_e.cpu().numpy().astype(bool), ref_empty)
 
 
 @pytest.mark.parametrize('n,m', [(20000, 2048), (4096, 512), (1000, 100), (777, 64), (37, 10), (30000, 300), (50000, 200)])
@@ -339,3 +352,64 @@ def test_fused_query_group_equals_query_and_group(dev):
     a.backward(g)
     b.backward(g[0].permute(1, 0, 2))
     torch.testing.assert_close(f1.grad, f2.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_training_sa_ops_full_size_properties(dev):
+    """size-independent checks of the training-path SA kernels at the PV-RCNN RoI-grid shape (16 x 128 x 216 queries x 16 samples
+    = 7.08 M rows x 64 channels, 1.8 GB per activation), where the CPU oracle would take minutes:
+    * gathered first layer: linear in the features and in the weight (rtol 1e-4 of the output scale), and its backward is the
+      adjoint of its forward, <y, G f> == <G^T y, f> and the same for the weight (relative 1e-4, float atomics / other order);
+    * BN+ReLU+max: invariant to the order of the rows inside a group and to a positive affine map of the input (BatchNorm
+      removes it), gradient rows sum to ~0 per channel (BatchNorm's backward projects the mean out)."""
+    from crbhip import bnrelu
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as U
+    torch.manual_seed(0)
+    B, NK, R, G3, C, H, ns = 16, 2048, 128, 216, 128, 64, 16
+    xyz = (torch.rand(B * NK, 3, device=dev) * torch.tensor([70.0, 80.0, 4.0], device=dev)).contiguous()
+    xc = torch.full((B,), NK, dtype=torch.int32, device=dev)
+    centres = xyz.view(B, NK, 3)[:, torch.randint(0, NK, (R,), device=dev)]
+    new = (centres[:, :, None, :] + (torch.rand(B, R, G3, 3, device=dev) - 0.5) * 4.0).reshape(-1, 3).contiguous()
+    nc = torch.full((B,), R * G3, dtype=torch.int32, device=dev)
+    ball = U.ball_query(1.6, ns, xyz, xc, new, nc)
+    f1 = torch.randn(B * NK, C, device=dev)
+    f2 = torch.randn(B * NK, C, device=dev)
+    w1 = torch.randn(H, 3 + C, device=dev) * 0.1
+    w2 = torch.randn(H, 3 + C, device=dev) * 0.1
+    fwd = lambda f, w: U.grouped_first_layer_rows(1.6, ns, xyz, xc, new, nc, f, w, ball=ball)
+    y11 = fwd(f1, w1)
+    assert y11.shape == (B * R * G3 * ns, H)
+    scale = float(y11.abs().max())
+    y0 = fwd(torch.zeros_like(f1), w1)                        # the offset term W1x (xyz_j - c_i): y is affine in f
+    d = fwd(2.0 * f1 - 0.5 * f2, w1) - (2.0 * y11 - 0.5 * fwd(f2, w1) - 0.5 * y0)
+    assert float(d.abs().max()) < 1e-4 * scale
+    d = fwd(f1, w1 + w2) - (y11 + fwd(f1, w2))
+    assert float(d.abs().max()) < 1e-4 * scale
+    del d
+    fa = f1.clone().requires_grad_(True)
+    wa = w1.clone().requires_grad_(True)
+    y = fwd(fa, wa)
+    go = torch.randn_like(y)
+    gf, gw = torch.autograd.grad(y, (fa, wa), go)
+    lhs = float((go.double() * y.detach().double()).sum())                       # <go, y>, y bilinear in (f | 1, w)
+    rhs_w = float((gw.double() * w1.double()).sum())                             # y is linear in w: <go, y> = <gw, w>
+    assert abs(lhs - rhs_w) < 1e-4 * max(1.0, abs(lhs))
+    rhs_f = float((gf.double() * f1.double()).sum()) + float((go.double() * y0.double()).sum())
+    assert abs(lhs - rhs_f) < 1e-4 * max(1.0, abs(lhs))
+    del y, gf, gw, fa, wa
+
+    bn = torch.nn.BatchNorm1d(H).to(dev).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.3, 0.3)
+    x = y11.detach().requires_grad_(True)
+    z = bnrelu.bn_relu_max_concat([x], [ns], [bn])
+    M = B * R * G3
+    assert z.shape == (M, H) and float(z.detach().min()) >= 0.0
+    perm = torch.argsort(torch.rand(M, ns, device=dev), dim=1)                   # shuffle the rows inside every group
+    xp = torch.gather(y11.view(M, ns, H), 1, perm[..., None].expand(-1, -1, H)).reshape(-1, H).contiguous()
+    zp = bnrelu.bn_relu_max_concat([xp], [ns], [bn])
+    assert float((zp - z.detach()).abs().max()) < 1e-5 * max(1.0, float(z.detach().abs().max()))  # statistics summed in another order
+    za = bnrelu.bn_relu_max_concat([(3.0 * y11 + 0.7).contiguous()], [ns], [bn])
+    assert float((za - z.detach()).abs().max()) < 2e-4 * max(1.0, float(z.detach().abs().max()))
+    gx, = torch.autograd.grad(z, x, torch.randn_like(z))
+    assert float(gx.sum(0).abs().max()) < 1e-3 * float(gx.abs().sum(0).max())
