@@ -260,6 +260,125 @@ __global__ __launch_bounds__(256) void ball_query2_multi_kernel(int B, int M, fl
   }
 }
 
+// Same contract again for queries that come in spatially compact GROUPS of `group` consecutive rows inside one frame (the
+// 216 grid points of one RoI, pvrcnn_head.py:97-132): one workgroup per group first keeps, in index order, the frame points
+// within (group radius + larger ball radius) of the group's centroid in LDS — a point outside that sphere cannot be in any
+// of the group's balls (triangle inequality, 0.1 % slack for rounding) — and every query then scans only those. At the
+// RoI-grid shape 2048 keypoints shrink to a few dozen candidates per RoI. Index-exact with ball_query2_kernel: the candidate
+// list preserves the scan order. A group whose candidates do not fit GQ_CAP falls back to scanning the frame.
+constexpr int GQ_CAP = 2048;
+
+__global__ __launch_bounds__(256) void ball_query2_grouped_kernel(int B, int M, int group, float ra, int nsa, float rb, int nsb,
+                                                                  const float* __restrict__ new_xyz,
+                                                                  const int* __restrict__ new_cnt,
+                                                                  const float* __restrict__ xyz, const int* __restrict__ xyz_cnt,
+                                                                  int* __restrict__ idx_a, int* __restrict__ idx_b,
+                                                                  unsigned char* __restrict__ empty_a,
+                                                                  unsigned char* __restrict__ empty_b) {
+  __shared__ float cpos[GQ_CAP][3];
+  __shared__ int cidx[GQ_CAP];
+  __shared__ float red[4][4];
+  __shared__ int wcount[4];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int q0 = blockIdx.x * group;
+  int start;
+  const int b = locate_batch(new_cnt, B, q0, xyz_cnt, &start);
+  const int n = xyz_cnt[b];
+  const float* p = xyz + (int64_t)start * 3;
+  const unsigned long long below = (1ULL << lane) - 1ULL;
+
+  // centroid and radius of the group (group <= 1024: strided over the threads)
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int t = threadIdx.x; t < group; t += 256) {
+    sx += new_xyz[(int64_t)(q0 + t) * 3 + 0]; sy += new_xyz[(int64_t)(q0 + t) * 3 + 1]; sz += new_xyz[(int64_t)(q0 + t) * 3 + 2];
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { sx += __shfl_xor(sx, d); sy += __shfl_xor(sy, d); sz += __shfl_xor(sz, d); }
+  if (lane == 0) { red[wave][0] = sx; red[wave][1] = sy; red[wave][2] = sz; }
+  __syncthreads();
+  const float cx = (red[0][0] + red[1][0] + red[2][0] + red[3][0]) / (float)group;
+  const float cy = (red[0][1] + red[1][1] + red[2][1] + red[3][1]) / (float)group;
+  const float cz = (red[0][2] + red[1][2] + red[2][2] + red[3][2]) / (float)group;
+  float r2 = 0.f;
+  for (int t = threadIdx.x; t < group; t += 256) {
+    const float dx = new_xyz[(int64_t)(q0 + t) * 3 + 0] - cx, dy = new_xyz[(int64_t)(q0 + t) * 3 + 1] - cy,
+                dz = new_xyz[(int64_t)(q0 + t) * 3 + 2] - cz;
+    r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, d));
+  if (lane == 0) red[wave][3] = r2;
+  __syncthreads();
+  const float R = sqrtf(fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3])));
+  const float rmax = fmaxf(ra, rb);
+  const float keep2 = (R + rmax) * (R + rmax) * 1.002f + 1e-6f;
+
+  // order-preserving compaction of the frame points inside the sphere
+  int total = 0;
+  bool overflow = false;
+  for (int k0 = 0; k0 < n; k0 += 256) {
+    const int k = k0 + threadIdx.x;
+    float x = 0.f, y = 0.f, z = 0.f;
+    bool keep = false;
+    if (k < n) {
+      x = p[k * 3 + 0]; y = p[k * 3 + 1]; z = p[k * 3 + 2];
+      keep = (x - cx) * (x - cx) + (y - cy) * (y - cy) + (z - cz) * (z - cz) <= keep2;
+    }
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wcount[wave] = __popcll(m);
+    __syncthreads();
+    int off = total;
+    for (int w = 0; w < wave; ++w) off += wcount[w];
+    const int step_total = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    const int pos = off + __popcll(m & below);
+    if (keep && pos < GQ_CAP) { cidx[pos] = k; cpos[pos][0] = x; cpos[pos][1] = y; cpos[pos][2] = z; }
+    total += step_total;
+    __syncthreads();
+  }
+  overflow = total > GQ_CAP;
+  const int nc = overflow ? n : total;
+  const float ra2 = ra * ra, rb2 = rb * rb;
+  for (int t = wave; t < group; t += 4) {
+    const int q = q0 + t;
+    const float qx = new_xyz[(int64_t)q * 3 + 0], qy = new_xyz[(int64_t)q * 3 + 1], qz = new_xyz[(int64_t)q * 3 + 2];
+    int* oa = idx_a + (int64_t)q * nsa;
+    int* ob = idx_b + (int64_t)q * nsb;
+    int ca = 0, cb = 0, fa = -1, fb = -1;
+    for (int k0 = 0; k0 < nc && (ca < nsa || cb < nsb); k0 += 64) {
+      const int k = k0 + lane;
+      bool ha = false, hb = false;
+      int gi = 0;
+      if (k < nc) {
+        float x, y, z;
+        if (overflow) { gi = k; x = p[k * 3 + 0]; y = p[k * 3 + 1]; z = p[k * 3 + 2]; }
+        else { gi = cidx[k]; x = cpos[k][0]; y = cpos[k][1]; z = cpos[k][2]; }
+        const float d2 = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z);
+        ha = d2 < ra2;
+        hb = d2 < rb2;
+      }
+      const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
+      if (ma != 0ULL && ca < nsa) {
+        if (fa < 0) fa = __shfl(gi, __ffsll((long long)ma) - 1);
+        const int pos = ca + __popcll(ma & below);
+        if (ha && pos < nsa) oa[pos] = gi;
+        ca += __popcll(ma);
+      }
+      if (mb != 0ULL && cb < nsb) {
+        if (fb < 0) fb = __shfl(gi, __ffsll((long long)mb) - 1);
+        const int pos = cb + __popcll(mb & below);
+        if (hb && pos < nsb) ob[pos] = gi;
+        cb += __popcll(mb);
+      }
+    }
+    ca = ca > nsa ? nsa : ca;
+    cb = cb > nsb ? nsb : cb;
+    for (int l = ca + lane; l < nsa; l += 64) oa[l] = (fa >= 0) ? fa : 0;
+    for (int l = cb + lane; l < nsb; l += 64) ob[l] = (fb >= 0) ? fb : 0;
+    if (lane == 0) { empty_a[q] = fa < 0; empty_b[q] = fb < 0; }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ grouping
 // out (M, C, ns) ; one workgroup per centre; LDS slab (ns, C+1)
 __global__ __launch_bounds__(256) void group_points_kernel(int B, int M, int C, int ns, const float* __restrict__ feat,
@@ -912,6 +1031,20 @@ extern "C" int crb_ball_query2_stack(int B, int64_t M, float radius_a, int nsamp
                        nsample_a, radius_b, nsample_b, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx_a, idx_b,
                        empty_a, empty_b);
   }
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_ball_query2_grouped_stack(int B, int64_t M, int group, float radius_a, int nsample_a, float radius_b,
+                                             int nsample_b, const float* new_xyz, const int32_t* new_xyz_batch_cnt,
+                                             const float* xyz, const int32_t* xyz_batch_cnt, int32_t* idx_a, int32_t* idx_b,
+                                             uint8_t* empty_a, uint8_t* empty_b, void* stream) {
+  if (B <= 0 || M < 0 || nsample_a <= 0 || nsample_b <= 0 || M >= (1LL << 31)) return CRB_ERR_ARG;
+  if (group <= 0 || group > 1024 || M % group) return CRB_ERR_ARG;
+  if (M == 0) return CRB_OK;
+  hipLaunchKernelGGL(ball_query2_grouped_kernel, dim3((unsigned)(M / group)), dim3(256), 0, (hipStream_t)stream, B, (int)M,
+                     group, radius_a, nsample_a, radius_b, nsample_b, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx_a,
+                     idx_b, empty_a, empty_b);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

@@ -73,7 +73,8 @@ class PVRCNNHead(RoIHeadTemplate):
         new_xyz = grid_pts.view(-1, 3)
         new_xyz_batch_cnt = xyz_batch_cnt.new_full((batch_size,), grid_pts.shape[1])
         _, pooled = self.roi_grid_pool_layer(xyz=xyz.contiguous(), xyz_batch_cnt=xyz_batch_cnt, new_xyz=new_xyz.contiguous(),
-                                             new_xyz_batch_cnt=new_xyz_batch_cnt, features=point_features.contiguous())
+                                             new_xyz_batch_cnt=new_xyz_batch_cnt, features=point_features.contiguous(),
+                                             query_group=G ** 3)      # the G^3 grid points of a RoI are consecutive rows
         return pooled.view(-1, G ** 3, pooled.shape[-1])
 
     def get_global_grid_points_of_roi(self, rois, grid_size):

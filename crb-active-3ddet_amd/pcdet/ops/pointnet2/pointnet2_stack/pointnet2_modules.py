@@ -95,26 +95,26 @@ class StackSAModuleMSG(nn.Module):
         w2t, b2 = fold_conv_bn(mods[3], mods[4], _transpose_second_layer)
         return w1x, w1f_t, b1, w2t, b2
 
-    def _forward_fused_eval(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features):
+    def _forward_fused_eval(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, query_group=None):
         folded = [self._folded_pair(m) for m in self.mlps]
         if any(f is None or not pointnet2_utils.sa_mlp2_max_supported(f[3].shape[0], f[3].shape[1]) for f in folded):
             return None
         widths = [f[3].shape[1] for f in folded]
         out = torch.empty((new_xyz.shape[0], sum(widths)), dtype=torch.float32, device=xyz.device)
         col = 0
-        balls = self._balls(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+        balls = self._balls(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, query_group)
         for grouper, f, w, ball in zip(self.groupers, folded, widths, balls):
             pointnet2_utils.sa_mlp2_max(grouper.radius, grouper.nsample, xyz, xyz_batch_cnt, new_xyz,
                                         new_xyz_batch_cnt, features, *f, out[:, col:col + w], ball=ball)
             col += w
         return out
 
-    def _balls(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt):
+    def _balls(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, query_group=None):
         """ball queries of all scales; two scales share one scan of the points (crb_ball_query2_stack)"""
         gs = list(self.groupers)
         if len(gs) == 2:
             return pointnet2_utils.ball_query_pair(gs[0].radius, gs[0].nsample, gs[1].radius, gs[1].nsample, xyz,
-                                                   xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+                                                   xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, group=query_group)
         return [None] * len(gs)
 
     @staticmethod
@@ -132,18 +132,21 @@ class StackSAModuleMSG(nn.Module):
                 return False
         return True
 
-    def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None, empty_voxel_set_zeros=True):
-        """xyz (N,3), features (N,C), new_xyz (M,3) -> new_xyz, new_features (M, sum C_out)"""
+    def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None, empty_voxel_set_zeros=True,
+                query_group=None):
+        """xyz (N,3), features (N,C), new_xyz (M,3) -> new_xyz, new_features (M, sum C_out). query_group (not in the reference
+        signature): the caller's promise that new_xyz comes in spatially compact groups of that many consecutive rows inside
+        one frame; only lets the ball query prefilter per group, the result does not depend on it."""
         if FUSED_SA_EVAL and not self.training and not torch.is_grad_enabled() and features is not None \
                 and xyz.is_cuda and self.pool_method == 'max_pool' and all(g.use_xyz for g in self.groupers):
-            fused = self._forward_fused_eval(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features)
+            fused = self._forward_fused_eval(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, query_group)
             if fused is not None:
                 return new_xyz, fused
         outs = []
         if ROWS_TRAIN and features is not None and xyz.is_cuda and self.pool_method == 'max_pool' \
                 and all(g.use_xyz for g in self.groupers) and all(self._rows_ok(m, features) for m in self.mlps):
             M = new_xyz.shape[0]
-            balls = self._balls(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+            balls = self._balls(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, query_group)
             fuse_max = FUSED_BN_MAX and self.training and M > 0 and \
                 all(list(m)[-2].training and list(m)[-2].momentum is not None for m in self.mlps)
             for grouper, mlp, ball in zip(self.groupers, self.mlps, balls):

@@ -39,9 +39,11 @@ ball_query = BallQuery.apply
 
 
 @torch.no_grad()
-def ball_query_pair(radius_a, nsample_a, radius_b, nsample_b, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt):
+def ball_query_pair(radius_a, nsample_a, radius_b, nsample_b, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, group=None):
     """both radii of a StackSAModuleMSG in one scan -> ((idx_a, empty_a), (idx_b, empty_b)), the same values as two
-    ball_query calls (idx int32 with empty balls zeroed, empty as uint8)"""
+    ball_query calls (idx int32 with empty balls zeroed, empty as uint8). `group`: the queries come in spatially compact groups
+    of that many consecutive rows, none straddling a frame (RoI grid points): crb_ball_query2_grouped_stack prefilters the
+    frame's points per group — same result."""
     require_cuda(xyz, new_xyz)
     xyz, new_xyz = xyz.contiguous(), new_xyz.contiguous()
     B, M, dev = xyz_batch_cnt.shape[0], new_xyz.shape[0], xyz.device
@@ -49,6 +51,12 @@ def ball_query_pair(radius_a, nsample_a, radius_b, nsample_b, xyz, xyz_batch_cnt
     ib = torch.empty((M, nsample_b), dtype=torch.int32, device=dev)
     ea = torch.empty((M,), dtype=torch.uint8, device=dev)
     eb = torch.empty((M,), dtype=torch.uint8, device=dev)
+    if group and 0 < group <= 1024 and M % group == 0:
+        check(lib.crb_ball_query2_grouped_stack(B, M, int(group), float(radius_a), int(nsample_a), float(radius_b),
+                                                int(nsample_b), ptr(new_xyz), ptr(_i32(new_xyz_batch_cnt)), ptr(xyz),
+                                                ptr(_i32(xyz_batch_cnt)), ptr(ia), ptr(ib), ptr(ea), ptr(eb),
+                                                cur_stream(dev)), 'crb_ball_query2_grouped_stack')
+        return (ia, ea), (ib, eb)
     check(lib.crb_ball_query2_stack(B, M, float(radius_a), int(nsample_a), float(radius_b), int(nsample_b), ptr(new_xyz),
                                     ptr(_i32(new_xyz_batch_cnt)), ptr(xyz), ptr(_i32(xyz_batch_cnt)), ptr(ia), ptr(ib),
                                     ptr(ea), ptr(eb), cur_stream(dev)), 'crb_ball_query2_stack')

@@ -413,3 +413,32 @@ def test_training_sa_ops_full_size_properties(dev):
     assert float((za - z.detach()).abs().max()) < 2e-4 * max(1.0, float(z.detach().abs().max()))
     gx, = torch.autograd.grad(z, x, torch.randn_like(z))
     assert float(gx.sum(0).abs().max()) < 1e-3 * float(gx.abs().sum(0).max())
+
+
+def test_grouped_ball_query_equals_ungrouped(dev):
+    """crb_ball_query2_grouped_stack (per-group bounding-sphere prefilter, RoI grid pooling) returns the index lists and empty
+    flags of crb_ball_query2_stack bit for bit: compact groups (RoI-like), groups as large as the frame (every point a
+    candidate -> the fallback scan when more than 2048 candidates), frames with different numbers of groups, ra > rb"""
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as U
+    rng = np.random.default_rng(3)
+    seen_empty = seen_full = 0
+    for n_pts, group, groups_per_frame, spread in ((2048, 216, (7, 0, 12, 3), 2.0), (6000, 64, (5, 9), 300.0),
+                                                  (1500, 216, (4, 4, 4), 1.0), (700, 1000, (1, 2), 30.0)):
+        B = len(groups_per_frame)
+        xyz = (rng.random((B * n_pts, 3)) * np.array([70.0, 80.0, 4.0])).astype(np.float32)
+        xc = np.full((B,), n_pts, np.int32)
+        new = []
+        for b, g in enumerate(groups_per_frame):
+            for _ in range(g):
+                c = xyz[b * n_pts + rng.integers(0, n_pts)]
+                new.append(c + (rng.random((group, 3)).astype(np.float32) - 0.5) * spread)
+        new = np.concatenate(new).astype(np.float32)
+        nc = np.array([g * group for g in groups_per_frame], np.int32)
+        for (ra, na, rb, nb) in ((0.8, 16, 1.6, 16), (1.6, 16, 0.8, 32), (2.4, 5, 2.4, 64)):
+            args = (ra, na, rb, nb, _t(xyz, dev), _t(xc, dev), _t(new, dev), _t(nc, dev))
+            (ia, ea), (ib, eb) = U.ball_query_pair(*args)
+            (ja, fa), (jb, fb) = U.ball_query_pair(*args, group=group)
+            assert torch.equal(ia, ja) and torch.equal(ib, jb) and torch.equal(ea, fa) and torch.equal(eb, fb)
+            seen_empty += int(ea.sum())
+            seen_full += int((ea == 0).sum())
+    assert seen_empty > 100 and seen_full > 100
