@@ -4,7 +4,7 @@ kernels in csrc/iou3d_nms.hip. Same function names / argument meaning / return v
 Extra (no host synchronisation, fixed-size output): nms_gpu_padded, nms_batched."""
 import torch
 
-from crbhip import lib, check, ptr, cur_stream, require_cuda, CrbHipError
+from crbhip import lib, check, ptr, cur_stream, require_cuda
 from ...utils import common_utils
 
 

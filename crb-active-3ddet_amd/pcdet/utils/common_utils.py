@@ -1,6 +1,5 @@
 """Pure-torch geometry / bookkeeping helpers with the reference's names (pcdet/utils/common_utils.py)."""
 import logging
-import os
 import random
 
 import numpy as np
