@@ -282,9 +282,10 @@ __global__ __launch_bounds__(256) void ball_query2_grouped_kernel(int B, int M, 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int q0 = blockIdx.x * group;
-  int start;
+  int start, start_last;
   const int b = locate_batch(new_cnt, B, q0, xyz_cnt, &start);
-  const int n = xyz_cnt[b];
+  const bool straddle = locate_batch(new_cnt, B, q0 + group - 1, xyz_cnt, &start_last) != b;   // caller broke its promise
+  int n = xyz_cnt[b];
   const float* p = xyz + (int64_t)start * 3;
   const unsigned long long below = (1ULL << lane) - 1ULL;
 
@@ -336,11 +337,18 @@ __global__ __launch_bounds__(256) void ball_query2_grouped_kernel(int B, int M, 
     total += step_total;
     __syncthreads();
   }
-  overflow = total > GQ_CAP;
-  const int nc = overflow ? n : total;
+  overflow = total > GQ_CAP || straddle;          // a group across two frames: every query scans its own frame
+  int nc = overflow ? n : total;
   const float ra2 = ra * ra, rb2 = rb * rb;
   for (int t = wave; t < group; t += 4) {
     const int q = q0 + t;
+    if (straddle) {
+      int st;
+      const int bq = locate_batch(new_cnt, B, q, xyz_cnt, &st);
+      n = xyz_cnt[bq];
+      nc = n;
+      p = xyz + (int64_t)st * 3;
+    }
     const float qx = new_xyz[(int64_t)q * 3 + 0], qy = new_xyz[(int64_t)q * 3 + 1], qz = new_xyz[(int64_t)q * 3 + 2];
     int* oa = idx_a + (int64_t)q * nsa;
     int* ob = idx_b + (int64_t)q * nsb;

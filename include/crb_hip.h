@@ -182,7 +182,8 @@ int crb_ball_query2_stack(int B, int64_t M, float radius_a, int nsample_a, float
                           const int32_t* xyz_batch_cnt, int32_t* idx_a, int32_t* idx_b, uint8_t* empty_a,
                           uint8_t* empty_b, void* stream);
 /* crb_ball_query2_stack for queries that come in spatially compact groups of `group` consecutive rows inside one frame
- * (every new_xyz_batch_cnt[b] a multiple of `group`; the 216 grid points of one RoI in PVRCNNHead.roi_grid_pool,
+ * (every new_xyz_batch_cnt[b] a multiple of `group` for the fast path; a group that straddles two frames is still answered
+ * correctly, by a per-query scan; the 216 grid points of one RoI in PVRCNNHead.roi_grid_pool,
  * pvrcnn_head.py:97-132, feeding pointnet2_utils.py:31-38): one workgroup per group prefilters the frame's points by the
  * group's bounding sphere, same index lists as crb_ball_query2_stack. */
 int crb_ball_query2_grouped_stack(int B, int64_t M, int group, float radius_a, int nsample_a, float radius_b, int nsample_b,

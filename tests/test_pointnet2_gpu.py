@@ -442,3 +442,13 @@ def test_grouped_ball_query_equals_ungrouped(dev):
             seen_empty += int(ea.sum())
             seen_full += int((ea == 0).sum())
     assert seen_empty > 100 and seen_full > 100
+    # a caller that breaks the "no group straddles a frame" promise still gets the ungrouped result (slow path)
+    xyz = (rng.random((2 * 900, 3)) * np.array([30.0, 30.0, 4.0])).astype(np.float32)
+    new = xyz[rng.choice(1800, 432, replace=False)] + 0.1
+    for counts in ((100, 332), (300, 132)):
+        new_s = np.concatenate([new[:counts[0]] % np.array([30, 30, 4], np.float32), new[counts[0]:]]).astype(np.float32)
+        args = (0.9, 16, 1.8, 16, _t(xyz, dev), _t(np.array([900, 900], np.int32), dev), _t(new_s, dev),
+                _t(np.array(counts, np.int32), dev))
+        (ia, ea), (ib, eb) = U.ball_query_pair(*args)
+        (ja, fa), (jb, fb) = U.ball_query_pair(*args, group=216)
+        assert torch.equal(ia, ja) and torch.equal(ib, jb) and torch.equal(ea, fa) and torch.equal(eb, fb)
