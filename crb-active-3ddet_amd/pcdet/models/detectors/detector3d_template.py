@@ -34,6 +34,31 @@ class Detector3DTemplate(nn.Module):
     def update_global_step(self):
         self.global_step += 1
 
+    def run_modules(self, batch_dict):
+        """the detector's module chain on one batch (what every reference detector's forward() starts with); a PFE that can
+        sample its keypoints ahead of time is told to start as soon as the points are known"""
+        pfe_mod = getattr(self, 'pfe', None)
+        if pfe_mod is not None and hasattr(pfe_mod, 'prefetch_keypoints'):
+            pfe_mod.prefetch_keypoints(batch_dict)             # FPS on a side stream, joined inside the PFE
+        for stage in self.module_list:
+            batch_dict = stage(batch_dict)
+        return batch_dict
+
+    def forward(self, batch_dict):
+        """training: ({'loss': ..., + training_outputs()}, tb_dict, disp_dict); inference: post_processing's (pred_dicts,
+        recall_dicts) — the contract of the reference detectors' forward()"""
+        batch_dict = self.run_modules(batch_dict)
+        if not self.training:
+            return self.post_processing(batch_dict)
+        loss, tb_dict, disp_dict = self.get_training_loss()
+        ret = {'loss': loss}
+        ret.update(self.training_outputs(batch_dict))
+        return ret, tb_dict, disp_dict
+
+    def training_outputs(self, batch_dict):
+        """extra entries of the training-mode return dict (detector specific)"""
+        return {}
+
     def build_networks(self):
         ds = self.dataset
         info = {
@@ -153,10 +178,6 @@ class Detector3DTemplate(nn.Module):
         model_info_dict['module_list'].append(m)
         return m, model_info_dict
 
-    def forward(self, **kwargs):
-        raise NotImplementedError
-
-    # ------------------------------------------------------------------------------------------------
     def post_processing(self, batch_dict):
         from .post_processing import crb_post_processing
         return crb_post_processing(self, batch_dict)

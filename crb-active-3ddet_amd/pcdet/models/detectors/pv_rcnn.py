@@ -1,4 +1,6 @@
-"""PVRCNN (pcdet/models/detectors/pv_rcnn.py:4-43)."""
+"""PVRCNN (pcdet/models/detectors/pv_rcnn.py:4-43): two-stage detector = RPN (dense head) + keypoint head + RoI head.
+forward() is Detector3DTemplate.forward; this class only says how the three losses combine and which second-stage tensors the
+training-mode return dict carries (the active-learning code reads them)."""
 from .detector3d_template import Detector3DTemplate
 
 
@@ -7,28 +9,15 @@ class PVRCNN(Detector3DTemplate):
         super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
         self.module_list = self.build_networks()
 
-    def forward(self, batch_dict):
-        if getattr(self, 'pfe', None) is not None and hasattr(self.pfe, 'prefetch_keypoints'):
-            self.pfe.prefetch_keypoints(batch_dict)          # FPS on a side stream, joined inside the PFE
-        for cur_module in self.module_list:
-            batch_dict = cur_module(batch_dict)
-        if self.training:
-            loss, tb_dict, disp_dict = self.get_training_loss()
-            ret_dict = {
-                'loss': loss,
-                'rcnn_reg_gt': self.roi_head.forward_ret_dict['rcnn_reg_gt'],
-                'rcnn_cls_gt': self.roi_head.forward_ret_dict['rcnn_cls_labels'],
-                'rcnn_cls': batch_dict['rcnn_cls'],
-                'rcnn_reg': batch_dict['rcnn_reg'],
-                'rpn_preds': batch_dict['rpn_preds'],
-            }
-            return ret_dict, tb_dict, disp_dict
-        pred_dicts, recall_dicts = self.post_processing(batch_dict)
-        return pred_dicts, recall_dicts
+    def training_outputs(self, batch_dict):
+        head = self.roi_head.forward_ret_dict
+        return {'rcnn_reg_gt': head['rcnn_reg_gt'], 'rcnn_cls_gt': head['rcnn_cls_labels'],
+                'rcnn_cls': batch_dict['rcnn_cls'], 'rcnn_reg': batch_dict['rcnn_reg'],
+                'rpn_preds': batch_dict['rpn_preds']}
 
     def get_training_loss(self):
-        disp_dict = {}
-        loss_rpn, tb_dict = self.dense_head.get_loss()
-        loss_point, tb_dict = self.point_head.get_loss(tb_dict)
-        loss_rcnn, tb_dict = self.roi_head.get_loss(tb_dict)
-        return loss_rpn + loss_point + loss_rcnn, tb_dict, disp_dict
+        total, tb_dict = self.dense_head.get_loss()
+        for head in (self.point_head, self.roi_head):
+            part, tb_dict = head.get_loss(tb_dict)
+            total = total + part
+        return total, tb_dict, {}

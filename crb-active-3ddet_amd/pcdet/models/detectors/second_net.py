@@ -1,4 +1,5 @@
-"""SECONDNet (pcdet/models/detectors/second_net.py:4-34)."""
+"""SECONDNet (pcdet/models/detectors/second_net.py:4-34): one-stage detector, the loss is the dense head's.
+forward() is Detector3DTemplate.forward."""
 from .detector3d_template import Detector3DTemplate
 
 
@@ -7,17 +8,6 @@ class SECONDNet(Detector3DTemplate):
         super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
         self.module_list = self.build_networks()
 
-    def forward(self, batch_dict):
-        for cur_module in self.module_list:
-            batch_dict = cur_module(batch_dict)
-        if self.training:
-            loss, tb_dict, disp_dict = self.get_training_loss()
-            return {'loss': loss}, tb_dict, disp_dict
-        pred_dicts, recall_dicts = self.post_processing(batch_dict)
-        return pred_dicts, recall_dicts
-
     def get_training_loss(self):
-        disp_dict = {}
         loss_rpn, tb_dict = self.dense_head.get_loss()
-        tb_dict = {'loss_rpn': loss_rpn.detach(), **tb_dict}
-        return loss_rpn, tb_dict, disp_dict
+        return loss_rpn, dict(tb_dict, loss_rpn=loss_rpn.detach()), {}
