@@ -248,7 +248,7 @@ def main():
     ds = SyntheticDataset(num_frames=args.batch, kind=args.kind, n_points=args.points)
     model = build_network(second_cfg(args.kind).MODEL, 3, ds).to(device)
     model.train()
-    opt = torch.optim.AdamW(model.parameters(), lr=3e-3, weight_decay=0.01, betas=(0.9, 0.99))
+    opt = torch.optim.AdamW(model.parameters(), lr=3e-3, weight_decay=0.01, betas=(0.9, 0.99), fused=True)   # one multi-tensor kernel (0.23 vs 0.42 ms for the 84 tensors)
     net = model
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_idx], gradient_as_bucket_view=True)
