@@ -93,3 +93,35 @@ def test_nms_normal_and_batched_padded(dev):
                                   rotated=True)
     r = oracle.nms(boxes[3, :333], 0.3)[:50]
     np.testing.assert_array_equal(idx.cpu().numpy()[valid.cpu().numpy()], r)
+
+
+def test_model_nms_utils_contract(dev):
+    """class_agnostic_nms / multi_classes_nms (model_nms_utils.py:6-66): selected indices refer to the INPUT arrays, scores come
+    back with them, per-class results are concatenated in class order — checked against the oracle NMS applied to the
+    thresholded, score-sorted, NMS_PRE_MAXSIZE-capped boxes; plus the empty cases"""
+    from pcdet.config import EasyDict
+    from pcdet.models.model_utils import model_nms_utils as M
+    rng = np.random.default_rng(5)
+    n = 600
+    b, _ = detection_boxes(rng, n, n_obj=40)
+    s = ((rng.permutation(n) + 1) / np.float32(n + 1)).astype(np.float32)
+    cfg = EasyDict({'NMS_TYPE': 'nms_gpu', 'NMS_THRESH': 0.3, 'NMS_PRE_MAXSIZE': 256, 'NMS_POST_MAXSIZE': 50})
+
+    def expect(scores, thresh):
+        cand = np.nonzero(scores >= thresh)[0] if thresh is not None else np.arange(len(scores))
+        cand = cand[np.argsort(-scores[cand], kind='stable')][:cfg.NMS_PRE_MAXSIZE]
+        return cand[oracle.nms(b[cand], cfg.NMS_THRESH)][:cfg.NMS_POST_MAXSIZE]
+
+    for thresh in (None, 0.35):
+        sel, sc = M.class_agnostic_nms(_t(s, dev), _t(b, dev), cfg, score_thresh=thresh)
+        want = expect(s, thresh)
+        np.testing.assert_array_equal(sel.cpu().numpy(), want)
+        np.testing.assert_array_equal(sc.cpu().numpy(), s[want])
+    sel, sc = M.class_agnostic_nms(_t(s, dev), _t(b, dev), cfg, score_thresh=2.0)         # nothing passes
+    assert len(sel) == 0 and len(sc) == 0
+    cls = np.stack([s, s[::-1].copy(), np.zeros_like(s)], 1)
+    ps, pl, pb = M.multi_classes_nms(_t(cls, dev), _t(b, dev), cfg, score_thresh=0.5)
+    w0, w1 = expect(cls[:, 0], 0.5), expect(cls[:, 1], 0.5)
+    np.testing.assert_array_equal(pl.cpu().numpy(), np.r_[np.zeros(len(w0), np.int64), np.ones(len(w1), np.int64)])
+    np.testing.assert_array_equal(ps.cpu().numpy(), np.r_[cls[w0, 0], cls[w1, 1]])
+    np.testing.assert_array_equal(pb.cpu().numpy(), np.r_[b[w0], b[w1]])
