@@ -211,6 +211,50 @@ def ref_boxes_iou_bev(boxes_a, boxes_b):
     return out
 
 
+def _ref_roiaware_path():
+    import sysconfig
+    return os.path.join(_HERE, '_ref', 'roiaware_pool3d_ref' + sysconfig.get_config_var('EXT_SUFFIX'))
+
+
+def have_ref_roiaware():
+    return os.path.exists(_ref_roiaware_path())
+
+
+def ref_points_in_boxes_cpu(boxes, points):
+    """the reference's points_in_boxes_cpu (pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:144-167) called through
+    its own pybind module, compiled from its own source by oracle/build_ref.sh. The module also declares CUDA launchers
+    that are never called: it is imported with RTLD_LAZY so they stay unresolved. -> (N,P) int32 membership"""
+    import importlib.util
+    import sys
+    import torch
+    global _RR
+    try:
+        mod = _RR
+    except NameError:
+        flags = sys.getdlopenflags()
+        sys.setdlopenflags(os.RTLD_LAZY)
+        try:
+            spec = importlib.util.spec_from_file_location('roiaware_pool3d_ref', _ref_roiaware_path())
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+        finally:
+            sys.setdlopenflags(flags)
+        _RR = mod
+    b, p = torch.from_numpy(_f32(boxes)), torch.from_numpy(_f32(points))
+    out = torch.zeros((b.shape[0], p.shape[0]), dtype=torch.int32)
+    mod.points_in_boxes_cpu(b, p, out)
+    return out.numpy()
+
+
+def points_in_boxes_cpu(boxes, points):
+    """restatement of the CPU twin (1e-2 margin) -> (N,P) int32 membership"""
+    L = _lib()
+    b, p = _f32(boxes), _f32(points)
+    out = np.empty((len(b), len(p)), np.int32)
+    L.oracle_points_in_boxes_cpu(_ci(len(b)), _ci(len(p)), _p(b), _p(p), _p(out))
+    return out
+
+
 # ------------------------------------------------------------------ PointNet++ stack ops, points-in-boxes, RoI-aware pool
 def _ci(v):
     return ctypes.c_int(int(v))

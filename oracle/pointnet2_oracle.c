@@ -7,8 +7,9 @@
  *   three_nn / three_interpolate[_grad] .../interpolate_gpu.cu:16-172
  *   points_in_boxes_kernel             pcdet/ops/roiaware_pool3d/src/roiaware_pool3d_kernel.cu:23-36,313-336
  *   roiaware pool (mask, collect, max/avg, backward)  .../roiaware_pool3d_kernel.cu:39-190,236-290
- * PARITY UNPINNED by the reference (no tests; the .cu files cannot run without a GPU). The points-in-box rotation is
- * cross-checked against an independent numpy formulation in tests/test_oracle_pointnet2.py.
+ * PARITY UNPINNED by the reference for the pointnet2 ops and the RoI-aware pool (no tests; the .cu files cannot run
+ * without a GPU). The points-in-box rotation + extent test IS pinned: bit-exact against the reference's own
+ * points_in_boxes_cpu compiled from /root/reference (oracle/_ref/roiaware_pool3d_ref*.so) + golden ref_points_in_boxes.npz.
  */
 #include <math.h>
 #include <stdint.h>
@@ -155,8 +156,11 @@ void oracle_three_interpolate_grad(int N, int C, int M, const float* grad_out, c
   free(acc);
 }
 
-static int pt_in_box(const float* pt, const float* box, float* lx, float* ly) {
-  const float MARGIN = 1e-5;
+/* one rotation + extent test for both margins: the .cu kernel's 1e-5 (roiaware_pool3d_kernel.cu:23-36) and the CPU
+ * twin's 1e-2 (roiaware_pool3d.cpp:121-141, check_pt_in_box3d_cpu). The CPU twin is compiled from the reference's own
+ * source into oracle/_ref (build_ref.sh) and tests/test_oracle_pointnet2.py pins oracle_points_in_boxes_cpu to it
+ * bit-exactly, which pins this rotation arithmetic. */
+static int pt_in_box_margin(const float* pt, const float* box, float* lx, float* ly, const float MARGIN) {
   float x = pt[0], y = pt[1], z = pt[2];
   float cx = box[0], cy = box[1], cz = box[2], dx = box[3], dy = box[4], dz = box[5], rz = box[6];
   if (fabsf(z - cz) > dz / 2.0) return 0;
@@ -165,6 +169,17 @@ static int pt_in_box(const float* pt, const float* box, float* lx, float* ly) {
   *lx = sx * cosa + sy * (-sina);
   *ly = sx * sina + sy * cosa;
   return (fabs(*lx) < dx / 2.0 + MARGIN) & (fabs(*ly) < dy / 2.0 + MARGIN);
+}
+static int pt_in_box(const float* pt, const float* box, float* lx, float* ly) {
+  return pt_in_box_margin(pt, box, lx, ly, 1e-5f);
+}
+
+/* points_in_boxes_cpu (roiaware_pool3d.cpp:144-167): (N,P) membership matrix, MARGIN = 1e-2 */
+void oracle_points_in_boxes_cpu(int N, int P, const float* boxes, const float* pts, int* out) {
+  float lx = 0, ly = 0;
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < P; ++j)
+      out[(size_t)i * P + j] = pt_in_box_margin(pts + 3 * (size_t)j, boxes + 7 * (size_t)i, &lx, &ly, 1e-2f);
 }
 
 void oracle_points_in_boxes(int B, int T, int M, const float* boxes, const float* pts, int* out) {

@@ -367,6 +367,41 @@ def save(name, d):
     print(name, '%.1f KB' % (os.path.getsize(path) / 1024))
 
 
+# ref_iou3d.npz is produced from oracle/_ref (the reference's iou3d_cpu.cpp compiled by oracle/build_ref.sh):
+#   python - <<'PY'
+#   import numpy as np, oracle; from boxes_synth import detection_boxes
+#   rng = np.random.default_rng(123); a,_ = detection_boxes(rng,160); b,_ = detection_boxes(rng,120)
+#   b[:40] = a[:40] + rng.normal(0,0.15,(40,7)).astype(np.float32)
+#   np.savez_compressed('tests/golden/ref_iou3d.npz', a=a, b=b, iou=oracle.ref_boxes_iou_bev(a,b))
+#   PY
+
+
+def gen_points_in_boxes_ref():
+    """ref_points_in_boxes.npz: the reference's own points_in_boxes_cpu (roiaware_pool3d.cpp:144-167, compiled from
+    /root/reference by oracle/build_ref.sh) on boxes with points sampled inside, on the faces (+- the two margins) and
+    around them"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    sys.path.insert(0, os.path.dirname(OUT))
+    import oracle
+    from boxes_synth import detection_boxes
+    rng = np.random.default_rng(77)
+    boxes, _ = detection_boxes(rng, 40)
+    pts = []
+    for b in boxes:
+        c, s = np.cos(b[6]), np.sin(b[6])
+        loc = rng.uniform(-0.75, 0.75, (60, 3)) * b[3:6]
+        # face samples: |local x| or |local y| = half extent + {-2e-2, -5e-3, -1e-5, 0, 5e-6, 5e-3, 2e-2}; |dz| = h/2 + ...
+        for k, eps in enumerate((-2e-2, -5e-3, -1e-5, 0.0, 5e-6, 5e-3, 2e-2)):
+            loc[k, 0] = np.sign(loc[k, 0] + 1e-9) * (b[3] / 2 + eps)
+            loc[7 + k, 1] = np.sign(loc[7 + k, 1] + 1e-9) * (b[4] / 2 + eps)
+            loc[14 + k, 2] = np.sign(loc[14 + k, 2] + 1e-9) * (b[5] / 2 + eps)
+        w = np.stack([loc[:, 0] * c - loc[:, 1] * s + b[0], loc[:, 0] * s + loc[:, 1] * c + b[1], loc[:, 2] + b[2]], 1)
+        pts.append(w)
+    pts = np.concatenate(pts).astype(np.float32)
+    d = {'boxes': boxes, 'points': pts, 'member': oracle.ref_points_in_boxes_cpu(boxes, pts).astype(np.int8)}
+    save('ref_points_in_boxes.npz', d)
+
+
 if __name__ == '__main__':
     import_reference()
     only = sys.argv[1:] 
@@ -377,12 +412,5 @@ if __name__ == '__main__':
         d = {}
         fn(d)
         save(name, d)
-
-
-# ref_iou3d.npz is produced from oracle/_ref (the reference's iou3d_cpu.cpp compiled by oracle/build_ref.sh):
-#   python - <<'PY'
-#   import numpy as np, oracle; from boxes_synth import detection_boxes
-#   rng = np.random.default_rng(123); a,_ = detection_boxes(rng,160); b,_ = detection_boxes(rng,120)
-#   b[:40] = a[:40] + rng.normal(0,0.15,(40,7)).astype(np.float32)
-#   np.savez_compressed('tests/golden/ref_iou3d.npz', a=a, b=b, iou=oracle.ref_boxes_iou_bev(a,b))
-#   PY
+    if not only or 'ref_points_in_boxes.npz' in only:
+        gen_points_in_boxes_ref()

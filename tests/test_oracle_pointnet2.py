@@ -71,3 +71,50 @@ def test_group_and_interpolate_roundtrip():
     assert abs(g.sum() - out.size) < 1e-3
     d2, nn = oracle.three_nn(feat[:, :3], [25, 25], feat[:, 3:], [25, 25])
     assert (nn[:25] < 25).all() and (nn[25:] >= 25).all() and (np.diff(d2, axis=1) >= 0).all()
+
+
+# ---- the rotation + extent test of points-in-boxes is pinned by the reference's own compiled points_in_boxes_cpu
+import os
+
+import pytest
+
+_G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_points_in_boxes.npz')
+
+
+def test_points_in_boxes_cpu_twin_matches_golden_from_reference_build():
+    """oracle_points_in_boxes_cpu (same pt_in_box arithmetic as the GPU-rule oracle, margin 1e-2) == the membership matrix the
+    reference's roiaware_pool3d.cpp produced (tests/golden/make_goldens.py:gen_points_in_boxes_ref), bit for bit, incl. the
+    points sitting on / just off the faces"""
+    g = np.load(_G)
+    got = oracle.points_in_boxes_cpu(g['boxes'], g['points'])
+    np.testing.assert_array_equal(got, g['member'].astype(np.int32))
+    assert g['member'].sum() > 800 and (1 - g['member']).sum() > 50000
+
+
+@pytest.mark.skipif(not oracle.have_ref_roiaware(), reason='oracle/_ref not built (needs /root/reference)')
+def test_points_in_boxes_cpu_twin_matches_live_reference_build():
+    rng = np.random.default_rng(5)
+    boxes, _ = detection_boxes(rng, 64)
+    pts = (boxes[rng.integers(0, 64, 6000), :3] + rng.normal(0, 1.2, (6000, 3))).astype(np.float32)
+    np.testing.assert_array_equal(oracle.points_in_boxes_cpu(boxes, pts), oracle.ref_points_in_boxes_cpu(boxes, pts))
+
+
+def test_gpu_rule_oracle_differs_from_cpu_twin_only_inside_the_margin_band():
+    """first-hit oracle with the .cu margin (1e-5) vs the pinned CPU twin (1e-2): whenever they disagree on a (box, point)
+    pair the point lies within 1e-2 of a lateral face — the two share one rotation routine, so pinning the twin pins both"""
+    g = np.load(_G)
+    boxes, pts = g['boxes'], g['points']
+    member = oracle.points_in_boxes_cpu(boxes, pts)                       # (N,P), margin 1e-2
+    first = oracle.points_in_boxes(pts[None], boxes[None])[0]             # (P), margin 1e-5, first hit
+    for j in range(len(pts)):
+        hits = np.nonzero(member[:, j])[0]
+        if first[j] >= 0:
+            assert member[first[j], j] == 1
+        # boxes before the first hit that the twin marks but the kernel rule rejects must be margin cases
+        for i in hits:
+            if first[j] < 0 or i < first[j]:
+                b = boxes[i]
+                c, s = np.cos(-b[6]), np.sin(-b[6])
+                lx = (pts[j, 0] - b[0]) * c - (pts[j, 1] - b[1]) * s
+                ly = (pts[j, 0] - b[0]) * s + (pts[j, 1] - b[1]) * c
+                assert abs(lx) >= b[3] / 2 - 1e-4 or abs(ly) >= b[4] / 2 - 1e-4
