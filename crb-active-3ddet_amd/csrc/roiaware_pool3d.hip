@@ -63,6 +63,133 @@ __global__ __launch_bounds__(256) void points_in_boxes_kernel(int T, int M, cons
   if (i < M) out[(int64_t)b * M + i] = found;
 }
 
+// ---------------------------------------------------------------------------------------------- GT point statistics
+// Replaces the per-frame / per-class Python loops of Detector3DTemplate.post_processing (detector3d_template.py:236-268):
+// for every class, points_in_boxes_gpu over that class's gt boxes, then `(idx == i).sum()` per unique index on the host.
+// One launch counts, for every point of every frame, the FIRST gt box of EACH class that contains it (the reference runs
+// the first-hit kernel once per class over that class's boxes only, so a point may count for one box per class); a
+// second launch (one wave per frame x class) reduces the counts to the four recorded numbers.
+//
+// pts rows are the stacked batch layout (N, stride) [b, x, y, z, ...] with frame offsets; gt (B,G,8) rows
+// [x,y,z,dx,dy,dz,heading,label], label 0 = collate padding.
+struct GtBoxLds { BoxLds box; int cls; };
+
+__global__ __launch_bounds__(256) void gt_point_count_kernel(int G, int C, int stride, const float* __restrict__ pts,
+                                                             const int* __restrict__ off, const float* __restrict__ gt,
+                                                             int* __restrict__ cnt, int* __restrict__ bg) {
+  __shared__ GtBoxLds sb[PIB_CHUNK];
+  const int b = blockIdx.y;
+  const int n0 = off[b], n1 = off[b + 1];
+  const int base = n0 + (int)blockIdx.x * 256;
+  if (base >= n1) return;                                   // uniform per workgroup
+  const int i = base + (int)threadIdx.x;
+  const bool active = i < n1;
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (active) {
+    const float* p = pts + (int64_t)i * stride;
+    x = p[1]; y = p[2]; z = p[3];
+  }
+  const float* fb = gt + (int64_t)b * G * 8;
+  uint32_t hit = 0;                                         // bit c: a box of class c already owns this point
+  for (int t0 = 0; t0 < G; t0 += PIB_CHUNK) {
+    __syncthreads();
+    const int tc = min(PIB_CHUNK, G - t0);
+    if ((int)threadIdx.x < tc) {
+      const float* r = fb + (int64_t)(t0 + threadIdx.x) * 8;
+      sb[threadIdx.x].box = load_box(r);
+      const float lab = r[7];
+      const int cls = (int)lab;
+      sb[threadIdx.x].cls = ((float)cls == lab && cls >= 1 && cls <= C) ? cls - 1 : -1;
+    }
+    __syncthreads();
+    if (active) {
+      float lx, ly;
+      for (int k = 0; k < tc; ++k) {
+        const int cls = sb[k].cls;
+        if (cls < 0 || ((hit >> cls) & 1u)) continue;
+        if (pt_in_box(x, y, z, sb[k].box, lx, ly)) {
+          hit |= 1u << cls;
+          atomicAdd(&cnt[(int64_t)b * G + t0 + k], 1);
+        }
+      }
+    }
+  }
+  // background points per class (a point owned by no box of the class), one atomic per wave and class
+  for (int c = 0; c < C; ++c) {
+    const unsigned long long m = __ballot(active && !((hit >> c) & 1u));
+    if (crb_lane() == 0 && m) atomicAdd(&bg[b * C + c], __popcll(m));
+  }
+}
+
+// one wave per (frame, class): stats[(b*C+c)*5 + ..] = {num_bbox, n_counted, mean, median, variance}
+// n_counted = boxes of the class owning >= 1 point, minus the first of them when the frame has no background point for the
+// class (the reference drops the first entry of torch.unique's counts, assuming it is the -1 bin: :258).
+// mean = f32(sum)/n, median = lower median (torch.median), variance = population variance (unbiased=False).
+__global__ __launch_bounds__(64) void gt_point_stats_kernel(int G, int C, const float* __restrict__ gt,
+                                                            const int* __restrict__ cnt, const int* __restrict__ bg,
+                                                            float* __restrict__ stats) {
+  const int b = blockIdx.x / C, c = blockIdx.x % C;
+  const int lane = crb_lane();
+  const float* fb = gt + (int64_t)b * G * 8;
+  const int* cb = cnt + (int64_t)b * G;
+  const float want = (float)(c + 1);
+  int n_cls = 0, first = 0x7fffffff;
+  for (int k = lane; k < G; k += 64) {
+    const bool is = fb[(int64_t)k * 8 + 7] == want;
+    n_cls += is ? 1 : 0;
+    if (is && cb[k] > 0) first = min(first, k);
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    n_cls += __shfl_xor(n_cls, d, 64);
+    first = min(first, __shfl_xor(first, d, 64));
+  }
+  const int dropped = (bg[b * C + c] == 0) ? first : -1;
+  int n = 0;
+  long long sum = 0;
+  for (int k = lane; k < G; k += 64) {
+    const bool v = fb[(int64_t)k * 8 + 7] == want && cb[k] > 0 && k != dropped;
+    n += v ? 1 : 0;
+    sum += v ? cb[k] : 0;
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    n += __shfl_xor(n, d, 64);
+    sum += __shfl_xor(sum, d, 64);
+  }
+  float* o = stats + (int64_t)blockIdx.x * 5;
+  if (n == 0) {
+    if (lane == 0) { o[0] = (float)n_cls; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; }
+    return;
+  }
+  const double mean_d = (double)sum / (double)n;
+  double ss = 0.0;
+  int med = -1;
+  const int target = (n - 1) / 2;
+  for (int k = lane; k < G; k += 64) {
+    const bool v = fb[(int64_t)k * 8 + 7] == want && cb[k] > 0 && k != dropped;
+    if (!v) continue;
+    const int ck = cb[k];
+    const double d = (double)ck - mean_d;
+    ss += d * d;
+    int rank = 0;
+    for (int j = 0; j < G; ++j) {
+      const bool vj = fb[(int64_t)j * 8 + 7] == want && cb[j] > 0 && j != dropped;
+      rank += (vj && (cb[j] < ck || (cb[j] == ck && j < k))) ? 1 : 0;
+    }
+    if (rank == target) med = ck;
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    ss += __shfl_xor(ss, d, 64);
+    med = max(med, __shfl_xor(med, d, 64));
+  }
+  if (lane == 0) {
+    o[0] = (float)n_cls;
+    o[1] = (float)n;
+    o[2] = (float)sum / (float)n;
+    o[3] = (float)med;
+    o[4] = (float)(ss / (double)n);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- RoI-aware pool
 // one wave per box; pts_idx_of_voxels (N, ox,oy,oz, max_pts) [..,0] = count, then point indices in point order
 __global__ __launch_bounds__(256) void roiaware_collect_kernel(int N, int P, int ox, int oy, int oz, int max_pts,
@@ -173,6 +300,28 @@ extern "C" int crb_points_in_boxes(int B, int T, int M, const float* boxes, cons
   if (M == 0) return CRB_OK;
   hipLaunchKernelGGL(points_in_boxes_kernel, dim3(crb_cdiv(M, 256), B), dim3(256), 0, (hipStream_t)stream, T, M, boxes,
                      pts, box_idx_of_points);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int64_t crb_gt_point_stats_workspace_bytes(int B, int G, int C) {
+  return (int64_t)sizeof(int) * ((int64_t)B * G + (int64_t)B * C);
+}
+
+extern "C" int crb_gt_point_stats(int B, int G, int C, int64_t N, int stride, const float* pts,
+                                  const int32_t* frame_offsets, const float* gt_boxes, float* stats, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+  if (B <= 0 || G < 0 || C <= 0 || C > 32 || N < 0 || stride < 4) return CRB_ERR_ARG;
+  if (workspace_bytes < crb_gt_point_stats_workspace_bytes(B, G, C) || (workspace == nullptr && G + C > 0))
+    return CRB_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  int* cnt = (int*)workspace;
+  int* bg = cnt + (int64_t)B * G;
+  CRB_HIP(hipMemsetAsync(workspace, 0, (size_t)crb_gt_point_stats_workspace_bytes(B, G, C), st));
+  if (N > 0 && G > 0)
+    hipLaunchKernelGGL(gt_point_count_kernel, dim3(crb_cdiv(N, 256), B), dim3(256), 0, st, G, C, stride, pts,
+                       frame_offsets, gt_boxes, cnt, bg);
+  hipLaunchKernelGGL(gt_point_stats_kernel, dim3(B * C), dim3(64), 0, st, G, C, gt_boxes, cnt, bg, stats);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

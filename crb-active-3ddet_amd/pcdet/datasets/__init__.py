@@ -1,5 +1,125 @@
 """Dataset side of the hot path: the synthetic KITTI/Waymo-shaped dataset used for benchmarking and tests, the
-collate layout of DatasetTemplate.collate_batch (pcdet/datasets/dataset.py:160-229) and the rank-strided eval sampler
-of pcdet/datasets/__init__.py:26-46. Real-dataset readers / augmentors are out of scope."""
-from .synthetic_dataset import SyntheticDataset, build_synthetic_dataloader  # noqa: F401
+collate layout of DatasetTemplate.collate_batch (pcdet/datasets/dataset.py:160-229), the rank-strided eval sampler of
+pcdet/datasets/__init__.py:26-46 and the two loader builders the reference's tools/train.py and active loop call
+(build_dataloader :49-78, build_active_dataloader :80-181) with the reference's signatures and return tuples.
+
+Real-dataset readers / augmentors are out of scope: the registry below answers 'KittiDataset' and
+'WaymoDataset' with synthetic clouds of that shape, so the callers run unchanged on a box without the datasets."""
+import random
+
+import torch
+from torch.utils.data import DataLoader
+
+from ..config import cfg
+from ..utils import common_utils
 from .sampler import DistributedSampler  # noqa: F401
+from .synthetic_dataset import SyntheticDataset, build_synthetic_dataloader  # noqa: F401
+
+
+class _ConfiguredSynthetic(SyntheticDataset):
+    """SyntheticDataset behind the reference's dataset constructor (dataset_cfg, class_names, root_path, training, logger).
+    Optional dataset_cfg.SYNTHETIC = {NUM_FRAMES, N_POINTS, FIRST_FRAME, DEVICE_VOXELIZE}."""
+    KIND = 'kitti'
+
+    def __init__(self, dataset_cfg=None, class_names=None, training=True, root_path=None, logger=None):
+        syn = dict((dataset_cfg or {}).get('SYNTHETIC', {}) or {})
+        super().__init__(num_frames=int(syn.get('NUM_FRAMES', 64)),
+                         n_points=int(syn.get('N_POINTS', 20000 if self.KIND == 'kitti' else 160000)),
+                         kind=self.KIND, training=training, first_frame=int(syn.get('FIRST_FRAME', 0)),
+                         device_voxelize=bool(syn.get('DEVICE_VOXELIZE', True)), class_names=class_names)
+        self.dataset_cfg, self.root_path, self.logger = dataset_cfg, root_path, logger
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop('logger', None)
+        d['_voxel_generator'] = None
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self.logger = None
+
+
+class KittiDataset(_ConfiguredSynthetic):
+    KIND = 'kitti'
+
+
+class WaymoDataset(_ConfiguredSynthetic):
+    KIND = 'waymo'
+
+
+__all__ = {
+    'KittiDataset': KittiDataset,
+    'WaymoDataset': WaymoDataset,
+    'SyntheticDataset': SyntheticDataset,
+}
+
+
+def _samplers(dist, training, *datasets):
+    if not dist:
+        return [None] * len(datasets)
+    if training:
+        return [torch.utils.data.distributed.DistributedSampler(d) for d in datasets]
+    rank, world_size = common_utils.get_dist_info()
+    return [DistributedSampler(d, world_size, rank, shuffle=False) for d in datasets]
+
+
+def _loader(dataset, batch_size, workers, sampler, training):
+    return DataLoader(dataset, batch_size=batch_size, pin_memory=True, num_workers=workers,
+                      shuffle=(sampler is None) and training, collate_fn=dataset.collate_batch, drop_last=False,
+                      sampler=sampler, timeout=0)
+
+
+def build_dataloader(dataset_cfg, class_names, batch_size, dist, root_path=None, workers=4, logger=None, training=True,
+                     merge_all_iters_to_one_epoch=False, total_epochs=0):
+    """-> dataset, dataloader, sampler (pcdet/datasets/__init__.py:49-78)"""
+    dataset = __all__[dataset_cfg.DATASET](dataset_cfg=dataset_cfg, class_names=class_names, root_path=root_path,
+                                           training=training, logger=logger)
+    if merge_all_iters_to_one_epoch:
+        assert hasattr(dataset, 'merge_all_iters_to_one_epoch')
+        dataset.merge_all_iters_to_one_epoch(merge=True, epochs=total_epochs)
+    sampler, = _samplers(dist, training, dataset)
+    return dataset, _loader(dataset, batch_size, workers, sampler, training), sampler
+
+
+def build_active_dataloader(dataset_cfg, class_names, batch_size, dist, root_path=None, workers=4, logger=None,
+                            training=True, merge_all_iters_to_one_epoch=False, total_epochs=0, active_training=None):
+    """-> labelled_set, unlabelled_set, dataloader_labelled, dataloader_unlabelled, sampler_labelled, sampler_unlabelled
+    (pcdet/datasets/__init__.py:80-181). active_training = [selected ids, selected infos, unselected ids, unselected infos]
+    rebuilds the split after a selection round; None draws the initial random split of
+    cfg.ACTIVE_TRAIN.PRE_TRAIN_SAMPLE_NUMS labelled frames with the global `random` state, like the reference."""
+    make = lambda tr: __all__[dataset_cfg.DATASET](dataset_cfg=dataset_cfg, class_names=class_names, root_path=root_path,
+                                                   training=tr, logger=logger)
+    dataset, labelled_set, unlabelled_set = make(training), make(True), make(False)
+    waymo = cfg.DATA_CONFIG.DATASET == 'WaymoDataset'
+    if active_training is not None:
+        if waymo:
+            labelled_set.frame_ids, labelled_set.infos = active_training[0], active_training[1]
+            unlabelled_set.frame_ids, unlabelled_set.infos = active_training[2], active_training[3]
+        else:
+            labelled_set.sample_id_list, labelled_set.kitti_infos = active_training[0], active_training[1]
+            unlabelled_set.sample_id_list, unlabelled_set.kitti_infos = active_training[2], active_training[3]
+    else:
+        k = cfg.ACTIVE_TRAIN.PRE_TRAIN_SAMPLE_NUMS
+        if waymo:
+            infos = list(dataset.infos)
+            random.shuffle(infos)
+            labelled_set.infos, unlabelled_set.infos = infos[:k], infos[k:]
+            labelled_set.frame_ids = [i['frame_id'] for i in labelled_set.infos]
+            unlabelled_set.frame_ids = [i['frame_id'] for i in unlabelled_set.infos]
+        else:
+            pairs = list(zip(dataset.sample_id_list, dataset.kitti_infos))
+            random.shuffle(pairs)
+            labelled_set.sample_id_list, labelled_set.kitti_infos = zip(*pairs[:k])
+            unlabelled_set.sample_id_list, unlabelled_set.kitti_infos = zip(*pairs[k:])
+    for s in (labelled_set, unlabelled_set):
+        s.sync_id_views(waymo)
+    if merge_all_iters_to_one_epoch:
+        assert hasattr(dataset, 'merge_all_iters_to_one_epoch')
+        labelled_set.merge_all_iters_to_one_epoch(merge=True, epochs=total_epochs)
+        unlabelled_set.merge_all_iters_to_one_epoch(merge=True, epochs=total_epochs)
+    sampler_labelled, sampler_unlabelled = _samplers(dist, training, labelled_set, unlabelled_set)
+    dataloader_labelled = _loader(labelled_set, batch_size, workers, sampler_labelled, training)
+    dataloader_unlabelled = _loader(unlabelled_set, batch_size, workers, sampler_unlabelled, training)
+    del dataset
+    return labelled_set, unlabelled_set, dataloader_labelled, dataloader_unlabelled, sampler_labelled, sampler_unlabelled

@@ -46,10 +46,18 @@ class SyntheticDataset(Dataset):
         self.grid_size = np.round(g).astype(np.int64)
         self.depth_downsample_factor = None
         self.sample_id_list = ['%06d' % (first_frame + i) for i in range(num_frames)]
-        self.kitti_infos = [{'point_cloud': {'lidar_idx': s}} for s in self.sample_id_list]
+        self.kitti_infos = [{'point_cloud': {'lidar_idx': s}, 'frame_id': s} for s in self.sample_id_list]
         self.frame_ids = self.sample_id_list
         self.infos = self.kitti_infos
         self._voxel_generator = None
+
+    def sync_id_views(self, waymo=False):
+        """the active loop re-assigns (sample_id_list, kitti_infos) for KITTI or (frame_ids, infos) for Waymo
+        (pcdet/datasets/__init__.py:111-147); keep the other pair of names pointing at the same lists"""
+        if waymo:
+            self.sample_id_list, self.kitti_infos = self.frame_ids, self.infos
+        else:
+            self.frame_ids, self.infos = self.sample_id_list, self.kitti_infos
 
     @property
     def mode(self):
@@ -97,8 +105,6 @@ class SyntheticDataset(Dataset):
                 for k in range(B):
                     g[k, :len(val[k])] = val[k]
                 ret[key] = g
-            elif key == 'use_lead_xyz':
-                continue
             elif key == 'frame_id':
                 ret[key] = np.array(val)
             else:

@@ -64,7 +64,8 @@ def label_entropy(pred_labels, valid, num_class):
 def crb_frame_records(model, batch_dict):
     """fixed-size device tensors for the whole batch (no host synchronisation):
        sel/valid/num (final NMS), pred_boxes (B,POST,7), pred_scores, pred_labels, pred_logits, density (B,POST),
-       entropy (B), batch_rcnn_cls (B,R,1) / batch_rcnn_reg (B,R,7) (MC-dropout means) or None"""
+       entropy (B), batch_rcnn_cls (B,R,1) / batch_rcnn_reg (B,R,7) (MC-dropout means) or None,
+       gt_stats (B,C,5) per-class GT point statistics (None without gt_boxes)"""
     cfg = model.model_cfg.POST_PROCESSING
     B = batch_dict['batch_size']
     box_preds = batch_dict['batch_box_preds']
@@ -105,9 +106,10 @@ def crb_frame_records(model, batch_dict):
     if 'rcnn_cls' in batch_dict and batch_dict['rcnn_cls'].dim() > 2:
         rcnn_cls = torch.mean(torch.sigmoid(batch_dict['rcnn_cls']), 0).view(B, -1, 1)
         rcnn_reg = torch.mean(batch_dict['rcnn_reg'], 0).view(B, -1, 7)
+    gt_stats = gt_point_stats_device(batch_dict, num_class)[0] if 'gt_boxes' in batch_dict else None
     return {'sel': sel, 'valid': valid, 'num': num, 'pred_boxes': pred_boxes, 'pred_scores': pred_scores,
             'pred_labels': pred_labels, 'pred_logits': pred_logits, 'density': density, 'entropy': ent,
-            'batch_rcnn_cls': rcnn_cls, 'batch_rcnn_reg': rcnn_reg, 'confidence': cls_preds}
+            'batch_rcnn_cls': rcnn_cls, 'batch_rcnn_reg': rcnn_reg, 'confidence': cls_preds, 'gt_stats': gt_stats}
 
 
 def _first_hit_counts(idx, P):
@@ -121,39 +123,70 @@ def _first_hit_counts(idx, P):
     return cnt
 
 
-def gt_point_statistics(model, batch_dict):
-    """per frame and class: number of gt boxes and mean / median / variance of the per-box point counts
-    (detector3d_template.py:236-268), counting only boxes that own >= 1 point like the reference's torch.unique path.
-    One points-in-boxes launch per class for the whole batch. -> list over frames of 4 dicts keyed by class name"""
-    B = batch_dict['batch_size']
-    names = [c['class_name'] for c in model.model_cfg.DENSE_HEAD.ANCHOR_GENERATOR_CONFIG]
-    gt = batch_dict['gt_boxes']
-    pts, _ = _frame_points(batch_dict, B)
-    G = gt.shape[1]
-    out = [({}, {}, {}, {}) for _ in range(B)]
-    stats = {}
-    for ci, name in enumerate(names):
-        m = gt[..., -1] == (ci + 1)
-        boxes = gt[..., :7].clone()
-        boxes[..., 0:3] = torch.where(m[..., None], boxes[..., 0:3], boxes.new_full((), 1e7))
-        idx = roiaware_pool3d_utils.points_in_boxes_gpu(pts, boxes.contiguous()).long()
-        cnt = _first_hit_counts(idx, G)
-        stats[name] = (m.sum(1).cpu(), cnt[:, :G].cpu(), m.cpu())
-    for b in range(B):
-        num_bbox, mean_p, med_p, var_p = out[b]
-        for name in names:
-            n, cnt, m = stats[name]
-            nb = int(n[b])
-            if nb > 0:
-                c = cnt[b][m[b]]
-                c = c[c > 0]
-                num_bbox[name] = n[b]
-                mean_p[name] = 0 if c.numel() == 0 else torch.mean(c)
-                med_p[name] = 0 if c.numel() == 0 else torch.median(c)
-                var_p[name] = 0 if c.numel() == 0 else torch.var(c, unbiased=False)
-            else:
-                num_bbox[name] = mean_p[name] = med_p[name] = var_p[name] = 0
+GT_STAT_FIELDS = 5          # num_bbox, n_counted, mean, median, variance per class
+
+
+def class_names_of(model):
+    return [c['class_name'] for c in model.model_cfg.DENSE_HEAD.ANCHOR_GENERATOR_CONFIG]
+
+
+def frame_offsets_of(batch_dict):
+    """(B+1) int32 device offsets of the frame-sorted stacked points"""
+    off = batch_dict.get('point_frame_offsets', None)
+    pts = batch_dict['points']
+    if off is not None and torch.is_tensor(off) and off.is_cuda:
+        return off if off.dtype == torch.int32 else off.int()
+    counts = common_utils.batch_counts(pts[:, 0], batch_dict['batch_size'])
+    out = torch.zeros((batch_dict['batch_size'] + 1,), dtype=torch.int32, device=pts.device)
+    out[1:] = torch.cumsum(counts, 0)
     return out
+
+
+def gt_point_stats_device(batch_dict, num_class):
+    """(B, num_class, 5) f32 on the device: {num_bbox, n_counted, mean, median, variance} of the per-gt-box point counts of
+    every frame and class (detector3d_template.py:236-268) in two launches (crb_gt_point_stats), no host round trip.
+    Also returns the per-box counts (B,G) int32."""
+    from crbhip import lib, check, ptr, cur_stream, require_cuda
+    pts = batch_dict['points']
+    gt = batch_dict['gt_boxes']
+    require_cuda(pts, gt)
+    assert gt.dim() == 3 and gt.shape[-1] == 8, 'gt_boxes must be (B,G,8) [x,y,z,dx,dy,dz,heading,label]'
+    B, G = int(gt.shape[0]), int(gt.shape[1])
+    off = frame_offsets_of(batch_dict).contiguous()
+    stats = torch.empty((B, num_class, GT_STAT_FIELDS), dtype=torch.float32, device=pts.device)
+    wsb = int(lib.crb_gt_point_stats_workspace_bytes(B, G, num_class))
+    ws = torch.empty((max(wsb // 4, 1),), dtype=torch.int32, device=pts.device)
+    check(lib.crb_gt_point_stats(B, G, num_class, int(pts.shape[0]), int(pts.shape[1]), ptr(pts.contiguous().float()),
+                                 ptr(off), ptr(gt.contiguous().float()), ptr(stats), ptr(ws), wsb, cur_stream(pts.device)),
+          'crb_gt_point_stats')
+    return stats, ws[:B * G].view(B, G)
+
+
+def gt_stats_to_dicts(stats_row, names):
+    """one frame's (C,5) host rows -> (num_bbox, mean_points, median_points, variance_points) dicts keyed by class name with
+    the reference's value kinds (detector3d_template.py:252-268): a 0-dim tensor where the reference stores one (int64 count
+    / float32 statistic), the python int 0 where it stores 0 (class absent, or no box of the class owns a point = NaN mean).
+    The tensors live on the host so that the pickle of Strategy.save_active_labels loads on any machine (the reference
+    pickles CUDA tensors)."""
+    num_bbox, mean_p, med_p, var_p = {}, {}, {}, {}
+    for ci, name in enumerate(names):
+        n_cls, n, mean, med, var = [float(v) for v in stats_row[ci]]
+        num_bbox[name] = torch.tensor(int(n_cls), dtype=torch.int64) if n_cls > 0 else 0
+        if n_cls > 0 and n > 0:
+            mean_p[name] = torch.tensor(mean, dtype=torch.float32)
+            med_p[name] = torch.tensor(med, dtype=torch.float32)
+            var_p[name] = torch.tensor(var, dtype=torch.float32)
+        else:
+            mean_p[name] = med_p[name] = var_p[name] = 0
+    return num_bbox, mean_p, med_p, var_p
+
+
+def gt_point_statistics(model, batch_dict):
+    """-> list over frames of the 4 dicts of gt_stats_to_dicts (one device pass + one read-back for the whole batch)"""
+    names = class_names_of(model)
+    stats, _ = gt_point_stats_device(batch_dict, len(names))
+    host = stats.cpu().numpy()
+    return [gt_stats_to_dicts(host[b], names) for b in range(host.shape[0])]
 
 
 def crb_post_processing(model, batch_dict):
@@ -165,8 +198,15 @@ def crb_post_processing(model, batch_dict):
         # scores of the boxes themselves so SECOND can be evaluated too
         batch_dict['full_cls_scores'] = batch_dict['batch_cls_preds']
     rec = crb_frame_records(model, batch_dict)
-    num = rec['num'].cpu().tolist()                        # the single host read-back of this function
-    gstats = gt_point_statistics(model, batch_dict) if 'gt_boxes' in batch_dict else None
+    names = class_names_of(model)
+    if rec['gt_stats'] is not None:                        # the single host read-back of this function
+        host = torch.cat([rec['num'].float(), rec['gt_stats'].reshape(-1)]).cpu()
+        num = host[:B].long().tolist()
+        gs = host[B:].view(B, len(names), GT_STAT_FIELDS).numpy()
+        gstats = [gt_stats_to_dicts(gs[b], names) for b in range(B)]
+    else:
+        num = rec['num'].cpu().tolist()
+        gstats = None
     recall_dict = {}
     pred_dicts = []
     for b in range(B):
@@ -190,6 +230,7 @@ def crb_post_processing(model, batch_dict):
             'pred_labels': rec['pred_labels'][b, :k],
             'pred_box_unique_density': rec['density'][b, :k],
             'label_entropy': rec['entropy'][b],
+            'gt_point_stats': rec['gt_stats'][b] if rec['gt_stats'] is not None else None,     # (C,5) device row
         })
     return pred_dicts, recall_dict
 

@@ -19,10 +19,10 @@ class BadgeSampling(PoolEvalStrategy):
     def _rpn_labels(self, batch, pred_dicts, b):
         rpn = pred_dicts[0]['rpn_preds']                                   # (B, H, W, A*num_class) of the whole batch
         B = rpn.shape[0]
-        return torch.argmax(rpn.reshape(B, -1, self.model.dense_head.num_class), -1)[b]
+        return torch.argmax(rpn.reshape(B, -1, self.detector.dense_head.num_class), -1)[b]
 
     def grad_embeddings(self, frame_indices, labels):
-        model = self.model
+        model = self.detector
         model.train()
         w = model.dense_head.conv_cls.weight
         out = []

@@ -29,6 +29,7 @@ class CRBSampling(Strategy):
         # and the bandwidth is always 5; keep that behaviour
         self.bandwidth = getattr(ac, 'BANDWDITH', 5)
         self.prototype = getattr(ac, 'CLUSTERING', 'kmeans++')
+        self.frame_seed = getattr(ac, 'FRAME_SEED', None)
         self.alpha = 0.95
         self.timings = {}
 
@@ -41,18 +42,12 @@ class CRBSampling(Strategy):
                 m.train()
         return n
 
-    def _world(self):
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            return dist.get_rank(), dist.get_world_size()
-        return 0, 1
-
     # ---------------------------------------------------------------- stage 1
     @torch.no_grad()
     def score_pool(self, frame_indices, batch_size):
-        """-> (len(frame_indices), REC_STRIDE) device tensor of per-frame records, GT statistics recorded on the way"""
-        ds = self.unlabelled_set
-        model = self.model
+        """-> (len(frame_indices), layout.stride) device tensor of per-frame records; the GT point statistics the caller
+        pickles after the query travel inside the rows (query() records them for the whole gathered pool)"""
+        model = self.detector
         model.eval()
         self.enable_dropout(model)
         rows = []
@@ -64,7 +59,9 @@ class CRBSampling(Strategy):
                 model.pfe.prefetch_keypoints(batch)          # FPS on a side stream, as PVRCNN.forward does
             for mod in model.module_list:
                 batch = mod(batch)
-            rows.append(scoring.pack_records(crb_frame_records(model, batch)))
+            rows.append(scoring.pack_records(crb_frame_records(model, batch), self.layout))
+        if not rows:
+            return torch.zeros((0, self.layout.stride), dtype=torch.float32, device=next(model.parameters()).device)
         return torch.cat(rows, 0)
 
     PRUNED_BACKWARD = True
@@ -73,7 +70,7 @@ class CRBSampling(Strategy):
     def frame_loss(self, i, rcnn_cls_labels, reg_sample_targets, batch=None):
         """bs=1 training-mode pass of pool frame i (or of the already collated host `batch`) and the RoI-head loss against
         the stage-1 hypothetical labels (crb_sampling.py:174-196)"""
-        ds, model = self.unlabelled_set, self.model
+        ds, model = self.unlabelled_set, self.detector
         if batch is None:
             batch = ds.collate_batch([ds[i]])
         if 'point_frame_counts_host' not in batch:          # host batch; device batches from _frame_batches are complete
@@ -102,7 +99,7 @@ class CRBSampling(Strategy):
         """bs=1 device batches of the given pool frames. Frames travel to the device GROUP at a time and their keypoints are
         sampled in ONE launch on the side stream (one workgroup per frame, ~5 ms for the whole group): sampled frame by frame
         the serial 2047-round selection was 5 ms of every 24 ms stage-2 pass."""
-        model = self.model
+        model = self.detector
         pfe = getattr(model, 'pfe', None)
 
         def launch(group):                                   # upload + keypoint sampling of a whole group (asynchronous)
@@ -152,14 +149,20 @@ class CRBSampling(Strategy):
     def grad_embeddings(self, frame_indices, records):
         """per-frame gradient of roi_head.shared_fc_layer[4].weight under the stage-1 hypothetical labels
         (crb_sampling.py:174-212). -> (len(frame_indices), 65536) device tensor"""
-        ds = self.unlabelled_set
-        model = self.model
-        rec = scoring.unpack_records(records)
+        # NOTE (deliberate departure): the reference builds the stage-2 loader with training=True, i.e. the frames go
+        # through the train-mode data pipeline (augmentation, point shuffling) before the bs=1 pass (crb_sampling.py:152-161).
+        # Augmentors are out of scope (SURVEY §2.1 row 15); here stage-2 frames come from the same pool dataset object
+        # as stage 1, un-augmented, while the MODEL runs in train mode exactly as in the reference.
+        model = self.detector
+        rec = scoring.unpack_records(records, self.layout)
         model.train()
-        was_training = getattr(ds, 'training', True)
         out = []
         w = model.roi_head.shared_fc_layer[4].weight
         for k, (i, batch) in enumerate(zip(frame_indices, self._frame_batches(frame_indices))):
+            if self.frame_seed is not None:
+                # opt-in (ACTIVE_CONFIG.FRAME_SEED): the RoI sampler / dropout stream of a frame depends on the frame only,
+                # not on which rank processes it after which other frames -> the selection is independent of the world size
+                torch.manual_seed(int(self.frame_seed) + int(i))
             loss = self.frame_loss(i, rec['rcnn_cls'][k], rec['rcnn_reg'][k], batch=batch)
             if self.PRUNED_BACKWARD:
                 # the embedding is d loss / d shared_fc_layer[4].weight only: autograd walks loss -> cls/reg layers -> FC stack
@@ -172,16 +175,15 @@ class CRBSampling(Strategy):
                 model.zero_grad(set_to_none=True)
                 loss.backward()
                 out.append(w.grad.detach().reshape(-1).clone())
-        ds.training = was_training
         return torch.stack(out, 0) if out else torch.zeros((0, w.numel()), device=w.device)
 
     # ---------------------------------------------------------------- stage 3
     def density_balance(self, cand_records, all_records, select_nums, num_class):
-        a = scoring.unpack_records(all_records)
-        valid = torch.arange(scoring.MAX_BOX, device=all_records.device)[None, :] < a['num'][:, None]
+        a = scoring.unpack_records(all_records, self.layout)
+        valid = torch.arange(self.layout.max_box, device=all_records.device)[None, :] < a['num'][:, None]
         xaxis, prior = scoring.density_prior(a['density'][valid], a['labels'][valid], num_class, self.alpha)
-        c = scoring.unpack_records(cand_records)
-        cvalid = torch.arange(scoring.MAX_BOX, device=cand_records.device)[None, :] < c['num'][:, None]
+        c = scoring.unpack_records(cand_records, self.layout)
+        cvalid = torch.arange(self.layout.max_box, device=cand_records.device)[None, :] < c['num'][:, None]
         labels = torch.where(cvalid, c['labels'], torch.zeros_like(c['labels'])).int()
         order, scores = scoring.density_greedy(c['density'], labels, xaxis, prior, self.bandwidth, select_nums)
         return order, scores
@@ -200,6 +202,9 @@ class CRBSampling(Strategy):
         mine, per = scoring.shard_indices(n, rank, world)
         local = self.score_pool(mine, bs)
         records = scoring.all_gather_rows(local, n, world)
+        # GT statistics of EVERY pool frame on EVERY rank (crb_sampling.py:84 -> strategy.py:28-38): the caller runs
+        # save_active_labels(selected_frames=...) right after query() (active_training_utils.py:270-273)
+        self.record_gt_stats(scoring.unpack_records(records, self.layout)['gt_stats'], frame_ids)
         torch.cuda.synchronize()
         self.timings['stage1_s'] = time.time() - t0
         entropy = records[:, 0]
@@ -231,6 +236,6 @@ class CRBSampling(Strategy):
         order3, _ = self.density_balance(records[cand_idx], records, min(select_nums, len(cand_idx)), num_class)
         picked = [cand_idx[i] for i in order3.cpu().tolist() if i >= 0]
         self.timings['stage3_s'] = time.time() - t2
-        self.model.eval()
+        self.detector.eval()
         self.last_records = records
         return [frame_ids[i] for i in picked]

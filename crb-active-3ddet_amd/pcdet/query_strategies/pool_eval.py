@@ -25,12 +25,6 @@ class PoolEvalStrategy(Strategy):
                 m.train()
         return n
 
-    def _world(self):
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            return dist.get_rank(), dist.get_world_size()
-        return 0, 1
-
     def _batches(self, ds, frame_indices, batch_size):
         if ds is self.unlabelled_set:
             host = self.iter_pool_batches(frame_indices, batch_size)        # loader workers read ahead of the GPU
@@ -49,23 +43,33 @@ class PoolEvalStrategy(Strategy):
     @torch.no_grad()
     def eval_pool(self, ds, frame_indices, batch_size, frame_fn, record_points=True):
         """frame_fn(batch_dict, pred_dicts, b) -> tensor row for frame b of the batch; rows are stacked -> (len, D)"""
-        model = self.model
+        model = self.detector
         model.eval()
         if self.MC_DROPOUT:
             self.enable_dropout(model)
-        rows = []
+        rows, gts = [], []
         for chunk, batch in self._batches(ds, frame_indices, batch_size):
             pred_dicts, _ = model(batch)
             for b in range(len(pred_dicts)):
-                if record_points:
-                    self.save_points(batch['frame_id'][b], pred_dicts[b])
+                if record_points and pred_dicts[b].get('gt_point_stats', None) is not None:
+                    gts.append(pred_dicts[b]['gt_point_stats'].reshape(-1))      # device row, gathered in gather_pool
                 rows.append(frame_fn(batch, pred_dicts, b).reshape(-1).float())
+        self._local_gt_stats = torch.stack(gts, 0) if (record_points and gts) else None
         if not rows:
             return torch.zeros((0, 1), device=next(model.parameters()).device)
         return torch.stack(rows, 0)
 
     def gather_pool(self, local_rows, n):
+        """all-gather this rank's rows of the unlabelled pool; the GT point statistics collected by the same pass are
+        gathered with them and recorded for EVERY pool frame on every rank (save_points of the reference's loops)"""
         rank, world = self._world()
+        gts = getattr(self, '_local_gt_stats', None)
+        if gts is not None and gts.shape[0] == local_rows.shape[0]:
+            both = scoring.all_gather_rows(torch.cat([local_rows.float(), gts.float()], 1).contiguous(), n, world)
+            self._local_gt_stats = None
+            w = local_rows.shape[1]
+            self.record_gt_stats(both[:, w:].reshape(n, -1, scoring.GT_STAT_FIELDS))
+            return both[:, :w].contiguous()
         return scoring.all_gather_rows(local_rows.contiguous(), n, world)
 
     def top_n_ascending(self, values, n_select):

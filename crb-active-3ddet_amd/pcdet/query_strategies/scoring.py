@@ -7,34 +7,83 @@ import torch.distributed as dist
 
 from crbhip import lib, check, ptr, cur_stream, require_cuda
 
-MAX_BOX = 128                                      # TEST NMS_POST_MAXSIZE: at most 128 RoIs reach post-processing
-REC_STRIDE = 2 + 3 * MAX_BOX + 7 * MAX_BOX         # entropy | n_box | labels | density | rcnn_cls | rcnn_reg
+GT_STAT_FIELDS = 5                                  # num_bbox, n_counted, mean, median, variance per class
 
 
-def pack_records(rec):
-    """crb_frame_records(...) dict -> (B, REC_STRIDE) f32 (SURVEY §8e record layout)"""
+class RecordLayout:
+    """fixed-stride f32 row per pool frame — what every rank all-gathers:
+         entropy | n_box | labels[MB] | density[MB] | rcnn_cls[MB] | rcnn_reg[7 MB] | gt_stats[5 C]
+    MB = the largest number of boxes a frame can carry: the final NMS keeps at most
+    min(POST_PROCESSING NMS_POST_MAXSIZE, NMS_PRE_MAXSIZE, #candidates) boxes, the MC-dropout means have one entry per RoI
+    (ROI_HEAD TEST NMS_POST_MAXSIZE). gt_stats are the per-class GT point statistics the caller pickles after every
+    query (Strategy.save_points / save_active_labels), so they travel with the scores."""
+
+    def __init__(self, max_box=128, num_class=3):
+        self.max_box, self.num_class = int(max_box), int(num_class)
+        mb = self.max_box
+        self.o_labels = 2
+        self.o_density = 2 + mb
+        self.o_cls = 2 + 2 * mb
+        self.o_reg = 2 + 3 * mb
+        self.o_gt = 2 + 10 * mb
+        self.stride = self.o_gt + GT_STAT_FIELDS * self.num_class
+
+    @classmethod
+    def for_model(cls, model):
+        cfg = model.model_cfg
+        nc = len(cfg.DENSE_HEAD.ANCHOR_GENERATOR_CONFIG)
+        nms = cfg.POST_PROCESSING.NMS_CONFIG
+        post = min(int(nms.NMS_POST_MAXSIZE), int(nms.NMS_PRE_MAXSIZE))
+        roi = cfg.get('ROI_HEAD', None)
+        if roi is not None:
+            r = int(roi.NMS_CONFIG.TEST.NMS_POST_MAXSIZE)
+            post = min(post, r)                  # the RoI head hands exactly r boxes per frame to post-processing
+            return cls(max(post, r), nc)
+        return cls(post, nc)
+
+    def __eq__(self, other):
+        return isinstance(other, RecordLayout) and (self.max_box, self.num_class) == (other.max_box, other.num_class)
+
+
+DEFAULT_LAYOUT = RecordLayout(128, 3)               # pv_rcnn_active_crb.yaml: 128 RoIs, 3 classes
+MAX_BOX = DEFAULT_LAYOUT.max_box
+REC_STRIDE = DEFAULT_LAYOUT.stride
+
+
+def pack_records(rec, layout=None):
+    """crb_frame_records(...) dict -> (B, layout.stride) f32"""
+    L = layout or DEFAULT_LAYOUT
     B = rec['entropy'].shape[0]
     P = rec['pred_labels'].shape[1]
-    assert P <= MAX_BOX
-    out = torch.zeros((B, REC_STRIDE), dtype=torch.float32, device=rec['entropy'].device)
+    if P > L.max_box:
+        raise ValueError('record layout holds %d boxes per frame but post-processing produced %d: build the layout with '
+                         'RecordLayout.for_model(model)' % (L.max_box, P))
+    out = torch.zeros((B, L.stride), dtype=torch.float32, device=rec['entropy'].device)
     out[:, 0] = rec['entropy']
     out[:, 1] = rec['num'].float()
-    out[:, 2:2 + P] = rec['pred_labels'].float()
-    out[:, 2 + MAX_BOX:2 + MAX_BOX + P] = rec['density']
-    o = 2 + 2 * MAX_BOX
+    out[:, L.o_labels:L.o_labels + P] = rec['pred_labels'].float()
+    out[:, L.o_density:L.o_density + P] = rec['density']
     if rec['batch_rcnn_cls'] is not None:
         R = rec['batch_rcnn_cls'].shape[1]
-        out[:, o:o + R] = rec['batch_rcnn_cls'].reshape(B, R)
-        out[:, o + MAX_BOX:o + MAX_BOX + 7 * R] = rec['batch_rcnn_reg'].reshape(B, 7 * R)
+        if R > L.max_box:
+            raise ValueError('record layout holds %d RoIs per frame, the head produced %d' % (L.max_box, R))
+        out[:, L.o_cls:L.o_cls + R] = rec['batch_rcnn_cls'].reshape(B, R)
+        out[:, L.o_reg:L.o_reg + 7 * R] = rec['batch_rcnn_reg'].reshape(B, 7 * R)
+    if rec.get('gt_stats', None) is not None:
+        out[:, L.o_gt:] = rec['gt_stats'].reshape(B, -1)
     return out
 
 
-def unpack_records(records):
-    """(F, REC_STRIDE) -> dict of views"""
-    o = 2 + 2 * MAX_BOX
-    return {'entropy': records[:, 0], 'num': records[:, 1].long(), 'labels': records[:, 2:2 + MAX_BOX].long(),
-            'density': records[:, 2 + MAX_BOX:o], 'rcnn_cls': records[:, o:o + MAX_BOX].unsqueeze(-1),
-            'rcnn_reg': records[:, o + MAX_BOX:].reshape(-1, MAX_BOX, 7)}
+def unpack_records(records, layout=None):
+    """(F, layout.stride) -> dict of views"""
+    L = layout or DEFAULT_LAYOUT
+    mb = L.max_box
+    return {'entropy': records[:, 0], 'num': records[:, 1].long(),
+            'labels': records[:, L.o_labels:L.o_labels + mb].long(),
+            'density': records[:, L.o_density:L.o_density + mb],
+            'rcnn_cls': records[:, L.o_cls:L.o_cls + mb].unsqueeze(-1),
+            'rcnn_reg': records[:, L.o_reg:L.o_reg + 7 * mb].reshape(-1, mb, 7),
+            'gt_stats': records[:, L.o_gt:].reshape(-1, L.num_class, GT_STAT_FIELDS)}
 
 
 def shard_indices(n, rank, world):

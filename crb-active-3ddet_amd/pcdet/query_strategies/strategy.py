@@ -77,6 +77,57 @@ class Strategy:
         except Exception:
             pass
 
+    # ------------------------------------------------------------------ distributed helpers / GT statistics
+    def _world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+
+    @property
+    def detector(self):
+        return getattr(self.model, 'module', self.model)          # DDP-wrapped or bare
+
+    @property
+    def layout(self):
+        """fixed-stride record layout of this detector (scoring.RecordLayout.for_model)"""
+        if getattr(self, '_layout', None) is None:
+            from . import scoring
+            self._layout = scoring.RecordLayout.for_model(self.detector)
+        return self._layout
+
+    def record_gt_stats(self, gt_stats, frame_ids=None):
+        """gt_stats (F, C, 5) rows {num_bbox, n_counted, mean, median, variance} in pool order (device or host) ->
+        save_points() for every frame: what the reference's loops do frame by frame with pred_dicts[b] (crb_sampling.py:84,
+        entropy_sampling.py:41, random_sampling.py:41), here once for the whole all-gathered pool so that EVERY rank can
+        answer save_active_labels() for any selected frame."""
+        from ..models.detectors.post_processing import class_names_of, gt_stats_to_dicts
+        names = class_names_of(self.detector)
+        host = gt_stats.detach().float().cpu().numpy() if hasattr(gt_stats, 'detach') else gt_stats
+        ids = frame_ids if frame_ids is not None else [p[0] for p in self.pairs]
+        assert len(ids) == host.shape[0], (len(ids), host.shape)
+        for fid, row in zip(ids, host):
+            nb, mean_p, med_p, var_p = gt_stats_to_dicts(row, names)
+            self.save_points(fid, {'num_bbox': nb, 'mean_points': mean_p, 'median_points': med_p,
+                                   'variance_points': var_p})
+
+    def gt_stats_pool(self, frame_indices, batch_size):
+        """GT point statistics of the given pool frames WITHOUT a detector pass (they depend on points and gt boxes only):
+        -> (len, C, 5) device tensor"""
+        import torch
+        from ..models import load_data_to_gpu
+        from ..models.detectors.post_processing import class_names_of, gt_point_stats_device
+        nc = len(class_names_of(self.detector))
+        rows = []
+        for batch in self.iter_pool_batches(frame_indices, batch_size):
+            load_data_to_gpu(batch)
+            batch['point_frame_offsets'] = batch['point_frame_offsets'].int()
+            rows.append(gt_point_stats_device(batch, nc)[0])
+        if not rows:
+            dev = next(self.detector.parameters()).device
+            return torch.zeros((0, nc, 5), dtype=torch.float32, device=dev)
+        return torch.cat(rows, 0)
+
     def save_points(self, frame_id, batch_dict):
         self.bbox_records[frame_id] = batch_dict['num_bbox']
         self.mean_point_records[frame_id] = batch_dict['mean_points']

@@ -263,6 +263,17 @@ int crb_three_interpolate_grad_stack(int64_t N, int C, const float* grad_out, co
  * ---------------------------------------------------------------------------------------------- */
 int crb_points_in_boxes(int B, int T, int M, const float* boxes, const float* pts, int32_t* box_idx_of_points,
                         void* stream);
+/* GT point statistics of the CRB-patched post-processing, all frames and classes in two launches.
+ * replaces: the per-frame / per-class loop of pcdet/models/detectors/detector3d_template.py:236-268 (points_in_boxes_gpu
+ *           per class + `(idx == i).sum()` per unique index + torch.mean / median / var on the host side).
+ * pts (N,stride) f32 rows [b,x,y,z,...] frame-sorted, frame_offsets (B+1) i32, gt_boxes (B,G,8) rows
+ * [x,y,z,dx,dy,dz,heading,label] (label 0 = padding) -> stats (B,C,5) f32 {num_bbox, n_counted, mean, median, variance}
+ * of the per-box point counts (boxes owning no point are not counted; when a frame has no background point for a class
+ * the first counted box is dropped, as the reference's `[1:]` does). workspace: the first B*G i32 hold the per-box
+ * counts afterwards (then B*C background counts). */
+int64_t crb_gt_point_stats_workspace_bytes(int B, int G, int C);
+int crb_gt_point_stats(int B, int G, int C, int64_t N, int stride, const float* pts, const int32_t* frame_offsets,
+                       const float* gt_boxes, float* stats, void* workspace, int64_t workspace_bytes, void* stream);
 int crb_roiaware_pool3d_forward(int N, int P, int C, int max_pts_each_voxel, int out_x, int out_y, int out_z,
                                 const float* rois, const float* pts, const float* pts_feature,
                                 int32_t* argmax, int32_t* pts_idx_of_voxels, float* pooled_features,

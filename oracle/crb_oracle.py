@@ -75,3 +75,28 @@ def density_greedy(density_list, label_list, x_axis, prior, num_class, select_nu
         scores.append(best)
         del density_list[best_i], label_list[best_i], ids[best_i]
     return picked, scores
+
+
+def gt_point_statistics(points_xyz, gt_boxes, num_class):
+    """per-class GT point statistics of ONE frame, following detector3d_template.py:236-268 step by step: per class the
+    first-hit points-in-boxes over that class's boxes only, `(idx == i).sum()` for every unique index, the first entry of
+    the sorted unique list dropped (`[1:]`, meant to skip the -1 bin), then torch.mean / median / var(unbiased=False) with
+    NaN -> 0. points_xyz (n,3), gt_boxes (G,8) -> list over classes of (num_bbox, n_counted, mean, median, variance)"""
+    import oracle
+    out = []
+    lab = gt_boxes[:, -1]
+    for c in range(num_class):
+        m = lab == (c + 1)
+        n_cls = int(m.sum())
+        if n_cls == 0:
+            out.append((0, 0, 0.0, 0.0, 0.0))
+            continue
+        idx = oracle.points_in_boxes(points_xyz[None].astype(np.float32), gt_boxes[m][None, :, :7].astype(np.float32))[0]
+        idx = torch.from_numpy(idx).long()
+        cnt = torch.tensor([(idx == i).sum() for i in torch.unique(idx)])[1:].float()
+        if cnt.numel() == 0:
+            out.append((n_cls, 0, 0.0, 0.0, 0.0))
+        else:
+            out.append((n_cls, int(cnt.numel()), float(torch.mean(cnt)), float(torch.median(cnt)),
+                        float(torch.var(cnt, unbiased=False))))
+    return out

@@ -1,7 +1,7 @@
 """ORACLE — test infrastructure only: CPU port of one SECOND forward+backward step, used as the `cpu_baseline` leg of
 bench.py and by smoke()/tests as a checker. The sparse half runs on the C restatements of this directory
 (voxelize_oracle.c, sparse_conv_oracle.c) wrapped as autograd Functions; the dense half (BEV backbone, anchor head,
-target assignment, losses) is stock PyTorch on the CPU. Follows pcdet/models/detectors/second_net.py:9-34 and the layer
+target assignment, losses) is oracle/anchor_head_oracle.py — functional torch on the CPU, pinned by the reference's goldens. Follows pcdet/models/detectors/second_net.py:9-34 and the layer
 list of pcdet/models/backbones_3d/spconv_backbone.py:77-117."""
 import numpy as np
 import torch
@@ -69,19 +69,31 @@ def sparse_backbone_cpu(backbone, feats, coords, batch_size):
     return dense.view(B, C * D, H, W), levels
 
 
-def second_step_cpu(model, points, frame_offsets, gt_boxes, max_voxels=16000, max_points=5):
-    """one fwd+bwd of SECOND on the CPU. model: pcdet SECONDNet on the CPU in train() mode.
-    points (n,C) ndarray, frame_offsets (B+1), gt_boxes (B,G,8) ndarray -> loss (float)"""
+def second_step_cpu(model, points, frame_offsets, gt_boxes, max_voxels=16000, max_points=5, return_parts=False):
+    """one fwd+bwd of SECOND on the CPU. model: pcdet SECONDNet on the CPU in train() mode — used as a PARAMETER CONTAINER
+    only: the sparse half runs on the C restatements, the dense half (BEV backbone, head, anchors, target assignment,
+    losses) on oracle/anchor_head_oracle.py, none of the product's forward code. Gradients land in the parameters' .grad.
+    points (n,C) ndarray, frame_offsets (B+1), gt_boxes (B,G,8) ndarray -> loss (float) [, (cls, loc, dir) floats]"""
+    from oracle import anchor_head_oracle as aho
     ds = model.dataset
     B = len(frame_offsets) - 1
     v, c, n, _ = oracle.voxelize_batch(points, frame_offsets, ds.point_cloud_range[:3], ds.voxel_size,
                                        [int(g) for g in ds.grid_size], max_voxels, max_points)
     feats = torch.from_numpy(oracle.mean_vfe(v, n))
     bev, _ = sparse_backbone_cpu(model.backbone_3d, feats, c, B)
-    bd = {'batch_size': B, 'spatial_features': bev, 'gt_boxes': torch.from_numpy(gt_boxes)}
-    bd = model.backbone_2d(bd)
-    bd = model.dense_head(bd)
-    loss, tb, _ = model.get_training_loss()
+    feats2d = aho.bev_backbone(model.backbone_2d, bev)
+    cls, box, dr = aho.head_preds(model.dense_head, feats2d)
+    hcfg = model.model_cfg.DENSE_HEAD
+    acfg = [dict(a) for a in hcfg.ANCHOR_GENERATOR_CONFIG]
+    fm = [np.asarray(ds.grid_size[:2]) // a['feature_map_stride'] for a in acfg]
+    anchors = aho.generate_anchors(ds.point_cloud_range, acfg, fm)
+    labels, targets, _ = aho.assign_targets(anchors, torch.from_numpy(gt_boxes), list(ds.class_names), acfg)
+    lw = hcfg.LOSS_CONFIG.LOSS_WEIGHTS
+    loss, lc, ll, ld = aho.rpn_loss(cls, box, dr, labels, targets, anchors, num_class=len(ds.class_names),
+                                    dir_offset=hcfg.DIR_OFFSET, num_bins=hcfg.NUM_DIR_BINS, w_cls=lw['cls_weight'],
+                                    w_loc=lw['loc_weight'], w_dir=lw['dir_weight'])
     model.zero_grad(set_to_none=True)
     loss.backward()
+    if return_parts:
+        return float(loss.detach()), (float(lc.detach()), float(ll.detach()), float(ld.detach()))
     return float(loss.detach())

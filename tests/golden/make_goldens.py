@@ -402,11 +402,229 @@ def gen_points_in_boxes_ref():
     save('ref_points_in_boxes.npz', d)
 
 
+def _install_cpu_ops():
+    """the reference's Python op wrappers stay in play; only the three compiled entry points they call are answered by the
+    oracle (pinned to the reference's own CPU sources where those exist: rotated overlap -> iou3d_cpu.cpp, point-in-box
+    -> roiaware_pool3d.cpp)"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    sys.path.insert(0, os.path.dirname(OUT))
+    import oracle
+    nms_mod = sys.modules['pcdet.ops.iou3d_nms.iou3d_nms_cuda']
+    pool_mod = sys.modules['pcdet.ops.roiaware_pool3d.roiaware_pool3d_cuda']
+
+    def nms_gpu(boxes, keep, thresh):
+        k = oracle.nms(boxes.numpy(), float(thresh), rotated=True)
+        keep[:len(k)] = torch.from_numpy(k.astype(np.int64))
+        return len(k)
+
+    def boxes_overlap_bev_gpu(a, b, out):
+        out.copy_(torch.from_numpy(oracle.boxes_pairwise(a.numpy(), b.numpy(), 0)))
+        return 1
+
+    def points_in_boxes_gpu(boxes, points, idx):
+        idx.copy_(torch.from_numpy(oracle.points_in_boxes(points.numpy(), boxes.numpy())))
+        return 1
+    nms_mod.nms_gpu, nms_mod.boxes_overlap_bev_gpu = nms_gpu, boxes_overlap_bev_gpu
+    pool_mod.points_in_boxes_gpu = points_in_boxes_gpu
+    torch.cuda.FloatTensor = torch.FloatTensor
+    return oracle
+
+
+def post_processing_inputs(seed=31):
+    """3 ragged frames: clustered points inside gt boxes + clutter, 128 RoIs around the objects, PV-RCNN-style head outputs"""
+    rng = np.random.default_rng(seed)
+    sizes = {1: (3.9, 1.6, 1.56), 2: (0.8, 0.6, 1.73), 3: (1.76, 0.6, 1.73)}
+    B, G, R = 3, 10, 128
+    gt = np.zeros((B, G, 8), np.float32)
+    pts, rois = [], np.zeros((B, R, 7), np.float32)
+    n_gt = [10, 7, 8]
+    for b in range(B):
+        for g in range(n_gt[b]):
+            c = int(rng.integers(1, 4)) if b != 1 else int(rng.integers(1, 3))          # frame 1 has no Cyclist
+            if b == 2:
+                c = 2 if g < 2 else int(rng.choice([1, 3]))      # frame 2: two Pedestrian boxes, both without points
+            s = np.array(sizes[c]) * rng.uniform(0.9, 1.1, 3)
+            gt[b, g] = [rng.uniform(5, 60), rng.uniform(-30, 30), rng.uniform(-1.2, -0.6), *s, rng.uniform(-np.pi, np.pi), c]
+        p = [np.stack([rng.uniform(0, 70, 1500), rng.uniform(-40, 40, 1500), rng.uniform(-3, 1, 1500)], 1)]
+        for g in range(n_gt[b]):
+            if b == 2 and gt[b, g, 7] == 2:
+                continue                                     # frame 2: Pedestrian boxes own no point (NaN mean -> 0)
+            k = int(rng.integers(1, 60))
+            loc = rng.uniform(-0.5, 0.5, (k, 3)) * gt[b, g, 3:6]
+            ca, sa = np.cos(gt[b, g, 6]), np.sin(gt[b, g, 6])
+            p.append(np.stack([loc[:, 0] * ca - loc[:, 1] * sa + gt[b, g, 0], loc[:, 0] * sa + loc[:, 1] * ca + gt[b, g, 1],
+                               loc[:, 2] + gt[b, g, 2]], 1))
+        p = np.concatenate(p).astype(np.float32)
+        if b == 2:                                           # keep the clutter away from the point-free boxes
+            far = np.ones(len(p), bool)
+            for g in range(n_gt[b]):
+                if gt[b, g, 7] == 2:
+                    far &= np.linalg.norm(p[:, :2] - gt[b, g, :2], axis=1) > 2.0
+            p = p[far]
+        p = p[rng.permutation(len(p))]
+        pts.append(np.concatenate([np.full((len(p), 1), b, np.float32), p, rng.uniform(0, 1, (len(p), 1)).astype(np.float32)], 1))
+        k = rng.integers(0, n_gt[b], R)
+        rois[b] = gt[b, k, :7] + rng.normal(0, 0.3, (R, 7)).astype(np.float32) * np.array([1, 1, .2, .1, .1, .1, .3], np.float32)
+        rois[b, 100:, :2] += rng.uniform(8, 20, (28, 2)).astype(np.float32)            # some boxes off the objects
+    points = np.concatenate(pts).astype(np.float32)
+    box_preds = rois + rng.normal(0, 0.05, rois.shape).astype(np.float32)
+    d = {
+        'points': points, 'gt_boxes': gt, 'rois': rois, 'batch_box_preds': box_preds,
+        'batch_cls_preds': rng.normal(0.3, 2.0, (B, R, 1)).astype(np.float32),
+        'roi_labels': rng.integers(1, 4, (B, R)).astype(np.int64),
+        'full_cls_scores': rng.normal(0, 1.5, (B, R, 3)).astype(np.float32),
+        'rcnn_cls': rng.normal(0, 1.5, (5, B * R, 1)).astype(np.float32),
+        'rcnn_reg': rng.normal(0, 0.4, (5, B * R, 7)).astype(np.float32),
+        'rpn_preds': rng.normal(0, 1, (B, 2, 3, 18)).astype(np.float32),
+    }
+    return d
+
+
+POST_CFG = {'RECALL_THRESH_LIST': [0.3, 0.5, 0.7], 'SCORE_THRESH': 0.1, 'OUTPUT_RAW_SCORE': False, 'EVAL_METRIC': 'kitti',
+            'NMS_CONFIG': {'MULTI_CLASSES_NMS': False, 'NMS_TYPE': 'nms_gpu', 'NMS_THRESH': 0.1, 'NMS_PRE_MAXSIZE': 4096,
+                           'NMS_POST_MAXSIZE': 500}}
+
+
+def gen_post_processing(out):
+    """ref_post_processing.npz + ref_selected_frames_epoch_7_rank_0.pkl: the reference's CRB-patched
+    Detector3DTemplate.post_processing (detector3d_template.py:186-409) on a 3-frame batch -> its 15 record keys per frame,
+    the recall dict, and the pickle its Strategy.save_points / save_active_labels (strategy.py:28-38,66-75) write for two
+    selected frames"""
+    import shutil
+    import tempfile
+    import types
+    _install_cpu_ops()
+    from pcdet.models.detectors.detector3d_template import Detector3DTemplate
+    from pcdet.query_strategies.strategy import Strategy
+    inp = post_processing_inputs()
+    names = ['Car', 'Pedestrian', 'Cyclist']
+    model_cfg = EasyDict({'POST_PROCESSING': POST_CFG,
+                          'DENSE_HEAD': {'ANCHOR_GENERATOR_CONFIG': [{'class_name': n} for n in names]}})
+    fake = types.SimpleNamespace(model_cfg=model_cfg, num_class=3,
+                                 generate_recall_record=Detector3DTemplate.generate_recall_record)
+    bd = {k: torch.from_numpy(v.copy()) for k, v in inp.items()}
+    bd.update({'batch_size': 3, 'cls_preds_normalized': False, 'has_class_labels': True})
+    with torch.no_grad():
+        pred_dicts, recall = Detector3DTemplate.post_processing(fake, bd)
+    for k, v in inp.items():
+        out['in_' + k] = v
+    f = lambda v: np.float64(v) if not torch.is_tensor(v) else _np(v).astype(np.float64)
+    for b, d in enumerate(pred_dicts):
+        for k in ('pred_boxes', 'pred_scores', 'pred_labels', 'pred_logits', 'pred_box_unique_density', 'batch_rcnn_cls',
+                  'batch_rcnn_reg', 'confidence'):
+            out['f%d_%s' % (b, k)] = _np(d[k])
+        for k in ('num_bbox', 'mean_points', 'median_points', 'variance_points'):
+            out['f%d_%s' % (b, k)] = np.array([f(d[k][n]) for n in names])
+            out['f%d_%s_is_tensor' % (b, k)] = np.array([torch.is_tensor(d[k][n]) for n in names])
+        assert d['loss_predictions'] is None and d['embeddings'] is None
+    out['recall_keys'] = np.array(sorted(recall.keys()))
+    out['recall_vals'] = np.array([recall[k] for k in sorted(recall.keys())], np.int64)
+    # the reference's bookkeeping + pickle
+    tmp = tempfile.mkdtemp()
+    st = Strategy.__new__(Strategy)
+    st.active_label_dir, st.rank = tmp, 0
+    st.bbox_records = {}
+    st.point_measures = ['mean', 'median', 'variance']
+    for met in st.point_measures:
+        setattr(st, '{}_point_records'.format(met), {})
+    ids = ['000010', '000011', '000012']
+    for b, d in enumerate(pred_dicts):
+        st.save_points(ids[b], d)
+    st.save_active_labels(selected_frames=['000012', '000010'], cur_epoch=7)
+    shutil.copy(os.path.join(tmp, 'selected_frames_epoch_7_rank_0.pkl'),
+                os.path.join(OUT, 'ref_selected_frames_epoch_7_rank_0.pkl'))
+    shutil.rmtree(tmp)
+    out['frame_ids'] = np.array(ids)
+
+
+def gen_glue(out):
+    """ref_glue.npz: host/device glue rows of SURVEY §8 that had no reference pin — DatasetTemplate.collate_batch
+    (dataset.py:160-229), the eval DistributedSampler (datasets/__init__.py:26-46), bilinear_interpolate_torch +
+    VoxelSetAbstraction.interpolate_from_bev_features (voxel_set_abstraction.py:11-42,176-204), PointHeadSimple forward /
+    assign_stack_targets / loss (point_head_simple.py:58-91, point_head_template.py:49-170)"""
+    import types
+    oracle = _install_cpu_ops()
+    from pcdet.datasets import DistributedSampler
+    from pcdet.datasets.dataset import DatasetTemplate
+    from pcdet.models.backbones_3d.pfe import voxel_set_abstraction as vsa
+    from pcdet.models.dense_heads.point_head_simple import PointHeadSimple
+    rng = np.random.default_rng(41)
+    # ---- collate_batch: 3 ragged frames in the reference loader's layout
+    frames = []
+    for i, (n, m, g) in enumerate(((50, 17, 4), (31, 9, 0), (44, 20, 7))):
+        frames.append({'points': rng.normal(size=(n, 4)).astype(np.float32),
+                       'voxels': rng.normal(size=(m, 5, 4)).astype(np.float32),
+                       'voxel_coords': rng.integers(0, 40, (m, 3)).astype(np.int32),
+                       'voxel_num_points': rng.integers(1, 6, m).astype(np.int32),
+                       'gt_boxes': rng.normal(size=(g, 8)).astype(np.float32), 'frame_id': '%06d' % (7 * i + 3),
+                       'use_lead_xyz': True})
+    col = DatasetTemplate.collate_batch([dict(f) for f in frames])
+    for i, f in enumerate(frames):
+        for k in ('points', 'voxels', 'voxel_coords', 'voxel_num_points', 'gt_boxes'):
+            out['col_in%d_%s' % (i, k)] = f[k]
+    out['col_in_frame_id'] = np.array([f['frame_id'] for f in frames])
+    for k, v in col.items():
+        out['col_out_' + k] = np.asarray(v)
+    # ---- eval sampler: every (n, world, rank)
+    for n, world in ((10, 4), (3000, 8), (7, 2), (5, 8), (16, 1)):
+        out['sampler_%d_%d' % (n, world)] = np.stack([
+            np.array(list(DistributedSampler(list(range(n)), world, r, shuffle=False)), np.int64) for r in range(world)])
+    # ---- bilinear lookup incl. positions outside the map (clamped taps)
+    im = rng.normal(size=(25, 22, 6)).astype(np.float32)
+    x = rng.uniform(-1.5, 23.5, 300).astype(np.float32)
+    y = rng.uniform(-1.5, 26.5, 300).astype(np.float32)
+    x[:5], y[:5] = [0, 21, 3, 21.0, 10.5], [0, 24, 24.0, 0.5, 7]
+    out['bil_im'], out['bil_x'], out['bil_y'] = im, x, y
+    out['bil_out'] = _np(vsa.bilinear_interpolate_torch(torch.from_numpy(im), torch.from_numpy(x), torch.from_numpy(y)))
+    fake = types.SimpleNamespace(voxel_size=[0.05, 0.05, 0.1], point_cloud_range=np.array([0, -40, -3, 70.4, 40, 1], np.float32))
+    B, K = 3, 40
+    kp = np.concatenate([np.repeat(np.arange(B), K)[:, None], rng.uniform(0, 8.8, (B * K, 1)), rng.uniform(-40, -30, (B * K, 1)),
+                         rng.uniform(-3, 1, (B * K, 1))], 1).astype(np.float32)
+    bev = rng.normal(size=(B, 6, 25, 22)).astype(np.float32)
+    out['bev_kp'], out['bev_map'] = kp, bev
+    out['bev_out'] = _np(vsa.VoxelSetAbstraction.interpolate_from_bev_features(fake, torch.from_numpy(kp), torch.from_numpy(bev), B, 8))
+    # ---- point head
+    cfg = EasyDict({'NAME': 'PointHeadSimple', 'CLS_FC': [16, 16], 'CLASS_AGNOSTIC': True,
+                    'USE_POINT_FEATURES_BEFORE_FUSION': True, 'NUM_KEYPOINTS': 64,
+                    'TARGET_CONFIG': {'GT_EXTRA_WIDTH': [0.2, 0.2, 0.2]},
+                    'LOSS_CONFIG': {'LOSS_REG': 'smooth-l1', 'LOSS_WEIGHTS': {'point_cls_weight': 1.0}}})
+    torch.manual_seed(9)
+    head = PointHeadSimple(num_class=1, input_channels=12, model_cfg=cfg)
+    head.train()
+    K = 64
+    gt = rand_gt(rng, B, 6, ((2, 30), (-12, 12)))
+    pc = []
+    for b in range(B):
+        p = np.stack([rng.uniform(0, 32, K), rng.uniform(-14, 14, K), rng.uniform(-2, 0.5, K)], 1)
+        for j in range(K // 2):                                        # half the keypoints on / just around the objects
+            g = gt[b, j % 6]
+            if g[7] == 0:
+                continue
+            loc = rng.uniform(-0.58, 0.58, 3) * g[3:6]
+            ca, sa = np.cos(g[6]), np.sin(g[6])
+            p[j] = [loc[0] * ca - loc[1] * sa + g[0], loc[0] * sa + loc[1] * ca + g[1], loc[2] + g[2]]
+        pc.append(np.concatenate([np.full((K, 1), b), p], 1))
+    pc = np.concatenate(pc).astype(np.float32)
+    feats = torch.from_numpy(rng.normal(size=(B * K, 12)).astype(np.float32)).requires_grad_(True)
+    bd = head({'point_features_before_fusion': feats, 'point_features': feats, 'point_coords': torch.from_numpy(pc),
+               'gt_boxes': torch.from_numpy(gt.copy()), 'batch_size': B})
+    loss, tb = head.get_loss()
+    loss.backward()
+    out['ph_state'] = {k: _np(v) for k, v in head.state_dict().items()}
+    out['ph_feats'], out['ph_coords'], out['ph_gt'] = _np(feats), pc, gt
+    out['ph_labels'] = _np(head.forward_ret_dict['point_cls_labels'])
+    out['ph_scores'] = _np(bd['point_cls_scores'])
+    out['ph_loss'] = np.array([float(loss), float(tb['point_loss_cls']), float(tb['point_pos_num'])])
+    out['ph_feats_grad'] = _np(feats.grad)
+    assert (out['ph_labels'] == -1).sum() > 3 and (out['ph_labels'] == 1).sum() > 10
+
+
 if __name__ == '__main__':
     import_reference()
     only = sys.argv[1:] 
     for name, fn in (('ref_utils.npz', gen_utils), ('ref_anchor_head.npz', gen_head), ('ref_bev_vfe.npz', gen_bev), ('ref_roi_head.npz', gen_roi_head),
-                     ('ref_strategies.npz', gen_strategies), ('ref_data_processor.npz', gen_data_processor)):
+                     ('ref_strategies.npz', gen_strategies), ('ref_data_processor.npz', gen_data_processor),
+                     ('ref_post_processing.npz', gen_post_processing), ('ref_glue.npz', gen_glue)):
         if only and name not in only:
             continue
         d = {}

@@ -42,7 +42,36 @@ def test_density_greedy_matches_sklearn_loop(dev, n, select):
     np.testing.assert_allclose(scores[1:len(ref)], ref_scores[1:], rtol=1e-9, atol=1e-12)
 
 
-def test_crb_query_end_to_end_small_pool(dev):
+def _check_gt_records(strat, pool, picked, tmp_path, tag):
+    """bbox / mean / median / variance records of all pool frames == oracle (reference loop restated), and the pickle
+    save_active_labels writes for the picked frames holds exactly those entries"""
+    import pickle
+    names = ['Car', 'Pedestrian', 'Cyclist']
+    assert set(strat.bbox_records) == set(pool.sample_id_list)
+    for i, fid in enumerate(pool.sample_id_list):
+        fr = pool[i]
+        ref = crb_oracle.gt_point_statistics(fr['points'][:, :3], fr['gt_boxes'], 3)
+        for c, name in enumerate(names):
+            assert int(strat.bbox_records[fid][name]) == ref[c][0], (fid, name)
+            np.testing.assert_allclose(float(strat.mean_point_records[fid][name]), ref[c][2], rtol=1e-6)
+            np.testing.assert_allclose(float(strat.median_point_records[fid][name]), ref[c][3], rtol=0)
+            np.testing.assert_allclose(float(strat.variance_point_records[fid][name]), ref[c][4], rtol=1e-5)
+            assert torch.is_tensor(strat.bbox_records[fid][name]) == (ref[c][0] > 0)
+            assert torch.is_tensor(strat.mean_point_records[fid][name]) == (ref[c][1] > 0)
+    strat.active_label_dir = str(tmp_path)
+    strat.save_active_labels(selected_frames=picked, cur_epoch=3)
+    with open(str(tmp_path / 'selected_frames_epoch_3_rank_0.pkl'), 'rb') as f:
+        d = pickle.load(f)
+    assert list(d.keys()) == ['frame_id', 'selected_mean_points', 'selected_bbox', 'selected_median_points',
+                              'selected_variance_points']
+    assert d['frame_id'] == picked and len(d['selected_bbox']) == len(picked)
+    for k, fid in enumerate(picked):
+        assert d['selected_bbox'][k] is strat.bbox_records[fid] or d['selected_bbox'][k].keys() == strat.bbox_records[fid].keys()
+        for name in names:
+            assert float(d['selected_mean_points'][k][name]) == float(strat.mean_point_records[fid][name])
+
+
+def test_crb_query_end_to_end_small_pool(dev, tmp_path):
     """24-frame pool, SELECT_NUMS=3, K1=4 (12 frames get gradients), K2=2 (6 prototypes)"""
     from pcdet.datasets import SyntheticDataset, build_synthetic_dataloader
     from pcdet.model_cfgs import pv_rcnn_cfg
@@ -66,15 +95,14 @@ def test_crb_query_end_to_end_small_pool(dev):
     rec = scoring.unpack_records(strat.last_records)
     assert strat.last_records.shape == (24, scoring.REC_STRIDE)
     assert int(rec['num'].sum()) > 0
-    # stage-1 ranking is the reference's: top K1*N by label entropy
+    # stage 1 keeps the K1*N = 12 frames of largest label entropy, stage 3 picks among the K2*N = 6 prototypes of those
     ent = rec['entropy'].cpu().numpy()
-    top = np.argsort(ent, kind='stable')[::-1][:12]
-    assert set(np.sort(top)) == set(np.argsort(-ent, kind='stable')[:12]) or True
+    top12 = set(np.argsort(ent, kind='stable')[::-1][:12].tolist())
+    assert {pool.sample_id_list.index(f) for f in picked} <= top12
     assert {'stage1_s', 'stage2_s', 'stage3_s'} <= set(strat.timings)
-    # determinism of the scoring pass itself is not expected (MC dropout); entropy strategy runs too
-    e = build_strategy('entropy', model, build_synthetic_dataloader(lab, 2), build_synthetic_dataloader(pool, 4), 0,
-                       '/tmp', cfg).query(cur_epoch=0)
-    assert len(e) == 3
+    # the caller's next step (active_training_utils.py:270-273): save_active_labels right after query() — the GT statistics of
+    # EVERY pool frame were recorded from the gathered rows; compare with the step-by-step restatement of the reference loop
+    _check_gt_records(strat, pool, picked, tmp_path, 'crb')
     # pool frames read by the loader's worker processes (as the reference's DataLoader does) == read inline
     w = build_strategy('crb', model, build_synthetic_dataloader(lab, 2), build_synthetic_dataloader(pool, 4, workers=2), 0,
                        '/tmp', cfg)
@@ -219,3 +247,69 @@ def test_stage2_group_uploaded_frames_equal_single_frame_batches(dev):
         kp, done = one['_keypoints_prefetched']
         torch.cuda.current_stream().wait_event(done)
         assert torch.equal(kp, model.pfe.get_sampled_points(ref))
+
+
+@pytest.mark.parametrize('method', ['entropy', 'random'])
+def test_query_then_save_active_labels_entropy_random(dev, tmp_path, method):
+    """the strategy <-> caller contract for the two other strategies VERDICT names: query() then save_active_labels()"""
+    import random
+    from pcdet.datasets import SyntheticDataset, build_synthetic_dataloader
+    from pcdet.model_cfgs import pv_rcnn_cfg
+    from pcdet.models import build_network
+    from pcdet.query_strategies import build_strategy
+    cfg = pv_rcnn_cfg()
+    cfg.ACTIVE_TRAIN.SELECT_NUMS = 3
+    torch.manual_seed(0)
+    pool = SyntheticDataset(num_frames=10, first_frame=900)
+    lab = SyntheticDataset(num_frames=4, first_frame=0)
+    model = build_network(cfg.MODEL, 3, pool).to(dev)
+    with torch.no_grad():
+        model.roi_head.cls_layers[-1].bias.fill_(1.0)
+    strat = build_strategy(method, model, build_synthetic_dataloader(lab, 2), build_synthetic_dataloader(pool, 4), 0,
+                           str(tmp_path), cfg)
+    random.seed(5)
+    picked = strat.query(cur_epoch=3)
+    assert len(picked) == 3 and len(set(picked)) == 3 and set(picked) <= set(pool.sample_id_list)
+    if method == 'random':
+        ids = list(pool.sample_id_list)
+        random.seed(5)
+        random.shuffle(ids)
+        assert picked == ids[:3]                               # the reference's rule: shuffle the pool ids, take the first N
+    else:
+        v = strat.last_values.cpu().numpy()
+        assert picked == [pool.sample_id_list[i] for i in np.argsort(v, kind='stable')[-3:]]
+    _check_gt_records(strat, pool, picked, tmp_path, method)
+
+
+def test_select_active_labels_moves_frames_and_rebuilds_loaders(dev, tmp_path):
+    """pcdet.utils.active_training_utils.select_active_labels (active_training_utils.py:240-325) over the synthetic
+    'KittiDataset': query -> pickle -> the picked frames leave the pool and join the labelled split"""
+    import pickle
+    import random
+    from pcdet.config import cfg as gcfg
+    from pcdet.datasets import build_active_dataloader
+    from pcdet.model_cfgs import pv_rcnn_cfg
+    from pcdet.models import build_network
+    from pcdet.utils.active_training_utils import select_active_labels
+    c = pv_rcnn_cfg()
+    c.ACTIVE_TRAIN.SELECT_NUMS = 2
+    c.ACTIVE_TRAIN.PRE_TRAIN_SAMPLE_NUMS = 3
+    c.DATA_CONFIG.SYNTHETIC = {'NUM_FRAMES': 9, 'FIRST_FRAME': 1200}
+    gcfg.update(c)
+    random.seed(1)
+    lab_set, unl_set, lab_loader, unl_loader, _, _ = build_active_dataloader(gcfg.DATA_CONFIG, gcfg.CLASS_NAMES, 2, False,
+                                                                            workers=0, training=True)
+    assert len(lab_set) == 3 and len(unl_set) == 6 and not (set(lab_set.sample_id_list) & set(unl_set.sample_id_list))
+    torch.manual_seed(0)
+    model = build_network(gcfg.MODEL, 3, unl_set).to(dev)
+    before_lab, before_unl = list(lab_set.sample_id_list), list(unl_set.sample_id_list)
+    new_lab, new_unl = select_active_labels(model, lab_loader, unl_loader, 0, None, 'random', cur_epoch=40,
+                                            active_label_dir=str(tmp_path))
+    with open(str(tmp_path / 'selected_frames_epoch_40_rank_0.pkl'), 'rb') as f:
+        picked = pickle.load(f)['frame_id']
+    assert len(picked) == 2 and set(picked) <= set(before_unl)
+    assert list(new_lab.dataset.sample_id_list) == before_lab + [f for f in before_unl if f in picked]
+    assert list(new_unl.dataset.sample_id_list) == [f for f in before_unl if f not in picked]
+    assert new_unl.batch_size == 2 and len(new_lab.dataset.kitti_infos) == 5
+    b = next(iter(new_lab))
+    assert b['batch_size'] == 2 and 'points' in b and 'gt_boxes' in b

@@ -13,29 +13,18 @@ import oracle
 from oracle import crb_oracle
 
 
-def test_shard_indices_match_reference_sampler():
-    from pcdet.datasets.sampler import DistributedSampler
-    from pcdet.query_strategies import scoring
-    for n, world in ((10, 4), (3000, 8), (7, 2), (5, 8)):
-        seen = []
-        for r in range(world):
-            idx, per = scoring.shard_indices(n, r, world)
-            ref = list(DistributedSampler(list(range(n)), world, r, shuffle=False))
-            assert idx == ref and len(idx) == per
-            seen += idx
-        assert set(seen) == set(range(n))
-
-
 def test_pack_unpack_records_roundtrip():
     from pcdet.query_strategies import scoring
     B, P, R = 3, 128, 128
     g = torch.Generator().manual_seed(0)
     rec = {'entropy': torch.rand(B, generator=g), 'num': torch.tensor([5, 0, 128]),
            'pred_labels': torch.randint(1, 4, (B, P), generator=g), 'density': torch.rand((B, P), generator=g) * 100,
-           'batch_rcnn_cls': torch.rand((B, R, 1), generator=g), 'batch_rcnn_reg': torch.randn((B, R, 7), generator=g)}
+           'batch_rcnn_cls': torch.rand((B, R, 1), generator=g), 'batch_rcnn_reg': torch.randn((B, R, 7), generator=g),
+           'gt_stats': torch.rand((B, 3, 5), generator=g)}
     rows = scoring.pack_records(rec)
-    assert rows.shape == (B, scoring.REC_STRIDE) and scoring.REC_STRIDE == 1282
+    assert rows.shape == (B, scoring.REC_STRIDE) and scoring.REC_STRIDE == 1282 + 15
     u = scoring.unpack_records(rows)
+    assert torch.equal(u['gt_stats'], rec['gt_stats'])
     assert torch.equal(u['num'], rec['num']) and torch.equal(u['labels'], rec['pred_labels'])
     assert torch.equal(u['density'], rec['density']) and torch.equal(u['rcnn_cls'], rec['batch_rcnn_cls'])
     assert torch.equal(u['rcnn_reg'], rec['batch_rcnn_reg']) and torch.equal(u['entropy'], rec['entropy'])

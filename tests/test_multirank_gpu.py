@@ -1,0 +1,132 @@
+"""N > 1 paths with two processes on ONE device (gloo rendezvous on 127.0.0.1; RCCL needs one GPU per rank, which the test
+box does not have): CRBSampling.query end to end with both all-gathers, and a 2-rank DDP SECOND step."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _setup(rank, world, port):
+    import torch.distributed as dist
+    for p in (ROOT, os.path.join(ROOT, 'crb-active-3ddet_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    return torch.device('cuda', 0)
+
+
+def _crb_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    dev = _setup(rank, world, port)
+    from pcdet.datasets import SyntheticDataset, build_synthetic_dataloader
+    from pcdet.model_cfgs import pv_rcnn_cfg
+    from pcdet.models import build_network
+    from pcdet.query_strategies import build_strategy
+    cfg = pv_rcnn_cfg()
+    cfg.ACTIVE_TRAIN.SELECT_NUMS = 2
+    cfg.ACTIVE_TRAIN.ACTIVE_CONFIG.K1 = 4            # 8 frames get gradient embeddings (4 per rank at world 2)
+    cfg.ACTIVE_TRAIN.ACTIVE_CONFIG.K2 = 2
+    cfg.ACTIVE_TRAIN.ACTIVE_CONFIG.FRAME_SEED = 1234
+    cfg.MODEL.ROI_HEAD.DP_RATIO = 0.0                # deterministic scoring: MC dropout is the identity
+    torch.manual_seed(0)
+    pool = SyntheticDataset(num_frames=11, first_frame=2100)          # 11 frames / 2 ranks: one wrap-around pad
+    model = build_network(cfg.MODEL, 3, pool).to(dev)
+    with torch.no_grad():
+        model.roi_head.cls_layers[-1].bias.fill_(1.0)
+    strat = build_strategy('crb', model, build_synthetic_dataloader(SyntheticDataset(num_frames=2), 2),
+                           build_synthetic_dataloader(pool, 3), rank, out_dir, cfg)
+    picked = strat.query(cur_epoch=5)
+    strat.save_active_labels(selected_frames=picked, cur_epoch=5)     # per-rank file, every rank can answer for any frame
+    torch.save({'picked': picked, 'records': strat.last_records.cpu(), 'n_records': len(strat.bbox_records)},
+               os.path.join(out_dir, 'w%d_r%d.pt' % (world, rank)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run(fn, world, args):
+    ctx = mp.get_context('spawn')
+    port = 29500 + (os.getpid() * 7 + world * 131) % 3000
+    procs = [ctx.Process(target=fn, args=(r, world, port) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=900)
+        assert p.exitcode == 0, 'worker failed (exit code %s)' % p.exitcode
+
+
+def test_crb_query_two_ranks_equals_one_rank(tmp_path):
+    out = str(tmp_path)
+    _run(_crb_worker, 2, (out,))
+    _run(_crb_worker, 1, (out,))
+    r0, r1 = torch.load(os.path.join(out, 'w2_r0.pt')), torch.load(os.path.join(out, 'w2_r1.pt'))
+    one = torch.load(os.path.join(out, 'w1_r0.pt'))
+    assert r0['picked'] == r1['picked'] and len(r0['picked']) == 2          # identical picks on both ranks
+    assert torch.equal(r0['records'], r1['records'])                         # the same gathered pool on both ranks
+    assert r0['n_records'] == r1['n_records'] == 11
+    # stage-1 records do not depend on how the pool was sharded (eval mode, per-frame quantities): integer fields exact,
+    # float fields to f32 rounding of differently batched GEMMs
+    from pcdet.query_strategies import scoring
+    a, b = scoring.unpack_records(r0['records']), scoring.unpack_records(one['records'])
+    assert torch.equal(a['num'], b['num']) and torch.equal(a['labels'], b['labels'])
+    assert torch.equal(a['gt_stats'], b['gt_stats'])
+    torch.testing.assert_close(a['entropy'], b['entropy'], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a['density'], b['density'], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(a['rcnn_cls'], b['rcnn_cls'], rtol=1e-3, atol=1e-4)
+    assert r0['picked'] == one['picked'], (r0['picked'], one['picked'])      # and so does the selection (FRAME_SEED set)
+    for r in (0, 1):
+        assert os.path.isfile(os.path.join(out, 'selected_frames_epoch_5_rank_%d.pkl' % r))
+
+
+def _ddp_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    dev = _setup(rank, world, port)
+    from pcdet.datasets import SyntheticDataset
+    from pcdet.datasets.synthetic import kitti_batch
+    from pcdet.model_cfgs import second_cfg
+    from pcdet.models import build_network
+    torch.manual_seed(0)
+    model = build_network(second_cfg().MODEL, 3, SyntheticDataset(num_frames=2)).to(dev)
+    model.train()
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0]) if world > 1 else model
+
+    def batch(first):
+        pts, off, gt = kitti_batch(first, 2, 6000)
+        bidx = np.repeat(np.arange(2, dtype=np.float32), np.diff(off))
+        return {'points': torch.from_numpy(np.concatenate([bidx[:, None], pts], 1)).to(dev),
+                'point_frame_offsets': torch.from_numpy(off).to(dev), 'gt_boxes': torch.from_numpy(gt).to(dev),
+                'batch_size': 2}
+    grads = None
+    for first in ([3000 + 2 * rank] if world > 1 else [3000, 3002]):          # world 1: both ranks' batches in turn
+        model.zero_grad(set_to_none=True)
+        ret, _, _ = net(batch(first))
+        ret['loss'].mean().backward()
+        g = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None]).double()
+        grads = g if grads is None else grads + g
+    if world == 1:
+        grads = grads / 2                                                    # DDP averages over ranks
+    torch.save(grads.cpu(), os.path.join(out_dir, 'ddp_w%d_r%d.pt' % (world, rank)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_ddp_second_step_two_ranks_averages_gradients(tmp_path):
+    out = str(tmp_path)
+    _run(_ddp_worker, 2, (out,))
+    _run(_ddp_worker, 1, (out,))
+    g0, g1 = torch.load(os.path.join(out, 'ddp_w2_r0.pt')), torch.load(os.path.join(out, 'ddp_w2_r1.pt'))
+    ref = torch.load(os.path.join(out, 'ddp_w1_r0.pt'))
+    assert torch.equal(g0, g1)                                               # the all-reduce left identical gradients
+    rel = float((g0 - ref).norm() / ref.norm())
+    assert rel < 2e-3, rel              # = mean of the two single-rank gradients (MIOpen weight-gradient kernels use atomics)

@@ -394,3 +394,64 @@ def test_fused_bn_relu_matches_torch(dev, C, n):
     bn_a.eval(); bn_b.eval()
     with torch.no_grad():
         torch.testing.assert_close(bnrelu.bn_relu(x, bn_a), torch.relu(bn_b(x)), rtol=1e-5, atol=1e-5)
+
+
+def test_sparse_basic_block_with_bias_matches_oracle(dev):
+    """SparseBasicBlock of VoxelResBackBone8x (spconv_backbone.py:30-66): two bias=True SubM convs sharing one rulebook,
+    BN (train statistics) + ReLU, residual add — forward and every gradient against the oracle convolution with the same
+    weights (bias added / reduced on the host in float64)"""
+    from functools import partial
+    import spconv.pytorch as spconv
+    from pcdet.models.backbones_3d.spconv_backbone import SparseBasicBlock
+    rng = np.random.default_rng(77)
+    torch.manual_seed(3)
+    shape = [21, 100, 88]
+    coords = random_sparse_coords(rng, 4000, 2, shape)
+    n, C = len(coords), 32
+    X = rng.normal(size=(n, C)).astype(np.float32)
+    dY = rng.normal(size=(n, C)).astype(np.float32)
+    blk = SparseBasicBlock(C, C, norm_fn=partial(torch.nn.BatchNorm1d, eps=1e-3, momentum=0.01), indice_key='res1').to(dev)
+    blk.train()
+    assert blk.conv1.bias is not None and blk.conv2.bias is not None
+    with torch.no_grad():
+        blk.conv1.bias.uniform_(-0.5, 0.5)
+        blk.conv2.bias.uniform_(-0.5, 0.5)
+    x = _t(X, dev).requires_grad_(True)
+    out = blk(spconv.SparseConvTensor(x, _t(coords, dev), shape, 2))
+    out.features.backward(_t(dY, dev))
+    # ---- oracle chain in float64 on the host (autograd over the oracle conv)
+    nbr = oracle.subm_nbr(coords, shape, [3, 3, 3])
+
+    class OConv(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, xx, ww):
+            ctx.save_for_backward(xx, ww)
+            return torch.from_numpy(oracle.conv_fwd(xx.numpy().astype(np.float32), ww.numpy().astype(np.float32), nbr)).double()
+
+        @staticmethod
+        def backward(ctx, g):
+            xx, ww = ctx.saved_tensors
+            gn = g.numpy().astype(np.float32)
+            return (torch.from_numpy(oracle.conv_dgrad(gn, ww.numpy().astype(np.float32), nbr, n)).double(),
+                    torch.from_numpy(oracle.conv_wgrad(xx.numpy().astype(np.float32), gn, nbr, 27)).double())
+    P = {k: v.detach().cpu().double().requires_grad_(True) for k, v in blk.named_parameters()}
+    w1 = blk.conv1.weight_kio().detach().cpu().double().requires_grad_(True)
+    w2 = blk.conv2.weight_kio().detach().cpu().double().requires_grad_(True)
+    xr = torch.from_numpy(X).double().requires_grad_(True)
+    bn = lambda t, k: torch.nn.functional.batch_norm(t, None, None, P[k + '.weight'], P[k + '.bias'], True, 0.0, 1e-3)
+    h = torch.relu(bn(OConv.apply(xr, w1) + P['conv1.bias'], 'bn1'))
+    h = bn(OConv.apply(h, w2) + P['conv2.bias'], 'bn2')
+    ref = torch.relu(h + xr)
+    ref.backward(torch.from_numpy(dY).double())
+    _close(out.features.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-4)
+    _close(x.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-3)
+    _close(_kio_grad(blk.conv1), w1.grad.numpy(), rtol=1e-3)
+    _close(_kio_grad(blk.conv2), w2.grad.numpy(), rtol=1e-3)
+    for k in ('conv1.bias', 'conv2.bias', 'bn1.weight', 'bn2.bias'):
+        _close(dict(blk.named_parameters())[k].grad.cpu().numpy(), P[k].grad.numpy(), rtol=1e-3)
+
+
+def _kio_grad(conv):
+    """gradient of the module's (Cout,k,k,k,Cin) weight viewed in the kernel's (K,Cin,Cout) layout"""
+    g = conv.weight.grad
+    return g.reshape(g.shape[0], -1, g.shape[-1]).permute(1, 2, 0).contiguous().cpu().numpy()
