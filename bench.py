@@ -41,17 +41,21 @@ def parse():
     ap.add_argument('--pool', type=int, default=2, help='distinct resident batches cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--nchw', action='store_true', help='A/B: NCHW memory format for the dense BEV part')
-    ap.add_argument('--cpu-frames', type=int, default=8)
-    ap.add_argument('--scoring-frames', type=int, default=32,
-                    help='frames per GPU for the CRB stage-1 scoring measurement (0 = skip)')
+    ap.add_argument('--cpu-frames', type=int, default=16, help='BASELINE configs[0]: 16 frames, one CPU fwd+bwd step')
+    ap.add_argument('--scoring-pool', type=int, default=3000,
+                    help='unlabeled pool size of the CRB stage-1 scoring measurement (BASELINE configs[3]: 3,000 frames, '
+                         'rank-strided shard per GPU; 0 = skip)')
+    ap.add_argument('--scoring-repeats', type=int, default=3)
+    ap.add_argument('--pvrcnn-steps', type=int, default=6, help='PV-RCNN fwd+bwd+AdamW steps (configs[2]; 0 = skip)')
     return ap.parse_args()
 
 
-def make_batches(args, rank, device):
+def make_batches(args, rank, device, first=0):
     from pcdet.datasets.synthetic import kitti_batch
     batches = []
+    base = first
     for k in range(args.pool):
-        first = 1000 * rank + k * args.batch
+        first = base + 1000 * rank + k * args.batch
         pts, off, gt = kitti_batch(first, args.batch, args.points, waymo=(args.kind == 'waymo'))
         bidx = np.repeat(np.arange(args.batch, dtype=np.float32), np.diff(off))
         pts5 = np.concatenate([bidx[:, None], pts], axis=1)
@@ -68,22 +72,38 @@ def pmc_traffic(cin, cout):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (bench.py cannot collect counters on itself:
     they come from `bash tools/pmc_sparse_conv.sh`, summarised in profiles/r01_pmc_sparse_conv_fwd.json); None if the
     summary is for another kernel instance"""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_sparse_conv_fwd.json')
-    try:
-        d = json.load(open(path))
-    except OSError:
+    d = None
+    for name in ('r02_pmc_sparse_conv_fwd.json', 'r01_pmc_sparse_conv_fwd.json'):
+        try:
+            d = json.load(open(os.path.join(ROOT, 'profiles', name)))
+            break
+        except OSError:
+            continue
+    if d is None:
         return None
     return d['traffic_bytes_per_launch_bench_mix'] if '<%d,%d>' % (cin, cout) in d.get('kernel', '') else None
 
 
-def roofline_from_profile(prof):
+def event_pair_overhead_ms(n=200):
+    """what an event pair reads with NOTHING between the two records (HIP event timestamps are taken by the command
+    processor around the launch, so a pair around one short kernel over-reads by this much): median of n empty pairs"""
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in evs:
+        a.record()
+        b.record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in evs]))
+
+
+def roofline_from_profile(prof, overhead_ms=0.0):
     """dominant subm gather-GEMM instance by total time; algorithmic bytes per SURVEY §8d:
-    B_alg = 4 N_in C_in + 4 N_out C_out + 8 P + 4 K C_in C_out"""
+    B_alg = 4 N_in C_in + 4 N_out C_out + 8 P + 4 K C_in C_out. Launch durations = HIP event pairs on the launch stream
+    inside the timed region minus the empty-pair reading (event_pair_overhead_ms)."""
     agg = {}
     for kind, cin, cout, K, n_in, n_out, tab, e0, e1 in prof:
         if kind not in ('subm_fwd', 'subm_dgrad'):
             continue
-        ms = e0.elapsed_time(e1)
+        ms = max(e0.elapsed_time(e1) - overhead_ms, 1e-4)
         key = ('subm_gather_gemm', cin, cout)
         a = agg.setdefault(key, {'ms': 0.0, 'n': 0, 'bytes': 0.0, 'flops': 0.0, 'pairs': {}})
         tab = tab if not isinstance(tab, tuple) else tab[0]
@@ -110,7 +130,11 @@ def roofline_from_profile(prof):
     t_hbm = a['bytes'] / (HBM_PEAK_GBS * 1e9)
     t_mfma = a['flops'] / (MFMA_F32_PEAK_TF * 1e12)
     kern = 'sparse_conv_fwd2_kernel<%d,%d> (subm gather-GEMM fwd+dgrad)' % (key[1], key[2])
-    common = {'traffic': pmc_traffic(key[1], key[2]), 'avg_launch_us': round(1e3 * a['ms'] / a['n'], 2), 'launches': a['n'],
+    common = {'traffic': pmc_traffic(key[1], key[2]),
+              'traffic_source': 'separate rocprofv3 --pmc passes of the same kernel on the same tables '
+                                '(tools/pmc_sparse_conv.sh -> profiles/*pmc_sparse_conv_fwd.json), not collected by this run',
+              'event_pair_overhead_us': round(1e3 * overhead_ms, 2),
+              'avg_launch_us': round(1e3 * a['ms'] / a['n'], 2), 'launches': a['n'],
               'alg_bytes_per_launch': round(a['bytes'] / a['n']), 'alg_flops_per_launch': round(a['flops'] / a['n']),
               'hbm_GBps_alg': round(gbs, 1), 'hbm_frac': round(gbs / HBM_PEAK_GBS, 4),
               'mfma_f32_TFLOPs': round(tfs, 2), 'mfma_f32_frac': round(tfs / MFMA_F32_PEAK_TF, 4),
@@ -150,69 +174,140 @@ def cpu_baseline(args):
     second_step_cpu(m, pts, off, gt, max_voxels=ds.max_num_voxels['train'])
     dt = time.time() - t0
     return {'value': round(args.cpu_frames / dt, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d synthetic %s frames x %d pts, one SECOND fwd+bwd step (oracle C voxelizer + sparse conv '
-                      'fwd/dgrad/wgrad with OpenMP, stock torch CPU for BEV/head/loss), %.1f s' %
+            'sample': '%d synthetic %s frames x %d pts (BASELINE configs[0]), one SECOND fwd+bwd step (oracle C voxelizer + '
+                      'sparse conv fwd/dgrad/wgrad with OpenMP, functional torch CPU for BEV/head/targets/loss), %.1f s' %
                       (args.cpu_frames, args.kind, args.points, dt)}
 
 
-def crb_scoring_bench(args, rank, world, device):
-    """CRB stage-1 acquisition scoring throughput: PV-RCNN eval forward with 5 MC-dropout head passes, batched
-    post-processing records (final NMS, box point densities, label entropy) for a shard of `scoring_frames` frames per
-    rank, then the RCCL all-gather of the fixed-stride records. Inputs resident in HBM; random-init weights."""
-    from pcdet.datasets.synthetic import kitti_batch
-    from pcdet.datasets import SyntheticDataset
-    from pcdet.model_cfgs import pv_rcnn_cfg
-    from pcdet.models import build_network
-    from pcdet.models.detectors.post_processing import crb_frame_records
-    from pcdet.query_strategies import scoring
-    torch.manual_seed(0)
-    cfg = pv_rcnn_cfg()
-    model = build_network(cfg.MODEL, 3, SyntheticDataset(num_frames=2)).to(device)
-    model.eval()
-    for m in model.modules():
-        if m.__class__.__name__.startswith('Dropout'):
-            m.train()
-    bs = 16
-    nb = max(1, args.scoring_frames // bs)
-    batches = []
-    for k in range(nb):
-        pts, off, gt = kitti_batch(5000 + 1000 * rank + k * bs, bs, args.points)
-        bidx = np.repeat(np.arange(bs, dtype=np.float32), np.diff(off))
-        batches.append({'points': torch.from_numpy(np.concatenate([bidx[:, None], pts], 1)).to(device),
-                        'point_frame_offsets': torch.from_numpy(off).to(device),
-                        'gt_boxes': torch.from_numpy(gt).to(device), 'batch_size': bs,
-                        'point_frame_counts_host': np.diff(off).tolist()})
+def _pctl(xs):
+    xs = np.asarray(xs, dtype=np.float64)
+    return {'median': round(float(np.median(xs)), 3), 'p10': round(float(np.percentile(xs, 10)), 3),
+            'p90': round(float(np.percentile(xs, 90)), 3)}
 
-    def run():
-        rows = []
-        with torch.no_grad():
-            for b in batches:
-                b = dict(b)
-                model.pfe.prefetch_keypoints(b)          # as PVRCNN.forward does: FPS on a side stream
-                for mod in model.module_list:
-                    b = mod(b)
-                rows.append(scoring.pack_records(crb_frame_records(model, b)))
-        local = torch.cat(rows, 0)
-        return scoring.all_gather_rows(local, local.shape[0] * world, world)
 
-    run()                                   # warm-up (MIOpen solver search, allocator)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    rec = run()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+def _max_over_ranks(dt, world, device):
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    frames = nb * bs * world
-    return {'metric': 'frames/s CRB stage-1 acquisition scoring (PV-RCNN eval, 5 MC-dropout passes, records + all-gather)',
-            'value': round(frames / dt, 3), 'unit': 'frames/s', 'frames': frames, 'seconds': round(dt, 3),
-            'record_bytes_per_frame': 4 * scoring.REC_STRIDE, 'boxes_kept_total': int(rec[:, 1].sum().item())}
+    return dt
+
+
+def crb_scoring_bench(args, rank, world, device):
+    """CRB stage-1 acquisition scoring over the BASELINE configs[3] pool (3,000 synthetic KITTI frames): every rank scores
+    its rank-strided shard with the PV-RCNN eval forward + 5 MC-dropout head passes and the batched post-processing records
+    (final NMS, box point densities, label entropy, GT point statistics), ONE all-gather of the fixed-stride rows (RCCL at
+    N > 1), then the per-frame GT-statistics bookkeeping of the whole pool on every rank (what the caller pickles after the
+    query). This is CRBSampling.stage1() — the code path of query() — timed two ways:
+      loader    frames generated / collated by the unlabelled loader's worker processes and uploaded inside the timed pass
+      resident  the shard's batches already in HBM (the `value`; median of --scoring-repeats passes)"""
+    from pcdet.datasets import SyntheticDataset, build_synthetic_dataloader
+    from pcdet.model_cfgs import pv_rcnn_cfg
+    from pcdet.models import build_network
+    from pcdet.query_strategies import build_strategy, scoring
+    torch.manual_seed(0)
+    cfg = pv_rcnn_cfg()
+    n = args.scoring_pool
+    bs = 16
+    pool = SyntheticDataset(num_frames=n, first_frame=5000, n_points=args.points, training=False)
+    lab = SyntheticDataset(num_frames=2, n_points=args.points)
+    model = build_network(cfg.MODEL, 3, pool).to(device)
+    workers = max(2, min(32, (os.cpu_count() or 8) // max(world, 1) - 2))
+    strat = build_strategy('crb', model, build_synthetic_dataloader(lab, 2),
+                           build_synthetic_dataloader(pool, bs, workers=workers), rank, '/tmp', cfg)
+    mine, per = scoring.shard_indices(n, rank, world)
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return out, _max_over_ranks(time.perf_counter() - t0, world, device)
+
+    # warm-up on one batch (MIOpen solver search, allocator, loader workers forked)
+    strat.score_pool(mine[:bs], bs)
+    # pass 1: through the loader; the uploaded batches are kept for the resident passes
+    kept = []
+
+    def loader_pass():
+        def gen():
+            for b in strat.upload_pool_batches(mine, bs):
+                kept.append(b)
+                yield b
+        return strat.stage1(device_batches=gen())
+    rec, dt_loader = timed(loader_pass)
+    strat.close()
+    times = []
+    for _ in range(max(1, args.scoring_repeats)):
+        rec, dt = timed(lambda: strat.stage1(device_batches=kept))
+        times.append(dt)
+    med = float(np.median(times))
+    assert rec.shape[0] == n and len(strat.bbox_records) == n
+    return {'metric': 'frames/s CRB stage-1 acquisition scoring (PV-RCNN eval, 5 MC-dropout passes, records incl. GT '
+                      'statistics, all-gather, per-frame bookkeeping)',
+            'value': round(n / med, 3), 'unit': 'frames/s',
+            'config': {'workload': 'BASELINE configs[3]: pool of %d synthetic KITTI frames x %d pts, rank-strided shard of %d '
+                                   'frames per GPU, batches of %d resident in HBM' % (n, args.points, per, bs),
+                       'pool_frames': n, 'frames_per_gpu': per, 'n_gpus': world, 'repeats': len(times)},
+            'seconds': _pctl(times), 'seconds_all': [round(t, 3) for t in times],
+            'through_loader': {'value': round(n / dt_loader, 3), 'unit': 'frames/s', 'seconds': round(dt_loader, 3),
+                               'loader_workers': workers,
+                               'note': 'one pass, frames generated + collated by the loader workers and uploaded inside '
+                                       'the timed region'},
+            'record_bytes_per_frame': 4 * strat.layout.stride, 'boxes_kept_total': int(rec[:, 1].sum().item())}
+
+
+def pvrcnn_bench(args, rank, world, device):
+    """BASELINE configs[2]: PV-RCNN fwd+bwd+AdamW, bs=16 per GPU, synthetic KITTI clouds (adds FPS / ball query / grouping /
+    RoI-grid pooling HIP kernels to the SECOND path)"""
+    from pcdet.datasets import SyntheticDataset
+    from pcdet.model_cfgs import pv_rcnn_cfg
+    from pcdet.models import build_network
+    torch.manual_seed(0)
+    model = build_network(pv_rcnn_cfg().MODEL, 3, SyntheticDataset(num_frames=2, n_points=args.points)).to(device)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01, fused=True)
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=True)
+    batches = make_batches(args, rank, device, first=20000)
+    for b in batches:
+        b['point_frame_counts_host'] = np.diff(b['point_frame_offsets'].cpu().numpy()).tolist()
+
+    def step(i):
+        opt.zero_grad(set_to_none=True)
+        ret, tb, _ = net(dict(batches[i % len(batches)]))
+        loss = ret['loss'].mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+        opt.step()
+        return loss
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.pvrcnn_steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = _max_over_ranks(time.perf_counter() - t0, world, device)
+    out = {'metric': 'frames/s PV-RCNN fwd+bwd+AdamW, KITTI 20k-pt clouds', 'unit': 'frames/s',
+           'value': round(args.batch * world * args.pvrcnn_steps / dt, 3), 'ms_per_step': round(1e3 * dt / args.pvrcnn_steps, 3),
+           'steps': args.pvrcnn_steps, 'warmup': 3, 'dtype': 'f32',
+           'config': {'workload': 'BASELINE configs[2]: PV-RCNN (VoxelBackBone8x + VSA + PointHeadSimple + PVRCNNHead) on '
+                                  'synthetic kitti clouds, %d pts/frame, bs=%d per GPU' % (args.points, args.batch),
+                      'global_batch': args.batch * world},
+           'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), 'final_loss': round(float(loss.item()), 4)}
+    del opt, net, model, batches
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -254,37 +349,47 @@ def main():
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_idx], gradient_as_bucket_view=True)
     batches = make_batches(args, rank, device)
 
-    def step(i):
+    def step(i, optimizer=True):
         b = dict(batches[i % len(batches)])
         opt.zero_grad(set_to_none=True)
         ret, tb, _ = net(b)
         loss = ret['loss'].mean()
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
-        opt.step()
+        if optimizer:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+            opt.step()
         return loss
+
+    def timed_steps(optimizer, profile):
+        """-> wall seconds for EXACTLY args.steps steps (barrier + synchronize on both sides, max over ranks) and the
+        per-step device-timeline durations (events at the step boundaries on the compute stream, no host sync inside)"""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        sp.PROFILE = profile
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(args.steps):
+            loss = step(i, optimizer)
+            marks[i + 1].record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        sp.PROFILE = None
+        per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+        return _max_over_ranks(dt, world, device), per_step, loss
 
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    overhead_ms = event_pair_overhead_ms() if rank == 0 else 0.0
     prof = [] if rank == 0 else None
-    sp.PROFILE = prof
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    sp.PROFILE = None
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, per_step, loss = timed_steps(True, prof)
+    # the same step without grad-clip / AdamW (SURVEY §8d: "one optimizer-less loss.backward() step"); not profiled
+    dt_nopt, per_step_nopt, _ = timed_steps(False, None)
     frames = args.batch * world * args.steps
     out = {
         'metric': 'frames/s SECOND fwd+bwd, KITTI 20k-pt clouds' if args.kind == 'kitti' else
@@ -296,15 +401,21 @@ def main():
                                'synthetic %s clouds, %d pts/frame, bs=%d per GPU, HIP voxelize + subm/strided '
                                'gather-GEMM (BASELINE configs[1])' % (args.kind, args.points, args.batch),
                    'global_batch': args.batch * world, 'points_per_frame': args.points,
-                   'parallelism': 'dp%d' % world, 'optimizer': 'AdamW in the timed region',
+                   'parallelism': 'dp%d' % world, 'optimizer': 'grad-clip + fused AdamW in the timed region',
                    'final_loss': round(float(loss.item()), 4)},
+        'ms_per_step_device': _pctl(per_step),
+        'fwd_bwd_only': {'value': round(frames / dt_nopt, 3), 'unit': 'frames/s',
+                         'ms_per_step': round(1e3 * dt_nopt / args.steps, 3), 'ms_per_step_device': _pctl(per_step_nopt),
+                         'note': 'same %d steps without grad-clip / optimizer' % args.steps},
     }
     del opt, net, model, batches
     torch.cuda.empty_cache()
-    score = crb_scoring_bench(args, rank, world, device) if args.scoring_frames > 0 else None
+    pv = pvrcnn_bench(args, rank, world, device) if (args.pvrcnn_steps > 0 and args.kind == 'kitti') else None
+    score = crb_scoring_bench(args, rank, world, device) if (args.scoring_pool > 0 and args.kind == 'kitti') else None
     if rank == 0:
         out['crb_scoring'] = score
-        roof, table = roofline_from_profile(prof)
+        out['pvrcnn'] = pv
+        roof, table = roofline_from_profile(prof, overhead_ms)
         out['roofline'] = roof
         out['kernel_table'] = table
         if world == 1 and not args.no_cpu_baseline:

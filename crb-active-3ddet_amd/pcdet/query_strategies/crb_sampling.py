@@ -44,17 +44,15 @@ class CRBSampling(Strategy):
 
     # ---------------------------------------------------------------- stage 1
     @torch.no_grad()
-    def score_pool(self, frame_indices, batch_size):
-        """-> (len(frame_indices), layout.stride) device tensor of per-frame records; the GT point statistics the caller
-        pickles after the query travel inside the rows (query() records them for the whole gathered pool)"""
+    def score_device_batches(self, batches):
+        """stage-1 records of device-resident batches (points, point_frame_offsets int32, gt_boxes, batch_size,
+        point_frame_counts_host) -> (frames, layout.stride) device tensor"""
         model = self.detector
         model.eval()
         self.enable_dropout(model)
         rows = []
-        for batch in self.iter_pool_batches(frame_indices, batch_size):
-            batch['point_frame_counts_host'] = np.diff(batch['point_frame_offsets']).tolist()
-            load_data_to_gpu(batch)
-            batch['point_frame_offsets'] = batch['point_frame_offsets'].int()
+        for batch in batches:
+            batch = dict(batch)
             if getattr(model, 'pfe', None) is not None and hasattr(model.pfe, 'prefetch_keypoints'):
                 model.pfe.prefetch_keypoints(batch)          # FPS on a side stream, as PVRCNN.forward does
             for mod in model.module_list:
@@ -63,6 +61,35 @@ class CRBSampling(Strategy):
         if not rows:
             return torch.zeros((0, self.layout.stride), dtype=torch.float32, device=next(model.parameters()).device)
         return torch.cat(rows, 0)
+
+    def upload_pool_batches(self, frame_indices, batch_size):
+        """host batches of the given pool frames (read ahead by the loader's workers) -> device batches, one at a time"""
+        for batch in self.iter_pool_batches(frame_indices, batch_size):
+            batch['point_frame_counts_host'] = np.diff(batch['point_frame_offsets']).tolist()
+            load_data_to_gpu(batch)
+            batch['point_frame_offsets'] = batch['point_frame_offsets'].int()
+            yield batch
+
+    def score_pool(self, frame_indices, batch_size):
+        """-> (len(frame_indices), layout.stride) device tensor of per-frame records; the GT point statistics the caller
+        pickles after the query travel inside the rows (stage1() records them for the whole gathered pool)"""
+        return self.score_device_batches(self.upload_pool_batches(frame_indices, batch_size))
+
+    def stage1(self, device_batches=None):
+        """concise label sampling over the WHOLE pool: this rank scores its rank-strided shard (frames from the loader, or
+        the given device-resident batches of exactly that shard), one all-gather of the fixed-stride rows, then the GT
+        statistics of every pool frame are recorded on every rank (crb_sampling.py:72-110 + strategy.py:28-38).
+        -> records (n_pool, layout.stride) in pool order"""
+        rank, world = self._world()
+        n = len(self.pairs)
+        if device_batches is None:
+            mine, _ = scoring.shard_indices(n, rank, world)
+            local = self.score_pool(mine, self.unlabelled_loader.batch_size or 1)
+        else:
+            local = self.score_device_batches(device_batches)
+        records = scoring.all_gather_rows(local, n, world)
+        self.record_gt_stats(scoring.unpack_records(records, self.layout)['gt_stats'], [p[0] for p in self.pairs])
+        return records
 
     PRUNED_BACKWARD = True
     SKIP_UNUSED_LOSSES = True
@@ -198,13 +225,9 @@ class CRBSampling(Strategy):
         num_class = len(self.labelled_loader.dataset.class_names)
         bs = self.unlabelled_loader.batch_size or 1
         t0 = time.time()
-        # Stage 1
-        mine, per = scoring.shard_indices(n, rank, world)
-        local = self.score_pool(mine, bs)
-        records = scoring.all_gather_rows(local, n, world)
-        # GT statistics of EVERY pool frame on EVERY rank (crb_sampling.py:84 -> strategy.py:28-38): the caller runs
-        # save_active_labels(selected_frames=...) right after query() (active_training_utils.py:270-273)
-        self.record_gt_stats(scoring.unpack_records(records, self.layout)['gt_stats'], frame_ids)
+        # Stage 1 (the caller runs save_active_labels(selected_frames=...) right after query(),
+        # active_training_utils.py:270-273: stage1() has recorded the GT statistics of every pool frame by then)
+        records = self.stage1()
         torch.cuda.synchronize()
         self.timings['stage1_s'] = time.time() - t0
         entropy = records[:, 0]

@@ -64,14 +64,14 @@ def _vsa_stub():
                                  point_cloud_range=np.array([0, -40, -3, 70.4, 40, 1], np.float32)), VoxelSetAbstraction
 
 
-def _check_bilinear(device):
+def _check_bilinear(device, tol=1e-6):
     from pcdet.models.backbones_3d.pfe.voxel_set_abstraction import bilinear_interpolate_torch
     t = lambda a: torch.from_numpy(a).to(device)
     got = bilinear_interpolate_torch(t(G['bil_im']), t(G['bil_x']), t(G['bil_y'])).cpu().numpy()
-    np.testing.assert_allclose(got, G['bil_out'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(got, G['bil_out'], rtol=tol, atol=tol)
     fake, VSA = _vsa_stub()
     got = VSA.interpolate_from_bev_features(fake, t(G['bev_kp']), t(G['bev_map']), 3, 8).cpu().numpy()
-    np.testing.assert_allclose(got, G['bev_out'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(got, G['bev_out'], rtol=tol, atol=tol)
 
 
 def test_bilinear_bev_lookup_matches_reference_cpu():
@@ -80,7 +80,9 @@ def test_bilinear_bev_lookup_matches_reference_cpu():
 
 @pytest.mark.gpu
 def test_bilinear_bev_lookup_matches_reference_gpu(dev):
-    _check_bilinear(dev)
+    # the device's elementwise kernels contract a*b+c into FMAs: the four tap weights (products of differences of
+    # pixel coordinates up to ~25, ulp 2e-6) and the weighted sum differ from the CPU's by a few 1e-6 on O(1) features
+    _check_bilinear(dev, tol=2e-5)
 
 
 @pytest.mark.gpu
