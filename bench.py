@@ -212,7 +212,7 @@ def crb_scoring_bench(args, rank, world, device):
     pool = SyntheticDataset(num_frames=n, first_frame=5000, n_points=args.points, training=False)
     lab = SyntheticDataset(num_frames=2, n_points=args.points)
     model = build_network(cfg.MODEL, 3, pool).to(device)
-    workers = max(2, min(32, (os.cpu_count() or 8) // max(world, 1) - 2))
+    workers = max(2, min(48, (os.cpu_count() or 8) // max(world, 1) - 2))
     strat = build_strategy('crb', model, build_synthetic_dataloader(lab, 2),
                            build_synthetic_dataloader(pool, bs, workers=workers), rank, '/tmp', cfg)
     mine, per = scoring.shard_indices(n, rank, world)
@@ -228,8 +228,9 @@ def crb_scoring_bench(args, rank, world, device):
             dist.barrier()
         return out, _max_over_ranks(time.perf_counter() - t0, world, device)
 
-    # warm-up on one batch (MIOpen solver search, allocator, loader workers forked)
-    strat.score_pool(mine[:bs], bs)
+    # warm-up on two batches (MIOpen solver search, allocator; two batches so that the loader's worker processes are forked
+    # here, outside the timed pass)
+    strat.score_pool(mine[:2 * bs], bs)
     # pass 1: through the loader; the uploaded batches are kept for the resident passes
     kept = []
 

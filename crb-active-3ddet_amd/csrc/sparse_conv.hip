@@ -19,6 +19,9 @@
 #include "../../include/crb_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static int g_wgrad_v1 = 0;        // measurement knob: 1 forces the v1 (16x16x4, register-gather) wgrad kernel for every shape
 
 namespace {
 
@@ -488,9 +491,9 @@ struct WgradCfg {
 // offset of a SubM conv holds N pairs, a corner offset a few thousand — with a fixed number of splits per offset the centre
 // workgroups ran 3x longer than the average and the launch ended on them.
 __global__ __launch_bounds__(64) void wgrad_plan_kernel(const int* __restrict__ pstart, int K, int target,
-                                                        int* __restrict__ plan) {
+                                                        int* __restrict__ plan, int shift = 4) {
   const int o = threadIdx.x;
-  const int nb16 = o < K ? (pstart[o + 1] - pstart[o] + 15) >> 4 : 0;
+  const int nb16 = o < K ? (pstart[o + 1] - pstart[o] + (1 << shift) - 1) >> shift : 0;   // pair blocks of 2^shift pairs
   int total = nb16;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
@@ -636,6 +639,188 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// wgrad v2 (CIN % 32 == 0 and COUT % 32 == 0): the gathered rows of a 32-pair step are staged ONCE per workgroup in LDS
+// with 16-byte loads (a 64-float row = 16 lanes x dwordx4: whole 256-B rows, against v1's 64-B segments fetched again by
+// every wave that needs them), double-buffered with one barrier per step, and the Cin x Cout tile is cut into 32x32 blocks
+// on v_mfma_f32_32x32x2_f32 (pair index on the MFMA k-dim: A = X[pin]^T from LDS as [pair][ci], B = dY[pout] as [pair][co];
+// one conflict-free ds_read_b32 per operand, half the LDS reads per flop of the 16x16x4 form). Waves own blocks; when the
+// tile has fewer than 4 blocks the waves split the 16 k-steps of a step instead and add their accumulators through LDS in
+// a fixed order. Same plan / partial / reduce scheme as v1 (deterministic), in units of 32 pairs.
+template <int CIN, int COUT>
+struct Wgrad2Cfg {
+  static constexpr int PS = 32;                           // pairs per step
+  static constexpr int NBI = CIN / 32, NBO = COUT / 32, BLOCKS = NBI * NBO;
+  static constexpr int SLICES = BLOCKS >= 4 ? 1 : 4 / BLOCKS;          // k-step slices per step
+  static constexpr int WB = 4 / SLICES;                                // waves along blocks
+  static constexpr int BPW = BLOCKS / WB;                              // blocks per wave
+  // blocks of a wave: BI_PW x BO_PW sub-grid (share the A read along bo, the B read along bi)
+  static constexpr int BO_PW = BPW >= NBO ? NBO : BPW;
+  static constexpr int BI_PW = BPW / BO_PW;
+  static constexpr int WBO = NBO / BO_PW;                              // waves along bo
+  static constexpr int ROWF = CIN + COUT;                              // floats per staged pair
+  static constexpr int CHUNKS = PS * ROWF / 4;                         // float4 chunks per step
+  static constexpr int CPT = CHUNKS / 256;                             // per thread
+  static constexpr size_t LDS_BYTES = 2 * sizeof(float) * PS * ROWF;
+  static_assert(CHUNKS % 256 == 0, "staging assumes a whole number of float4 chunks per thread");
+  static_assert(BPW * WB == BLOCKS && BI_PW * BO_PW == BPW, "block split");
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void sparse_conv_wgrad2_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                                 const int* __restrict__ pin, const int* __restrict__ pout,
+                                                                 const int* __restrict__ pstart, const int* __restrict__ plan,
+                                                                 float* __restrict__ partial /* (workgroup,CIN,COUT) */,
+                                                                 int K) {
+  using C = Wgrad2Cfg<CIN, COUT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* stage = reinterpret_cast<float*>(smem);            // [2][PS][CIN + COUT]: X row then dY row of each pair
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  if (wg >= plan[1]) return;
+  const int cb = plan[0];
+  int o = 0;
+  for (int k = 1; k < K; ++k)
+    if (plan[2 + k] <= wg) o = k;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p0 = pstart[o], p1 = pstart[o + 1];
+  const int blk_lo = (wg - plan[2 + o]) * cb;
+  const int nblocks = min((p1 - p0 + C::PS - 1) / C::PS, blk_lo + cb);
+  const int wb = wave % C::WB, slice = wave / C::WB;
+  const int bi0 = (wb / C::WBO) * C::BI_PW, bo0 = (wb % C::WBO) * C::BO_PW;
+
+  f32x16 acc[C::BI_PW][C::BO_PW];
+#pragma unroll
+  for (int a = 0; a < C::BI_PW; ++a)
+#pragma unroll
+    for (int b = 0; b < C::BO_PW; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // staging assignment: chunk c = t + 256 j covers float4 `col` of pair row `pr`; X part first, then dY part
+  int c_pr[C::CPT], c_col[C::CPT];
+  bool c_isx[C::CPT];
+#pragma unroll
+  for (int j = 0; j < C::CPT; ++j) {
+    const int c = (int)threadIdx.x + 256 * j;
+    constexpr int XCH = C::PS * CIN / 4;
+    c_isx[j] = c < XCH;
+    const int cc = c_isx[j] ? c : c - XCH;
+    const int per = c_isx[j] ? CIN / 4 : COUT / 4;
+    c_pr[j] = cc / per;
+    c_col[j] = cc - c_pr[j] * per;
+  }
+  struct Idx { int row[C::CPT]; };
+  struct Feat { f32x4 v[C::CPT]; };
+  auto load_idx = [&](Idx& x, int b) {
+#pragma unroll
+    for (int j = 0; j < C::CPT; ++j) {
+      int p = p0 + b * C::PS + c_pr[j];
+      p = p < p1 ? p : p1 - 1;                                  // clamped: value zeroed at the LDS write
+      x.row[j] = c_isx[j] ? pin[p] : pout[p];
+    }
+  };
+  auto load_feat = [&](Feat& f, const Idx& x) {
+#pragma unroll
+    for (int j = 0; j < C::CPT; ++j) {
+      const float* src = c_isx[j] ? X + (int64_t)x.row[j] * CIN : dY + (int64_t)x.row[j] * COUT;
+      f.v[j] = *reinterpret_cast<const f32x4*>(src + c_col[j] * 4);
+    }
+  };
+  auto store_feat = [&](const Feat& f, int b, float* buf) {
+#pragma unroll
+    for (int j = 0; j < C::CPT; ++j) {
+      const bool ok = (b < nblocks) && (p0 + b * C::PS + c_pr[j] < p1);
+      f32x4 v = f.v[j];
+      if (!ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(buf + c_pr[j] * C::ROWF + (c_isx[j] ? 0 : CIN) + c_col[j] * 4) = v;
+    }
+  };
+  const int l31 = lane & 31, kh = lane >> 5;
+  auto compute = [&](const float* buf) {
+    constexpr int KSTEPS = C::PS / 2, KPS = KSTEPS / C::SLICES;
+#pragma unroll
+    for (int q = 0; q < KPS; ++q) {
+      const int kk = slice * KPS + q;
+      const float* row = buf + (2 * kk + kh) * C::ROWF;
+      float av[C::BI_PW], bv[C::BO_PW];
+#pragma unroll
+      for (int a = 0; a < C::BI_PW; ++a) av[a] = row[(bi0 + a) * 32 + l31];
+#pragma unroll
+      for (int b = 0; b < C::BO_PW; ++b) bv[b] = row[CIN + (bo0 + b) * 32 + l31];
+#pragma unroll
+      for (int a = 0; a < C::BI_PW; ++a)
+#pragma unroll
+        for (int b = 0; b < C::BO_PW; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  // pipeline: indices two steps ahead, gathered rows one step ahead (registers), LDS double-buffered, one barrier per step
+  Idx ix;
+  Feat ft;
+  int blk = blk_lo;
+  load_idx(ix, blk);
+  load_feat(ft, ix);
+  load_idx(ix, blk + 1);
+  int cur = 0;
+  while (blk < nblocks) {
+    float* buf = stage + cur * (C::PS * C::ROWF);
+    store_feat(ft, blk, buf);
+    __syncthreads();
+    if (blk + 1 < nblocks) {
+      load_feat(ft, ix);
+      load_idx(ix, blk + 2);
+    }
+    compute(buf);
+    cur ^= 1;
+    ++blk;
+  }
+
+  // slices > 1: add the slices' accumulators through LDS in a fixed order (reuses the staging buffers)
+  float* dst = partial + (int64_t)wg * CIN * COUT;
+  if constexpr (C::SLICES > 1) {
+    __syncthreads();
+    float* red = stage;                                      // (SLICES-1) x BLOCKS x 32 x 32 floats <= staging size
+    static_assert((C::SLICES - 1) * C::BLOCKS * 1024 * sizeof(float) <= C::LDS_BYTES, "reduction scratch fits the stage");
+    if (slice > 0) {
+#pragma unroll
+      for (int a = 0; a < C::BI_PW; ++a)
+#pragma unroll
+        for (int b = 0; b < C::BO_PW; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            red[(((slice - 1) * C::BLOCKS + (bi0 + a) * C::NBO + bo0 + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (slice == 0) {
+#pragma unroll
+      for (int a = 0; a < C::BI_PW; ++a)
+#pragma unroll
+        for (int b = 0; b < C::BO_PW; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[a][b][r];
+#pragma unroll
+            for (int sl = 1; sl < C::SLICES; ++sl)
+              v += red[(((sl - 1) * C::BLOCKS + (bi0 + a) * C::NBO + bo0 + b) * 16 + r) * 64 + lane];
+            acc[a][b][r] = v;
+          }
+    }
+  }
+  if (slice == 0) {
+    // C/D map of the 32x32 forms: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int a = 0; a < C::BI_PW; ++a)
+#pragma unroll
+      for (int b = 0; b < C::BO_PW; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ci = (bi0 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          dst[ci * COUT + (bo0 + b) * 32 + l31] = acc[a][b][r];
+        }
+  }
+}
+
 // dW[o] = sum of the partials of offset o's workgroups. A 256-thread workgroup owns 32 consecutive elements of one offset;
 // 8 thread groups stride over the partials, then a fixed-shape LDS tree adds the 8 sums (same association every run).
 // The centre offset of a SubM conv has hundreds of partials: a serial per-element loop took longer than the wgrad itself
@@ -722,6 +907,19 @@ int launch_fwd(const float* X, const float* W, const int* nbr, const int* perm, 
 template <int CIN, int COUT>
 int launch_wgrad(const float* X, const float* dY, const int* pin, const int* pout, const int* pstart, float* dW,
                  float* partial, int* plan, int K, int S, hipStream_t st) {
+  if constexpr (CIN % 32 == 0 && COUT % 32 == 0) {
+    if (!g_wgrad_v1) {
+      using C2 = Wgrad2Cfg<CIN, COUT>;
+      const int maxwg = K * S;
+      hipLaunchKernelGGL(wgrad_plan_kernel, dim3(1), dim3(64), 0, st, pstart, K, maxwg - K, plan, 5);
+      hipLaunchKernelGGL((sparse_conv_wgrad2_kernel<CIN, COUT>), dim3(((maxwg + 7) / 8) * 8), dim3(256), C2::LDS_BYTES, st,
+                         X, dY, pin, pout, pstart, plan, partial, K);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(K * ((CIN * COUT + 31) / 32)), dim3(256), 0, st, partial, plan, dW, K,
+                         CIN * COUT);
+      CRB_CHECK_LAUNCH();
+      return CRB_OK;
+    }
+  }
   using C = WgradCfg<CIN, COUT>;
   size_t lds = C::SLICES > 1 ? sizeof(float) * (C::SLICES - 1) * C::NCI * 16 * C::NB * 16 : 0;
   const int maxwg = K * S;                                   // partial slots; the plan aims at maxwg - K workgroups
@@ -792,11 +990,20 @@ extern "C" int crb_sparse_conv_forward(const float* X, const float* W, const int
   return CRB_ERR_UNSUPPORTED;
 }
 
+extern "C" int crb_sparse_conv_set_wgrad_v1(int on) { g_wgrad_v1 = on ? 1 : 0; return CRB_OK; }
+
 static int g_wgrad_splits = 96;   // workgroups per kernel offset the plan aims at (multiple of 8: XCD mapping)
 extern "C" int crb_sparse_conv_wgrad_splits(void) { return g_wgrad_splits; }
 // 16x16 tiles: the partial reduction costs as much as the MFMA work, fewer and larger workgroups win (sweep on the SECOND
 // bs=16 geometry: 32 / 96 / 256 workgroups per offset = 39 / 52 / 95 us at C=16, 292 / 264 / 259 us at C=64)
-static inline int wgrad_splits_for(int cin, int cout) { return (cin * cout <= 256 && g_wgrad_splits == 96) ? 32 : g_wgrad_splits; }
+// v2 shapes (both multiples of 32): ~1000 workgroups = two rounds of 2 per CU; every extra workgroup is one more Cin x Cout
+// partial to write and reduce (at 96 per offset the partials of a 64x64 layer were 42 MB, as much as the gathered rows)
+static inline int wgrad_splits_for(int cin, int cout) {
+  if (g_wgrad_splits != 96) return g_wgrad_splits;
+  if (cin * cout <= 256) return 32;
+  if (cin % 32 == 0 && cout % 32 == 0 && !g_wgrad_v1) return 40;
+  return 96;
+}
 extern "C" int crb_sparse_conv_set_wgrad_splits(int s) {      // A/B measurements; 0 restores the default
   g_wgrad_splits = (s >= 8 && s <= 1024 && s % 8 == 0) ? s : 96;
   return CRB_OK;

@@ -119,7 +119,8 @@ int crb_sparse_conv_set_subtiles(int subt);
 int crb_sparse_conv_timing(uint64_t* out16_host);
 /* dW (K,cin,cout) = sum over pairs X[pin]^T dY[pout] */
 int crb_sparse_conv_wgrad_splits(void);
-int crb_sparse_conv_set_wgrad_splits(int splits);   /* measurement knob: workgroups per offset (multiple of 8), 0 = default */
+int crb_sparse_conv_set_wgrad_splits(int splits);    /* measurement knob: workgroups per offset (multiple of 8), 0 = default */
+int crb_sparse_conv_set_wgrad_v1(int on);            /* measurement knob: 1 = the v1 (16x16x4, register-gather) wgrad kernel for every shape */
 int64_t crb_sparse_conv_wgrad_workspace_bytes(int K, int cin, int cout);
 int crb_sparse_conv_wgrad(const float* X, const float* dY, const int32_t* pair_in, const int32_t* pair_out,
                           const int32_t* pair_start, float* dW, int K, int cin, int cout,

@@ -447,8 +447,29 @@ def test_sparse_basic_block_with_bias_matches_oracle(dev):
     _close(x.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-3)
     _close(_kio_grad(blk.conv1), w1.grad.numpy(), rtol=1e-3)
     _close(_kio_grad(blk.conv2), w2.grad.numpy(), rtol=1e-3)
-    for k in ('conv1.bias', 'conv2.bias', 'bn1.weight', 'bn2.bias'):
-        _close(dict(blk.named_parameters())[k].grad.cpu().numpy(), P[k].grad.numpy(), rtol=1e-3)
+    named = dict(blk.named_parameters())
+    for k in ('bn1.weight', 'bn1.bias', 'bn2.weight', 'bn2.bias'):
+        _close(named[k].grad.cpu().numpy(), P[k].grad.numpy(), rtol=1e-3)
+    # a bias in front of a train-mode BatchNorm has a mathematically zero gradient (the batch mean is subtracted again):
+    # both chains must produce rounding noise only, far below the BN parameter gradients
+    scale = float(P['bn2.bias'].grad.abs().max())
+    for k in ('conv1.bias', 'conv2.bias'):
+        assert float(P[k].grad.abs().max()) < 1e-6 * scale
+        assert float(named[k].grad.abs().max()) < 1e-4 * scale, (k, float(named[k].grad.abs().max()), scale)
+    # ... so the bias is pinned through the forward instead: eval-mode BN (running statistics) keeps it visible
+    blk.eval()
+    with torch.no_grad():
+        out_e = blk(spconv.SparseConvTensor(_t(X, dev), _t(coords, dev), shape, 2)).features.cpu().numpy()
+        st = {k: v.detach().cpu().double() for k, v in blk.state_dict().items()}
+        bne = lambda t, k: torch.nn.functional.batch_norm(t, st[k + '.running_mean'], st[k + '.running_var'], st[k + '.weight'],
+                                                          st[k + '.bias'], False, 0.0, 1e-3)
+        xe = torch.from_numpy(X).double()
+        he = torch.relu(bne(OConv.apply(xe, w1.detach()) + st['conv1.bias'], 'bn1'))
+        he = bne(OConv.apply(he, w2.detach()) + st['conv2.bias'], 'bn2')
+        ref_e = torch.relu(he + xe).numpy()
+    _close(out_e, ref_e, rtol=2e-4)
+    no_bias = torch.relu(bne(OConv.apply(torch.relu(bne(OConv.apply(xe, w1.detach()), 'bn1')), w2.detach()), 'bn2') + xe).numpy()
+    assert np.abs(no_bias - ref_e).max() > 1e-2              # the check would notice a dropped bias
 
 
 def _kio_grad(conv):

@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--chunk', type=int, default=None)
     ap.add_argument('--dense-random', action='store_true', help='all 27 neighbours present, rows drawn at random inside +-4096 rows (real-table-like locality)')
     ap.add_argument('--dense-k', type=int, default=27, help='with --dense: only the first k offsets are present in every row')
+    ap.add_argument('--wgrad-sweep', action='store_true', help='sweep the workgroups-per-offset knob of the wgrad')
     ap.add_argument('--dense', action='store_true', help='synthetic table with all 27 neighbours present (no skip imbalance)')
     args = ap.parse_args()
     from crbhip import sparse, voxel
@@ -93,12 +94,25 @@ def main():
         lib.crb_sparse_conv_set_subtiles(0)
         t_f = timeit(lambda: sparse._conv_forward_raw(x, w, table, n))
         t_w = timeit(lambda: sparse._conv_wgrad_raw(x, dy, pairs, 27))
+        lib.crb_sparse_conv_set_wgrad_v1(1)
+        t_w1 = timeit(lambda: sparse._conv_wgrad_raw(x, dy, pairs, 27))
+        dw1 = sparse._conv_wgrad_raw(x, dy, pairs, 27)
+        lib.crb_sparse_conv_set_wgrad_v1(0)
+        dw2 = sparse._conv_wgrad_raw(x, dy, pairs, 27)
+        werr = float((dw2 - dw1).abs().max() / dw1.abs().max())
+        sweep = ''
+        if args.wgrad_sweep:
+            for sp_ in (16, 24, 40, 64, 96, 160):
+                lib.crb_sparse_conv_set_wgrad_splits(sp_)
+                sweep += ' S%d=%.1f' % (sp_, timeit(lambda: sparse._conv_wgrad_raw(x, dy, pairs, 27)))
+            lib.crb_sparse_conv_set_wgrad_splits(0)
         balg = 4.0 * n * cin + 4.0 * n * cout + 8.0 * P + 4.0 * 27 * cin * cout
         fl = 2.0 * P * cin * cout
         print('L%d subm %dx%d N=%d P=%d (%.2f/row) | fwd %.1f us  %.0f GB/s alg (%.1f%% of 8TB/s)  %.1f TF | '
-              'wgrad %.1f us %.1f TF' % (
+              'wgrad %.1f us %.1f TF (%.1f%% of 157.3) [v1 kernel %.1f us, max rel diff %.1e]%s' % (
                   lvl, cin, cout, n, P, P / n, t_f, balg / t_f / 1e3, balg / t_f / 1e3 / 80, fl / t_f / 1e6, t_w,
-                  fl / t_w / 1e6), 'v1/v2-noremap/v2 %.1f %.1f %.1f us' % (ts[1], ts[16], ts[8]), flush=True)
+                  fl / t_w / 1e6, fl / t_w / 1e6 / 1.573, t_w1, werr, sweep),
+              'v1/v2-noremap/v2 %.1f %.1f %.1f us' % (ts[1], ts[16], ts[8]), flush=True)
 
 
 if __name__ == '__main__':
