@@ -21,7 +21,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static int g_wgrad_v1 = 0;        // measurement knob: 1 forces the v1 (16x16x4, register-gather) wgrad kernel for every shape
+static unsigned long long* g_wgrad_dbg = nullptr;   // measurement runs: device buffer of 4 u64 per workgroup (see wgrad2)
+static int g_wgrad_mode = 0;      // measurement builds of the 64x64 v3 wgrad: 1 = no MFMAs, 2 = no gather pipeline (wrong results)
+static int g_wgrad_v1 = 0;        // measurement knob: 0 = default (v3 / v2 by shape), 1 = v1 (16x16x4, register gather) everywhere, 2 = v2 where it exists
 
 namespace {
 
@@ -649,8 +651,9 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad_kernel(const float* __r
 // a fixed order. Same plan / partial / reduce scheme as v1 (deterministic), in units of 32 pairs.
 template <int CIN, int COUT>
 struct Wgrad2Cfg {
-  static constexpr int PS = 32;                           // pairs per step
   static constexpr int NBI = CIN / 32, NBO = COUT / 32, BLOCKS = NBI * NBO;
+  // pairs per step: >= 8 MFMAs per wave between two barriers (a 32x32 tile gives each wave only a quarter of the k-steps)
+  static constexpr int PS = BLOCKS == 1 ? 64 : 32;
   static constexpr int SLICES = BLOCKS >= 4 ? 1 : 4 / BLOCKS;          // k-step slices per step
   static constexpr int WB = 4 / SLICES;                                // waves along blocks
   static constexpr int BPW = BLOCKS / WB;                              // blocks per wave
@@ -671,8 +674,9 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad2_kernel(const float* __
                                                                  const int* __restrict__ pin, const int* __restrict__ pout,
                                                                  const int* __restrict__ pstart, const int* __restrict__ plan,
                                                                  float* __restrict__ partial /* (workgroup,CIN,COUT) */,
-                                                                 int K) {
+                                                                 int K, unsigned long long* __restrict__ dbg = nullptr) {
   using C = Wgrad2Cfg<CIN, COUT>;
+  const unsigned long long t_start = dbg ? wall_clock64() : 0ULL;   // 100 MHz, common to all XCDs (s_memtime is per XCD)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* stage = reinterpret_cast<float*>(smem);            // [2][PS][CIN + COUT]: X row then dY row of each pair
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -738,20 +742,24 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad2_kernel(const float* __
   const int l31 = lane & 31, kh = lane >> 5;
   auto compute = [&](const float* buf) {
     constexpr int KSTEPS = C::PS / 2, KPS = KSTEPS / C::SLICES;
+    float av[2][C::BI_PW], bv[2][C::BO_PW];
+    auto fetch = [&](int q, int s) {               // operands one k-step ahead of the MFMAs (see wgrad v3)
+      const float* row = buf + (2 * (slice * KPS + q) + kh) * C::ROWF;
+#pragma unroll
+      for (int a = 0; a < C::BI_PW; ++a) av[s][a] = row[(bi0 + a) * 32 + l31];
+#pragma unroll
+      for (int b = 0; b < C::BO_PW; ++b) bv[s][b] = row[CIN + (bo0 + b) * 32 + l31];
+    };
+    fetch(0, 0);
 #pragma unroll
     for (int q = 0; q < KPS; ++q) {
-      const int kk = slice * KPS + q;
-      const float* row = buf + (2 * kk + kh) * C::ROWF;
-      float av[C::BI_PW], bv[C::BO_PW];
-#pragma unroll
-      for (int a = 0; a < C::BI_PW; ++a) av[a] = row[(bi0 + a) * 32 + l31];
-#pragma unroll
-      for (int b = 0; b < C::BO_PW; ++b) bv[b] = row[CIN + (bo0 + b) * 32 + l31];
+      if (q + 1 < KPS) fetch(q + 1, (q + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int a = 0; a < C::BI_PW; ++a)
 #pragma unroll
         for (int b = 0; b < C::BO_PW; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 1][a], bv[q & 1][b], acc[a][b], 0, 0, 0);
     }
   };
 
@@ -807,6 +815,13 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad2_kernel(const float* __
           }
     }
   }
+  if (dbg && threadIdx.x == 0) {          // measurement runs: lifetime and placement of this workgroup
+    unsigned long long* d = dbg + (size_t)wg * 4;
+    d[0] = t_start;
+    d[1] = wall_clock64();
+    d[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+    d[3] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) | ((unsigned long long)(nblocks - blk_lo) << 32);
+  }
   if (slice == 0) {
     // C/D map of the 32x32 forms: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
@@ -817,6 +832,229 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad2_kernel(const float* __
         for (int r = 0; r < 16; ++r) {
           const int ci = (bi0 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
           dst[ci * COUT + (bo0 + b) * 32 + l31] = acc[a][b][r];
+        }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad v3 (tiles of 1, 2 or 4 blocks of 32x32): the four waves of a workgroup are INDEPENDENT workers. In v2 the waves of
+// a workgroup share each staged step and meet at a barrier per step; with 4 workgroups per CU every SIMD hosts one wave of
+// each and a workgroup only advances when all four of its waves have had their 1024-cycle MFMA turn on their SIMDs: the
+// per-workgroup timeline showed the matrix pipe 62 % busy with 4 resident workgroups per CU against 73 % with 3 (convoys at
+// the barriers). Here a wave owns the whole Cin x Cout tile (1/2/4 accumulator blocks), stages ITS OWN pairs in a private
+// LDS double buffer (wave-level ordering only, no s_barrier in the loop), reads every staged value for 2 MFMAs instead of
+// 1, and the four accumulator sets are added through LDS in a fixed order once at the end (one partial per workgroup).
+template <int CIN, int COUT>
+struct Wgrad3Cfg {
+  static constexpr int NBI = CIN / 32, NBO = COUT / 32, BLOCKS = NBI * NBO;
+  static constexpr int ROWF = CIN + COUT;
+  static constexpr int PSW = ROWF <= 64 ? 32 : 16;                      // pairs per wave-step (32 staging VGPRs at most)
+  static constexpr int CHUNKS = PSW * ROWF / 4, CPT = CHUNKS / 64;      // float4 chunks per wave-step / per lane
+  static constexpr int WAVE_FLOATS = 2 * PSW * ROWF;                    // private double buffer
+  static constexpr size_t LDS_BYTES = sizeof(float) * 4 * WAVE_FLOATS;
+  static_assert(CHUNKS % 64 == 0, "whole chunks per lane");
+  static_assert(3 * CIN * COUT <= 4 * WAVE_FLOATS, "end-of-kernel reduction scratch fits the staging buffers");
+};
+
+template <int CIN, int COUT, int MODE = 0>     // MODE (measurement builds): 1 = no MFMAs, 2 = no gather pipeline (MFMAs + LDS reads only)
+__global__ __launch_bounds__(256) void sparse_conv_wgrad3_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                                 const int* __restrict__ pin, const int* __restrict__ pout,
+                                                                 const int* __restrict__ pstart, const int* __restrict__ plan,
+                                                                 float* __restrict__ partial /* (workgroup,CIN,COUT) */,
+                                                                 int K, unsigned long long* __restrict__ dbg = nullptr) {
+  using C = Wgrad3Cfg<CIN, COUT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* stage_all = reinterpret_cast<float*>(smem);
+  const unsigned long long t_start = dbg ? wall_clock64() : 0ULL;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  if (wg >= plan[1]) return;
+  const int cb = plan[0];                                   // workgroup blocks (4 * PSW pairs) per workgroup
+  int o = 0;
+  for (int k = 1; k < K; ++k)
+    if (plan[2 + k] <= wg) o = k;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p0 = pstart[o], p1 = pstart[o + 1];
+  const int blk_lo = (wg - plan[2 + o]) * cb;
+  const int nblocks = min((p1 - p0 + 4 * C::PSW - 1) / (4 * C::PSW), blk_lo + cb);
+  float* stage = stage_all + wave * C::WAVE_FLOATS;
+
+  f32x16 acc[C::NBI][C::NBO];
+#pragma unroll
+  for (int a = 0; a < C::NBI; ++a)
+#pragma unroll
+    for (int b = 0; b < C::NBO; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // lane's float4 chunks of a wave-step: chunk c = lane + 64 j -> pair row c / (ROWF/4), X part first then dY part
+  constexpr int RCH = C::ROWF / 4;
+  auto chunk = [&](int j, int& pr, int& col, bool& isx) {
+    const int c = lane + 64 * j;
+    pr = c / RCH;
+    const int w = c - pr * RCH;
+    isx = w < CIN / 4;
+    col = isx ? w : w - CIN / 4;
+  };
+  struct Idx { int row[C::CPT]; };
+  struct Feat { f32x4 v[C::CPT]; };
+  // wave-step b of this workgroup block-range: pairs p0 + (b * 4 + wave) * PSW ... (the four waves interleave, so they walk
+  // neighbouring rows at the same time)
+  auto pair_base = [&](int b) { return p0 + (b * 4 + wave) * C::PSW; };
+  auto load_idx = [&](Idx& x, int b) {
+#pragma unroll
+    for (int j = 0; j < C::CPT; ++j) {
+      int pr, col; bool isx;
+      chunk(j, pr, col, isx);
+      int p = pair_base(b) + pr;
+      p = p < p1 ? p : p1 - 1;
+      x.row[j] = isx ? pin[p] : pout[p];
+    }
+  };
+  auto load_feat = [&](Feat& f, const Idx& x) {
+#pragma unroll
+    for (int j = 0; j < C::CPT; ++j) {
+      int pr, col; bool isx;
+      chunk(j, pr, col, isx);
+      const float* src = isx ? X + (int64_t)x.row[j] * CIN : dY + (int64_t)x.row[j] * COUT;
+      f.v[j] = *reinterpret_cast<const f32x4*>(src + col * 4);
+    }
+  };
+  auto store_feat = [&](const Feat& f, int b, float* buf) {
+#pragma unroll
+    for (int j = 0; j < C::CPT; ++j) {
+      int pr, col; bool isx;
+      chunk(j, pr, col, isx);
+      const bool ok = (b < nblocks) && (pair_base(b) + pr < p1);
+      f32x4 v = f.v[j];
+      if (!ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(buf + pr * C::ROWF + (isx ? 0 : CIN) + col * 4) = v;
+    }
+  };
+  const int l31 = lane & 31, kh = lane >> 5;
+  // One step = KS k-steps of NBI x NBO MFMAs (64 cycles each) on buffer `cur`, with everything else of the pipeline
+  // INTERLEAVED between the MFMA groups so that it issues in their shadow (a lone wave that did its loads, address
+  // arithmetic and LDS writes between two MFMA bursts kept the pipe 49 % busy): after the MFMAs of k-step kk the lane
+  //   writes chunk j of step s+1 (in registers since step s-1) to the other buffer,
+  //   re-uses the register for the gather of chunk j of step s+2 (row index loaded during step s-1),
+  //   loads the row index of chunk j of step s+3.
+  // Operands of k-step kk+1 are read from LDS before the MFMAs of kk (the scheduler otherwise sinks the reads).
+  constexpr int KS = C::PSW / 2;
+  constexpr int STEPF = C::PSW * C::ROWF;
+  auto load_idx1 = [&](Idx& x, int b, int j) {
+    int pr, col; bool isx;
+    chunk(j, pr, col, isx);
+    int p = pair_base(b) + pr;
+    p = p < p1 ? p : p1 - 1;
+    x.row[j] = isx ? pin[p] : pout[p];
+  };
+  auto load_feat1 = [&](Feat& f, const Idx& x, int j) {
+    int pr, col; bool isx;
+    chunk(j, pr, col, isx);
+    const float* src = isx ? X + (int64_t)x.row[j] * CIN : dY + (int64_t)x.row[j] * COUT;
+    f.v[j] = *reinterpret_cast<const f32x4*>(src + col * 4);
+  };
+  auto store_feat1 = [&](const Feat& f, int b, float* buf, int j) {
+    int pr, col; bool isx;
+    chunk(j, pr, col, isx);
+    const bool ok = (b < nblocks) && (pair_base(b) + pr < p1);
+    f32x4 v = f.v[j];
+    if (!ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(buf + pr * C::ROWF + (isx ? 0 : CIN) + col * 4) = v;
+  };
+  auto step = [&](int b, const float* buf, float* other, Feat& f, Idx& x) {
+    float av[2][C::NBI], bv[2][C::NBO];
+    auto fetch = [&](int kk, int s) {
+      const float* row = buf + (2 * kk + kh) * C::ROWF;
+#pragma unroll
+      for (int a = 0; a < C::NBI; ++a) av[s][a] = row[a * 32 + l31];
+#pragma unroll
+      for (int bb = 0; bb < C::NBO; ++bb) bv[s][bb] = row[CIN + bb * 32 + l31];
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      if (kk + 1 < KS) fetch(kk + 1, (kk + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < C::NBI; ++a)
+#pragma unroll
+        for (int bb = 0; bb < C::NBO; ++bb)
+          if constexpr (MODE == 1) acc[a][bb][0] += av[kk & 1][a] * bv[kk & 1][bb];
+          else acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][a], bv[kk & 1][bb], acc[a][bb], 0, 0, 0);
+      // chunks kk*CPT/KS .. (kk+1)*CPT/KS of the pipeline, in the shadow of the MFMAs just issued
+      if constexpr (MODE != 2) {
+#pragma unroll
+        for (int jj = (kk * C::CPT) / KS; jj < ((kk + 1) * C::CPT) / KS; ++jj) {
+          store_feat1(f, b + 1, other, jj);
+          load_feat1(f, x, jj);
+          load_idx1(x, b + 3, jj);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // the LDS double buffer is private to the wave: its own ds_write / ds_read are executed in order, what is needed is that the
+  // compiler keeps them in program order (the lanes exchange data) -> a wave-scope fence, no s_barrier
+  auto wave_fence = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  Idx ix;
+  Feat ft;
+  int blk = blk_lo;
+  if (blk < nblocks) {                       // prologue: step blk -> LDS, step blk+1 -> registers, indices of step blk+2
+    load_idx(ix, blk);
+    load_feat(ft, ix);
+    store_feat(ft, blk, stage);
+    load_idx(ix, blk + 1);
+    load_feat(ft, ix);
+    load_idx(ix, blk + 2);
+    wave_fence();
+  }
+  int cur = 0;
+  const unsigned long long t_loop = dbg ? __builtin_amdgcn_s_memtime() : 0ULL;
+  while (blk < nblocks) {
+    step(blk, stage + cur * STEPF, stage + (cur ^ 1) * STEPF, ft, ix);
+    wave_fence();
+    cur ^= 1;
+    ++blk;
+  }
+  const unsigned long long loop_cycles = dbg ? __builtin_amdgcn_s_memtime() - t_loop : 0ULL;   // shader cycles of wave 0's loop
+
+  // add the four waves' accumulators through LDS in a fixed order (scratch aliases the staging buffers: barrier first)
+  __syncthreads();
+  float* red = stage_all;                                    // 3 x (BLOCKS x 16 x 64) floats
+  if (wave > 0) {
+#pragma unroll
+    for (int a = 0; a < C::NBI; ++a)
+#pragma unroll
+      for (int b = 0; b < C::NBO; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(((wave - 1) * C::BLOCKS + a * C::NBO + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+  }
+  __syncthreads();
+  if (dbg && threadIdx.x == 0) {
+    unsigned long long* d = dbg + (size_t)wg * 4;
+    d[0] = t_start;
+    d[1] = wall_clock64();
+    d[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) | (loop_cycles << 32);
+    d[3] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) | ((unsigned long long)(nblocks - blk_lo) << 32);
+  }
+  if (wave == 0) {
+    float* dst = partial + (int64_t)wg * CIN * COUT;
+#pragma unroll
+    for (int a = 0; a < C::NBI; ++a)
+#pragma unroll
+      for (int b = 0; b < C::NBO; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[a][b][r];
+#pragma unroll
+          for (int w = 1; w < 4; ++w) v += red[(((w - 1) * C::BLOCKS + a * C::NBO + b) * 16 + r) * 64 + lane];
+          const int ci = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          dst[ci * COUT + b * 32 + l31] = v;
         }
   }
 }
@@ -907,13 +1145,36 @@ int launch_fwd(const float* X, const float* W, const int* nbr, const int* perm, 
 template <int CIN, int COUT>
 int launch_wgrad(const float* X, const float* dY, const int* pin, const int* pout, const int* pstart, float* dW,
                  float* partial, int* plan, int K, int S, hipStream_t st) {
+  if constexpr (CIN % 32 == 0 && COUT % 32 == 0 && (CIN / 32) * (COUT / 32) <= 4) {
+    if (g_wgrad_v1 == 0) {
+      using C3 = Wgrad3Cfg<CIN, COUT>;
+      const int maxwg = K * S;
+      constexpr int shift = C3::PSW == 32 ? 7 : 6;           // workgroup block = 4 waves x PSW pairs
+      hipLaunchKernelGGL(wgrad_plan_kernel, dim3(1), dim3(64), 0, st, pstart, K, maxwg - K, plan, shift);
+      if constexpr (CIN == 64 && COUT == 64) {
+        if (g_wgrad_mode == 1)
+          hipLaunchKernelGGL((sparse_conv_wgrad3_kernel<CIN, COUT, 1>), dim3(((maxwg + 7) / 8) * 8), dim3(256), C3::LDS_BYTES,
+                             st, X, dY, pin, pout, pstart, plan, partial, K, g_wgrad_dbg);
+        if (g_wgrad_mode == 2)
+          hipLaunchKernelGGL((sparse_conv_wgrad3_kernel<CIN, COUT, 2>), dim3(((maxwg + 7) / 8) * 8), dim3(256), C3::LDS_BYTES,
+                             st, X, dY, pin, pout, pstart, plan, partial, K, g_wgrad_dbg);
+      }
+      if (g_wgrad_mode == 0 || !(CIN == 64 && COUT == 64))
+        hipLaunchKernelGGL((sparse_conv_wgrad3_kernel<CIN, COUT>), dim3(((maxwg + 7) / 8) * 8), dim3(256), C3::LDS_BYTES, st,
+                           X, dY, pin, pout, pstart, plan, partial, K, g_wgrad_dbg);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(K * ((CIN * COUT + 31) / 32)), dim3(256), 0, st, partial, plan, dW, K,
+                         CIN * COUT);
+      CRB_CHECK_LAUNCH();
+      return CRB_OK;
+    }
+  }
   if constexpr (CIN % 32 == 0 && COUT % 32 == 0) {
-    if (!g_wgrad_v1) {
+    if (g_wgrad_v1 != 1) {
       using C2 = Wgrad2Cfg<CIN, COUT>;
       const int maxwg = K * S;
-      hipLaunchKernelGGL(wgrad_plan_kernel, dim3(1), dim3(64), 0, st, pstart, K, maxwg - K, plan, 5);
+      hipLaunchKernelGGL(wgrad_plan_kernel, dim3(1), dim3(64), 0, st, pstart, K, maxwg - K, plan, C2::PS == 64 ? 6 : 5);
       hipLaunchKernelGGL((sparse_conv_wgrad2_kernel<CIN, COUT>), dim3(((maxwg + 7) / 8) * 8), dim3(256), C2::LDS_BYTES, st,
-                         X, dY, pin, pout, pstart, plan, partial, K);
+                         X, dY, pin, pout, pstart, plan, partial, K, g_wgrad_dbg);
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(K * ((CIN * COUT + 31) / 32)), dim3(256), 0, st, partial, plan, dW, K,
                          CIN * COUT);
       CRB_CHECK_LAUNCH();
@@ -990,18 +1251,82 @@ extern "C" int crb_sparse_conv_forward(const float* X, const float* W, const int
   return CRB_ERR_UNSUPPORTED;
 }
 
-extern "C" int crb_sparse_conv_set_wgrad_v1(int on) { g_wgrad_v1 = on ? 1 : 0; return CRB_OK; }
+extern "C" int crb_sparse_conv_set_wgrad_v1(int on) { g_wgrad_v1 = (on == 1 || on == 2) ? on : 0; return CRB_OK; }
+extern "C" int crb_sparse_conv_set_wgrad_mode(int mode) { g_wgrad_mode = (mode == 1 || mode == 2) ? mode : 0; return CRB_OK; }
+extern "C" int crb_sparse_conv_set_wgrad_debug(void* dev_buf_u64x4_per_wg) {
+  g_wgrad_dbg = (unsigned long long*)dev_buf_u64x4_per_wg;
+  return CRB_OK;
+}
+
+// measurement helper: resident workgroups per CU of the wgrad kernel instance the dispatcher would pick (-1: no instance)
+template <int A, int B>
+static int wgrad_occ_of() {
+  int n = -1;
+  if constexpr (A % 32 == 0 && B % 32 == 0 && (A / 32) * (B / 32) <= 4) {
+    if (g_wgrad_v1 == 0) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sparse_conv_wgrad3_kernel<A, B>, 256,
+                                                       Wgrad3Cfg<A, B>::LDS_BYTES) != hipSuccess) n = -1;
+      return n;
+    }
+  }
+  if constexpr (A % 32 == 0 && B % 32 == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sparse_conv_wgrad2_kernel<A, B>, 256,
+                                                     Wgrad2Cfg<A, B>::LDS_BYTES) != hipSuccess) n = -1;
+  }
+  return n;
+}
+extern "C" int crb_sparse_conv_wgrad_occupancy(int cin, int cout) {
+#define X_(a, b) if (cin == a && cout == b) return wgrad_occ_of<a, b>();
+  X_(32, 32) X_(32, 64) X_(64, 32) X_(64, 64) X_(64, 128) X_(128, 64) X_(128, 128)
+#undef X_
+  return -1;
+}
 
 static int g_wgrad_splits = 96;   // workgroups per kernel offset the plan aims at (multiple of 8: XCD mapping)
 extern "C" int crb_sparse_conv_wgrad_splits(void) { return g_wgrad_splits; }
 // 16x16 tiles: the partial reduction costs as much as the MFMA work, fewer and larger workgroups win (sweep on the SECOND
 // bs=16 geometry: 32 / 96 / 256 workgroups per offset = 39 / 52 / 95 us at C=16, 292 / 264 / 259 us at C=64)
-// v2 shapes (both multiples of 32): ~1000 workgroups = two rounds of 2 per CU; every extra workgroup is one more Cin x Cout
-// partial to write and reduce (at 96 per offset the partials of a 64x64 layer were 42 MB, as much as the gathered rows)
-static inline int wgrad_splits_for(int cin, int cout) {
+// v2 shapes (both multiples of 32): ONE round of workgroups, all resident from the start. A per-workgroup timeline
+// (tools/wgrad_timeline.py) of the 64x64 layer with 1058 workgroups showed 1010 starting at t = 0 and 48 queueing ~100 us for
+// a slot, then running alone: kernel span 183 us for a median workgroup lifetime of 118 us. The occupancy API answers 5
+// workgroups per CU there (160 KB / 32 KB of LDS) but 4 run, so the launch is sized for (API - 1) x CUs slots; each extra
+// workgroup is also one more Cin x Cout partial to write and reduce.
+template <int A, int B>
+static size_t wgrad_lds_of() {
+  if constexpr (A % 32 == 0 && B % 32 == 0 && (A / 32) * (B / 32) <= 4) {
+    if (g_wgrad_v1 == 0) return Wgrad3Cfg<A, B>::LDS_BYTES;
+  }
+  if constexpr (A % 32 == 0 && B % 32 == 0) return Wgrad2Cfg<A, B>::LDS_BYTES;
+  return 0;
+}
+static int wgrad2_slots(int cin, int cout) {
+  static int cache[3][5][5];                                // [kernel-selection knob][cin/32][cout/32]
+  int& c = cache[g_wgrad_v1][cin / 32][cout / 32];
+  if (c == 0) {
+    int occ = crb_sparse_conv_wgrad_occupancy(cin, cout);
+    size_t lds = 0;
+#define X_(a, b) if (cin == a && cout == b) lds = wgrad_lds_of<a, b>();
+    X_(32, 32) X_(32, 64) X_(64, 32) X_(64, 64) X_(64, 128) X_(128, 64) X_(128, 128)
+#undef X_
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      cus = 256;
+    // the API answers 160 KB / LDS-per-workgroup, but a workgroup set that fills the CU's LDS to the last byte is not
+    // admitted (5 x 32 KB: 4 run) -> leave 1 KB
+    const int fit = lds ? (int)((160 * 1024 - 1024) / lds) : occ;
+    if (occ > fit) occ = fit;
+    if (occ < 1) occ = 1;
+    c = occ * cus;
+  }
+  return c;
+}
+static inline int wgrad_splits_for(int K, int cin, int cout) {
   if (g_wgrad_splits != 96) return g_wgrad_splits;
   if (cin * cout <= 256) return 32;
-  if (cin % 32 == 0 && cout % 32 == 0 && !g_wgrad_v1) return 40;
+  if (cin % 32 == 0 && cout % 32 == 0 && cin <= 128 && cout <= 128 && g_wgrad_v1 != 1) {
+    int s = (wgrad2_slots(cin, cout) - 8) / K;               // K*s workgroup slots, of which K are rounding slack of the plan
+    return s < 4 ? 4 : (s > 96 ? 96 : s);
+  }
   return 96;
 }
 extern "C" int crb_sparse_conv_set_wgrad_splits(int s) {      // A/B measurements; 0 restores the default
@@ -1010,7 +1335,7 @@ extern "C" int crb_sparse_conv_set_wgrad_splits(int s) {      // A/B measurement
 }
 
 extern "C" int64_t crb_sparse_conv_wgrad_workspace_bytes(int K, int cin, int cout) {
-  return (int64_t)wgrad_splits_for(cin, cout) * K * cin * cout * 4 + 256;
+  return (int64_t)wgrad_splits_for(K, cin, cout) * K * cin * cout * 4 + 256;
 }
 
 extern "C" int crb_sparse_conv_wgrad(const float* X, const float* dY, const int32_t* pair_in, const int32_t* pair_out,
@@ -1019,7 +1344,7 @@ extern "C" int crb_sparse_conv_wgrad(const float* X, const float* dY, const int3
   if (K <= 0 || K > 32) return CRB_ERR_ARG;
   if (workspace_bytes < crb_sparse_conv_wgrad_workspace_bytes(K, cin, cout) || !workspace) return CRB_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  const int S = wgrad_splits_for(cin, cout);
+  const int S = wgrad_splits_for(K, cin, cout);
 #define X_(a, b)                                                                                              \
   if (cin == a && cout == b)                                                                                  \
     return launch_wgrad<a, b>(X, dY, pair_in, pair_out, pair_start, dW, (float*)workspace,                     \

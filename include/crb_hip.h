@@ -120,6 +120,9 @@ int crb_sparse_conv_timing(uint64_t* out16_host);
 /* dW (K,cin,cout) = sum over pairs X[pin]^T dY[pout] */
 int crb_sparse_conv_wgrad_splits(void);
 int crb_sparse_conv_set_wgrad_splits(int splits);    /* measurement knob: workgroups per offset (multiple of 8), 0 = default */
+int crb_sparse_conv_wgrad_occupancy(int cin, int cout); /* measurement helper: resident workgroups per CU of the v2 wgrad instance */
+int crb_sparse_conv_set_wgrad_debug(void* dev_buf_u64x4_per_wg); /* measurement runs: per-workgroup {start, end, HW_ID, XCC_ID | steps<<32} of the v2 wgrad; NULL = off */
+int crb_sparse_conv_set_wgrad_mode(int mode);        /* measurement builds of the 64x64 wgrad: 1 = no MFMAs, 2 = no gather pipeline (results are wrong by design), 0 = normal */
 int crb_sparse_conv_set_wgrad_v1(int on);            /* measurement knob: 1 = the v1 (16x16x4, register-gather) wgrad kernel for every shape */
 int64_t crb_sparse_conv_wgrad_workspace_bytes(int K, int cin, int cout);
 int crb_sparse_conv_wgrad(const float* X, const float* dY, const int32_t* pair_in, const int32_t* pair_out,

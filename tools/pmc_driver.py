@@ -12,6 +12,7 @@ if __name__ == '__main__':
     from pcdet.datasets.synthetic import kitti_batch, KITTI_RANGE, KITTI_VOXEL
     level = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    kind = sys.argv[3] if len(sys.argv) > 3 else 'fwd'            # fwd | wgrad
     dev = torch.device('cuda', 0)
     pts, off, _ = kitti_batch(0, 16)
     r = voxel.voxelize(torch.from_numpy(pts).to(dev), torch.from_numpy(off).to(dev), KITTI_RANGE, KITTI_VOXEL, 16000, 5,
@@ -29,9 +30,14 @@ if __name__ == '__main__':
     x = torch.randn(n, cin, device=dev)
     w = torch.randn(27, cin, cout, device=dev) / 10
     table = rb.sorted_table('nbr')
+    dy = torch.randn(n, cout, device=dev)
+    pairs = rb.pairs()
     torch.cuda.synchronize()
     for _ in range(iters):
-        sparse._conv_forward_raw(x, w, table, n)
+        if kind == 'wgrad':
+            sparse._conv_wgrad_raw(x, dy, pairs, 27)
+        else:
+            sparse._conv_forward_raw(x, w, table, n)
     torch.cuda.synchronize()
     balg = 4.0 * n * cin + 4.0 * n * cout + 8.0 * P + 4.0 * 27 * cin * cout
-    print('PMC_DRIVER level %d N=%d P=%d alg_bytes=%d flops=%d' % (level, n, P, balg, 2 * P * cin * cout))
+    print('PMC_DRIVER %s level %d N=%d P=%d alg_bytes=%d flops=%d' % (kind, level, n, P, balg, 2 * P * cin * cout))
