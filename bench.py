@@ -107,9 +107,10 @@ def roofline_from_profile(prof, overhead_ms=0.0):
         key = ('subm_gather_gemm', cin, cout)
         a = agg.setdefault(key, {'ms': 0.0, 'n': 0, 'bytes': 0.0, 'flops': 0.0, 'pairs': {}})
         tab = tab if not isinstance(tab, tuple) else tab[0]
-        pid = tab.data_ptr()
+        compact = hasattr(tab, 'cbase')
+        pid = tab.cbase.data_ptr() if compact else tab.data_ptr()
         if pid not in a['pairs']:
-            a['pairs'][pid] = int((tab >= 0).sum().item())
+            a['pairs'][pid] = tab.num_pairs() if compact else int((tab >= 0).sum().item())
         P = a['pairs'][pid]
         a['ms'] += ms
         a['n'] += 1

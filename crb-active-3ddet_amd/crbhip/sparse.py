@@ -37,13 +37,43 @@ class Rulebook(object):
         self._pairs_t = None
         self._sorted = {}
 
+    def row_perm(self, which):
+        """kernel order of the rows of 'nbr' | 'nbr_t' (mask-sorted chunks, tiles heaviest first) or None"""
+        key = 'perm_' + which
+        if key not in self._sorted:
+            table = self.nbr if which == 'nbr' else self.nbr_t
+            self._sorted[key] = _mask_perm(table, self.K)
+        return self._sorted[key]
+
     def sorted_table(self, which):
-        """('nbr' | 'nbr_t') -> (table rows in neighbour-mask order, perm int32): the layout the gather-GEMM kernel
-        consumes (rows of a wave share their set of active kernel offsets)"""
+        """('nbr' | 'nbr_t') -> (table rows in neighbour-mask order, perm int32): the (n,K) layout of the kernels without a
+        compact-table instance (rows of a wave share their set of active kernel offsets)"""
         if which not in self._sorted:
             table = self.nbr if which == 'nbr' else self.nbr_t
-            self._sorted[which] = _mask_sort(table, self.K)
+            perm = self.row_perm(which)
+            if perm is None:
+                self._sorted[which] = (table, None)
+            else:
+                out = torch.empty_like(table)
+                check(lib.crb_nbr_permute(ptr(table), ptr(perm), table.shape[0], self.K, ptr(out), cur_stream(table.device)),
+                      'crb_nbr_permute')
+                self._sorted[which] = (out, perm)
         return self._sorted[which]
+
+    def compact_table(self, which):
+        """('nbr' | 'nbr_t') -> CompactTable: per row of the kernel order a mask of present offsets + the present
+        neighbour indices packed row after row (crb_nbr_compact): 8 + 4 P/n bytes per row instead of 4 K"""
+        key = 'compact_' + which
+        if key not in self._sorted:
+            table = self.nbr if which == 'nbr' else self.nbr_t
+            self._sorted[key] = _compact(table, self.row_perm(which), self.K)
+        return self._sorted[key]
+
+    def table_for(self, which, cin, cout):
+        """the table form the gather-GEMM instance of (cin, cout) consumes"""
+        if COMPACT_TABLES and lib.crb_sparse_conv_compact_supported(cin, cout):
+            return self.compact_table(which)
+        return self.sorted_table(which)
 
     def pairs(self):
         if self._pairs is None:
@@ -65,11 +95,47 @@ MASK_SORT = True      # set False to run the kernel on the natural row order (A/
 MASK_SORT_CHUNK = int(__import__('os').environ.get('CRB_MASK_SORT_CHUNK', '4096'))
 
 
-def _mask_sort(table, K):
+COMPACT_TABLES = True  # mask + packed-index tables for the kernels that have a compact instance (A/B: set False)
+
+
+class CompactTable(object):
+    __slots__ = ('cmask', 'cbase', 'packed', 'perm', 'n', 'K')
+
+    def __init__(self, cmask, cbase, packed, perm, n, K):
+        self.cmask, self.cbase, self.packed, self.perm, self.n, self.K = cmask, cbase, packed, perm, n, K
+
+    def num_pairs(self):
+        return int(self.cbase[-1].item())
+
+    def to_nbr(self):
+        """the (n,K) table in kernel order this compact table encodes (tests)"""
+        n, K = self.n, self.K
+        bits = ((self.cmask.long()[:, None] >> torch.arange(K, device=self.cmask.device)[None, :]) & 1).bool()
+        rank = torch.cumsum(bits.long(), 1) - bits.long()
+        idx = (self.cbase[:-1].long()[:, None] + rank).clamp(max=max(self.packed.numel() - 1, 0))
+        out = torch.where(bits, self.packed.long()[idx], torch.full_like(idx, -1))
+        return out.int()
+
+
+def _compact(table, perm, K):
+    n = table.shape[0]
+    dev = table.device
+    cmask = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+    cbase = torch.empty((n + 1,), dtype=torch.int32, device=dev)
+    packed = torch.empty((max(n * K, 1),), dtype=torch.int32, device=dev)     # worst case; only cbase[n] entries are touched
+    wsb = lib.crb_nbr_compact_workspace_bytes(n)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    check(lib.crb_nbr_compact(ptr(table), ptr(perm), n, K, ptr(cmask), ptr(cbase), ptr(packed), ptr(ws), wsb, cur_stream(dev)),
+          'crb_nbr_compact')
+    return CompactTable(cmask[:n], cbase, packed, perm, n, K)
+
+
+def _mask_perm(table, K):
+    """row permutation of the gather-GEMM's kernel order (None = natural order)"""
     n = table.shape[0]
     dev = table.device
     if n == 0 or not MASK_SORT:
-        return table, None
+        return None
     mask = torch.empty((n,), dtype=torch.int32, device=dev)
     check(lib.crb_nbr_masks(ptr(table), n, K, ptr(mask), cur_stream(dev)), 'crb_nbr_masks')
     if MASK_SORT_CHUNK == lib.crb_mask_sort_chunk_rows():
@@ -89,9 +155,7 @@ def _mask_sort(table, K):
         check(lib.crb_tile_lpt_perm(ptr(mask), ptr(perm), n, ptr(perm2), ptr(ws), wsb, cur_stream(dev)),
               'crb_tile_lpt_perm')
         perm = perm2
-    out = torch.empty_like(table)
-    check(lib.crb_nbr_permute(ptr(table), ptr(perm), n, K, ptr(out), cur_stream(dev)), 'crb_nbr_permute')
-    return out, perm
+    return perm
 
 
 def _pairs_from_nbr(nbr, n_rows, K):
@@ -134,7 +198,43 @@ def subm_rulebook(coords, shape, ksize):
     return rb
 
 
-def spconv_rulebook(coords, shape, batch_size, ksize, stride, padding):
+def strided_chain_counts(coords, shape, batch_size, geoms):
+    """output bitmaps and output-site counts of a CHAIN of strided convs (geoms = [(ksize, stride, padding), ...], each
+    applied to the previous one's output) with ONE host read-back: level 1 is marked from the coordinates, every further
+    level straight from the previous level's bitmap. -> [(bitmap int32 tensor, n_out int, out_shape)] per level, to be
+    handed to spconv_rulebook(..., premarked=...) which then needs no synchronisation of its own."""
+    require_cuda(coords)
+    dev = coords.device
+    st = cur_stream(dev)
+    counts = torch.empty((len(geoms),), dtype=torch.int32, device=dev)
+    out, in_shape, in_bitmap = [], list(shape), None
+    for lvl, (ks, sd, pd) in enumerate(geoms):
+        ks, sd, pd = _triple(ks), _triple(sd), _triple(pd)
+        oshape = conv_out_shape(in_shape, ks, sd, pd)
+        if min(oshape) <= 0:
+            raise CrbHipError(f'sparse conv output shape {oshape} is empty')
+        oc = host_i32x3(oshape)
+        words = lib.crb_spconv_bitmap_words(batch_size, oc)
+        bitmap = torch.empty((words,), dtype=torch.int32, device=dev)
+        if in_bitmap is None:
+            check(lib.crb_spconv_mark(ptr(coords), coords.shape[0], batch_size, host_i32x3(ks), host_i32x3(sd),
+                                      host_i32x3(pd), oc, ptr(bitmap), st), 'crb_spconv_mark')
+        else:
+            check(lib.crb_spconv_mark_from_bitmap(ptr(in_bitmap), batch_size, host_i32x3(in_shape), host_i32x3(ks),
+                                                  host_i32x3(sd), host_i32x3(pd), oc, ptr(bitmap), st),
+                  'crb_spconv_mark_from_bitmap')
+        check(lib.crb_bitmap_count(ptr(bitmap), words, ptr(counts[lvl:lvl + 1]), st), 'crb_bitmap_count')
+        out.append([bitmap, None, oshape])
+        in_shape, in_bitmap = oshape, bitmap
+    host = counts.cpu().tolist()                       # the single read-back of the chain
+    for lvl, n_out in enumerate(host):
+        out[lvl][1] = int(n_out)
+    return [tuple(o) for o in out]
+
+
+def spconv_rulebook(coords, shape, batch_size, ksize, stride, padding, premarked=None):
+    """premarked = (bitmap, n_out, out_shape) from strided_chain_counts: the output set is already marked and counted, no
+    host synchronisation happens here"""
     require_cuda(coords)
     assert coords.dtype == torch.int32 and coords.is_contiguous()
     ksize, stride, padding = _triple(ksize), _triple(stride), _triple(padding)
@@ -146,23 +246,31 @@ def spconv_rulebook(coords, shape, batch_size, ksize, stride, padding):
         raise CrbHipError(f'sparse conv output shape {out_shape} is empty')
     oshape_c = host_i32x3(out_shape)
     words = lib.crb_spconv_bitmap_words(batch_size, oshape_c)
-    bitmap = torch.empty((words,), dtype=torch.int32, device=dev)
     prefix = torch.empty((words,), dtype=torch.int32, device=dev)
     scan_tmp = torch.empty((words // 2048 + 2,), dtype=torch.int32, device=dev)
-    max_out = min(max(n * K, 1), batch_size * out_shape[0] * out_shape[1] * out_shape[2])
-    # upper bound used for the coordinate buffer: an input site feeds at most prod(ceil(k/s)) outputs
-    fan = 1
-    for k, s in zip(ksize, stride):
-        fan *= (k + s - 1) // s
-    max_out = min(max_out, max(n * fan, 1))
-    out_coords = torch.empty((max_out, 4), dtype=torch.int32, device=dev)
     n_out_dev = torch.empty((1,), dtype=torch.int32, device=dev)
     st = cur_stream(dev)
-    check(lib.crb_spconv_out_coords(ptr(coords), n, batch_size, host_i32x3(ksize), host_i32x3(stride),
-                                    host_i32x3(padding), oshape_c, ptr(bitmap), ptr(prefix), ptr(scan_tmp),
-                                    ptr(out_coords), max_out, ptr(n_out_dev), st), 'crb_spconv_out_coords')
-    n_out = int(n_out_dev.item())      # sync: the output row count sizes every later buffer
-    assert n_out <= max_out
+    if premarked is not None:
+        bitmap, n_out, pshape = premarked
+        assert list(pshape) == list(out_shape) and bitmap.numel() == words
+        out_coords = torch.empty((max(n_out, 1), 4), dtype=torch.int32, device=dev)
+        check(lib.crb_spconv_out_coords_premarked(batch_size, oshape_c, ptr(bitmap), ptr(prefix), ptr(scan_tmp),
+                                                  ptr(out_coords), n_out, ptr(n_out_dev), st),
+              'crb_spconv_out_coords_premarked')
+    else:
+        bitmap = torch.empty((words,), dtype=torch.int32, device=dev)
+        max_out = min(max(n * K, 1), batch_size * out_shape[0] * out_shape[1] * out_shape[2])
+        # upper bound used for the coordinate buffer: an input site feeds at most prod(ceil(k/s)) outputs
+        fan = 1
+        for k, s in zip(ksize, stride):
+            fan *= (k + s - 1) // s
+        max_out = min(max_out, max(n * fan, 1))
+        out_coords = torch.empty((max_out, 4), dtype=torch.int32, device=dev)
+        check(lib.crb_spconv_out_coords(ptr(coords), n, batch_size, host_i32x3(ksize), host_i32x3(stride),
+                                        host_i32x3(padding), oshape_c, ptr(bitmap), ptr(prefix), ptr(scan_tmp),
+                                        ptr(out_coords), max_out, ptr(n_out_dev), st), 'crb_spconv_out_coords')
+        n_out = int(n_out_dev.item())      # sync: the output row count sizes every later buffer
+        assert n_out <= max_out
     out_coords = out_coords[:n_out]
     nbr = torch.empty((n_out, K), dtype=torch.int32, device=dev)
     nbr_t = torch.empty((n, K), dtype=torch.int32, device=dev)
@@ -180,8 +288,8 @@ PROFILE = None
 
 
 def _conv_forward_raw(x, w_kio, table, n_out, kind='fwd'):
-    """x (n_in,cin), w (K,cin,cout), table = (nbr rows in kernel order (n_out,K), perm or None) -> (n_out,cout)"""
-    nbr, perm = table
+    """x (n_in,cin), w (K,cin,cout), table = (nbr rows in kernel order (n_out,K), perm or None) or a CompactTable
+    -> (n_out,cout)"""
     K, cin, cout = w_kio.shape
     if not lib.crb_sparse_conv_supported(cin, cout):
         raise CrbHipError(f'sparse conv channel pair ({cin},{cout}) has no gfx950 kernel instance')
@@ -190,9 +298,16 @@ def _conv_forward_raw(x, w_kio, table, n_out, kind='fwd'):
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(lib.crb_sparse_conv_forward(ptr(x), ptr(w_kio), ptr(nbr), ptr(perm), ptr(y), n_out, K, cin, cout,
-                                      cur_stream(x.device)),
-          'crb_sparse_conv_forward')
+    if isinstance(table, CompactTable):
+        check(lib.crb_sparse_conv_forward_compact(ptr(x), ptr(w_kio), ptr(table.cmask), ptr(table.cbase), ptr(table.packed),
+                                                  ptr(table.perm), ptr(y), n_out, K, cin, cout, cur_stream(x.device)),
+              'crb_sparse_conv_forward_compact')
+        nbr = table
+    else:
+        nbr, perm = table
+        check(lib.crb_sparse_conv_forward(ptr(x), ptr(w_kio), ptr(nbr), ptr(perm), ptr(y), n_out, K, cin, cout,
+                                          cur_stream(x.device)),
+              'crb_sparse_conv_forward')
     if prof is not None:
         ev1.record()
         prof.append((kind, cin, cout, K, x.shape[0], n_out, nbr, ev0, ev1))
@@ -225,10 +340,11 @@ class SparseConvFunction(torch.autograd.Function):
         require_cuda(x, w_kio)
         x = x.contiguous().float()
         w_kio = w_kio.contiguous().float()
+        K, cin, cout = w_kio.shape
         if inverse:
-            table, n_out = rb.sorted_table('nbr_t'), rb.n_in
+            table, n_out = rb.table_for('nbr_t', cin, cout), rb.n_in
         else:
-            table, n_out = rb.sorted_table('nbr'), rb.n_out
+            table, n_out = rb.table_for('nbr', cin, cout), rb.n_out
         ctx.rb, ctx.inverse = rb, inverse
         ctx.save_for_backward(x, w_kio)
         return _conv_forward_raw(x, w_kio, table, n_out, ('subm' if rb.subm else 'spconv') + '_fwd')
@@ -242,10 +358,11 @@ class SparseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if rb.subm:
                 wd = w.flip(0).transpose(1, 2).contiguous()      # Wd[o] = W[K-1-o]^T
-                dx = _conv_forward_raw(dy, wd, rb.sorted_table('nbr'), rb.n_in, 'subm_dgrad')
+                dx = _conv_forward_raw(dy, wd, rb.table_for('nbr', wd.shape[1], wd.shape[2]), rb.n_in, 'subm_dgrad')
             else:
                 wd = w.transpose(1, 2).contiguous()
-                table, n_in = (rb.sorted_table('nbr'), rb.n_out) if inverse else (rb.sorted_table('nbr_t'), rb.n_in)
+                table, n_in = (rb.table_for('nbr', wd.shape[1], wd.shape[2]), rb.n_out) if inverse else \
+                    (rb.table_for('nbr_t', wd.shape[1], wd.shape[2]), rb.n_in)
                 dx = _conv_forward_raw(dy, wd, table, n_in, 'spconv_dgrad')
         if ctx.needs_input_grad[1]:
             pairs = rb.pairs_t() if inverse else rb.pairs()

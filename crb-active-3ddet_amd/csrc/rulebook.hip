@@ -81,6 +81,48 @@ __global__ __launch_bounds__(256) void spconv_mark_kernel(const int* __restrict_
   atomicOr(&bitmap[lin >> 5], 1u << (lin & 31));
 }
 
+// the same marking, driven by the BITMAP of the input sites instead of their coordinate list: the output set of the next
+// strided level can be marked before the current level's coordinates exist, so the output counts of a whole chain of
+// strided convs are known after ONE host read-back (the coordinate lists and tables are then sized without further syncs)
+__global__ __launch_bounds__(256) void spconv_mark_from_bitmap_kernel(const uint32_t* __restrict__ in_bitmap,
+                                                                      int64_t in_words, Shape3 si, ConvGeom g, Shape3 so,
+                                                                      uint32_t* __restrict__ bitmap) {
+  const int64_t wi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (wi >= in_words) return;
+  uint32_t m = in_bitmap[wi];
+  while (m) {
+    const int bit = __ffs(m) - 1;
+    m &= m - 1;
+    int64_t lin = wi * 32 + bit;
+    const int x = (int)(lin % si.w); lin /= si.w;
+    const int y = (int)(lin % si.h); lin /= si.h;
+    const int z = (int)(lin % si.d); lin /= si.d;
+    const int b = (int)lin;
+    for (int kz = 0; kz < g.kd; ++kz) {
+      const int tz = z + g.pd - kz;
+      if (tz < 0 || tz % g.sd || tz / g.sd >= so.d) continue;
+      for (int ky = 0; ky < g.kh; ++ky) {
+        const int ty = y + g.ph - ky;
+        if (ty < 0 || ty % g.sh || ty / g.sh >= so.h) continue;
+        for (int kx = 0; kx < g.kw; ++kx) {
+          const int tx = x + g.pw - kx;
+          if (tx < 0 || tx % g.sw || tx / g.sw >= so.w) continue;
+          const int64_t lo = lin_index(b, tz / g.sd, ty / g.sh, tx / g.sw, so);
+          atomicOr(&bitmap[lo >> 5], 1u << (lo & 31));
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bitmap_count_kernel(const uint32_t* __restrict__ bitmap, int64_t words,
+                                                           int* __restrict__ count) {
+  int c = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (int64_t)gridDim.x * 256) c += __popc(bitmap[i]);
+  for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+  if (crb_lane() == 0 && c) atomicAdd(count, c);
+}
+
 struct PopcF {
   const uint32_t* bm;
   __device__ int operator()(int64_t i) const { return __popc(bm[i]); }
@@ -306,6 +348,66 @@ extern "C" int64_t crb_spconv_out_coords_workspace_bytes(int B, const int32_t* o
 }
 
 // Stage 1 of a strided conv: output active set. bitmap/prefix (words each) stay alive for stage 2.
+extern "C" int crb_spconv_mark(const int32_t* coords, int64_t n, int B, const int32_t* ksize, const int32_t* stride,
+                               const int32_t* padding, const int32_t* out_shape_dhw, uint32_t* bitmap, void* stream) {
+  if (n < 0 || B <= 0) return CRB_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  Shape3 so{out_shape_dhw[0], out_shape_dhw[1], out_shape_dhw[2]};
+  ConvGeom g{ksize[0], ksize[1], ksize[2], stride[0], stride[1], stride[2], padding[0], padding[1], padding[2]};
+  const int K = g.kd * g.kh * g.kw;
+  CRB_HIP(hipMemsetAsync(bitmap, 0, (size_t)crb_spconv_bitmap_words(B, out_shape_dhw) * 4, st));
+  if (n > 0)
+    hipLaunchKernelGGL(spconv_mark_kernel, dim3(crb_cdiv(n * K, 256)), dim3(256), 0, st, coords, (int)n, g, so, bitmap);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_spconv_mark_from_bitmap(const uint32_t* in_bitmap, int B, const int32_t* in_shape_dhw,
+                                           const int32_t* ksize, const int32_t* stride, const int32_t* padding,
+                                           const int32_t* out_shape_dhw, uint32_t* bitmap, void* stream) {
+  if (B <= 0) return CRB_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  Shape3 si{in_shape_dhw[0], in_shape_dhw[1], in_shape_dhw[2]};
+  Shape3 so{out_shape_dhw[0], out_shape_dhw[1], out_shape_dhw[2]};
+  ConvGeom g{ksize[0], ksize[1], ksize[2], stride[0], stride[1], stride[2], padding[0], padding[1], padding[2]};
+  const int64_t in_words = crb_spconv_bitmap_words(B, in_shape_dhw);
+  CRB_HIP(hipMemsetAsync(bitmap, 0, (size_t)crb_spconv_bitmap_words(B, out_shape_dhw) * 4, st));
+  hipLaunchKernelGGL(spconv_mark_from_bitmap_kernel, dim3(crb_cdiv(in_words, 256)), dim3(256), 0, st, in_bitmap, in_words, si,
+                     g, so, bitmap);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_bitmap_count(const uint32_t* bitmap, int64_t words, int32_t* count_dev, void* stream) {
+  if (words < 0) return CRB_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  CRB_HIP(hipMemsetAsync(count_dev, 0, sizeof(int), st));
+  if (words > 0) {
+    int blocks = crb_cdiv(words, 256 * 8);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bitmap_count_kernel, dim3(blocks), dim3(256), 0, st, bitmap, words, count_dev);
+  }
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_spconv_out_coords_premarked(int B, const int32_t* out_shape_dhw, const uint32_t* bitmap, int32_t* prefix,
+                                               int32_t* scan_tmp, int32_t* out_coords, int64_t max_out,
+                                               int32_t* n_out_dev, void* stream) {
+  if (B <= 0) return CRB_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  Shape3 so{out_shape_dhw[0], out_shape_dhw[1], out_shape_dhw[2]};
+  const int64_t words = crb_spconv_bitmap_words(B, out_shape_dhw);
+  PopcF f{bitmap};
+  PrefixW w{prefix};
+  int rc = crb_device_excl_scan(f, w, words, scan_tmp, n_out_dev, st);
+  if (rc != CRB_OK) return rc;
+  hipLaunchKernelGGL(spconv_emit_coords_kernel, dim3(crb_cdiv(words, 256)), dim3(256), 0, st, bitmap, prefix, words,
+                     so, (int)(max_out > 0x7fffffff ? 0x7fffffff : max_out), out_coords);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
 extern "C" int crb_spconv_out_coords(const int32_t* coords, int64_t n, int B, const int32_t* ksize,
                                      const int32_t* stride, const int32_t* padding, const int32_t* out_shape_dhw,
                                      uint32_t* bitmap, int32_t* prefix, int32_t* scan_tmp,

@@ -250,10 +250,16 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
 // fetch + store + first gather issue + barrier)
 __device__ unsigned long long g_fwd2_timing[16];
 
-template <int CIN, int COUT, bool NOMFMA = false, bool REMAP = true, bool TIMING = false>
+// COMPACT: the neighbour table arrives as one 27-bit mask per row + the present indices packed row after row (cbase =
+// exclusive prefix of the masks' popcounts): 8 + 4 P/N bytes per row instead of 4 K (22 against 108 at the 16-channel level,
+// where the table was 40 % of the launch's HBM bytes). A row's neighbour through offset o is
+// packed[cbase[row] + popcount(mask & ((1 << o) - 1))] when bit o is set.
+template <int CIN, int COUT, bool NOMFMA = false, bool REMAP = true, bool TIMING = false, bool COMPACT = false>
 __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                                const int* __restrict__ nbr, const int* __restrict__ perm,
-                                                               float* __restrict__ Y, int n_out, int K, int ntiles) {
+                                                               float* __restrict__ Y, int n_out, int K, int ntiles,
+                                                               const unsigned* __restrict__ cmask = nullptr,
+                                                               const int* __restrict__ cbase = nullptr) {
   static_assert(CIN % 16 == 0 && COUT % 16 == 0, "v2 needs whole float4 k-groups and unmasked column blocks");
   constexpr int NB = (COUT + 15) / 16;
   constexpr int WS = NB * 16;
@@ -266,6 +272,8 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
   float* w_lds1 = w_lds0 + CIN * WS;
   int* nbr_lds = reinterpret_cast<int*>(smem + 2 * sizeof(float) * CIN * WS);   // 64 * K ints
   __shared__ unsigned wg_mask_sh[4];
+  __shared__ unsigned row_mask_sh[COMPACT ? 64 : 1];
+  __shared__ int row_base_sh[COMPACT ? 64 : 1];
 
   const int tile = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   if (tile >= ntiles) return;
@@ -286,8 +294,19 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
   // INSTRUCTIONS: the 64 x K table is copied without a division per element, a wave derives its tile's offset mask from
   // ceil(K/4) LDS reads per lane + an OR butterfly (not K reads + K ballots), and the output-row indirection perm[] is
   // fetched here, long before the final stores need it.
-  const int lim = min(64, n_out - row0) * K;
-  for (int t = threadIdx.x; t < 64 * K; t += 256) nbr_lds[t] = (t < lim) ? nbr[(int64_t)row0 * K + t] : -1;
+  if constexpr (COMPACT) {
+    const int nrow = min(64, n_out - row0);
+    const int b0 = cbase[row0], b1 = cbase[row0 + nrow];              // wave-uniform
+    if (threadIdx.x < 64) {
+      const int t = threadIdx.x;
+      row_mask_sh[t] = t < nrow ? cmask[row0 + t] : 0u;
+      row_base_sh[t] = (t < nrow ? cbase[row0 + t] : b1) - b0;
+    }
+    for (int t = threadIdx.x; t < b1 - b0; t += 256) nbr_lds[t] = nbr[b0 + t];      // nbr = the packed index array
+  } else {
+    const int lim = min(64, n_out - row0) * K;
+    for (int t = threadIdx.x; t < 64 * K; t += 256) nbr_lds[t] = (t < lim) ? nbr[(int64_t)row0 * K + t] : -1;
+  }
   int out_row[4];
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) {
@@ -297,8 +316,22 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
   __syncthreads();
   lap(13);
   const int* my_nbr = nbr_lds + (wave * 16 + li) * K;
+  const unsigned my_mask = COMPACT ? row_mask_sh[wave * 16 + li] : 0u;
+  const int my_lb = COMPACT ? row_base_sh[wave * 16 + li] : 0;
+  auto nbr_of = [&](int o) -> int {
+    if constexpr (COMPACT) {
+      const int idx = nbr_lds[my_lb + __popc(my_mask & ((1u << o) - 1u))];   // in-bounds also when bit o is clear
+      return ((my_mask >> o) & 1u) ? idx : -1;
+    } else {
+      return my_nbr[o];
+    }
+  };
   unsigned sm = 0;
-  for (int o = g; o < K; o += 4) sm |= (my_nbr[o] >= 0 ? 1u : 0u) << o;      // lane (li, g): offsets g, g+4, ...
+  if constexpr (COMPACT) {
+    sm = my_mask;
+  } else {
+    for (int o = g; o < K; o += 4) sm |= (my_nbr[o] >= 0 ? 1u : 0u) << o;      // lane (li, g): offsets g, g+4, ...
+  }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) sm |= (unsigned)__shfl_xor((int)sm, d);
   sm = __builtin_amdgcn_readfirstlane(sm);
@@ -387,7 +420,7 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
   // the workgroup (also for offsets its own tile lacks: those rows are -1 -> row 0, never multiplied), so all paths issue
   // the same loads and only the MFMA block itself sits under the wave-uniform `has` branch.
   f32x4 a0[KS], a1[KS];
-  int r0 = cur >= 0 ? my_nbr[cur] : -1, r1 = -1;
+  int r0 = cur >= 0 ? nbr_of(cur) : -1, r1 = -1;
   load_a(a0, X, r0);
   __syncthreads();
   lap(2);
@@ -399,7 +432,7 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
       if constexpr (TIMING) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lap(12); }
       w_fetch(oq);
       lap(10);
-      r1 = my_nbr[oq];
+      r1 = nbr_of(oq);
       if constexpr (TIMING) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); lap(11); }
       load_a(a1, X, r1);
       lap(3);
@@ -420,7 +453,7 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
       if constexpr (TIMING) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lap(12); }
       w_fetch(oq);
       lap(10);
-      r0 = my_nbr[oq];
+      r0 = nbr_of(oq);
       if constexpr (TIMING) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); lap(11); }
       load_a(a0, X, r0);
       lap(3);
@@ -468,6 +501,33 @@ __global__ __launch_bounds__(256) void nbr_permute_kernel(const int* __restrict_
   if (t >= (int64_t)n * K) return;
   const int i = (int)(t / K), o = (int)(t - (int64_t)i * K);
   out[t] = nbr[(int64_t)perm[i] * K + o];
+}
+
+// compact neighbour table (consumed by sparse_conv_fwd2_kernel<.., COMPACT = true>): row i of the kernel order is row
+// perm[i] of nbr. Pass 1: cmask[i]; device scan of the popcounts -> cbase; pass 2: half a wave per row, lane o looks at
+// offset o (one coalesced 4K-byte read per row) and writes its index at cbase[i] + rank of bit o in the mask.
+__global__ __launch_bounds__(256) void nbr_compact_mask_kernel(const int* __restrict__ nbr, const int* __restrict__ perm,
+                                                               int n, int K, unsigned* __restrict__ cmask) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int i = t >> 5, o = t & 31;
+  const bool live = i < n;
+  const int src = live ? (perm ? perm[i] : i) : 0;
+  const bool has = live && o < K && nbr[(int64_t)src * K + o] >= 0;
+  const unsigned long long b = __ballot(has);
+  const unsigned m = (unsigned)(((threadIdx.x & 63) < 32) ? (b & 0xffffffffULL) : (b >> 32));
+  if (live && o == 0) cmask[i] = m;
+}
+
+__global__ __launch_bounds__(256) void nbr_compact_fill_kernel(const int* __restrict__ nbr, const int* __restrict__ perm,
+                                                               int n, int K, const unsigned* __restrict__ cmask,
+                                                               const int* __restrict__ cbase, int* __restrict__ packed) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int i = t >> 5, o = t & 31;
+  if (i >= n || o >= K) return;
+  const unsigned m = cmask[i];
+  if (!((m >> o) & 1u)) return;
+  const int src = perm ? perm[i] : i;
+  packed[cbase[i] + __popc(m & ((1u << o) - 1u))] = nbr[(int64_t)src * K + o];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1143,6 +1203,21 @@ int launch_fwd(const float* X, const float* W, const int* nbr, const int* perm, 
 }
 
 template <int CIN, int COUT>
+int launch_fwd_compact(const float* X, const float* W, const unsigned* cmask, const int* cbase, const int* packed,
+                       const int* perm, float* Y, int64_t n_out, int K, hipStream_t st) {
+  if constexpr (CIN % 16 == 0 && COUT % 16 == 0 && CIN <= 64) {
+    const int ntiles = crb_cdiv(n_out, 64);
+    const int grid = ((ntiles + 7) / 8) * 8;
+    size_t lds = 2 * sizeof(float) * CIN * (((COUT + 15) / 16) * 16) + sizeof(int) * 64 * K + 16;
+    hipLaunchKernelGGL((sparse_conv_fwd2_kernel<CIN, COUT, false, true, false, true>), dim3(grid), dim3(256), lds, st, X, W,
+                       packed, perm, Y, (int)n_out, K, ntiles, cmask, cbase);
+    CRB_CHECK_LAUNCH();
+    return CRB_OK;
+  }
+  return CRB_ERR_UNSUPPORTED;
+}
+
+template <int CIN, int COUT>
 int launch_wgrad(const float* X, const float* dY, const int* pin, const int* pout, const int* pstart, float* dW,
                  float* partial, int* plan, int K, int S, hipStream_t st) {
   if constexpr (CIN % 32 == 0 && COUT % 32 == 0 && (CIN / 32) * (COUT / 32) <= 4) {
@@ -1280,6 +1355,46 @@ extern "C" int crb_sparse_conv_wgrad_occupancy(int cin, int cout) {
   X_(32, 32) X_(32, 64) X_(64, 32) X_(64, 64) X_(64, 128) X_(128, 64) X_(128, 128)
 #undef X_
   return -1;
+}
+
+extern "C" int crb_sparse_conv_compact_supported(int cin, int cout) {
+  return (cin % 16 == 0 && cout % 16 == 0 && cin <= 64 && crb_sparse_conv_supported(cin, cout)) ? 1 : 0;
+}
+
+extern "C" int64_t crb_nbr_compact_workspace_bytes(int64_t n) {
+  return (int64_t)sizeof(int) * (crb_scan_num_tiles(n) + 8) + 256;
+}
+
+extern "C" int crb_nbr_compact(const int32_t* nbr, const int32_t* perm, int64_t n, int K, uint32_t* cmask, int32_t* cbase,
+                               int32_t* packed, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (n < 0 || K <= 0 || K > 32) return CRB_ERR_ARG;
+  if (workspace_bytes < crb_nbr_compact_workspace_bytes(n) || !workspace) return CRB_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) { CRB_HIP(hipMemsetAsync(cbase, 0, sizeof(int), st)); return CRB_OK; }
+  const int blocks = crb_cdiv(n * 32, 256);
+  hipLaunchKernelGGL(nbr_compact_mask_kernel, dim3(blocks), dim3(256), 0, st, nbr, perm, (int)n, K, cmask);
+  int* tiles = (int*)workspace;
+  const unsigned* cm = cmask;
+  int* cb = cbase;
+  auto f = [cm] __device__(int64_t i) { return __popc(cm[i]); };
+  auto w = [cb] __device__(int64_t i, int ex, int v) { cb[i] = ex; };
+  int rc = crb_device_excl_scan(f, w, n, tiles, cbase + n, st);
+  if (rc != CRB_OK) return rc;
+  hipLaunchKernelGGL(nbr_compact_fill_kernel, dim3(blocks), dim3(256), 0, st, nbr, perm, (int)n, K, cmask, cbase, packed);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_sparse_conv_forward_compact(const float* X, const float* W, const uint32_t* cmask, const int32_t* cbase,
+                                               const int32_t* packed, const int32_t* perm, float* Y, int64_t n_out, int K,
+                                               int cin, int cout, void* stream) {
+  if (n_out < 0 || K <= 0 || K > 32) return CRB_ERR_ARG;
+  if (n_out == 0) return CRB_OK;
+  hipStream_t st = (hipStream_t)stream;
+#define X_(a, b) if (cin == a && cout == b) return launch_fwd_compact<a, b>(X, W, cmask, cbase, packed, perm, Y, n_out, K, st);
+  CRB_CONV_SHAPES(X_)
+#undef X_
+  return CRB_ERR_UNSUPPORTED;
 }
 
 static int g_wgrad_splits = 96;   // workgroups per kernel offset the plan aims at (multiple of 8: XCD mapping)

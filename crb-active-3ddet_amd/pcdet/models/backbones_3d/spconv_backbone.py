@@ -5,6 +5,9 @@ from functools import partial
 import torch.nn as nn
 
 from ...utils.spconv_utils import replace_feature, spconv
+from spconv.pytorch.conv import plan_indices
+
+PLAN_INDICES = True      # A/B: False builds every rulebook where the forward pass first needs it (a host sync per strided layer)
 
 
 def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stride=1, padding=0, conv_type='subm',
@@ -59,6 +62,9 @@ class _Backbone8xBase(nn.Module):
         voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
         x = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords.int().contiguous(),
                                     spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
+        if PLAN_INDICES:
+            # all rulebooks first: one host read-back for the four strided output sets instead of a sync per strided layer
+            plan_indices([self.conv_input, self.conv1, self.conv2, self.conv3, self.conv4, self.conv_out], x)
         x = self.conv_input(x)
         x1 = self.conv1(x)
         x2 = self.conv2(x1)

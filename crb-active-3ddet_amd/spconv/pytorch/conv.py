@@ -158,3 +158,46 @@ class SparseConv2d(SparseConvolution):
                  indice_key=None, algo=None, fp32_accum=None, name=None):
         super().__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
                          indice_key=indice_key)
+
+
+def plan_indices(modules, input):
+    """Build the rulebooks of every (non 1x1, non inverse) SparseConvolution found in `modules` (in module order, as the
+    forward pass will meet them) BEFORE the first feature kernel runs, and leave them in input.indice_dict under their
+    indice_key. The active sets depend on the coordinates only, so the whole chain of strided output sets is marked and
+    counted with ONE host read-back (crbhip.sparse.strided_chain_counts) instead of one synchronisation per strided layer in
+    the middle of the forward pass (each of which let the GPU run dry while the host refilled the launch queue).
+    Layers without an indice_key, or whose key is already planned, are skipped; the forward pass falls back to building a
+    missing rulebook on the spot."""
+    convs = []
+    for root in modules:
+        for m in root.modules():
+            if isinstance(m, SparseConvolution) and m.ndim == 3 and not m.inverse and not m.conv1x1 and \
+                    m.indice_key is not None:
+                convs.append(m)
+    strided = [m for m in convs if not m.subm and m.indice_key not in input.indice_dict]
+    seen, chain = set(), []
+    for m in strided:
+        if m.indice_key not in seen:
+            seen.add(m.indice_key)
+            chain.append(m)
+    if not chain:
+        marks = {}
+    else:
+        geoms = [(m._k3(m.kernel_size, 1), m._k3(m.stride, 1), m._k3(m.padding, 0)) for m in chain]
+        res = _sp.strided_chain_counts(input.indices, list(input.spatial_shape), input.batch_size, geoms)
+        marks = {m.indice_key: r for m, r in zip(chain, res)}
+    idx, shape = input.indices, list(input.spatial_shape)
+    for m in convs:
+        key = m.indice_key
+        if key in input.indice_dict:
+            rb = input.indice_dict[key]
+        elif m.subm:
+            rb = _sp.subm_rulebook(idx, shape, m._k3(m.kernel_size, 1))
+            input.indice_dict[key] = rb
+        else:
+            rb = _sp.spconv_rulebook(idx, shape, input.batch_size, m._k3(m.kernel_size, 1), m._k3(m.stride, 1),
+                                     m._k3(m.padding, 0), premarked=marks.get(key))
+            input.indice_dict[key] = rb
+        if not m.subm:
+            idx, shape = rb.out_coords, list(rb.out_shape)
+    return input

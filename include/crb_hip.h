@@ -79,6 +79,21 @@ int crb_spconv_out_coords(const int32_t* coords, int64_t n, int B, const int32_t
                           uint32_t* bitmap, int32_t* prefix, int32_t* scan_tmp,
                           int32_t* out_coords, int64_t max_out, int32_t* n_out_dev, void* stream);
 /* strided conv stage 2: nbr (n_out,K) and its transpose nbr_t (n,K) */
+/* Output counts of a CHAIN of strided convs with one host read-back: crb_spconv_mark marks the output bitmap of the first
+ * level from its input coordinates, crb_spconv_mark_from_bitmap marks level l+1 straight from level l's bitmap (no
+ * coordinate list needed yet), crb_bitmap_count leaves each level's number of output sites in device memory — the caller
+ * reads all counts back at once, then sizes every coordinate list / table and runs crb_spconv_out_coords_premarked (scan +
+ * emit on an already marked bitmap) + crb_spconv_rulebook per level without further synchronisation. Bitmap layout and
+ * results are those of crb_spconv_out_coords. */
+int crb_spconv_mark(const int32_t* coords, int64_t n, int B, const int32_t* ksize, const int32_t* stride,
+                    const int32_t* padding, const int32_t* out_shape_dhw, uint32_t* bitmap, void* stream);
+int crb_spconv_mark_from_bitmap(const uint32_t* in_bitmap, int B, const int32_t* in_shape_dhw, const int32_t* ksize,
+                                const int32_t* stride, const int32_t* padding, const int32_t* out_shape_dhw,
+                                uint32_t* bitmap, void* stream);
+int crb_bitmap_count(const uint32_t* bitmap, int64_t words, int32_t* count_dev, void* stream);
+int crb_spconv_out_coords_premarked(int B, const int32_t* out_shape_dhw, const uint32_t* bitmap, int32_t* prefix,
+                                    int32_t* scan_tmp, int32_t* out_coords, int64_t max_out, int32_t* n_out_dev,
+                                    void* stream);
 int crb_spconv_rulebook(const int32_t* coords, int64_t n, int B, const int32_t* ksize,
                         const int32_t* stride, const int32_t* padding, const int32_t* out_shape_dhw,
                         const uint32_t* bitmap, const int32_t* prefix, int64_t n_out,
@@ -107,6 +122,18 @@ int64_t crb_tile_lpt_workspace_bytes(int64_t n);
 int crb_tile_lpt_perm(const int32_t* mask, const int32_t* perm_in, int64_t n, int32_t* perm_out, void* workspace,
                       int64_t workspace_bytes, void* stream);
 int crb_nbr_permute(const int32_t* nbr, const int32_t* perm, int64_t n, int K, int32_t* nbr_sorted, void* stream);
+/* Compact neighbour table of the gather-GEMM: cmask (n) u32 = kernel offsets present in row i of the KERNEL order (row
+ * perm[i] of nbr; perm NULL = identity), cbase (n+1) i32 = exclusive prefix of the masks' popcounts, packed (>= cbase[n],
+ * caller allocates n*K) = the present neighbour indices row after row, offsets ascending. 8 + 4 P/n bytes per row instead
+ * of 4 K. crb_sparse_conv_forward_compact is crb_sparse_conv_forward on that table (bit-identical results); shapes for
+ * which crb_sparse_conv_compact_supported() is 0 keep the (n,K) table. */
+int crb_sparse_conv_compact_supported(int cin, int cout);
+int64_t crb_nbr_compact_workspace_bytes(int64_t n);
+int crb_nbr_compact(const int32_t* nbr, const int32_t* perm, int64_t n, int K, uint32_t* cmask, int32_t* cbase,
+                    int32_t* packed, void* workspace, int64_t workspace_bytes, void* stream);
+int crb_sparse_conv_forward_compact(const float* X, const float* W, const uint32_t* cmask, const int32_t* cbase,
+                                    const int32_t* packed, const int32_t* perm, float* Y, int64_t n_out, int K, int cin,
+                                    int cout, void* stream);
 int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, const int32_t* perm, float* Y,
                             int64_t n_out, int K, int cin, int cout, void* stream);
 /* kernel-variant knob for A/B measurements only: 0 = default (v2 kernel where Cin,Cout are multiples of 16 and Cin <= 64,

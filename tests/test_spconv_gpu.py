@@ -476,3 +476,90 @@ def _kio_grad(conv):
     """gradient of the module's (Cout,k,k,k,Cin) weight viewed in the kernel's (K,Cin,Cout) layout"""
     g = conv.weight.grad
     return g.reshape(g.shape[0], -1, g.shape[-1]).permute(1, 2, 0).contiguous().cpu().numpy()
+
+
+@pytest.mark.parametrize('kind', ['subm', 'strided'])
+def test_compact_table_is_the_sorted_table_and_gives_identical_results(dev, kind):
+    """crb_nbr_compact: mask + packed present indices decode to exactly the (n,K) table in kernel order (itself bit-exact
+    vs the oracle), and crb_sparse_conv_forward_compact == crb_sparse_conv_forward bit for bit, forward and dgrad"""
+    from crbhip import lib, sparse
+    rng = np.random.default_rng(31)
+    shape = [21, 120, 100]
+    coords = random_sparse_coords(rng, 9000, 2, shape)
+    if kind == 'subm':
+        rb = sparse.subm_rulebook(_t(coords, dev), shape, [3, 3, 3])
+        which = ['nbr']
+    else:
+        rb = sparse.spconv_rulebook(_t(coords, dev), shape, 2, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+        which = ['nbr', 'nbr_t']
+    for w_ in which:
+        full, perm = rb.sorted_table(w_)
+        ct = rb.compact_table(w_)
+        assert torch.equal(ct.to_nbr(), full)
+        P = int((full >= 0).sum())
+        assert ct.num_pairs() == P and int(ct.cbase[0]) == 0
+        assert torch.equal(ct.perm, perm)
+        n_in = rb.n_in if w_ == 'nbr' else rb.n_out
+        for cin, cout in ((16, 16), (16, 32), (32, 16), (32, 32), (32, 64), (64, 64), (64, 128)):
+            assert lib.crb_sparse_conv_compact_supported(cin, cout) == 1
+            x = torch.randn(n_in, cin, device=dev)
+            w = torch.randn(27, cin, cout, device=dev) / 8
+            a = sparse._conv_forward_raw(x, w, (full, perm), full.shape[0])
+            b = sparse._conv_forward_raw(x, w, ct, full.shape[0])
+            assert torch.equal(a, b), (cin, cout, float((a - b).abs().max()))
+    assert lib.crb_sparse_conv_compact_supported(4, 16) == 0 and lib.crb_sparse_conv_compact_supported(128, 64) == 0
+    # natural row order (no permutation) and an all-empty table
+    ct0 = sparse._compact(rb.nbr, None, 27)
+    assert torch.equal(ct0.to_nbr(), rb.nbr)
+    empty = torch.full((130, 27), -1, dtype=torch.int32, device=dev)
+    cte = sparse._compact(empty, None, 27)
+    assert cte.num_pairs() == 0
+    y = sparse._conv_forward_raw(torch.randn(5, 16, device=dev), torch.randn(27, 16, 16, device=dev), cte, 130)
+    assert float(y.abs().max()) == 0.0
+
+
+def test_planned_strided_chain_equals_layer_by_layer_rulebooks(dev):
+    """crbhip.sparse.strided_chain_counts (next level marked from the previous level's BITMAP, one host read-back for the
+    whole chain) + premarked rulebooks == the rulebooks built one strided layer at a time, on the geometry chain of
+    VoxelBackBone8x (k3 s2 p1, k3 s2 p1, k3 s2 p(0,1,1), k(3,1,1) s(2,1,1) p0); counts equal the oracle's"""
+    from crbhip import sparse
+    rng = np.random.default_rng(5)
+    shape = [41, 160, 144]
+    coords = random_sparse_coords(rng, 12000, 3, shape)
+    geoms = [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)),
+             ((3, 1, 1), (2, 1, 1), (0, 0, 0))]
+    c = _t(coords, dev)
+    marks = sparse.strided_chain_counts(c, shape, 3, geoms)
+    cur, cur_shape = c, shape
+    oc_np, oshape_np = coords, shape
+    for (ks, st, pd), mk in zip(geoms, marks):
+        a = sparse.spconv_rulebook(cur, cur_shape, 3, ks, st, pd)
+        b = sparse.spconv_rulebook(cur, cur_shape, 3, ks, st, pd, premarked=mk)
+        assert a.n_out == b.n_out == mk[1] and a.out_shape == b.out_shape == list(mk[2])
+        assert torch.equal(a.out_coords, b.out_coords) and torch.equal(a.nbr, b.nbr) and torch.equal(a.nbr_t, b.nbr_t)
+        oc_np, oshape_np = oracle.spconv_out(oc_np, oshape_np, ks, st, pd)
+        np.testing.assert_array_equal(b.out_coords.cpu().numpy(), oc_np)
+        cur, cur_shape = b.out_coords.contiguous(), b.out_shape
+
+
+def test_backbone_with_planned_indices_equals_unplanned(dev):
+    from pcdet.models.backbones_3d import spconv_backbone as sb
+    from pcdet.datasets import SyntheticDataset
+    from pcdet.model_cfgs import second_cfg
+    from pcdet.models import build_network
+    torch.manual_seed(0)
+    model = build_network(second_cfg().MODEL, 3, SyntheticDataset(num_frames=2)).to(dev)
+    model.eval()
+    pts, off, gt = kitti_batch(0, 2)
+    bidx = np.repeat(np.arange(2, dtype=np.float32), np.diff(off))[:, None]
+    outs = []
+    for plan in (True, False):
+        sb.PLAN_INDICES = plan
+        bd = {'points': _t(np.concatenate([bidx, pts], 1), dev), 'point_frame_offsets': _t(off, dev), 'batch_size': 2}
+        with torch.no_grad():
+            bd = model.vfe(bd)
+            bd = model.backbone_3d(bd)
+        outs.append(bd['encoded_spconv_tensor'])
+    sb.PLAN_INDICES = True
+    assert torch.equal(outs[0].indices, outs[1].indices) and torch.equal(outs[0].features, outs[1].features)
+    assert set(outs[0].indice_dict.keys()) == set(outs[1].indice_dict.keys())

@@ -87,7 +87,7 @@ def main():
         rb = sparse.subm_rulebook(coords, shape, [3, 3, 3])
         N = rb.n_out
         row('SubM rulebook L%d (hash + nbr): %d rows' % (lvl, N), t, 16 * N + 4 * 27 * N)
-        t = timeit(lambda: sparse._mask_sort(rb.nbr, 27), max(5, it // 3))
+        t = timeit(lambda: sparse._compact(rb.nbr, sparse._mask_perm(rb.nbr, 27), 27), max(5, it // 3))
         row('mask sort + tile order + permute L%d' % lvl, t, 2 * 4 * 27 * N + 12 * N)
         C = chans[lvl]
         P = int((rb.nbr >= 0).sum())

@@ -55,7 +55,7 @@ def main():
         x = torch.randn(n, cin, device=dev)
         dy = torch.randn(n, cout, device=dev)
         w = torch.randn(27, cin, cout, device=dev) / 10
-        table = rb.sorted_table('nbr')
+        table = rb.table_for('nbr', cin, cout) if not os.environ.get('CRB_NO_COMPACT') else rb.sorted_table('nbr')
         pairs = rb.pairs()
         if args.dense_random:
             g = torch.Generator(device=dev).manual_seed(0)
@@ -93,6 +93,11 @@ def main():
             ts[st_] = timeit(lambda: sparse._conv_forward_raw(x, w, table, n))
         lib.crb_sparse_conv_set_subtiles(0)
         t_f = timeit(lambda: sparse._conv_forward_raw(x, w, table, n))
+        t_fk = t_f
+        if isinstance(table, sparse.CompactTable):
+            tk_ = rb.sorted_table('nbr')
+            t_fk = timeit(lambda: sparse._conv_forward_raw(x, w, tk_, n))
+            assert torch.equal(sparse._conv_forward_raw(x, w, tk_, n), sparse._conv_forward_raw(x, w, table, n))
         t_w = timeit(lambda: sparse._conv_wgrad_raw(x, dy, pairs, 27))
         lib.crb_sparse_conv_set_wgrad_v1(1)
         t_w1 = timeit(lambda: sparse._conv_wgrad_raw(x, dy, pairs, 27))
@@ -112,7 +117,7 @@ def main():
               'wgrad %.1f us %.1f TF (%.1f%% of 157.3) [v1 kernel %.1f us, max rel diff %.1e]%s' % (
                   lvl, cin, cout, n, P, P / n, t_f, balg / t_f / 1e3, balg / t_f / 1e3 / 80, fl / t_f / 1e6, t_w,
                   fl / t_w / 1e6, fl / t_w / 1e6 / 1.573, t_w1, werr, sweep),
-              'v1/v2-noremap/v2 %.1f %.1f %.1f us' % (ts[1], ts[16], ts[8]), flush=True)
+              'v1/v2-noremap/v2 %.1f %.1f %.1f us | (n,K) table fwd %.1f us' % (ts[1], ts[16], ts[8], t_fk), flush=True)
 
 
 if __name__ == '__main__':

@@ -29,7 +29,7 @@ if __name__ == '__main__':
     P = int((rb.nbr >= 0).sum())
     x = torch.randn(n, cin, device=dev)
     w = torch.randn(27, cin, cout, device=dev) / 10
-    table = rb.sorted_table('nbr')
+    table = rb.table_for('nbr', cin, cout) if not os.environ.get('CRB_NO_COMPACT') else rb.sorted_table('nbr')
     dy = torch.randn(n, cout, device=dev)
     pairs = rb.pairs()
     torch.cuda.synchronize()

@@ -37,9 +37,25 @@ def main(path, K, marker='vox_insert'):
         a[0] += 1
         a[1] += d
     busy = sum(v[1] for v in agg.values())
+    # union of the kernel intervals (streams overlap) -> time with NO kernel running, and the largest gaps
+    iv = sorted((int(r[key_s]), int(r[key_e]), r[key_n]) for r in sel)
+    union, gaps, cur_e, cur_name = 0, [], iv[0][0], ''
+    for s0, e0, nm in iv:
+        if s0 > cur_e:
+            gaps.append((s0 - cur_e, cur_name, nm))
+            union += 0
+            cur_s = s0
+        union += max(0, e0 - max(s0, cur_e))
+        if e0 > cur_e:
+            cur_e, cur_name = e0, nm
+    idle = span_ns - union
     w = csv.writer(sys.stdout)
     w.writerow(['# steps', K, 'wall_ms_per_step', '%.3f' % (span_ns / 1e6 / K), 'kernel_busy_ms_per_step',
-                '%.3f' % (busy / 1e6 / K)])
+                '%.3f' % (busy / 1e6 / K), 'gpu_idle_ms_per_step (no kernel on any stream)', '%.3f' % (idle / 1e6 / K),
+                'gaps_over_20us_per_step', '%.1f' % (sum(1 for g in gaps if g[0] > 20000) / K)])
+    if os.environ.get('PROF_GAPS'):
+        for g in sorted(gaps, reverse=True)[:int(os.environ['PROF_GAPS'])]:
+            w.writerow(['# gap_us', '%.1f' % (g[0] / 1e3), 'after', g[1][:70], 'before', g[2][:70]])
     w.writerow(['kernel', 'calls_per_step', 'avg_us', 'ms_per_step', 'pct_of_busy'])
     for name, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         w.writerow([name[:160], '%.2f' % (n / K), '%.2f' % (t / n / 1e3), '%.4f' % (t / 1e6 / K), '%.2f' % (100.0 * t / busy)])
