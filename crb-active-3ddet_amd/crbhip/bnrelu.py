@@ -7,6 +7,72 @@ from ._lib import lib, check, ptr, cur_stream, require_cuda
 FUSE_RUNNING = __import__('os').environ.get('CRB_BN_FUSE_RUNNING', '1') == '1'
 
 
+# ---- per-frame statistics ------------------------------------------------------------------------------------------
+# CRB stage 2 runs the detector in train mode on ONE frame at a time (crb_sampling.py:174-212): every BatchNorm layer
+# normalises with that frame's own statistics. To batch G frames per pass with the same values, the training-mode entry
+# points below split their rows into the frames' row ranges and run the SAME kernels once per range while a `frame_groups`
+# context is active (ranges: G equal parts, or the offsets noted for a tensor whose rows are ragged per frame — sparse
+# voxel features). Running statistics are updated once per range, in frame order, exactly like G separate passes.
+_GROUPS = None
+
+
+class frame_groups(object):
+    def __init__(self, G):
+        self.G = int(G)
+        self.ragged = {}
+
+    def __enter__(self):
+        global _GROUPS
+        self.prev, _GROUPS = _GROUPS, self
+        return self
+
+    def __exit__(self, *exc):
+        global _GROUPS
+        _GROUPS = self.prev
+        return False
+
+    def note_rows(self, t, offsets):
+        """rows of tensor t belong to the frames by these G+1 host offsets (not G equal parts)"""
+        if offsets is not None:
+            assert len(offsets) == self.G + 1 and offsets[-1] == t.shape[0], (len(offsets), offsets[-1], t.shape)
+            self.ragged[t.data_ptr()] = [int(v) for v in offsets]
+
+    def offsets(self, t, n_units=None):
+        """row ranges of t per frame; n_units: t has this many equal units per row block (rows = units * k)"""
+        r = self.ragged.get(t.data_ptr())
+        if r is not None and r[-1] == t.shape[0]:             # (the allocator may hand a noted tensor's address to a later one)
+            return r
+        n = t.shape[0]
+        if n % self.G:
+            raise ValueError('%d rows do not split into %d frames: note_rows() the ragged offsets first' % (n, self.G))
+        return [g * (n // self.G) for g in range(self.G + 1)]
+
+
+def active_groups():
+    return _GROUPS
+
+
+def _frames_forward(x, off, bn, relu, out=None, col=0):
+    """no-grad training BatchNorm(+ReLU) of x (n,C) with per-frame statistics (row ranges `off`), one C-ABI call; written
+    into columns [col, col+C) of `out` (n, W) when given"""
+    import ctypes
+    x = x.contiguous()
+    n, C = x.shape
+    z = torch.empty_like(x) if out is None else out
+    ld = 0 if out is None else out.shape[1]
+    arr = (ctypes.c_int64 * len(off))(*[int(v) for v in off])
+    wsb = lib.crb_bn_frames_workspace_bytes(max(b - a for a, b in zip(off[:-1], off[1:])), C)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+    with torch.no_grad():
+        bn.num_batches_tracked += len(off) - 1
+    zp = ctypes.c_void_p(z.data_ptr() + 4 * col)
+    check(lib.crb_bn_relu_forward_frames(ptr(x), len(off) - 1, arr, C, ptr(bn.weight.contiguous().float()),
+                                         ptr(bn.bias.contiguous().float()), float(bn.eps), int(relu), zp, ld,
+                                         ptr(bn.running_mean), ptr(bn.running_var), float(bn.momentum), ptr(ws), wsb,
+                                         cur_stream(x.device)), 'crb_bn_relu_forward_frames')
+    return z
+
+
 def supported(x, bn):
     C = x.shape[1]
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 2 and C % 4 == 0 and
@@ -55,6 +121,12 @@ def bn_relu(x, bn, relu=True):
     """x (N,C) cuda f32; bn: nn.BatchNorm1d. Same semantics as relu(bn(x)) incl. the running-statistics update
     (momentum, unbiased running variance, num_batches_tracked)."""
     n, C = x.shape
+    if bn.training and _GROUPS is not None and _GROUPS.G > 1:
+        off, grp = _GROUPS.offsets(x), _GROUPS
+        if not torch.is_grad_enabled() and bn.momentum is not None and min(b - a for a, b in zip(off[:-1], off[1:])) >= 2:
+            return _frames_forward(x, off, bn, relu)
+        with frame_groups(1):
+            return torch.cat([bn_relu(x[a:b], bn, relu) for a, b in zip(off[:-1], off[1:]) if b > a], 0)
     if bn.training:
         with torch.no_grad():
             bn.num_batches_tracked += 1
@@ -168,6 +240,18 @@ class _BNReLUConcatTrain(torch.autograd.Function):
 def bn_relu_concat(xs, bns, relu=True):
     """training-mode relu(bn_i(x_i)) for row matrices x_i (n, C_i), concatenated along the channel axis -> (n, sum C_i).
     Every bn must be in training mode with a momentum (running statistics are updated in the forward launch)."""
+    if _GROUPS is not None and _GROUPS.G > 1:
+        off = _GROUPS.offsets(xs[0])
+        if not torch.is_grad_enabled():
+            total = sum(x.shape[1] for x in xs)
+            out = torch.empty((xs[0].shape[0], total), dtype=torch.float32, device=xs[0].device)
+            col = 0
+            for x, bn in zip(xs, bns):
+                _frames_forward(x, off, bn, relu, out, col)
+                col += x.shape[1]
+            return out
+        with frame_groups(1):
+            return torch.cat([bn_relu_concat([x[a:b] for x in xs], bns, relu) for a, b in zip(off[:-1], off[1:])], 0)
     args = []
     for x, bn in zip(xs, bns):
         with torch.no_grad():
@@ -242,6 +326,35 @@ class _BNReLUMaxConcatTrain(torch.autograd.Function):
 def bn_relu_max_concat(xs, nss, bns):
     """training-mode max over groups of nss[i] rows of relu(bn_i(x_i)), concatenated along the channel axis -> (M, sum C_i);
     every bn in training mode with a momentum (running statistics are updated in the forward launch)"""
+    if _GROUPS is not None and _GROUPS.G > 1:
+        G = _GROUPS.G
+        M = xs[0].shape[0] // int(nss[0])
+        assert M % G == 0, 'query points must come in equal numbers per frame'
+        m = M // G
+        if not torch.is_grad_enabled():
+            import ctypes
+            total = sum(x.shape[1] for x in xs)
+            out = torch.empty((M, total), dtype=torch.float32, device=xs[0].device)
+            col = 0
+            for x, ns, bn in zip(xs, nss, bns):
+                x = x.contiguous()
+                C = x.shape[1]
+                arg = torch.empty((M, C), dtype=torch.int32, device=x.device)
+                wsb = lib.crb_bn_frames_workspace_bytes(m * int(ns), C)
+                ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+                with torch.no_grad():
+                    bn.num_batches_tracked += G
+                check(lib.crb_bn_relu_max_forward_frames(ptr(x), G, m, int(ns), C, ptr(bn.weight.contiguous().float()),
+                                                         ptr(bn.bias.contiguous().float()), float(bn.eps),
+                                                         ctypes.c_void_p(out.data_ptr() + 4 * col), total, ptr(arg),
+                                                         ptr(bn.running_mean), ptr(bn.running_var), float(bn.momentum),
+                                                         ptr(ws), wsb, cur_stream(x.device)),
+                      'crb_bn_relu_max_forward_frames')
+                col += C
+            return out
+        with frame_groups(1):
+            return torch.cat([bn_relu_max_concat([x[g * m * int(ns):(g + 1) * m * int(ns)] for x, ns in zip(xs, nss)], nss, bns)
+                              for g in range(G)], 0)
     args = []
     for x, ns, bn in zip(xs, nss, bns):
         with torch.no_grad():

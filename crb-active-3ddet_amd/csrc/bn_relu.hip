@@ -375,3 +375,54 @@ extern "C" int crb_bn_relu_max_backward(const float* x, const float* gz, int64_t
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-frame statistics: the same launches once per row range of a frame (frame_row_offsets: HOST int64[n_frames+1]) — what
+// n_frames separate train-mode passes of one frame each compute (batched CRB stage 2: every frame normalises with its own
+// statistics, crb_sampling.py:174-212). The loop lives here so that a BatchNorm layer of a 16-frame pass costs one call from
+// the host language instead of 16. The batch statistics themselves are scratch (first 3*C floats of the workspace);
+// running statistics are updated once per frame, in frame order. workspace: crb_bn_frames_workspace_bytes(max rows, C).
+extern "C" int64_t crb_bn_frames_workspace_bytes(int64_t max_rows_per_frame, int C) {
+  return crb_bn_workspace_bytes(max_rows_per_frame, C) + (int64_t)crb_align_up(3 * C * (int64_t)sizeof(float), 256);
+}
+
+extern "C" int crb_bn_relu_forward_frames(const float* x, int n_frames, const int64_t* frame_row_offsets, int C,
+                                          const float* gamma, const float* beta, float eps, int relu, float* z,
+                                          int64_t z_row_stride, float* running_mean, float* running_var, float momentum,
+                                          void* workspace, int64_t workspace_bytes, void* stream) {
+  if (n_frames <= 0 || !frame_row_offsets) return CRB_ERR_ARG;
+  const int64_t ld_z = z_row_stride > 0 ? z_row_stride : C;
+  const int64_t head = crb_align_up(3 * C * (int64_t)sizeof(float), 256);
+  float* stats = (float*)workspace;
+  for (int f = 0; f < n_frames; ++f) {
+    const int64_t a = frame_row_offsets[f], b = frame_row_offsets[f + 1];
+    if (b <= a) continue;
+    if (b - a < 2) return CRB_ERR_ARG;                       // a one-row batch has no variance (nn.BatchNorm raises too)
+    int rc = crb_bn_relu_forward(x + a * C, b - a, C, gamma, beta, eps, relu, z + a * ld_z, ld_z, stats, stats + C,
+                                 stats + 2 * C, running_mean, running_var, momentum, (char*)workspace + head,
+                                 workspace_bytes - head, stream);
+    if (rc != CRB_OK) return rc;
+  }
+  return CRB_OK;
+}
+
+// the StackSAModuleMSG tail (BatchNorm + ReLU + max over nsample) with per-frame statistics: every frame owns
+// groups_per_frame consecutive query points
+extern "C" int crb_bn_relu_max_forward_frames(const float* x, int n_frames, int64_t groups_per_frame, int ns, int C,
+                                              const float* gamma, const float* beta, float eps, float* zmax,
+                                              int64_t out_row_stride, int32_t* arg, float* running_mean, float* running_var,
+                                              float momentum, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (n_frames <= 0 || groups_per_frame <= 0) return CRB_ERR_ARG;
+  const int64_t ld = out_row_stride > 0 ? out_row_stride : C;
+  const int64_t head = crb_align_up(3 * C * (int64_t)sizeof(float), 256);
+  float* stats = (float*)workspace;
+  for (int f = 0; f < n_frames; ++f) {
+    const int64_t g0 = (int64_t)f * groups_per_frame;
+    int rc = crb_bn_relu_max_forward(x + g0 * ns * C, groups_per_frame, ns, C, gamma, beta, eps, zmax + g0 * ld, ld,
+                                     arg + g0 * C, stats, stats + C, stats + 2 * C, running_mean, running_var, momentum,
+                                     (char*)workspace + head, workspace_bytes - head, stream);
+    if (rc != CRB_OK) return rc;
+  }
+  return CRB_OK;
+}
+

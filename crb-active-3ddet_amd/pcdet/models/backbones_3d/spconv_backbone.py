@@ -64,7 +64,9 @@ class _Backbone8xBase(nn.Module):
                                     spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
         if PLAN_INDICES:
             # all rulebooks first: one host read-back for the four strided output sets instead of a sync per strided layer
-            plan_indices([self.conv_input, self.conv1, self.conv2, self.conv3, self.conv4, self.conv_out], x)
+            from crbhip import bnrelu
+            plan_indices([self.conv_input, self.conv1, self.conv2, self.conv3, self.conv4, self.conv_out], x,
+                         with_frame_offsets=bnrelu.active_groups() is not None)
         x = self.conv_input(x)
         x1 = self.conv1(x)
         x2 = self.conv2(x1)

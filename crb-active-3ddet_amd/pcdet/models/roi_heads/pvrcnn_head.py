@@ -144,16 +144,17 @@ class PVRCNNHead(RoIHeadTemplate):
         targets_dict = self.proposal_layer(batch_dict,
                                            nms_config=self.model_cfg.NMS_CONFIG['TRAIN' if self.training else 'TEST'])
         if self.training:
-            targets_dict = batch_dict.get('roi_targets_dict', None)
+            targets_dict = batch_dict.get('roi_targets_dict', None)        # injected RoI sample (tests / measurements)
             if targets_dict is None:
                 targets_dict = self.assign_targets(batch_dict)
-                batch_dict['rois'] = targets_dict['rois']
-                batch_dict['roi_labels'] = targets_dict['roi_labels']
+            batch_dict['rois'] = targets_dict['rois']
+            batch_dict['roi_labels'] = targets_dict['roi_labels']
         pooled = self.roi_grid_pool(batch_dict)                                   # (BN, G^3, C)
         n = pooled.shape[0]
-        pooled_flat = pooled.permute(0, 2, 1).contiguous().view(n, -1, 1)          # (BN, C*G^3, 1)
         fast = (not self.training) and (not torch.is_grad_enabled()) and \
             not any(m.training for m in self.modules() if isinstance(m, nn.BatchNorm1d))
+        # the reference's channel-major flattening (a 226 MB copy at bs=16) is only needed off the fast path
+        pooled_flat = None if fast else pooled.permute(0, 2, 1).contiguous().view(n, -1, 1)          # (BN, C*G^3, 1)
         if fast:
             rounds = self.model_cfg.get('SAMPLING_ROUND', None) or 1
             passes = self._heads_eval(pooled, rounds)

@@ -73,7 +73,8 @@ class RoIHeadTemplate(nn.Module):
     def assign_targets(self, batch_dict):
         batch_size = batch_dict['batch_size']
         with torch.no_grad():
-            targets_dict = self.proposal_target_layer.forward(batch_dict)
+            # optional injected uniforms (u_perm (B,R), u_slot (B,P)): the batched CRB stage 2 draws them frame by frame
+            targets_dict = self.proposal_target_layer.forward(batch_dict, batch_dict.get('roi_sampler_uniforms', None))
         rois = targets_dict['rois']
         gt = targets_dict['gt_of_rois']
         targets_dict['gt_of_rois_src'] = gt.clone().detach()

@@ -30,6 +30,12 @@ class CRBSampling(Strategy):
         self.bandwidth = getattr(ac, 'BANDWDITH', 5)
         self.prototype = getattr(ac, 'CLUSTERING', 'kmeans++')
         self.frame_seed = getattr(ac, 'FRAME_SEED', None)
+        # frames per stage-2 pass: 1 = the reference's loop of bs=1 training-mode passes; > 1 = the same per-frame quantities
+        # (per-frame BatchNorm statistics, per-frame RoI sampling and loss) computed for that many frames at once
+        self.stage2_batch = int(getattr(ac, 'STAGE2_BATCH', 16))
+        self.keep_stage2_targets = False   # tests: keep every frame's sampled RoI targets of the batched stage 2
+        self.last_stage2_targets = []
+        self.profile_stage2 = False        # measurement: split the stage-2 time into waiting for frames / device passes
         self.alpha = 0.95
         self.timings = {}
 
@@ -173,7 +179,7 @@ class CRBSampling(Strategy):
             yield from frames(prev)
 
     # ---------------------------------------------------------------- stage 2
-    def grad_embeddings(self, frame_indices, records):
+    def grad_embeddings(self, frame_indices, records, roi_targets=None):
         """per-frame gradient of roi_head.shared_fc_layer[4].weight under the stage-1 hypothetical labels
         (crb_sampling.py:174-212). -> (len(frame_indices), 65536) device tensor"""
         # NOTE (deliberate departure): the reference builds the stage-2 loader with training=True, i.e. the frames go
@@ -190,6 +196,8 @@ class CRBSampling(Strategy):
                 # opt-in (ACTIVE_CONFIG.FRAME_SEED): the RoI sampler / dropout stream of a frame depends on the frame only,
                 # not on which rank processes it after which other frames -> the selection is independent of the world size
                 torch.manual_seed(int(self.frame_seed) + int(i))
+            if roi_targets is not None:                # measurement / tests: the RoI sample of this frame is given
+                batch['roi_targets_dict'] = roi_targets[k]
             loss = self.frame_loss(i, rec['rcnn_cls'][k], rec['rcnn_reg'][k], batch=batch)
             if self.PRUNED_BACKWARD:
                 # the embedding is d loss / d shared_fc_layer[4].weight only: autograd walks loss -> cls/reg layers -> FC stack
@@ -203,6 +211,101 @@ class CRBSampling(Strategy):
                 loss.backward()
                 out.append(w.grad.detach().reshape(-1).clone())
         return torch.stack(out, 0) if out else torch.zeros((0, w.numel()), device=w.device)
+
+    def grad_embeddings_batched(self, frame_indices, records, group=16):
+        """grad_embeddings with `group` frames per pass instead of one (SURVEY §7 step 7 / finding 11).
+
+        Per frame the reference's quantities are kept: every BatchNorm layer of the train-mode detector normalises with the
+        frame's OWN statistics (pcdet/utils/frame_bn.py), RoIs are sampled per frame, the loss of a frame is the mean over its
+        128 RoIs (crb_sampling.py:194-196). The gradient of shared_fc_layer[4].weight of frame b is taken analytically:
+        that layer is a 1x1 Conv1d, so dL_b/dW = sum over the frame's RoIs of delta_r (x) a_r with a = the layer's input and
+        delta = dL/d(output); since L = sum_b L_b and the layers after it only mix rows of one frame (per-frame BatchNorm),
+        one autograd.grad of the batch's summed loss w.r.t. the layer's OUTPUT gives every frame its own delta.
+        Nothing before the RoI head's FC stack is differentiated (as with PRUNED_BACKWARD). -> (len, 65536) device tensor"""
+        from ..utils.frame_bn import per_frame_batchnorm
+        model = self.detector
+        head = model.roi_head
+        rec = scoring.unpack_records(records, self.layout)
+        model.train()
+        conv = head.shared_fc_layer[4]
+        w = conv.weight
+        out = []
+        pos = 0
+        t_wait = t_comp = 0.0
+        t_mark = time.perf_counter()
+        # a short last pass would be a new batch size for every dense layer (MIOpen searches its solvers again for each new
+        # convolution shape: ~1 s): pad it with repeats of the last frame and drop their rows afterwards
+        n_real = len(frame_indices)
+        frame_indices = list(frame_indices)
+        if n_real > group and n_real % group:
+            pad = group - n_real % group
+            frame_indices = frame_indices + [frame_indices[-1]] * pad
+            records = torch.cat([records, records[-1:].expand(pad, -1)], 0)
+            rec = scoring.unpack_records(records, self.layout)
+        for batch in self.upload_pool_batches(frame_indices, group):
+            if self.profile_stage2:
+                torch.cuda.synchronize()
+                t_wait += time.perf_counter() - t_mark
+                t_mark = time.perf_counter()
+            G = int(batch['batch_size'])
+            idx = frame_indices[pos:pos + G]
+            if self.frame_seed is not None:                 # the RoI sampler's uniforms of a frame depend on the frame only
+                cfg_t = head.proposal_target_layer.roi_sampler_cfg
+                R = head.model_cfg.NMS_CONFIG.TRAIN.NMS_POST_MAXSIZE
+                up, us = [], []
+                for i in idx:
+                    torch.manual_seed(int(self.frame_seed) + int(i))
+                    up.append(torch.rand((1, R), device=w.device))
+                    us.append(torch.rand((1, cfg_t.ROI_PER_IMAGE), device=w.device))
+                batch['roi_sampler_uniforms'] = (torch.cat(up, 0), torch.cat(us, 0))
+            captured = {}
+
+            def hook(mod, inp, outp):
+                captured['a'], captured['z'] = inp[0], outp
+            with per_frame_batchnorm(model, G):
+                with torch.no_grad():
+                    if getattr(model, 'pfe', None) is not None and hasattr(model.pfe, 'prefetch_keypoints'):
+                        model.pfe.prefetch_keypoints(batch)
+                    for mod in model.module_list:
+                        if mod is head:
+                            break
+                        batch = mod(batch)
+                    batch = dict(batch)
+                    head.proposal_layer(batch, nms_config=head.model_cfg.NMS_CONFIG['TRAIN'])
+                    targets = head.assign_targets(batch)
+                    batch['rois'], batch['roi_labels'] = targets['rois'], targets['roi_labels']
+                    if self.keep_stage2_targets:
+                        self.last_stage2_targets += [{k2: (v[b:b + 1].clone() if torch.is_tensor(v) else v)
+                                                      for k2, v in targets.items()} for b in range(G)]
+                    pooled = head.roi_grid_pool(batch)                                    # (G*128, 216, C)
+                n = pooled.shape[0]
+                pooled_flat = pooled.permute(0, 2, 1).contiguous().view(n, -1, 1)
+                h = conv.register_forward_hook(hook)
+                try:
+                    shared, rcnn_cls, rcnn_reg = head._heads(pooled_flat)                 # the only differentiated part
+                finally:
+                    h.remove()
+            P = n // G
+            # sum over the frames of (mean BCE over the frame's P RoIs + mean smooth-L1 over its P x 7 targets): every frame has
+            # the same P, so this is G times the means over all rows — two loss calls for the whole pass instead of 2 G
+            k0 = pos
+            lab = rec['rcnn_cls'][k0:k0 + G, :P].reshape(G * P, 1)
+            tgt = rec['rcnn_reg'][k0:k0 + G, :P].reshape(G * P, -1)
+            cls_loss, _ = head.get_box_cls_layer_loss({'rcnn_cls': rcnn_cls, 'rcnn_cls_labels': lab})
+            reg_loss = head.get_box_reg_layer_loss({'rcnn_reg': rcnn_reg, 'reg_sample_targets': tgt})
+            total = float(G) * (cls_loss + reg_loss.mean())
+            delta, = torch.autograd.grad(total, captured['z'])                            # (G*P, 256, 1)
+            a = captured['a'].detach()
+            emb = torch.einsum('gpk,gpj->gkj', delta.reshape(G, P, -1), a.reshape(G, P, -1))
+            out.append(emb.reshape(G, -1))
+            pos += G
+            if self.profile_stage2:
+                torch.cuda.synchronize()
+                t_comp += time.perf_counter() - t_mark
+                t_mark = time.perf_counter()
+        if self.profile_stage2:
+            self.timings['stage2_wait_for_frames_s'], self.timings['stage2_passes_s'] = t_wait, t_comp
+        return torch.cat(out, 0)[:n_real] if out else torch.zeros((0, w.numel()), device=w.device)
 
     # ---------------------------------------------------------------- stage 3
     def density_balance(self, cand_records, all_records, select_nums, num_class):
@@ -239,7 +342,11 @@ class CRBSampling(Strategy):
         # Stage 2
         t1 = time.time()
         mine2, _ = scoring.shard_indices(len(stage2_idx), rank, world)
-        emb_local = self.grad_embeddings([stage2_idx[j] for j in mine2], records[[stage2_idx[j] for j in mine2]])
+        idx2 = [stage2_idx[j] for j in mine2]
+        if self.stage2_batch > 1:
+            emb_local = self.grad_embeddings_batched(idx2, records[idx2], self.stage2_batch)
+        else:
+            emb_local = self.grad_embeddings(idx2, records[idx2])
         emb = scoring.all_gather_rows(emb_local, len(stage2_idx), world)
         torch.cuda.synchronize()
         self.timings['stage2_embed_s'] = time.time() - t1

@@ -9,6 +9,7 @@ from torch import nn
 from torch.nn import init
 
 from crbhip import sparse as _sp
+from crbhip import bnrelu as _bnrelu
 from .core import SparseConvTensor
 from .modules import SparseModule
 
@@ -123,6 +124,15 @@ class SparseConvolution(SparseModule):
             out_indices, out_shape = out_indices3, out_shape3
         out = SparseConvTensor(out_feats, out_indices, out_shape, input.batch_size, input.grid, input.voxel_num,
                                input.indice_dict, input.benchmark)
+        if self.inverse:
+            out.frame_offsets = getattr(rb, 'in_frame_offsets', None)
+        elif self.subm:
+            out.frame_offsets = input.frame_offsets
+        else:
+            out.frame_offsets = getattr(rb, 'out_frame_offsets', None)
+        grp = _bnrelu.active_groups()
+        if grp is not None and out.frame_offsets is not None:
+            grp.note_rows(out_feats, out.frame_offsets)             # a BatchNorm called on these rows finds their frames
         return out
 
 
@@ -160,7 +170,7 @@ class SparseConv2d(SparseConvolution):
                          indice_key=indice_key)
 
 
-def plan_indices(modules, input):
+def plan_indices(modules, input, with_frame_offsets=False):
     """Build the rulebooks of every (non 1x1, non inverse) SparseConvolution found in `modules` (in module order, as the
     forward pass will meet them) BEFORE the first feature kernel runs, and leave them in input.indice_dict under their
     indice_key. The active sets depend on the coordinates only, so the whole chain of strided output sets is marked and
@@ -200,4 +210,23 @@ def plan_indices(modules, input):
             input.indice_dict[key] = rb
         if not m.subm:
             idx, shape = rb.out_coords, list(rb.out_shape)
+    if with_frame_offsets:
+        # rows per frame of the input and of every strided level (sparse rows are frame-sorted): ONE read-back. Used by the
+        # per-frame BatchNorm of batched CRB stage 2 (crbhip.bnrelu.frame_groups).
+        import torch
+        B = input.batch_size
+        levels = [('in', input.indices)] + [(m.indice_key, input.indice_dict[m.indice_key].out_coords)
+                                            for m in convs if not m.subm]
+        counts = torch.zeros((len(levels), B), dtype=torch.int64, device=input.indices.device)
+        for k, (_, c) in enumerate(levels):
+            if c.shape[0]:
+                counts[k].scatter_add_(0, c[:, 0].long(), torch.ones((c.shape[0],), dtype=torch.int64, device=c.device))
+        host = counts.cpu().tolist()
+        offs = [[0] + [sum(row[:k + 1]) for k in range(B)] for row in host]
+        input.frame_offsets = offs[0]
+        prev = offs[0]
+        for (key, _), o in zip(levels[1:], offs[1:]):
+            input.indice_dict[key].in_frame_offsets = prev
+            input.indice_dict[key].out_frame_offsets = o
+            prev = o
     return input

@@ -20,6 +20,7 @@ class SparseConvTensor(object):
         self.grid = grid
         self.voxel_num = voxel_num
         self.benchmark = benchmark
+        self.frame_offsets = None          # host row offsets per frame (B+1), set by plan_indices(with_frame_offsets=True)
 
     @property
     def features(self):
@@ -34,6 +35,7 @@ class SparseConvTensor(object):
     def replace_feature(self, feature):
         new = SparseConvTensor(feature, self.indices, self.spatial_shape, self.batch_size, self.grid, self.voxel_num,
                                self.indice_dict, self.benchmark)
+        new.frame_offsets = self.frame_offsets
         return new
 
     @property

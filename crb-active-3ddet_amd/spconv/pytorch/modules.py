@@ -67,6 +67,9 @@ class SparseSequential(SparseModule):
                     feats = input.features
                     if (FUSE_BN_RELU and isinstance(module, nn.BatchNorm1d) and i + 1 < len(mods) and
                             isinstance(mods[i + 1], nn.ReLU) and _bnrelu.supported(feats, module)):
+                        grp = _bnrelu.active_groups()
+                        if grp is not None and module.training:
+                            grp.note_rows(feats, input.frame_offsets)        # sparse rows are ragged per frame
                         input = input.replace_feature(_bnrelu.bn_relu(feats, module, relu=True))
                         i += 1                      # the ReLU module was consumed by the fused op
                     else:

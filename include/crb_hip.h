@@ -362,6 +362,19 @@ int crb_bn_relu_max_backward(const float* x, const float* gz, int64_t gz_row_str
                              int ns, int C, const float* mean, const float* invstd, const float* gamma, const float* beta,
                              float* dx, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
                              void* stream);
+/* Per-frame statistics (batched CRB stage 2: G frames per train-mode pass, every BatchNorm layer normalising each frame
+ * with that frame's own batch statistics like G bs=1 passes, crb_sampling.py:174-212): the forward launches above once per
+ * frame row range. frame_row_offsets is a HOST int64[n_frames+1] array; the batch statistics are scratch, running
+ * statistics are updated once per frame in frame order. Forward only (stage 2 differentiates the RoI-head FC stack only). */
+int64_t crb_bn_frames_workspace_bytes(int64_t max_rows_per_frame, int C);
+int crb_bn_relu_forward_frames(const float* x, int n_frames, const int64_t* frame_row_offsets, int C, const float* gamma,
+                               const float* beta, float eps, int relu, float* z, int64_t z_row_stride,
+                               float* running_mean, float* running_var, float momentum, void* workspace,
+                               int64_t workspace_bytes, void* stream);
+int crb_bn_relu_max_forward_frames(const float* x, int n_frames, int64_t groups_per_frame, int ns, int C,
+                                   const float* gamma, const float* beta, float eps, float* zmax, int64_t out_row_stride,
+                                   int32_t* arg, float* running_mean, float* running_var, float momentum, void* workspace,
+                                   int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a10  anchor target assignment (nearest-BEV IoU + thresholds + residual box encoding)

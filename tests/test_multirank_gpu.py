@@ -37,10 +37,12 @@ def _crb_worker(rank, world, port, out_dir):
     cfg.ACTIVE_TRAIN.ACTIVE_CONFIG.K1 = 4            # 8 frames get gradient embeddings (4 per rank at world 2)
     cfg.ACTIVE_TRAIN.ACTIVE_CONFIG.K2 = 2
     cfg.ACTIVE_TRAIN.ACTIVE_CONFIG.FRAME_SEED = 1234
-    cfg.MODEL.ROI_HEAD.DP_RATIO = 0.0                # deterministic scoring: MC dropout is the identity
     torch.manual_seed(0)
     pool = SyntheticDataset(num_frames=11, first_frame=2100)          # 11 frames / 2 ranks: one wrap-around pad
     model = build_network(cfg.MODEL, 3, pool).to(dev)
+    for m in model.modules():                        # deterministic scoring: MC dropout becomes the identity (the layers
+        if isinstance(m, torch.nn.Dropout):          # stay in place: shared_fc_layer[4] must remain the second conv)
+            m.p = 0.0
     with torch.no_grad():
         model.roi_head.cls_layers[-1].bias.fill_(1.0)
     strat = build_strategy('crb', model, build_synthetic_dataloader(SyntheticDataset(num_frames=2), 2),

@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--clustering', default='kmeans++', choices=['kmeans++', 'kmeans++_device'])
     ap.add_argument('--workers', type=int, default=16, help='DataLoader workers of the unlabelled pool loader')
+    ap.add_argument('--stage2-batch', type=int, default=16, help='frames per stage-2 pass (1 = the reference loop of bs=1 passes)')
     a = ap.parse_args()
     from pcdet.datasets import SyntheticDataset, build_synthetic_dataloader
     from pcdet.model_cfgs import pv_rcnn_cfg
@@ -29,6 +30,7 @@ def main():
     cfg = pv_rcnn_cfg()
     cfg.ACTIVE_TRAIN.SELECT_NUMS = a.select
     cfg.ACTIVE_TRAIN.ACTIVE_CONFIG.CLUSTERING = a.clustering
+    cfg.ACTIVE_TRAIN.ACTIVE_CONFIG.STAGE2_BATCH = a.stage2_batch
     torch.manual_seed(0)
     pool = SyntheticDataset(num_frames=a.pool, first_frame=2000)
     model = build_network(cfg.MODEL, 3, pool).to(dev)
@@ -37,7 +39,11 @@ def main():
     strat.score_pool(list(range(2 * a.batch)), a.batch)                       # warm-up: MIOpen solver search, caches
     rec = strat.score_pool(list(range(4)), a.batch)
     strat.grad_embeddings(list(range(4)), rec)
+    if a.stage2_batch > 1:
+        rec = strat.score_pool(list(range(a.stage2_batch)), a.batch)
+        strat.grad_embeddings_batched(list(range(a.stage2_batch)), rec, a.stage2_batch)
     torch.cuda.synchronize()
+    strat.profile_stage2 = bool(os.environ.get('CRB_STAGE2_TIMING'))
     t0 = time.perf_counter()
     picked = strat.query()
     torch.cuda.synchronize()
@@ -47,8 +53,10 @@ def main():
            'selected': len(picked), 'loader_workers': a.workers, 'stage1_s': round(t['stage1_s'], 3),
            'stage1_frames_per_s': round(a.pool / t['stage1_s'], 1),
            'stage2_s': round(t['stage2_s'], 3), 'stage2_grad_embeddings_s': round(t['stage2_embed_s'], 3),
-           'clustering': a.clustering, 'stage2_kmeanspp_s': round(t['stage2_s'] - t['stage2_embed_s'], 3),
+           'clustering': a.clustering, 'stage2_batch': a.stage2_batch, 'stage2_kmeanspp_s': round(t['stage2_s'] - t['stage2_embed_s'], 3),
            'stage3_s': round(t['stage3_s'], 4), 'round_s': round(total, 3),
+           'stage2_wait_for_frames_s': round(t.get('stage2_wait_for_frames_s', -1), 3),
+           'stage2_passes_s': round(t.get('stage2_passes_s', -1), 3),
            'data': 'synthetic KITTI-shaped frames, generated on the host by the pool loader\'s workers inside the stage times'}
     print(json.dumps(out))
 
