@@ -242,13 +242,27 @@ def crb_scoring_bench(args, rank, world, device):
                 yield b
         return strat.stage1(device_batches=gen())
     rec, dt_loader = timed(loader_pass)
-    strat.close()
     times = []
     for _ in range(max(1, args.scoring_repeats)):
         rec, dt = timed(lambda: strat.stage1(device_batches=kept))
         times.append(dt)
     med = float(np.median(times))
     assert rec.shape[0] == n and len(strat.bbox_records) == n
+    # the rest of one selection round at the reference's KITTI budget (SURVEY §8d metric 2: K1 N = 500 frames get gradient
+    # embeddings — 16 frames per train-mode pass with per-frame BatchNorm statistics, frames re-read through the loader —
+    # k-means++ to K2 N = 300 prototypes with the device restatement of sklearn's seeding, greedy KDE balance to N = 100)
+    strat.prototype = 'kmeans++_device'
+    warm = strat.score_pool(mine[:bs], bs)
+    strat.grad_embeddings_batched(mine[:bs], warm, strat.stage2_batch)          # MIOpen train-mode solver search
+    _, dt_sel = timed(lambda: strat.select_from_records(rec))
+    strat.close()
+    sel_round = {'stage2_s': round(strat.timings['stage2_s'], 3),
+                 'stage2_grad_embeddings_s': round(strat.timings['stage2_embed_s'], 3),
+                 'stage3_s': round(strat.timings['stage3_s'], 4), 'stages_2_3_s': round(dt_sel, 3),
+                 'round_s_with_resident_stage1': round(med + dt_sel, 3),
+                 'K1N': min(strat.k1 * cfg.ACTIVE_TRAIN.SELECT_NUMS, n), 'K2N': min(strat.k2 * cfg.ACTIVE_TRAIN.SELECT_NUMS, n),
+                 'N': cfg.ACTIVE_TRAIN.SELECT_NUMS, 'stage2_frames_per_pass': strat.stage2_batch,
+                 'clustering': 'kmeans++_device (same picks as sklearn kmeans_plusplus(random_state=0) in the tests)'}
     return {'metric': 'frames/s CRB stage-1 acquisition scoring (PV-RCNN eval, 5 MC-dropout passes, records incl. GT '
                       'statistics, all-gather, per-frame bookkeeping)',
             'value': round(n / med, 3), 'unit': 'frames/s',
@@ -260,6 +274,7 @@ def crb_scoring_bench(args, rank, world, device):
                                'loader_workers': workers,
                                'note': 'one pass, frames generated + collated by the loader workers and uploaded inside '
                                        'the timed region'},
+            'selection_round': sel_round,
             'record_bytes_per_frame': 4 * strat.layout.stride, 'boxes_kept_total': int(rec[:, 1].sum().item())}
 
 

@@ -319,20 +319,12 @@ class CRBSampling(Strategy):
         return order, scores
 
     # ---------------------------------------------------------------- query
-    def query(self, leave_pbar=True, cur_epoch=None):
+    def select_from_records(self, records):
+        """stages 2 and 3 on the gathered stage-1 records of the whole pool -> picked pool indices (all ranks the same)"""
         rank, world = self._world()
-        ds = self.unlabelled_set
-        frame_ids = [p[0] for p in self.pairs]
-        n = len(frame_ids)
+        n = records.shape[0]
         select_nums = self.cfg.ACTIVE_TRAIN.SELECT_NUMS
         num_class = len(self.labelled_loader.dataset.class_names)
-        bs = self.unlabelled_loader.batch_size or 1
-        t0 = time.time()
-        # Stage 1 (the caller runs save_active_labels(selected_frames=...) right after query(),
-        # active_training_utils.py:270-273: stage1() has recorded the GT statistics of every pool frame by then)
-        records = self.stage1()
-        torch.cuda.synchronize()
-        self.timings['stage1_s'] = time.time() - t0
         entropy = records[:, 0]
         k1n = min(int(self.k1 * select_nums), n)
         # sort ascending (stable) then take from the end, like sorted(dict.items())[::-1][:K1*N] (crb_sampling.py:118-121)
@@ -367,5 +359,16 @@ class CRBSampling(Strategy):
         picked = [cand_idx[i] for i in order3.cpu().tolist() if i >= 0]
         self.timings['stage3_s'] = time.time() - t2
         self.detector.eval()
+        return picked
+
+    def query(self, leave_pbar=True, cur_epoch=None):
+        frame_ids = [p[0] for p in self.pairs]
+        t0 = time.time()
+        # Stage 1 (the caller runs save_active_labels(selected_frames=...) right after query(),
+        # active_training_utils.py:270-273: stage1() has recorded the GT statistics of every pool frame by then)
+        records = self.stage1()
+        torch.cuda.synchronize()
+        self.timings['stage1_s'] = time.time() - t0
+        picked = self.select_from_records(records)
         self.last_records = records
         return [frame_ids[i] for i in picked]
