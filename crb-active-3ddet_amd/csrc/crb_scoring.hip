@@ -124,6 +124,11 @@ __global__ __launch_bounds__(1024) void density_greedy_kernel(int N, int C, int 
           }
           kl = wave_sum_d(kl);
           prop = 0.6366197723675814 * atan(1.5707963267948966 * kl);      // 2/pi * atan(pi/2 * KL)
+          // degenerate prior (the class's 95 % density interval has zero width: scipy's uniform.pdf(scale = 0) is NaN, so is
+          // the reference's entropy and inverse_coff, and `NaN > best` never holds, crb_sampling.py:256-259,317): the
+          // candidate's score becomes NaN and it is never preferred; if every candidate is NaN the first unused one is taken
+          // (the reference would crash on best_frame_index = None there)
+          if (pk[c * AX] != pk[c * AX]) prop = NAN;
         }
         if (lane == 0) prop_ws[task] = prop;
       }

@@ -355,3 +355,34 @@ def test_stage2_batched_embeddings_equal_the_bs1_loop(dev):
     assert (rel_free <= 1e-4).sum() >= 2, rel_free
     # BatchNorm modules are back to their own forward
     assert all('forward' not in m.__dict__ for m in model.modules())
+
+
+def test_density_greedy_degenerate_prior_is_never_preferred(dev):
+    """a class whose 95 % density interval has zero width gives a NaN prior (scipy's uniform.pdf with scale 0): in the
+    reference every candidate owning a box of that class then scores NaN and `NaN > best` never selects it
+    (crb_sampling.py:256-259,317). Candidates WITHOUT that class are picked first, in the order the NaN-free problem gives;
+    the NaN ones only fill the remaining slots (first unused)."""
+    from pcdet.query_strategies import scoring
+    rng = np.random.default_rng(3)
+    dens, labs = _cands(rng, 30)
+    for i in range(30):                                       # class 2 only in the candidates 3, 7, 11, ...
+        labs[i] = torch.where(labs[i] == 2, torch.ones_like(labs[i]) if i % 4 != 3 else labs[i], labs[i])
+    owners = [i for i in range(30) if (labs[i] == 2).any()]
+    assert 0 not in owners and 3 <= len(owners) <= 8
+    xa, pr = scoring.density_prior(torch.cat(dens), torch.cat(labs), 3)
+    pr[1, :] = np.nan                                         # what a zero-width interval produces
+    D = max(len(d) for d in dens)
+    dpad = torch.zeros((30, D))
+    lpad = torch.zeros((30, D), dtype=torch.int32)
+    for i, (d, l) in enumerate(zip(dens, labs)):
+        dpad[i, :len(d)] = d
+        lpad[i, :len(l)] = l.int()
+    n_free = 30 - len(owners)
+    order, scores = scoring.density_greedy(dpad.to(dev), lpad.to(dev), xa, pr, 5, 30)
+    order = order.cpu().numpy().tolist()
+    assert sorted(order) == list(range(30))
+    assert set(order[:n_free]).isdisjoint(owners) and order[n_free:] == sorted(owners)
+    ref, _ = crb_oracle.density_greedy([dens[i] for i in range(30) if i not in owners],
+                                       [labs[i] for i in range(30) if i not in owners], list(xa), list(pr), 3, n_free, 5)
+    free_ids = [i for i in range(30) if i not in owners]
+    assert order[:n_free] == [free_ids[k] for k in ref]
