@@ -95,6 +95,10 @@ MASK_SORT = True      # set False to run the kernel on the natural row order (A/
 MASK_SORT_CHUNK = int(__import__('os').environ.get('CRB_MASK_SORT_CHUNK', '4096'))
 
 
+# output-row-window work decomposition of the wgrad (crb_sparse_conv_wgrad_windowed): L2 hit rate of the gathers 7 % -> 64 %,
+# fabric reads 800 -> 350 MB per 64x64 launch, but 150 -> 196 us: the matrix pipe, not the memory side, paces the kernel once
+# 3 waves share a SIMD, and 64-96 workgroup slots per XCD cannot be dealt evenly to 27 offsets. Opt-in.
+WGRAD_WINDOWED = False
 COMPACT_TABLES = True  # mask + packed-index tables for the kernels that have a compact instance (A/B: set False)
 
 
@@ -168,7 +172,10 @@ def _pairs_from_nbr(nbr, n_rows, K):
     ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
     check(lib.crb_pairs_from_nbr(ptr(nbr), n_rows, K, ptr(pin), ptr(pout), ptr(pstart), ptr(ws), wsb, cur_stream(dev)),
           'crb_pairs_from_nbr')
-    return pin, pout, pstart
+    # first pair of every output-row window per offset: the windowed wgrad's work decomposition (once per rulebook)
+    bnd = torch.empty((K, lib.crb_wgrad_num_windows() + 1), dtype=torch.int32, device=dev)
+    check(lib.crb_wgrad_window_bounds(ptr(pout), ptr(pstart), K, n_rows, ptr(bnd), cur_stream(dev)), 'crb_wgrad_window_bounds')
+    return pin, pout, pstart, bnd
 
 
 def build_hash(coords, shape):
@@ -316,16 +323,23 @@ def _conv_forward_raw(x, w_kio, table, n_out, kind='fwd'):
 
 def _conv_wgrad_raw(x, dy, pairs, K, kind='wgrad'):
     cin, cout = x.shape[1], dy.shape[1]
-    pin, pout, pstart = pairs
+    pin, pout, pstart = pairs[:3]
+    bnd = pairs[3] if len(pairs) > 3 else None
     dw = torch.empty((K, cin, cout), dtype=torch.float32, device=x.device)
-    wsb = lib.crb_sparse_conv_wgrad_workspace_bytes(K, cin, cout)
+    windowed = WGRAD_WINDOWED and bnd is not None and lib.crb_sparse_conv_wgrad_windowed_supported(cin, cout)
+    wsb = lib.crb_sparse_conv_wgrad_windowed_workspace_bytes(K, cin, cout) if windowed else \
+        lib.crb_sparse_conv_wgrad_workspace_bytes(K, cin, cout)
     ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
     prof = PROFILE
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(lib.crb_sparse_conv_wgrad(ptr(x), ptr(dy), ptr(pin), ptr(pout), ptr(pstart), ptr(dw), K, cin, cout, ptr(ws),
-                                    wsb, cur_stream(x.device)), 'crb_sparse_conv_wgrad')
+    if windowed:
+        check(lib.crb_sparse_conv_wgrad_windowed(ptr(x), ptr(dy), ptr(pin), ptr(pout), ptr(pstart), ptr(bnd), ptr(dw), K, cin,
+                                                 cout, ptr(ws), wsb, cur_stream(x.device)), 'crb_sparse_conv_wgrad_windowed')
+    else:
+        check(lib.crb_sparse_conv_wgrad(ptr(x), ptr(dy), ptr(pin), ptr(pout), ptr(pstart), ptr(dw), K, cin, cout, ptr(ws),
+                                        wsb, cur_stream(x.device)), 'crb_sparse_conv_wgrad')
     if prof is not None:
         ev1.record()
         prof.append((kind, cin, cout, K, x.shape[0], dy.shape[0], pstart, ev0, ev1))

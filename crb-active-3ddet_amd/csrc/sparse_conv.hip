@@ -908,34 +908,72 @@ template <int CIN, int COUT>
 struct Wgrad3Cfg {
   static constexpr int NBI = CIN / 32, NBO = COUT / 32, BLOCKS = NBI * NBO;
   static constexpr int ROWF = CIN + COUT;
-  static constexpr int PSW = ROWF <= 64 ? 32 : 16;                      // pairs per wave-step (32 staging VGPRs at most)
+  // pairs per wave-step: 32 staging VGPRs at 32x32 / 32x64, 16 at 64x64 (3 waves per SIMD instead of 2: 156 -> 150 us)
+  static constexpr int PSW = ROWF <= 64 ? 32 : (ROWF >= 128 ? 8 : 16);
   static constexpr int CHUNKS = PSW * ROWF / 4, CPT = CHUNKS / 64;      // float4 chunks per wave-step / per lane
   static constexpr int WAVE_FLOATS = 2 * PSW * ROWF;                    // private double buffer
-  static constexpr size_t LDS_BYTES = sizeof(float) * 4 * WAVE_FLOATS;
+  // the four private double buffers, or the end-of-kernel reduction scratch (3 accumulator sets) that aliases them
+  static constexpr size_t LDS_BYTES = sizeof(float) * (4 * WAVE_FLOATS > 3 * CIN * COUT ? 4 * WAVE_FLOATS : 3 * CIN * COUT);
   static_assert(CHUNKS % 64 == 0, "whole chunks per lane");
-  static_assert(3 * CIN * COUT <= 4 * WAVE_FLOATS, "end-of-kernel reduction scratch fits the staging buffers");
 };
 
-template <int CIN, int COUT, int MODE = 0>     // MODE (measurement builds): 1 = no MFMAs, 2 = no gather pipeline (MFMAs + LDS reads only)
+// WINDOWED (default): the work of a workgroup is not one contiguous pair range of its offset but, for each of the WPX row
+// windows of its XCD in turn, its 1/m share of the offset's pairs whose OUTPUT row lies in that window (bnd = per offset
+// the first pair of every window, computed once per rulebook). All 27 offsets' workgroups of an XCD then walk the same few
+// thousand rows at the same time, and an XCD only ever touches its own eighth of the rows: the gathered X / dY rows are
+// fetched from HBM once per XCD window instead of once per (offset, XCD) — with the offset-major ranges of the first version
+// every gathered row missed L2 (PMC: 798 MB of fabric reads per 64x64 launch against 112 MB algorithmic, 5.1 TB/s: the
+// kernel ran at the memory side's speed, not the matrix pipe's).
+constexpr int WG_WPX = 4;                       // row windows per XCD partition
+constexpr int WG_NWIN = 8 * WG_WPX;             // windows over the output rows
+
+template <int CIN, int COUT, int MODE = 0, bool WINDOWED = false>   // MODE (measurement builds): 1 = no MFMAs, 2 = no gather pipeline
 __global__ __launch_bounds__(256) void sparse_conv_wgrad3_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                                  const int* __restrict__ pin, const int* __restrict__ pout,
                                                                  const int* __restrict__ pstart, const int* __restrict__ plan,
                                                                  float* __restrict__ partial /* (workgroup,CIN,COUT) */,
-                                                                 int K, unsigned long long* __restrict__ dbg = nullptr) {
+                                                                 int K, unsigned long long* __restrict__ dbg = nullptr,
+                                                                 const int* __restrict__ bnd = nullptr) {
   using C = Wgrad3Cfg<CIN, COUT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* stage_all = reinterpret_cast<float*>(smem);
   const unsigned long long t_start = dbg ? wall_clock64() : 0ULL;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  if (wg >= plan[1]) return;
-  const int cb = plan[0];                                   // workgroup blocks (4 * PSW pairs) per workgroup
-  int o = 0;
-  for (int k = 1; k < K; ++k)
-    if (plan[2 + k] <= wg) o = k;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int p0 = pstart[o], p1 = pstart[o + 1];
-  const int blk_lo = (wg - plan[2 + o]) * cb;
-  const int nblocks = min((p1 - p0 + 4 * C::PSW - 1) / (4 * C::PSW), blk_lo + cb);
+  int wg, o, p0, p1, blk_lo, nblocks;
+  int seg_a[WG_WPX], seg_e[WG_WPX], seg_t[WG_WPX + 1];      // WINDOWED: pair range and first step of every window
+  if constexpr (WINDOWED) {
+    const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;  // XCD (hardware round-robin: locality only), slot on it
+    const int S = plan[0];
+    if (slot >= S) return;
+    wg = x * S + slot;
+    const int4 d = reinterpret_cast<const int4*>(plan + 8)[wg];
+    if (d.x < 0) return;
+    o = d.x;
+    p0 = pstart[0];
+    p1 = pstart[K];                                         // clamp range of the loads: the whole pair list
+    seg_t[0] = 0;
+#pragma unroll
+    for (int w = 0; w < WG_WPX; ++w) {
+      const int lo = bnd[o * (WG_NWIN + 1) + x * WG_WPX + w], hi = bnd[o * (WG_NWIN + 1) + x * WG_WPX + w + 1];
+      const long long len = hi - lo;
+      seg_a[w] = lo + (int)(len * d.y / d.z);
+      seg_e[w] = lo + (int)(len * (d.y + 1) / d.z);
+      seg_t[w + 1] = seg_t[w] + (seg_e[w] - seg_a[w] + 4 * C::PSW - 1) / (4 * C::PSW);
+    }
+    blk_lo = 0;
+    nblocks = seg_t[WG_WPX];
+  } else {
+    wg = xcd_remap(blockIdx.x, gridDim.x);
+    if (wg >= plan[1]) return;
+    const int cb = plan[0];                                 // workgroup blocks (4 * PSW pairs) per workgroup
+    o = 0;
+    for (int k = 1; k < K; ++k)
+      if (plan[2 + k] <= wg) o = k;
+    p0 = pstart[o];
+    p1 = pstart[o + 1];
+    blk_lo = (wg - plan[2 + o]) * cb;
+    nblocks = min((p1 - p0 + 4 * C::PSW - 1) / (4 * C::PSW), blk_lo + cb);
+  }
   float* stage = stage_all + wave * C::WAVE_FLOATS;
 
   f32x16 acc[C::NBI][C::NBO];
@@ -959,7 +997,24 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad3_kernel(const float* __
   struct Feat { f32x4 v[C::CPT]; };
   // wave-step b of this workgroup block-range: pairs p0 + (b * 4 + wave) * PSW ... (the four waves interleave, so they walk
   // neighbouring rows at the same time)
-  auto pair_base = [&](int b) { return p0 + (b * 4 + wave) * C::PSW; };
+  // -> first pair of this wave's slice of step b, and (by reference) one past the last valid pair of that step's range
+  auto pair_base_lim = [&](int b, int& lim) {
+    if constexpr (WINDOWED) {
+      int w = 0;
+#pragma unroll
+      for (int q = 1; q < WG_WPX; ++q) w += (b >= seg_t[q]) ? 1 : 0;
+      int a = seg_a[0], e = seg_e[0], t0 = 0;
+#pragma unroll
+      for (int q = 1; q < WG_WPX; ++q)
+        if (w == q) { a = seg_a[q]; e = seg_e[q]; t0 = seg_t[q]; }
+      lim = (b < nblocks) ? e : 0;
+      return a + ((b - t0) * 4 + wave) * C::PSW;
+    } else {
+      lim = (b < nblocks) ? p1 : 0;
+      return p0 + (b * 4 + wave) * C::PSW;
+    }
+  };
+  auto pair_base = [&](int b) { int l; return pair_base_lim(b, l); };
   auto load_idx = [&](Idx& x, int b) {
 #pragma unroll
     for (int j = 0; j < C::CPT; ++j) {
@@ -967,6 +1022,7 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad3_kernel(const float* __
       chunk(j, pr, col, isx);
       int p = pair_base(b) + pr;
       p = p < p1 ? p : p1 - 1;
+      p = p < p0 ? p0 : p;
       x.row[j] = isx ? pin[p] : pout[p];
     }
   };
@@ -984,7 +1040,9 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad3_kernel(const float* __
     for (int j = 0; j < C::CPT; ++j) {
       int pr, col; bool isx;
       chunk(j, pr, col, isx);
-      const bool ok = (b < nblocks) && (pair_base(b) + pr < p1);
+      int lim;
+      const int pb = pair_base_lim(b, lim);
+      const bool ok = pb + pr < lim;
       f32x4 v = f.v[j];
       if (!ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(buf + pr * C::ROWF + (isx ? 0 : CIN) + col * 4) = v;
@@ -1005,6 +1063,7 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad3_kernel(const float* __
     chunk(j, pr, col, isx);
     int p = pair_base(b) + pr;
     p = p < p1 ? p : p1 - 1;
+    p = p < p0 ? p0 : p;
     x.row[j] = isx ? pin[p] : pout[p];
   };
   auto load_feat1 = [&](Feat& f, const Idx& x, int j) {
@@ -1016,7 +1075,9 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad3_kernel(const float* __
   auto store_feat1 = [&](const Feat& f, int b, float* buf, int j) {
     int pr, col; bool isx;
     chunk(j, pr, col, isx);
-    const bool ok = (b < nblocks) && (pair_base(b) + pr < p1);
+    int lim;
+    const int pb = pair_base_lim(b, lim);
+    const bool ok = pb + pr < lim;
     f32x4 v = f.v[j];
     if (!ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
     *reinterpret_cast<f32x4*>(buf + pr * C::ROWF + (isx ? 0 : CIN) + col * 4) = v;
@@ -1119,6 +1180,109 @@ __global__ __launch_bounds__(256) void sparse_conv_wgrad3_kernel(const float* __
   }
 }
 
+// bnd[o][w] = first pair of offset o whose output row is >= w * ceil(n_out / WG_NWIN)  (w = 0..WG_NWIN), by binary search in
+// the offset's ascending out rows. Once per rulebook.
+__global__ __launch_bounds__(256) void wgrad_window_bounds_kernel(const int* __restrict__ pout, const int* __restrict__ pstart,
+                                                                  int K, int n_out, int* __restrict__ bnd) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= K * (WG_NWIN + 1)) return;
+  const int o = t / (WG_NWIN + 1), w = t - o * (WG_NWIN + 1);
+  const int rows = (n_out + WG_NWIN - 1) / WG_NWIN;
+  const long long r = (long long)w * rows;
+  int lo = pstart[o], hi = pstart[o + 1];
+  if (w == WG_NWIN) { bnd[t] = hi; return; }
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (pout[mid] < r) lo = mid + 1; else hi = mid;
+  }
+  bnd[t] = lo;
+}
+
+// windowed plan (one workgroup of 8 waves: wave x = XCD partition x, lane = kernel offset): S workgroup slots per XCD are
+// dealt to the offsets in proportion to their pairs inside the partition (>= 1 for an offset with any pair), so that every
+// workgroup of the XCD has about the same number of pairs per window. Layout of `plan` (ints):
+//   [0] S   [8 + 4 q ..] descriptor of workgroup q = x S + slot: {offset or -1, index i, m workgroups share the offset, -}
+//   [LIST0 + o] start of offset o's partial list (o = 0..K)   [LIST0 + K + 1 + k] workgroup q of the k-th partial
+__device__ __forceinline__ int wgrad_plan_list0(int S) { return 8 + 4 * 8 * S; }
+
+__global__ __launch_bounds__(512) void wgrad_window_plan_kernel(const int* __restrict__ bnd, int K, int S,
+                                                                int* __restrict__ plan) {
+  __shared__ int m_sh[8][32], first_sh[8][32];
+  const int x = threadIdx.x >> 6, o = threadIdx.x & 63;
+  int P = 0;
+  if (o < K) P = bnd[o * (WG_NWIN + 1) + (x + 1) * WG_WPX] - bnd[o * (WG_NWIN + 1) + x * WG_WPX];
+  long long T = P;
+  for (int d = 32; d > 0; d >>= 1) T += __shfl_xor(T, d, 64);
+  int m = (P > 0 && T > 0) ? (int)((long long)S * P / T) : 0;
+  if (P > 0 && m < 1) m = 1;
+  int sum = m;
+  for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+  // too many: take from the offset with the most workgroups; too few: give to the most loaded (pairs per workgroup)
+  for (int it = 0; it < 4 * 64 && sum != S && T > 0; ++it) {
+    float key = sum > S ? (m > 1 ? (float)m : -1.f) : (m > 0 ? (float)P / (float)m : -1.f);
+    float best = key;
+    int who = o;
+    for (int d = 32; d > 0; d >>= 1) {
+      const float ob = __shfl_xor(best, d, 64);
+      const int ow = __shfl_xor(who, d, 64);
+      if (ob > best || (ob == best && ow < who)) { best = ob; who = ow; }
+    }
+    if (best < 0.f) break;
+    if (o == who) m += sum > S ? -1 : 1;
+    sum += sum > S ? -1 : 1;
+  }
+  int incl = m;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(incl, d, 64);
+    if (o >= d) incl += v;
+  }
+  const int first = incl - m;
+  if (o < 32) { m_sh[x][o] = (o < K) ? m : 0; first_sh[x][o] = first; }
+  if (threadIdx.x == 0) plan[0] = S;
+  int4* desc = reinterpret_cast<int4*>(plan + 8);
+  // slots beyond the dealt ones stay empty
+  for (int q = o; q < S; q += 64) desc[x * S + q] = make_int4(-1, 0, 1, 0);
+  __syncthreads();
+  for (int j = 0; j < m; ++j)
+    if (first + j < S) desc[x * S + first + j] = make_int4(o, j, m, 0);
+  // per-offset partial lists (fixed order: XCD partition, then index)
+  const int L0 = wgrad_plan_list0(S);
+  if (threadIdx.x <= K) {
+    const int oo = threadIdx.x;
+    int start = 0;
+    for (int k = 0; k < oo; ++k)
+      for (int xx = 0; xx < 8; ++xx) start += m_sh[xx][k];
+    plan[L0 + oo] = start;
+    if (oo < K) {
+      int k = start;
+      for (int xx = 0; xx < 8; ++xx)
+        for (int j = 0; j < m_sh[xx][oo]; ++j)
+          if (first_sh[xx][oo] + j < S) plan[L0 + K + 1 + k++] = xx * S + first_sh[xx][oo] + j;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_windowed_kernel(const float* __restrict__ partial,
+                                                                    const int* __restrict__ plan, float* __restrict__ dW,
+                                                                    int K, int per /* CIN*COUT */) {
+  __shared__ float sh[8][32];
+  const int chunks = (per + 31) >> 5;
+  const int o = blockIdx.x / chunks, e = (blockIdx.x - o * chunks) * 32 + (threadIdx.x & 31);
+  const int part = threadIdx.x >> 5;
+  const int L0 = wgrad_plan_list0(plan[0]);
+  const int w0 = plan[L0 + o], w1 = plan[L0 + o + 1];
+  const int* list = plan + L0 + K + 1;
+  float s = 0.f;
+  if (e < per)
+    for (int w = w0 + part; w < w1; w += 8) s += partial[(int64_t)list[w] * per + e];
+  sh[part][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (part == 0 && e < per) {
+    const int l = threadIdx.x & 31;
+    dW[(int64_t)o * per + e] = ((sh[0][l] + sh[1][l]) + (sh[2][l] + sh[3][l])) + ((sh[4][l] + sh[5][l]) + (sh[6][l] + sh[7][l]));
+  }
+}
+
 // dW[o] = sum of the partials of offset o's workgroups. A 256-thread workgroup owns 32 consecutive elements of one offset;
 // 8 thread groups stride over the partials, then a fixed-shape LDS tree adds the 8 sums (same association every run).
 // The centre offset of a SubM conv has hundreds of partials: a serial per-element loop took longer than the wgrad itself
@@ -1217,6 +1381,35 @@ int launch_fwd_compact(const float* X, const float* W, const unsigned* cmask, co
   return CRB_ERR_UNSUPPORTED;
 }
 
+
+// windowed v3 launch: S = resident workgroup slots per XCD; partial (8 S, CIN, COUT); plan ints >= wgrad_windowed_plan_ints(S)
+static inline int64_t wgrad_windowed_plan_ints(int S, int K) { return 8 + 4 * 8 * (int64_t)S + (K + 1) + 8 * (int64_t)S + 64; }
+
+template <int CIN, int COUT>
+int launch_wgrad_windowed(const float* X, const float* dY, const int* pin, const int* pout, const int* pstart,
+                          const int* bnd, float* dW, float* partial, int* plan, int K, int S, hipStream_t st) {
+  if constexpr (CIN % 32 == 0 && COUT % 32 == 0 && (CIN / 32) * (COUT / 32) <= 4) {
+    using C3 = Wgrad3Cfg<CIN, COUT>;
+    hipLaunchKernelGGL(wgrad_window_plan_kernel, dim3(1), dim3(512), 0, st, bnd, K, S, plan);
+    if constexpr (CIN == 64 && COUT == 64) {
+      if (g_wgrad_mode == 1)
+        hipLaunchKernelGGL((sparse_conv_wgrad3_kernel<CIN, COUT, 1, true>), dim3(8 * S), dim3(256), C3::LDS_BYTES, st, X, dY,
+                           pin, pout, pstart, plan, partial, K, g_wgrad_dbg, bnd);
+      if (g_wgrad_mode == 2)
+        hipLaunchKernelGGL((sparse_conv_wgrad3_kernel<CIN, COUT, 2, true>), dim3(8 * S), dim3(256), C3::LDS_BYTES, st, X, dY,
+                           pin, pout, pstart, plan, partial, K, g_wgrad_dbg, bnd);
+    }
+    if (g_wgrad_mode == 0 || !(CIN == 64 && COUT == 64))
+      hipLaunchKernelGGL((sparse_conv_wgrad3_kernel<CIN, COUT, 0, true>), dim3(8 * S), dim3(256), C3::LDS_BYTES, st, X, dY,
+                         pin, pout, pstart, plan, partial, K, g_wgrad_dbg, bnd);
+    hipLaunchKernelGGL(wgrad_reduce_windowed_kernel, dim3(K * ((CIN * COUT + 31) / 32)), dim3(256), 0, st, partial, plan, dW,
+                       K, CIN * COUT);
+    CRB_CHECK_LAUNCH();
+    return CRB_OK;
+  }
+  return CRB_ERR_UNSUPPORTED;
+}
+
 template <int CIN, int COUT>
 int launch_wgrad(const float* X, const float* dY, const int* pin, const int* pout, const int* pstart, float* dW,
                  float* partial, int* plan, int K, int S, hipStream_t st) {
@@ -1224,7 +1417,7 @@ int launch_wgrad(const float* X, const float* dY, const int* pin, const int* pou
     if (g_wgrad_v1 == 0) {
       using C3 = Wgrad3Cfg<CIN, COUT>;
       const int maxwg = K * S;
-      constexpr int shift = C3::PSW == 32 ? 7 : 6;           // workgroup block = 4 waves x PSW pairs
+      constexpr int shift = C3::PSW == 32 ? 7 : (C3::PSW == 16 ? 6 : 5);   // workgroup block = 4 waves x PSW pairs
       hipLaunchKernelGGL(wgrad_plan_kernel, dim3(1), dim3(64), 0, st, pstart, K, maxwg - K, plan, shift);
       if constexpr (CIN == 64 && COUT == 64) {
         if (g_wgrad_mode == 1)
@@ -1451,6 +1644,52 @@ extern "C" int crb_sparse_conv_set_wgrad_splits(int s) {      // A/B measurement
 
 extern "C" int64_t crb_sparse_conv_wgrad_workspace_bytes(int K, int cin, int cout) {
   return (int64_t)wgrad_splits_for(K, cin, cout) * K * cin * cout * 4 + 256;
+}
+
+extern "C" int crb_wgrad_num_windows(void) { return WG_NWIN; }
+
+extern "C" int crb_wgrad_window_bounds(const int32_t* pair_out, const int32_t* pair_start, int K, int64_t n_out,
+                                       int32_t* bounds /* K * (crb_wgrad_num_windows() + 1) */, void* stream) {
+  if (K <= 0 || K > 32 || n_out < 0) return CRB_ERR_ARG;
+  hipLaunchKernelGGL(wgrad_window_bounds_kernel, dim3(crb_cdiv(K * (WG_NWIN + 1), 256)), dim3(256), 0, (hipStream_t)stream,
+                     pair_out, pair_start, K, (int)n_out, bounds);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_sparse_conv_wgrad_windowed_supported(int cin, int cout) {
+  return (cin % 32 == 0 && cout % 32 == 0 && (cin / 32) * (cout / 32) <= 4 && crb_sparse_conv_supported(cin, cout) &&
+          g_wgrad_v1 == 0) ? 1 : 0;
+}
+
+static inline int wgrad_windowed_slots_per_xcd(int cin, int cout) {
+  int s = wgrad2_slots(cin, cout) / 8;
+  return s < 1 ? 1 : (s > 256 ? 256 : s);
+}
+
+extern "C" int64_t crb_sparse_conv_wgrad_windowed_workspace_bytes(int K, int cin, int cout) {
+  const int S = wgrad_windowed_slots_per_xcd(cin, cout);
+  return (int64_t)8 * S * cin * cout * 4 + wgrad_windowed_plan_ints(S, K) * 4 + 512;
+}
+
+extern "C" int crb_sparse_conv_wgrad_windowed(const float* X, const float* dY, const int32_t* pair_in,
+                                              const int32_t* pair_out, const int32_t* pair_start, const int32_t* bounds,
+                                              float* dW, int K, int cin, int cout, void* workspace,
+                                              int64_t workspace_bytes, void* stream) {
+  if (K <= 0 || K > 32) return CRB_ERR_ARG;
+  if (!crb_sparse_conv_wgrad_windowed_supported(cin, cout)) return CRB_ERR_UNSUPPORTED;
+  if (workspace_bytes < crb_sparse_conv_wgrad_windowed_workspace_bytes(K, cin, cout) || !workspace) return CRB_ERR_WORKSPACE;
+  const int S = wgrad_windowed_slots_per_xcd(cin, cout);
+  if (S < K) return CRB_ERR_UNSUPPORTED;                    // every offset needs its own workgroup on every XCD
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  int* plan = (int*)((char*)workspace + crb_align_up((int64_t)8 * S * cin * cout * 4, 256));
+#define X_(a, b)                                                                                              \
+  if (cin == a && cout == b)                                                                                  \
+    return launch_wgrad_windowed<a, b>(X, dY, pair_in, pair_out, pair_start, bounds, dW, partial, plan, K, S, st);
+  CRB_CONV_SHAPES(X_)
+#undef X_
+  return CRB_ERR_UNSUPPORTED;
 }
 
 extern "C" int crb_sparse_conv_wgrad(const float* X, const float* dY, const int32_t* pair_in, const int32_t* pair_out,

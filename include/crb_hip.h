@@ -152,6 +152,20 @@ int crb_sparse_conv_set_wgrad_debug(void* dev_buf_u64x4_per_wg); /* measurement 
 int crb_sparse_conv_set_wgrad_mode(int mode);        /* measurement builds of the 64x64 wgrad: 1 = no MFMAs, 2 = no gather pipeline (results are wrong by design), 0 = normal */
 int crb_sparse_conv_set_wgrad_v1(int on);            /* measurement knob: 1 = the v1 (16x16x4, register-gather) wgrad kernel for every shape */
 int64_t crb_sparse_conv_wgrad_workspace_bytes(int K, int cin, int cout);
+/* Windowed wgrad (tiles of <= 4 blocks of 32x32): work is cut by WINDOWS OF OUTPUT ROWS instead of per-offset pair ranges —
+ * XCD x owns the x-th eighth of the rows, all kernel offsets' workgroups of an XCD walk the same window at the same time,
+ * so gathered rows are served by the XCD's L2 instead of being fetched once per offset. bounds (K, crb_wgrad_num_windows()+1)
+ * = first pair of every window per offset (crb_wgrad_window_bounds, once per rulebook; pair_out ascending inside an offset).
+ * Same deterministic partial + fixed-order reduction scheme as crb_sparse_conv_wgrad, same result up to f32 summation
+ * order. */
+int crb_wgrad_num_windows(void);
+int crb_wgrad_window_bounds(const int32_t* pair_out, const int32_t* pair_start, int K, int64_t n_out, int32_t* bounds,
+                            void* stream);
+int crb_sparse_conv_wgrad_windowed_supported(int cin, int cout);
+int64_t crb_sparse_conv_wgrad_windowed_workspace_bytes(int K, int cin, int cout);
+int crb_sparse_conv_wgrad_windowed(const float* X, const float* dY, const int32_t* pair_in, const int32_t* pair_out,
+                                   const int32_t* pair_start, const int32_t* bounds, float* dW, int K, int cin, int cout,
+                                   void* workspace, int64_t workspace_bytes, void* stream);
 int crb_sparse_conv_wgrad(const float* X, const float* dY, const int32_t* pair_in, const int32_t* pair_out,
                           const int32_t* pair_start, float* dW, int K, int cin, int cout,
                           void* workspace, int64_t workspace_bytes, void* stream);

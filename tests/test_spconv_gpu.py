@@ -29,7 +29,7 @@ def test_subm_rulebook_exact(dev, clustered):
     coords = random_sparse_coords(rng, 30000, 3, shape, clustered)
     rb = sparse.subm_rulebook(_t(coords, dev), shape, [3, 3, 3])
     np.testing.assert_array_equal(rb.nbr.cpu().numpy(), oracle.subm_nbr(coords, shape, [3, 3, 3]))
-    pin, pout, pstart = [x.cpu().numpy() for x in rb.pairs()]
+    pin, pout, pstart = [x.cpu().numpy() for x in rb.pairs()[:3]]
     nbr = rb.nbr.cpu().numpy()
     P = int(pstart[-1])
     assert P == (nbr >= 0).sum()
@@ -563,3 +563,28 @@ def test_backbone_with_planned_indices_equals_unplanned(dev):
     sb.PLAN_INDICES = True
     assert torch.equal(outs[0].indices, outs[1].indices) and torch.equal(outs[0].features, outs[1].features)
     assert set(outs[0].indice_dict.keys()) == set(outs[1].indice_dict.keys())
+
+
+def test_windowed_wgrad_equals_default_wgrad(dev):
+    """crb_sparse_conv_wgrad_windowed (work cut by windows of output rows, opt-in) == the default wgrad == the oracle"""
+    from crbhip import sparse
+    rng = np.random.default_rng(91)
+    shape = [21, 160, 140]
+    coords = random_sparse_coords(rng, 30000, 3, shape)
+    rb = sparse.subm_rulebook(_t(coords, dev), shape, [3, 3, 3])
+    n = rb.n_out
+    nbr = oracle.subm_nbr(coords, shape, [3, 3, 3])
+    for cin, cout in ((32, 32), (32, 64), (64, 64)):
+        X = rng.normal(size=(n, cin)).astype(np.float32)
+        dY = rng.normal(size=(n, cout)).astype(np.float32)
+        ref = oracle.conv_wgrad(X, dY, nbr, 27)
+        got = {}
+        for w_ in (False, True):
+            sparse.WGRAD_WINDOWED = w_
+            got[w_] = sparse._conv_wgrad_raw(_t(X, dev), _t(dY, dev), rb.pairs(), 27).cpu().numpy()
+        sparse.WGRAD_WINDOWED = False
+        _close(got[False], ref)
+        _close(got[True], ref)
+    bnd = rb.pairs()[3].cpu().numpy()
+    pstart = rb.pairs()[2].cpu().numpy()
+    assert (bnd[:, 0] == pstart[:-1]).all() and (bnd[:, -1] == pstart[1:]).all() and (np.diff(bnd, axis=1) >= 0).all()

@@ -88,13 +88,13 @@ def main():
         N = rb.n_out
         row('SubM rulebook L%d (hash + nbr): %d rows' % (lvl, N), t, 16 * N + 4 * 27 * N)
         t = timeit(lambda: sparse._compact(rb.nbr, sparse._mask_perm(rb.nbr, 27), 27), max(5, it // 3))
-        row('mask sort + tile order + permute L%d' % lvl, t, 2 * 4 * 27 * N + 12 * N)
+        row('mask sort + tile order + compact table L%d' % lvl, t, 4 * 27 * N + 12 * N + 8 * N + 4 * int((rb.nbr >= 0).sum()))
         C = chans[lvl]
         P = int((rb.nbr >= 0).sum())
         x = torch.randn(N, C, device=dev)
         dy = torch.randn(N, C, device=dev)
         w = torch.randn(27, C, C, device=dev) / 10
-        table, pairs = rb.sorted_table('nbr'), rb.pairs()
+        table, pairs = rb.table_for('nbr', C, C), rb.pairs()
         balg = 4.0 * N * C * 2 + 8.0 * P + 4.0 * 27 * C * C
         fl = 2.0 * P * C * C
         row('gather-GEMM fwd/dgrad %dx%d L%d (P=%.2fM)' % (C, C, lvl, P / 1e6),

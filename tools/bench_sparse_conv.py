@@ -22,11 +22,14 @@ def main():
     ap.add_argument('--chunk', type=int, default=None)
     ap.add_argument('--dense-random', action='store_true', help='all 27 neighbours present, rows drawn at random inside +-4096 rows (real-table-like locality)')
     ap.add_argument('--dense-k', type=int, default=27, help='with --dense: only the first k offsets are present in every row')
+    ap.add_argument('--no-windowed', action='store_true', help='wgrad: per-offset pair ranges instead of output-row windows')
     ap.add_argument('--wgrad-sweep', action='store_true', help='sweep the workgroups-per-offset knob of the wgrad')
     ap.add_argument('--dense', action='store_true', help='synthetic table with all 27 neighbours present (no skip imbalance)')
     args = ap.parse_args()
     from crbhip import sparse, voxel
     from pcdet.datasets.synthetic import kitti_batch, KITTI_RANGE, KITTI_VOXEL
+    if args.no_windowed:
+        sparse.WGRAD_WINDOWED = False
     if args.no_sort:
         sparse.MASK_SORT = False
     if args.no_lpt:
