@@ -28,6 +28,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense f32-input MFMA (exact f32), the dtype this path computes in
+MFMA_BF16_PEAK_TF = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -41,6 +42,7 @@ def parse():
     ap.add_argument('--pool', type=int, default=2, help='distinct resident batches cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--nchw', action='store_true', help='A/B: NCHW memory format for the dense BEV part')
+    ap.add_argument('--bf16x3-steps', type=int, default=6, help='extra steps under the opt-in split-bf16 gather-GEMM (second roofline); 0 = skip')
     ap.add_argument('--cpu-frames', type=int, default=16, help='BASELINE configs[0]: 16 frames, one CPU fwd+bwd step')
     ap.add_argument('--scoring-pool', type=int, default=3000,
                     help='unlabeled pool size of the CRB stage-1 scoring measurement (BASELINE configs[3]: 3,000 frames, '
@@ -95,13 +97,16 @@ def event_pair_overhead_ms(n=200):
     return float(np.median([a.elapsed_time(b) for a, b in evs]))
 
 
-def roofline_from_profile(prof, overhead_ms=0.0):
+def roofline_from_profile(prof, overhead_ms=0.0, arithmetic='f32'):
     """dominant subm gather-GEMM instance by total time; algorithmic bytes per SURVEY §8d:
     B_alg = 4 N_in C_in + 4 N_out C_out + 8 P + 4 K C_in C_out. Launch durations = HIP event pairs on the launch stream
-    inside the timed region minus the empty-pair reading (event_pair_overhead_ms)."""
+    inside the timed region minus the empty-pair reading (event_pair_overhead_ms). arithmetic='bf16x3': the launches of the
+    opt-in split-bf16 kernel (its event pair also covers the W split kernel), priced against the HBM roof and the bf16 MFMA
+    roof of its three passes."""
     agg = {}
+    kinds = ('subm_fwd', 'subm_dgrad') if arithmetic == 'f32' else ('subm_fwd_bf16x3', 'subm_dgrad_bf16x3')
     for kind, cin, cout, K, n_in, n_out, tab, e0, e1 in prof:
-        if kind not in ('subm_fwd', 'subm_dgrad'):
+        if kind not in kinds:
             continue
         ms = max(e0.elapsed_time(e1) - overhead_ms, 1e-4)
         key = ('subm_gather_gemm', cin, cout)
@@ -129,6 +134,17 @@ def roofline_from_profile(prof, overhead_ms=0.0):
     # (v_mfma_f32_16x16x4_f32, 157.3 TF dense, MI355X_MICROARCH.md). At C=64 the intensity is ~117 flop/B against a
     # machine balance of 19.7, so the f32 gather-GEMM is MFMA-bound; the HBM fraction is reported beside it.
     t_hbm = a['bytes'] / (HBM_PEAK_GBS * 1e9)
+    if arithmetic == 'bf16x3':
+        t_mfma3 = 3.0 * a['flops'] / (MFMA_BF16_PEAK_TF * 1e12)
+        return {'bound': 'hbm' if t_hbm >= t_mfma3 else 'mfma',
+                'kernel': 'sparse_conv_fwd_bf16x3_kernel<%d,%d> + w_split_pack_kernel (subm gather-GEMM fwd+dgrad, OPT-IN '
+                          'split-bf16 contract: |y - y_f32| <= 2^-16 sum|x||w|)' % (key[1], key[2]),
+                'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+                'traffic': None, 'avg_launch_us': round(1e3 * a['ms'] / a['n'], 2), 'launches': a['n'],
+                'event_pair_overhead_us': round(1e3 * overhead_ms, 2),
+                'alg_bytes_per_launch': round(a['bytes'] / a['n']), 'alg_flops_per_launch': round(a['flops'] / a['n']),
+                'roof_us': {'hbm': round(1e6 * t_hbm / a['n'], 2), 'mfma_bf16_3pass': round(1e6 * t_mfma3 / a['n'], 2)},
+                'note': 'second roofline of the same launches (VERDICT r01 item 6); the default path and `value` stay exact f32'}, table
     t_mfma = a['flops'] / (MFMA_F32_PEAK_TF * 1e12)
     kern = 'sparse_conv_fwd2_kernel<%d,%d> (subm gather-GEMM fwd+dgrad)' % (key[1], key[2])
     common = {'traffic': pmc_traffic(key[1], key[2]),
@@ -407,6 +423,20 @@ def main():
     dt, per_step, loss = timed_steps(True, prof)
     # the same step without grad-clip / AdamW ("one optimizer-less loss.backward() step"); not profiled
     dt_nopt, per_step_nopt, _ = timed_steps(False, None)
+    # OPT-IN split-bf16 gather-GEMM (crbhip.sparse.ARITHMETIC = 'bf16x3'): a few more steps of the same training loop with
+    # the contract switched on, only to report its roofline and step time beside the exact-f32 ones; never part of `value`
+    prof3, dt3, per_step3 = ([] if rank == 0 else None), None, None
+    if args.bf16x3_steps > 0:
+        sp.ARITHMETIC = 'bf16x3'
+        try:
+            step(0)
+            keep = args.steps
+            args.steps = args.bf16x3_steps
+            dt3, per_step3, loss3 = timed_steps(True, prof3)
+            bf16x3_loss = float(loss3.item())
+        finally:
+            args.steps = keep
+            sp.ARITHMETIC = 'f32'
     frames = args.batch * world * args.steps
     out = {
         'metric': 'frames/s SECOND fwd+bwd, KITTI 20k-pt clouds' if args.kind == 'kitti' else
@@ -435,6 +465,15 @@ def main():
         roof, table = roofline_from_profile(prof, overhead_ms)
         out['roofline'] = roof
         out['kernel_table'] = table
+        if dt3 is not None:
+            roof3, table3 = roofline_from_profile(prof3, overhead_ms, 'bf16x3')
+            out['roofline_bf16x3'] = roof3
+            out['bf16x3'] = {'frames_per_s': round(args.batch * world * args.bf16x3_steps / dt3, 3),
+                             'ms_per_step': round(1e3 * dt3 / args.bf16x3_steps, 3), 'steps': args.bf16x3_steps,
+                             'ms_per_step_device': _pctl(per_step3), 'final_loss': round(bf16x3_loss, 4),
+                             'kernel_table': table3,
+                             'note': 'same training loop, gather-GEMM fwd+dgrad of the C>=32 layers under the opt-in '
+                                     'split-bf16 contract (wgrad, BEV backbone and heads unchanged, f32)'}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
         else:

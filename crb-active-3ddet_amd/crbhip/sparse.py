@@ -71,7 +71,8 @@ class Rulebook(object):
 
     def table_for(self, which, cin, cout):
         """the table form the gather-GEMM instance of (cin, cout) consumes"""
-        if COMPACT_TABLES and lib.crb_sparse_conv_compact_supported(cin, cout):
+        if COMPACT_TABLES and (lib.crb_sparse_conv_compact_supported(cin, cout) or
+                               (ARITHMETIC == 'bf16x3' and lib.crb_sparse_conv_bf16x3_supported(cin, cout))):
             return self.compact_table(which)
         return self.sorted_table(which)
 
@@ -292,6 +293,10 @@ def spconv_rulebook(coords, shape, batch_size, ksize, stride, padding, premarked
 # When set to a list, every gather-GEMM launch appends (kind, cin, cout, K, n_in, n_out, nbr, ev0, ev1): HIP events on
 # the launch stream (torch's current stream IS the stream handed to the C-ABI), read back by bench.py for the roofline.
 PROFILE = None
+# Arithmetic contract of the gather-GEMM (forward and dgrad). 'f32' (default): exact f32 MFMA. 'bf16x3' (OPT-IN): operands
+# split into two bf16 values, three bf16 MFMA passes, f32 accumulation: |y - y_f32| <= 2^-16 sum |x||w| (include/crb_hip.h,
+# crb_sparse_conv_forward_bf16x3); shapes without a bf16x3 instance (C <= 16) keep the f32 kernel.
+ARITHMETIC = 'f32'
 
 
 def _conv_forward_raw(x, w_kio, table, n_out, kind='fwd'):
@@ -305,7 +310,15 @@ def _conv_forward_raw(x, w_kio, table, n_out, kind='fwd'):
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    if isinstance(table, CompactTable):
+    if ARITHMETIC == 'bf16x3' and isinstance(table, CompactTable) and lib.crb_sparse_conv_bf16x3_supported(cin, cout):
+        wsb = lib.crb_sparse_conv_bf16x3_workspace_bytes(K, cin, cout)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+        check(lib.crb_sparse_conv_forward_bf16x3(ptr(x), ptr(w_kio), ptr(table.cmask), ptr(table.cbase), ptr(table.packed),
+                                                 ptr(table.perm), ptr(y), x.shape[0], n_out, K, cin, cout, ptr(ws), wsb,
+                                                 cur_stream(x.device)), 'crb_sparse_conv_forward_bf16x3')
+        nbr = table
+        kind = kind + '_bf16x3'
+    elif isinstance(table, CompactTable):
         check(lib.crb_sparse_conv_forward_compact(ptr(x), ptr(w_kio), ptr(table.cmask), ptr(table.cbase), ptr(table.packed),
                                                   ptr(table.perm), ptr(y), n_out, K, cin, cout, cur_stream(x.device)),
               'crb_sparse_conv_forward_compact')

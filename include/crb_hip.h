@@ -134,6 +134,24 @@ int crb_nbr_compact(const int32_t* nbr, const int32_t* perm, int64_t n, int K, u
 int crb_sparse_conv_forward_compact(const float* X, const float* W, const uint32_t* cmask, const int32_t* cbase,
                                     const int32_t* packed, const int32_t* perm, float* Y, int64_t n_out, int K, int cin,
                                     int cout, void* stream);
+
+/* OPT-IN arithmetic contract "bf16x3" for the same gather-GEMM (exact f32 above stays the default): every operand is split
+ * into two bf16 values, x = x_hi + x_lo (+ a residual <= 2^-18 |x|), and a product is taken as x_lo*w_hi + x_hi*w_lo +
+ * x_hi*w_hi on the bf16 MFMA (products exact, f32 accumulation; x_lo*w_lo dropped). Stated bound, checked by
+ * tests/test_spconv_gpu.py: |y - y_exact| <= 2^-16 * sum |x||w| over the gathered products of the output element (plus
+ * f32 accumulation error). bf16 keeps the f32 exponent range: no scaling, no overflow case of its own. Needs the compact
+ * table of crb_nbr_compact; workspace >= crb_sparse_conv_bf16x3_workspace_bytes (holds the split copy of W). n_in = rows of
+ * X (the gathers are bounds-checked buffer loads; n_in*cin*4 must stay below 2^31).
+ * No reference counterpart: spconv-cu113 v2.1.21 multiplies in f32 (or fp16 under AMP, which the reference does not use). */
+int crb_sparse_conv_bf16x3_supported(int cin, int cout);
+int64_t crb_sparse_conv_bf16x3_workspace_bytes(int K, int cin, int cout);
+int crb_sparse_conv_forward_bf16x3(const float* X, const float* W, const uint32_t* cmask, const int32_t* cbase,
+                                   const int32_t* packed, const int32_t* perm, float* Y, int64_t n_in, int64_t n_out,
+                                   int K, int cin, int cout, void* workspace, int64_t workspace_bytes, void* stream);
+/* measurement knob: 16-row tiles per wave (1 or 2; 0 = default) */
+int crb_sparse_conv_bf16x3_set_tiles_per_wave(int tpw);
+/* measurement builds of the 64x64 kernel (wrong results): 1 = no MFMAs, 2 = no row gathers, 3 = no W hand-over, 4 = 2+3 */
+int crb_sparse_conv_bf16x3_set_mode(int mode);
 int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, const int32_t* perm, float* Y,
                             int64_t n_out, int K, int cin, int cout, void* stream);
 /* kernel-variant knob for A/B measurements only: 0 = default (v2 kernel where Cin,Cout are multiples of 16 and Cin <= 64,

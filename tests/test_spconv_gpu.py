@@ -588,3 +588,81 @@ def test_windowed_wgrad_equals_default_wgrad(dev):
     bnd = rb.pairs()[3].cpu().numpy()
     pstart = rb.pairs()[2].cpu().numpy()
     assert (bnd[:, 0] == pstart[:-1]).all() and (bnd[:, -1] == pstart[1:]).all() and (np.diff(bnd, axis=1) >= 0).all()
+
+
+BF16X3_BOUND = 2.0 ** -16          # the stated contract of crb_sparse_conv_forward_bf16x3 (include/crb_hip.h)
+F32_ACC_SLACK = 2.0 ** -20         # f32 accumulation of <= 27*128 terms on top (either kernel has it)
+
+
+def _bf16x3_check(got, exact, absum):
+    err = np.abs(got.astype(np.float64) - exact)
+    lim = (BF16X3_BOUND + F32_ACC_SLACK) * absum
+    assert (err <= lim).all(), (float((err / np.maximum(absum, 1e-30)).max()), BF16X3_BOUND)
+    return float((err / np.maximum(absum, 1e-30)).max())
+
+
+@pytest.mark.parametrize('tpw', [0, 1, 2])
+@pytest.mark.parametrize('cin,cout', [(32, 32), (32, 64), (64, 64), (64, 32)])
+def test_bf16x3_subm_forward_and_dgrad_within_the_stated_bound(dev, cin, cout, tpw):
+    """OPT-IN arithmetic (crbhip.sparse.ARITHMETIC = 'bf16x3'): operands split into two bf16 values, 3 bf16 MFMA passes.
+    Stated contract: |y - y_exact| <= 2^-16 * sum |x||w| over the products of the output element; checked against the
+    double-accumulating oracle on rows whose magnitudes span six decades; dgrad runs the same kernel on the transposed
+    table (here also the (64,32)/(32,64) pairs); wgrad keeps exact f32. The default path must stay exact f32."""
+    from crbhip import sparse
+    from crbhip._lib import lib
+    rng = np.random.default_rng(300 + cin + cout)
+    shape = [21, 100, 88]
+    coords = random_sparse_coords(rng, 5000, 2, shape)
+    n = len(coords)
+    X = (rng.normal(size=(n, cin)) * 10.0 ** rng.uniform(-3, 3, size=(n, 1))).astype(np.float32)
+    W = (rng.normal(size=(27, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    dY = (rng.normal(size=(n, cout)) * 10.0 ** rng.uniform(-3, 3, size=(n, 1))).astype(np.float32)
+    nbr = oracle.subm_nbr(coords, shape, [3, 3, 3])
+    rb = sparse.subm_rulebook(_t(coords, dev), shape, [3, 3, 3])
+    x = _t(X, dev).requires_grad_(True)
+    w = _t(W, dev).requires_grad_(True)
+    y_f32 = sparse.sparse_conv(x, w, rb).detach()
+    assert sparse.ARITHMETIC == 'f32'
+    lib.crb_sparse_conv_bf16x3_set_tiles_per_wave(tpw)
+    sparse.ARITHMETIC = 'bf16x3'
+    try:
+        y = sparse.sparse_conv(x, w, rb)
+        y.backward(_t(dY, dev))
+    finally:
+        sparse.ARITHMETIC = 'f32'
+        lib.crb_sparse_conv_bf16x3_set_tiles_per_wave(0)
+    worst = _bf16x3_check(y.detach().cpu().numpy(), oracle.conv_fwd(X, W, nbr).astype(np.float64),
+                          oracle.conv_fwd(np.abs(X), np.abs(W), nbr).astype(np.float64))
+    _bf16x3_check(x.grad.cpu().numpy(), oracle.conv_dgrad(dY, W, nbr, n).astype(np.float64),
+                  oracle.conv_dgrad(np.abs(dY), np.abs(W), nbr, n).astype(np.float64))
+    _close(w.grad.cpu().numpy(), oracle.conv_wgrad(X, dY, nbr, 27), rtol=2e-4)          # exact-f32 wgrad, unchanged
+    assert not torch.equal(y.detach(), y_f32) and worst > 2.0 ** -24       # the opt-in kernel really ran
+    _close(y_f32.cpu().numpy(), oracle.conv_fwd(X, W, nbr))
+
+
+def test_bf16x3_strided_conv_out_layer(dev):
+    """the (3,1,1)/(2,1,1) 64->128 conv_out geometry and its 128->64 dgrad under the opt-in contract"""
+    from crbhip import sparse
+    rng = np.random.default_rng(77)
+    shape = [11, 100, 88]
+    coords = random_sparse_coords(rng, 6000, 2, shape)
+    n = len(coords)
+    ks, st, pd = (3, 1, 1), (2, 1, 1), (0, 0, 0)
+    X = rng.normal(size=(n, 64)).astype(np.float32)
+    W = (rng.normal(size=(3, 64, 128)) / 8).astype(np.float32)
+    rb = sparse.spconv_rulebook(_t(coords, dev), shape, 2, ks, st, pd)
+    dY = rng.normal(size=(rb.n_out, 128)).astype(np.float32)
+    x = _t(X, dev).requires_grad_(True)
+    w = _t(W, dev).requires_grad_(True)
+    sparse.ARITHMETIC = 'bf16x3'
+    try:
+        y = sparse.sparse_conv(x, w, rb)
+        y.backward(_t(dY, dev))
+    finally:
+        sparse.ARITHMETIC = 'f32'
+    oc, _ = oracle.spconv_out(coords, shape, ks, st, pd)
+    nbr = oracle.spconv_nbr(coords, shape, oc, ks, st, pd)
+    _bf16x3_check(y.detach().cpu().numpy(), oracle.conv_fwd(X, W, nbr).astype(np.float64),
+                  oracle.conv_fwd(np.abs(X), np.abs(W), nbr).astype(np.float64))
+    _bf16x3_check(x.grad.cpu().numpy(), oracle.conv_dgrad(dY, W, nbr, n).astype(np.float64),
+                  oracle.conv_dgrad(np.abs(dY), np.abs(W), nbr, n).astype(np.float64))

@@ -12,6 +12,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
+def balg_of(n, cin, cout, P):
+    return 4.0 * n * cin + 4.0 * n * cout + 8.0 * P + 4.0 * 27 * cin * cout
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=16)
@@ -101,6 +105,32 @@ def main():
             tk_ = rb.sorted_table('nbr')
             t_fk = timeit(lambda: sparse._conv_forward_raw(x, w, tk_, n))
             assert torch.equal(sparse._conv_forward_raw(x, w, tk_, n), sparse._conv_forward_raw(x, w, table, n))
+        bx = ''
+        if isinstance(table, sparse.CompactTable) and lib.crb_sparse_conv_bf16x3_supported(cin, cout):
+            sparse.ARITHMETIC = 'bf16x3'
+            y3 = sparse._conv_forward_raw(x, w, table, n)
+            tb = []
+            for tpw in (1, 2, 3):
+                lib.crb_sparse_conv_bf16x3_set_tiles_per_wave(tpw)
+                tb.append(timeit(lambda: sparse._conv_forward_raw(x, w, table, n)))
+            if cin == 64 and cout == 64:
+                for tpw in (1, 2):
+                    lib.crb_sparse_conv_bf16x3_set_tiles_per_wave(tpw)
+                    tm = []
+                    for mode in (1, 2, 3, 4):
+                        lib.crb_sparse_conv_bf16x3_set_mode(mode)
+                        tm.append(timeit(lambda: sparse._conv_forward_raw(x, w, table, n)))
+                    lib.crb_sparse_conv_bf16x3_set_mode(0)
+                    print('   bf16x3 tpw%d measurement builds: no-MFMA %.1f, no-gather %.1f, no-W %.1f, no-gather-no-W %.1f us' % (
+                        tpw, *tm))
+            lib.crb_sparse_conv_bf16x3_set_tiles_per_wave(0)
+            sparse.ARITHMETIC = 'f32'
+            yf = sparse._conv_forward_raw(x, w, table, n)
+            S = sparse._conv_forward_raw(x.abs(), w.abs(), table, n)
+            rel = float(((y3 - yf).abs() / S.clamp_min(1e-30)).max())
+            bx = ' | bf16x3 fwd (incl. W split) tpw1 %.1f us, tpw2 %.1f us, 8 waves x 1 tile %.1f us = %.0f GB/s alg (%.1f%% of 8TB/s), max |d|/sum|x||w| = 2^%.1f' % (
+                tb[0], tb[1], tb[2], balg_of(n, cin, cout, P) / min(tb) / 1e3, balg_of(n, cin, cout, P) / min(tb) / 1e3 / 80,
+                np.log2(max(rel, 1e-30)))
         t_w = timeit(lambda: sparse._conv_wgrad_raw(x, dy, pairs, 27))
         lib.crb_sparse_conv_set_wgrad_v1(1)
         t_w1 = timeit(lambda: sparse._conv_wgrad_raw(x, dy, pairs, 27))
@@ -120,7 +150,7 @@ def main():
               'wgrad %.1f us %.1f TF (%.1f%% of 157.3) [v1 kernel %.1f us, max rel diff %.1e]%s' % (
                   lvl, cin, cout, n, P, P / n, t_f, balg / t_f / 1e3, balg / t_f / 1e3 / 80, fl / t_f / 1e6, t_w,
                   fl / t_w / 1e6, fl / t_w / 1e6 / 1.573, t_w1, werr, sweep),
-              'v1/v2-noremap/v2 %.1f %.1f %.1f us | (n,K) table fwd %.1f us' % (ts[1], ts[16], ts[8], t_fk), flush=True)
+              'v1/v2-noremap/v2 %.1f %.1f %.1f us | (n,K) table fwd %.1f us' % (ts[1], ts[16], ts[8], t_fk) + bx, flush=True)
 
 
 if __name__ == '__main__':

@@ -12,7 +12,7 @@ if __name__ == '__main__':
     from pcdet.datasets.synthetic import kitti_batch, KITTI_RANGE, KITTI_VOXEL
     level = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-    kind = sys.argv[3] if len(sys.argv) > 3 else 'fwd'            # fwd | wgrad
+    kind = sys.argv[3] if len(sys.argv) > 3 else 'fwd'            # fwd | wgrad | bf16x3
     dev = torch.device('cuda', 0)
     pts, off, _ = kitti_batch(0, 16)
     r = voxel.voxelize(torch.from_numpy(pts).to(dev), torch.from_numpy(off).to(dev), KITTI_RANGE, KITTI_VOXEL, 16000, 5,
@@ -33,6 +33,11 @@ if __name__ == '__main__':
     dy = torch.randn(n, cout, device=dev)
     pairs = rb.pairs()
     torch.cuda.synchronize()
+    if kind == 'bf16x3':
+        from crbhip import lib
+        sparse.ARITHMETIC = 'bf16x3'
+        lib.crb_sparse_conv_bf16x3_set_tiles_per_wave(int(os.environ.get('CRB_BF16X3_TPW', '0')))
+        lib.crb_sparse_conv_bf16x3_set_mode(int(os.environ.get('CRB_BF16X3_MODE', '0')))
     for _ in range(iters):
         if kind == 'wgrad':
             sparse._conv_wgrad_raw(x, dy, pairs, 27)
