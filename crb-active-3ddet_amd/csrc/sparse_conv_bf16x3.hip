@@ -46,6 +46,21 @@ __device__ __forceinline__ void split8(const u32x4& v0, const u32x4& v1, bf16x8&
   }
 }
 
+template <int CTRL>
+__device__ __forceinline__ u32x4 dpp4(const u32x4& v) {          // every component from the quad lane CTRL names
+  u32x4 r;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) r[t] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[t], CTRL, 0xF, 0xF, false);
+  return r;
+}
+
+// k index of element e of lane group g in k-group s (see w_split_pack_kernel). CIN = 64 uses the row-contiguous gather
+// (each lane ends up with 16 consecutive channels of its row), the other shapes the fragment-shaped one.
+template <int CIN>
+__device__ __forceinline__ int k_of(int s, int g, int e) {
+  return CIN == 64 ? 16 * g + 8 * s + e : 32 * s + 16 * (e >> 2) + 4 * g + (e & 3);
+}
+
 // Wp layout per offset o: [s = k-group of 32][nb = 16-column block][hl: 0 hi, 1 lo][lane = 16 g + li] -> 8 bf16 =
 // W[o][k(s, g, e)][16 nb + li], e = 0..7: the B operand of lane (li, g) for v_mfma_f32_16x16x32_bf16. The MFMA sums over
 // all (g, e) of a k-group, so any bijection k(s, g, e) serves as long as A uses the same one; k = 32 s + 16 (e / 4) + 4 g +
@@ -60,7 +75,7 @@ __global__ __launch_bounds__(256) void w_split_pack_kernel(const float* __restri
   bf16x8 hi, lo;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const float v = W[((int64_t)o * CIN + 32 * s + 16 * (e >> 2) + 4 * g + (e & 3)) * COUT + nb * 16 + li];
+    const float v = W[((int64_t)o * CIN + k_of<CIN>(s, g, e)) * COUT + nb * 16 + li];
     const __bf16 h = (__bf16)v;
     hi[e] = h;
     lo[e] = (__bf16)(v - (float)h);
@@ -70,7 +85,8 @@ __global__ __launch_bounds__(256) void w_split_pack_kernel(const float* __restri
   dst[64 + lane] = lo;
 }
 
-// MODE (measurement builds, wrong results): 1 = no MFMAs, 2 = no row gathers, 3 = no W fetch / store, 4 = 2 + 3
+// MODE (measurement builds; 1-4 give wrong results): 1 = no MFMAs, 2 = no row gathers, 3 = no W fetch / store, 4 = 2 + 3,
+// 5 = row gathers with the non-temporal cache policy
 template <int CIN, int COUT, int TPW, int MODE = 0, int NW = 4>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void sparse_conv_fwd_bf16x3_kernel(
     const float* __restrict__ X, const bf16x8* __restrict__ Wp, const int* __restrict__ packed,
@@ -158,21 +174,59 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void sparse_conv_fwd_bf16
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)x_bytes, 0x00020000);
   typedef u32x4 AFrag[TPW][2 * KS];
   AFrag afA, afB;                                    // two register sets, alternating statically (no copies at the back edge)
+  // CIN = 64 (ROWG): the four lanes of a quad read 64 contiguous bytes of ONE row per load instruction (instruction i: row
+  // 4 (li / 4) + i of the tile, bytes 64 g + 16 (li % 4) ..), because the texture-address unit prices a wave load by the
+  // cache lines its quads touch: the fragment-shaped load (a quad = 4 different rows) costs 64 line look-ups per
+  // instruction, this one 16. A 4x4 transpose inside each quad (DPP, VALU that idles anyway) then hands lane (li, g) the
+  // channels 16 g .. 16 g + 15 of its own row li.
+  constexpr bool ROWG = CIN == 64;
   auto gather = [&](AFrag& af, int o) {
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
       const int r = nbr_of(j, o);
-      const int voff = r < 0 ? (int)0x80000000 : r * (CIN * 4) + 16 * g;
+      if constexpr (ROWG) {
+        const int cb = 64 * g + 16 * (lane & 3);
+        const int r0 = __builtin_amdgcn_update_dpp(0, r, 0x00, 0xF, 0xF, false);
+        const int r1 = __builtin_amdgcn_update_dpp(0, r, 0x55, 0xF, 0xF, false);
+        const int r2 = __builtin_amdgcn_update_dpp(0, r, 0xAA, 0xF, 0xF, false);
+        const int r3 = __builtin_amdgcn_update_dpp(0, r, 0xFF, 0xF, 0xF, false);
+        af[j][0] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, r0 < 0 ? (int)0x80000000 : r0 * 256 + cb, 0, 0);
+        af[j][1] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, r1 < 0 ? (int)0x80000000 : r1 * 256 + cb, 0, 0);
+        af[j][2] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, r2 < 0 ? (int)0x80000000 : r2 * 256 + cb, 0, 0);
+        af[j][3] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, r3 < 0 ? (int)0x80000000 : r3 * 256 + cb, 0, 0);
+      } else {
+        const int voff = r < 0 ? (int)0x80000000 : r * (CIN * 4) + 16 * g;
 #pragma unroll
-      for (int q = 0; q < 2 * KS; ++q) af[j][q] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 64 * q, 0);
+        for (int q = 0; q < 2 * KS; ++q)
+          af[j][q] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 64 * q, MODE == 5 ? 2 : 0);   // 5: nt policy
+      }
     }
   };
   bf16x8 ah[TPW][KS], al[TPW][KS];
   auto split = [&](const AFrag& af) {
 #pragma unroll
-    for (int j = 0; j < TPW; ++j)
+    for (int j = 0; j < TPW; ++j) {
+      if constexpr (ROWG) {
+        // tr[c](quad lane q) = af[q](quad lane c): two butterfly stages (lane bit 0 / register bit 0, then bit 1)
+        const bool q0 = (lane & 1) != 0, q1 = (lane & 2) != 0;
+        u32x4 t1[4], tr[4];
 #pragma unroll
-      for (int s = 0; s < KS; ++s) split8(af[j][2 * s], af[j][2 * s + 1], ah[j][s], al[j][s]);
+        for (int r = 0; r < 4; ++r) {
+          const u32x4 other = dpp4<0xB1>(af[j][r ^ 1]);         // quad_perm [1,0,3,2]
+          t1[r] = (((r & 1) != 0) == q0) ? af[j][r] : other;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const u32x4 other = dpp4<0x4E>(t1[r ^ 2]);            // quad_perm [2,3,0,1]
+          tr[r] = (((r & 2) != 0) == q1) ? t1[r] : other;
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) split8(tr[2 * s], tr[2 * s + 1], ah[j][s], al[j][s]);
+      } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) split8(af[j][2 * s], af[j][2 * s + 1], ah[j][s], al[j][s]);
+      }
+    }
   };
   // tiles of the wave that have the offset: wave-uniform bit set `act`; consecutive MFMAs go to different accumulators
   auto mfma_block = [&](const bf16x8* wl, unsigned act) {
@@ -269,6 +323,7 @@ int launch_tpw(const float* X, const bf16x8* Wp, const unsigned* cmask, const in
     if (g_bf16x3_mode == 2) kern = sparse_conv_fwd_bf16x3_kernel<CIN, COUT, TPW, 2>;
     if (g_bf16x3_mode == 3) kern = sparse_conv_fwd_bf16x3_kernel<CIN, COUT, TPW, 3>;
     if (g_bf16x3_mode == 4) kern = sparse_conv_fwd_bf16x3_kernel<CIN, COUT, TPW, 4>;
+    if (g_bf16x3_mode == 5) kern = sparse_conv_fwd_bf16x3_kernel<CIN, COUT, TPW, 5>;
   }
   static bool attr_done = false;                    // per instantiation; the measurement builds set it every time
   if (!attr_done || g_bf16x3_mode) {
@@ -317,7 +372,7 @@ extern "C" int64_t crb_sparse_conv_bf16x3_workspace_bytes(int K, int cin, int co
 }
 
 extern "C" int crb_sparse_conv_bf16x3_set_mode(int mode) {
-  g_bf16x3_mode = (mode >= 1 && mode <= 4) ? mode : 0;
+  g_bf16x3_mode = (mode >= 1 && mode <= 5) ? mode : 0;
   return CRB_OK;
 }
 

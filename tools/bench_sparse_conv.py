@@ -117,11 +117,11 @@ def main():
                 for tpw in (1, 2):
                     lib.crb_sparse_conv_bf16x3_set_tiles_per_wave(tpw)
                     tm = []
-                    for mode in (1, 2, 3, 4):
+                    for mode in (1, 2, 3, 4, 5, 0):
                         lib.crb_sparse_conv_bf16x3_set_mode(mode)
                         tm.append(timeit(lambda: sparse._conv_forward_raw(x, w, table, n)))
                     lib.crb_sparse_conv_bf16x3_set_mode(0)
-                    print('   bf16x3 tpw%d measurement builds: no-MFMA %.1f, no-gather %.1f, no-W %.1f, no-gather-no-W %.1f us' % (
+                    print('   bf16x3 tpw%d measurement builds: no-MFMA %.1f, no-gather %.1f, no-W %.1f, no-gather-no-W %.1f, nt gathers %.1f, normal %.1f us' % (
                         tpw, *tm))
             lib.crb_sparse_conv_bf16x3_set_tiles_per_wave(0)
             sparse.ARITHMETIC = 'f32'
