@@ -16,10 +16,24 @@ from .pool_eval import PoolEvalStrategy
 class BadgeSampling(PoolEvalStrategy):
     MC_DROPOUT = True
 
+    @staticmethod
+    def hypothetical_labels(rpn_preds, num_class):
+        """(B, H, W, A*num_class) class scores of the dense head -> (B, H*W*A) arg-max labels (badge_sampling.py:86-89)"""
+        B = rpn_preds.shape[0]
+        return torch.argmax(rpn_preds.reshape(B, -1, num_class), -1)
+
+    @staticmethod
+    def head_embedding(dense_head, rpn_preds, labels):
+        """one frame (bs = 1, train-mode rpn_preds): gradient of the RPN classification loss against the hypothetical
+        labels w.r.t. conv_cls.weight, flattened (badge_sampling.py:146-160; pinned by tests/golden/ref_badge.npz)"""
+        new_data = {'box_cls_labels': labels.long().reshape(1, -1), 'cls_preds': rpn_preds}
+        loss = dense_head.get_cls_layer_loss(new_data=new_data)[0]
+        g, = torch.autograd.grad(loss, dense_head.conv_cls.weight)
+        return g.detach().reshape(-1)
+
     def _rpn_labels(self, batch, pred_dicts, b):
         rpn = pred_dicts[0]['rpn_preds']                                   # (B, H, W, A*num_class) of the whole batch
-        B = rpn.shape[0]
-        return torch.argmax(rpn.reshape(B, -1, self.detector.dense_head.num_class), -1)[b]
+        return self.hypothetical_labels(rpn, self.detector.dense_head.num_class)[b]
 
     def grad_embeddings(self, frame_indices, labels):
         model = self.detector
@@ -28,10 +42,7 @@ class BadgeSampling(PoolEvalStrategy):
         out = []
         for k, (chunk, batch) in enumerate(self._batches(self.unlabelled_set, frame_indices, 1)):
             ret, _, _ = model(batch)
-            new_data = {'box_cls_labels': labels[k].long().unsqueeze(0), 'cls_preds': ret['rpn_preds']}
-            loss = model.dense_head.get_cls_layer_loss(new_data=new_data)[0]
-            g, = torch.autograd.grad(loss, w)
-            out.append(g.detach().reshape(-1))
+            out.append(self.head_embedding(model.dense_head, ret['rpn_preds'], labels[k]))
         model.eval()
         return torch.stack(out, 0) if out else torch.zeros((0, w.numel()), device=w.device)
 

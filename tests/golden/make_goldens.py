@@ -336,6 +336,48 @@ def gen_strategies(out):
     out['ent_selected'] = np.array(list(sel.keys())[len(sel) - 3:], np.int64)
 
 
+def gen_badge(out):
+    """BADGE embedding at the level the strategy computes it (badge_sampling.py:84-90,146-160): eval pass of the reference's
+    AnchorHeadSingle -> rpn_preds -> arg-max over classes = hypothetical labels; then, frame by frame (bs = 1, train mode),
+    get_cls_layer_loss(new_data={'box_cls_labels', 'cls_preds'}) (anchor_head_template.py:101-142) -> backward ->
+    conv_cls.weight.grad = the embedding row. Inputs are the BEV features the detector would hand the head."""
+    from pcdet.models.dense_heads.anchor_head_single import AnchorHeadSingle
+    rng = np.random.default_rng(31)
+    pc_range = np.array([0, -8, -3, 17.6, 8, 1], np.float32)
+    grid = np.array([176, 160, 40], np.int64)
+    torch.manual_seed(32)
+    head = AnchorHeadSingle(small_head_cfg(), input_channels=24, num_class=3,
+                            class_names=['Car', 'Pedestrian', 'Cyclist'], grid_size=grid, point_cloud_range=pc_range,
+                            predict_boxes_when_training=True)
+    torch.nn.init.normal_(head.conv_cls.weight, std=0.3)          # away from the -log(99) bias-only start: mixed labels
+    B = 3
+    feats = rng.normal(0, 1, (B, 24, 20, 22)).astype(np.float32)
+    head.eval()
+    with torch.no_grad():
+        dd = head({'spatial_features_2d': torch.from_numpy(feats), 'batch_size': B})
+    rpn = dd['rpn_preds']
+    labels = torch.argmax(rpn.view(B, -1, head.num_class), -1)
+    head.train()
+    gt = rand_gt(rng, B, 5, ((0.5, 17), (-7.5, 7.5)))
+    embs, losses = [], []
+    for b in range(B):
+        d1 = head({'spatial_features_2d': torch.from_numpy(feats[b:b + 1]), 'gt_boxes': torch.from_numpy(gt[b:b + 1].copy()),
+                   'batch_size': 1})
+        new_data = {'box_cls_labels': labels[b].unsqueeze(0), 'cls_preds': d1['rpn_preds']}
+        loss = head.get_cls_layer_loss(new_data=new_data)[0]
+        head.zero_grad()
+        loss.backward()
+        embs.append(_np(head.conv_cls.weight.grad).reshape(-1).copy())
+        losses.append(float(loss))
+    out['badge_state'] = {k: _np(v) for k, v in head.state_dict().items()}
+    out['badge_feats'], out['badge_gt'] = feats, gt
+    out['badge_rpn_preds'] = _np(rpn)
+    out['badge_labels'] = _np(labels).astype(np.int8)
+    out['badge_loss'] = np.array(losses, np.float64)
+    out['badge_emb'] = np.stack(embs)
+    assert len(np.unique(out['badge_labels'])) == 3 and np.abs(out['badge_emb']).max() > 0
+
+
 def gen_data_processor(out):
     """DataProcessor.mask_points_and_boxes_outside_range through the reference's own class (train mode, shuffle off)"""
     from pcdet.datasets.processor.data_processor import DataProcessor
@@ -624,7 +666,8 @@ if __name__ == '__main__':
     only = sys.argv[1:] 
     for name, fn in (('ref_utils.npz', gen_utils), ('ref_anchor_head.npz', gen_head), ('ref_bev_vfe.npz', gen_bev), ('ref_roi_head.npz', gen_roi_head),
                      ('ref_strategies.npz', gen_strategies), ('ref_data_processor.npz', gen_data_processor),
-                     ('ref_post_processing.npz', gen_post_processing), ('ref_glue.npz', gen_glue)):
+                     ('ref_post_processing.npz', gen_post_processing), ('ref_glue.npz', gen_glue),
+                     ('ref_badge.npz', gen_badge)):
         if only and name not in only:
             continue
         d = {}

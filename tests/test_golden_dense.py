@@ -178,3 +178,29 @@ def test_fused_head_convs_equal_three_convs():
     torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-5)
     for a, b in zip(outs[0][2], outs[1][2]):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-3)
+
+
+def test_badge_hypothetical_labels_and_gradient_embedding_match_reference():
+    """BadgeSampling's two rules (badge_sampling.py:86-89,146-160) through the product's own helpers against
+    ref_badge.npz (reference AnchorHeadSingle, eval pass -> arg-max labels, then per frame get_cls_layer_loss(new_data) ->
+    conv_cls.weight.grad): labels exact, embeddings 1e-5 relative to the largest entry of the row."""
+    from pcdet.query_strategies.badge_sampling import BadgeSampling
+    g = _load('ref_badge.npz')
+    head = _small_head()
+    head.load_state_dict({k[len('badge_state/'):]: _t(v) for k, v in g.items() if k.startswith('badge_state/')})
+    feats = _t(g['badge_feats'])
+    B = feats.shape[0]
+    head.eval()
+    with torch.no_grad():
+        dd = head({'spatial_features_2d': feats, 'batch_size': B})
+    np.testing.assert_allclose(dd['rpn_preds'].numpy(), g['badge_rpn_preds'], rtol=1e-5, atol=1e-5)
+    labels = BadgeSampling.hypothetical_labels(_t(g['badge_rpn_preds']), head.num_class)
+    np.testing.assert_array_equal(labels.numpy(), g['badge_labels'].astype(np.int64))
+    assert len(np.unique(g['badge_labels'])) == 3
+    head.train()
+    for b in range(B):
+        d1 = head({'spatial_features_2d': feats[b:b + 1], 'gt_boxes': _t(g['badge_gt'][b:b + 1]), 'batch_size': 1})
+        emb = BadgeSampling.head_embedding(head, d1['rpn_preds'], labels[b]).numpy()
+        ref = g['badge_emb'][b]
+        np.testing.assert_allclose(emb, ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+        assert np.abs(ref).max() > 1e-3
