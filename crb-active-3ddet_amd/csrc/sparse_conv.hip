@@ -78,8 +78,7 @@ __global__ __launch_bounds__(256) void sparse_conv_fwd_kernel(const float* __res
   constexpr int WS = NB * 16;
   constexpr int KSTEPS = (CIN + 3) / 4;  // MFMA k-steps
   constexpr int CINP = KSTEPS * 4;
-  constexpr int WELEMS = CINP * NB * 16;            // staged elements of one W[o]
-  constexpr int WPT = (WELEMS + 255) / 256;         // per thread
+  constexpr int WPT = ((CINP * 16 + 255) / 256) * NB;   // per thread: its (k, li) pairs x all NB column blocks
   constexpr int TROWS = 64 * SUBT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* w_lds0 = reinterpret_cast<float*>(smem);
@@ -1464,7 +1463,7 @@ int launch_wgrad(const float* X, const float* dY, const int* pin, const int* pou
 }  // namespace
 
 #define CRB_CONV_SHAPES(X_) \
-  X_(4, 16) X_(5, 16) X_(16, 4) X_(16, 5) X_(16, 16) X_(16, 32) X_(32, 16) X_(32, 32) X_(32, 64) X_(64, 32) X_(64, 64) X_(64, 128) \
+  X_(4, 16) X_(5, 16) X_(16, 4) X_(16, 5) X_(4, 64) X_(64, 4) X_(16, 16) X_(16, 32) X_(32, 16) X_(32, 32) X_(32, 64) X_(64, 32) X_(64, 64) X_(64, 128) \
   X_(128, 64) X_(128, 128)
 
 extern "C" int crb_sparse_conv_supported(int cin, int cout) {

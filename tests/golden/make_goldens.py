@@ -378,6 +378,156 @@ def gen_badge(out):
     assert len(np.unique(out['badge_labels'])) == 3 and np.abs(out['badge_emb']).max() > 0
 
 
+def seeded_state(module, seed):
+    """parameters and buffers of a module filled from ONE numpy stream in name order (weights are regenerated the same way
+    by the test instead of being stored): conv / linear weights ~ N(0, 1/sqrt(fan_in)), BN weight in [0.5, 1.5], BN bias
+    and running_mean ~ N(0, 0.2), running_var in [0.5, 1.5]"""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for name, v in sorted(module.state_dict().items()):
+        shape = tuple(v.shape)
+        if name.endswith('num_batches_tracked'):
+            a = np.zeros(shape, np.int64)
+        elif name.endswith('running_var') or (name.endswith('weight') and len(shape) == 1):
+            a = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif len(shape) == 1:
+            a = rng.normal(0, 0.2, shape).astype(np.float32)
+        else:
+            fan_in = int(np.prod(shape)) // shape[0]
+            a = (rng.normal(0, 1, shape) / np.sqrt(fan_in)).astype(np.float32)
+        sd[name] = torch.from_numpy(a)
+    return sd
+
+
+def parta2_cfg():
+    return EasyDict({
+        'NAME': 'PartA2FCHead', 'CLASS_AGNOSTIC': True, 'SHARED_FC': [48, 48], 'CLS_FC': [24], 'REG_FC': [24], 'DP_RATIO': 0.0,
+        'DISABLE_PART': False, 'SEG_MASK_SCORE_THRESH': 0.3,
+        'NMS_CONFIG': {'TRAIN': {'NMS_TYPE': 'nms_gpu', 'MULTI_CLASSES_NMS': False, 'NMS_PRE_MAXSIZE': 64,
+                                 'NMS_POST_MAXSIZE': 16, 'NMS_THRESH': 0.8},
+                       'TEST': {'NMS_TYPE': 'nms_gpu', 'MULTI_CLASSES_NMS': False, 'NMS_PRE_MAXSIZE': 64,
+                                'NMS_POST_MAXSIZE': 16, 'NMS_THRESH': 0.7}},
+        'ROI_AWARE_POOL': {'POOL_SIZE': 4, 'NUM_FEATURES': 64, 'MAX_POINTS_PER_VOXEL': 32},
+        'TARGET_CONFIG': {'BOX_CODER': 'ResidualCoder', 'ROI_PER_IMAGE': 16, 'FG_RATIO': 0.5, 'SAMPLE_ROI_BY_EACH_CLASS': True,
+                          'CLS_SCORE_TYPE': 'roi_iou', 'CLS_FG_THRESH': 0.75, 'CLS_BG_THRESH': 0.25,
+                          'CLS_BG_THRESH_LO': 0.1, 'HARD_BG_RATIO': 0.8, 'REG_FG_THRESH': 0.55},
+        'LOSS_CONFIG': {'CLS_LOSS': 'BinaryCrossEntropy', 'REG_LOSS': 'smooth-l1', 'CORNER_LOSS_REGULARIZATION': True,
+                        'LOSS_WEIGHTS': {'rcnn_cls_weight': 1.0, 'rcnn_reg_weight': 1.0, 'rcnn_corner_weight': 1.0,
+                                         'code_weights': [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]}},
+    })
+
+
+def parta2_inputs(seed=41, B=2, R=16, C=32):
+    """per frame: 5 objects with 40-120 points each + clutter; 16 RoIs = jittered object boxes, far-away empty boxes and two
+    all-zero rows (the padding proposal_layer leaves)"""
+    rng = np.random.default_rng(seed)
+    sizes = [(3.9, 1.6, 1.56), (0.8, 0.6, 1.73), (1.76, 0.6, 1.73)]
+    pts, rois = [], np.zeros((B, R, 7), np.float32)
+    for b in range(B):
+        obj = []
+        for g in range(5):
+            s = np.array(sizes[g % 3]) * rng.uniform(0.9, 1.1, 3)
+            obj.append([rng.uniform(5, 60), rng.uniform(-30, 30), rng.uniform(-1.2, -0.6), *s, rng.uniform(-np.pi, np.pi)])
+        obj = np.array(obj, np.float32)
+        p = [np.stack([rng.uniform(0, 70, 300), rng.uniform(-40, 40, 300), rng.uniform(-3, 1, 300)], 1)]
+        for o in obj:
+            k = int(rng.integers(40, 120))
+            loc = rng.uniform(-0.55, 0.55, (k, 3)) * o[3:6]
+            ca, sa = np.cos(o[6]), np.sin(o[6])
+            p.append(np.stack([loc[:, 0] * ca - loc[:, 1] * sa + o[0], loc[:, 0] * sa + loc[:, 1] * ca + o[1], loc[:, 2] + o[2]], 1))
+        p = np.concatenate(p).astype(np.float32)
+        pts.append(np.concatenate([np.full((len(p), 1), b, np.float32), p], 1))
+        for r in range(R - 2):
+            if r < 11:
+                o = obj[r % 5].copy()
+                o[:3] += rng.normal(0, 0.25, 3)
+                o[3:6] *= rng.uniform(0.9, 1.2, 3)
+                o[6] += rng.normal(0, 0.15)
+                rois[b, r] = o
+            else:
+                rois[b, r] = [rng.uniform(80, 90), rng.uniform(50, 60), 0, 2, 2, 2, 0.3]      # no point inside
+    pc = np.concatenate(pts).astype(np.float32)
+    P = len(pc)
+    return {'point_coords': pc, 'point_features': rng.normal(0, 1, (P, C)).astype(np.float32),
+            'point_part_offset': rng.uniform(0, 1, (P, 3)).astype(np.float32),
+            'point_cls_scores': rng.uniform(0, 1, (P,)).astype(np.float32), 'rois': rois,
+            'roi_labels': rng.integers(1, 4, (B, R)).astype(np.int64), 'batch_size': B}
+
+
+def gen_partA2(out):
+    """ref_partA2.npz: the reference's PartA2FCHead (partA2_head.py:10-224) end to end — RoI-aware pooling (avg part
+    features, max point features), occupied cells of all RoI grids as one sparse tensor, the two SubM conv stacks, dense
+    flatten, FC branches, box decoding — in eval mode (running BatchNorm statistics) and in train mode (batch statistics;
+    proposal / target assignment bypassed with the same fixed RoIs, which partA2_head.py:165-172 allows through
+    batch_dict['rois']). Compiled entry points are answered by the oracle: roiaware_pool3d_cuda.forward -> oracle
+    roiaware_pool (points-in-box rule pinned to roiaware_pool3d.cpp), spconv.SubMConv3d / SparseConvTensor.dense ->
+    oracle subm_nbr + conv_fwd + dense (spconv itself is not in the reference tree: restated semantics)."""
+    oracle = _install_cpu_ops()
+    pool_mod = sys.modules['pcdet.ops.roiaware_pool3d.roiaware_pool3d_cuda']
+
+    def pool_forward(rois, pts, feat, argmax, pts_idx, pooled, method):
+        o = tuple(int(v) for v in pooled.shape[1:4])
+        p, a, i = oracle.roiaware_pool(rois.numpy(), pts.numpy(), feat.detach().numpy(), o, int(pts_idx.shape[-1]), int(method))
+        pooled.copy_(torch.from_numpy(p)); argmax.copy_(torch.from_numpy(a)); pts_idx.copy_(torch.from_numpy(i))
+    pool_mod.forward = pool_forward
+
+    class SparseConvTensor:
+        def __init__(self, features, indices, spatial_shape, batch_size):
+            self.features, self.indices = features, indices
+            self.spatial_shape, self.batch_size = [int(v) for v in spatial_shape], int(batch_size)
+
+        def replace_feature(self, f):
+            return SparseConvTensor(f, self.indices, self.spatial_shape, self.batch_size)
+
+        def dense(self):
+            return torch.from_numpy(oracle.dense(self.features.detach().numpy(), self.indices.numpy(), self.batch_size,
+                                                 self.spatial_shape))
+
+    class SubMConv3d(torch.nn.Module):
+        def __init__(self, cin, cout, k, bias=True, indice_key=None, **kw):
+            super().__init__()
+            assert k == 3 and not bias
+            self.weight = torch.nn.Parameter(torch.zeros(cout, 3, 3, 3, cin))      # spconv 2.x layout
+
+        def forward(self, x):
+            nbr = oracle.subm_nbr(x.indices.numpy(), x.spatial_shape, [3, 3, 3])
+            w = self.weight.detach().reshape(self.weight.shape[0], 27, -1).permute(1, 2, 0).contiguous().numpy()
+            return x.replace_feature(torch.from_numpy(oracle.conv_fwd(x.features.detach().numpy(), w, nbr)))
+
+    class SparseSequential(torch.nn.Sequential):
+        def forward(self, x):
+            for m in self:
+                x = m(x) if isinstance(m, (SubMConv3d, SparseSequential)) else x.replace_feature(m(x.features))
+            return x
+
+    spp = sys.modules['spconv.pytorch']
+    spp.SparseConvTensor, spp.SubMConv3d, spp.SparseSequential = SparseConvTensor, SubMConv3d, SparseSequential
+    from pcdet.config import cfg as ref_cfg
+    ref_cfg.CLASS_NAMES = ['Car', 'Pedestrian', 'Cyclist']
+    from pcdet.models.roi_heads.partA2_head import PartA2FCHead
+    head = PartA2FCHead(input_channels=32, model_cfg=parta2_cfg(), num_class=1)
+    head.load_state_dict(seeded_state(head, 43))
+    inp = parta2_inputs()
+
+    def batch():
+        return {k: (torch.from_numpy(v.copy()) if isinstance(v, np.ndarray) else v) for k, v in inp.items()}
+    head.eval()
+    with torch.no_grad():
+        bd = head(batch())
+        pooled_part, pooled_rpn = head.roiaware_pool(batch())
+    out['pa2_keys'] = np.array(sorted(head.state_dict().keys()))
+    out['pa2_pooled_part'], out['pa2_pooled_rpn'] = _np(pooled_part), _np(pooled_rpn)
+    out['pa2_eval_cls'], out['pa2_eval_box'] = _np(bd['batch_cls_preds']), _np(bd['batch_box_preds'])
+    head.train()
+    head.assign_targets = lambda bdict: {'rois': bdict['rois'], 'roi_labels': bdict['roi_labels']}
+    with torch.no_grad():
+        head(batch())
+    out['pa2_train_cls'], out['pa2_train_reg'] = _np(head.forward_ret_dict['rcnn_cls']), _np(head.forward_ret_dict['rcnn_reg'])
+    cells = int((out['pa2_pooled_part'].sum(-1) != 0).sum())
+    assert cells > 200 and np.abs(out['pa2_eval_cls']).max() > 1e-3 and np.isfinite(out['pa2_train_reg']).all(), cells
+    print('  occupied cells', cells, 'of', out['pa2_pooled_part'][..., 0].size)
+
+
 def gen_data_processor(out):
     """DataProcessor.mask_points_and_boxes_outside_range through the reference's own class (train mode, shuffle off)"""
     from pcdet.datasets.processor.data_processor import DataProcessor
@@ -667,7 +817,7 @@ if __name__ == '__main__':
     for name, fn in (('ref_utils.npz', gen_utils), ('ref_anchor_head.npz', gen_head), ('ref_bev_vfe.npz', gen_bev), ('ref_roi_head.npz', gen_roi_head),
                      ('ref_strategies.npz', gen_strategies), ('ref_data_processor.npz', gen_data_processor),
                      ('ref_post_processing.npz', gen_post_processing), ('ref_glue.npz', gen_glue),
-                     ('ref_badge.npz', gen_badge)):
+                     ('ref_badge.npz', gen_badge), ('ref_partA2.npz', gen_partA2)):
         if only and name not in only:
             continue
         d = {}

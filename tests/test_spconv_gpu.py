@@ -60,7 +60,7 @@ def test_spconv_rulebook_exact(dev, ks, st, pd):
     np.testing.assert_array_equal(nbr_t, ref_t)
 
 
-CHANNELS = [(4, 16), (5, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (32, 16),
+CHANNELS = [(4, 16), (5, 16), (4, 64), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (32, 16),
             (64, 32), (128, 64)]
 
 
