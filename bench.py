@@ -136,10 +136,16 @@ def roofline_from_profile(prof, overhead_ms=0.0, arithmetic='f32'):
     t_hbm = a['bytes'] / (HBM_PEAK_GBS * 1e9)
     if arithmetic == 'bf16x3':
         t_mfma3 = 3.0 * a['flops'] / (MFMA_BF16_PEAK_TF * 1e12)
-        return {'bound': 'hbm' if t_hbm >= t_mfma3 else 'mfma',
+        tf3 = 3.0 * tfs                                  # bf16 MFMA flops actually issued: three passes
+        hbm_bound = t_hbm >= t_mfma3                     # the two roofs are within 20 % of each other at C = 64
+        return {'bound': 'hbm' if hbm_bound else 'mfma',
                 'kernel': 'sparse_conv_fwd_bf16x3_kernel<%d,%d> + w_split_pack_kernel (subm gather-GEMM fwd+dgrad, OPT-IN '
                           'split-bf16 contract: |y - y_f32| <= 2^-16 sum|x||w|)' % (key[1], key[2]),
-                'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+                'achieved': round(gbs, 1) if hbm_bound else round(tf3, 1),
+                'peak': HBM_PEAK_GBS if hbm_bound else MFMA_BF16_PEAK_TF, 'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
+                'frac': round(gbs / HBM_PEAK_GBS, 4) if hbm_bound else round(tf3 / MFMA_BF16_PEAK_TF, 4),
+                'hbm_GBps_alg': round(gbs, 1), 'hbm_frac': round(gbs / HBM_PEAK_GBS, 4),
+                'mfma_bf16_TFLOPs_3pass': round(tf3, 1), 'mfma_bf16_frac': round(tf3 / MFMA_BF16_PEAK_TF, 4),
                 'traffic': None, 'avg_launch_us': round(1e3 * a['ms'] / a['n'], 2), 'launches': a['n'],
                 'event_pair_overhead_us': round(1e3 * overhead_ms, 2),
                 'alg_bytes_per_launch': round(a['bytes'] / a['n']), 'alg_flops_per_launch': round(a['flops'] / a['n']),

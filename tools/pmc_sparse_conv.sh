@@ -1,9 +1,9 @@
 # PMC passes for the subm gather-GEMM forward (level-3 geometry of SECOND bs=16). Separate passes (SQ / FETCH_SIZE /
 # WRITE_SIZE), counters only (+ --kernel-trace), instrumentation limited to the conv kernel, every pass under `timeout`.
-# usage (GPU box): bash tools/pmc_sparse_conv.sh [level] [fwd|wgrad] ; writes gpurun_out/pmc_sparse_conv_<kind>_L<level>.txt
+# usage (GPU box): bash tools/pmc_sparse_conv.sh [level] [fwd|wgrad|bf16x3] [kernel regex] ; writes gpurun_out/pmc_sparse_conv_<kind>_L<level>.txt
 LEVEL=${1:-3}
 KIND=${2:-fwd}
-REGEX="sparse_conv_$KIND"
+REGEX=${3:-sparse_conv_$KIND}      # kind bf16x3: pass sparse_conv_fwd_bf16x3 (env CRB_BF16X3_TPW / _MODE as in tools/pmc_driver.py)
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_sparse_conv_${KIND}_L$LEVEL.txt
 cd /tmp && export TMPDIR=/tmp
 : > $OUT
