@@ -61,7 +61,7 @@ def _frames_forward(x, off, bn, relu, out=None, col=0):
     z = torch.empty_like(x) if out is None else out
     ld = 0 if out is None else out.shape[1]
     arr = (ctypes.c_int64 * len(off))(*[int(v) for v in off])
-    wsb = lib.crb_bn_frames_workspace_bytes(max(b - a for a, b in zip(off[:-1], off[1:])), C)
+    wsb = lib.crb_bn_frames_workspace_bytes(len(off) - 1, max(b - a for a, b in zip(off[:-1], off[1:])), C)
     ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
     with torch.no_grad():
         bn.num_batches_tracked += len(off) - 1
@@ -340,7 +340,7 @@ def bn_relu_max_concat(xs, nss, bns):
                 x = x.contiguous()
                 C = x.shape[1]
                 arg = torch.empty((M, C), dtype=torch.int32, device=x.device)
-                wsb = lib.crb_bn_frames_workspace_bytes(m * int(ns), C)
+                wsb = lib.crb_bn_frames_workspace_bytes(G, m * int(ns), C)
                 ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
                 with torch.no_grad():
                     bn.num_batches_tracked += G

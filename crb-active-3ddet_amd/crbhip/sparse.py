@@ -299,9 +299,14 @@ PROFILE = None
 ARITHMETIC = 'f32'
 
 
-def _conv_forward_raw(x, w_kio, table, n_out, kind='fwd'):
+def epilogue_supported(cin, cout):
+    """shapes whose forward kernel can apply (bias,) BatchNorm1d(eval) and ReLU to the accumulator before the store"""
+    return bool(COMPACT_TABLES and ARITHMETIC == 'f32' and lib.crb_sparse_conv_compact_supported(cin, cout))
+
+
+def _conv_forward_raw(x, w_kio, table, n_out, kind='fwd', epilogue=None):
     """x (n_in,cin), w (K,cin,cout), table = (nbr rows in kernel order (n_out,K), perm or None) or a CompactTable
-    -> (n_out,cout)"""
+    -> (n_out,cout). epilogue = (bias or None, BatchNorm1d in eval mode, relu flag): inference only, compact tables only."""
     K, cin, cout = w_kio.shape
     if not lib.crb_sparse_conv_supported(cin, cout):
         raise CrbHipError(f'sparse conv channel pair ({cin},{cout}) has no gfx950 kernel instance')
@@ -310,7 +315,17 @@ def _conv_forward_raw(x, w_kio, table, n_out, kind='fwd'):
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    if ARITHMETIC == 'bf16x3' and isinstance(table, CompactTable) and lib.crb_sparse_conv_bf16x3_supported(cin, cout):
+    if epilogue is not None:
+        bias, bn, relu = epilogue
+        assert isinstance(table, CompactTable) and not bn.training
+        check(lib.crb_sparse_conv_forward_compact_bn(
+            ptr(x), ptr(w_kio), ptr(table.cmask), ptr(table.cbase), ptr(table.packed), ptr(table.perm), ptr(y), n_out, K, cin,
+            cout, ptr(bias.contiguous()) if bias is not None else None, ptr(bn.weight.contiguous()), ptr(bn.bias.contiguous()),
+            ptr(bn.running_mean.contiguous()), ptr(bn.running_var.contiguous()), float(bn.eps), int(bool(relu)),
+            cur_stream(x.device)), 'crb_sparse_conv_forward_compact_bn')
+        nbr = table
+        kind = kind + '_bn'
+    elif ARITHMETIC == 'bf16x3' and isinstance(table, CompactTable) and lib.crb_sparse_conv_bf16x3_supported(cin, cout):
         wsb = lib.crb_sparse_conv_bf16x3_workspace_bytes(K, cin, cout)
         ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
         check(lib.crb_sparse_conv_forward_bf16x3(ptr(x), ptr(w_kio), ptr(table.cmask), ptr(table.cbase), ptr(table.packed),
@@ -399,6 +414,16 @@ class SparseConvFunction(torch.autograd.Function):
 
 def sparse_conv(x, w_kio, rb, inverse=False):
     return SparseConvFunction.apply(x, w_kio, rb, inverse)
+
+
+@torch.no_grad()
+def sparse_conv_bn_eval(x, w_kio, rb, bias, bn, relu):
+    """inference: conv (+bias) -> BatchNorm1d(running statistics) -> ReLU in ONE launch (epilogue on the accumulator)"""
+    require_cuda(x, w_kio)
+    x, w_kio = x.contiguous().float(), w_kio.contiguous().float()
+    cin, cout = w_kio.shape[1], w_kio.shape[2]
+    return _conv_forward_raw(x, w_kio, rb.table_for('nbr', cin, cout), rb.n_out,
+                             ('subm' if rb.subm else 'spconv') + '_fwd', epilogue=(bias, bn, relu))
 
 
 class ToDenseFunction(torch.autograd.Function):

@@ -259,6 +259,155 @@ __global__ __launch_bounds__(256) void bn_max_bwd_apply_kernel(const float* __re
   *reinterpret_cast<f4*>(dx + t * 4) = ga * is * (d - db * inv_n - xh * (dg * inv_n));
 }
 
+// ---- a batch of frames with PER-FRAME statistics in four launches (CRB stage 2: G frames per training-mode pass, every
+// BatchNorm keeps the statistics of the reference's bs=1 loop). A frame's rows are cut into the SAME blocks a single-frame
+// call would use (rows per block and block count follow from the frame's own row count), the partials are summed in the
+// same fixed order, the running statistics are advanced frame after frame: bit-identical to n_frames calls of
+// crb_bn_relu_forward, in 4 launches instead of 3 per frame.
+#define BN_MAXF 64
+struct BnFrames {
+  long long off[BN_MAXF + 1];      // row range of frame f: [off[f], off[f+1])
+  int rpb[BN_MAXF];                // rows per statistics block of frame f
+  int nblk[BN_MAXF];               // statistics blocks of frame f
+  int pbase[BN_MAXF];              // first partial slot of frame f
+};
+
+__global__ __launch_bounds__(256) void bn_partial_frames_kernel(const float* __restrict__ x, int C, BnFrames fr,
+                                                                float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f4* red = reinterpret_cast<f4*>(smem);
+  const int f = blockIdx.y;
+  if ((int)blockIdx.x >= fr.nblk[f]) return;
+  const int c4n = C >> 2;
+  const int tc = threadIdx.x % c4n, tr = threadIdx.x / c4n;
+  const int rlanes = 256 / c4n;
+  const int64_t r0 = fr.off[f] + (int64_t)blockIdx.x * fr.rpb[f];
+  const int64_t r1 = min((int64_t)fr.off[f + 1], r0 + fr.rpb[f]);
+  f4 a = (f4){0, 0, 0, 0}, b = (f4){0, 0, 0, 0};
+  if (tr < rlanes)
+    for (int64_t r = r0 + tr; r < r1; r += rlanes) {
+      const f4 v = *reinterpret_cast<const f4*>(x + r * C + tc * 4);
+      a += v;
+      b += v * v;
+    }
+  red[threadIdx.x] = a;
+  red[256 + threadIdx.x] = b;
+  __syncthreads();
+  if (tr == 0) {
+    for (int k = 1; k < rlanes; ++k) { a += red[k * c4n + tc]; b += red[256 + k * c4n + tc]; }
+    const int64_t slot = fr.pbase[f] + blockIdx.x;
+    *reinterpret_cast<f4*>(partial + (slot * 2 + 0) * C + tc * 4) = a;
+    *reinterpret_cast<f4*>(partial + (slot * 2 + 1) * C + tc * 4) = b;
+  }
+}
+
+// stats[f] = {mean (C), biased var (C), invstd (C), unbiased var (C)}; same summation order and roundings as bn_finalize_kernel
+__global__ __launch_bounds__(256) void bn_finalize_frames_kernel(const float* __restrict__ partial, int C, float eps,
+                                                                 BnFrames fr, float* __restrict__ stats) {
+  __shared__ double sa[32][8], sb[32][8];
+  const int f = blockIdx.y;
+  const int64_t n = fr.off[f + 1] - fr.off[f];
+  if (n <= 0) return;
+  const int nblk = fr.nblk[f];
+  const float* p = partial + (int64_t)fr.pbase[f] * 2 * C;
+  const int cl = threadIdx.x & 7, part = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int k = part; k < nblk; k += 32) {
+      a += (double)p[((int64_t)k * 2 + 0) * C + c];
+      b += (double)p[((int64_t)k * 2 + 1) * C + c];
+    }
+  sa[part][cl] = a;
+  sb[part][cl] = b;
+  __syncthreads();
+  if (part != 0 || c >= C) return;
+  for (int k = 1; k < 32; ++k) { a += sa[k][cl]; b += sb[k][cl]; }
+  const double m = a / (double)n;
+  double v = b / (double)n - m * m;
+  if (v < 0.0) v = 0.0;
+  float* o = stats + (int64_t)f * 4 * C;
+  o[c] = (float)m;
+  o[C + c] = (float)v;
+  o[2 * C + c] = (float)(1.0 / sqrt(v + (double)eps));
+  o[3 * C + c] = (float)(n > 1 ? v * ((double)n / (double)(n - 1)) : v);
+}
+
+// running statistics advanced once per frame, in frame order (what n_frames single-frame calls do)
+__global__ __launch_bounds__(256) void bn_running_frames_kernel(const float* __restrict__ stats, int C, int n_frames,
+                                                                BnFrames fr, float momentum,
+                                                                float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float rm = running_mean[c], rv = running_var[c];
+  for (int f = 0; f < n_frames; ++f) {
+    const int64_t n = fr.off[f + 1] - fr.off[f];
+    if (n <= 0) continue;
+    const float m = stats[(int64_t)f * 4 * C + c];
+    const float unbiased = stats[(int64_t)f * 4 * C + 3 * C + c];
+    rm = rm * (1.f - momentum) + momentum * m;
+    rv = rv * (1.f - momentum) + momentum * unbiased;
+  }
+  running_mean[c] = rm;
+  running_var[c] = rv;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_frames_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ z, int C, int relu, int64_t ld_z,
+                                                              BnFrames fr) {
+  const int f = blockIdx.y;
+  const int64_t rows = fr.off[f + 1] - fr.off[f];
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;          // float4 index inside the frame
+  if (t * 4 >= rows * C) return;
+  const int c = (int)((t * 4) % C);
+  const int64_t row = fr.off[f] + (t * 4) / C;
+  const float* st = stats + (int64_t)f * 4 * C;
+  const f4 v = *reinterpret_cast<const f4*>(x + row * C + c);
+  const f4 mu = *reinterpret_cast<const f4*>(st + c), is = *reinterpret_cast<const f4*>(st + 2 * C + c);
+  const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
+  f4 o = ga * ((v - mu) * is) + be;
+  if (relu) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = o[k] > 0.f ? o[k] : 0.f;
+  }
+  *reinterpret_cast<f4*>(z + row * ld_z + c) = o;
+}
+
+// bn_relu_max_kernel with the statistics of the group's frame (groups_per_frame consecutive groups per frame)
+__global__ __launch_bounds__(256) void bn_relu_max_frames_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 int64_t groups, int64_t groups_per_frame, int ns, int C,
+                                                                 float* __restrict__ zmax, int64_t ld_out,
+                                                                 int* __restrict__ arg) {
+  const int c4n = C >> 2;
+  const int tc = threadIdx.x % c4n, tr = threadIdx.x / c4n;
+  const int glanes = 256 / c4n;
+  if (tr >= glanes) return;
+  const int64_t m = (int64_t)blockIdx.x * glanes + tr;
+  if (m >= groups) return;
+  const int c = tc * 4;
+  const float* st = stats + (m / groups_per_frame) * 4 * C;
+  const f4 mu = *reinterpret_cast<const f4*>(st + c), is = *reinterpret_cast<const f4*>(st + 2 * C + c);
+  const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
+  const float* src = x + m * ns * C + c;
+  f4 best = (f4){-1.f, -1.f, -1.f, -1.f};
+  int bi[4] = {0, 0, 0, 0};
+  for (int s = 0; s < ns; ++s) {
+    const f4 v = *reinterpret_cast<const f4*>(src + (int64_t)s * C);
+    f4 o = ga * ((v - mu) * is) + be;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o[k] = o[k] > 0.f ? o[k] : 0.f;
+      if (o[k] > best[k]) { best[k] = o[k]; bi[k] = s; }
+    }
+  }
+  *reinterpret_cast<f4*>(zmax + m * ld_out + c) = best;
+  int* a = arg + m * C + c;
+  a[0] = bi[0]; a[1] = bi[1]; a[2] = bi[2]; a[3] = bi[3];
+}
+
 }  // namespace
 
 static inline int bn_blocks(int64_t n) { return crb_cdiv(n, bn_rows_per_block(n)); }
@@ -381,28 +530,68 @@ extern "C" int crb_bn_relu_max_backward(const float* x, const float* gz, int64_t
 // n_frames separate train-mode passes of one frame each compute (batched CRB stage 2: every frame normalises with its own
 // statistics, crb_sampling.py:174-212). The loop lives here so that a BatchNorm layer of a 16-frame pass costs one call from
 // the host language instead of 16. The batch statistics themselves are scratch (first 3*C floats of the workspace);
-// running statistics are updated once per frame, in frame order. workspace: crb_bn_frames_workspace_bytes(max rows, C).
-extern "C" int64_t crb_bn_frames_workspace_bytes(int64_t max_rows_per_frame, int C) {
-  return crb_bn_workspace_bytes(max_rows_per_frame, C) + (int64_t)crb_align_up(3 * C * (int64_t)sizeof(float), 256);
+// running statistics are updated once per frame, in frame order. workspace: crb_bn_frames_workspace_bytes(n_frames, max rows
+// of a frame, C) = partials of every frame + 4 C statistics per frame.
+extern "C" int64_t crb_bn_frames_workspace_bytes(int n_frames, int64_t max_rows_per_frame, int C) {
+  const int64_t f = n_frames < 1 ? 1 : (n_frames > BN_MAXF ? BN_MAXF : n_frames);     // more frames run in chunks of BN_MAXF
+  return f * crb_bn_workspace_bytes(max_rows_per_frame, C) + crb_align_up(f * 4 * C * (int64_t)sizeof(float), 256);
+}
+
+// statistics of up to BN_MAXF frames: partial sums, finalize, running update. stats (n_frames, 4, C) at the workspace head.
+static int bn_frames_statistics(const float* x, int n_frames, const int64_t* off, int C, float eps, float* running_mean,
+                                float* running_var, float momentum, void* workspace, int64_t workspace_bytes,
+                                BnFrames& fr, float** stats_out, int64_t* max_rows_out, hipStream_t st) {
+  if (n_frames <= 0 || n_frames > BN_MAXF || !off) return CRB_ERR_ARG;
+  if (C <= 0 || (C & 3) || C > 1024 || (256 % (C >> 2) && (C >> 2) < 256)) return CRB_ERR_ARG;
+  int slots = 0, max_blk = 0;
+  int64_t max_rows = 0;
+  for (int f = 0; f < n_frames; ++f) {
+    const int64_t n = off[f + 1] - off[f];
+    if (n < 0 || n == 1) return CRB_ERR_ARG;                 // a one-row batch has no variance (nn.BatchNorm raises too)
+    fr.off[f] = off[f];
+    fr.rpb[f] = n > 0 ? bn_rows_per_block(n) : 1;
+    fr.nblk[f] = n > 0 ? bn_blocks(n) : 0;
+    fr.pbase[f] = slots;
+    slots += fr.nblk[f];
+    max_blk = fr.nblk[f] > max_blk ? fr.nblk[f] : max_blk;
+    max_rows = n > max_rows ? n : max_rows;
+  }
+  fr.off[n_frames] = off[n_frames];
+  const int64_t head = crb_align_up((int64_t)n_frames * 4 * C * (int64_t)sizeof(float), 256);
+  if (!workspace || workspace_bytes < head + (int64_t)slots * 2 * C * 4) return CRB_ERR_WORKSPACE;
+  float* stats = (float*)workspace;
+  float* partial = (float*)((char*)workspace + head);
+  *stats_out = stats;
+  *max_rows_out = max_rows;
+  if (max_blk == 0) return CRB_OK;
+  hipLaunchKernelGGL(bn_partial_frames_kernel, dim3(max_blk, n_frames), dim3(256), 2 * 256 * 16, st, x, C, fr, partial);
+  hipLaunchKernelGGL(bn_finalize_frames_kernel, dim3(crb_cdiv(C, 8), n_frames), dim3(256), 0, st, partial, C, eps, fr, stats);
+  if (running_mean && running_var)
+    hipLaunchKernelGGL(bn_running_frames_kernel, dim3(crb_cdiv(C, 256)), dim3(256), 0, st, stats, C, n_frames, fr, momentum,
+                       running_mean, running_var);
+  return CRB_OK;
 }
 
 extern "C" int crb_bn_relu_forward_frames(const float* x, int n_frames, const int64_t* frame_row_offsets, int C,
                                           const float* gamma, const float* beta, float eps, int relu, float* z,
                                           int64_t z_row_stride, float* running_mean, float* running_var, float momentum,
                                           void* workspace, int64_t workspace_bytes, void* stream) {
-  if (n_frames <= 0 || !frame_row_offsets) return CRB_ERR_ARG;
   const int64_t ld_z = z_row_stride > 0 ? z_row_stride : C;
-  const int64_t head = crb_align_up(3 * C * (int64_t)sizeof(float), 256);
-  float* stats = (float*)workspace;
-  for (int f = 0; f < n_frames; ++f) {
-    const int64_t a = frame_row_offsets[f], b = frame_row_offsets[f + 1];
-    if (b <= a) continue;
-    if (b - a < 2) return CRB_ERR_ARG;                       // a one-row batch has no variance (nn.BatchNorm raises too)
-    int rc = crb_bn_relu_forward(x + a * C, b - a, C, gamma, beta, eps, relu, z + a * ld_z, ld_z, stats, stats + C,
-                                 stats + 2 * C, running_mean, running_var, momentum, (char*)workspace + head,
-                                 workspace_bytes - head, stream);
+  if (ld_z < C || (ld_z & 3) || n_frames <= 0 || !frame_row_offsets) return CRB_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  for (int f0 = 0; f0 < n_frames; f0 += BN_MAXF) {           // offsets are absolute rows: x and z stay unshifted
+    const int nf = n_frames - f0 < BN_MAXF ? n_frames - f0 : BN_MAXF;
+    BnFrames fr;
+    float* stats = nullptr;
+    int64_t max_rows = 0;
+    int rc = bn_frames_statistics(x, nf, frame_row_offsets + f0, C, eps, running_mean, running_var, momentum, workspace,
+                                  workspace_bytes, fr, &stats, &max_rows, st);
     if (rc != CRB_OK) return rc;
+    if (max_rows > 0)
+      hipLaunchKernelGGL(bn_apply_frames_kernel, dim3(crb_cdiv(max_rows * C / 4, 256), nf), dim3(256), 0, st, x, stats, gamma,
+                         beta, z, C, relu, ld_z, fr);
   }
+  CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
 
@@ -412,17 +601,27 @@ extern "C" int crb_bn_relu_max_forward_frames(const float* x, int n_frames, int6
                                               const float* gamma, const float* beta, float eps, float* zmax,
                                               int64_t out_row_stride, int32_t* arg, float* running_mean, float* running_var,
                                               float momentum, void* workspace, int64_t workspace_bytes, void* stream) {
-  if (n_frames <= 0 || groups_per_frame <= 0) return CRB_ERR_ARG;
+  if (n_frames <= 0 || groups_per_frame <= 0 || ns <= 0) return CRB_ERR_ARG;
   const int64_t ld = out_row_stride > 0 ? out_row_stride : C;
-  const int64_t head = crb_align_up(3 * C * (int64_t)sizeof(float), 256);
-  float* stats = (float*)workspace;
-  for (int f = 0; f < n_frames; ++f) {
-    const int64_t g0 = (int64_t)f * groups_per_frame;
-    int rc = crb_bn_relu_max_forward(x + g0 * ns * C, groups_per_frame, ns, C, gamma, beta, eps, zmax + g0 * ld, ld,
-                                     arg + g0 * C, stats, stats + C, stats + 2 * C, running_mean, running_var, momentum,
-                                     (char*)workspace + head, workspace_bytes - head, stream);
+  if (ld < C || (ld & 3)) return CRB_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int glanes = 256 / (C >> 2) > 0 ? 256 / (C >> 2) : 1;
+  for (int f0 = 0; f0 < n_frames; f0 += BN_MAXF) {
+    const int nf = n_frames - f0 < BN_MAXF ? n_frames - f0 : BN_MAXF;
+    const int64_t g0 = (int64_t)f0 * groups_per_frame;
+    int64_t off[BN_MAXF + 1];
+    for (int f = 0; f <= nf; ++f) off[f] = (int64_t)f * groups_per_frame * ns;            // relative to the chunk's rows
+    BnFrames fr;
+    float* stats = nullptr;
+    int64_t max_rows = 0;
+    int rc = bn_frames_statistics(x + g0 * ns * C, nf, off, C, eps, running_mean, running_var, momentum, workspace,
+                                  workspace_bytes, fr, &stats, &max_rows, st);
     if (rc != CRB_OK) return rc;
+    const int64_t groups = (int64_t)nf * groups_per_frame;
+    hipLaunchKernelGGL(bn_relu_max_frames_kernel, dim3(crb_cdiv(groups, glanes)), dim3(256), 0, st, x + g0 * ns * C, stats,
+                       gamma, beta, groups, groups_per_frame, ns, C, zmax + g0 * ld, ld, arg + g0 * C);
   }
+  CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
 

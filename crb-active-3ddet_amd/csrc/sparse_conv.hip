@@ -253,12 +253,27 @@ __device__ unsigned long long g_fwd2_timing[16];
 // exclusive prefix of the masks' popcounts): 8 + 4 P/N bytes per row instead of 4 K (22 against 108 at the 16-channel level,
 // where the table was 40 % of the launch's HBM bytes). A row's neighbour through offset o is
 // packed[cbase[row] + popcount(mask & ((1 << o) - 1))] when bit o is set.
+// Optional epilogue of the forward kernel (inference): y = relu(gamma * ((acc + bias - mean) * rsqrt(var + eps)) + beta) per
+// output channel — the conv bias, the BatchNorm1d of the running statistics and the ReLU that follow a sparse conv in the
+// reference's post_act_block, in the arithmetic order of bn_apply_kernel (crb_bn_relu_apply). mean == nullptr: plain conv.
+struct ConvEpilogue {
+  const float* bias;
+  const float* gamma;
+  const float* beta;
+  const float* mean;
+  const float* var;
+  float eps;
+  int relu;
+};
+
 template <int CIN, int COUT, bool NOMFMA = false, bool REMAP = true, bool TIMING = false, bool COMPACT = false>
 __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                                const int* __restrict__ nbr, const int* __restrict__ perm,
                                                                float* __restrict__ Y, int n_out, int K, int ntiles,
                                                                const unsigned* __restrict__ cmask = nullptr,
-                                                               const int* __restrict__ cbase = nullptr) {
+                                                               const int* __restrict__ cbase = nullptr,
+                                                               ConvEpilogue ep = ConvEpilogue{nullptr, nullptr, nullptr, nullptr,
+                                                                                              nullptr, 0.f, 0}) {
   static_assert(CIN % 16 == 0 && COUT % 16 == 0, "v2 needs whole float4 k-groups and unmasked column blocks");
   constexpr int NB = (COUT + 15) / 16;
   constexpr int WS = NB * 16;
@@ -467,6 +482,21 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
     }
   }
 
+  if (ep.mean != nullptr) {                          // wave-uniform
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int c = nb * 16 + li;
+      const float mu = ep.mean[c], is = rsqrtf(ep.var[c] + ep.eps), ga = ep.gamma[c], be = ep.beta[c];
+      const float bi = ep.bias ? ep.bias[c] : 0.f;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        float v = acc[nb][rg];
+        if (ep.bias) v = v + bi;
+        v = ga * ((v - mu) * is) + be;
+        acc[nb][rg] = (ep.relu && !(v > 0.f)) ? 0.f : v;
+      }
+    }
+  }
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) {
     if (out_row[rg] >= 0) {
@@ -1367,13 +1397,14 @@ int launch_fwd(const float* X, const float* W, const int* nbr, const int* perm, 
 
 template <int CIN, int COUT>
 int launch_fwd_compact(const float* X, const float* W, const unsigned* cmask, const int* cbase, const int* packed,
-                       const int* perm, float* Y, int64_t n_out, int K, hipStream_t st) {
+                       const int* perm, float* Y, int64_t n_out, int K, hipStream_t st,
+                       ConvEpilogue ep = ConvEpilogue{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0}) {
   if constexpr (CIN % 16 == 0 && COUT % 16 == 0 && CIN <= 64) {
     const int ntiles = crb_cdiv(n_out, 64);
     const int grid = ((ntiles + 7) / 8) * 8;
     size_t lds = 2 * sizeof(float) * CIN * (((COUT + 15) / 16) * 16) + sizeof(int) * 64 * K + 16;
     hipLaunchKernelGGL((sparse_conv_fwd2_kernel<CIN, COUT, false, true, false, true>), dim3(grid), dim3(256), lds, st, X, W,
-                       packed, perm, Y, (int)n_out, K, ntiles, cmask, cbase);
+                       packed, perm, Y, (int)n_out, K, ntiles, cmask, cbase, ep);
     CRB_CHECK_LAUNCH();
     return CRB_OK;
   }
@@ -1584,6 +1615,22 @@ extern "C" int crb_sparse_conv_forward_compact(const float* X, const float* W, c
   if (n_out == 0) return CRB_OK;
   hipStream_t st = (hipStream_t)stream;
 #define X_(a, b) if (cin == a && cout == b) return launch_fwd_compact<a, b>(X, W, cmask, cbase, packed, perm, Y, n_out, K, st);
+  CRB_CONV_SHAPES(X_)
+#undef X_
+  return CRB_ERR_UNSUPPORTED;
+}
+
+extern "C" int crb_sparse_conv_forward_compact_bn(const float* X, const float* W, const uint32_t* cmask, const int32_t* cbase,
+                                                  const int32_t* packed, const int32_t* perm, float* Y, int64_t n_out, int K,
+                                                  int cin, int cout, const float* bias, const float* gamma, const float* beta,
+                                                  const float* running_mean, const float* running_var, float eps, int relu,
+                                                  void* stream) {
+  if (n_out < 0 || K <= 0 || K > 32 || !gamma || !beta || !running_mean || !running_var) return CRB_ERR_ARG;
+  if (n_out == 0) return CRB_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const ConvEpilogue ep{bias, gamma, beta, running_mean, running_var, eps, relu};
+#define X_(a, b) \
+  if (cin == a && cout == b) return launch_fwd_compact<a, b>(X, W, cmask, cbase, packed, perm, Y, n_out, K, st, ep);
   CRB_CONV_SHAPES(X_)
 #undef X_
   return CRB_ERR_UNSUPPORTED;

@@ -66,6 +66,11 @@ class SparseConvolution(SparseModule):
     def _k3(self, v, fill):
         return ([fill] + list(v)) if self.ndim == 2 else list(v)
 
+    def fuses_bn_eval(self, feats):
+        """can this conv take the following BatchNorm1d(eval) + ReLU as an epilogue of its forward kernel?"""
+        return (not self.inverse and not self.conv1x1 and feats.is_cuda and feats.shape[0] > 0 and
+                _sp.epilogue_supported(self.in_channels, self.out_channels))
+
     def weight_kio(self):
         """(Cout,k..,Cin) -> (K,Cin,Cout) contiguous; differentiable"""
         w = self.weight
@@ -74,7 +79,9 @@ class SparseConvolution(SparseModule):
             K *= k
         return w.reshape(self.out_channels, K, self.in_channels).permute(1, 2, 0).contiguous()
 
-    def forward(self, input):
+    def forward(self, input, epilogue=None):
+        """epilogue = (BatchNorm1d in eval mode, relu flag): inference only (SparseSequential decides), the conv bias, the
+        normalisation and the ReLU are then applied inside the forward kernel"""
         assert isinstance(input, SparseConvTensor)
         feats, indices = input.features, input.indices
         ndim = self.ndim
@@ -113,9 +120,12 @@ class SparseConvolution(SparseModule):
                     rb = _sp.spconv_rulebook(idx3, shape3, input.batch_size, ks, st, pd)
                 if self.indice_key is not None:
                     input.indice_dict[self.indice_key] = rb
-            out_feats = _sp.sparse_conv(feats, self.weight_kio(), rb, False)
+            if epilogue is not None:
+                out_feats = _sp.sparse_conv_bn_eval(feats, self.weight_kio(), rb, self.bias, epilogue[0], epilogue[1])
+            else:
+                out_feats = _sp.sparse_conv(feats, self.weight_kio(), rb, False)
             out_indices3, out_shape3 = (idx3, shape3) if self.subm else (rb.out_coords, rb.out_shape)
-        if self.bias is not None:
+        if self.bias is not None and epilogue is None:
             out_feats = out_feats + self.bias
         if ndim == 2:
             out_indices = out_indices3[:, [0, 2, 3]].contiguous()

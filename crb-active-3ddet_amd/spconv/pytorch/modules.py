@@ -2,11 +2,14 @@
 (pcdet/models/backbones_3d/spconv_backbone.py:21-25,77-117)."""
 from collections import OrderedDict
 
+import torch
 from torch import nn
 
 from crbhip import bnrelu as _bnrelu
 from .core import SparseConvTensor
 
+FUSE_CONV_BN_EVAL = True  # inference (no grad, BatchNorm1d in eval mode): conv -> BatchNorm1d -> ReLU triples run as ONE launch,
+                          # normalisation and ReLU applied to the accumulator (crb_sparse_conv_forward_compact_bn)
 FUSE_BN_RELU = True      # run BatchNorm1d -> ReLU pairs that follow a sparse conv as one fused HIP op (same modules,
                          # same parameters / buffers / state_dict; set False for the plain torch path)
 
@@ -61,7 +64,15 @@ class SparseSequential(SparseModule):
             module = mods[i]
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
-                input = module(input)
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                if (FUSE_CONV_BN_EVAL and not torch.is_grad_enabled() and hasattr(module, 'fuses_bn_eval') and
+                        isinstance(nxt, nn.BatchNorm1d) and not nxt.training and nxt.affine and
+                        nxt.running_mean is not None and module.fuses_bn_eval(input.features)):
+                    relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                    input = module(input, epilogue=(nxt, relu))
+                    i += 1 + int(relu)                  # BatchNorm1d (and ReLU) consumed by the conv's epilogue
+                else:
+                    input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
                     feats = input.features

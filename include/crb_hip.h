@@ -135,6 +135,17 @@ int crb_sparse_conv_forward_compact(const float* X, const float* W, const uint32
                                     const int32_t* packed, const int32_t* perm, float* Y, int64_t n_out, int K, int cin,
                                     int cout, void* stream);
 
+/* Inference epilogue in the gather-GEMM: y = relu(gamma * ((conv + bias - running_mean) * rsqrt(running_var + eps)) + beta),
+ * i.e. the (bias,) nn.BatchNorm1d in eval mode and nn.ReLU that follow a sparse conv in post_act_block
+ * (pcdet/models/backbones_3d/spconv_backbone.py:8-31), evaluated on the accumulator before the store instead of in two more
+ * passes over the rows; same arithmetic order as crb_bn_relu_apply. bias may be NULL; relu 0/1. Shapes of
+ * crb_sparse_conv_compact_supported only. */
+int crb_sparse_conv_forward_compact_bn(const float* X, const float* W, const uint32_t* cmask, const int32_t* cbase,
+                                       const int32_t* packed, const int32_t* perm, float* Y, int64_t n_out, int K, int cin,
+                                       int cout, const float* bias, const float* gamma, const float* beta,
+                                       const float* running_mean, const float* running_var, float eps, int relu,
+                                       void* stream);
+
 /* OPT-IN arithmetic contract "bf16x3" for the same gather-GEMM (exact f32 above stays the default): every operand is split
  * into two bf16 values, x = x_hi + x_lo (+ a residual <= 2^-18 |x|), and a product is taken as x_lo*w_hi + x_hi*w_lo +
  * x_hi*w_hi on the bf16 MFMA (products exact, f32 accumulation; x_lo*w_lo dropped). Stated bound, checked by
@@ -395,10 +406,11 @@ int crb_bn_relu_max_backward(const float* x, const float* gz, int64_t gz_row_str
                              float* dx, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
                              void* stream);
 /* Per-frame statistics (batched CRB stage 2: G frames per train-mode pass, every BatchNorm layer normalising each frame
- * with that frame's own batch statistics like G bs=1 passes, crb_sampling.py:174-212): the forward launches above once per
- * frame row range. frame_row_offsets is a HOST int64[n_frames+1] array; the batch statistics are scratch, running
+ * with that frame's own batch statistics like G bs=1 passes, crb_sampling.py:174-212): four launches for all frames
+ * (partial sums / finalize / running update / apply, a frame's rows cut into the blocks a single-frame call would use and
+ * summed in the same order: bit-identical to n_frames calls of the forward above on the frames' row ranges). frame_row_offsets is a HOST int64[n_frames+1] array; the batch statistics are scratch, running
  * statistics are updated once per frame in frame order. Forward only (stage 2 differentiates the RoI-head FC stack only). */
-int64_t crb_bn_frames_workspace_bytes(int64_t max_rows_per_frame, int C);
+int64_t crb_bn_frames_workspace_bytes(int n_frames, int64_t max_rows_per_frame, int C);
 int crb_bn_relu_forward_frames(const float* x, int n_frames, const int64_t* frame_row_offsets, int C, const float* gamma,
                                const float* beta, float eps, int relu, float* z, int64_t z_row_stride,
                                float* running_mean, float* running_var, float momentum, void* workspace,

@@ -1,0 +1,65 @@
+"""GPU: BatchNorm with per-frame statistics for a batch of frames (crb_bn_relu_forward_frames /
+crb_bn_relu_max_forward_frames, four launches for all frames) against the per-frame calls of the single-frame entry points
+they replace — bit-identical outputs and running statistics (same blocks, same summation order, running statistics advanced
+frame after frame), ragged frames, an empty frame, more frames than one launch carries."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bn(C, dev, seed):
+    torch.manual_seed(seed)
+    bn = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).to(dev).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.2)
+        bn.running_var.uniform_(0.5, 1.5)
+    return bn
+
+
+def _clone_bn(bn):
+    import copy
+    return copy.deepcopy(bn)
+
+
+@pytest.mark.parametrize('C,rows', [(16, [5000, 0, 131, 70000, 2, 999]), (128, [35200] * 4), (64, [257] * 70)])
+def test_frames_forward_equals_single_frame_calls(dev, C, rows):
+    from crbhip import bnrelu
+    off = [0] + list(np.cumsum(rows))
+    g = torch.Generator(device=dev).manual_seed(C)
+    x = torch.randn(off[-1], C, device=dev, generator=g) * 2 + 0.5
+    bn_a, bn_b = _bn(C, dev, 1), None
+    bn_b = _clone_bn(bn_a)
+    with torch.no_grad():
+        z_frames = bnrelu._frames_forward(x, off, bn_a, True)
+        parts = [bnrelu.bn_relu(x[a:b].contiguous(), bn_b, True) for a, b in zip(off[:-1], off[1:]) if b > a]
+    z_loop = torch.cat(parts, 0)
+    assert torch.equal(z_frames, z_loop)
+    assert torch.equal(bn_a.running_mean, bn_b.running_mean) and torch.equal(bn_a.running_var, bn_b.running_var)
+    assert float((z_frames > 0).float().mean()) > 0.2
+
+
+def test_frames_max_forward_equals_single_frame_calls(dev):
+    """the StackSAModuleMSG tail (BatchNorm + ReLU + max over nsample + concat of the scales) under frame_groups(G)"""
+    from crbhip import bnrelu
+    G, m, C = 5, 300, 32
+    nss = [16, 32]
+    g = torch.Generator(device=dev).manual_seed(3)
+    xs = [torch.randn(G * m * ns, C, device=dev, generator=g) for ns in nss]
+    bns_a = [_bn(C, dev, 10 + k) for k in range(2)]
+    bns_b = [_clone_bn(b) for b in bns_a]
+    with torch.no_grad():
+        with bnrelu.frame_groups(G):
+            out = bnrelu.bn_relu_max_concat(xs, nss, bns_a)
+        ref = []
+        for f in range(G):
+            ref.append(bnrelu.bn_relu_max_concat([x[f * m * ns:(f + 1) * m * ns].contiguous() for x, ns in zip(xs, nss)], nss,
+                                                 bns_b))
+    ref = torch.cat([r if torch.is_tensor(r) else r[0] for r in ref], 0)
+    out = out if torch.is_tensor(out) else out[0]
+    assert torch.equal(out, ref)
+    for a, b in zip(bns_a, bns_b):
+        assert torch.equal(a.running_mean, b.running_mean) and torch.equal(a.running_var, b.running_var)

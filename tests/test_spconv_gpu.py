@@ -666,3 +666,43 @@ def test_bf16x3_strided_conv_out_layer(dev):
                   oracle.conv_fwd(np.abs(X), np.abs(W), nbr).astype(np.float64))
     _bf16x3_check(x.grad.cpu().numpy(), oracle.conv_dgrad(dY, W, nbr, n).astype(np.float64),
                   oracle.conv_dgrad(np.abs(dY), np.abs(W), nbr, n).astype(np.float64))
+
+
+@pytest.mark.parametrize('cin,cout,bias', [(16, 16, False), (32, 64, True), (64, 64, False), (64, 128, False)])
+def test_eval_conv_bn_relu_epilogue_equals_the_three_modules(dev, cin, cout, bias):
+    """inference: SparseSequential(conv, BatchNorm1d, ReLU) with BatchNorm in eval mode runs as ONE launch (normalisation and
+    ReLU on the accumulator, crb_sparse_conv_forward_compact_bn). Same arithmetic order as conv -> crb_bn_relu_apply:
+    results equal the unfused path to 1e-6 of the largest magnitude (rsqrt of the epilogue vs torch.rsqrt), for a SubM
+    and a strided block, with and without conv bias; with grad enabled or BatchNorm in train mode nothing is fused."""
+    import spconv.pytorch as spconv
+    from spconv.pytorch import modules as spm
+    rng = np.random.default_rng(900 + cin + cout)
+    shape = [21, 100, 88]
+    coords = random_sparse_coords(rng, 5000, 2, shape)
+    n = len(coords)
+    torch.manual_seed(cin * 131 + cout)
+    blocks = [spconv.SparseSequential(spconv.SubMConv3d(cin, cout, 3, bias=bias, indice_key='s'),
+                                      torch.nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01), torch.nn.ReLU()),
+              spconv.SparseSequential(spconv.SparseConv3d(cin, cout, 3, stride=2, padding=1, bias=bias, indice_key='d'),
+                                      torch.nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01), torch.nn.ReLU())]
+    for blk in blocks:
+        blk.to(dev).eval()
+        with torch.no_grad():
+            blk[1].running_mean.normal_(0, 0.5)
+            blk[1].running_var.uniform_(0.3, 2.0)
+            blk[1].weight.uniform_(0.5, 1.5)
+            blk[1].bias.normal_(0, 0.3)
+        x = spconv.SparseConvTensor(_t(rng.normal(size=(n, cin)).astype(np.float32), dev), _t(coords, dev), shape, 2)
+        with torch.no_grad():
+            fused = blk(x).features
+            spm.FUSE_CONV_BN_EVAL = False
+            try:
+                plain = blk(x).features
+            finally:
+                spm.FUSE_CONV_BN_EVAL = True
+        assert fused.shape == plain.shape and float((plain > 0).float().mean()) > 0.2
+        tol = 1e-6 * float(plain.abs().max())
+        assert float((fused - plain).abs().max()) <= tol, float((fused - plain).abs().max())
+        with torch.enable_grad():                      # grad mode: the module path, untouched
+            y = blk(spconv.SparseConvTensor(x.features.clone().requires_grad_(True), x.indices, shape, 2)).features
+        assert y.requires_grad and float((y.detach() - plain).abs().max()) <= 1e-5 * float(plain.abs().max())

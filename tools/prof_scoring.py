@@ -10,6 +10,6 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 if __name__ == '__main__':
-    a = argparse.Namespace(scoring_frames=32, points=20000)
+    a = argparse.Namespace(scoring_pool=96, scoring_repeats=2, points=20000)
     torch.cuda.set_device(0)
     print(bench.crb_scoring_bench(a, 0, 1, torch.device('cuda', 0)))
