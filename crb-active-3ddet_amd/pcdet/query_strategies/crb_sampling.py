@@ -19,6 +19,11 @@ from . import scoring
 from .strategy import Strategy
 
 
+def _chain(model):
+    """the detector's modules in execution order (Detector3DTemplate.scheduled_modules: dense half before the PFE)"""
+    return model.scheduled_modules() if hasattr(model, 'scheduled_modules') else list(model.module_list)
+
+
 class CRBSampling(Strategy):
     def __init__(self, model, labelled_loader, unlabelled_loader, rank, active_label_dir, cfg):
         super().__init__(model, labelled_loader, unlabelled_loader, rank, active_label_dir, cfg)
@@ -61,7 +66,7 @@ class CRBSampling(Strategy):
             batch = dict(batch)
             if getattr(model, 'pfe', None) is not None and hasattr(model.pfe, 'prefetch_keypoints'):
                 model.pfe.prefetch_keypoints(batch)          # FPS on a side stream, as PVRCNN.forward does
-            for mod in model.module_list:
+            for mod in _chain(model):
                 batch = mod(batch)
             rows.append(scoring.pack_records(crb_frame_records(model, batch), self.layout))
         if not rows:
@@ -116,7 +121,7 @@ class CRBSampling(Strategy):
             if '_keypoints_prefetched' not in batch and getattr(model, 'pfe', None) is not None \
                     and hasattr(model.pfe, 'prefetch_keypoints'):
                 model.pfe.prefetch_keypoints(batch)
-            for mod in model.module_list:
+            for mod in _chain(model):
                 batch = mod(batch)
             rcnn_cls, rcnn_reg = batch['rcnn_cls'], batch['rcnn_reg']
         else:
@@ -266,7 +271,7 @@ class CRBSampling(Strategy):
                 with torch.no_grad():
                     if getattr(model, 'pfe', None) is not None and hasattr(model.pfe, 'prefetch_keypoints'):
                         model.pfe.prefetch_keypoints(batch)
-                    for mod in model.module_list:
+                    for mod in _chain(model):
                         if mod is head:
                             break
                         batch = mod(batch)

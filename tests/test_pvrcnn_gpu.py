@@ -199,3 +199,27 @@ def test_ragged_batch_train_and_scoring(model, dev):
             assert bool((kk[:64, None, :] == seg[None, :, :]).all(-1).any(1).all())
         rows = scoring.pack_records(crb_frame_records(model, b))
     assert rows.shape == (3, scoring.REC_STRIDE) and torch.isfinite(rows).all()
+
+
+def test_dense_half_before_pfe_schedule_gives_identical_outputs(model, dev):
+    """Detector3DTemplate.scheduled_modules runs BACKBONE_2D + DENSE_HEAD before the PFE (they commute: the PFE reads the
+    BEV input map, not their outputs) so that the keypoint FPS on the side stream is hidden: same module set, every output
+    of the chain bit-identical to the reference order, in eval (dropout off) and in the training forward."""
+    order = [type(m).__name__ for m in model.scheduled_modules()]
+    ref_order = [type(m).__name__ for m in model.module_list]
+    assert sorted(order) == sorted(ref_order) and order != ref_order
+    assert order.index('BaseBEVBackbone') < order.index('VoxelSetAbstraction') < order.index('PointHeadSimple')
+    model.eval()
+    outs = []
+    for flag in (True, False):
+        type(model).DENSE_BEFORE_PFE = flag
+        try:
+            b, *_ = _batch(dev, 7, 2)
+            with torch.no_grad():
+                b = model.run_modules(b)
+            outs.append({k: b[k] for k in ('rois', 'point_features', 'batch_cls_preds', 'batch_box_preds', 'rcnn_cls',
+                                           'rcnn_reg', 'spatial_features_2d')})
+        finally:
+            type(model).DENSE_BEFORE_PFE = True
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), (k, float((outs[0][k] - outs[1][k]).abs().max()))

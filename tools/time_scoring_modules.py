@@ -25,7 +25,7 @@ with torch.no_grad():
     for it in range(6):
         b = dict(base)
         torch.cuda.synchronize(); t_all = time.perf_counter()
-        for mod in model.module_list:
+        for mod in model.scheduled_modules():
             t0 = time.perf_counter()
             b = mod(b)
             torch.cuda.synchronize()

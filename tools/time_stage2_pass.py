@@ -32,7 +32,7 @@ if __name__ == '__main__':
         batch = dict(base)
         t = {}
         with per_frame_batchnorm(model, G), torch.no_grad():
-            for mod in model.module_list:
+            for mod in model.scheduled_modules():
                 if mod is head:
                     break
                 torch.cuda.synchronize(); t0 = time.perf_counter()
