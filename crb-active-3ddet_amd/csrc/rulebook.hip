@@ -219,14 +219,54 @@ __global__ void fill_i32_kernel(int* p, int64_t n, int v) {
 // One 1024-thread workgroup per chunk; bitonic network on 64-bit (mask << 32 | local index) keys in LDS.
 constexpr int SORT_CHUNK = 4096;
 
-__global__ __launch_bounds__(1024) void mask_sort_chunks_kernel(const int* __restrict__ mask, int n, int* __restrict__ perm) {
+// Sort key of a row: its mask with the bits re-ranked so that the RAREST offsets are the most significant. A 16-row tile pays
+// a full MFMA pass for an offset as soon as ONE of its rows has it, so what has to be clustered is the rare offsets; in plain
+// numeric order only the corners of the +z plane of a 3x3x3 kernel were on top. rank_bits 2 (default): bits ranked by their
+// frequency inside the chunk (works for every kernel size and for transposed / strided tables); 1: by geometry (8 corners, 12
+// edges, 6 faces, centre of a 3x3x3 kernel); 0: numeric. Any bijection of the bits keeps equal masks adjacent. Measured on the
+// SECOND bs=16 tables (tools/ab_sort_key.py): tile fill 0.823 -> 0.849 (L3), 0.769 -> 0.830 (L4); 64x64 forward 153.6 -> 147.1
+// us (L3), 115.3 -> 100.7 us (L4); 32x32 55.5 -> 52.8 us.
+struct SortBits { unsigned char pos[32]; };
+
+__global__ __launch_bounds__(1024) void mask_sort_chunks_kernel(const int* __restrict__ mask, int n, int* __restrict__ perm,
+                                                                SortBits sb, int rank_bits) {
   __shared__ unsigned long long key[SORT_CHUNK];
+  __shared__ int hist[32];
+  __shared__ unsigned char lpos[32];
   const int base = blockIdx.x * SORT_CHUNK;
+  if (rank_bits == 2) {                               // rank the bits by how rare they are IN THIS CHUNK
+    if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+    __syncthreads();
+    int cnt = 0;                                       // lane b of a wave accumulates the wave's count of bit b
+    for (int t = threadIdx.x; t < SORT_CHUNK; t += 1024) {
+      const int i = base + t;
+      const unsigned m = (i < n) ? (unsigned)mask[i] : 0u;
+      for (int b = 0; b < 32; ++b) {
+        const int c = __popcll(__ballot((m >> b) & 1u));
+        if ((int)(threadIdx.x & 63) == b) cnt += c;
+      }
+    }
+    if ((threadIdx.x & 63) < 32 && cnt) atomicAdd(&hist[threadIdx.x & 63], cnt);
+    __syncthreads();
+    if (threadIdx.x < 32) {                           // position = number of bits that are more frequent (ties: lower index)
+      const int mine = hist[threadIdx.x];
+      int p = 0;
+      for (int b = 0; b < 32; ++b) p += (hist[b] > mine) || (hist[b] == mine && b < (int)threadIdx.x);
+      lpos[threadIdx.x] = (unsigned char)p;
+    }
+    __syncthreads();
+  }
   for (int t = threadIdx.x; t < SORT_CHUNK; t += 1024) {
     const int i = base + t;
-    // descending mask order: the rows with the most neighbours (longest-running tiles) come first inside every chunk, so
+    // descending order: the rows with the most (rare) neighbours (longest-running tiles) come first inside every chunk, so
     // the last tiles a launch dispatches are light ones (no heavy-tile tail); equal masks stay adjacent either way
-    key[t] = (i < n) ? (((unsigned long long)(~(unsigned)mask[i]) << 32) | (unsigned)t) : ~0ULL;
+    unsigned m = (i < n) ? (unsigned)mask[i] : 0u;
+    if (rank_bits) {
+      unsigned r = 0;
+      for (int b = 0; b < 32; ++b) r |= ((m >> b) & 1u) << (rank_bits == 2 ? lpos[b] : sb.pos[b]);
+      m = r;
+    }
+    key[t] = (i < n) ? (((unsigned long long)(~m) << 32) | (unsigned)t) : ~0ULL;
   }
   __syncthreads();
   for (int k = 2; k <= SORT_CHUNK; k <<= 1)
@@ -295,12 +335,24 @@ __global__ __launch_bounds__(256) void tile_perm_kernel(const int* __restrict__ 
 
 extern "C" int crb_mask_sort_chunk_rows(void) { return SORT_CHUNK; }
 
+static int g_sort_rank_bits = 2;    // sort key: 2 = bits ranked rarest first inside the chunk (default), 1 = by 3x3x3 geometry, 0 = numeric
+extern "C" int crb_mask_sort_set_rank_bits(int mode) { g_sort_rank_bits = (mode >= 0 && mode <= 2) ? mode : 2; return CRB_OK; }
+
 // perm (n) i32: row permutation that sorts every chunk of crb_mask_sort_chunk_rows() consecutive rows by mask (stable)
 extern "C" int crb_mask_sort_chunks(const int32_t* mask, int64_t n, int32_t* perm, void* stream) {
   if (n < 0) return CRB_ERR_ARG;
   if (n == 0) return CRB_OK;
+  SortBits sb;
+  {
+    int next[4] = {0, 1, 7, 19};                       // first bit of the class with 0 / 1 / 2 / 3 non-zero coordinates
+    for (int o = 0; o < 32; ++o) {
+      if (o >= 27) { sb.pos[o] = (unsigned char)o; continue; }
+      const int nz = (o / 9 != 1) + ((o / 3) % 3 != 1) + (o % 3 != 1);
+      sb.pos[o] = (unsigned char)next[nz]++;
+    }
+  }
   hipLaunchKernelGGL(mask_sort_chunks_kernel, dim3(crb_cdiv(n, SORT_CHUNK)), dim3(1024), 0, (hipStream_t)stream, mask,
-                     (int)n, perm);
+                     (int)n, perm, sb, g_sort_rank_bits);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

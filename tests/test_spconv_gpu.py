@@ -261,20 +261,54 @@ def test_spconv_module_api_backbone_chain(dev):
     assert d.shape == (2, 128, 2, 200, 176)
 
 
-def test_chunk_mask_sort_is_a_stable_sort_per_chunk(dev):
-    """the LDS bitonic chunk sort equals a stable sort by (chunk, unsigned mask DESCENDING: heaviest tiles first) — the
-    gather-GEMM result does not depend on it, the MFMA skipping efficiency and the launch tail do"""
+def _rank_bits_key(mask, chunk, mode):
+    """numpy restatement of the sort key of mask_sort_chunks_kernel: 0 = the mask itself; 1 = bits re-ranked rarest offset of
+    a 3x3x3 kernel first (corners, edges, faces, centre); 2 = bits re-ranked by their frequency inside the chunk (rarest = most
+    significant, ties by bit index)"""
+    m = mask.astype(np.int64) & 0xffffffff
+    n = len(m)
+    out = np.zeros(n, np.int64)
+    for c0 in range(0, n, chunk):
+        mc = m[c0:c0 + chunk]
+        if mode == 0:
+            pos = np.arange(32)
+        elif mode == 1:
+            nxt, pos = [0, 1, 7, 19], np.arange(32)
+            for o in range(27):
+                nz = (o // 9 != 1) + ((o // 3) % 3 != 1) + (o % 3 != 1)
+                pos[o] = nxt[nz]
+                nxt[nz] += 1
+        else:
+            hist = np.array([int(((mc >> b) & 1).sum()) for b in range(32)])
+            pos = np.array([int(((hist > hist[b]) | ((hist == hist[b]) & (np.arange(32) < b))).sum()) for b in range(32)])
+        r = np.zeros(len(mc), np.int64)
+        for b in range(32):
+            r |= ((mc >> b) & 1) << int(pos[b])
+        out[c0:c0 + chunk] = r
+    return out
+
+
+@pytest.mark.parametrize('mode', [0, 1, 2])
+def test_chunk_mask_sort_is_a_stable_sort_per_chunk(dev, mode):
+    """the LDS bitonic chunk sort equals a stable sort by (chunk, key DESCENDING: heaviest tiles first), key = the mask with
+    its bits re-ranked rarest first (mode 2, the default: by frequency inside the chunk; 1: by the geometry of a 3x3x3
+    kernel; 0: plain mask) — the gather-GEMM result does not depend on it, the MFMA tile fill and the launch tail do"""
     from crbhip import lib, check, ptr, cur_stream
     rng = np.random.default_rng(3)
-    for n in (1, 100, 4096, 4097, 50000):
-        mask = rng.integers(0, 1 << 27, n).astype(np.int32)
-        mask[rng.random(n) < 0.5] = 7                         # many ties
-        m = _t(mask, dev)
-        perm = torch.empty(n, dtype=torch.int32, device=dev)
-        check(lib.crb_mask_sort_chunks(ptr(m), n, ptr(perm), cur_stream(dev)), 'sort')
-        chunk = lib.crb_mask_sort_chunk_rows()
-        key = (np.arange(n) // chunk).astype(np.int64) * (1 << 32) + ((~mask.astype(np.int64)) & 0xffffffff)
-        np.testing.assert_array_equal(perm.cpu().numpy(), np.argsort(key, kind='stable'))
+    lib.crb_mask_sort_set_rank_bits(mode)
+    try:
+        for n in (1, 100, 4096, 4097, 50000):
+            mask = (rng.integers(0, 1 << 27, n) & rng.integers(0, 1 << 27, n)).astype(np.int32)   # bits at 25 %: skewed by hand below
+            mask |= (rng.random(n) < 0.9).astype(np.int32) << 13
+            mask[rng.random(n) < 0.5] = 7                         # many ties
+            m = _t(mask, dev)
+            perm = torch.empty(n, dtype=torch.int32, device=dev)
+            check(lib.crb_mask_sort_chunks(ptr(m), n, ptr(perm), cur_stream(dev)), 'sort')
+            chunk = lib.crb_mask_sort_chunk_rows()
+            key = (np.arange(n) // chunk).astype(np.int64) * (1 << 32) + ((~_rank_bits_key(mask, chunk, mode)) & 0xffffffff)
+            np.testing.assert_array_equal(perm.cpu().numpy(), np.argsort(key, kind='stable'))
+    finally:
+        lib.crb_mask_sort_set_rank_bits(2)
 
 
 def test_tile_lpt_perm_orders_whole_tiles_heaviest_first(dev):
