@@ -217,7 +217,7 @@ __global__ void fill_i32_kernel(int* p, int64_t n, int v) {
 // Sort the rows of every chunk of SORT_CHUNK consecutive rows by their neighbour mask, descending (stable: ties keep row
 // order).
 // One 1024-thread workgroup per chunk; bitonic network on 64-bit (mask << 32 | local index) keys in LDS.
-constexpr int SORT_CHUNK = 4096;
+static int g_sort_chunk = 4096;     // rows per sort chunk: 4096 (default), 8192 or 16384 (measurement knob)
 
 // Sort key of a row: its mask with the bits re-ranked so that the RAREST offsets are the most significant. A 16-row tile pays
 // a full MFMA pass for an offset as soon as ONE of its rows has it, so what has to be clustered is the rare offsets; in plain
@@ -228,9 +228,10 @@ constexpr int SORT_CHUNK = 4096;
 // us (L3), 115.3 -> 100.7 us (L4); 32x32 55.5 -> 52.8 us.
 struct SortBits { unsigned char pos[32]; };
 
+template <int SORT_CHUNK>
 __global__ __launch_bounds__(1024) void mask_sort_chunks_kernel(const int* __restrict__ mask, int n, int* __restrict__ perm,
                                                                 SortBits sb, int rank_bits) {
-  __shared__ unsigned long long key[SORT_CHUNK];
+  extern __shared__ __attribute__((aligned(16))) unsigned long long key[];      // SORT_CHUNK keys
   __shared__ int hist[32];
   __shared__ unsigned char lpos[32];
   const int base = blockIdx.x * SORT_CHUNK;
@@ -333,7 +334,12 @@ __global__ __launch_bounds__(256) void tile_perm_kernel(const int* __restrict__ 
 
 }  // namespace
 
-extern "C" int crb_mask_sort_chunk_rows(void) { return SORT_CHUNK; }
+extern "C" int crb_mask_sort_chunk_rows(void) { return g_sort_chunk; }
+extern "C" int crb_mask_sort_set_chunk_rows(int rows) {
+  if (rows != 4096 && rows != 8192 && rows != 16384) return CRB_ERR_ARG;
+  g_sort_chunk = rows;
+  return CRB_OK;
+}
 
 static int g_sort_rank_bits = 2;    // sort key: 2 = bits ranked rarest first inside the chunk (default), 1 = by 3x3x3 geometry, 0 = numeric
 extern "C" int crb_mask_sort_set_rank_bits(int mode) { g_sort_rank_bits = (mode >= 0 && mode <= 2) ? mode : 2; return CRB_OK; }
@@ -351,8 +357,19 @@ extern "C" int crb_mask_sort_chunks(const int32_t* mask, int64_t n, int32_t* per
       sb.pos[o] = (unsigned char)next[nz]++;
     }
   }
-  hipLaunchKernelGGL(mask_sort_chunks_kernel, dim3(crb_cdiv(n, SORT_CHUNK)), dim3(1024), 0, (hipStream_t)stream, mask,
-                     (int)n, perm, sb, g_sort_rank_bits);
+  hipStream_t st = (hipStream_t)stream;
+  if (g_sort_chunk == 4096) {
+    hipLaunchKernelGGL(mask_sort_chunks_kernel<4096>, dim3(crb_cdiv(n, 4096)), dim3(1024), 4096 * 8, st, mask, (int)n, perm, sb,
+                       g_sort_rank_bits);
+  } else if (g_sort_chunk == 8192) {
+    CRB_HIP(hipFuncSetAttribute((const void*)mask_sort_chunks_kernel<8192>, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
+    hipLaunchKernelGGL(mask_sort_chunks_kernel<8192>, dim3(crb_cdiv(n, 8192)), dim3(1024), 8192 * 8, st, mask, (int)n, perm, sb,
+                       g_sort_rank_bits);
+  } else {
+    CRB_HIP(hipFuncSetAttribute((const void*)mask_sort_chunks_kernel<16384>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+    hipLaunchKernelGGL(mask_sort_chunks_kernel<16384>, dim3(crb_cdiv(n, 16384)), dim3(1024), 16384 * 8, st, mask, (int)n, perm,
+                       sb, g_sort_rank_bits);
+  }
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

@@ -111,6 +111,7 @@ int crb_nbr_masks(const int32_t* nbr, int64_t n, int K, int32_t* mask, void* str
 /* stable sort of the rows of every chunk of crb_mask_sort_chunk_rows() consecutive rows by mask, DESCENDING (rows with the
  * most neighbours first) -> perm (n) */
 int crb_mask_sort_chunk_rows(void);
+int crb_mask_sort_set_chunk_rows(int rows);            /* 4096 (default), 8192, 16384 */
 /* sort key of crb_mask_sort_chunks: the mask with its bits re-ranked rarest offset first — 2 (default): by frequency inside the
  * chunk, 1: by the geometry of a 3x3x3 kernel (corners, edges, faces, centre), 0: numeric mask order. The gather-GEMM's
  * results do not depend on the row order; the MFMA tile fill does. */

@@ -40,20 +40,25 @@ if __name__ == '__main__':
             coords, shape = rbs.out_coords.contiguous(), rbs.out_shape
         c = chans[lvl]
         tabs, ys = {}, {}
-        for arm in (0, 1, 2):
-            lib.crb_mask_sort_set_rank_bits(arm)
+        for arm in (0, 1, 2, 3, 4):                  # 3 / 4: per-chunk ranking with 8192- / 16384-row chunks
+            lib.crb_mask_sort_set_rank_bits(min(arm, 2))
+            rows = {3: 8192, 4: 16384}.get(arm, 4096)
+            lib.crb_mask_sort_set_chunk_rows(rows)
+            sparse.MASK_SORT_CHUNK = rows
             rb = sparse.subm_rulebook(coords, shape, [3, 3, 3])
             tabs[arm] = (rb, rb.table_for('nbr', c, c))
-        lib.crb_mask_sort_set_rank_bits(1)
+        lib.crb_mask_sort_set_rank_bits(2)
+        lib.crb_mask_sort_set_chunk_rows(4096)
+        sparse.MASK_SORT_CHUNK = 4096
         n = tabs[0][0].n_out
         x = torch.randn(n, c, device=dev)
         w = torch.randn(27, c, c, device=dev) / 10
         for _ in range(300):
             sparse._conv_forward_raw(x, w, tabs[0][1], n)
         torch.cuda.synchronize()
-        res = {0: [], 1: [], 2: []}
+        res = {0: [], 1: [], 2: [], 3: [], 4: []}
         for rep in range(10):
-            for arm in (0, 1, 2):
+            for arm in (0, 1, 2, 3, 4):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(40):
@@ -62,7 +67,8 @@ if __name__ == '__main__':
                 torch.cuda.synchronize()
                 res[arm].append(e0.elapsed_time(e1) / 40 * 1e3)
         print('L%d %dx%d N=%d: numeric order %.1f us (tile fill %.3f) | geometric rarest-first %.1f us (%.3f) | per-chunk rarest-first '
-              '%.1f us (%.3f) | results equal: %s' % (
+              '%.1f us (%.3f) | 8192-row chunks %.1f us (%.3f) | 16384-row chunks %.1f us (%.3f) | results equal: %s' % (
                   lvl, c, c, n, np.median(res[0]), tile_fill(tabs[0][1], n), np.median(res[1]), tile_fill(tabs[1][1], n),
-                  np.median(res[2]), tile_fill(tabs[2][1], n), bool(torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2]))),
+                  np.median(res[2]), tile_fill(tabs[2][1], n), np.median(res[3]), tile_fill(tabs[3][1], n),
+                  np.median(res[4]), tile_fill(tabs[4][1], n), all(bool(torch.equal(ys[0], ys[a])) for a in (1, 2, 3, 4))),
               flush=True)
