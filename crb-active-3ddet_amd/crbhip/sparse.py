@@ -146,6 +146,12 @@ def _mask_perm(table, K):
     if MASK_SORT_CHUNK == lib.crb_mask_sort_chunk_rows():
         perm = torch.empty((n,), dtype=torch.int32, device=dev)            # one LDS bitonic-sort workgroup per chunk
         check(lib.crb_mask_sort_chunks(ptr(mask), n, ptr(perm), cur_stream(dev)), 'crb_mask_sort_chunks')
+    elif MASK_SORT_CHUNK > 0 and MASK_SORT_CHUNK % 1024 == 0:
+        perm = torch.empty((n,), dtype=torch.int32, device=dev)            # ranked keys per chunk + one device radix sort
+        wsb = lib.crb_mask_sort_rows_workspace_bytes(n)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        check(lib.crb_mask_sort_rows(ptr(mask), n, MASK_SORT_CHUNK, ptr(perm), ptr(ws), wsb, cur_stream(dev)),
+              'crb_mask_sort_rows')
     else:
         if MASK_SORT_CHUNK > 0:
             key = (torch.arange(n, device=dev, dtype=torch.int64) // MASK_SORT_CHUNK) * (1 << 32) + \

@@ -14,6 +14,7 @@
 // strided conv is de-duplicated AND ordered through a bitmap over the output volume (rank = popcount
 // prefix), which makes the output row order canonical: ascending linear index (b,z,y,x).
 #include "crb_common.h"
+#include <hipcub/hipcub.hpp>
 #include "../../include/crb_hip.h"
 
 namespace {
@@ -217,7 +218,6 @@ __global__ void fill_i32_kernel(int* p, int64_t n, int v) {
 // Sort the rows of every chunk of SORT_CHUNK consecutive rows by their neighbour mask, descending (stable: ties keep row
 // order).
 // One 1024-thread workgroup per chunk; bitonic network on 64-bit (mask << 32 | local index) keys in LDS.
-static int g_sort_chunk = 4096;     // rows per sort chunk: 4096 (default), 8192 or 16384 (measurement knob)
 
 // Sort key of a row: its mask with the bits re-ranked so that the RAREST offsets are the most significant. A 16-row tile pays
 // a full MFMA pass for an offset as soon as ONE of its rows has it, so what has to be clustered is the rare offsets; in plain
@@ -288,6 +288,51 @@ __global__ __launch_bounds__(1024) void mask_sort_chunks_kernel(const int* __res
   }
 }
 
+// Sort keys for chunks of ANY size (crb_mask_sort_rows): one 1024-thread workgroup per chunk ranks the bits by their frequency
+// inside the chunk exactly like mask_sort_chunks_kernel and writes key = chunk << 32 | ~ranked mask, value = row; a device
+// radix sort (hipCUB, stable) of the (key, row) pairs then gives the same order the LDS bitonic sort gives for 4,096-row
+// chunks, for chunks that do not fit one workgroup's LDS.
+__global__ __launch_bounds__(1024) void mask_rank_keys_kernel(const int* __restrict__ mask, int n, int chunk_rows,
+                                                              SortBits sb, int rank_bits,
+                                                              unsigned long long* __restrict__ keys, int* __restrict__ rows) {
+  __shared__ int hist[32];
+  __shared__ unsigned char lpos[32];
+  const int base = blockIdx.x * chunk_rows;
+  const int end = min(n, base + chunk_rows);
+  if (rank_bits == 2) {
+    if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int t0 = base; t0 < end; t0 += 1024) {      // whole waves stay in the loop: the ballot needs every lane
+      const int i = t0 + threadIdx.x;
+      const unsigned m = (i < end) ? (unsigned)mask[i] : 0u;
+      for (int b = 0; b < 32; ++b) {
+        const int c = __popcll(__ballot((m >> b) & 1u));
+        if ((int)(threadIdx.x & 63) == b) cnt += c;
+      }
+    }
+    if ((threadIdx.x & 63) < 32 && cnt) atomicAdd(&hist[threadIdx.x & 63], cnt);
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      const int mine = hist[threadIdx.x];
+      int p = 0;
+      for (int b = 0; b < 32; ++b) p += (hist[b] > mine) || (hist[b] == mine && b < (int)threadIdx.x);
+      lpos[threadIdx.x] = (unsigned char)p;
+    }
+    __syncthreads();
+  }
+  for (int i = base + threadIdx.x; i < end; i += 1024) {
+    unsigned m = (unsigned)mask[i];
+    if (rank_bits) {
+      unsigned r = 0;
+      for (int b = 0; b < 32; ++b) r |= ((m >> b) & 1u) << (rank_bits == 2 ? lpos[b] : sb.pos[b]);
+      m = r;
+    }
+    keys[i] = ((unsigned long long)blockIdx.x << 32) | (unsigned long long)(~m);
+    rows[i] = i;
+  }
+}
+
 // ---- heaviest-tile-first order of the 64-row tiles of a mask-sorted table -------------------------------------------
 // A gather-GEMM workgroup runs one phase per kernel offset present in ANY of its 64 rows (1..27 phases), so tile run times
 // differ by more than an order of magnitude; dispatched in table order the last tiles of a launch can be 27-phase ones and
@@ -334,12 +379,9 @@ __global__ __launch_bounds__(256) void tile_perm_kernel(const int* __restrict__ 
 
 }  // namespace
 
-extern "C" int crb_mask_sort_chunk_rows(void) { return g_sort_chunk; }
-extern "C" int crb_mask_sort_set_chunk_rows(int rows) {
-  if (rows != 4096 && rows != 8192 && rows != 16384) return CRB_ERR_ARG;
-  g_sort_chunk = rows;
-  return CRB_OK;
-}
+static SortBits geometric_sort_bits();
+
+extern "C" int crb_mask_sort_chunk_rows(void) { return 4096; }
 
 static int g_sort_rank_bits = 2;    // sort key: 2 = bits ranked rarest first inside the chunk (default), 1 = by 3x3x3 geometry, 0 = numeric
 extern "C" int crb_mask_sort_set_rank_bits(int mode) { g_sort_rank_bits = (mode >= 0 && mode <= 2) ? mode : 2; return CRB_OK; }
@@ -348,28 +390,57 @@ extern "C" int crb_mask_sort_set_rank_bits(int mode) { g_sort_rank_bits = (mode 
 extern "C" int crb_mask_sort_chunks(const int32_t* mask, int64_t n, int32_t* perm, void* stream) {
   if (n < 0) return CRB_ERR_ARG;
   if (n == 0) return CRB_OK;
+  const SortBits sb = geometric_sort_bits();
+  hipLaunchKernelGGL(mask_sort_chunks_kernel<4096>, dim3(crb_cdiv(n, 4096)), dim3(1024), 4096 * 8, (hipStream_t)stream, mask,
+                     (int)n, perm, sb, g_sort_rank_bits);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+static SortBits geometric_sort_bits() {
   SortBits sb;
-  {
-    int next[4] = {0, 1, 7, 19};                       // first bit of the class with 0 / 1 / 2 / 3 non-zero coordinates
-    for (int o = 0; o < 32; ++o) {
-      if (o >= 27) { sb.pos[o] = (unsigned char)o; continue; }
-      const int nz = (o / 9 != 1) + ((o / 3) % 3 != 1) + (o % 3 != 1);
-      sb.pos[o] = (unsigned char)next[nz]++;
-    }
+  int next[4] = {0, 1, 7, 19};                         // first bit of the class with 0 / 1 / 2 / 3 non-zero coordinates
+  for (int o = 0; o < 32; ++o) {
+    if (o >= 27) { sb.pos[o] = (unsigned char)o; continue; }
+    const int nz = (o / 9 != 1) + ((o / 3) % 3 != 1) + (o % 3 != 1);
+    sb.pos[o] = (unsigned char)next[nz]++;
   }
+  return sb;
+}
+
+static size_t radix_temp_bytes(int64_t n) {
+  size_t b = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                           (const int*)nullptr, (int*)nullptr, (int)n, 0, 64, (hipStream_t)0);
+  return b;
+}
+
+extern "C" int64_t crb_mask_sort_rows_workspace_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  return crb_align_up(8 * n, 256) * 2 + crb_align_up(4 * n, 256) + crb_align_up((int64_t)radix_temp_bytes(n), 256) + 256;
+}
+
+// perm (n) i32: the order crb_mask_sort_chunks produces, for chunks of chunk_rows rows (any multiple of 1024)
+extern "C" int crb_mask_sort_rows(const int32_t* mask, int64_t n, int chunk_rows, int32_t* perm, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+  if (n < 0 || n >= (1LL << 31) || chunk_rows < 1024 || chunk_rows % 1024) return CRB_ERR_ARG;
+  if (n == 0) return CRB_OK;
+  if (!workspace || workspace_bytes < crb_mask_sort_rows_workspace_bytes(n)) return CRB_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  if (g_sort_chunk == 4096) {
-    hipLaunchKernelGGL(mask_sort_chunks_kernel<4096>, dim3(crb_cdiv(n, 4096)), dim3(1024), 4096 * 8, st, mask, (int)n, perm, sb,
-                       g_sort_rank_bits);
-  } else if (g_sort_chunk == 8192) {
-    CRB_HIP(hipFuncSetAttribute((const void*)mask_sort_chunks_kernel<8192>, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
-    hipLaunchKernelGGL(mask_sort_chunks_kernel<8192>, dim3(crb_cdiv(n, 8192)), dim3(1024), 8192 * 8, st, mask, (int)n, perm, sb,
-                       g_sort_rank_bits);
-  } else {
-    CRB_HIP(hipFuncSetAttribute((const void*)mask_sort_chunks_kernel<16384>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
-    hipLaunchKernelGGL(mask_sort_chunks_kernel<16384>, dim3(crb_cdiv(n, 16384)), dim3(1024), 16384 * 8, st, mask, (int)n, perm,
-                       sb, g_sort_rank_bits);
-  }
+  CrbArena ar(workspace, (size_t)workspace_bytes);
+  unsigned long long* kin = ar.take<unsigned long long>(n);
+  unsigned long long* kout = ar.take<unsigned long long>(n);
+  int* vin = ar.take<int>(n);
+  size_t tb = radix_temp_bytes(n);
+  char* temp = ar.take<char>((int64_t)tb);
+  if (!ar.ok) return CRB_ERR_WORKSPACE;
+  const int chunks = crb_cdiv(n, chunk_rows);
+  hipLaunchKernelGGL(mask_rank_keys_kernel, dim3(chunks), dim3(1024), 0, st, mask, (int)n, chunk_rows, geometric_sort_bits(),
+                     g_sort_rank_bits, kin, vin);
+  int chunk_bits = 1;
+  while ((1 << chunk_bits) < chunks) ++chunk_bits;
+  if (hipcub::DeviceRadixSort::SortPairs(temp, tb, kin, kout, vin, perm, (int)n, 0, 32 + chunk_bits, st) != hipSuccess)
+    return CRB_ERR_LAUNCH;
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

@@ -111,12 +111,16 @@ int crb_nbr_masks(const int32_t* nbr, int64_t n, int K, int32_t* mask, void* str
 /* stable sort of the rows of every chunk of crb_mask_sort_chunk_rows() consecutive rows by mask, DESCENDING (rows with the
  * most neighbours first) -> perm (n) */
 int crb_mask_sort_chunk_rows(void);
-int crb_mask_sort_set_chunk_rows(int rows);            /* 4096 (default), 8192, 16384 */
 /* sort key of crb_mask_sort_chunks: the mask with its bits re-ranked rarest offset first — 2 (default): by frequency inside the
  * chunk, 1: by the geometry of a 3x3x3 kernel (corners, edges, faces, centre), 0: numeric mask order. The gather-GEMM's
  * results do not depend on the row order; the MFMA tile fill does. */
 int crb_mask_sort_set_rank_bits(int mode);
 int crb_mask_sort_chunks(const int32_t* mask, int64_t n, int32_t* perm, void* stream);
+/* the same order for chunks of chunk_rows rows (a multiple of 1024; chunks too large for one workgroup's LDS): keys ranked
+ * per chunk, then one stable device radix sort (hipCUB) of (chunk, key, row) */
+int64_t crb_mask_sort_rows_workspace_bytes(int64_t n);
+int crb_mask_sort_rows(const int32_t* mask, int64_t n, int chunk_rows, int32_t* perm, void* workspace,
+                       int64_t workspace_bytes, void* stream);
 /* perm_out = perm_in with the full 64-row tiles of each of crb_tile_lpt_ranges() contiguous tile ranges (one per XCD, the
  * split the gather-GEMM's workgroup->tile map uses) re-ordered heaviest first; weight = kernel offsets present in any row
  * of the tile = phases its workgroup will run. A launch then ends on light tiles instead of idling behind 27-phase ones,

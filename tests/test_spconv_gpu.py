@@ -311,6 +311,28 @@ def test_chunk_mask_sort_is_a_stable_sort_per_chunk(dev, mode):
         lib.crb_mask_sort_set_rank_bits(2)
 
 
+@pytest.mark.parametrize('chunk', [4096, 16384])
+def test_radix_chunk_sort_equals_the_lds_sort_and_the_restatement(dev, chunk):
+    """crb_mask_sort_rows (ranked keys per chunk + one stable device radix sort) gives the order of crb_mask_sort_chunks for
+    4,096-row chunks and the stable (chunk, ranked key descending) order for chunks beyond one workgroup's LDS"""
+    from crbhip import lib, check, ptr, cur_stream
+    rng = np.random.default_rng(5)
+    for n in (1, 5000, 16385, 70001):
+        mask = (rng.integers(0, 1 << 27, n) & rng.integers(0, 1 << 27, n)).astype(np.int32)
+        mask[rng.random(n) < 0.4] = 21
+        m = _t(mask, dev)
+        perm = torch.empty(n, dtype=torch.int32, device=dev)
+        wsb = lib.crb_mask_sort_rows_workspace_bytes(n)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        check(lib.crb_mask_sort_rows(ptr(m), n, chunk, ptr(perm), ptr(ws), wsb, cur_stream(dev)), 'rows')
+        key = (np.arange(n) // chunk).astype(np.int64) * (1 << 32) + ((~_rank_bits_key(mask, chunk, 2)) & 0xffffffff)
+        np.testing.assert_array_equal(perm.cpu().numpy(), np.argsort(key, kind='stable'))
+        if chunk == lib.crb_mask_sort_chunk_rows():
+            perm2 = torch.empty(n, dtype=torch.int32, device=dev)
+            check(lib.crb_mask_sort_chunks(ptr(m), n, ptr(perm2), cur_stream(dev)), 'chunks')
+            assert torch.equal(perm, perm2)
+
+
 def test_tile_lpt_perm_orders_whole_tiles_heaviest_first(dev):
     """crb_tile_lpt_perm: output = input perm with its full 64-row tiles moved as units INSIDE their range (8 contiguous
     ranges of ceil(ceil(n/64)/8) tiles), tile weights (popcount of the OR of the tile's row masks) non-increasing within a

@@ -40,15 +40,13 @@ if __name__ == '__main__':
             coords, shape = rbs.out_coords.contiguous(), rbs.out_shape
         c = chans[lvl]
         tabs, ys = {}, {}
-        for arm in (0, 1, 2, 3, 4):                  # 3 / 4: per-chunk ranking with 8192- / 16384-row chunks
+        for arm in (0, 1, 2, 3, 4):                  # 3 / 4: per-chunk ranking with 8192- / 16384-row chunks (radix path)
             lib.crb_mask_sort_set_rank_bits(min(arm, 2))
             rows = {3: 8192, 4: 16384}.get(arm, 4096)
-            lib.crb_mask_sort_set_chunk_rows(rows)
             sparse.MASK_SORT_CHUNK = rows
             rb = sparse.subm_rulebook(coords, shape, [3, 3, 3])
             tabs[arm] = (rb, rb.table_for('nbr', c, c))
         lib.crb_mask_sort_set_rank_bits(2)
-        lib.crb_mask_sort_set_chunk_rows(4096)
         sparse.MASK_SORT_CHUNK = 4096
         n = tabs[0][0].n_out
         x = torch.randn(n, c, device=dev)
