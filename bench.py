@@ -48,7 +48,7 @@ def parse():
                     help='unlabeled pool size of the CRB stage-1 scoring measurement (BASELINE configs[3]: 3,000 frames, '
                          'rank-strided shard per GPU; 0 = skip)')
     ap.add_argument('--scoring-repeats', type=int, default=3)
-    ap.add_argument('--pvrcnn-steps', type=int, default=6, help='PV-RCNN fwd+bwd+AdamW steps (configs[2]; 0 = skip)')
+    ap.add_argument('--pvrcnn-steps', type=int, default=12, help='PV-RCNN fwd+bwd+AdamW steps (configs[2]; 0 = skip)')
     return ap.parse_args()
 
 
