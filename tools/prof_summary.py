@@ -2,8 +2,8 @@
 """Summarise a rocprofv3 --kernel-trace CSV over the steady-state steps only.
 
 MIOpen's find phase (naive_conv_*, GEMM trials) pollutes whole-process --stats; a training step of this repo launches
-the voxelizer's `vox_insert` kernel exactly once, so the trace is cut at the (last-K)-th vox_insert and only the
-K last steps are aggregated.  Usage: prof_summary.py <kernel_trace.csv> <K> > summary.csv
+the voxelizer's `vox_insert` kernel exactly once, so the trace is cut at vox_insert launches and only K complete steps
+near the end of the trace are aggregated.  Usage: prof_summary.py <kernel_trace.csv> <K> > summary.csv
 PROF_MARKER=<kernel substring> picks another once-per-step kernel; PROF_SPLIT_GRID=<kernel substring> lists the matching
 kernel once per launch geometry (the subm and the strided layers run the same gather-GEMM instance)."""
 import csv
@@ -20,10 +20,12 @@ def main(path, K, marker='vox_insert'):
     key_n = 'Kernel_Name' if 'Kernel_Name' in rows[0] else 'Name'
     rows.sort(key=lambda r: int(r[key_s]))
     marks = [i for i, r in enumerate(rows) if marker in r[key_n]]
-    if len(marks) <= K:
+    if len(marks) <= K + 1:
         raise SystemExit('not enough steps in trace: %d markers' % len(marks))
-    first = marks[-K]
-    sel = rows[first:]
+    # K COMPLETE steps: from the (K+1)-th last marker up to (not including) the last one — what follows the last step of a
+    # process (final synchronisation, result read-backs, bookkeeping kernels) is not part of any step (until r02 the window
+    # ran to the end of the trace and charged one ~5 ms post-run gap to the steps)
+    sel = rows[marks[-K - 1]:marks[-1]]
     span_ns = int(sel[-1][key_e]) - int(sel[0][key_s])
     agg = defaultdict(lambda: [0, 0])
     split = os.environ.get('PROF_SPLIT_GRID', '')          # e.g. "sparse_conv_fwd2": one line per launch geometry
