@@ -159,7 +159,9 @@ int crb_sparse_conv_forward_compact_bn(const float* X, const float* W, const uin
  * into two bf16 values, x = x_hi + x_lo (+ a residual <= 2^-18 |x|), and a product is taken as x_lo*w_hi + x_hi*w_lo +
  * x_hi*w_hi on the bf16 MFMA (products exact, f32 accumulation; x_lo*w_lo dropped). Stated bound, checked by
  * tests/test_spconv_gpu.py: |y - y_exact| <= 2^-16 * sum |x||w| over the gathered products of the output element (plus
- * f32 accumulation error). bf16 keeps the f32 exponent range: no scaling, no overflow case of its own. Needs the compact
+ * f32 accumulation error). bf16 keeps the f32 exponent range: no scaling, no overflow case of its own. Model-level reading
+ * (tests/test_second_gpu.py): a SECOND training step reproduces the f32 loss to 2e-6 and the dense-head gradients to 4e-5,
+ * the weight gradients of the sparse backbone — sums that cancel to ~1e-3 of their terms — to 1-4 % of their largest entry. Needs the compact
  * table of crb_nbr_compact; workspace >= crb_sparse_conv_bf16x3_workspace_bytes (holds the split copy of W). n_in = rows of
  * X (the gathers are bounds-checked buffer loads; n_in*cin*4 must stay below 2^31).
  * No reference counterpart: spconv-cu113 v2.1.21 multiplies in f32 (or fp16 under AMP, which the reference does not use). */

@@ -696,18 +696,22 @@ def test_bf16x3_subm_forward_and_dgrad_within_the_stated_bound(dev, cin, cout, t
     _close(y_f32.cpu().numpy(), oracle.conv_fwd(X, W, nbr))
 
 
-def test_bf16x3_strided_conv_out_layer(dev):
-    """the (3,1,1)/(2,1,1) 64->128 conv_out geometry and its 128->64 dgrad under the opt-in contract"""
+@pytest.mark.parametrize('cin,cout,ks,st,pd', [(64, 128, (3, 1, 1), (2, 1, 1), (0, 0, 0)),
+                                                (32, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+                                                (64, 64, (3, 3, 3), (2, 2, 2), (0, 1, 1))])
+def test_bf16x3_strided_conv_out_layer(dev, cin, cout, ks, st, pd):
+    """strided layers under the opt-in contract: the (3,1,1)/(2,1,1) 64->128 conv_out geometry with its 128->64 dgrad, and the
+    3x3x3 stride-2 down-sampling convs (32->64, 64->64) with their dgrads through the transposed table"""
     from crbhip import sparse
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + cin + cout)
     shape = [11, 100, 88]
     coords = random_sparse_coords(rng, 6000, 2, shape)
     n = len(coords)
-    ks, st, pd = (3, 1, 1), (2, 1, 1), (0, 0, 0)
-    X = rng.normal(size=(n, 64)).astype(np.float32)
-    W = (rng.normal(size=(3, 64, 128)) / 8).astype(np.float32)
+    K = ks[0] * ks[1] * ks[2]
+    X = rng.normal(size=(n, cin)).astype(np.float32)
+    W = (rng.normal(size=(K, cin, cout)) / 8).astype(np.float32)
     rb = sparse.spconv_rulebook(_t(coords, dev), shape, 2, ks, st, pd)
-    dY = rng.normal(size=(rb.n_out, 128)).astype(np.float32)
+    dY = rng.normal(size=(rb.n_out, cout)).astype(np.float32)
     x = _t(X, dev).requires_grad_(True)
     w = _t(W, dev).requires_grad_(True)
     sparse.ARITHMETIC = 'bf16x3'
