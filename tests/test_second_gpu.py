@@ -27,17 +27,17 @@ def test_second_waymo_shape(dev):
     from pcdet.model_cfgs import second_cfg
     from pcdet.models import build_network
     torch.manual_seed(0)
-    ds = SyntheticDataset(num_frames=2, kind='waymo', n_points=160000)
+    ds = SyntheticDataset(num_frames=4, kind='waymo', n_points=160000)
     model = build_network(second_cfg('waymo').MODEL, 3, ds).to(dev)
     model.train()
-    pts, off, gt = kitti_batch(0, 2, 160000, waymo=True)
+    pts, off, gt = kitti_batch(0, 4, 160000, waymo=True)              # BASELINE configs[4]: bs = 4 per GPU, 160k points
     ret, tb, _ = model(_dev_batch(dev, pts, off, gt))
     ret['loss'].backward()
     assert torch.isfinite(ret['loss'])
     assert model.backbone_3d.sparse_shape == [41, 1504, 1504]
     g = model.backbone_3d.conv_input[0].weight.grad
     assert g.shape == (16, 3, 3, 3, 5) and torch.isfinite(g).all() and float(g.abs().sum()) > 0
-    assert model.dense_head.forward_ret_dict['cls_preds'].shape == (2, 188, 188, 18)
+    assert model.dense_head.forward_ret_dict['cls_preds'].shape == (4, 188, 188, 18)
 
 
 def test_res_backbone_and_reference_layout_batch(dev):
