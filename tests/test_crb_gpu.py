@@ -389,3 +389,34 @@ def test_density_greedy_degenerate_prior_is_never_preferred(dev):
                                        [labs[i] for i in range(30) if i not in owners], list(xa), list(pr), 3, n_free, 5)
     free_ids = [i for i in range(30) if i not in owners]
     assert order[:n_free] == [free_ids[k] for k in ref]
+
+
+def test_stage1_one_rank_share_of_the_3000_frame_pool(dev):
+    """BASELINE configs[3] at its own shape: the share rank 5 of 8 owns of a 3,000-frame pool (375 rank-strided frames, batches
+    of 16 through the loader path) -> 375 finite record rows; the GT statistics inside a few of them equal the step-by-step
+    restatement of the reference loop, the rows sit where the all-gather will put them (frame 5, 13, 21, ...)"""
+    from pcdet.datasets import SyntheticDataset, build_synthetic_dataloader
+    from pcdet.model_cfgs import pv_rcnn_cfg
+    from pcdet.models import build_network
+    from pcdet.query_strategies import build_strategy, scoring
+    cfg = pv_rcnn_cfg()
+    torch.manual_seed(0)
+    pool = SyntheticDataset(num_frames=3000, first_frame=5000, training=False)
+    model = build_network(cfg.MODEL, 3, pool).to(dev)
+    strat = build_strategy('crb', model, build_synthetic_dataloader(SyntheticDataset(num_frames=2), 2),
+                           build_synthetic_dataloader(pool, 16, workers=8), 0, '/tmp', cfg)
+    try:
+        mine, per = scoring.shard_indices(3000, 5, 8)
+        assert per == 375 and mine[:3] == [5, 13, 21] and len(mine) == 375
+        rows = strat.score_pool(mine, 16)
+    finally:
+        strat.close()
+    assert rows.shape == (375, strat.layout.stride) and bool(torch.isfinite(rows).all())
+    stats = scoring.unpack_records(rows, strat.layout)['gt_stats'].cpu().numpy()
+    for k in (0, 17, 374):
+        fr = pool[mine[k]]
+        ref = crb_oracle.gt_point_statistics(fr['points'][:, :3], fr['gt_boxes'], 3)
+        for c in range(3):
+            assert int(stats[k, c, 0]) == ref[c][0]
+            np.testing.assert_allclose(stats[k, c, 2], ref[c][2], rtol=1e-6)
+            np.testing.assert_allclose(stats[k, c, 3], ref[c][3], rtol=0)
