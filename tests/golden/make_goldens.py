@@ -528,6 +528,157 @@ def gen_partA2(out):
     print('  occupied cells', cells, 'of', out['pa2_pooled_part'][..., 0].size)
 
 
+def _install_pointnet2_ops(oracle):
+    """answer pointnet2_stack_cuda's entry points (ball query, grouping + its gradient, farthest point sampling) with the
+    oracle's loop-for-loop restatement of the reference's .cu kernels (oracle/pointnet2_oracle.c); the reference's autograd
+    Functions, QueryAndGroup, StackSAModuleMSG and every caller above them run unmodified"""
+    m = sys.modules['pcdet.ops.pointnet2.pointnet2_stack.pointnet2_stack_cuda']
+
+    def ball_query_wrapper(B, M, radius, nsample, new_xyz, new_cnt, xyz, xyz_cnt, idx):
+        idx.copy_(torch.from_numpy(oracle.ball_query(float(radius), int(nsample), xyz.detach().numpy(), xyz_cnt.numpy(),
+                                                     new_xyz.detach().numpy(), new_cnt.numpy())))
+
+    def group_points_wrapper(B, M, C, nsample, feat, feat_cnt, idx, idx_cnt, out):
+        out.copy_(torch.from_numpy(oracle.group_points(feat.detach().numpy(), feat_cnt.numpy(), idx.numpy(), idx_cnt.numpy())))
+
+    def group_points_grad_wrapper(B, M, C, N, nsample, grad_out, idx, idx_cnt, feat_cnt, grad_feat):
+        grad_feat.copy_(torch.from_numpy(oracle.group_points_grad(grad_out.numpy(), idx.numpy(), idx_cnt.numpy(),
+                                                                  feat_cnt.numpy(), int(N))))
+
+    def farthest_point_sampling_wrapper(B, N, npoint, xyz, temp, out):
+        out.copy_(torch.from_numpy(oracle.fps(xyz.numpy(), int(npoint))))
+    m.ball_query_wrapper, m.group_points_wrapper = ball_query_wrapper, group_points_wrapper
+    m.group_points_grad_wrapper, m.farthest_point_sampling_wrapper = group_points_grad_wrapper, farthest_point_sampling_wrapper
+    torch.cuda.IntTensor = torch.IntTensor
+    torch.cuda.FloatTensor = torch.FloatTensor
+
+
+PP_PCR = [0.0, -40.0, -3.0, 70.4, 40.0, 1.0]
+PP_VOXEL = [0.05, 0.05, 0.1]
+PP_KEYPOINTS = 96
+PP_LEVELS = (('x_conv1', 1, 16), ('x_conv2', 2, 32), ('x_conv3', 4, 64), ('x_conv4', 8, 64))
+
+
+def point_path_inputs(seed=51, n_pts=(1500, 1300), c_bev=16, n_roi=12):
+    """two ragged frames: ground clutter + 6 object clusters inside x 8..32 m, y -12..12 m; the four sparse feature
+    volumes are the occupied voxels of the frame at strides 1/2/4/8 in ascending (b,z,y,x) order with seeded features (what
+    VoxelBackBone8x hands to the PFE: .indices / .features only); a seeded BEV map; RoIs on the clusters, next to them and
+    far away (empty balls for every grid point); keypoint scores in (0,1)"""
+    rng = np.random.default_rng(seed)
+    B = len(n_pts)
+    pts, rois = [], np.zeros((B, n_roi, 7), np.float32)
+    for b, n in enumerate(n_pts):
+        ctr = np.stack([rng.uniform(10, 30, 6), rng.uniform(-10, 10, 6), rng.uniform(-1.4, -0.8, 6)], 1)
+        k = n // 2
+        p = [np.stack([rng.uniform(8, 32, n - k), rng.uniform(-12, 12, n - k), rng.uniform(-2.4, -1.6, n - k)], 1)]
+        which = rng.integers(0, 6, k)
+        p.append(ctr[which] + rng.normal(0, 1, (k, 3)) * np.array([1.2, 0.6, 0.5]))
+        p = np.concatenate(p)
+        p[:, 2] = np.clip(p[:, 2], -2.5, 0.5)
+        p = p[rng.permutation(n)]
+        pts.append(np.concatenate([np.full((n, 1), b), p, rng.uniform(0, 1, (n, 1))], 1))
+        for r in range(n_roi):
+            c = ctr[r % 6]
+            if r < 8:
+                rois[b, r] = [c[0] + rng.normal(0, 0.3), c[1] + rng.normal(0, 0.3), c[2], *(np.array([3.9, 1.6, 1.56]) * rng.uniform(0.8, 1.2, 3)),
+                              rng.uniform(-np.pi, np.pi)]
+            elif r < 10:
+                rois[b, r] = [rng.uniform(50, 60), rng.uniform(25, 35), -1, 3.9, 1.6, 1.56, 0.4]     # nothing near
+            # last two rows stay all-zero (the padding proposal_layer leaves)
+    points = np.concatenate(pts).astype(np.float32)
+    lo, vs = np.array(PP_PCR[:3]), np.array(PP_VOXEL)
+    levels = {}
+    for name, stride, C in PP_LEVELS:
+        ijk = np.floor((points[:, 1:4].astype(np.float64) - lo) / (vs * stride)).astype(np.int64)
+        c = np.unique(np.concatenate([points[:, :1].astype(np.int64), ijk[:, ::-1]], 1), axis=0)      # sorted (b,z,y,x)
+        levels[name] = (c.astype(np.int32), rng.normal(0, 1, (len(c), C)).astype(np.float32))
+    bev = rng.normal(0, 1, (B, c_bev, 200, 176)).astype(np.float32)
+    scores = rng.uniform(0.05, 1.0, (B * PP_KEYPOINTS,)).astype(np.float32)
+    return {'points': points, 'levels': levels, 'bev': bev, 'rois': rois, 'scores': scores, 'batch_size': B}
+
+
+def _ref_pfe_cfg():
+    import yaml
+    y = yaml.safe_load(open(os.path.join(REF, 'tools/cfgs/active-kitti_models/pv_rcnn_active_crb.yaml')))
+    pfe, roi = EasyDict(y['MODEL']['PFE']), EasyDict(y['MODEL']['ROI_HEAD'])
+    pfe.NUM_KEYPOINTS = PP_KEYPOINTS
+    return pfe, roi
+
+
+def gen_point_path(out):
+    """ref_point_path.npz: the PV-RCNN point path as the reference's own classes compose it —
+    VoxelSetAbstraction.forward (voxel_set_abstraction.py:284-411: FPS keypoints, bilinear BEV lookup, raw-point SA, the four
+    voxel-centre SAs in FEATURES_SOURCE order, concat, fusion Linear+BN+ReLU), StackSAModuleMSG.forward
+    (pointnet2_modules.py:78-112) underneath each source, and PVRCNNHead.roi_grid_pool (pvrcnn_head.py:68-114) on the result
+    — with the PFE / ROI_GRID_POOL sections of the reference's own pv_rcnn_active_crb.yaml (only NUM_KEYPOINTS reduced),
+    in eval mode (running statistics) and train mode (batch statistics + a backward pass through GroupingOperation.backward).
+    pointnet2_stack_cuda's entry points are answered by the oracle."""
+    oracle = _install_cpu_ops()
+    _install_pointnet2_ops(oracle)
+    from pcdet.config import cfg as ref_cfg
+    ref_cfg.CLASS_NAMES = ['Car', 'Pedestrian', 'Cyclist']
+    from pcdet.models.backbones_3d.pfe.voxel_set_abstraction import VoxelSetAbstraction
+    from pcdet.models.roi_heads.pvrcnn_head import PVRCNNHead
+    pfe_cfg, roi_cfg = _ref_pfe_cfg()
+    inp = point_path_inputs()
+    c_bev = inp['bev'].shape[1]
+    vsa = VoxelSetAbstraction(pfe_cfg, voxel_size=PP_VOXEL, point_cloud_range=PP_PCR, num_bev_features=c_bev,
+                              num_rawpoint_features=4)
+    vsa.load_state_dict(seeded_state(vsa, 53))
+    head = PVRCNNHead(input_channels=vsa.num_point_features, model_cfg=roi_cfg, num_class=1)
+    head.load_state_dict(seeded_state(head, 57))
+    out['pp_vsa_keys'] = np.array(sorted(vsa.state_dict().keys()))
+    out['pp_head_pool_keys'] = np.array(sorted(k for k in head.state_dict() if k.startswith('roi_grid_pool_layer')))
+
+    class Level:
+        def __init__(self, c, f):
+            self.indices, self.features = torch.from_numpy(c.copy()), torch.from_numpy(f.copy())
+
+    def batch():
+        return {'batch_size': inp['batch_size'], 'points': torch.from_numpy(inp['points'].copy()),
+                'multi_scale_3d_features': {k: Level(*v) for k, v in inp['levels'].items()},
+                'spatial_features': torch.from_numpy(inp['bev'].copy()), 'spatial_features_stride': 8,
+                'rois': torch.from_numpy(inp['rois'].copy())}
+
+    for mode in ('eval', 'train'):
+        vsa.train(mode == 'train'); head.train(mode == 'train')
+        bd = batch()
+        with torch.set_grad_enabled(mode == 'train'):
+            bd = vsa(bd)
+            bd['point_cls_scores'] = torch.from_numpy(inp['scores'].copy())
+            pooled = head.roi_grid_pool(bd)
+        out['pp_%s_before_fusion' % mode] = _np(bd['point_features_before_fusion'])
+        out['pp_%s_point_features' % mode] = _np(bd['point_features'])
+        out['pp_%s_pooled' % mode] = _np(pooled)
+        if mode == 'eval':
+            out['pp_point_coords'] = _np(bd['point_coords'])
+        else:
+            (pooled.square().sum() + bd['point_features'].square().sum()).backward()
+            for n in ('SA_rawpoints.mlps.0.0.weight', 'SA_layers.0.mlps.1.3.weight', 'SA_layers.3.mlps.1.0.weight',
+                      'vsa_point_feature_fusion.0.weight'):
+                out['pp_grad/' + n] = _np(dict(vsa.named_parameters())[n].grad)
+            out['pp_grad/roi_grid_pool_layer.mlps.0.0.weight'] = _np(head.roi_grid_pool_layer.mlps[0][0].weight.grad)
+    # the running statistics after the train pass are part of the contract too (momentum update of every BN layer)
+    out['pp_running_mean_after'] = _np(vsa.vsa_point_feature_fusion[1].running_mean)
+    # StackSAModuleMSG.forward on its own with ragged counts on both sides (first frame 40 queries, second 7)
+    vsa.load_state_dict(seeded_state(vsa, 53))          # the train pass above advanced the running statistics
+    sa = vsa.SA_layers[1]
+    sa.eval()
+    c, f = inp['levels']['x_conv2']
+    from pcdet.utils import common_utils
+    xyz = common_utils.get_voxel_centers(torch.from_numpy(c[:, 1:4].copy()), 2, PP_VOXEL, PP_PCR)
+    cnt = torch.from_numpy(np.bincount(c[:, 0], minlength=2).astype(np.int32))
+    kp = out['pp_point_coords']
+    q = np.concatenate([kp[kp[:, 0] == 0][:40, 1:4], kp[kp[:, 0] == 1][:7, 1:4]]).astype(np.float32)
+    with torch.no_grad():
+        _, y = sa(xyz=xyz.contiguous(), xyz_batch_cnt=cnt, new_xyz=torch.from_numpy(q),
+                  new_xyz_batch_cnt=torch.tensor([40, 7], dtype=torch.int32), features=torch.from_numpy(f.copy()))
+    out['pp_sa_queries'], out['pp_sa_out'] = q, _np(y)
+    print('  keypoints', kp.shape, 'before_fusion', out['pp_eval_before_fusion'].shape, 'pooled', out['pp_eval_pooled'].shape)
+    assert out['pp_eval_before_fusion'].shape[1] == c_bev + 32 * 2 + 64 + 128 + 128
+    assert np.isfinite(out['pp_train_pooled']).all() and np.abs(out['pp_grad/SA_rawpoints.mlps.0.0.weight']).max() > 0
+
+
 def gen_data_processor(out):
     """DataProcessor.mask_points_and_boxes_outside_range through the reference's own class (train mode, shuffle off)"""
     from pcdet.datasets.processor.data_processor import DataProcessor
@@ -817,7 +968,8 @@ if __name__ == '__main__':
     for name, fn in (('ref_utils.npz', gen_utils), ('ref_anchor_head.npz', gen_head), ('ref_bev_vfe.npz', gen_bev), ('ref_roi_head.npz', gen_roi_head),
                      ('ref_strategies.npz', gen_strategies), ('ref_data_processor.npz', gen_data_processor),
                      ('ref_post_processing.npz', gen_post_processing), ('ref_glue.npz', gen_glue),
-                     ('ref_badge.npz', gen_badge), ('ref_partA2.npz', gen_partA2)):
+                     ('ref_badge.npz', gen_badge), ('ref_partA2.npz', gen_partA2),
+                     ('ref_point_path.npz', gen_point_path)):
         if only and name not in only:
             continue
         d = {}

@@ -22,6 +22,16 @@ def test_second_kitti_step_matches_cpu_oracle(dev):
     ge.smoke()
 
 
+def test_second_waymo_shaped_step_matches_cpu_oracle(dev):
+    """configs[4] shapes at B=1 against the oracle step: 5 point features, [41,1504,1504] grid, 188x188 BEV map, the Waymo
+    anchors; same tolerances as smoke() (10 x the KITTI errors observed) except the first sparse layer (conv_input sums
+    ~100k voxel rows per weight entry: 3e-3)"""
+    import __graft_entry__ as ge
+    tol = dict(ge.SMOKE_TOL, conv_input=3e-3, conv_out=2e-3)
+    msg, err = ge.second_step_parity('waymo', 1, 160000, tol=tol)
+    print(msg)
+
+
 def test_second_waymo_shape(dev):
     from pcdet.datasets import SyntheticDataset
     from pcdet.model_cfgs import second_cfg

@@ -766,3 +766,76 @@ def test_eval_conv_bn_relu_epilogue_equals_the_three_modules(dev, cin, cout, bia
         with torch.enable_grad():                      # grad mode: the module path, untouched
             y = blk(spconv.SparseConvTensor(x.features.clone().requires_grad_(True), x.indices, shape, 2)).features
         assert y.requires_grad and float((y.detach() - plain).abs().max()) <= 1e-5 * float(plain.abs().max())
+
+
+def test_sparse_inverse_conv3d_matches_the_transposed_rulebook_of_the_oracle(dev):
+    """SparseInverseConv3d (spconv/pytorch/conv.py:163-180 in spconv 2.1; the reference's UNet decoder,
+    pcdet/models/backbones_3d/spconv_unet.py:100-107): it re-uses the rulebook its indice_key names with input and output
+    swapped — fine row i receives sum_o x_coarse[nbr_t[i,o]] W[o], where nbr_t is the exact transpose of the forward
+    table, and its output lives on the forward conv's INPUT coordinates. Forward, dgrad and wgrad vs the oracle."""
+    import spconv.pytorch as spconv
+    rng = np.random.default_rng(77)
+    shape = [21, 120, 100]
+    coords = random_sparse_coords(rng, 9000, 2, shape)
+    n = len(coords)
+    torch.manual_seed(5)
+    down = spconv.SparseConv3d(16, 32, 3, stride=2, padding=1, bias=False, indice_key='spconv2').to(dev)
+    up = spconv.SparseInverseConv3d(32, 16, 3, indice_key='spconv2', bias=False).to(dev)
+    X = rng.normal(size=(n, 16)).astype(np.float32)
+    x = spconv.SparseConvTensor(_t(X, dev), _t(coords, dev), shape, 2)
+    mid = down(x)
+    Z = rng.normal(size=(mid.features.shape[0], 32)).astype(np.float32)        # fresh coarse features: test `up` alone
+    z = _t(Z, dev).requires_grad_(True)
+    out = up(mid.replace_feature(z))
+    assert out.spatial_shape == shape
+    np.testing.assert_array_equal(out.indices.cpu().numpy(), coords)            # back on the fine active set, same row order
+    dY = rng.normal(size=(n, 16)).astype(np.float32)
+    out.features.backward(_t(dY, dev))
+    oc, oshape = oracle.spconv_out(coords, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    np.testing.assert_array_equal(mid.indices.cpu().numpy(), oc)
+    nbr = oracle.spconv_nbr(coords, shape, oc, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    i, o = np.nonzero(nbr >= 0)
+    nbr_t = np.full((n, 27), -1, np.int32)
+    nbr_t[nbr[i, o], o] = i
+    W = up.weight_kio().detach().cpu().numpy()
+    _close(out.features.detach().cpu().numpy(), oracle.conv_fwd(Z, W, nbr_t))
+    _close(z.grad.cpu().numpy(), oracle.conv_dgrad(dY, W, nbr_t, len(oc)))
+    _close(_kio_grad(up), oracle.conv_wgrad(Z, dY, nbr_t, 27))
+
+
+@pytest.mark.parametrize('strided', [False, True])
+def test_2d_sparse_convs_match_the_oracle_on_a_one_slice_volume(dev, strided):
+    """SubMConv2d / SparseConv2d (named in SURVEY §8b): indices (N,3) [b,y,x]; the oracle sees the same sites as a volume
+    with D = 1 and a (1,k,k) kernel"""
+    import spconv.pytorch as spconv
+    rng = np.random.default_rng(78)
+    H, W_ = 150, 130
+    c3 = random_sparse_coords(rng, 7000, 2, [1, H, W_], clustered=False)
+    c2 = np.ascontiguousarray(c3[:, [0, 2, 3]])
+    n = len(c2)
+    torch.manual_seed(6)
+    if strided:
+        conv = spconv.SparseConv2d(16, 32, 3, stride=2, padding=1, bias=True, indice_key='sp').to(dev)
+    else:
+        conv = spconv.SubMConv2d(16, 32, 3, padding=1, bias=True, indice_key='sm').to(dev)
+    X = rng.normal(size=(n, 16)).astype(np.float32)
+    x = _t(X, dev).requires_grad_(True)
+    y = conv(spconv.SparseConvTensor(x, _t(c2, dev), [H, W_], 2))
+    if strided:
+        oc, oshape = oracle.spconv_out(c3, [1, H, W_], [1, 3, 3], [1, 2, 2], [0, 1, 1])
+        nbr = oracle.spconv_nbr(c3, [1, H, W_], oc, [1, 3, 3], [1, 2, 2], [0, 1, 1])
+        assert y.spatial_shape == oshape[1:]
+        np.testing.assert_array_equal(y.indices.cpu().numpy(), oc[:, [0, 2, 3]])
+    else:
+        nbr = oracle.subm_nbr(c3, [1, H, W_], [1, 3, 3])
+        assert y.spatial_shape == [H, W_]
+        np.testing.assert_array_equal(y.indices.cpu().numpy(), c2)
+    dY = rng.normal(size=(nbr.shape[0], 32)).astype(np.float32)
+    y.features.backward(_t(dY, dev))
+    Wk = conv.weight_kio().detach().cpu().numpy()
+    _close(y.features.detach().cpu().numpy(), oracle.conv_fwd(X, Wk, nbr) + conv.bias.detach().cpu().numpy())
+    _close(x.grad.cpu().numpy(), oracle.conv_dgrad(dY, Wk, nbr, n))
+    _close(_kio_grad(conv), oracle.conv_wgrad(X, dY, nbr, 9))
+    _close(conv.bias.grad.cpu().numpy(), dY.sum(0), rtol=2e-4)
+    d = y.dense()
+    assert d.shape == (2, 32) + tuple(y.spatial_shape)
