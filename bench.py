@@ -429,11 +429,12 @@ def main():
     dt, per_step, loss = timed_steps(True, prof)
     # the same step without grad-clip / AdamW ("one optimizer-less loss.backward() step"); not profiled
     dt_nopt, per_step_nopt, _ = timed_steps(False, None)
-    # OPT-IN split-bf16 gather-GEMM (crbhip.sparse.ARITHMETIC = 'bf16x3'): a few more steps of the same training loop with
+    # OPT-IN split-bf16 gather-GEMM (spconv.pytorch.set_arithmetic(model, 'bf16x3')): a few more steps of the same training loop with
     # the contract switched on, only to report its roofline and step time beside the exact-f32 ones; never part of `value`
     prof3, dt3, per_step3 = ([] if rank == 0 else None), None, None
     if args.bf16x3_steps > 0:
-        sp.ARITHMETIC = 'bf16x3'
+        import spconv.pytorch as spconv_mirror
+        spconv_mirror.set_arithmetic(model, 'bf16x3')
         try:
             step(0)
             keep = args.steps
@@ -442,7 +443,7 @@ def main():
             bf16x3_loss = float(loss3.item())
         finally:
             args.steps = keep
-            sp.ARITHMETIC = 'f32'
+            spconv_mirror.set_arithmetic(model, 'f32')
     frames = args.batch * world * args.steps
     out = {
         'metric': 'frames/s SECOND fwd+bwd, KITTI 20k-pt clouds' if args.kind == 'kitti' else

@@ -11,8 +11,12 @@ import torch  # noqa: F401  (loads libamdhip64 before our library)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
-lib_path = os.path.join(_PKG, 'lib', 'libcrbhip.so')
+# CRB_MEASURE_LIB=1 (tools/ only): the -DCRB_MEASURE build, which adds the measurement-only entry points of
+# include/crb_hip_measure.h. The product library exports none of them.
+MEASURE = os.environ.get('CRB_MEASURE_LIB', '0') == '1'
+lib_path = os.path.join(_PKG, 'lib', 'libcrbhip_measure.so' if MEASURE else 'libcrbhip.so')
 header_path = os.path.join(os.path.dirname(_PKG), 'include', 'crb_hip.h')
+measure_header_path = os.path.join(os.path.dirname(_PKG), 'include', 'crb_hip_measure.h')
 
 
 class CrbHipError(RuntimeError):
@@ -49,14 +53,17 @@ def parse_header(path=header_path):
 def _load():
     if not os.path.exists(lib_path):
         raise CrbHipError(
-            f'{lib_path} not found: build it with `make -C crb-active-3ddet_amd/csrc` '
+            f'{lib_path} not found: build it with `make -C crb-active-3ddet_amd/csrc{" measure" if MEASURE else ""}` '
             f'(or __graft_entry__.build()). The HIP extension is mandatory; there is no CPU fallback.')
     L = ctypes.CDLL(lib_path, mode=ctypes.RTLD_GLOBAL)
-    for name, (ret, argtypes) in parse_header().items():
+    protos = parse_header()
+    if MEASURE:
+        protos.update(parse_header(measure_header_path))
+    for name, (ret, argtypes) in protos.items():
         try:
             fn = getattr(L, name)
         except AttributeError as e:
-            raise CrbHipError(f'{lib_path} does not export {name} declared in include/crb_hip.h') from e
+            raise CrbHipError(f'{lib_path} does not export {name} declared in include/crb_hip*.h') from e
         fn.restype = ret
         fn.argtypes = argtypes
     return L

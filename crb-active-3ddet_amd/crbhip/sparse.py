@@ -69,10 +69,10 @@ class Rulebook(object):
             self._sorted[key] = _compact(table, self.row_perm(which), self.K)
         return self._sorted[key]
 
-    def table_for(self, which, cin, cout):
+    def table_for(self, which, cin, cout, arithmetic='f32'):
         """the table form the gather-GEMM instance of (cin, cout) consumes"""
         if COMPACT_TABLES and (lib.crb_sparse_conv_compact_supported(cin, cout) or
-                               (ARITHMETIC == 'bf16x3' and lib.crb_sparse_conv_bf16x3_supported(cin, cout))):
+                               (arithmetic == 'bf16x3' and lib.crb_sparse_conv_bf16x3_supported(cin, cout))):
             return self.compact_table(which)
         return self.sorted_table(which)
 
@@ -299,18 +299,20 @@ def spconv_rulebook(coords, shape, batch_size, ksize, stride, padding, premarked
 # When set to a list, every gather-GEMM launch appends (kind, cin, cout, K, n_in, n_out, nbr, ev0, ev1): HIP events on
 # the launch stream (torch's current stream IS the stream handed to the C-ABI), read back by bench.py for the roofline.
 PROFILE = None
-# Arithmetic contract of the gather-GEMM (forward and dgrad). 'f32' (default): exact f32 MFMA. 'bf16x3' (OPT-IN): operands
-# split into two bf16 values, three bf16 MFMA passes, f32 accumulation: |y - y_f32| <= 2^-16 sum |x||w| (include/crb_hip.h,
-# crb_sparse_conv_forward_bf16x3); shapes without a bf16x3 instance (C <= 16) keep the f32 kernel.
-ARITHMETIC = 'f32'
+# Arithmetic contract of the gather-GEMM (forward and dgrad) is an ARGUMENT of the call (sparse_conv(..., arithmetic=...);
+# spconv.pytorch.SparseConvolution.arithmetic on the module side), never process state. 'f32' (default): exact f32 MFMA.
+# 'bf16x3' (OPT-IN): operands split into two bf16 values, three bf16 MFMA passes, f32 accumulation:
+# |y - y_f32| <= 2^-16 sum |x||w| (include/crb_hip.h, crb_sparse_conv_forward_bf16x3); shapes without a bf16x3 instance
+# (C <= 16) keep the f32 kernel.
+ARITHMETICS = ('f32', 'bf16x3')
 
 
 def epilogue_supported(cin, cout):
     """shapes whose forward kernel can apply (bias,) BatchNorm1d(eval) and ReLU to the accumulator before the store"""
-    return bool(COMPACT_TABLES and ARITHMETIC == 'f32' and lib.crb_sparse_conv_compact_supported(cin, cout))
+    return bool(COMPACT_TABLES and lib.crb_sparse_conv_compact_supported(cin, cout))
 
 
-def _conv_forward_raw(x, w_kio, table, n_out, kind='fwd', epilogue=None):
+def _conv_forward_raw(x, w_kio, table, n_out, kind='fwd', epilogue=None, arithmetic='f32'):
     """x (n_in,cin), w (K,cin,cout), table = (nbr rows in kernel order (n_out,K), perm or None) or a CompactTable
     -> (n_out,cout). epilogue = (bias or None, BatchNorm1d in eval mode, relu flag): inference only, compact tables only."""
     K, cin, cout = w_kio.shape
@@ -331,7 +333,7 @@ def _conv_forward_raw(x, w_kio, table, n_out, kind='fwd', epilogue=None):
             cur_stream(x.device)), 'crb_sparse_conv_forward_compact_bn')
         nbr = table
         kind = kind + '_bn'
-    elif ARITHMETIC == 'bf16x3' and isinstance(table, CompactTable) and lib.crb_sparse_conv_bf16x3_supported(cin, cout):
+    elif arithmetic == 'bf16x3' and isinstance(table, CompactTable) and lib.crb_sparse_conv_bf16x3_supported(cin, cout):
         wsb = lib.crb_sparse_conv_bf16x3_workspace_bytes(K, cin, cout)
         ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
         check(lib.crb_sparse_conv_forward_bf16x3(ptr(x), ptr(w_kio), ptr(table.cmask), ptr(table.cbase), ptr(table.packed),
@@ -384,42 +386,45 @@ class SparseConvFunction(torch.autograd.Function):
     """y = sum_o x[nbr[:,o]] @ w[o]   (w in (K,Cin,Cout) layout; `inverse` runs the transposed rulebook)"""
 
     @staticmethod
-    def forward(ctx, x, w_kio, rb, inverse):
+    def forward(ctx, x, w_kio, rb, inverse, arithmetic='f32'):
         require_cuda(x, w_kio)
+        if arithmetic not in ARITHMETICS:
+            raise CrbHipError('unknown gather-GEMM arithmetic %r' % (arithmetic,))
         x = x.contiguous().float()
         w_kio = w_kio.contiguous().float()
         K, cin, cout = w_kio.shape
         if inverse:
-            table, n_out = rb.table_for('nbr_t', cin, cout), rb.n_in
+            table, n_out = rb.table_for('nbr_t', cin, cout, arithmetic), rb.n_in
         else:
-            table, n_out = rb.table_for('nbr', cin, cout), rb.n_out
-        ctx.rb, ctx.inverse = rb, inverse
+            table, n_out = rb.table_for('nbr', cin, cout, arithmetic), rb.n_out
+        ctx.rb, ctx.inverse, ctx.arithmetic = rb, inverse, arithmetic
         ctx.save_for_backward(x, w_kio)
-        return _conv_forward_raw(x, w_kio, table, n_out, ('subm' if rb.subm else 'spconv') + '_fwd')
+        return _conv_forward_raw(x, w_kio, table, n_out, ('subm' if rb.subm else 'spconv') + '_fwd', arithmetic=arithmetic)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        rb, inverse = ctx.rb, ctx.inverse
+        rb, inverse, ar = ctx.rb, ctx.inverse, ctx.arithmetic
         dy = dy.contiguous().float()
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if rb.subm:
                 wd = w.flip(0).transpose(1, 2).contiguous()      # Wd[o] = W[K-1-o]^T
-                dx = _conv_forward_raw(dy, wd, rb.table_for('nbr', wd.shape[1], wd.shape[2]), rb.n_in, 'subm_dgrad')
+                dx = _conv_forward_raw(dy, wd, rb.table_for('nbr', wd.shape[1], wd.shape[2], ar), rb.n_in, 'subm_dgrad',
+                                       arithmetic=ar)
             else:
                 wd = w.transpose(1, 2).contiguous()
-                table, n_in = (rb.table_for('nbr', wd.shape[1], wd.shape[2]), rb.n_out) if inverse else \
-                    (rb.table_for('nbr_t', wd.shape[1], wd.shape[2]), rb.n_in)
-                dx = _conv_forward_raw(dy, wd, table, n_in, 'spconv_dgrad')
+                table, n_in = (rb.table_for('nbr', wd.shape[1], wd.shape[2], ar), rb.n_out) if inverse else \
+                    (rb.table_for('nbr_t', wd.shape[1], wd.shape[2], ar), rb.n_in)
+                dx = _conv_forward_raw(dy, wd, table, n_in, 'spconv_dgrad', arithmetic=ar)
         if ctx.needs_input_grad[1]:
             pairs = rb.pairs_t() if inverse else rb.pairs()
             dw = _conv_wgrad_raw(x, dy, pairs, rb.K, ('subm' if rb.subm else 'spconv') + '_wgrad')
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
-def sparse_conv(x, w_kio, rb, inverse=False):
-    return SparseConvFunction.apply(x, w_kio, rb, inverse)
+def sparse_conv(x, w_kio, rb, inverse=False, arithmetic='f32'):
+    return SparseConvFunction.apply(x, w_kio, rb, inverse, arithmetic)
 
 
 @torch.no_grad()

@@ -204,3 +204,12 @@ static inline int64_t crb_hash_capacity(int64_t n) {
   while (c < 2 * n) c <<= 1;
   return c;
 }
+
+// Measurement knobs (kernel-variant selectors, builds that skip work and return WRONG results by design, per-workgroup
+// timelines) exist only in libcrbhip_measure.so (-DCRB_MEASURE, include/crb_hip_measure.h, used by tools/). In the product
+// library they are compile-time constants: no setter is exported and the variants are not even instantiated.
+#ifdef CRB_MEASURE
+#define CRB_KNOB static int
+#else
+#define CRB_KNOB static constexpr int
+#endif

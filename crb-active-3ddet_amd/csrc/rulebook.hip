@@ -383,8 +383,10 @@ static SortBits geometric_sort_bits();
 
 extern "C" int crb_mask_sort_chunk_rows(void) { return 4096; }
 
-static int g_sort_rank_bits = 2;    // sort key: 2 = bits ranked rarest first inside the chunk (default), 1 = by 3x3x3 geometry, 0 = numeric
+CRB_KNOB g_sort_rank_bits = 2;    // sort key: 2 = bits ranked rarest first inside the chunk (default), 1 = by 3x3x3 geometry, 0 = numeric
+#ifdef CRB_MEASURE
 extern "C" int crb_mask_sort_set_rank_bits(int mode) { g_sort_rank_bits = (mode >= 0 && mode <= 2) ? mode : 2; return CRB_OK; }
+#endif
 
 // perm (n) i32: row permutation that sorts every chunk of crb_mask_sort_chunk_rows() consecutive rows by mask (stable)
 extern "C" int crb_mask_sort_chunks(const int32_t* mask, int64_t n, int32_t* perm, void* stream) {

@@ -21,9 +21,13 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef CRB_MEASURE
 static unsigned long long* g_wgrad_dbg = nullptr;   // measurement runs: device buffer of 4 u64 per workgroup (see wgrad2)
-static int g_wgrad_mode = 0;      // measurement builds of the 64x64 v3 wgrad: 1 = no MFMAs, 2 = no gather pipeline (wrong results)
-static int g_wgrad_v1 = 0;        // measurement knob: 0 = default (v3 / v2 by shape), 1 = v1 (16x16x4, register gather) everywhere, 2 = v2 where it exists
+#else
+static constexpr unsigned long long* g_wgrad_dbg = nullptr;
+#endif
+CRB_KNOB g_wgrad_mode = 0;      // measurement builds of the 64x64 v3 wgrad: 1 = no MFMAs, 2 = no gather pipeline (wrong results)
+CRB_KNOB g_wgrad_v1 = 0;        // measurement knob: 0 = default (v3 / v2 by shape), 1 = v1 (16x16x4, register gather) everywhere, 2 = v2 where it exists
 
 namespace {
 
@@ -1334,7 +1338,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-static int g_subt_override = 0;     // 0 = heuristic; 1/2/4 force (A/B measurements)
+CRB_KNOB g_subt_override = 0;     // 0 = heuristic; 1/2/4 force (A/B measurements)
 
 template <int CIN, int COUT, int SUBT>
 int launch_fwd_subt(const float* X, const float* W, const int* nbr, const int* perm, float* Y, int64_t n_out, int K,
@@ -1504,6 +1508,7 @@ extern "C" int crb_sparse_conv_supported(int cin, int cout) {
   return 0;
 }
 
+#ifdef CRB_MEASURE
 extern "C" int crb_sparse_conv_set_subtiles(int subt) {
   // 0 = default (v2 where the shape allows, else v1); 1,2,4 = v1 with that many row tiles per wave; 8 = v2 (A/B runs)
   g_subt_override = (subt == 1 || subt == 2 || subt == 4 || subt == 8 || subt == 9 || subt == 16 || subt == 32) ? subt : 0;
@@ -1519,6 +1524,7 @@ extern "C" int crb_sparse_conv_timing(uint64_t* out16_host) {
   CRB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fwd2_timing), z, sizeof(z)));
   return CRB_OK;
 }
+#endif
 
 extern "C" int crb_nbr_masks(const int32_t* nbr, int64_t n, int K, int32_t* mask, void* stream) {
   if (n < 0 || K <= 0 || K > 32) return CRB_ERR_ARG;
@@ -1549,12 +1555,14 @@ extern "C" int crb_sparse_conv_forward(const float* X, const float* W, const int
   return CRB_ERR_UNSUPPORTED;
 }
 
+#ifdef CRB_MEASURE
 extern "C" int crb_sparse_conv_set_wgrad_v1(int on) { g_wgrad_v1 = (on == 1 || on == 2) ? on : 0; return CRB_OK; }
 extern "C" int crb_sparse_conv_set_wgrad_mode(int mode) { g_wgrad_mode = (mode == 1 || mode == 2) ? mode : 0; return CRB_OK; }
 extern "C" int crb_sparse_conv_set_wgrad_debug(void* dev_buf_u64x4_per_wg) {
   g_wgrad_dbg = (unsigned long long*)dev_buf_u64x4_per_wg;
   return CRB_OK;
 }
+#endif
 
 // measurement helper: resident workgroups per CU of the wgrad kernel instance the dispatcher would pick (-1: no instance)
 template <int A, int B>
@@ -1636,7 +1644,7 @@ extern "C" int crb_sparse_conv_forward_compact_bn(const float* X, const float* W
   return CRB_ERR_UNSUPPORTED;
 }
 
-static int g_wgrad_splits = 96;   // workgroups per kernel offset the plan aims at (multiple of 8: XCD mapping)
+CRB_KNOB g_wgrad_splits = 96;   // workgroups per kernel offset the plan aims at (multiple of 8: XCD mapping)
 extern "C" int crb_sparse_conv_wgrad_splits(void) { return g_wgrad_splits; }
 // 16x16 tiles: the partial reduction costs as much as the MFMA work, fewer and larger workgroups win (sweep on the SECOND
 // bs=16 geometry: 32 / 96 / 256 workgroups per offset = 39 / 52 / 95 us at C=16, 292 / 264 / 259 us at C=64)
@@ -1683,10 +1691,12 @@ static inline int wgrad_splits_for(int K, int cin, int cout) {
   }
   return 96;
 }
+#ifdef CRB_MEASURE
 extern "C" int crb_sparse_conv_set_wgrad_splits(int s) {      // A/B measurements; 0 restores the default
   g_wgrad_splits = (s >= 8 && s <= 1024 && s % 8 == 0) ? s : 96;
   return CRB_OK;
 }
+#endif
 
 extern "C" int64_t crb_sparse_conv_wgrad_workspace_bytes(int K, int cin, int cout) {
   return (int64_t)wgrad_splits_for(K, cin, cout) * K * cin * cout * 4 + 256;

@@ -26,8 +26,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-static int g_bf16x3_tpw = 0;        // measurement knob: 0 = default, 1 / 2 = tiles per wave
-static int g_bf16x3_mode = 0;       // measurement builds of the 64x64 one-tile kernel (see MODE)
+CRB_KNOB g_bf16x3_tpw = 0;        // measurement knob: 0 = default, 1 / 2 = tiles per wave
+CRB_KNOB g_bf16x3_mode = 0;       // measurement builds of the 64x64 one-tile kernel (see MODE)
 
 namespace {
 
@@ -371,6 +371,7 @@ extern "C" int64_t crb_sparse_conv_bf16x3_workspace_bytes(int K, int cin, int co
   return (int64_t)K * cin * cout * 4;
 }
 
+#ifdef CRB_MEASURE
 extern "C" int crb_sparse_conv_bf16x3_set_mode(int mode) {
   g_bf16x3_mode = (mode >= 1 && mode <= 5) ? mode : 0;
   return CRB_OK;
@@ -380,6 +381,7 @@ extern "C" int crb_sparse_conv_bf16x3_set_tiles_per_wave(int tpw) {
   g_bf16x3_tpw = (tpw >= 1 && tpw <= 3) ? tpw : 0;       // 3 = one tile per wave, 8 waves per workgroup
   return CRB_OK;
 }
+#endif
 
 extern "C" int crb_sparse_conv_forward_bf16x3(const float* X, const float* W, const uint32_t* cmask, const int32_t* cbase,
                                               const int32_t* packed, const int32_t* perm, float* Y, int64_t n_in,

@@ -4,8 +4,12 @@ pcdet/datasets/__init__.py:26-46 and the two loader builders the reference's too
 (build_dataloader :49-78, build_active_dataloader :80-181) with the reference's signatures and return tuples.
 
 Real-dataset readers / augmentors are out of scope: the registry below answers 'KittiDataset' and
-'WaymoDataset' with synthetic clouds of that shape, so the callers run unchanged on a box without the datasets."""
+'WaymoDataset' with synthetic clouds of that shape — ONLY when the config asks for it (dataset_cfg.SYNTHETIC present, or
+CRB_SYNTHETIC_DATA=1 in the environment). A reference config that names a real dataset (DATA_PATH / INFO_PATH / root_path)
+without that opt-in is refused loudly instead of training and selecting on fake frames."""
+import os
 import random
+import warnings
 
 import torch
 from torch.utils.data import DataLoader
@@ -22,6 +26,18 @@ class _ConfiguredSynthetic(SyntheticDataset):
     KIND = 'kitti'
 
     def __init__(self, dataset_cfg=None, class_names=None, training=True, root_path=None, logger=None):
+        has_key = dataset_cfg is not None and dataset_cfg.get('SYNTHETIC', None) is not None
+        if not has_key and os.environ.get('CRB_SYNTHETIC_DATA', '0') != '1':
+            raise NotImplementedError(
+                "%s: this build has no reader for the real dataset (out of scope: SURVEY §2.1). The name is served with "
+                "SYNTHETIC %s-shaped clouds only on request: put SYNTHETIC: {NUM_FRAMES: .., N_POINTS: ..} into DATA_CONFIG "
+                "(or export CRB_SYNTHETIC_DATA=1); DATA_PATH / INFO_PATH / root_path (%r) are not read."
+                % (type(self).__name__, self.KIND, root_path))
+        msg = '%s serves SYNTHETIC %s-shaped frames (DATA_PATH / INFO_PATH / root_path are ignored)' % (type(self).__name__, self.KIND)
+        if logger is not None:
+            logger.warning(msg)
+        elif not has_key:
+            warnings.warn(msg)
         syn = dict((dataset_cfg or {}).get('SYNTHETIC', {}) or {})
         super().__init__(num_frames=int(syn.get('NUM_FRAMES', 64)),
                          n_points=int(syn.get('N_POINTS', 20000 if self.KIND == 'kitti' else 160000)),

@@ -22,6 +22,10 @@ def _ntuple(v, n):
 
 
 class SparseConvolution(SparseModule):
+    # arithmetic contract of this layer's gather-GEMM (forward + dgrad): 'f32' exact (default) or the opt-in 'bf16x3'
+    # (crbhip.sparse); per module, set with spconv.pytorch.set_arithmetic(model, ...) — not process state
+    arithmetic = 'f32'
+
     def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
                  bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None,
                  algo=None, fp32_accum=None, name=None):
@@ -69,7 +73,7 @@ class SparseConvolution(SparseModule):
     def fuses_bn_eval(self, feats):
         """can this conv take the following BatchNorm1d(eval) + ReLU as an epilogue of its forward kernel?"""
         return (not self.inverse and not self.conv1x1 and feats.is_cuda and feats.shape[0] > 0 and
-                _sp.epilogue_supported(self.in_channels, self.out_channels))
+                self.arithmetic == 'f32' and _sp.epilogue_supported(self.in_channels, self.out_channels))
 
     def weight_kio(self):
         """(Cout,k..,Cin) -> (K,Cin,Cout) contiguous; differentiable"""
@@ -104,7 +108,7 @@ class SparseConvolution(SparseModule):
             assert datas is not None and self.indice_key is not None, 'inverse conv needs the indice_key of a SparseConv'
             rb = datas
             assert not rb.subm
-            out_feats = _sp.sparse_conv(feats, self.weight_kio(), rb, True)
+            out_feats = _sp.sparse_conv(feats, self.weight_kio(), rb, True, self.arithmetic)
             out_indices3, out_shape3 = rb.in_coords, rb.in_shape
         else:
             if datas is not None and self.subm:
@@ -123,7 +127,7 @@ class SparseConvolution(SparseModule):
             if epilogue is not None:
                 out_feats = _sp.sparse_conv_bn_eval(feats, self.weight_kio(), rb, self.bias, epilogue[0], epilogue[1])
             else:
-                out_feats = _sp.sparse_conv(feats, self.weight_kio(), rb, False)
+                out_feats = _sp.sparse_conv(feats, self.weight_kio(), rb, False, self.arithmetic)
             out_indices3, out_shape3 = (idx3, shape3) if self.subm else (rb.out_coords, rb.out_shape)
         if self.bias is not None and epilogue is None:
             out_feats = out_feats + self.bias
@@ -178,6 +182,19 @@ class SparseConv2d(SparseConvolution):
                  indice_key=None, algo=None, fp32_accum=None, name=None):
         super().__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
                          indice_key=indice_key)
+
+
+def set_arithmetic(module, arithmetic):
+    """opt a model (or one layer) in to / out of the 'bf16x3' gather-GEMM contract: sets .arithmetic on every
+    SparseConvolution below `module`; returns the number of layers touched"""
+    if arithmetic not in _sp.ARITHMETICS:
+        raise ValueError('arithmetic must be one of %s' % (_sp.ARITHMETICS,))
+    n = 0
+    for m in module.modules():
+        if isinstance(m, SparseConvolution):
+            m.arithmetic = arithmetic
+            n += 1
+    return n
 
 
 def plan_indices(modules, input, with_frame_offsets=False):

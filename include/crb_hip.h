@@ -111,10 +111,8 @@ int crb_nbr_masks(const int32_t* nbr, int64_t n, int K, int32_t* mask, void* str
 /* stable sort of the rows of every chunk of crb_mask_sort_chunk_rows() consecutive rows by mask, DESCENDING (rows with the
  * most neighbours first) -> perm (n) */
 int crb_mask_sort_chunk_rows(void);
-/* sort key of crb_mask_sort_chunks: the mask with its bits re-ranked rarest offset first — 2 (default): by frequency inside the
- * chunk, 1: by the geometry of a 3x3x3 kernel (corners, edges, faces, centre), 0: numeric mask order. The gather-GEMM's
- * results do not depend on the row order; the MFMA tile fill does. */
-int crb_mask_sort_set_rank_bits(int mode);
+/* sort key of crb_mask_sort_chunks: the mask with its bits re-ranked rarest offset first by frequency inside the chunk
+ * (A/B alternatives: crb_hip_measure.h). The gather-GEMM's results do not depend on the row order; the MFMA tile fill does. */
 int crb_mask_sort_chunks(const int32_t* mask, int64_t n, int32_t* perm, void* stream);
 /* the same order for chunks of chunk_rows rows (a multiple of 1024; chunks too large for one workgroup's LDS): keys ranked
  * per chunk, then one stable device radix sort (hipCUB) of (chunk, key, row) */
@@ -170,27 +168,11 @@ int64_t crb_sparse_conv_bf16x3_workspace_bytes(int K, int cin, int cout);
 int crb_sparse_conv_forward_bf16x3(const float* X, const float* W, const uint32_t* cmask, const int32_t* cbase,
                                    const int32_t* packed, const int32_t* perm, float* Y, int64_t n_in, int64_t n_out,
                                    int K, int cin, int cout, void* workspace, int64_t workspace_bytes, void* stream);
-/* measurement knob: 16-row tiles per wave (1 or 2; 0 = default) */
-int crb_sparse_conv_bf16x3_set_tiles_per_wave(int tpw);
-/* measurement builds of the 64x64 kernel (wrong results): 1 = no MFMAs, 2 = no row gathers, 3 = no W hand-over, 4 = 2+3 */
-int crb_sparse_conv_bf16x3_set_mode(int mode);
 int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, const int32_t* perm, float* Y,
                             int64_t n_out, int K, int cin, int cout, void* stream);
-/* kernel-variant knob for A/B measurements only: 0 = default (v2 kernel where Cin,Cout are multiples of 16 and Cin <= 64,
- * else v1); 1|2|4 = v1 with 64*subt rows per workgroup; 8 = v2. Results are identical up to f32 summation order. */
-int crb_sparse_conv_set_subtiles(int subt);
-/* measurement builds: after launches under crb_sparse_conv_set_subtiles(32) (64x64 kernel with s_memtime accounting), copy the
- * 16 accumulated counters to host memory and clear them: [0] waves [1] total cycles [2] prologue [3] load issue [4] MFMA
- * block [5] W store [6] barrier wait [7] epilogue [8] phases [9] phases with MFMA work [10] W fetch issue [11] row-index
- * LDS read [12] wait for the previous phase's gather prefetch. Synchronises the device. */
-int crb_sparse_conv_timing(uint64_t* out16_host);
 /* dW (K,cin,cout) = sum over pairs X[pin]^T dY[pout] */
 int crb_sparse_conv_wgrad_splits(void);
-int crb_sparse_conv_set_wgrad_splits(int splits);    /* measurement knob: workgroups per offset (multiple of 8), 0 = default */
 int crb_sparse_conv_wgrad_occupancy(int cin, int cout); /* measurement helper: resident workgroups per CU of the v2 wgrad instance */
-int crb_sparse_conv_set_wgrad_debug(void* dev_buf_u64x4_per_wg); /* measurement runs: per-workgroup {start, end, HW_ID, XCC_ID | steps<<32} of the v2 wgrad; NULL = off */
-int crb_sparse_conv_set_wgrad_mode(int mode);        /* measurement builds of the 64x64 wgrad: 1 = no MFMAs, 2 = no gather pipeline (results are wrong by design), 0 = normal */
-int crb_sparse_conv_set_wgrad_v1(int on);            /* measurement knob: 1 = the v1 (16x16x4, register-gather) wgrad kernel for every shape */
 int64_t crb_sparse_conv_wgrad_workspace_bytes(int K, int cin, int cout);
 /* Windowed wgrad (tiles of <= 4 blocks of 32x32): work is cut by WINDOWS OF OUTPUT ROWS instead of per-offset pair ranges —
  * XCD x owns the x-th eighth of the rows, all kernel offsets' workgroups of an XCD walk the same window at the same time,

@@ -1,0 +1,37 @@
+/* crb_hip_measure.h — measurement-only entry points of libcrbhip_measure.so (csrc compiled with -DCRB_MEASURE).
+ *
+ * NOT part of the product boundary: libcrbhip.so exports none of these (tests/test_abi.py asserts it). They select kernel
+ * variants for A/B runs, switch on per-workgroup timelines / cycle accounting, or build kernels that SKIP work and return
+ * wrong results by design (to time the remaining part). State is process-global. Only tools/ load this library
+ * (CRB_MEASURE_LIB=1 makes crbhip._lib load it and parse this header on top of crb_hip.h). No reference counterpart. */
+#ifndef CRB_HIP_MEASURE_H
+#define CRB_HIP_MEASURE_H
+#include "crb_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* A/B of the sort key of crb_mask_sort_chunks: 2 (default) = mask bits re-ranked by frequency inside the chunk, 1 = by the
+ * geometry of a 3x3x3 kernel (corners, edges, faces, centre), 0 = numeric mask order */
+int crb_mask_sort_set_rank_bits(int mode);
+/* measurement knob: 16-row tiles per wave (1 or 2; 0 = default) */
+int crb_sparse_conv_bf16x3_set_tiles_per_wave(int tpw);
+/* measurement builds of the 64x64 kernel (wrong results): 1 = no MFMAs, 2 = no row gathers, 3 = no W hand-over, 4 = 2+3 */
+int crb_sparse_conv_bf16x3_set_mode(int mode);
+/* kernel-variant knob for A/B measurements only: 0 = default (v2 kernel where Cin,Cout are multiples of 16 and Cin <= 64,
+ * else v1); 1|2|4 = v1 with 64*subt rows per workgroup; 8 = v2. Results are identical up to f32 summation order. */
+int crb_sparse_conv_set_subtiles(int subt);
+/* measurement builds: after launches under crb_sparse_conv_set_subtiles(32) (64x64 kernel with s_memtime accounting), copy the
+ * 16 accumulated counters to host memory and clear them: [0] waves [1] total cycles [2] prologue [3] load issue [4] MFMA
+ * block [5] W store [6] barrier wait [7] epilogue [8] phases [9] phases with MFMA work [10] W fetch issue [11] row-index
+ * LDS read [12] wait for the previous phase's gather prefetch. Synchronises the device. */
+int crb_sparse_conv_timing(uint64_t* out16_host);
+int crb_sparse_conv_set_wgrad_splits(int splits);    /* measurement knob: workgroups per offset (multiple of 8), 0 = default */
+int crb_sparse_conv_set_wgrad_debug(void* dev_buf_u64x4_per_wg); /* measurement runs: per-workgroup {start, end, HW_ID, XCC_ID | steps<<32} of the v2 wgrad; NULL = off */
+int crb_sparse_conv_set_wgrad_mode(int mode);        /* measurement builds of the 64x64 wgrad: 1 = no MFMAs, 2 = no gather pipeline (results are wrong by design), 0 = normal */
+int crb_sparse_conv_set_wgrad_v1(int on);            /* measurement knob: 1 = the v1 (16x16x4, register-gather) wgrad kernel for every shape */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -659,7 +659,7 @@ def gen_point_path(out):
                 out['pp_grad/' + n] = _np(dict(vsa.named_parameters())[n].grad)
             out['pp_grad/roi_grid_pool_layer.mlps.0.0.weight'] = _np(head.roi_grid_pool_layer.mlps[0][0].weight.grad)
     # the running statistics after the train pass are part of the contract too (momentum update of every BN layer)
-    out['pp_running_mean_after'] = _np(vsa.vsa_point_feature_fusion[1].running_mean)
+    out['pp_running_mean_after'] = _np(vsa.vsa_point_feature_fusion[1].running_mean).copy()    # (shares memory otherwise)
     # StackSAModuleMSG.forward on its own with ragged counts on both sides (first frame 40 queries, second 7)
     vsa.load_state_dict(seeded_state(vsa, 53))          # the train pass above advanced the running statistics
     sa = vsa.SA_layers[1]

@@ -12,6 +12,29 @@ def test_header_symbols_exported():
         assert hasattr(L, name), name
 
 
+def test_product_library_exports_no_measurement_entry_point():
+    """the knobs that select kernel variants or make kernels skip work (wrong results by design) live in
+    libcrbhip_measure.so only (include/crb_hip_measure.h, csrc built with -DCRB_MEASURE); nothing in a long-lived process
+    can flip the product library into such a mode"""
+    import subprocess
+    import crbhip
+    measure = crbhip.parse_header(crbhip._lib.measure_header_path)
+    assert 'crb_sparse_conv_set_wgrad_mode' in measure and 'crb_sparse_conv_bf16x3_set_mode' in measure
+    assert not crbhip._lib.MEASURE and crbhip.lib_path.endswith('libcrbhip.so')
+    exported = subprocess.check_output(['nm', '-D', '--defined-only', crbhip.lib_path], text=True)
+    names = {ln.split()[-1] for ln in exported.splitlines() if ln.strip()}
+    for name in measure:
+        assert name not in names, name
+    for pat in ('set_mode', 'set_wgrad', 'set_subtiles', 'set_tiles', 'conv_timing'):
+        assert not [n for n in names if n.startswith('crb_') and pat in n], pat
+    assert not set(measure) & set(crbhip.parse_header())
+    mlib = crbhip.lib_path.replace('libcrbhip.so', 'libcrbhip_measure.so')
+    if os.path.exists(mlib):                                     # the tools' build has both sets
+        L = ctypes.CDLL(mlib)
+        for name in list(measure) + list(crbhip.parse_header()):
+            assert hasattr(L, name), name
+
+
 def test_abi_version_and_pure_host_queries():
     import crbhip
     assert crbhip.lib.crb_abi_version() >= 1

@@ -24,10 +24,13 @@ def test_second_kitti_step_matches_cpu_oracle(dev):
 
 def test_second_waymo_shaped_step_matches_cpu_oracle(dev):
     """configs[4] shapes at B=1 against the oracle step: 5 point features, [41,1504,1504] grid, 188x188 BEV map, the Waymo
-    anchors; same tolerances as smoke() (10 x the KITTI errors observed) except the first sparse layer (conv_input sums
-    ~100k voxel rows per weight entry: 3e-3)"""
+    anchors. Loss, loss parts and the head gradient keep smoke()'s tolerances. The sparse weight gradients are sums that
+    cancel to ~1e-3 of their terms, so they carry the rounding noise of the dense half's convolution algorithms amplified:
+    two GPU runs of this very step that differ only in the storage order of the BEV map (channels_last vs NCHW, i.e. other
+    MIOpen kernels) differ by 1.4e-3 (conv_out) / 1.9e-3 (conv_input) relative L2 (tools/grad_noise.py, r03); observed
+    against the oracle: 2.0e-3 / 1.6e-3. Tolerance = 3 x that floor; a wrong kernel or rulebook gives O(1)."""
     import __graft_entry__ as ge
-    tol = dict(ge.SMOKE_TOL, conv_input=3e-3, conv_out=2e-3)
+    tol = dict(ge.SMOKE_TOL, conv_input=6e-3, conv_out=6e-3)
     msg, err = ge.second_step_parity('waymo', 1, 160000, tol=tol)
     print(msg)
 
@@ -218,14 +221,14 @@ def test_pointwise_conv_as_row_gemm(dev):
 
 
 def test_second_step_under_the_bf16x3_contract_stays_close_to_f32(dev):
-    """model-level reading of the opt-in split-bf16 gather-GEMM (crbhip.sparse.ARITHMETIC = 'bf16x3', forward + dgrad of the
+    """model-level reading of the opt-in split-bf16 gather-GEMM (spconv.pytorch.set_arithmetic(model, 'bf16x3'), forward + dgrad of the
     C >= 32 sparse layers): one SECOND training step on the same batch and weights. Both arithmetics are bit-reproducible
     run to run. Loss within 1e-5 relative of the exact-f32 step (measured 2e-6), dense-head gradients within 1e-3 of their
     largest entry (measured 4e-5) — but the WEIGHT gradients of the sparse backbone only within 5e-2 of their largest entry
     (measured 1.4e-2 .. 3.5e-2): they are sums over ~10^5 rows that cancel to ~10^-3 of their terms (BatchNorm makes the
     loss invariant to the scale and shift of every conv output), so a 2^-17 perturbation of the activations shows up ~100x
     larger there, the same factor by which it exceeds f32's own 2^-24 rounding. That is what the contract costs."""
-    from crbhip import sparse
+    import spconv.pytorch as spconv
     from pcdet.datasets import SyntheticDataset
     from pcdet.model_cfgs import second_cfg
     from pcdet.models import build_network
@@ -237,7 +240,7 @@ def test_second_step_under_the_bf16x3_contract_stays_close_to_f32(dev):
              'dense_head.conv_cls.weight')
     res = {}
     for mode in ('f32', 'bf16x3', 'f32'):
-        sparse.ARITHMETIC = mode
+        assert spconv.set_arithmetic(model, mode) == 12
         try:
             model.zero_grad(set_to_none=True)
             for m in model.modules():                          # same running statistics going in
@@ -251,7 +254,7 @@ def test_second_step_under_the_bf16x3_contract_stays_close_to_f32(dev):
                 assert out[0] == res['f32'][0] and all(torch.equal(a, b) for a, b in zip(out[1], res['f32'][1]))
             res[mode] = out
         finally:
-            sparse.ARITHMETIC = 'f32'
+            spconv.set_arithmetic(model, 'f32')
     lf, lb = res['f32'][0], res['bf16x3'][0]
     assert abs(lf - lb) <= 1e-5 * abs(lf) and lf != lb, (lf, lb)
     for n, a, b in zip(names, res['f32'][1], res['bf16x3'][1]):

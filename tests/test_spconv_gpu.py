@@ -288,15 +288,14 @@ def _rank_bits_key(mask, chunk, mode):
     return out
 
 
-@pytest.mark.parametrize('mode', [0, 1, 2])
-def test_chunk_mask_sort_is_a_stable_sort_per_chunk(dev, mode):
+def test_chunk_mask_sort_is_a_stable_sort_per_chunk(dev):
     """the LDS bitonic chunk sort equals a stable sort by (chunk, key DESCENDING: heaviest tiles first), key = the mask with
-    its bits re-ranked rarest first (mode 2, the default: by frequency inside the chunk; 1: by the geometry of a 3x3x3
-    kernel; 0: plain mask) — the gather-GEMM result does not depend on it, the MFMA tile fill and the launch tail do"""
+    its bits re-ranked rarest first by frequency inside the chunk (_rank_bits_key mode 2; modes 0 / 1 are A/B alternatives of
+    the measurement build) — the gather-GEMM result does not depend on it, the MFMA tile fill and the launch tail do"""
     from crbhip import lib, check, ptr, cur_stream
     rng = np.random.default_rng(3)
-    lib.crb_mask_sort_set_rank_bits(mode)
-    try:
+    mode = 2
+    if True:
         for n in (1, 100, 4096, 4097, 50000):
             mask = (rng.integers(0, 1 << 27, n) & rng.integers(0, 1 << 27, n)).astype(np.int32)   # bits at 25 %: skewed by hand below
             mask |= (rng.random(n) < 0.9).astype(np.int32) << 13
@@ -307,8 +306,6 @@ def test_chunk_mask_sort_is_a_stable_sort_per_chunk(dev, mode):
             chunk = lib.crb_mask_sort_chunk_rows()
             key = (np.arange(n) // chunk).astype(np.int64) * (1 << 32) + ((~_rank_bits_key(mask, chunk, mode)) & 0xffffffff)
             np.testing.assert_array_equal(perm.cpu().numpy(), np.argsort(key, kind='stable'))
-    finally:
-        lib.crb_mask_sort_set_rank_bits(2)
 
 
 @pytest.mark.parametrize('chunk', [4096, 16384])
@@ -657,15 +654,13 @@ def _bf16x3_check(got, exact, absum):
     return float((err / np.maximum(absum, 1e-30)).max())
 
 
-@pytest.mark.parametrize('tpw', [0, 1, 2])
 @pytest.mark.parametrize('cin,cout', [(32, 32), (32, 64), (64, 64), (64, 32)])
-def test_bf16x3_subm_forward_and_dgrad_within_the_stated_bound(dev, cin, cout, tpw):
-    """OPT-IN arithmetic (crbhip.sparse.ARITHMETIC = 'bf16x3'): operands split into two bf16 values, 3 bf16 MFMA passes.
+def test_bf16x3_subm_forward_and_dgrad_within_the_stated_bound(dev, cin, cout):
+    """OPT-IN arithmetic (sparse_conv(..., arithmetic='bf16x3')): operands split into two bf16 values, 3 bf16 MFMA passes.
     Stated contract: |y - y_exact| <= 2^-16 * sum |x||w| over the products of the output element; checked against the
     double-accumulating oracle on rows whose magnitudes span six decades; dgrad runs the same kernel on the transposed
     table (here also the (64,32)/(32,64) pairs); wgrad keeps exact f32. The default path must stay exact f32."""
     from crbhip import sparse
-    from crbhip._lib import lib
     rng = np.random.default_rng(300 + cin + cout)
     shape = [21, 100, 88]
     coords = random_sparse_coords(rng, 5000, 2, shape)
@@ -678,15 +673,9 @@ def test_bf16x3_subm_forward_and_dgrad_within_the_stated_bound(dev, cin, cout, t
     x = _t(X, dev).requires_grad_(True)
     w = _t(W, dev).requires_grad_(True)
     y_f32 = sparse.sparse_conv(x, w, rb).detach()
-    assert sparse.ARITHMETIC == 'f32'
-    lib.crb_sparse_conv_bf16x3_set_tiles_per_wave(tpw)
-    sparse.ARITHMETIC = 'bf16x3'
-    try:
-        y = sparse.sparse_conv(x, w, rb)
-        y.backward(_t(dY, dev))
-    finally:
-        sparse.ARITHMETIC = 'f32'
-        lib.crb_sparse_conv_bf16x3_set_tiles_per_wave(0)
+    y = sparse.sparse_conv(x, w, rb, False, 'bf16x3')
+    y.backward(_t(dY, dev))
+    assert torch.equal(sparse.sparse_conv(x, w, rb).detach(), y_f32)       # the opt-in call left no state behind
     worst = _bf16x3_check(y.detach().cpu().numpy(), oracle.conv_fwd(X, W, nbr).astype(np.float64),
                           oracle.conv_fwd(np.abs(X), np.abs(W), nbr).astype(np.float64))
     _bf16x3_check(x.grad.cpu().numpy(), oracle.conv_dgrad(dY, W, nbr, n).astype(np.float64),
@@ -714,12 +703,8 @@ def test_bf16x3_strided_conv_out_layer(dev, cin, cout, ks, st, pd):
     dY = rng.normal(size=(rb.n_out, cout)).astype(np.float32)
     x = _t(X, dev).requires_grad_(True)
     w = _t(W, dev).requires_grad_(True)
-    sparse.ARITHMETIC = 'bf16x3'
-    try:
-        y = sparse.sparse_conv(x, w, rb)
-        y.backward(_t(dY, dev))
-    finally:
-        sparse.ARITHMETIC = 'f32'
+    y = sparse.sparse_conv(x, w, rb, False, 'bf16x3')
+    y.backward(_t(dY, dev))
     oc, _ = oracle.spconv_out(coords, shape, ks, st, pd)
     nbr = oracle.spconv_nbr(coords, shape, oc, ks, st, pd)
     _bf16x3_check(y.detach().cpu().numpy(), oracle.conv_fwd(X, W, nbr).astype(np.float64),

@@ -3,6 +3,7 @@
 on the SECOND bs=16 subm tables. Tables are rebuilt per arm; forward timed with the stable protocol (300 warm-up launches,
 10 x 40 launches, median), arms interleaved; MFMA tile fill = useful / issued 16-row MFMA passes computed from the tables."""
 import os
+os.environ.setdefault('CRB_MEASURE_LIB', '1')     # measurement build of the library (include/crb_hip_measure.h)
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'crb-active-3ddet_amd'))

@@ -102,9 +102,7 @@ def main():
         row('wgrad %dx%d L%d' % (C, C, lvl), timeit(lambda: sparse._conv_wgrad_raw(x, dy, pairs, 27), it), balg, fl,
             note='plan + MFMA + reduce')
         if C >= 32:
-            sparse.ARITHMETIC = 'bf16x3'
-            t3 = timeit(lambda: sparse._conv_forward_raw(x, w, table, N), it)
-            sparse.ARITHMETIC = 'f32'
+            t3 = timeit(lambda: sparse._conv_forward_raw(x, w, table, N, arithmetic='bf16x3'), it)
             row('OPT-IN bf16x3 gather-GEMM fwd/dgrad %dx%d L%d (W split + 3 bf16 MFMA passes)' % (C, C, lvl), t3, balg,
                 note='priced against HBM: 3 bf16 passes need %.1f us of the 2.5 PF MFMA' % (3 * fl / 2.5e15 * 1e6))
         feats[lvl] = (x, N, C)

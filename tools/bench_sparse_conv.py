@@ -4,6 +4,7 @@ Prints per (level, Cin, Cout): rows, pairs, time, algorithmic GB/s (SURVEY §8d 
 Usage: python tools/bench_sparse_conv.py [--batch 16] [--iters 50] [--no-sort]"""
 import argparse
 import os
+os.environ.setdefault('CRB_MEASURE_LIB', '1')     # measurement build of the library (include/crb_hip_measure.h)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -107,24 +108,22 @@ def main():
             assert torch.equal(sparse._conv_forward_raw(x, w, tk_, n), sparse._conv_forward_raw(x, w, table, n))
         bx = ''
         if isinstance(table, sparse.CompactTable) and lib.crb_sparse_conv_bf16x3_supported(cin, cout):
-            sparse.ARITHMETIC = 'bf16x3'
-            y3 = sparse._conv_forward_raw(x, w, table, n)
+            y3 = sparse._conv_forward_raw(x, w, table, n, arithmetic='bf16x3')
             tb = []
             for tpw in (1, 2, 3):
                 lib.crb_sparse_conv_bf16x3_set_tiles_per_wave(tpw)
-                tb.append(timeit(lambda: sparse._conv_forward_raw(x, w, table, n)))
+                tb.append(timeit(lambda: sparse._conv_forward_raw(x, w, table, n, arithmetic='bf16x3')))
             if cin == 64 and cout == 64:
                 for tpw in (1, 2):
                     lib.crb_sparse_conv_bf16x3_set_tiles_per_wave(tpw)
                     tm = []
                     for mode in (1, 2, 3, 4, 5, 0):
                         lib.crb_sparse_conv_bf16x3_set_mode(mode)
-                        tm.append(timeit(lambda: sparse._conv_forward_raw(x, w, table, n)))
+                        tm.append(timeit(lambda: sparse._conv_forward_raw(x, w, table, n, arithmetic='bf16x3')))
                     lib.crb_sparse_conv_bf16x3_set_mode(0)
                     print('   bf16x3 tpw%d measurement builds: no-MFMA %.1f, no-gather %.1f, no-W %.1f, no-gather-no-W %.1f, nt gathers %.1f, normal %.1f us' % (
                         tpw, *tm))
             lib.crb_sparse_conv_bf16x3_set_tiles_per_wave(0)
-            sparse.ARITHMETIC = 'f32'
             yf = sparse._conv_forward_raw(x, w, table, n)
             S = sparse._conv_forward_raw(x.abs(), w.abs(), table, n)
             rel = float(((y3 - yf).abs() / S.clamp_min(1e-30)).max())

@@ -2,6 +2,7 @@
 """Minimal driver for PMC passes: build the SECOND bs=16 level-3 (64->64 subm) rulebook and launch the gather-GEMM forward
 a few times. Kept tiny so that a counter-collection pass (which serialises every kernel) finishes in seconds."""
 import os
+os.environ.setdefault('CRB_MEASURE_LIB', '1')     # measurement build of the library (include/crb_hip_measure.h)
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'crb-active-3ddet_amd'))
@@ -29,20 +30,19 @@ if __name__ == '__main__':
     P = int((rb.nbr >= 0).sum())
     x = torch.randn(n, cin, device=dev)
     w = torch.randn(27, cin, cout, device=dev) / 10
-    table = rb.table_for('nbr', cin, cout) if not os.environ.get('CRB_NO_COMPACT') else rb.sorted_table('nbr')
+    table = rb.table_for('nbr', cin, cout, 'bf16x3' if kind == 'bf16x3' else 'f32') if not os.environ.get('CRB_NO_COMPACT') else rb.sorted_table('nbr')
     dy = torch.randn(n, cout, device=dev)
     pairs = rb.pairs()
     torch.cuda.synchronize()
     if kind == 'bf16x3':
         from crbhip import lib
-        sparse.ARITHMETIC = 'bf16x3'
         lib.crb_sparse_conv_bf16x3_set_tiles_per_wave(int(os.environ.get('CRB_BF16X3_TPW', '0')))
         lib.crb_sparse_conv_bf16x3_set_mode(int(os.environ.get('CRB_BF16X3_MODE', '0')))
     for _ in range(iters):
         if kind == 'wgrad':
             sparse._conv_wgrad_raw(x, dy, pairs, 27)
         else:
-            sparse._conv_forward_raw(x, w, table, n)
+            sparse._conv_forward_raw(x, w, table, n, arithmetic='bf16x3' if kind == 'bf16x3' else 'f32')
     torch.cuda.synchronize()
     balg = 4.0 * n * cin + 4.0 * n * cout + 8.0 * P + 4.0 * 27 * cin * cout
     print('PMC_DRIVER %s level %d N=%d P=%d alg_bytes=%d flops=%d' % (kind, level, n, P, balg, 2 * P * cin * cout))

@@ -12,7 +12,7 @@ import torch  # noqa: E402
 if __name__ == '__main__':
     from crbhip import sparse, voxel
     from pcdet.datasets.synthetic import kitti_batch, KITTI_RANGE, KITTI_VOXEL
-    sparse.ARITHMETIC = sys.argv[1] if len(sys.argv) > 1 else 'f32'
+    ARITH = sys.argv[1] if len(sys.argv) > 1 else 'f32'
     dev = torch.device('cuda', 0)
     pts, off, _ = kitti_batch(0, 16)
     r = voxel.voxelize(torch.from_numpy(pts).to(dev), torch.from_numpy(off).to(dev), KITTI_RANGE, KITTI_VOXEL, 16000, 5,
@@ -28,21 +28,21 @@ if __name__ == '__main__':
         n, c = rb.n_out, chans[lvl]
         x = torch.randn(n, c, device=dev)
         w = torch.randn(27, c, c, device=dev) / 10
-        table = rb.table_for('nbr', c, c)
+        table = rb.table_for('nbr', c, c, ARITH)
         P = table.num_pairs() if hasattr(table, 'num_pairs') else int((rb.nbr >= 0).sum())
         for _ in range(300):
-            sparse._conv_forward_raw(x, w, table, n)
+            sparse._conv_forward_raw(x, w, table, n, arithmetic=ARITH)
         torch.cuda.synchronize()
         ts = []
         for rep in range(12):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(40):
-                sparse._conv_forward_raw(x, w, table, n)
+                sparse._conv_forward_raw(x, w, table, n, arithmetic=ARITH)
             e1.record()
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) / 40 * 1e3)
         t = float(np.median(ts))
         balg = 4.0 * n * c * 2 + 8.0 * P + 4.0 * 27 * c * c
         print('%s L%d subm %dx%d N=%d P=%d: median %.1f us (min %.1f) = %.1f TF, %.0f GB/s alg' % (
-            sparse.ARITHMETIC, lvl, c, c, n, P, t, min(ts), 2.0 * P * c * c / t / 1e6, balg / t / 1e3), flush=True)
+            ARITH, lvl, c, c, n, P, t, min(ts), 2.0 * P * c * c / t / 1e6, balg / t / 1e3), flush=True)

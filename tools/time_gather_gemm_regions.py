@@ -3,6 +3,7 @@
 crb_sparse_conv_set_subtiles(32)) on the SECOND bs=16 level-3/4 tables and on a table with all 27 neighbours present."""
 import ctypes
 import os
+os.environ.setdefault('CRB_MEASURE_LIB', '1')     # measurement build of the library (include/crb_hip_measure.h)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

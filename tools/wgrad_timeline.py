@@ -3,6 +3,7 @@
 how many workgroups each CU got, when they started and ended (wall_clock64 ticks = 10 ns), steps per workgroup.
 Usage: python tools/wgrad_timeline.py [level]"""
 import os
+os.environ.setdefault('CRB_MEASURE_LIB', '1')     # measurement build of the library (include/crb_hip_measure.h)
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'crb-active-3ddet_amd'))
