@@ -1,4 +1,6 @@
-"""Host side of the HIP sparse-convolution path (C-ABI: crb_sparse_*, crb_subm_*, crb_spconv_*, crb_pairs_*)."""
+"""Host side of the HIP sparse-convolution path (C-ABI: crb_sparse_*, crb_subm_*, crb_spconv_*, crb_table*_)."""
+import ctypes
+
 import torch
 
 from ._lib import lib, check, ptr, cur_stream, require_cuda, host_i32x3, CrbHipError
@@ -15,87 +17,15 @@ def conv_out_shape(shape, ksize, stride, padding):
     return [(int(s) + 2 * p - k) // st + 1 for s, k, st, p in zip(shape, ksize, stride, padding)]
 
 
-class Rulebook(object):
-    """Indice data of one sparse conv (shared by layers with the same indice_key).
+CHUNK = lib.crb_table_chunk_rows()       # rows per sort chunk of the kernel order
 
-    nbr   (n_out,K) i32 : input row feeding output row through offset o, or -1   (forward table)
-    nbr_t (n_in,K)  i32 : output row fed by input row through offset o, or -1    (dgrad table; None for SubM,
-                          whose table is its own transpose under o -> K-1-o)
-    pairs : (pair_in, pair_out, pair_start) built lazily for wgrad
-    """
-
-    def __init__(self, nbr, nbr_t, n_in, n_out, ksize, stride, padding, subm, in_shape, out_shape, out_coords):
-        self.nbr, self.nbr_t = nbr, nbr_t
-        self.n_in, self.n_out = n_in, n_out
-        self.ksize, self.stride, self.padding = ksize, stride, padding
-        self.K = ksize[0] * ksize[1] * ksize[2]
-        self.subm = subm
-        self.in_shape, self.out_shape = in_shape, out_shape
-        self.out_coords = out_coords
-        self.in_coords = None
-        self._pairs = None
-        self._pairs_t = None
-        self._sorted = {}
-
-    def row_perm(self, which):
-        """kernel order of the rows of 'nbr' | 'nbr_t' (mask-sorted chunks, tiles heaviest first) or None"""
-        key = 'perm_' + which
-        if key not in self._sorted:
-            table = self.nbr if which == 'nbr' else self.nbr_t
-            self._sorted[key] = _mask_perm(table, self.K)
-        return self._sorted[key]
-
-    def sorted_table(self, which):
-        """('nbr' | 'nbr_t') -> (table rows in neighbour-mask order, perm int32): the (n,K) layout of the kernels without a
-        compact-table instance (rows of a wave share their set of active kernel offsets)"""
-        if which not in self._sorted:
-            table = self.nbr if which == 'nbr' else self.nbr_t
-            perm = self.row_perm(which)
-            if perm is None:
-                self._sorted[which] = (table, None)
-            else:
-                out = torch.empty_like(table)
-                check(lib.crb_nbr_permute(ptr(table), ptr(perm), table.shape[0], self.K, ptr(out), cur_stream(table.device)),
-                      'crb_nbr_permute')
-                self._sorted[which] = (out, perm)
-        return self._sorted[which]
-
-    def compact_table(self, which):
-        """('nbr' | 'nbr_t') -> CompactTable: per row of the kernel order a mask of present offsets + the present
-        neighbour indices packed row after row (crb_nbr_compact): 8 + 4 P/n bytes per row instead of 4 K"""
-        key = 'compact_' + which
-        if key not in self._sorted:
-            table = self.nbr if which == 'nbr' else self.nbr_t
-            self._sorted[key] = _compact(table, self.row_perm(which), self.K)
-        return self._sorted[key]
-
-    def table_for(self, which, cin, cout, arithmetic='f32'):
-        """the table form the gather-GEMM instance of (cin, cout) consumes"""
-        if COMPACT_TABLES and (lib.crb_sparse_conv_compact_supported(cin, cout) or
-                               (arithmetic == 'bf16x3' and lib.crb_sparse_conv_bf16x3_supported(cin, cout))):
-            return self.compact_table(which)
-        return self.sorted_table(which)
-
-    def pairs(self):
-        if self._pairs is None:
-            self._pairs = _pairs_from_nbr(self.nbr, self.n_out, self.K)
-        return self._pairs
-
-    def pairs_t(self):
-        """pairs of the transposed conv (inverse conv): 'in' = rows of this conv's output"""
-        if self._pairs_t is None:
-            self._pairs_t = _pairs_from_nbr(self.nbr_t, self.n_in, self.K)
-        return self._pairs_t
-
-
-TILE_LPT = True       # 64-row tiles of the sorted table dispatched heaviest first (crb_tile_lpt_perm)
-MASK_SORT = True      # set False to run the kernel on the natural row order (A/B measurements)
+TILE_LPT = True       # 64-row tiles dispatched heaviest first inside each XCD range (tile_order of crb_tables_finish)
+MASK_SORT = True      # set False to run the kernels on the natural row order (A/B measurements, order-independence tests)
 # rows are sorted by neighbour mask inside chunks of this many consecutive rows: a global sort maximises MFMA skipping
 # (0.89 vs 0.80 useful/issued) but scatters each tile's gathers over the whole feature map (L2 misses); chunks keep the
-# spatial locality of the row order
-MASK_SORT_CHUNK = int(__import__('os').environ.get('CRB_MASK_SORT_CHUNK', '4096'))
-
-
+# spatial locality of the row order. 4096 = the fused path (crb_tables_finish); other values take the one-table-at-a-time
+# building blocks (ranked keys + device radix sort) and exist for A/B runs only.
+MASK_SORT_CHUNK = int(__import__('os').environ.get('CRB_MASK_SORT_CHUNK', str(CHUNK)))
 # output-row-window work decomposition of the wgrad (crb_sparse_conv_wgrad_windowed): L2 hit rate of the gathers 7 % -> 64 %,
 # fabric reads 800 -> 350 MB per 64x64 launch, but 150 -> 196 us: the matrix pipe, not the memory side, paces the kernel once
 # 3 waves share a SIMD, and 64-96 workgroup slots per XCD cannot be dealt evenly to 27 offsets. Opt-in.
@@ -104,10 +34,13 @@ COMPACT_TABLES = True  # mask + packed-index tables for the kernels that have a 
 
 
 class CompactTable(object):
-    __slots__ = ('cmask', 'cbase', 'packed', 'perm', 'n', 'K')
+    """what the gather-GEMM reads: per row of the KERNEL order (row perm[i] of the (n,K) table) the mask of present offsets,
+    the exclusive prefix of the masks' popcounts and the present neighbour indices packed row after row; order = dispatch
+    order of the 64-row tiles (heaviest first inside each XCD range) or None"""
+    __slots__ = ('cmask', 'cbase', 'packed', 'perm', 'n', 'K', 'order')
 
-    def __init__(self, cmask, cbase, packed, perm, n, K):
-        self.cmask, self.cbase, self.packed, self.perm, self.n, self.K = cmask, cbase, packed, perm, n, K
+    def __init__(self, cmask, cbase, packed, perm, n, K, order=None):
+        self.cmask, self.cbase, self.packed, self.perm, self.n, self.K, self.order = cmask, cbase, packed, perm, n, K, order
 
     def num_pairs(self):
         return int(self.cbase[-1].item())
@@ -122,7 +55,166 @@ class CompactTable(object):
         return out.int()
 
 
+class KernelTable(object):
+    """one (n,K) neighbour table of a rulebook with everything derived from it"""
+    __slots__ = ('nbr', 'mask', 'hist', 'n', 'K', 'compact', 'pairs', 'legacy')
+
+    def __init__(self, nbr, mask, hist, K):
+        self.nbr, self.mask, self.hist, self.n, self.K = nbr, mask, hist, nbr.shape[0], K
+        self.compact = self.pairs = self.legacy = None
+
+
+def _hist_rows(n):
+    return max((n + CHUNK - 1) // CHUNK, 1) * 32
+
+
+def table_from_nbr(nbr, K):
+    """KernelTable of an existing (n,K) table: one launch for masks + per-chunk offset counts"""
+    dev = nbr.device
+    n = nbr.shape[0]
+    mask = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+    hist = torch.zeros((_hist_rows(n),), dtype=torch.int32, device=dev)
+    check(lib.crb_table_masks(ptr(nbr), n, K, ptr(mask), ptr(hist), cur_stream(dev)), 'crb_table_masks')
+    return KernelTable(nbr, mask, hist, K)
+
+
+class _TablePlan(ctypes.Structure):            # include/crb_hip.h: CrbTablePlan
+    _fields_ = [(k, ctypes.c_void_p) for k in ('nbr', 'mask', 'hist', 'perm', 'cmask', 'cbase', 'packed', 'tile_weight',
+                                               'tile_order', 'pair_in', 'pair_out', 'pair_start')] + \
+               [('n', ctypes.c_int64), ('K', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+def finish_tables(tables, want_pairs):
+    """kernel order, compact table, tile order and (want_pairs[i]) the wgrad pair lists of every KernelTable in `tables`:
+    two launches for all of them (crb_tables_finish)"""
+    tables = [t for t in tables]
+    if not tables:
+        return
+    dev = tables[0].nbr.device
+    plans = (_TablePlan * len(tables))()
+    keep = []
+    for i, (t, wp) in enumerate(zip(tables, want_pairs)):
+        n, K = t.n, t.K
+        i32 = lambda m: torch.empty((max(m, 1),), dtype=torch.int32, device=dev)
+        perm, cmask, cbase, packed = i32(n), i32(n), i32(n + 1), i32(n * K)
+        tiles = (n + 63) // 64
+        weight, order = i32(tiles), i32(tiles)
+        pin = pout = pstart = None
+        if wp:
+            pin, pout, pstart = i32(n * K), i32(n * K), i32(K + 1)
+        p = plans[i]
+        for name, ten in (('nbr', t.nbr), ('mask', t.mask), ('hist', t.hist), ('perm', perm), ('cmask', cmask), ('cbase', cbase),
+                          ('packed', packed), ('tile_weight', weight), ('tile_order', order), ('pair_in', pin),
+                          ('pair_out', pout), ('pair_start', pstart)):
+            setattr(p, name, ten.data_ptr() if ten is not None else None)
+        p.n, p.K, p.reserved = n, K, 0
+        keep.append((perm, cmask, cbase, packed, weight, order, pin, pout, pstart))
+    check(lib.crb_tables_finish(plans, len(tables), cur_stream(dev)), 'crb_tables_finish')
+    for t, wp, (perm, cmask, cbase, packed, weight, order, pin, pout, pstart) in zip(tables, want_pairs, keep):
+        n = t.n
+        t.compact = CompactTable(cmask[:n], cbase, packed, perm[:n] if n else None, n, t.K,
+                                 order if (TILE_LPT and n >= 128) else None)
+        if wp:
+            t.pairs = (pin, pout, pstart)
+
+
+class Rulebook(object):
+    """Indice data of one sparse conv (shared by layers with the same indice_key).
+
+    nbr   (n_out,K) i32 : input row feeding output row through offset o, or -1   (forward table)
+    nbr_t (n_in,K)  i32 : output row fed by input row through offset o, or -1    (dgrad table; None for SubM,
+                          whose table is its own transpose under o -> K-1-o)
+    pairs : (pair_in, pair_out, pair_start) for wgrad
+    """
+
+    def __init__(self, nbr, nbr_t, n_in, n_out, ksize, stride, padding, subm, in_shape, out_shape, out_coords,
+                 table=None, table_t=None):
+        self.nbr, self.nbr_t = nbr, nbr_t
+        self.n_in, self.n_out = n_in, n_out
+        self.ksize, self.stride, self.padding = ksize, stride, padding
+        self.K = ksize[0] * ksize[1] * ksize[2]
+        self.subm = subm
+        self.in_shape, self.out_shape = in_shape, out_shape
+        self.out_coords = out_coords
+        self.in_coords = None
+        self._tab = {'nbr': table, 'nbr_t': table_t}
+        self._alt = {}                      # A/B variants of the kernel tables (natural order, other chunk sizes)
+
+    def table(self, which):
+        """KernelTable of 'nbr' | 'nbr_t' (built on first use when the plan did not include it)"""
+        t = self._tab[which]
+        if t is None:
+            t = self._tab[which] = table_from_nbr(self.nbr if which == 'nbr' else self.nbr_t, self.K)
+        return t
+
+    def _finished(self, which, pairs=False):
+        t = self.table(which)
+        if t.compact is None or (pairs and t.pairs is None):
+            finish_tables([t], [pairs or t.pairs is not None])
+        return t
+
+    def row_perm(self, which):
+        """kernel order of the rows of 'nbr' | 'nbr_t' (mask-sorted chunks) or None"""
+        return self.compact_table(which).perm
+
+    def compact_table(self, which):
+        """('nbr' | 'nbr_t') -> CompactTable"""
+        if MASK_SORT and MASK_SORT_CHUNK == CHUNK:
+            return self._finished(which).compact
+        key = ('compact', which, MASK_SORT, MASK_SORT_CHUNK)
+        if key not in self._alt:
+            table = self.nbr if which == 'nbr' else self.nbr_t
+            self._alt[key] = _compact(table, _mask_perm(table, self.K), self.K)
+        return self._alt[key]
+
+    def sorted_table(self, which):
+        """('nbr' | 'nbr_t') -> (table rows in kernel order (n,K), perm int32 or None): the layout of the kernels without a
+        compact-table instance; the tile order is applied to the rows here (those kernels take no indirection)"""
+        key = ('sorted', which, MASK_SORT, MASK_SORT_CHUNK, TILE_LPT)
+        if key not in self._alt:
+            table = self.nbr if which == 'nbr' else self.nbr_t
+            ct = self.compact_table(which)
+            perm = ct.perm
+            if perm is not None and ct.order is not None:
+                full = table.shape[0] // 64
+                body = perm[:full * 64].view(full, 64)[ct.order[:full].long()].reshape(-1)
+                perm = torch.cat([body, perm[full * 64:]]).contiguous()
+            if perm is None:
+                self._alt[key] = (table, None)
+            else:
+                out = torch.empty_like(table)
+                check(lib.crb_nbr_permute(ptr(table), ptr(perm), table.shape[0], self.K, ptr(out), cur_stream(table.device)),
+                      'crb_nbr_permute')
+                self._alt[key] = (out, perm)
+        return self._alt[key]
+
+    def table_for(self, which, cin, cout, arithmetic='f32'):
+        """the table form the gather-GEMM instance of (cin, cout) consumes"""
+        if COMPACT_TABLES and (lib.crb_sparse_conv_compact_supported(cin, cout) or
+                               (arithmetic == 'bf16x3' and lib.crb_sparse_conv_bf16x3_supported(cin, cout))):
+            return self.compact_table(which)
+        return self.sorted_table(which)
+
+    def _pairs_of(self, which):
+        p = self._finished(which, pairs=True).pairs
+        if WGRAD_WINDOWED and len(p) == 3:
+            t = self._tab[which]
+            bnd = torch.empty((self.K, lib.crb_wgrad_num_windows() + 1), dtype=torch.int32, device=p[0].device)
+            check(lib.crb_wgrad_window_bounds(ptr(p[1]), ptr(p[2]), self.K, t.n, ptr(bnd), cur_stream(bnd.device)),
+                  'crb_wgrad_window_bounds')
+            p = t.pairs = (p[0], p[1], p[2], bnd)
+        return p
+
+    def pairs(self):
+        return self._pairs_of('nbr')
+
+    def pairs_t(self):
+        """pairs of the transposed conv (inverse conv): 'in' = rows of this conv's output"""
+        return self._pairs_of('nbr_t')
+
+
 def _compact(table, perm, K):
+    """one-table-at-a-time compact table (A/B paths: natural order, other chunk sizes)"""
     n = table.shape[0]
     dev = table.device
     cmask = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
@@ -136,7 +228,7 @@ def _compact(table, perm, K):
 
 
 def _mask_perm(table, K):
-    """row permutation of the gather-GEMM's kernel order (None = natural order)"""
+    """one-table-at-a-time row permutation (A/B paths): mask -> chunk sort -> tiles heaviest first, rows physically ordered"""
     n = table.shape[0]
     dev = table.device
     if n == 0 or not MASK_SORT:
@@ -169,22 +261,6 @@ def _mask_perm(table, K):
     return perm
 
 
-def _pairs_from_nbr(nbr, n_rows, K):
-    dev = nbr.device
-    cap = max(n_rows * K, 1)
-    pin = torch.empty((cap,), dtype=torch.int32, device=dev)
-    pout = torch.empty((cap,), dtype=torch.int32, device=dev)
-    pstart = torch.empty((K + 1,), dtype=torch.int32, device=dev)
-    wsb = lib.crb_pairs_workspace_bytes(n_rows, K)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
-    check(lib.crb_pairs_from_nbr(ptr(nbr), n_rows, K, ptr(pin), ptr(pout), ptr(pstart), ptr(ws), wsb, cur_stream(dev)),
-          'crb_pairs_from_nbr')
-    # first pair of every output-row window per offset: the windowed wgrad's work decomposition (once per rulebook)
-    bnd = torch.empty((K, lib.crb_wgrad_num_windows() + 1), dtype=torch.int32, device=dev)
-    check(lib.crb_wgrad_window_bounds(ptr(pout), ptr(pstart), K, n_rows, ptr(bnd), cur_stream(dev)), 'crb_wgrad_window_bounds')
-    return pin, pout, pstart, bnd
-
-
 def build_hash(coords, shape):
     require_cuda(coords)
     n = coords.shape[0]
@@ -196,104 +272,137 @@ def build_hash(coords, shape):
     return hkeys, hvals, cap
 
 
+def _host_i32(vals):
+    return (ctypes.c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+def _host_i64(vals):
+    return (ctypes.c_int64 * len(vals))(*[int(v) for v in vals])
+
+
+def build_rulebooks(coords, shape, batch_size, specs, want_grad=True):
+    """Rulebooks of a CHAIN of sparse convs over one coordinate set, every table finished, in ~3 launches per table and ONE
+    host read-back for the whole chain.
+
+    specs, in forward order: ('subm', ksize) or ('spconv', ksize, stride, padding); a strided conv consumes the current set
+    and its output set becomes the current one. want_grad: also the transposed tables of the strided convs (dgrad) and the
+    wgrad pair lists; without it (inference) they are built on first use.
+    coords (N,4) i32 cuda contiguous [b,z,y,x], unique rows in any order -> list of Rulebook (one per spec)."""
+    require_cuda(coords)
+    assert coords.dtype == torch.int32 and coords.is_contiguous()
+    dev = coords.device
+    st = cur_stream(dev)
+    specs = [(s[0], _triple(s[1])) + tuple(_triple(v) for v in s[2:]) for s in specs]
+    strided = [s for s in specs if s[0] == 'spconv']
+    # ---- the chain of output sets: bitmaps -> counts (the read-back) -> coordinates + rank tables
+    levels = []                                   # per strided conv: (out_shape, n_out, out_coords, rank pointer)
+    if strided:
+        L = len(strided)
+        if L > 8:
+            raise CrbHipError('more than 8 strided convs in one chain')
+        geoms, oshapes, cur = [], [], list(shape)
+        for _, ks, sd, pd in strided:
+            o = conv_out_shape(cur, ks, sd, pd)
+            if min(o) <= 0:
+                raise CrbHipError(f'sparse conv output shape {o} is empty')
+            geoms += ks + sd + pd
+            oshapes.append(o)
+            cur = o
+        flat_shapes = _host_i32([v for o in oshapes for v in o])
+        word_off = [0]
+        for o in oshapes:
+            word_off.append(word_off[-1] + lib.crb_spconv_padded_words(batch_size, host_i32x3(o)))
+        woff = _host_i64(word_off)
+        bitmap_all = torch.empty((word_off[-1],), dtype=torch.int32, device=dev)
+        tile_sums = torch.empty((word_off[-1] // 2048,), dtype=torch.int32, device=dev)
+        counts = torch.empty((L,), dtype=torch.int32, device=dev)
+        check(lib.crb_spconv_chain_mark(ptr(coords), coords.shape[0], batch_size, host_i32x3(shape), L, _host_i32(geoms),
+                                        flat_shapes, woff, ptr(bitmap_all), ptr(tile_sums), ptr(counts), st),
+              'crb_spconv_chain_mark')
+        n_outs = [int(v) for v in counts.cpu().tolist()]                   # the single read-back of the chain
+        rank_all = torch.empty((word_off[-1], 2), dtype=torch.int32, device=dev)
+        out_coords = [torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev) for n in n_outs]
+        oc_ptrs = (ctypes.c_void_p * L)(*[c.data_ptr() for c in out_coords])
+        check(lib.crb_spconv_chain_emit(batch_size, L, flat_shapes, woff, ptr(bitmap_all), ptr(tile_sums), ptr(rank_all),
+                                        oc_ptrs, _host_i64(n_outs), st), 'crb_spconv_chain_emit')
+        for l in range(L):
+            levels.append((oshapes[l], n_outs[l], out_coords[l][:n_outs[l]],
+                           ctypes.c_void_p(rank_all.data_ptr() + word_off[l] * 8)))
+    # ---- neighbour rows: one kernel per table; all per-chunk offset counts live in one zero-filled buffer
+    cur_coords, cur_shape, cur_rank, cur_n = coords, list(shape), None, coords.shape[0]
+    sizes, lvl = [], 0
+    for s in specs:
+        K = s[1][0] * s[1][1] * s[1][2]
+        if K > 32:
+            raise CrbHipError('kernel volumes above 32 offsets have no gfx950 table kernels')
+        if s[0] == 'subm':
+            sizes.append((cur_n,))
+        else:
+            sizes.append((levels[lvl][1], cur_n))
+            cur_n = levels[lvl][1]
+            lvl += 1
+    hist_all = torch.zeros((sum(_hist_rows(n) for t in sizes for n in t),), dtype=torch.int32, device=dev)
+    hoff = [0]
+
+    def take_hist(n):
+        h = hist_all[hoff[0]:hoff[0] + _hist_rows(n)]
+        hoff[0] += _hist_rows(n)
+        return h
+
+    def i32(*shape_):
+        return torch.empty(shape_, dtype=torch.int32, device=dev)
+    cur_n, lvl, site_hash, books, to_finish, pairs_flag = coords.shape[0], 0, None, [], [], []
+    for s in specs:
+        ks = s[1]
+        K = ks[0] * ks[1] * ks[2]
+        if s[0] == 'subm':
+            n = cur_n
+            nbr, mask, hist = i32(n, K), i32(max(n, 1)), take_hist(n)
+            if cur_rank is None and site_hash is None and n > 0:
+                site_hash = build_hash(cur_coords, cur_shape)
+            hk, hv, cap = site_hash if cur_rank is None and site_hash is not None else (None, None, 0)
+            check(lib.crb_subm_rows(ptr(cur_coords), n, host_i32x3(cur_shape), host_i32x3(ks), ptr(hk), ptr(hv), cap, cur_rank,
+                                    ptr(nbr), ptr(mask), ptr(hist), st), 'crb_subm_rows')
+            tab = KernelTable(nbr, mask, hist, K)
+            rb = Rulebook(nbr, None, n, n, ks, [1, 1, 1], [k // 2 for k in ks], True, list(cur_shape), list(cur_shape),
+                          cur_coords, tab, None)
+            rb.in_coords = cur_coords
+            to_finish.append(tab)
+            pairs_flag.append(want_grad)
+        else:
+            _, _, sd, pd = s
+            oshape, n_out, ocoords, orank = levels[lvl]
+            lvl += 1
+            n = cur_n
+            nbr, nbr_t = i32(n_out, K), i32(n, K)
+            mask_t, hist_t = i32(max(n, 1)), take_hist(n)
+            check(lib.crb_spconv_rows(ptr(cur_coords), n, host_i32x3(ks), host_i32x3(sd), host_i32x3(pd), host_i32x3(oshape),
+                                      orank, n_out, ptr(nbr), ptr(nbr_t), ptr(mask_t), ptr(hist_t), st), 'crb_spconv_rows')
+            mask, hist = i32(max(n_out, 1)), take_hist(n_out)
+            check(lib.crb_table_masks(ptr(nbr), n_out, K, ptr(mask), ptr(hist), st), 'crb_table_masks')
+            tab, tab_t = KernelTable(nbr, mask, hist, K), KernelTable(nbr_t, mask_t, hist_t, K)
+            rb = Rulebook(nbr, nbr_t, n, n_out, ks, sd, pd, False, list(cur_shape), list(oshape), ocoords, tab, tab_t)
+            rb.in_coords = cur_coords
+            to_finish.append(tab)
+            pairs_flag.append(want_grad)
+            if want_grad:
+                to_finish.append(tab_t)
+                pairs_flag.append(False)
+            cur_coords, cur_shape, cur_rank, cur_n, site_hash = ocoords, list(oshape), orank, n_out, None
+        books.append(rb)
+    if MASK_SORT and MASK_SORT_CHUNK == CHUNK:
+        finish_tables(to_finish, pairs_flag)
+    return books
+
+
 def subm_rulebook(coords, shape, ksize):
     """coords (N,4) i32 cuda contiguous [b,z,y,x]"""
-    require_cuda(coords)
-    assert coords.dtype == torch.int32 and coords.is_contiguous()
-    ksize = _triple(ksize)
-    n = coords.shape[0]
-    K = ksize[0] * ksize[1] * ksize[2]
-    hkeys, hvals, cap = build_hash(coords, shape)
-    nbr = torch.empty((n, K), dtype=torch.int32, device=coords.device)
-    check(lib.crb_subm_rulebook(ptr(coords), n, host_i32x3(shape), host_i32x3(ksize), ptr(hkeys), ptr(hvals), cap,
-                                ptr(nbr), cur_stream(coords.device)), 'crb_subm_rulebook')
-    rb = Rulebook(nbr, None, n, n, ksize, [1, 1, 1], [k // 2 for k in ksize], True, list(shape), list(shape), coords)
-    rb.in_coords = coords
-    return rb
+    return build_rulebooks(coords, shape, 1, [('subm', ksize)], want_grad=torch.is_grad_enabled())[0]
 
 
-def strided_chain_counts(coords, shape, batch_size, geoms):
-    """output bitmaps and output-site counts of a CHAIN of strided convs (geoms = [(ksize, stride, padding), ...], each
-    applied to the previous one's output) with ONE host read-back: level 1 is marked from the coordinates, every further
-    level straight from the previous level's bitmap. -> [(bitmap int32 tensor, n_out int, out_shape)] per level, to be
-    handed to spconv_rulebook(..., premarked=...) which then needs no synchronisation of its own."""
-    require_cuda(coords)
-    dev = coords.device
-    st = cur_stream(dev)
-    counts = torch.empty((len(geoms),), dtype=torch.int32, device=dev)
-    out, in_shape, in_bitmap = [], list(shape), None
-    for lvl, (ks, sd, pd) in enumerate(geoms):
-        ks, sd, pd = _triple(ks), _triple(sd), _triple(pd)
-        oshape = conv_out_shape(in_shape, ks, sd, pd)
-        if min(oshape) <= 0:
-            raise CrbHipError(f'sparse conv output shape {oshape} is empty')
-        oc = host_i32x3(oshape)
-        words = lib.crb_spconv_bitmap_words(batch_size, oc)
-        bitmap = torch.empty((words,), dtype=torch.int32, device=dev)
-        if in_bitmap is None:
-            check(lib.crb_spconv_mark(ptr(coords), coords.shape[0], batch_size, host_i32x3(ks), host_i32x3(sd),
-                                      host_i32x3(pd), oc, ptr(bitmap), st), 'crb_spconv_mark')
-        else:
-            check(lib.crb_spconv_mark_from_bitmap(ptr(in_bitmap), batch_size, host_i32x3(in_shape), host_i32x3(ks),
-                                                  host_i32x3(sd), host_i32x3(pd), oc, ptr(bitmap), st),
-                  'crb_spconv_mark_from_bitmap')
-        check(lib.crb_bitmap_count(ptr(bitmap), words, ptr(counts[lvl:lvl + 1]), st), 'crb_bitmap_count')
-        out.append([bitmap, None, oshape])
-        in_shape, in_bitmap = oshape, bitmap
-    host = counts.cpu().tolist()                       # the single read-back of the chain
-    for lvl, n_out in enumerate(host):
-        out[lvl][1] = int(n_out)
-    return [tuple(o) for o in out]
-
-
-def spconv_rulebook(coords, shape, batch_size, ksize, stride, padding, premarked=None):
-    """premarked = (bitmap, n_out, out_shape) from strided_chain_counts: the output set is already marked and counted, no
-    host synchronisation happens here"""
-    require_cuda(coords)
-    assert coords.dtype == torch.int32 and coords.is_contiguous()
-    ksize, stride, padding = _triple(ksize), _triple(stride), _triple(padding)
-    dev = coords.device
-    n = coords.shape[0]
-    K = ksize[0] * ksize[1] * ksize[2]
-    out_shape = conv_out_shape(shape, ksize, stride, padding)
-    if min(out_shape) <= 0:
-        raise CrbHipError(f'sparse conv output shape {out_shape} is empty')
-    oshape_c = host_i32x3(out_shape)
-    words = lib.crb_spconv_bitmap_words(batch_size, oshape_c)
-    prefix = torch.empty((words,), dtype=torch.int32, device=dev)
-    scan_tmp = torch.empty((words // 2048 + 2,), dtype=torch.int32, device=dev)
-    n_out_dev = torch.empty((1,), dtype=torch.int32, device=dev)
-    st = cur_stream(dev)
-    if premarked is not None:
-        bitmap, n_out, pshape = premarked
-        assert list(pshape) == list(out_shape) and bitmap.numel() == words
-        out_coords = torch.empty((max(n_out, 1), 4), dtype=torch.int32, device=dev)
-        check(lib.crb_spconv_out_coords_premarked(batch_size, oshape_c, ptr(bitmap), ptr(prefix), ptr(scan_tmp),
-                                                  ptr(out_coords), n_out, ptr(n_out_dev), st),
-              'crb_spconv_out_coords_premarked')
-    else:
-        bitmap = torch.empty((words,), dtype=torch.int32, device=dev)
-        max_out = min(max(n * K, 1), batch_size * out_shape[0] * out_shape[1] * out_shape[2])
-        # upper bound used for the coordinate buffer: an input site feeds at most prod(ceil(k/s)) outputs
-        fan = 1
-        for k, s in zip(ksize, stride):
-            fan *= (k + s - 1) // s
-        max_out = min(max_out, max(n * fan, 1))
-        out_coords = torch.empty((max_out, 4), dtype=torch.int32, device=dev)
-        check(lib.crb_spconv_out_coords(ptr(coords), n, batch_size, host_i32x3(ksize), host_i32x3(stride),
-                                        host_i32x3(padding), oshape_c, ptr(bitmap), ptr(prefix), ptr(scan_tmp),
-                                        ptr(out_coords), max_out, ptr(n_out_dev), st), 'crb_spconv_out_coords')
-        n_out = int(n_out_dev.item())      # sync: the output row count sizes every later buffer
-        assert n_out <= max_out
-    out_coords = out_coords[:n_out]
-    nbr = torch.empty((n_out, K), dtype=torch.int32, device=dev)
-    nbr_t = torch.empty((n, K), dtype=torch.int32, device=dev)
-    check(lib.crb_spconv_rulebook(ptr(coords), n, batch_size, host_i32x3(ksize), host_i32x3(stride),
-                                  host_i32x3(padding), oshape_c, ptr(bitmap), ptr(prefix), n_out, ptr(nbr), ptr(nbr_t),
-                                  st), 'crb_spconv_rulebook')
-    rb = Rulebook(nbr, nbr_t, n, n_out, ksize, stride, padding, False, list(shape), out_shape, out_coords)
-    rb.in_coords = coords
-    return rb
+def spconv_rulebook(coords, shape, batch_size, ksize, stride, padding):
+    return build_rulebooks(coords, shape, batch_size, [('spconv', ksize, stride, padding)],
+                           want_grad=torch.is_grad_enabled())[0]
 
 
 # When set to a list, every gather-GEMM launch appends (kind, cin, cout, K, n_in, n_out, nbr, ev0, ev1): HIP events on
@@ -327,8 +436,8 @@ def _conv_forward_raw(x, w_kio, table, n_out, kind='fwd', epilogue=None, arithme
         bias, bn, relu = epilogue
         assert isinstance(table, CompactTable) and not bn.training
         check(lib.crb_sparse_conv_forward_compact_bn(
-            ptr(x), ptr(w_kio), ptr(table.cmask), ptr(table.cbase), ptr(table.packed), ptr(table.perm), ptr(y), n_out, K, cin,
-            cout, ptr(bias.contiguous()) if bias is not None else None, ptr(bn.weight.contiguous()), ptr(bn.bias.contiguous()),
+            ptr(x), ptr(w_kio), ptr(table.cmask), ptr(table.cbase), ptr(table.packed), ptr(table.perm), ptr(table.order), ptr(y), n_out,
+            K, cin, cout, ptr(bias.contiguous()) if bias is not None else None, ptr(bn.weight.contiguous()), ptr(bn.bias.contiguous()),
             ptr(bn.running_mean.contiguous()), ptr(bn.running_var.contiguous()), float(bn.eps), int(bool(relu)),
             cur_stream(x.device)), 'crb_sparse_conv_forward_compact_bn')
         nbr = table
@@ -337,14 +446,14 @@ def _conv_forward_raw(x, w_kio, table, n_out, kind='fwd', epilogue=None, arithme
         wsb = lib.crb_sparse_conv_bf16x3_workspace_bytes(K, cin, cout)
         ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
         check(lib.crb_sparse_conv_forward_bf16x3(ptr(x), ptr(w_kio), ptr(table.cmask), ptr(table.cbase), ptr(table.packed),
-                                                 ptr(table.perm), ptr(y), x.shape[0], n_out, K, cin, cout, ptr(ws), wsb,
+                                                 ptr(table.perm), ptr(table.order), ptr(y), x.shape[0], n_out, K, cin, cout, ptr(ws), wsb,
                                                  cur_stream(x.device)), 'crb_sparse_conv_forward_bf16x3')
         nbr = table
         kind = kind + '_bf16x3'
     elif isinstance(table, CompactTable):
         check(lib.crb_sparse_conv_forward_compact(ptr(x), ptr(w_kio), ptr(table.cmask), ptr(table.cbase), ptr(table.packed),
-                                                  ptr(table.perm), ptr(y), n_out, K, cin, cout, cur_stream(x.device)),
-              'crb_sparse_conv_forward_compact')
+                                                  ptr(table.perm), ptr(table.order), ptr(y), n_out, K, cin, cout,
+                                                  cur_stream(x.device)), 'crb_sparse_conv_forward_compact')
         nbr = table
     else:
         nbr, perm = table

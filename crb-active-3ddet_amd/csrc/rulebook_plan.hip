@@ -1,0 +1,610 @@
+// Fused construction of everything the sparse-conv kernels read (row a4 of SURVEY §8), sized for a whole backbone per call.
+//
+// Replaces the indice-pair generation inside spconv.pytorch SubMConv3d / SparseConv3d as configured by the reference at
+// pcdet/models/backbones_3d/spconv_backbone.py:77-117 (third-party spconv-cu113 v2.1.21, absent from the reference tree;
+// semantics restated in SURVEY Appendix A). rulebook.hip holds the one-table-at-a-time building blocks (kept for callers that
+// need a single piece); this file is what the training / scoring step runs: ~26 launches and ONE host read-back for the 8
+// rulebooks (12 kernel tables) of VoxelBackBone8x instead of ~230 launches.
+//
+//   chain   crb_spconv_chain_mark : the output sets of a CHAIN of strided convs as bitmaps — level 1 marked from the input
+//           coordinates, every further level from the previous level's bitmap; the pass that reads a bitmap also leaves
+//           its per-tile popcounts, one small kernel scans them for all levels -> counts (the single read-back)
+//           crb_spconv_chain_emit : per level ONE kernel: coordinates in ascending (b,z,y,x) order + a rank table
+//           {bits, exclusive popcount} per bitmap word (site -> row = one 8-byte load)
+//   rows    crb_subm_rows / crb_spconv_rows / crb_table_masks : ONE kernel per table: neighbour rows (n,K), the per-row
+//           mask of present offsets and per-4096-row-chunk counts of every offset. A stride-s conv needs no existence test
+//           (every site an input reaches IS an output) and only the offsets of matching parity do a rank lookup; SubM on a
+//           set that came out of the chain looks sites up in the rank table (no hash), on a foreign set in a site hash.
+//   finish  crb_tables_finish : for ALL tables of the backbone in TWO launches: per 4096-row chunk one workgroup — mask sort
+//           (rarest offset first), kernel-order masks, prefix of their popcounts, packed neighbour indices, tile weights and
+//           the wgrad pair lists (offset-major, ascending output row) of its rows; then per (table, XCD range) the
+//           heaviest-first order of the 64-row tiles, which the gather-GEMM reads as an indirection (nothing is permuted).
+#include "crb_common.h"
+#include "../../include/crb_hip.h"
+
+namespace {
+
+constexpr int CHUNK = 4096;          // rows per sort chunk (= crb_mask_sort_chunk_rows())
+constexpr int TILE_WORDS = 2048;     // bitmap words per scan tile (256 threads x 8 words)
+constexpr int ROWS_PER_WG = 256;     // rows kernels: 8 row slots x 32 iterations (divides CHUNK)
+
+struct Shape3 { int d, h, w; };
+struct ConvGeom {
+  int kd, kh, kw;
+  int sd, sh, sw;
+  int pd, ph, pw;
+};
+
+__device__ __forceinline__ int64_t lin_index(int b, int z, int y, int x, Shape3 s) {
+  return (((int64_t)b * s.d + z) * s.h + y) * (int64_t)s.w + x;
+}
+
+__device__ __forceinline__ int rank_lookup(const uint2* __restrict__ rank, int64_t lin) {
+  const uint2 e = rank[lin >> 5];
+  const unsigned bit = (unsigned)(lin & 31);
+  return ((e.x >> bit) & 1u) ? (int)(e.y + __popc(e.x & ((1u << bit) - 1u))) : -1;
+}
+
+// ------------------------------------------------------------------------------------------------ chain of output sets
+
+// outputs reached by one input site through a conv of geometry g: per axis the kernel taps k with (c + p - k) % s == 0
+__device__ __forceinline__ void mark_outputs(int b, int z, int y, int x, ConvGeom g, Shape3 so, uint32_t* __restrict__ bitmap) {
+  for (int kz = 0; kz < g.kd; ++kz) {
+    const int tz = z + g.pd - kz;
+    if (tz < 0 || tz % g.sd || tz / g.sd >= so.d) continue;
+    for (int ky = 0; ky < g.kh; ++ky) {
+      const int ty = y + g.ph - ky;
+      if (ty < 0 || ty % g.sh || ty / g.sh >= so.h) continue;
+      for (int kx = 0; kx < g.kw; ++kx) {
+        const int tx = x + g.pw - kx;
+        if (tx < 0 || tx % g.sw || tx / g.sw >= so.w) continue;
+        const int64_t lo = lin_index(b, tz / g.sd, ty / g.sh, tx / g.sw, so);
+        atomicOr(&bitmap[lo >> 5], 1u << (lo & 31));
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void chain_mark_coords_kernel(const int* __restrict__ coords, int n, ConvGeom g, Shape3 so,
+                                                                uint32_t* __restrict__ bitmap) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const int4 c = *reinterpret_cast<const int4*>(coords + (int64_t)j * 4);
+  mark_outputs(c.x, c.y, c.z, c.w, g, so, bitmap);
+}
+
+// one workgroup per 2048-word tile of the INPUT bitmap: marks the next level (out_bitmap != nullptr) and leaves the tile's
+// popcount (what the emit pass of this level needs as scan input)
+__global__ __launch_bounds__(256) void chain_mark_bitmap_kernel(const uint32_t* __restrict__ in_bitmap, Shape3 si, ConvGeom g,
+                                                                Shape3 so, uint32_t* __restrict__ out_bitmap,
+                                                                int* __restrict__ tile_sums) {
+  __shared__ int sh[4];
+  const int64_t w0 = (int64_t)blockIdx.x * TILE_WORDS + (int64_t)threadIdx.x * 8;
+  const uint4 a = *reinterpret_cast<const uint4*>(in_bitmap + w0);
+  const uint4 b4 = *reinterpret_cast<const uint4*>(in_bitmap + w0 + 4);
+  const uint32_t wds[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    uint32_t m = wds[k];
+    cnt += __popc(m);
+    if (out_bitmap == nullptr) continue;
+    while (m) {
+      const int bit = __ffs(m) - 1;
+      m &= m - 1;
+      int64_t lin = (w0 + k) * 32 + bit;
+      const int x = (int)(lin % si.w); lin /= si.w;
+      const int y = (int)(lin % si.h); lin /= si.h;
+      const int z = (int)(lin % si.d); lin /= si.d;
+      mark_outputs((int)lin, z, y, x, g, so, out_bitmap);
+    }
+  }
+  int tot;
+  crb_block_excl_scan_256(cnt, sh, &tot);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+struct ChainScanArgs {
+  int tile_off[9];      // first tile of level l in tile_sums (l = 0..L)
+  int levels;
+};
+
+// one workgroup per level: exclusive scan of the level's tile popcounts in place, total -> counts[level]
+__global__ __launch_bounds__(256) void chain_scan_kernel(int* __restrict__ tile_sums, ChainScanArgs a, int* __restrict__ counts) {
+  __shared__ int sh[4];
+  const int l = blockIdx.x;
+  int* ts = tile_sums + a.tile_off[l];
+  const int m = a.tile_off[l + 1] - a.tile_off[l];
+  int carry = 0;
+  for (int base = 0; base < m; base += 256) {
+    const int i = base + (int)threadIdx.x;
+    const int v = (i < m) ? ts[i] : 0;
+    int tot;
+    const int ex = crb_block_excl_scan_256(v, sh, &tot);
+    if (i < m) ts[i] = carry + ex;
+    carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[l] = carry;
+}
+
+// one workgroup per tile: rank table {bits, exclusive popcount} per word + the coordinates of the set bits, rows in
+// ascending linear (b,z,y,x) order
+__global__ __launch_bounds__(256) void chain_emit_kernel(const uint32_t* __restrict__ bitmap, const int* __restrict__ tile_prefix,
+                                                         Shape3 so, int max_out, uint2* __restrict__ rank,
+                                                         int* __restrict__ out_coords) {
+  __shared__ int sh[4];
+  const int64_t w0 = (int64_t)blockIdx.x * TILE_WORDS + (int64_t)threadIdx.x * 8;
+  const uint4 a = *reinterpret_cast<const uint4*>(bitmap + w0);
+  const uint4 b4 = *reinterpret_cast<const uint4*>(bitmap + w0 + 4);
+  const uint32_t wds[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cnt += __popc(wds[k]);
+  int tot;
+  int r = crb_block_excl_scan_256(cnt, sh, &tot) + tile_prefix[blockIdx.x];
+  uint2 e[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    e[k] = make_uint2(wds[k], (unsigned)r);
+    uint32_t m = wds[k];
+    while (m) {
+      const int bit = __ffs(m) - 1;
+      m &= m - 1;
+      if (r < max_out) {
+        int64_t lin = (w0 + k) * 32 + bit;
+        const int x = (int)(lin % so.w); lin /= so.w;
+        const int y = (int)(lin % so.h); lin /= so.h;
+        const int z = (int)(lin % so.d); lin /= so.d;
+        *reinterpret_cast<int4*>(out_coords + (int64_t)r * 4) = make_int4((int)lin, z, y, x);
+      }
+      ++r;
+    }
+  }
+  uint4* dst = reinterpret_cast<uint4*>(rank + w0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) dst[k] = make_uint4(e[2 * k].x, e[2 * k].y, e[2 * k + 1].x, e[2 * k + 1].y);
+}
+
+// ------------------------------------------------------------------------------------------------ neighbour rows
+
+struct RowsArgs {
+  const int* coords;        // (n,4) the rows of this table
+  int n, K, mode;           // mode 0 SubM via site hash, 1 SubM via rank table, 2 strided (input-stationary), 3 table -> masks
+  Shape3 s;                 // SubM: the volume; strided: the OUTPUT volume
+  ConvGeom g;
+  const long long* hkeys;
+  const int* hvals;
+  uint32_t hmask;
+  const uint2* rank;        // mode 1: of this set; mode 2: of the output set
+  int n_lookup;             // rows of the looked-up set
+  int* nbr;                 // (n,K): SubM table / strided nbr_t / mode 3: the table read
+  int* scatter;             // mode 2: nbr (n_out,K), pre-filled with -1
+  unsigned* mask;           // (n) or null
+  int* hist;                // (chunks,32), zero-filled by the caller, or null
+};
+
+__device__ __forceinline__ int row_neighbour(const RowsArgs& a, int i, int o, int4 c) {
+  const ConvGeom g = a.g;
+  const int kx = o % g.kw, ky = (o / g.kw) % g.kh, kz = o / (g.kw * g.kh);
+  if (a.mode == 2) {
+    const int tz = c.y + g.pd - kz, ty = c.z + g.ph - ky, tx = c.w + g.pw - kx;
+    if (tz < 0 || ty < 0 || tx < 0 || tz % g.sd || ty % g.sh || tx % g.sw) return -1;
+    const int oz = tz / g.sd, oy = ty / g.sh, ox = tx / g.sw;
+    if (oz >= a.s.d || oy >= a.s.h || ox >= a.s.w) return -1;
+    const int r = rank_lookup(a.rank, lin_index(c.x, oz, oy, ox, a.s));
+    return r < a.n_lookup ? r : -1;
+  }
+  const int z = c.y + kz - g.kd / 2, y = c.z + ky - g.kh / 2, x = c.w + kx - g.kw / 2;
+  if (z < 0 || z >= a.s.d || y < 0 || y >= a.s.h || x < 0 || x >= a.s.w) return -1;
+  const int64_t lin = lin_index(c.x, z, y, x, a.s);
+  if (a.mode == 1) {
+    const int r = rank_lookup(a.rank, lin);
+    return r < a.n_lookup ? r : -1;
+  }
+  const uint32_t slot = crb_hash_find(a.hkeys, a.hmask, lin);
+  return slot != 0xffffffffu ? a.hvals[slot] : -1;
+}
+
+// 32 lanes per row (lane = kernel offset), 8 rows per workgroup iteration, 256 consecutive rows per workgroup
+__global__ __launch_bounds__(256) void table_rows_kernel(RowsArgs a) {
+  __shared__ int cnt_sh[8][32];
+  const int o = threadIdx.x & 31, slot = threadIdx.x >> 5;
+  const int row0 = blockIdx.x * ROWS_PER_WG;
+  const bool act = o < a.K;
+  int cnt = 0;
+#pragma unroll 4
+  for (int it = 0; it < ROWS_PER_WG / 8; ++it) {
+    const int i = row0 + it * 8 + slot;
+    const bool live = i < a.n;                        // uniform over the 32 lanes of a row
+    int r = -1;
+    if (live && act) {
+      if (a.mode == 3) {
+        r = a.nbr[(int64_t)i * a.K + o];
+      } else {
+        const int4 c = *reinterpret_cast<const int4*>(a.coords + (int64_t)i * 4);
+        r = row_neighbour(a, i, o, c);
+        a.nbr[(int64_t)i * a.K + o] = r;
+        if (a.mode == 2 && r >= 0) a.scatter[(int64_t)r * a.K + o] = i;   // unique writer: (output site, offset) -> input site
+      }
+    }
+    const unsigned long long b = __ballot(r >= 0);
+    if (live && o == 0 && a.mask) a.mask[i] = (unsigned)((threadIdx.x & 32) ? (b >> 32) : (b & 0xffffffffULL));
+    cnt += r >= 0;
+  }
+  if (a.hist == nullptr) return;
+  cnt_sh[slot][o] = cnt;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += cnt_sh[k][threadIdx.x];
+    if (s) atomicAdd(&a.hist[(row0 / CHUNK) * 32 + threadIdx.x], s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ finish: chunk pass
+
+constexpr int MAX_TABLES = 16;
+
+struct FinishArgs {
+  CrbTablePlan t[MAX_TABLES];
+  int chunk_start[MAX_TABLES + 1];     // first workgroup of table k
+  int n_tables;
+};
+
+// One 1024-thread workgroup per chunk of 4096 consecutive rows of one table.
+// LDS: key (32 KB: sort keys, then kernel-order masks + prefixes), idx (16 KB: kernel-order -> local row), ucnt (8 KB).
+__global__ __launch_bounds__(1024) void tables_chunk_kernel(FinishArgs fa) {
+  __shared__ __attribute__((aligned(16))) unsigned long long key[CHUNK];
+  __shared__ int idx_sh[CHUNK];
+  __shared__ int ucnt[64][32];                       // first use: [0..31] = "before" partials, [32..63] = "total" partials
+  __shared__ int lpos[32], pbase[33], wave_tot[16];
+  __shared__ int chunk_base_sh;
+  int k = 0;
+  while (k + 1 < fa.n_tables && (int)blockIdx.x >= fa.chunk_start[k + 1]) ++k;
+  const CrbTablePlan T = fa.t[k];
+  const int chunk = blockIdx.x - fa.chunk_start[k];
+  const int n = (int)T.n, K = T.K;
+  const int nchunks = (n + CHUNK - 1) / CHUNK;
+  const int base = chunk * CHUNK;
+  const int rows = min(CHUNK, n - base);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // ---- per-offset counts: of this chunk (sort key), of the chunks before it (pair positions), of the table (pair_start)
+  {
+    const int o = tid & 31, part = tid >> 5;
+    int before = 0, total = 0;
+    for (int c = part; c < nchunks; c += 32) {
+      const int v = T.hist[c * 32 + o];
+      total += v;
+      if (c < chunk) before += v;
+    }
+    ucnt[part][o] = before;
+    ucnt[32 + part][o] = total;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    int before = 0, total = 0;
+#pragma unroll
+    for (int p = 0; p < 32; ++p) { before += ucnt[p][tid]; total += ucnt[32 + p][tid]; }
+    const int mine = T.hist[chunk * 32 + tid];
+    // exclusive prefix over offsets of the table totals = pair_start; wave-level scan over 32 lanes
+    int incl = total;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+      const int v = __shfl_up(incl, d, 64);
+      if (tid >= d) incl += v;
+    }
+    pbase[tid] = incl - total + before;
+    if (tid == 31) pbase[32] = incl;                                  // P
+    if (chunk == 0 && T.pair_start) {
+      if (tid <= K) T.pair_start[tid] = incl - total;                 // offsets >= K have no pairs: entry K = P
+      if (K == 32 && tid == 31) T.pair_start[32] = incl;
+    }
+    int cb = before;                                                  // packed base of the chunk = pairs of earlier chunks
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) cb += __shfl_xor(cb, d, 64);
+    if (tid == 0) chunk_base_sh = cb;
+    // rank of the bits: rarest offset of THIS chunk = most significant (ties: lower bit index first)
+    int p = 0;
+    for (int b = 0; b < 32; ++b) {
+      const int hb = __shfl(mine, b, 64);
+      p += (hb > mine) || (hb == mine && b < tid);
+    }
+    lpos[tid] = p;
+  }
+  __syncthreads();
+
+  // ---- sort keys: (~ranked mask) << 32 | local row : descending ranked mask, stable
+  for (int t = tid; t < CHUNK; t += 1024) {
+    unsigned long long kk = ~0ULL;
+    if (t < rows) {
+      const unsigned m = T.mask[base + t];
+      unsigned r = 0;
+      for (int b = 0; b < 32; ++b) r |= ((m >> b) & 1u) << lpos[b];
+      kk = ((unsigned long long)(~r) << 32) | (unsigned)t;
+    }
+    key[t] = kk;
+  }
+  __syncthreads();
+  for (int kk = 2; kk <= CHUNK; kk <<= 1)
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < CHUNK / 2; t += 1024) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int p = i | j;
+        const bool up = (i & kk) == 0;
+        const unsigned long long a = key[i], b = key[p];
+        if ((a > b) == up) { key[i] = b; key[p] = a; }
+      }
+      __syncthreads();
+    }
+
+  // ---- kernel order: perm, cmask, cbase (4 consecutive rows per thread)
+  unsigned m4[4];
+  int id4[4], pc = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int t = tid * 4 + q;
+    id4[q] = (int)(key[t] & 0xffffffffULL);
+    m4[q] = t < rows ? T.mask[base + id4[q]] : 0u;
+    pc += __popc(m4[q]);
+  }
+  __syncthreads();                                                    // every key read before the buffer is reused
+  int incl = crb_wave_incl_scan(pc);
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < wave; ++w) woff += wave_tot[w];
+  int ex = chunk_base_sh + woff + incl - pc;
+  unsigned* m_sh = reinterpret_cast<unsigned*>(key);                  // [CHUNK]
+  int* cb_sh = reinterpret_cast<int*>(key) + CHUNK;                   // [CHUNK]
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int t = tid * 4 + q;
+    m_sh[t] = m4[q];
+    cb_sh[t] = ex;
+    idx_sh[t] = id4[q];
+    if (t < rows) {
+      T.perm[base + t] = base + id4[q];
+      T.cmask[base + t] = m4[q];
+      T.cbase[base + t] = ex;
+    }
+    ex += __popc(m4[q]);
+  }
+  if (chunk == nchunks - 1 && tid == 1023) T.cbase[n] = ex;           // = P (rows beyond n have empty masks)
+  __syncthreads();
+
+  // ---- tile weights: offsets present in any of the 64 rows of a tile
+  for (int tl = wave; tl < CHUNK / 64; tl += 16) {
+    unsigned m = m_sh[tl * 64 + lane];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m |= (unsigned)__shfl_xor((int)m, d, 64);
+    if (lane == 0 && tl * 64 < rows) T.tile_weight[chunk * (CHUNK / 64) + tl] = __popc(m);
+  }
+
+  // ---- packed neighbour indices: 32 lanes per kernel-order row
+  {
+    const int o = tid & 31;
+    for (int t = tid >> 5; t < rows; t += 32) {
+      const unsigned m = m_sh[t];
+      if ((m >> o) & 1u)
+        T.packed[cb_sh[t] + __popc(m & ((1u << o) - 1u))] = T.nbr[(int64_t)(base + idx_sh[t]) * K + o];
+    }
+  }
+
+  // ---- pair lists of this chunk's rows (natural order): offset-major, ascending output row
+  if (T.pair_in == nullptr) return;
+  for (int u = wave; u < CHUNK / 64; u += 16) {
+    const int r = u * 64 + lane;
+    const unsigned m = r < rows ? T.mask[base + r] : 0u;
+    for (int o = 0; o < 32; ++o) {
+      const int c = __popcll(__ballot((m >> o) & 1u));
+      if (lane == o) ucnt[u][o] = c;
+    }
+  }
+  __syncthreads();
+  if (tid < 32) {                                                     // exclusive prefix over the 64 units, per offset
+    int run = pbase[tid];
+    for (int u = 0; u < CHUNK / 64; ++u) {
+      const int c = ucnt[u][tid];
+      ucnt[u][tid] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  for (int u = wave; u < CHUNK / 64; u += 16) {
+    const int r = u * 64 + lane;
+    const unsigned m = r < rows ? T.mask[base + r] : 0u;
+    const int* row = T.nbr + (int64_t)(base + r) * K;
+    for (int o = 0; o < K; ++o) {
+      const unsigned long long b = __ballot((m >> o) & 1u);
+      if ((m >> o) & 1u) {
+        const int pos = ucnt[u][o] + __popcll(b & ((1ULL << lane) - 1ULL));
+        T.pair_in[pos] = row[o];
+        T.pair_out[pos] = base + r;
+      }
+    }
+  }
+}
+
+// Heaviest-tile-first order of the 64-row tiles inside each of the 8 contiguous tile ranges (one per XCD: workgroup b of the
+// gather-GEMM runs on XCD b % 8 and takes position (b % 8) * per + b / 8). Stable (ties keep table order): deterministic.
+// One workgroup per (table, range); ranges of up to 8192 tiles are sorted (keys in LDS), longer ones keep table order.
+constexpr int LPT_RANGES = 8;
+constexpr int LPT_MAX = 8192;
+
+__global__ __launch_bounds__(1024) void tables_order_kernel(FinishArgs fa) {
+  __shared__ unsigned key[LPT_MAX];
+  const int k = blockIdx.x / LPT_RANGES, r = blockIdx.x % LPT_RANGES;
+  const CrbTablePlan T = fa.t[k];
+  const int n = (int)T.n;
+  const int tiles_all = (n + 63) / 64, tiles_full = n / 64;
+  const int per = (tiles_all + LPT_RANGES - 1) / LPT_RANGES;
+  const int lo = r * per, hi = min(lo + per, tiles_all);
+  if (lo >= hi) return;
+  const int hi_full = min(hi, tiles_full);                           // the trailing partial tile keeps its (last) place
+  const int cnt = max(hi_full - lo, 0);
+  if (hi > hi_full && threadIdx.x == 0) T.tile_order[hi_full] = hi_full;
+  if (cnt == 0) return;
+  if (cnt > LPT_MAX) {
+    for (int t = threadIdx.x; t < cnt; t += 1024) T.tile_order[lo + t] = lo + t;
+    return;
+  }
+  int p2 = 2;
+  while (p2 < cnt) p2 <<= 1;
+  for (int t = threadIdx.x; t < p2; t += 1024)
+    key[t] = t < cnt ? ((unsigned)(32 - T.tile_weight[lo + t]) << 16) | (unsigned)t : 0xffffffffu;
+  __syncthreads();
+  for (int kk = 2; kk <= p2; kk <<= 1)
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < p2 / 2; t += 1024) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int p = i | j;
+        const bool up = (i & kk) == 0;
+        const unsigned a = key[i], b = key[p];
+        if ((a > b) == up) { key[i] = b; key[p] = a; }
+      }
+      __syncthreads();
+    }
+  for (int t = threadIdx.x; t < cnt; t += 1024) T.tile_order[lo + t] = lo + (int)(key[t] & 0xffffu);
+}
+
+}  // namespace
+
+// ================================================================================================ C-ABI
+
+extern "C" int64_t crb_spconv_padded_words(int B, const int32_t* out_shape_dhw) {
+  const int64_t sites = (int64_t)B * out_shape_dhw[0] * out_shape_dhw[1] * out_shape_dhw[2];
+  return crb_align_up((sites + 31) / 32, TILE_WORDS);
+}
+
+static inline ConvGeom geom_of(const int32_t* g9) { return ConvGeom{g9[0], g9[1], g9[2], g9[3], g9[4], g9[5], g9[6], g9[7], g9[8]}; }
+static inline Shape3 shape_of(const int32_t* s) { return Shape3{s[0], s[1], s[2]}; }
+
+extern "C" int crb_spconv_chain_mark(const int32_t* coords, int64_t n, int B, const int32_t* in_shape_dhw, int n_levels,
+                                     const int32_t* geoms, const int32_t* out_shapes, const int64_t* word_off,
+                                     uint32_t* bitmap_all, int32_t* tile_sums_all, int32_t* counts_dev, void* stream) {
+  if (n < 0 || B <= 0 || n_levels < 1 || n_levels > 8) return CRB_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  for (int l = 0; l <= n_levels; ++l)
+    if (word_off[l] % TILE_WORDS || (l && word_off[l] - word_off[l - 1] < crb_spconv_padded_words(B, out_shapes + 3 * (l - 1))))
+      return CRB_ERR_ARG;
+  CRB_HIP(hipMemsetAsync(bitmap_all + word_off[0], 0, (size_t)(word_off[n_levels] - word_off[0]) * 4, st));
+  if (n > 0)
+    hipLaunchKernelGGL(chain_mark_coords_kernel, dim3(crb_cdiv(n, 256)), dim3(256), 0, st, coords, (int)n, geom_of(geoms),
+                       shape_of(out_shapes), bitmap_all + word_off[0]);
+  ChainScanArgs sa;
+  sa.levels = n_levels;
+  for (int l = 0; l <= n_levels; ++l) sa.tile_off[l] = (int)((word_off[l] - word_off[0]) / TILE_WORDS);
+  for (int l = 0; l < n_levels; ++l) {
+    const int tiles = sa.tile_off[l + 1] - sa.tile_off[l];
+    const bool last = l + 1 == n_levels;
+    hipLaunchKernelGGL(chain_mark_bitmap_kernel, dim3(tiles), dim3(256), 0, st, bitmap_all + word_off[l],
+                       shape_of(out_shapes + 3 * l), last ? ConvGeom{1, 1, 1, 1, 1, 1, 0, 0, 0} : geom_of(geoms + 9 * (l + 1)),
+                       last ? Shape3{1, 1, 1} : shape_of(out_shapes + 3 * (l + 1)),
+                       last ? (uint32_t*)nullptr : bitmap_all + word_off[l + 1], tile_sums_all + sa.tile_off[l]);
+  }
+  hipLaunchKernelGGL(chain_scan_kernel, dim3(n_levels), dim3(256), 0, st, tile_sums_all, sa, counts_dev);
+  CRB_CHECK_LAUNCH();
+  (void)in_shape_dhw;
+  return CRB_OK;
+}
+
+extern "C" int crb_spconv_chain_emit(int B, int n_levels, const int32_t* out_shapes, const int64_t* word_off,
+                                     const uint32_t* bitmap_all, const int32_t* tile_sums_all, void* rank_all,
+                                     int32_t* const* out_coords, const int64_t* n_out, void* stream) {
+  if (B <= 0 || n_levels < 1 || n_levels > 8) return CRB_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  for (int l = 0; l < n_levels; ++l) {
+    const int tiles = (int)((word_off[l + 1] - word_off[l]) / TILE_WORDS);
+    const int64_t cap = n_out[l] > 0x7fffffff ? 0x7fffffff : n_out[l];
+    hipLaunchKernelGGL(chain_emit_kernel, dim3(tiles), dim3(256), 0, st, bitmap_all + word_off[l],
+                       tile_sums_all + (word_off[l] - word_off[0]) / TILE_WORDS, shape_of(out_shapes + 3 * l), (int)cap,
+                       (uint2*)rank_all + word_off[l], out_coords[l]);
+  }
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_table_chunk_rows(void) { return CHUNK; }
+
+static int launch_rows(const RowsArgs& a, hipStream_t st) {
+  if (a.n <= 0) return CRB_OK;
+  if (a.K <= 0 || a.K > 32) return CRB_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(table_rows_kernel, dim3(crb_cdiv(a.n, ROWS_PER_WG)), dim3(256), 0, st, a);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_subm_rows(const int32_t* coords, int64_t n, const int32_t* shape_dhw, const int32_t* ksize,
+                             const int64_t* hkeys, const int32_t* hvals, int64_t capacity, const void* rank,
+                             int32_t* nbr, uint32_t* mask, int32_t* hist, void* stream) {
+  if (n < 0 || n >= (1LL << 31)) return CRB_ERR_ARG;
+  if (n == 0) return CRB_OK;
+  if (!(ksize[0] & 1) || !(ksize[1] & 1) || !(ksize[2] & 1)) return CRB_ERR_UNSUPPORTED;
+  if (!rank && (!hkeys || !hvals || capacity <= 0 || (capacity & (capacity - 1)))) return CRB_ERR_ARG;
+  RowsArgs a{};
+  a.coords = coords; a.n = (int)n; a.K = ksize[0] * ksize[1] * ksize[2]; a.mode = rank ? 1 : 0;
+  a.s = shape_of(shape_dhw);
+  a.g = ConvGeom{ksize[0], ksize[1], ksize[2], 1, 1, 1, ksize[0] / 2, ksize[1] / 2, ksize[2] / 2};
+  a.hkeys = (const long long*)hkeys; a.hvals = hvals; a.hmask = (uint32_t)(capacity - 1);
+  a.rank = (const uint2*)rank; a.n_lookup = (int)n;
+  a.nbr = nbr; a.scatter = nullptr; a.mask = mask; a.hist = hist;
+  return launch_rows(a, (hipStream_t)stream);
+}
+
+extern "C" int crb_spconv_rows(const int32_t* coords, int64_t n, const int32_t* ksize, const int32_t* stride,
+                               const int32_t* padding, const int32_t* out_shape_dhw, const void* rank_out, int64_t n_out,
+                               int32_t* nbr, int32_t* nbr_t, uint32_t* mask_t, int32_t* hist_t, void* stream) {
+  if (n < 0 || n_out < 0 || n >= (1LL << 31) || n_out >= (1LL << 31) || !rank_out) return CRB_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  RowsArgs a{};
+  a.coords = coords; a.n = (int)n; a.K = ksize[0] * ksize[1] * ksize[2]; a.mode = 2;
+  a.s = shape_of(out_shape_dhw);
+  a.g = ConvGeom{ksize[0], ksize[1], ksize[2], stride[0], stride[1], stride[2], padding[0], padding[1], padding[2]};
+  a.rank = (const uint2*)rank_out; a.n_lookup = (int)n_out;
+  a.nbr = nbr_t; a.scatter = nbr; a.mask = mask_t; a.hist = hist_t;
+  if (a.K > 32) return CRB_ERR_UNSUPPORTED;
+  if (n_out > 0) CRB_HIP(hipMemsetAsync(nbr, 0xff, (size_t)n_out * a.K * 4, st));
+  return launch_rows(a, st);
+}
+
+extern "C" int crb_table_masks(const int32_t* nbr, int64_t n, int K, uint32_t* mask, int32_t* hist, void* stream) {
+  if (n < 0 || n >= (1LL << 31)) return CRB_ERR_ARG;
+  RowsArgs a{};
+  a.n = (int)n; a.K = K; a.mode = 3; a.nbr = const_cast<int32_t*>(nbr); a.mask = mask; a.hist = hist;
+  return launch_rows(a, (hipStream_t)stream);
+}
+
+extern "C" int crb_tables_finish(const CrbTablePlan* tables, int n_tables, void* stream) {
+  if (n_tables < 0) return CRB_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  for (int t0 = 0; t0 < n_tables; t0 += MAX_TABLES) {
+    FinishArgs fa;
+    fa.n_tables = 0;
+    int wgs = 0;
+    for (int t = t0; t < n_tables && fa.n_tables < MAX_TABLES; ++t) {
+      const CrbTablePlan& T = tables[t];
+      if (T.n < 0 || T.n >= (1LL << 31) || T.K <= 0 || T.K > 32) return CRB_ERR_ARG;
+      if (T.n == 0) {
+        CRB_HIP(hipMemsetAsync(T.cbase, 0, sizeof(int), st));
+        if (T.pair_start) CRB_HIP(hipMemsetAsync(T.pair_start, 0, sizeof(int) * (T.K + 1), st));
+        continue;
+      }
+      if (!T.nbr || !T.mask || !T.hist || !T.perm || !T.cmask || !T.cbase || !T.packed || !T.tile_weight || !T.tile_order)
+        return CRB_ERR_ARG;
+      if ((T.pair_in || T.pair_out || T.pair_start) && !(T.pair_in && T.pair_out && T.pair_start)) return CRB_ERR_ARG;
+      fa.t[fa.n_tables] = T;
+      fa.chunk_start[fa.n_tables] = wgs;
+      wgs += crb_cdiv(T.n, CHUNK);
+      ++fa.n_tables;
+    }
+    if (fa.n_tables == 0) continue;
+    for (int k = fa.n_tables; k <= MAX_TABLES; ++k) fa.chunk_start[k] = wgs;
+    hipLaunchKernelGGL(tables_chunk_kernel, dim3(wgs), dim3(1024), 0, st, fa);
+    hipLaunchKernelGGL(tables_order_kernel, dim3(fa.n_tables * LPT_RANGES), dim3(1024), 0, st, fa);
+  }
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}

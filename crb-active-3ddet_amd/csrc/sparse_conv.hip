@@ -277,7 +277,8 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
                                                                const unsigned* __restrict__ cmask = nullptr,
                                                                const int* __restrict__ cbase = nullptr,
                                                                ConvEpilogue ep = ConvEpilogue{nullptr, nullptr, nullptr, nullptr,
-                                                                                              nullptr, 0.f, 0}) {
+                                                                                              nullptr, 0.f, 0},
+                                                               const int* __restrict__ tile_order = nullptr) {
   static_assert(CIN % 16 == 0 && COUT % 16 == 0, "v2 needs whole float4 k-groups and unmasked column blocks");
   constexpr int NB = (COUT + 15) / 16;
   constexpr int WS = NB * 16;
@@ -293,8 +294,10 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
   __shared__ unsigned row_mask_sh[COMPACT ? 64 : 1];
   __shared__ int row_base_sh[COMPACT ? 64 : 1];
 
-  const int tile = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  if (tile >= ntiles) return;
+  const int pos = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  if (pos >= ntiles) return;
+  // heaviest-first dispatch inside the XCD's tile range as an indirection (crb_tables_finish): nothing is permuted in memory
+  const int tile = tile_order ? tile_order[pos] : pos;
   unsigned long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_begin = TIMING ? __builtin_readcyclecounter() : 0ULL;
   unsigned long long t_mark = t_begin;
@@ -1401,14 +1404,14 @@ int launch_fwd(const float* X, const float* W, const int* nbr, const int* perm, 
 
 template <int CIN, int COUT>
 int launch_fwd_compact(const float* X, const float* W, const unsigned* cmask, const int* cbase, const int* packed,
-                       const int* perm, float* Y, int64_t n_out, int K, hipStream_t st,
+                       const int* perm, const int* tile_order, float* Y, int64_t n_out, int K, hipStream_t st,
                        ConvEpilogue ep = ConvEpilogue{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0}) {
   if constexpr (CIN % 16 == 0 && COUT % 16 == 0 && CIN <= 64) {
     const int ntiles = crb_cdiv(n_out, 64);
     const int grid = ((ntiles + 7) / 8) * 8;
     size_t lds = 2 * sizeof(float) * CIN * (((COUT + 15) / 16) * 16) + sizeof(int) * 64 * K + 16;
     hipLaunchKernelGGL((sparse_conv_fwd2_kernel<CIN, COUT, false, true, false, true>), dim3(grid), dim3(256), lds, st, X, W,
-                       packed, perm, Y, (int)n_out, K, ntiles, cmask, cbase, ep);
+                       packed, perm, Y, (int)n_out, K, ntiles, cmask, cbase, ep, tile_order);
     CRB_CHECK_LAUNCH();
     return CRB_OK;
   }
@@ -1617,19 +1620,20 @@ extern "C" int crb_nbr_compact(const int32_t* nbr, const int32_t* perm, int64_t 
 }
 
 extern "C" int crb_sparse_conv_forward_compact(const float* X, const float* W, const uint32_t* cmask, const int32_t* cbase,
-                                               const int32_t* packed, const int32_t* perm, float* Y, int64_t n_out, int K,
-                                               int cin, int cout, void* stream) {
+                                               const int32_t* packed, const int32_t* perm, const int32_t* tile_order, float* Y,
+                                               int64_t n_out, int K, int cin, int cout, void* stream) {
   if (n_out < 0 || K <= 0 || K > 32) return CRB_ERR_ARG;
   if (n_out == 0) return CRB_OK;
   hipStream_t st = (hipStream_t)stream;
-#define X_(a, b) if (cin == a && cout == b) return launch_fwd_compact<a, b>(X, W, cmask, cbase, packed, perm, Y, n_out, K, st);
+#define X_(a, b) if (cin == a && cout == b) return launch_fwd_compact<a, b>(X, W, cmask, cbase, packed, perm, tile_order, Y, n_out, K, st);
   CRB_CONV_SHAPES(X_)
 #undef X_
   return CRB_ERR_UNSUPPORTED;
 }
 
 extern "C" int crb_sparse_conv_forward_compact_bn(const float* X, const float* W, const uint32_t* cmask, const int32_t* cbase,
-                                                  const int32_t* packed, const int32_t* perm, float* Y, int64_t n_out, int K,
+                                                  const int32_t* packed, const int32_t* perm, const int32_t* tile_order,
+                                                  float* Y, int64_t n_out, int K,
                                                   int cin, int cout, const float* bias, const float* gamma, const float* beta,
                                                   const float* running_mean, const float* running_var, float eps, int relu,
                                                   void* stream) {
@@ -1638,7 +1642,7 @@ extern "C" int crb_sparse_conv_forward_compact_bn(const float* X, const float* W
   hipStream_t st = (hipStream_t)stream;
   const ConvEpilogue ep{bias, gamma, beta, running_mean, running_var, eps, relu};
 #define X_(a, b) \
-  if (cin == a && cout == b) return launch_fwd_compact<a, b>(X, W, cmask, cbase, packed, perm, Y, n_out, K, st, ep);
+  if (cin == a && cout == b) return launch_fwd_compact<a, b>(X, W, cmask, cbase, packed, perm, tile_order, Y, n_out, K, st, ep);
   CRB_CONV_SHAPES(X_)
 #undef X_
   return CRB_ERR_UNSUPPORTED;

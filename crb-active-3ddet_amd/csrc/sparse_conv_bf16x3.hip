@@ -91,7 +91,8 @@ template <int CIN, int COUT, int TPW, int MODE = 0, int NW = 4>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void sparse_conv_fwd_bf16x3_kernel(
     const float* __restrict__ X, const bf16x8* __restrict__ Wp, const int* __restrict__ packed,
     const int* __restrict__ perm, float* __restrict__ Y, int n_out, int K, int ntiles,
-    const unsigned* __restrict__ cmask, const int* __restrict__ cbase, unsigned x_bytes) {
+    const unsigned* __restrict__ cmask, const int* __restrict__ cbase, unsigned x_bytes,
+    const int* __restrict__ tile_order) {
   static_assert(CIN % 32 == 0 && COUT % 16 == 0, "k-groups of 32 channels, 16-column blocks");
   constexpr int NB = COUT / 16, KS = CIN / 32, ROWS = 16 * NW * TPW, NT = 64 * NW;
   constexpr int WVEC = KS * NB * 128;               // 16-byte vectors per offset (hi + lo)
@@ -106,8 +107,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void sparse_conv_fwd_bf16
   __shared__ unsigned row_mask_sh[ROWS];
   __shared__ int row_base_sh[ROWS];
 
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  if (tile >= ntiles) return;
+  const int pos = xcd_remap(blockIdx.x, gridDim.x);
+  if (pos >= ntiles) return;
+  const int tile = (tile_order && ROWS == 64) ? tile_order[pos] : pos;    // the order is over 64-row tiles
   const int row0 = tile * ROWS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
   {
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void sparse_conv_fwd_bf16
 
 template <int CIN, int COUT, int TPW, int NW = 4>
 int launch_tpw(const float* X, const bf16x8* Wp, const unsigned* cmask, const int* cbase, const int* packed, const int* perm,
-               float* Y, int64_t n_in, int64_t n_out, int K, hipStream_t st) {
+               const int* tile_order, float* Y, int64_t n_in, int64_t n_out, int K, hipStream_t st) {
   constexpr int WVEC = (CIN / 32) * (COUT / 16) * 128;
   const int ntiles = crb_cdiv(n_out, 16 * NW * TPW);
   const int grid = ((ntiles + 7) / 8) * 8;
@@ -331,14 +333,14 @@ int launch_tpw(const float* X, const bf16x8* Wp, const unsigned* cmask, const in
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, X, Wp, packed, perm, Y, (int)n_out, K, ntiles, cmask, cbase,
-                     (unsigned)(n_in * CIN * 4));
+                     (unsigned)(n_in * CIN * 4), tile_order);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
 
 template <int CIN, int COUT>
 int launch_bf16x3(const float* X, const float* W, const unsigned* cmask, const int* cbase, const int* packed, const int* perm,
-                  float* Y, int64_t n_in, int64_t n_out, int K, void* ws, int64_t wsb, hipStream_t st) {
+                  const int* tile_order, float* Y, int64_t n_in, int64_t n_out, int K, void* ws, int64_t wsb, hipStream_t st) {
   if (n_in * CIN * 4 >= (int64_t)1 << 31) return CRB_ERR_UNSUPPORTED;      // 32-bit buffer offsets, top half = "absent row"
   if (!ws || wsb < (int64_t)K * CIN * COUT * 4) return CRB_ERR_WORKSPACE;
   bf16x8* Wp = (bf16x8*)ws;
@@ -349,10 +351,10 @@ int launch_bf16x3(const float* X, const float* W, const unsigned* cmask, const i
   // two tiles per wave 112-118 / 78; 8 waves x one tile 106 / 72
   const int tpw = g_bf16x3_tpw ? g_bf16x3_tpw : 1;
   if constexpr (!BIG && ((CIN / 32) * (COUT / 16) * 128) % 512 == 0) {
-    if (tpw == 3) return launch_tpw<CIN, COUT, 1, 8>(X, Wp, cmask, cbase, packed, perm, Y, n_in, n_out, K, st);
+    if (tpw == 3) return launch_tpw<CIN, COUT, 1, 8>(X, Wp, cmask, cbase, packed, perm, tile_order, Y, n_in, n_out, K, st);
   }
-  if (BIG || tpw == 1) return launch_tpw<CIN, COUT, 1>(X, Wp, cmask, cbase, packed, perm, Y, n_in, n_out, K, st);
-  if constexpr (!BIG) return launch_tpw<CIN, COUT, 2>(X, Wp, cmask, cbase, packed, perm, Y, n_in, n_out, K, st);
+  if (BIG || tpw == 1) return launch_tpw<CIN, COUT, 1>(X, Wp, cmask, cbase, packed, perm, tile_order, Y, n_in, n_out, K, st);
+  if constexpr (!BIG) return launch_tpw<CIN, COUT, 2>(X, Wp, cmask, cbase, packed, perm, tile_order, Y, n_in, n_out, K, st);
   return CRB_ERR_UNSUPPORTED;
 }
 
@@ -384,7 +386,8 @@ extern "C" int crb_sparse_conv_bf16x3_set_tiles_per_wave(int tpw) {
 #endif
 
 extern "C" int crb_sparse_conv_forward_bf16x3(const float* X, const float* W, const uint32_t* cmask, const int32_t* cbase,
-                                              const int32_t* packed, const int32_t* perm, float* Y, int64_t n_in,
+                                              const int32_t* packed, const int32_t* perm, const int32_t* tile_order,
+                                              float* Y, int64_t n_in,
                                               int64_t n_out, int K, int cin, int cout, void* workspace,
                                               int64_t workspace_bytes, void* stream) {
   if (n_in < 0 || n_out < 0 || K <= 0 || K > 32) return CRB_ERR_ARG;
@@ -392,7 +395,7 @@ extern "C" int crb_sparse_conv_forward_bf16x3(const float* X, const float* W, co
   hipStream_t st = (hipStream_t)stream;
 #define X_(a, b) \
   if (cin == a && cout == b) \
-    return launch_bf16x3<a, b>(X, W, cmask, cbase, packed, perm, Y, n_in, n_out, K, workspace, workspace_bytes, st);
+    return launch_bf16x3<a, b>(X, W, cmask, cbase, packed, perm, tile_order, Y, n_in, n_out, K, workspace, workspace_bytes, st);
   CRB_BF16X3_SHAPES(X_)
 #undef X_
   return CRB_ERR_UNSUPPORTED;

@@ -200,47 +200,51 @@ def set_arithmetic(module, arithmetic):
 def plan_indices(modules, input, with_frame_offsets=False):
     """Build the rulebooks of every (non 1x1, non inverse) SparseConvolution found in `modules` (in module order, as the
     forward pass will meet them) BEFORE the first feature kernel runs, and leave them in input.indice_dict under their
-    indice_key. The active sets depend on the coordinates only, so the whole chain of strided output sets is marked and
-    counted with ONE host read-back (crbhip.sparse.strided_chain_counts) instead of one synchronisation per strided layer in
-    the middle of the forward pass (each of which let the GPU run dry while the host refilled the launch queue).
-    Layers without an indice_key, or whose key is already planned, are skipped; the forward pass falls back to building a
-    missing rulebook on the spot."""
+    indice_key: crbhip.sparse.build_rulebooks takes the whole chain — the output sets of all strided layers are marked and
+    counted with ONE host read-back, every table costs one launch and all of them are finished (kernel order, compact
+    tables, tile order, wgrad pair lists) by two more — instead of ~30 launches and a synchronisation per layer in the
+    middle of the forward pass.
+    Precondition (checked): the convs that carry a new indice_key form one linear chain starting at `input` — every strided
+    conv consumes the output set of the strided conv before it. A tensor on which some of the strided keys already exist
+    is left alone: the forward pass then builds what is missing layer by layer."""
     convs = []
     for root in modules:
         for m in root.modules():
             if isinstance(m, SparseConvolution) and m.ndim == 3 and not m.inverse and not m.conv1x1 and \
                     m.indice_key is not None:
                 convs.append(m)
-    strided = [m for m in convs if not m.subm and m.indice_key not in input.indice_dict]
-    seen, chain = set(), []
-    for m in strided:
-        if m.indice_key not in seen:
-            seen.add(m.indice_key)
-            chain.append(m)
-    if not chain:
-        marks = {}
-    else:
-        geoms = [(m._k3(m.kernel_size, 1), m._k3(m.stride, 1), m._k3(m.padding, 0)) for m in chain]
-        res = _sp.strided_chain_counts(input.indices, list(input.spatial_shape), input.batch_size, geoms)
-        marks = {m.indice_key: r for m, r in zip(chain, res)}
-    idx, shape = input.indices, list(input.spatial_shape)
+    have = [m.indice_key in input.indice_dict for m in convs if not m.subm]
+    if any(have) and not all(have):
+        return input                              # partially planned tensor: no assumption about where the chain stands
+    specs, todo, seen = [], [], set(input.indice_dict.keys())
+    shape = list(input.spatial_shape)
+    geom_of = {}
     for m in convs:
         key = m.indice_key
-        if key in input.indice_dict:
-            rb = input.indice_dict[key]
-        elif m.subm:
-            rb = _sp.subm_rulebook(idx, shape, m._k3(m.kernel_size, 1))
-            input.indice_dict[key] = rb
+        ks = m._k3(m.kernel_size, 1)
+        if m.subm:
+            g = ('subm', tuple(ks), tuple(shape))
         else:
-            rb = _sp.spconv_rulebook(idx, shape, input.batch_size, m._k3(m.kernel_size, 1), m._k3(m.stride, 1),
-                                     m._k3(m.padding, 0), premarked=marks.get(key))
-            input.indice_dict[key] = rb
+            g = ('spconv', tuple(ks), tuple(m._k3(m.stride, 1)), tuple(m._k3(m.padding, 0)), tuple(shape))
+        if key in geom_of:
+            if geom_of[key] != g:
+                raise ValueError('indice_key %r is shared by convs of different geometry or level: %s vs %s' % (key, geom_of[key], g))
+        else:
+            geom_of[key] = g
+            if key not in seen:
+                specs.append(g[:2] if m.subm else g[:4])
+                todo.append(key)
         if not m.subm:
-            idx, shape = rb.out_coords, list(rb.out_shape)
+            shape = _sp.conv_out_shape(shape, g[1], g[2], g[3])
+    if specs and not (have and all(have)):
+        books = _sp.build_rulebooks(input.indices, list(input.spatial_shape), input.batch_size, specs,
+                                    want_grad=torch.is_grad_enabled())
+        for key, rb in zip(todo, books):
+            input.indice_dict[key] = rb
+    # (all strided keys present, SubM keys missing: each is built on its level by the forward pass)
     if with_frame_offsets:
         # rows per frame of the input and of every strided level (sparse rows are frame-sorted): ONE read-back. Used by the
         # per-frame BatchNorm of batched CRB stage 2 (crbhip.bnrelu.frame_groups).
-        import torch
         B = input.batch_size
         levels = [('in', input.indices)] + [(m.indice_key, input.indice_dict[m.indice_key].out_coords)
                                             for m in convs if not m.subm]

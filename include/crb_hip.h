@@ -138,9 +138,72 @@ int crb_sparse_conv_compact_supported(int cin, int cout);
 int64_t crb_nbr_compact_workspace_bytes(int64_t n);
 int crb_nbr_compact(const int32_t* nbr, const int32_t* perm, int64_t n, int K, uint32_t* cmask, int32_t* cbase,
                     int32_t* packed, void* workspace, int64_t workspace_bytes, void* stream);
+/* tile_order (ceil(n_out/64)) or NULL: position -> 64-row tile of the kernel order, the heaviest-first dispatch order inside
+ * each XCD's contiguous range of tiles (crb_tables_finish); results do not depend on it. */
 int crb_sparse_conv_forward_compact(const float* X, const float* W, const uint32_t* cmask, const int32_t* cbase,
-                                    const int32_t* packed, const int32_t* perm, float* Y, int64_t n_out, int K, int cin,
-                                    int cout, void* stream);
+                                    const int32_t* packed, const int32_t* perm, const int32_t* tile_order, float* Y,
+                                    int64_t n_out, int K, int cin, int cout, void* stream);
+
+/* ---- the whole backbone's tables in ~26 launches and ONE host read-back (csrc/rulebook_plan.hip) --------------------------
+ * replaces: the indice-pair generation of every spconv.pytorch.SubMConv3d / SparseConv3d of
+ *   pcdet/models/backbones_3d/spconv_backbone.py:77-117 (VoxelBackBone8x: 4 SubM keys + 4 strided keys), which spconv builds
+ *   layer by layer inside forward with one synchronisation per strided layer.
+ * chain: output sets of a chain of strided convs (level l+1 = conv l+1 applied to level l's set). geoms = n_levels x 9 ints
+ *   {k,s,p} (d,h,w), out_shapes = n_levels x 3; the bitmaps of all levels live in one caller-owned buffer, level l at word
+ *   word_off[l] (n_levels+1 entries, multiples of 2048, word_off[l+1]-word_off[l] >= crb_spconv_padded_words of level l);
+ *   tile_sums_all holds one int per 2048-word tile. crb_spconv_chain_mark zero-fills and marks every level and writes the
+ *   per-level site counts to counts_dev (device; the caller reads them back ONCE and sizes every later buffer).
+ *   crb_spconv_chain_emit: per level the coordinates (ascending (b,z,y,x), n_out[l] rows, host array of device pointers) and
+ *   the rank table: 8 bytes per bitmap word {bits, rows before the word} so that site -> row is ONE load. */
+int64_t crb_spconv_padded_words(int B, const int32_t* out_shape_dhw);
+int crb_spconv_chain_mark(const int32_t* coords, int64_t n, int B, const int32_t* in_shape_dhw, int n_levels,
+                          const int32_t* geoms, const int32_t* out_shapes, const int64_t* word_off, uint32_t* bitmap_all,
+                          int32_t* tile_sums_all, int32_t* counts_dev, void* stream);
+int crb_spconv_chain_emit(int B, int n_levels, const int32_t* out_shapes, const int64_t* word_off,
+                          const uint32_t* bitmap_all, const int32_t* tile_sums_all, void* rank_all,
+                          int32_t* const* out_coords, const int64_t* n_out, void* stream);
+/* rows: ONE kernel per table writes the neighbour rows (n,K), mask (n) u32 = offsets present per row and hist
+ * (ceil(n / crb_table_chunk_rows()), 32) i32 += per-chunk count of every offset (caller zero-fills hist).
+ * crb_subm_rows: SubM table of a site set; sites are looked up in `rank` (rank table of THIS set from crb_spconv_chain_emit:
+ *   rows are bitmap ranks) or, rank == NULL, in the site hash of crb_sparse_hash_build (any row order).
+ * crb_spconv_rows: strided conv from the input rows `coords` to the set whose rank table is rank_out: nbr_t (n,K) = output row
+ *   per (input row, offset) with its mask / hist, and nbr (n_out,K) filled by the unique writer of every entry (the launch
+ *   first fills it with -1). No existence test is needed (every site an input reaches is an output).
+ * crb_table_masks: mask + hist of an existing (n,K) table. */
+int crb_table_chunk_rows(void);
+int crb_subm_rows(const int32_t* coords, int64_t n, const int32_t* shape_dhw, const int32_t* ksize, const int64_t* hkeys,
+                  const int32_t* hvals, int64_t capacity, const void* rank, int32_t* nbr, uint32_t* mask, int32_t* hist,
+                  void* stream);
+int crb_spconv_rows(const int32_t* coords, int64_t n, const int32_t* ksize, const int32_t* stride, const int32_t* padding,
+                    const int32_t* out_shape_dhw, const void* rank_out, int64_t n_out, int32_t* nbr, int32_t* nbr_t,
+                    uint32_t* mask_t, int32_t* hist_t, void* stream);
+int crb_table_masks(const int32_t* nbr, int64_t n, int K, uint32_t* mask, int32_t* hist, void* stream);
+/* finish: everything the kernels read, for any number of tables, in TWO launches per 16 tables.
+ * per table (host array of CrbTablePlan; all pointers device, caller-owned):
+ *   in : nbr (n,K), mask (n), hist (chunks,32) as written by the rows kernels
+ *   out: perm (n) kernel order of the rows (every 4096-row chunk sorted by mask, rarest offset first, descending, stable);
+ *        cmask (n) / cbase (n+1) / packed (>= P, caller allocates n*K) the compact table of crb_nbr_compact in that order;
+ *        tile_weight / tile_order (ceil(n/64)) offsets present per 64-row tile and the heaviest-first order of the tiles
+ *        inside each of the 8 XCD ranges (stable: deterministic);
+ *        pair_in / pair_out (>= P) / pair_start (K+1), or all three NULL: the wgrad pair lists of crb_pairs_from_nbr. */
+typedef struct CrbTablePlan {
+  const int32_t* nbr;
+  const uint32_t* mask;
+  const int32_t* hist;
+  int32_t* perm;
+  uint32_t* cmask;
+  int32_t* cbase;
+  int32_t* packed;
+  int32_t* tile_weight;
+  int32_t* tile_order;
+  int32_t* pair_in;
+  int32_t* pair_out;
+  int32_t* pair_start;
+  int64_t n;
+  int32_t K;
+  int32_t reserved;
+} CrbTablePlan;
+int crb_tables_finish(const CrbTablePlan* tables, int n_tables, void* stream);
 
 /* Inference epilogue in the gather-GEMM: y = relu(gamma * ((conv + bias - running_mean) * rsqrt(running_var + eps)) + beta),
  * i.e. the (bias,) nn.BatchNorm1d in eval mode and nn.ReLU that follow a sparse conv in post_act_block
@@ -148,8 +211,8 @@ int crb_sparse_conv_forward_compact(const float* X, const float* W, const uint32
  * passes over the rows; same arithmetic order as crb_bn_relu_apply. bias may be NULL; relu 0/1. Shapes of
  * crb_sparse_conv_compact_supported only. */
 int crb_sparse_conv_forward_compact_bn(const float* X, const float* W, const uint32_t* cmask, const int32_t* cbase,
-                                       const int32_t* packed, const int32_t* perm, float* Y, int64_t n_out, int K, int cin,
-                                       int cout, const float* bias, const float* gamma, const float* beta,
+                                       const int32_t* packed, const int32_t* perm, const int32_t* tile_order, float* Y,
+                                       int64_t n_out, int K, int cin, int cout, const float* bias, const float* gamma, const float* beta,
                                        const float* running_mean, const float* running_var, float eps, int relu,
                                        void* stream);
 
@@ -166,8 +229,9 @@ int crb_sparse_conv_forward_compact_bn(const float* X, const float* W, const uin
 int crb_sparse_conv_bf16x3_supported(int cin, int cout);
 int64_t crb_sparse_conv_bf16x3_workspace_bytes(int K, int cin, int cout);
 int crb_sparse_conv_forward_bf16x3(const float* X, const float* W, const uint32_t* cmask, const int32_t* cbase,
-                                   const int32_t* packed, const int32_t* perm, float* Y, int64_t n_in, int64_t n_out,
-                                   int K, int cin, int cout, void* workspace, int64_t workspace_bytes, void* stream);
+                                   const int32_t* packed, const int32_t* perm, const int32_t* tile_order, float* Y,
+                                   int64_t n_in, int64_t n_out, int K, int cin, int cout, void* workspace,
+                                   int64_t workspace_bytes, void* stream);
 int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, const int32_t* perm, float* Y,
                             int64_t n_out, int K, int cin, int cout, void* stream);
 /* dW (K,cin,cout) = sum over pairs X[pin]^T dY[pout] */

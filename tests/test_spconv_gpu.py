@@ -533,33 +533,56 @@ def _kio_grad(conv):
 
 @pytest.mark.parametrize('kind', ['subm', 'strided'])
 def test_compact_table_is_the_sorted_table_and_gives_identical_results(dev, kind):
-    """crb_nbr_compact: mask + packed present indices decode to exactly the (n,K) table in kernel order (itself bit-exact
-    vs the oracle), and crb_sparse_conv_forward_compact == crb_sparse_conv_forward bit for bit, forward and dgrad"""
+    """the tables crb_tables_finish leaves for the gather-GEMM: mask + packed present indices decode to exactly the (n,K)
+    table (itself bit-exact vs the oracle) in kernel order; the kernel order is the stable per-chunk sort by ranked mask; the
+    tile order is the stable heaviest-first order inside each of the 8 XCD ranges; crb_sparse_conv_forward_compact (with and
+    without the tile order) == crb_sparse_conv_forward on the (n,K) rows, bit for bit, forward and dgrad shapes"""
     from crbhip import lib, sparse
     rng = np.random.default_rng(31)
     shape = [21, 120, 100]
     coords = random_sparse_coords(rng, 9000, 2, shape)
-    if kind == 'subm':
-        rb = sparse.subm_rulebook(_t(coords, dev), shape, [3, 3, 3])
-        which = ['nbr']
-    else:
-        rb = sparse.spconv_rulebook(_t(coords, dev), shape, 2, [3, 3, 3], [2, 2, 2], [1, 1, 1])
-        which = ['nbr', 'nbr_t']
+    with torch.enable_grad():                                  # want_grad: the transposed table is part of the plan
+        if kind == 'subm':
+            rb = sparse.subm_rulebook(_t(coords, dev), shape, [3, 3, 3])
+            which = ['nbr']
+        else:
+            rb = sparse.spconv_rulebook(_t(coords, dev), shape, 2, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+            which = ['nbr', 'nbr_t']
+    chunk = lib.crb_table_chunk_rows()
+    assert chunk == lib.crb_mask_sort_chunk_rows()
     for w_ in which:
-        full, perm = rb.sorted_table(w_)
+        nat = rb.nbr if w_ == 'nbr' else rb.nbr_t
         ct = rb.compact_table(w_)
-        assert torch.equal(ct.to_nbr(), full)
-        P = int((full >= 0).sum())
+        n = nat.shape[0]
+        assert torch.equal(ct.to_nbr(), nat[ct.perm.long()])
+        P = int((nat >= 0).sum())
         assert ct.num_pairs() == P and int(ct.cbase[0]) == 0
-        assert torch.equal(ct.perm, perm)
+        mask = (((nat >= 0).long() << torch.arange(27, device=dev)[None, :]).sum(1)).cpu().numpy()
+        key = (np.arange(n) // chunk).astype(np.int64) * (1 << 32) + ((~_rank_bits_key(mask, chunk, 2)) & 0xffffffff)
+        np.testing.assert_array_equal(ct.perm.cpu().numpy(), np.argsort(key, kind='stable'))
+        # tile order: stable sort by weight (offsets present in any row of the tile), descending, inside each range
+        sm = mask[ct.perm.cpu().numpy()]
+        tiles_all, full = (n + 63) // 64, n // 64
+        wt = np.array([bin(int(np.bitwise_or.reduce(sm[t * 64:(t + 1) * 64]))).count('1') for t in range(full)])
+        per = (tiles_all + 7) // 8
+        expect = np.arange(tiles_all)
+        for r in range(8):
+            lo, hi = r * per, min((r + 1) * per, full)
+            if lo < hi:
+                expect[lo:hi] = lo + np.argsort(-wt[lo:hi], kind='stable')
+        np.testing.assert_array_equal(ct.order.cpu().numpy(), expect)
+        full_rows, perm = rb.sorted_table(w_)                          # rows physically in dispatch order (v1 kernels)
+        assert torch.equal(full_rows, nat[perm.long()]) and sorted(perm.cpu().tolist()) == list(range(n))
         n_in = rb.n_in if w_ == 'nbr' else rb.n_out
+        ct_plain = sparse.CompactTable(ct.cmask, ct.cbase, ct.packed, ct.perm, ct.n, ct.K, None)
         for cin, cout in ((16, 16), (16, 32), (32, 16), (32, 32), (32, 64), (64, 64), (64, 128)):
             assert lib.crb_sparse_conv_compact_supported(cin, cout) == 1
             x = torch.randn(n_in, cin, device=dev)
             w = torch.randn(27, cin, cout, device=dev) / 8
-            a = sparse._conv_forward_raw(x, w, (full, perm), full.shape[0])
-            b = sparse._conv_forward_raw(x, w, ct, full.shape[0])
-            assert torch.equal(a, b), (cin, cout, float((a - b).abs().max()))
+            a = sparse._conv_forward_raw(x, w, (full_rows, perm), n)
+            b = sparse._conv_forward_raw(x, w, ct, n)
+            c = sparse._conv_forward_raw(x, w, ct_plain, n)
+            assert torch.equal(a, b) and torch.equal(a, c), (cin, cout, float((a - b).abs().max()))
     assert lib.crb_sparse_conv_compact_supported(4, 16) == 0 and lib.crb_sparse_conv_compact_supported(128, 64) == 0
     # natural row order (no permutation) and an all-empty table
     ct0 = sparse._compact(rb.nbr, None, 27)
@@ -569,29 +592,54 @@ def test_compact_table_is_the_sorted_table_and_gives_identical_results(dev, kind
     assert cte.num_pairs() == 0
     y = sparse._conv_forward_raw(torch.randn(5, 16, device=dev), torch.randn(27, 16, 16, device=dev), cte, 130)
     assert float(y.abs().max()) == 0.0
+    rbe = sparse.Rulebook(empty, None, 130, 130, [3, 3, 3], [1, 1, 1], [1, 1, 1], True, shape, shape, None)
+    cte2 = rbe.compact_table('nbr')                                     # the fused path on an all-empty table
+    assert cte2.num_pairs() == 0 and torch.equal(cte2.to_nbr(), empty[cte2.perm.long()])
+    assert int(rbe.pairs()[2][-1]) == 0
 
 
-def test_planned_strided_chain_equals_layer_by_layer_rulebooks(dev):
-    """crbhip.sparse.strided_chain_counts (next level marked from the previous level's BITMAP, one host read-back for the
-    whole chain) + premarked rulebooks == the rulebooks built one strided layer at a time, on the geometry chain of
-    VoxelBackBone8x (k3 s2 p1, k3 s2 p1, k3 s2 p(0,1,1), k(3,1,1) s(2,1,1) p0); counts equal the oracle's"""
+def test_planned_chain_equals_layer_by_layer_rulebooks_and_the_oracle(dev):
+    """crbhip.sparse.build_rulebooks on the whole geometry chain of VoxelBackBone8x (subm, k3 s2 p1, subm, k3 s2 p1, subm,
+    k3 s2 p(0,1,1), subm, k(3,1,1) s(2,1,1) p0): every level marked from the previous level's BITMAP, one host read-back,
+    SubM tables of the chain's own levels through the rank table instead of a hash == the rulebooks built one layer at a
+    time == the oracle (output sets, both tables of the strided convs, SubM tables, pair lists)"""
     from crbhip import sparse
     rng = np.random.default_rng(5)
     shape = [41, 160, 144]
     coords = random_sparse_coords(rng, 12000, 3, shape)
     geoms = [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)),
              ((3, 1, 1), (2, 1, 1), (0, 0, 0))]
+    specs = []
+    for g in geoms:
+        specs += [('subm', (3, 3, 3)), ('spconv',) + g]
     c = _t(coords, dev)
-    marks = sparse.strided_chain_counts(c, shape, 3, geoms)
+    with torch.enable_grad():
+        books = sparse.build_rulebooks(c, shape, 3, specs, want_grad=True)
     cur, cur_shape = c, shape
     oc_np, oshape_np = coords, shape
-    for (ks, st, pd), mk in zip(geoms, marks):
+    for k, (ks, st, pd) in enumerate(geoms):
+        sub, b = books[2 * k], books[2 * k + 1]
+        np.testing.assert_array_equal(sub.nbr.cpu().numpy(), oracle.subm_nbr(oc_np, oshape_np, [3, 3, 3]))
+        assert torch.equal(sparse.subm_rulebook(cur, cur_shape, [3, 3, 3]).nbr, sub.nbr)         # hash path == rank path
         a = sparse.spconv_rulebook(cur, cur_shape, 3, ks, st, pd)
-        b = sparse.spconv_rulebook(cur, cur_shape, 3, ks, st, pd, premarked=mk)
-        assert a.n_out == b.n_out == mk[1] and a.out_shape == b.out_shape == list(mk[2])
+        assert a.n_out == b.n_out and a.out_shape == b.out_shape
         assert torch.equal(a.out_coords, b.out_coords) and torch.equal(a.nbr, b.nbr) and torch.equal(a.nbr_t, b.nbr_t)
-        oc_np, oshape_np = oracle.spconv_out(oc_np, oshape_np, ks, st, pd)
-        np.testing.assert_array_equal(b.out_coords.cpu().numpy(), oc_np)
+        nxt, nshape = oracle.spconv_out(oc_np, oshape_np, ks, st, pd)
+        np.testing.assert_array_equal(b.out_coords.cpu().numpy(), nxt)
+        nbr_ref = oracle.spconv_nbr(oc_np, oshape_np, nxt, ks, st, pd)
+        np.testing.assert_array_equal(b.nbr.cpu().numpy(), nbr_ref)
+        i, o = np.nonzero(nbr_ref >= 0)
+        ref_t = np.full((len(oc_np), nbr_ref.shape[1]), -1, np.int32)
+        ref_t[nbr_ref[i, o], o] = i
+        np.testing.assert_array_equal(b.nbr_t.cpu().numpy(), ref_t)
+        pin, pout, pstart = [x.cpu().numpy() for x in b.pairs()[:3]]
+        K = nbr_ref.shape[1]
+        assert int(pstart[K]) == (nbr_ref >= 0).sum()
+        for o_ in range(K):
+            rows = np.nonzero(nbr_ref[:, o_] >= 0)[0]
+            np.testing.assert_array_equal(pout[pstart[o_]:pstart[o_ + 1]], rows)
+            np.testing.assert_array_equal(pin[pstart[o_]:pstart[o_ + 1]], nbr_ref[rows, o_])
+        oc_np, oshape_np = nxt, nshape
         cur, cur_shape = b.out_coords.contiguous(), b.out_shape
 
 
