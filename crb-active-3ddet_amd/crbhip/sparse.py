@@ -80,35 +80,51 @@ def table_from_nbr(nbr, K):
 
 class _TablePlan(ctypes.Structure):            # include/crb_hip.h: CrbTablePlan
     _fields_ = [(k, ctypes.c_void_p) for k in ('nbr', 'mask', 'hist', 'perm', 'cmask', 'cbase', 'packed', 'tile_weight',
-                                               'tile_order', 'pair_in', 'pair_out', 'pair_start')] + \
+                                               'tile_order', 'pair_in', 'pair_out', 'pair_start', 'pair_unit_base')] + \
                [('n', ctypes.c_int64), ('K', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+def plan_tables(tables, want_pairs):
+    """output buffers + the CrbTablePlan array of crb_tables_finish for `tables` -> (plans, buffers)"""
+    dev = tables[0].nbr.device
+    plans = (_TablePlan * len(tables))()
+    keep = []
+    # ONE allocation for all outputs of all tables (a hundred torch.empty calls cost more host time than the kernels run)
+    need, layout = 0, []
+    for t, wp in zip(tables, want_pairs):
+        n, K = t.n, t.K
+        tiles = (n + 63) // 64
+        sizes = [max(n, 1), max(n, 1), n + 1, max(n * K, 1), max(tiles, 1), max(tiles, 1)]
+        if wp:
+            sizes += [max(n * K, 1), max(n * K, 1), K + 1, max(tiles * 32, 1)]
+        offs = []
+        for sz in sizes:
+            offs.append(need)
+            need += (sz + 63) // 64 * 64                       # 256-byte aligned carves
+        layout.append((sizes, offs))
+    arena = torch.empty((need,), dtype=torch.int32, device=dev)
+    for i, (t, wp, (sizes, offs)) in enumerate(zip(tables, want_pairs, layout)):
+        bufs = [arena[o:o + sz] for sz, o in zip(sizes, offs)]
+        perm, cmask, cbase, packed, weight, order = bufs[:6]
+        pin, pout, pstart, ubase = bufs[6:] if wp else (None, None, None, None)
+        p = plans[i]
+        for name, ten in (('nbr', t.nbr), ('mask', t.mask), ('hist', t.hist), ('perm', perm), ('cmask', cmask), ('cbase', cbase),
+                          ('packed', packed), ('tile_weight', weight), ('tile_order', order), ('pair_in', pin),
+                          ('pair_out', pout), ('pair_start', pstart), ('pair_unit_base', ubase)):
+            setattr(p, name, ten.data_ptr() if ten is not None else None)
+        p.n, p.K, p.reserved = t.n, t.K, 0
+        keep.append((perm, cmask, cbase, packed, weight, order, pin, pout, pstart))
+    return plans, keep
 
 
 def finish_tables(tables, want_pairs):
     """kernel order, compact table, tile order and (want_pairs[i]) the wgrad pair lists of every KernelTable in `tables`:
-    two launches for all of them (crb_tables_finish)"""
+    three launches for all of them (crb_tables_finish)"""
     tables = [t for t in tables]
     if not tables:
         return
     dev = tables[0].nbr.device
-    plans = (_TablePlan * len(tables))()
-    keep = []
-    for i, (t, wp) in enumerate(zip(tables, want_pairs)):
-        n, K = t.n, t.K
-        i32 = lambda m: torch.empty((max(m, 1),), dtype=torch.int32, device=dev)
-        perm, cmask, cbase, packed = i32(n), i32(n), i32(n + 1), i32(n * K)
-        tiles = (n + 63) // 64
-        weight, order = i32(tiles), i32(tiles)
-        pin = pout = pstart = None
-        if wp:
-            pin, pout, pstart = i32(n * K), i32(n * K), i32(K + 1)
-        p = plans[i]
-        for name, ten in (('nbr', t.nbr), ('mask', t.mask), ('hist', t.hist), ('perm', perm), ('cmask', cmask), ('cbase', cbase),
-                          ('packed', packed), ('tile_weight', weight), ('tile_order', order), ('pair_in', pin),
-                          ('pair_out', pout), ('pair_start', pstart)):
-            setattr(p, name, ten.data_ptr() if ten is not None else None)
-        p.n, p.K, p.reserved = n, K, 0
-        keep.append((perm, cmask, cbase, packed, weight, order, pin, pout, pstart))
+    plans, keep = plan_tables(tables, want_pairs)
     check(lib.crb_tables_finish(plans, len(tables), cur_stream(dev)), 'crb_tables_finish')
     for t, wp, (perm, cmask, cbase, packed, weight, order, pin, pout, pstart) in zip(tables, want_pairs, keep):
         n = t.n

@@ -199,6 +199,34 @@ __device__ __forceinline__ uint32_t crb_hash_find(const long long* __restrict__ 
   }
 }
 
+// The same table with x-GROUPED slots (site hash of the sparse-conv rulebooks): slot = group(key / 8) * 8 + key % 8 and a
+// collision moves on by whole groups — eight interleaved open-addressing tables, one per key % 8, that share the group hash.
+// Keys are linear site indices with x fastest, so the 3 x-neighbours a kernel row looks up fall into ONE 64-byte line of
+// keys most of the time (a separate hash per site touched 27 lines per row: the level-1 SubM table took 115 us).
+__device__ __forceinline__ uint32_t crb_ghash_insert(long long* __restrict__ keys, uint32_t mask, int64_t key) {
+  const uint32_t gmask = mask >> 3, sub = (uint32_t)(key & 7);
+  uint32_t g = crb_hash64(key >> 3) & gmask;
+  while (true) {
+    const uint32_t slot = (g << 3) | sub;
+    long long prev = (long long)atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)CRB_HASH_EMPTY,
+                                          (unsigned long long)key);
+    if (prev == CRB_HASH_EMPTY || prev == (long long)key) return slot;
+    g = (g + 1) & gmask;
+  }
+}
+
+__device__ __forceinline__ uint32_t crb_ghash_find(const long long* __restrict__ keys, uint32_t mask, int64_t key) {
+  const uint32_t gmask = mask >> 3, sub = (uint32_t)(key & 7);
+  uint32_t g = crb_hash64(key >> 3) & gmask;
+  while (true) {
+    const uint32_t slot = (g << 3) | sub;
+    const long long k = keys[slot];
+    if (k == (long long)key) return slot;
+    if (k == CRB_HASH_EMPTY) return 0xffffffffu;
+    g = (g + 1) & gmask;
+  }
+}
+
 static inline int64_t crb_hash_capacity(int64_t n) {
   int64_t c = 1024;
   while (c < 2 * n) c <<= 1;

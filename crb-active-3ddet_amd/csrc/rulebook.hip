@@ -1,4 +1,5 @@
-// Sparse-conv "rulebook" construction for gfx950 (row a4 of SURVEY §8).
+// Sparse-conv "rulebook" building blocks for gfx950 (row a4 of SURVEY §8): the site hash, and the one-table-at-a-time row
+// orders (mask sort, tile order) kept for A/B runs. What a training / scoring step runs is rulebook_plan.hip.
 //
 // Replaces the indice-pair generation inside spconv.pytorch SubMConv3d / SparseConv3d as configured by
 // the reference at pcdet/models/backbones_3d/spconv_backbone.py:77-117 (third-party spconv-cu113 v2.1.21,
@@ -31,188 +32,9 @@ __global__ __launch_bounds__(256) void hash_build_kernel(const int* __restrict__
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   int4 c = *reinterpret_cast<const int4*>(coords + (int64_t)i * 4);
-  uint32_t slot = crb_hash_insert(hkeys, hmask, lin_index(c.x, c.y, c.z, c.w, s));
+  uint32_t slot = crb_ghash_insert(hkeys, hmask, lin_index(c.x, c.y, c.z, c.w, s));
   // duplicate coordinates: the smallest row wins (deterministic)
   atomicMin(&hvals[slot], i);
-}
-
-struct ConvGeom {
-  int kd, kh, kw;
-  int sd, sh, sw;
-  int pd, ph, pw;
-};
-
-// SubM: one thread per (row, offset)
-__global__ __launch_bounds__(256) void subm_nbr_kernel(const int* __restrict__ coords, int n, Shape3 s, ConvGeom g,
-                                                       const long long* __restrict__ hkeys,
-                                                       const int* __restrict__ hvals, uint32_t hmask,
-                                                       int* __restrict__ nbr) {
-  const int K = g.kd * g.kh * g.kw;
-  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (int64_t)n * K) return;
-  int i = (int)(t / K);
-  int o = (int)(t - (int64_t)i * K);
-  int kx = o % g.kw, ky = (o / g.kw) % g.kh, kz = o / (g.kw * g.kh);
-  int4 c = *reinterpret_cast<const int4*>(coords + (int64_t)i * 4);
-  int z = c.y + kz - g.kd / 2, y = c.z + ky - g.kh / 2, x = c.w + kx - g.kw / 2;
-  int r = -1;
-  if (z >= 0 && z < s.d && y >= 0 && y < s.h && x >= 0 && x < s.w) {
-    uint32_t slot = crb_hash_find(hkeys, hmask, lin_index(c.x, z, y, x, s));
-    if (slot != 0xffffffffu) r = hvals[slot];
-  }
-  nbr[t] = r;
-}
-
-// strided conv, pass 1: mark every output site reached by (input row, offset) in the bitmap
-__global__ __launch_bounds__(256) void spconv_mark_kernel(const int* __restrict__ coords, int n, ConvGeom g,
-                                                          Shape3 so, uint32_t* __restrict__ bitmap) {
-  const int K = g.kd * g.kh * g.kw;
-  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (int64_t)n * K) return;
-  int j = (int)(t / K);
-  int o = (int)(t - (int64_t)j * K);
-  int kx = o % g.kw, ky = (o / g.kw) % g.kh, kz = o / (g.kw * g.kh);
-  int4 c = *reinterpret_cast<const int4*>(coords + (int64_t)j * 4);
-  int tz = c.y + g.pd - kz, ty = c.z + g.ph - ky, tx = c.w + g.pw - kx;
-  if (tz < 0 || ty < 0 || tx < 0) return;
-  if (tz % g.sd || ty % g.sh || tx % g.sw) return;
-  int oz = tz / g.sd, oy = ty / g.sh, ox = tx / g.sw;
-  if (oz >= so.d || oy >= so.h || ox >= so.w) return;
-  int64_t lin = lin_index(c.x, oz, oy, ox, so);
-  atomicOr(&bitmap[lin >> 5], 1u << (lin & 31));
-}
-
-// the same marking, driven by the BITMAP of the input sites instead of their coordinate list: the output set of the next
-// strided level can be marked before the current level's coordinates exist, so the output counts of a whole chain of
-// strided convs are known after ONE host read-back (the coordinate lists and tables are then sized without further syncs)
-__global__ __launch_bounds__(256) void spconv_mark_from_bitmap_kernel(const uint32_t* __restrict__ in_bitmap,
-                                                                      int64_t in_words, Shape3 si, ConvGeom g, Shape3 so,
-                                                                      uint32_t* __restrict__ bitmap) {
-  const int64_t wi = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (wi >= in_words) return;
-  uint32_t m = in_bitmap[wi];
-  while (m) {
-    const int bit = __ffs(m) - 1;
-    m &= m - 1;
-    int64_t lin = wi * 32 + bit;
-    const int x = (int)(lin % si.w); lin /= si.w;
-    const int y = (int)(lin % si.h); lin /= si.h;
-    const int z = (int)(lin % si.d); lin /= si.d;
-    const int b = (int)lin;
-    for (int kz = 0; kz < g.kd; ++kz) {
-      const int tz = z + g.pd - kz;
-      if (tz < 0 || tz % g.sd || tz / g.sd >= so.d) continue;
-      for (int ky = 0; ky < g.kh; ++ky) {
-        const int ty = y + g.ph - ky;
-        if (ty < 0 || ty % g.sh || ty / g.sh >= so.h) continue;
-        for (int kx = 0; kx < g.kw; ++kx) {
-          const int tx = x + g.pw - kx;
-          if (tx < 0 || tx % g.sw || tx / g.sw >= so.w) continue;
-          const int64_t lo = lin_index(b, tz / g.sd, ty / g.sh, tx / g.sw, so);
-          atomicOr(&bitmap[lo >> 5], 1u << (lo & 31));
-        }
-      }
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void bitmap_count_kernel(const uint32_t* __restrict__ bitmap, int64_t words,
-                                                           int* __restrict__ count) {
-  int c = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (int64_t)gridDim.x * 256) c += __popc(bitmap[i]);
-  for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
-  if (crb_lane() == 0 && c) atomicAdd(count, c);
-}
-
-struct PopcF {
-  const uint32_t* bm;
-  __device__ int operator()(int64_t i) const { return __popc(bm[i]); }
-};
-struct PrefixW {
-  int* prefix;
-  __device__ void operator()(int64_t i, int ex, int) const { prefix[i] = ex; }
-};
-
-// pass 2: expand bitmap words into sorted output coordinates
-__global__ __launch_bounds__(256) void spconv_emit_coords_kernel(const uint32_t* __restrict__ bitmap,
-                                                                 const int* __restrict__ prefix, int64_t nwords,
-                                                                 Shape3 so, int max_out, int* __restrict__ out_coords) {
-  int64_t wi = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (wi >= nwords) return;
-  uint32_t m = bitmap[wi];
-  int r = prefix[wi];
-  while (m) {
-    int bit = __ffs(m) - 1;
-    m &= m - 1;
-    if (r < max_out) {
-      int64_t lin = wi * 32 + bit;
-      int x = (int)(lin % so.w); lin /= so.w;
-      int y = (int)(lin % so.h); lin /= so.h;
-      int z = (int)(lin % so.d); lin /= so.d;
-      *reinterpret_cast<int4*>(out_coords + (int64_t)r * 4) = make_int4((int)lin, z, y, x);
-    }
-    ++r;
-  }
-}
-
-// pass 3: per (input row, offset) find the output row (bitmap rank) and fill both tables
-__global__ __launch_bounds__(256) void spconv_nbr_kernel(const int* __restrict__ coords, int n, ConvGeom g, Shape3 so,
-                                                         const uint32_t* __restrict__ bitmap,
-                                                         const int* __restrict__ prefix, int n_out,
-                                                         int* __restrict__ nbr /* (n_out,K) pre-filled -1 */,
-                                                         int* __restrict__ nbr_t /* (n,K) */) {
-  const int K = g.kd * g.kh * g.kw;
-  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (int64_t)n * K) return;
-  int j = (int)(t / K);
-  int o = (int)(t - (int64_t)j * K);
-  int kx = o % g.kw, ky = (o / g.kw) % g.kh, kz = o / (g.kw * g.kh);
-  int4 c = *reinterpret_cast<const int4*>(coords + (int64_t)j * 4);
-  int tz = c.y + g.pd - kz, ty = c.z + g.ph - ky, tx = c.w + g.pw - kx;
-  int r = -1;
-  if (tz >= 0 && ty >= 0 && tx >= 0 && !(tz % g.sd) && !(ty % g.sh) && !(tx % g.sw)) {
-    int oz = tz / g.sd, oy = ty / g.sh, ox = tx / g.sw;
-    if (oz < so.d && oy < so.h && ox < so.w) {
-      int64_t lin = lin_index(c.x, oz, oy, ox, so);
-      uint32_t word = bitmap[lin >> 5];
-      r = prefix[lin >> 5] + __popc(word & ((1u << (lin & 31)) - 1u));
-      if (r >= n_out) r = -1;
-    }
-  }
-  nbr_t[t] = r;
-  if (r >= 0) nbr[(int64_t)r * K + o] = j;   // unique writer: (out site, offset) determines the input site
-}
-
-// pair lists: flattened offset-major index f = o*n_out + i
-// flags are read from the per-row neighbour bit-mask (coalesced along rows for a fixed offset); reading nbr[i*K+o]
-// directly in offset-major order is a stride-K access and made this scan the most expensive rulebook kernel
-struct PairFlag {
-  const unsigned* mask; int n_out;
-  __device__ int operator()(int64_t f) const {
-    int o = (int)(f / n_out); int i = (int)(f - (int64_t)o * n_out);
-    return (int)((mask[i] >> o) & 1u);
-  }
-};
-
-__global__ __launch_bounds__(256) void row_mask_kernel(const int* __restrict__ nbr, int n, int K, unsigned* __restrict__ mask) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  unsigned m = 0;
-  for (int o = 0; o < K; ++o) m |= (nbr[(int64_t)i * K + o] >= 0 ? 1u : 0u) << o;
-  mask[i] = m;
-}
-struct PairWrite {
-  const int* nbr; int n_out; int K; int* pin; int* pout; int* pstart;
-  __device__ void operator()(int64_t f, int ex, int v) const {
-    int o = (int)(f / n_out); int i = (int)(f - (int64_t)o * n_out);
-    if (i == 0) pstart[o] = ex;
-    if (v) { pin[ex] = nbr[(int64_t)i * K + o]; pout[ex] = i; }
-  }
-};
-
-__global__ void fill_i32_kernel(int* p, int64_t n, int v) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) p[i] = v;
 }
 
 // Sort the rows of every chunk of SORT_CHUNK consecutive rows by their neighbour mask, descending (stable: ties keep row
@@ -461,159 +283,6 @@ extern "C" int crb_sparse_hash_build(const int32_t* coords, int64_t n, const int
                      (long long*)hkeys, hvals, (uint32_t)(capacity - 1));
   CRB_CHECK_LAUNCH();
   return CRB_OK;
-}
-
-extern "C" int crb_subm_rulebook(const int32_t* coords, int64_t n, const int32_t* shape_dhw, const int32_t* ksize,
-                                 const int64_t* hkeys, const int32_t* hvals, int64_t capacity,
-                                 int32_t* nbr, void* stream) {
-  if (n < 0 || (capacity & (capacity - 1))) return CRB_ERR_ARG;
-  if (n == 0) return CRB_OK;
-  if (!(ksize[0] & 1) || !(ksize[1] & 1) || !(ksize[2] & 1)) return CRB_ERR_UNSUPPORTED;
-  hipStream_t st = (hipStream_t)stream;
-  Shape3 s{shape_dhw[0], shape_dhw[1], shape_dhw[2]};
-  ConvGeom g{ksize[0], ksize[1], ksize[2], 1, 1, 1, ksize[0] / 2, ksize[1] / 2, ksize[2] / 2};
-  const int K = g.kd * g.kh * g.kw;
-  hipLaunchKernelGGL(subm_nbr_kernel, dim3(crb_cdiv(n * K, 256)), dim3(256), 0, st, coords, (int)n, s, g,
-                     (const long long*)hkeys, hvals, (uint32_t)(capacity - 1), nbr);
-  CRB_CHECK_LAUNCH();
-  return CRB_OK;
-}
-
-extern "C" int64_t crb_spconv_bitmap_words(int B, const int32_t* out_shape_dhw) {
-  int64_t sites = (int64_t)B * out_shape_dhw[0] * out_shape_dhw[1] * out_shape_dhw[2];
-  return (sites + 31) / 32;
-}
-
-extern "C" int64_t crb_spconv_out_coords_workspace_bytes(int B, const int32_t* out_shape_dhw) {
-  int64_t words = crb_spconv_bitmap_words(B, out_shape_dhw);
-  return crb_align_up(words * 4, 256) * 2 + crb_align_up((int64_t)crb_scan_num_tiles(words) * 4, 256) + 1024;
-}
-
-// Stage 1 of a strided conv: output active set. bitmap/prefix (words each) stay alive for stage 2.
-extern "C" int crb_spconv_mark(const int32_t* coords, int64_t n, int B, const int32_t* ksize, const int32_t* stride,
-                               const int32_t* padding, const int32_t* out_shape_dhw, uint32_t* bitmap, void* stream) {
-  if (n < 0 || B <= 0) return CRB_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  Shape3 so{out_shape_dhw[0], out_shape_dhw[1], out_shape_dhw[2]};
-  ConvGeom g{ksize[0], ksize[1], ksize[2], stride[0], stride[1], stride[2], padding[0], padding[1], padding[2]};
-  const int K = g.kd * g.kh * g.kw;
-  CRB_HIP(hipMemsetAsync(bitmap, 0, (size_t)crb_spconv_bitmap_words(B, out_shape_dhw) * 4, st));
-  if (n > 0)
-    hipLaunchKernelGGL(spconv_mark_kernel, dim3(crb_cdiv(n * K, 256)), dim3(256), 0, st, coords, (int)n, g, so, bitmap);
-  CRB_CHECK_LAUNCH();
-  return CRB_OK;
-}
-
-extern "C" int crb_spconv_mark_from_bitmap(const uint32_t* in_bitmap, int B, const int32_t* in_shape_dhw,
-                                           const int32_t* ksize, const int32_t* stride, const int32_t* padding,
-                                           const int32_t* out_shape_dhw, uint32_t* bitmap, void* stream) {
-  if (B <= 0) return CRB_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  Shape3 si{in_shape_dhw[0], in_shape_dhw[1], in_shape_dhw[2]};
-  Shape3 so{out_shape_dhw[0], out_shape_dhw[1], out_shape_dhw[2]};
-  ConvGeom g{ksize[0], ksize[1], ksize[2], stride[0], stride[1], stride[2], padding[0], padding[1], padding[2]};
-  const int64_t in_words = crb_spconv_bitmap_words(B, in_shape_dhw);
-  CRB_HIP(hipMemsetAsync(bitmap, 0, (size_t)crb_spconv_bitmap_words(B, out_shape_dhw) * 4, st));
-  hipLaunchKernelGGL(spconv_mark_from_bitmap_kernel, dim3(crb_cdiv(in_words, 256)), dim3(256), 0, st, in_bitmap, in_words, si,
-                     g, so, bitmap);
-  CRB_CHECK_LAUNCH();
-  return CRB_OK;
-}
-
-extern "C" int crb_bitmap_count(const uint32_t* bitmap, int64_t words, int32_t* count_dev, void* stream) {
-  if (words < 0) return CRB_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  CRB_HIP(hipMemsetAsync(count_dev, 0, sizeof(int), st));
-  if (words > 0) {
-    int blocks = crb_cdiv(words, 256 * 8);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(bitmap_count_kernel, dim3(blocks), dim3(256), 0, st, bitmap, words, count_dev);
-  }
-  CRB_CHECK_LAUNCH();
-  return CRB_OK;
-}
-
-extern "C" int crb_spconv_out_coords_premarked(int B, const int32_t* out_shape_dhw, const uint32_t* bitmap, int32_t* prefix,
-                                               int32_t* scan_tmp, int32_t* out_coords, int64_t max_out,
-                                               int32_t* n_out_dev, void* stream) {
-  if (B <= 0) return CRB_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  Shape3 so{out_shape_dhw[0], out_shape_dhw[1], out_shape_dhw[2]};
-  const int64_t words = crb_spconv_bitmap_words(B, out_shape_dhw);
-  PopcF f{bitmap};
-  PrefixW w{prefix};
-  int rc = crb_device_excl_scan(f, w, words, scan_tmp, n_out_dev, st);
-  if (rc != CRB_OK) return rc;
-  hipLaunchKernelGGL(spconv_emit_coords_kernel, dim3(crb_cdiv(words, 256)), dim3(256), 0, st, bitmap, prefix, words,
-                     so, (int)(max_out > 0x7fffffff ? 0x7fffffff : max_out), out_coords);
-  CRB_CHECK_LAUNCH();
-  return CRB_OK;
-}
-
-extern "C" int crb_spconv_out_coords(const int32_t* coords, int64_t n, int B, const int32_t* ksize,
-                                     const int32_t* stride, const int32_t* padding, const int32_t* out_shape_dhw,
-                                     uint32_t* bitmap, int32_t* prefix, int32_t* scan_tmp,
-                                     int32_t* out_coords, int64_t max_out, int32_t* n_out_dev, void* stream) {
-  if (n < 0 || B <= 0) return CRB_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  Shape3 so{out_shape_dhw[0], out_shape_dhw[1], out_shape_dhw[2]};
-  ConvGeom g{ksize[0], ksize[1], ksize[2], stride[0], stride[1], stride[2], padding[0], padding[1], padding[2]};
-  const int K = g.kd * g.kh * g.kw;
-  const int64_t words = crb_spconv_bitmap_words(B, out_shape_dhw);
-  CRB_HIP(hipMemsetAsync(bitmap, 0, (size_t)words * 4, st));
-  if (n > 0)
-    hipLaunchKernelGGL(spconv_mark_kernel, dim3(crb_cdiv(n * K, 256)), dim3(256), 0, st, coords, (int)n, g, so, bitmap);
-  PopcF f{bitmap};
-  PrefixW w{prefix};
-  int rc = crb_device_excl_scan(f, w, words, scan_tmp, n_out_dev, st);
-  if (rc != CRB_OK) return rc;
-  hipLaunchKernelGGL(spconv_emit_coords_kernel, dim3(crb_cdiv(words, 256)), dim3(256), 0, st, bitmap, prefix, words,
-                     so, (int)(max_out > 0x7fffffff ? 0x7fffffff : max_out), out_coords);
-  CRB_CHECK_LAUNCH();
-  return CRB_OK;
-}
-
-// Stage 2: both neighbour tables.
-extern "C" int crb_spconv_rulebook(const int32_t* coords, int64_t n, int B, const int32_t* ksize,
-                                   const int32_t* stride, const int32_t* padding, const int32_t* out_shape_dhw,
-                                   const uint32_t* bitmap, const int32_t* prefix, int64_t n_out,
-                                   int32_t* nbr, int32_t* nbr_t, void* stream) {
-  if (n < 0 || n_out < 0) return CRB_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  Shape3 so{out_shape_dhw[0], out_shape_dhw[1], out_shape_dhw[2]};
-  ConvGeom g{ksize[0], ksize[1], ksize[2], stride[0], stride[1], stride[2], padding[0], padding[1], padding[2]};
-  const int K = g.kd * g.kh * g.kw;
-  if (n_out > 0)
-    hipLaunchKernelGGL(fill_i32_kernel, dim3(crb_cdiv(n_out * K, 256)), dim3(256), 0, st, nbr, n_out * K, -1);
-  if (n > 0)
-    hipLaunchKernelGGL(spconv_nbr_kernel, dim3(crb_cdiv(n * K, 256)), dim3(256), 0, st, coords, (int)n, g, so, bitmap,
-                       prefix, (int)n_out, nbr, nbr_t);
-  CRB_CHECK_LAUNCH();
-  return CRB_OK;
-}
-
-extern "C" int64_t crb_pairs_workspace_bytes(int64_t n_out, int K) {
-  return crb_align_up((int64_t)crb_scan_num_tiles(n_out * K) * 4, 256) + crb_align_up(n_out * 4, 256) + 256;
-}
-
-// Classic rulebook (pair lists sorted by (offset, output row)) from the output-stationary table.
-// pair_in/pair_out need n_out*K entries of capacity (P is only known on the device: pair_start[K]).
-extern "C" int crb_pairs_from_nbr(const int32_t* nbr, int64_t n_out, int K, int32_t* pair_in, int32_t* pair_out,
-                                  int32_t* pair_start /* K+1 */, void* workspace, int64_t workspace_bytes,
-                                  void* stream) {
-  if (n_out < 0 || K <= 0) return CRB_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  if (n_out == 0) { CRB_HIP(hipMemsetAsync(pair_start, 0, sizeof(int) * (K + 1), st)); return CRB_OK; }
-  if (n_out * K > 0x7fffffffLL) return CRB_ERR_ARG;
-  CrbArena a(workspace, (size_t)workspace_bytes);
-  int* tiles = a.take<int>(crb_scan_num_tiles(n_out * K));
-  unsigned* mask = a.take<unsigned>(n_out);
-  if (!a.ok) return CRB_ERR_WORKSPACE;
-  if (K > 32) return CRB_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(row_mask_kernel, dim3(crb_cdiv(n_out, 256)), dim3(256), 0, st, nbr, (int)n_out, K, mask);
-  PairFlag f{mask, (int)n_out};
-  PairWrite w{nbr, (int)n_out, K, pair_in, pair_out, pair_start};
-  return crb_device_excl_scan(f, w, n_out * K, tiles, pair_start + K, st);
 }
 
 extern "C" int64_t crb_tile_lpt_workspace_bytes(int64_t n) { return (2 * LPT_RANGES * 64 + 2 * (n / 64 + 1)) * 4; }

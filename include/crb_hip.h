@@ -61,47 +61,12 @@ int crb_voxelize(const float* points, int64_t n_points, int num_features,
  * Kernel offset index o = (kz*KH + ky)*KW + kx; weights are (K, Cin, Cout) f32 contiguous.
  * ---------------------------------------------------------------------------------------------- */
 int64_t crb_hash_capacity_for(int64_t n);   /* power of two >= 2n */
-/* site -> row hash; hkeys (capacity) i64, hvals (capacity) i32 */
+/* site -> row hash for a coordinate set in ANY row order (the voxelizer's output): hkeys (capacity) i64, hvals (capacity) i32.
+ * Slots are grouped by 8 consecutive x-sites (slot = group(site / 8) * 8 + site % 8, whole groups probe linearly), so the
+ * three x-neighbours of a kernel row usually share one 64-byte line of keys. Duplicate coordinates: the smallest row wins.
+ * Consumed by crb_subm_rows; sets that come out of crb_spconv_chain_emit need no hash (rank tables). */
 int crb_sparse_hash_build(const int32_t* coords, int64_t n, const int32_t* shape_dhw,
                           int64_t* hkeys, int32_t* hvals, int64_t capacity, void* stream);
-/* SubM: nbr (n,K) i32, nbr[i][o] = row of site coords[i] + (o - centre), or -1 */
-int crb_subm_rulebook(const int32_t* coords, int64_t n, const int32_t* shape_dhw, const int32_t* ksize,
-                      const int64_t* hkeys, const int32_t* hvals, int64_t capacity,
-                      int32_t* nbr, void* stream);
-/* strided conv stage 1: output active set, rows in ascending (b,z,y,x) order.
- * bitmap/prefix: crb_spconv_bitmap_words() u32/i32 words each, kept alive for stage 2;
- * scan_tmp: crb_spconv_out_coords_workspace_bytes() is an upper bound for bitmap+prefix+scan_tmp together.
- * n_out_dev: device i32 scalar (caller reads it back to size the outputs of stage 2). */
-int64_t crb_spconv_bitmap_words(int B, const int32_t* out_shape_dhw);
-int64_t crb_spconv_out_coords_workspace_bytes(int B, const int32_t* out_shape_dhw);
-int crb_spconv_out_coords(const int32_t* coords, int64_t n, int B, const int32_t* ksize,
-                          const int32_t* stride, const int32_t* padding, const int32_t* out_shape_dhw,
-                          uint32_t* bitmap, int32_t* prefix, int32_t* scan_tmp,
-                          int32_t* out_coords, int64_t max_out, int32_t* n_out_dev, void* stream);
-/* strided conv stage 2: nbr (n_out,K) and its transpose nbr_t (n,K) */
-/* Output counts of a CHAIN of strided convs with one host read-back: crb_spconv_mark marks the output bitmap of the first
- * level from its input coordinates, crb_spconv_mark_from_bitmap marks level l+1 straight from level l's bitmap (no
- * coordinate list needed yet), crb_bitmap_count leaves each level's number of output sites in device memory — the caller
- * reads all counts back at once, then sizes every coordinate list / table and runs crb_spconv_out_coords_premarked (scan +
- * emit on an already marked bitmap) + crb_spconv_rulebook per level without further synchronisation. Bitmap layout and
- * results are those of crb_spconv_out_coords. */
-int crb_spconv_mark(const int32_t* coords, int64_t n, int B, const int32_t* ksize, const int32_t* stride,
-                    const int32_t* padding, const int32_t* out_shape_dhw, uint32_t* bitmap, void* stream);
-int crb_spconv_mark_from_bitmap(const uint32_t* in_bitmap, int B, const int32_t* in_shape_dhw, const int32_t* ksize,
-                                const int32_t* stride, const int32_t* padding, const int32_t* out_shape_dhw,
-                                uint32_t* bitmap, void* stream);
-int crb_bitmap_count(const uint32_t* bitmap, int64_t words, int32_t* count_dev, void* stream);
-int crb_spconv_out_coords_premarked(int B, const int32_t* out_shape_dhw, const uint32_t* bitmap, int32_t* prefix,
-                                    int32_t* scan_tmp, int32_t* out_coords, int64_t max_out, int32_t* n_out_dev,
-                                    void* stream);
-int crb_spconv_rulebook(const int32_t* coords, int64_t n, int B, const int32_t* ksize,
-                        const int32_t* stride, const int32_t* padding, const int32_t* out_shape_dhw,
-                        const uint32_t* bitmap, const int32_t* prefix, int64_t n_out,
-                        int32_t* nbr, int32_t* nbr_t, void* stream);
-/* classic pair lists sorted by (offset, output row); pair_in/pair_out capacity n_out*K, pair_start (K+1) */
-int64_t crb_pairs_workspace_bytes(int64_t n_out, int K);
-int crb_pairs_from_nbr(const int32_t* nbr, int64_t n_out, int K, int32_t* pair_in, int32_t* pair_out,
-                       int32_t* pair_start, void* workspace, int64_t workspace_bytes, void* stream);
 /* Y (n_out,cout) = sum_o X[nbr[:,o]] @ W[o]; also used for dgrad with the transposed table / weights.
  * Optional row permutation: when perm != NULL, `nbr` holds the table rows in permuted order (nbr_sorted[s] =
  * nbr[perm[s]]) and the result of sorted row s is written to Y[perm[s]]. Sorting rows by their neighbour bit-mask
@@ -178,14 +143,16 @@ int crb_spconv_rows(const int32_t* coords, int64_t n, const int32_t* ksize, cons
                     const int32_t* out_shape_dhw, const void* rank_out, int64_t n_out, int32_t* nbr, int32_t* nbr_t,
                     uint32_t* mask_t, int32_t* hist_t, void* stream);
 int crb_table_masks(const int32_t* nbr, int64_t n, int K, uint32_t* mask, int32_t* hist, void* stream);
-/* finish: everything the kernels read, for any number of tables, in TWO launches per 16 tables.
+/* finish: everything the kernels read, for any number of tables, in THREE launches per 16 tables (sort pass: one
+ * workgroup per 4096-row chunk, register/shuffle bitonic network; fill pass: one workgroup per 256 rows; tile order).
  * per table (host array of CrbTablePlan; all pointers device, caller-owned):
  *   in : nbr (n,K), mask (n), hist (chunks,32) as written by the rows kernels
  *   out: perm (n) kernel order of the rows (every 4096-row chunk sorted by mask, rarest offset first, descending, stable);
  *        cmask (n) / cbase (n+1) / packed (>= P, caller allocates n*K) the compact table of crb_nbr_compact in that order;
  *        tile_weight / tile_order (ceil(n/64)) offsets present per 64-row tile and the heaviest-first order of the tiles
  *        inside each of the 8 XCD ranges (stable: deterministic);
- *        pair_in / pair_out (>= P) / pair_start (K+1), or all three NULL: the wgrad pair lists of crb_pairs_from_nbr. */
+ *        pair_in / pair_out (>= P) / pair_start (K+1) + workspace pair_unit_base, or all four NULL: the wgrad pair lists of
+ *        wgrad kernels: pair_in / pair_out sorted by (offset, output row), pair_start[o] = first pair of offset o, [K] = P. */
 typedef struct CrbTablePlan {
   const int32_t* nbr;
   const uint32_t* mask;
@@ -199,6 +166,7 @@ typedef struct CrbTablePlan {
   int32_t* pair_in;
   int32_t* pair_out;
   int32_t* pair_start;
+  int32_t* pair_unit_base;      /* workspace, ceil(n/64) x 32 ints (NULL with the pair lists): first pair of every (64-row unit, offset) */
   int64_t n;
   int32_t K;
   int32_t reserved;

@@ -5,7 +5,8 @@ MIOpen's find phase (naive_conv_*, GEMM trials) pollutes whole-process --stats; 
 the voxelizer's `vox_insert` kernel exactly once, so the trace is cut at vox_insert launches and only K complete steps
 near the end of the trace are aggregated.  Usage: prof_summary.py <kernel_trace.csv> <K> > summary.csv
 PROF_MARKER=<kernel substring> picks another once-per-step kernel; PROF_SPLIT_GRID=<kernel substring> lists the matching
-kernel once per launch geometry (the subm and the strided layers run the same gather-GEMM instance)."""
+kernel once per launch geometry (the subm and the strided layers run the same gather-GEMM instance);
+PROF_LIST=<substr,substr> lists every matching launch of the last complete step (start offset, duration, grid)."""
 import csv
 import sys
 from collections import defaultdict
@@ -58,6 +59,16 @@ def main(path, K, marker='vox_insert'):
     if os.environ.get('PROF_GAPS'):
         for g in sorted(gaps, reverse=True)[:int(os.environ['PROF_GAPS'])]:
             w.writerow(['# gap_us', '%.1f' % (g[0] / 1e3), 'after', g[1][:70], 'before', g[2][:70]])
+    if os.environ.get('PROF_LIST'):
+        # every launch of the LAST complete step whose name holds one of the comma-separated substrings, in time order:
+        # start offset inside the step, duration, grid, name (per-launch view of kernels that run once per table / level)
+        pats = [x for x in os.environ['PROF_LIST'].split(',') if x]
+        last = rows[marks[-2]:marks[-1]]
+        t0 = int(last[0][key_s])
+        for r in last:
+            if any(x in r[key_n] for x in pats):
+                w.writerow(['# launch', '%.1f' % ((int(r[key_s]) - t0) / 1e3), 'dur_us', '%.1f' % ((int(r[key_e]) - int(r[key_s])) / 1e3),
+                            'grid', r.get(key_g, ''), r[key_n][:60]])
     w.writerow(['kernel', 'calls_per_step', 'avg_us', 'ms_per_step', 'pct_of_busy'])
     for name, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         w.writerow([name[:160], '%.2f' % (n / K), '%.2f' % (t / n / 1e3), '%.4f' % (t / 1e6 / K), '%.2f' % (100.0 * t / busy)])
