@@ -196,16 +196,76 @@ def cpu_baseline(args):
     t0 = time.time()
     second_step_cpu(m, pts, off, gt, max_voxels=ds.max_num_voxels['train'])
     dt = time.time() - t0
-    return {'value': round(args.cpu_frames / dt, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+    crb = cpu_baseline_crb(cores) if args.kind == 'kitti' else None
+    return {'value': round(args.cpu_frames / dt, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port', 'crb': crb,
+            'threads_note': 'capped at 32 host threads: the oracle\'s OpenMP loops and torch\'s CPU convolutions of this '
+                            '16-frame problem get slower beyond that (first bench of r01: 152 s for 2 frames on 256 threads, '
+                            '8 s per frame on 8)',
             'sample': '%d synthetic %s frames x %d pts (BASELINE configs[0]), one SECOND fwd+bwd step (oracle C voxelizer + '
                       'sparse conv fwd/dgrad/wgrad with OpenMP, functional torch CPU for BEV/head/targets/loss), %.1f s' %
                       (args.cpu_frames, args.kind, args.points, dt)}
+
+
+def cpu_baseline_crb(cores, frames=48, picks=6):
+    """CRB half of the CPU baseline ("CRB stage-1 scoring ... plus stage-3 KDE greedy"), with the very
+    library calls the reference makes (oracle/crb_oracle.py: torch Categorical, sklearn KernelDensity, scipy entropy):
+    stage-1 RECORDS of `frames` synthetic frames (label entropy, per-box point density through the oracle's
+    points-in-boxes, per-class GT point statistics; crb_sampling.py:72-121 — the detector forward that produces the
+    boxes is NOT in this figure: its CPU cost is the SECOND leg's scale) and the first `picks` greedy picks of stage 3 over
+    K2*N = 300 candidates (crb_sampling.py:276-331), extrapolated to N = 100 picks with the last pick's time (the cost
+    per pick grows with the selected set, so this is a lower bound)."""
+    import oracle
+    from oracle import crb_oracle
+    from pcdet.datasets.synthetic import kitti_frame
+    rng = np.random.default_rng(0)
+    t0 = time.time()
+    dens, labs = [], []
+    for f in range(frames):
+        pts, gt = kitti_frame(5000 + f, 20000)
+        gt = gt[gt[:, 7] > 0]
+        # detections: the frame's objects, jittered (what a trained detector returns), labels kept
+        det = gt[:, :7] + rng.normal(0, 0.1, (len(gt), 7)).astype(np.float32) * np.array([1, 1, .3, .3, .3, .3, .2], np.float32)
+        lab = torch.from_numpy(gt[:, 7].astype(np.int64))
+        crb_oracle.label_entropy(lab, 3)
+        idx = oracle.points_in_boxes(pts[None, :, :3].astype(np.float32), det[None].astype(np.float32))[0]
+        cnt = np.bincount(idx[idx >= 0], minlength=len(det)).astype(np.float32)
+        dens.append(torch.from_numpy(cnt / (det[:, 3] * det[:, 4] * det[:, 5])))
+        labs.append(lab)
+        crb_oracle.gt_point_statistics(pts[:, :3], gt, 3)
+    t_rec = time.time() - t0
+    # stage 3 over 300 candidates (the frames above, cycled) — the reference's O(picks x candidates x classes) KDE loop
+    cand_d = [dens[i % frames] for i in range(300)]
+    cand_l = [labs[i % frames] for i in range(300)]
+    x_axis, prior = crb_oracle.build_prior(torch.cat(cand_d), torch.cat(cand_l), 3)
+    ts = []
+    for n_pick in (picks - 1, picks):
+        t0 = time.time()
+        crb_oracle.density_greedy(cand_d, cand_l, x_axis, prior, 3, n_pick)
+        ts.append(time.time() - t0)
+    per_pick = max(ts[1] - ts[0], 1e-9)
+    stage3_est = ts[1] + per_pick * (100 - picks)
+    return {'stage1_records_frames_per_s': round(frames / t_rec, 2), 'stage1_records_s_per_3000_frames': round(3000 * t_rec / frames, 1),
+            'stage3_s_first_%d_picks' % picks: round(ts[1], 2), 'stage3_s_per_pick_at_%d' % picks: round(per_pick, 3),
+            'stage3_s_100_picks_extrapolated': round(stage3_est, 1), 'cores': cores, 'kind': 'port',
+            'sample': '%d synthetic KITTI frames x 20000 pts: stage-1 records (entropy, box point density, GT point '
+                      'statistics; detector forward excluded) %.1f s; stage 3: %d of 100 greedy picks over 300 candidates '
+                      '%.1f s, extrapolated linearly with the last pick' % (frames, t_rec, picks, ts[1])}
 
 
 def _pctl(xs):
     xs = np.asarray(xs, dtype=np.float64)
     return {'median': round(float(np.median(xs)), 3), 'p10': round(float(np.percentile(xs, 10)), 3),
             'p90': round(float(np.percentile(xs, 90)), 3)}
+
+
+def _all_ranks(x, world, device):
+    """the value of every rank, in rank order (diagnostics of the first multi-GPU runs: which rank is slow)"""
+    if world == 1:
+        return [float(x)]
+    t = torch.tensor([float(x)], dtype=torch.float64, device='cpu' if dist.get_backend() == 'gloo' else device)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
 
 
 def _max_over_ranks(dt, world, device):
@@ -240,6 +300,8 @@ def crb_scoring_bench(args, rank, world, device):
                            build_synthetic_dataloader(pool, bs, workers=workers), rank, '/tmp', cfg)
     mine, per = scoring.shard_indices(n, rank, world)
 
+    rank_seconds = []
+
     def timed(fn):
         torch.cuda.synchronize()
         if world > 1:
@@ -247,9 +309,13 @@ def crb_scoring_bench(args, rank, world, device):
         t0 = time.perf_counter()
         out = fn()
         torch.cuda.synchronize()
+        mine_s = time.perf_counter() - t0                     # this rank alone, before it waits for the others
         if world > 1:
             dist.barrier()
-        return out, _max_over_ranks(time.perf_counter() - t0, world, device)
+        dt = _max_over_ranks(time.perf_counter() - t0, world, device)
+        rank_seconds.append([round(v, 4) for v in _all_ranks(mine_s, world, device)])
+        return out, dt
+    scoring.COLLECTIVE_LOG = []
 
     # warm-up on two batches (MIOpen solver search, allocator; two batches so that the loader's worker processes are forked
     # here, outside the timed pass)
@@ -278,6 +344,7 @@ def crb_scoring_bench(args, rank, world, device):
     strat.grad_embeddings_batched(mine[:bs], warm, strat.stage2_batch)          # MIOpen train-mode solver search
     _, dt_sel = timed(lambda: strat.select_from_records(rec))
     strat.close()
+    coll, scoring.COLLECTIVE_LOG = scoring.COLLECTIVE_LOG, None
     sel_round = {'stage2_s': round(strat.timings['stage2_s'], 3),
                  'stage2_grad_embeddings_s': round(strat.timings['stage2_embed_s'], 3),
                  'stage3_s': round(strat.timings['stage3_s'], 4), 'stages_2_3_s': round(dt_sel, 3),
@@ -297,6 +364,9 @@ def crb_scoring_bench(args, rank, world, device):
                                'note': 'one pass, frames generated + collated by the loader workers and uploaded inside '
                                        'the timed region'},
             'selection_round': sel_round,
+            'per_rank_seconds': {'loader_pass': rank_seconds[0], 'resident_passes': rank_seconds[1:1 + len(times)],
+                                 'note': 'each rank\'s own time for the pass (its scoring + the all-gather it waits in), before the closing barrier'},
+            'collectives': [dict(c, seconds=round(c['seconds'], 5)) for c in coll],
             'record_bytes_per_frame': 4 * strat.layout.stride, 'boxes_kept_total': int(rec[:, 1].sum().item())}
 
 
@@ -399,6 +469,8 @@ def main():
             opt.step()
         return loss
 
+    rank_step_ms = []          # per timed_steps call: every rank's median device time per step
+
     def timed_steps(optimizer, profile):
         """-> wall seconds for EXACTLY args.steps steps (barrier + synchronize on both sides, max over ranks) and the
         per-step device-timeline durations (events at the step boundaries on the compute stream, no host sync inside)"""
@@ -420,6 +492,7 @@ def main():
         dt = time.perf_counter() - t0
         sp.PROFILE = None
         per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+        rank_step_ms.append([round(v, 3) for v in _all_ranks(float(np.median(per_step)), world, device)])
         return _max_over_ranks(dt, world, device), per_step, loss
 
     for i in range(args.warmup):
@@ -458,6 +531,7 @@ def main():
                    'parallelism': 'dp%d' % world, 'optimizer': 'grad-clip + fused AdamW in the timed region',
                    'final_loss': round(float(loss.item()), 4)},
         'ms_per_step_device': _pctl(per_step),
+        'ms_per_step_device_per_rank': rank_step_ms[0],
         'fwd_bwd_only': {'value': round(frames / dt_nopt, 3), 'unit': 'frames/s',
                          'ms_per_step': round(1e3 * dt_nopt / args.steps, 3), 'ms_per_step_device': _pctl(per_step_nopt),
                          'note': 'same %d steps without grad-clip / optimizer' % args.steps},

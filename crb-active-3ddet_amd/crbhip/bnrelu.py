@@ -32,15 +32,25 @@ class frame_groups(object):
         return False
 
     def note_rows(self, t, offsets):
-        """rows of tensor t belong to the frames by these G+1 host offsets (not G equal parts)"""
+        """rows of tensor t belong to the frames by these G+1 host offsets (not G equal parts). Keyed on the tensor OBJECT
+        (weak reference): the caching allocator hands a freed tensor's address to later ones, an address key would let an
+        unrelated tensor with the same row count inherit stale frame boundaries"""
         if offsets is not None:
+            import weakref
             assert len(offsets) == self.G + 1 and offsets[-1] == t.shape[0], (len(offsets), offsets[-1], t.shape)
-            self.ragged[t.data_ptr()] = [int(v) for v in offsets]
+            if len(self.ragged) > 64:                       # drop entries whose tensor is gone
+                self.ragged = {k: v for k, v in self.ragged.items() if v[0]() is not None}
+            self.ragged[id(t)] = (weakref.ref(t), [int(v) for v in offsets])
+
+    def noted(self, t):
+        """the ragged offsets noted for exactly this tensor object, or None"""
+        e = self.ragged.get(id(t))
+        return e[1] if (e is not None and e[0]() is t and e[1][-1] == t.shape[0]) else None
 
     def offsets(self, t, n_units=None):
         """row ranges of t per frame; n_units: t has this many equal units per row block (rows = units * k)"""
-        r = self.ragged.get(t.data_ptr())
-        if r is not None and r[-1] == t.shape[0]:             # (the allocator may hand a noted tensor's address to a later one)
+        r = self.noted(t)
+        if r is not None:
             return r
         n = t.shape[0]
         if n % self.G:

@@ -534,7 +534,10 @@ extern "C" int crb_bn_relu_max_backward(const float* x, const float* gz, int64_t
 // of a frame, C) = partials of every frame + 4 C statistics per frame.
 extern "C" int64_t crb_bn_frames_workspace_bytes(int n_frames, int64_t max_rows_per_frame, int C) {
   const int64_t f = n_frames < 1 ? 1 : (n_frames > BN_MAXF ? BN_MAXF : n_frames);     // more frames run in chunks of BN_MAXF
-  return f * crb_bn_workspace_bytes(max_rows_per_frame, C) + crb_align_up(f * 4 * C * (int64_t)sizeof(float), 256);
+  // bn_blocks(n) is not monotonic above 131072 rows (1024 blocks at 131072, 1017 at 131073): a batch that mixes frames just
+  // under and just over needs the larger count for each -> size every frame for the maximum any row count <= max can take
+  const int64_t blocks = max_rows_per_frame > 131072 ? 1024 : bn_blocks(max_rows_per_frame < 1 ? 1 : max_rows_per_frame);
+  return f * (blocks * 2 * C * 4 + 256) + crb_align_up(f * 4 * C * (int64_t)sizeof(float), 256);
 }
 
 // statistics of up to BN_MAXF frames: partial sums, finalize, running update. stats (n_frames, 4, C) at the workspace head.

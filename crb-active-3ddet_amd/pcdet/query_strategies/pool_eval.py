@@ -64,7 +64,17 @@ class PoolEvalStrategy(Strategy):
         gathered with them and recorded for EVERY pool frame on every rank (save_points of the reference's loops)"""
         rank, world = self._world()
         gts = getattr(self, '_local_gt_stats', None)
-        if gts is not None and gts.shape[0] == local_rows.shape[0]:
+        widen = gts is not None and gts.shape[0] == local_rows.shape[0]
+        if world > 1:
+            # the row width of the collective must be the same on every rank: widen only if EVERY rank collected the
+            # statistics of all of its frames (a rank whose frames carry no gt_boxes would otherwise send narrower rows
+            # and the all-gather would hang or corrupt)
+            import torch.distributed as dist
+            flag = torch.tensor([1 if widen else 0], dtype=torch.int32,
+                                device=local_rows.device if dist.get_backend() != 'gloo' else 'cpu')
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            widen = bool(int(flag.item()))
+        if widen:
             both = scoring.all_gather_rows(torch.cat([local_rows.float(), gts.float()], 1).contiguous(), n, world)
             self._local_gt_stats = None
             w = local_rows.shape[1]

@@ -95,12 +95,24 @@ def shard_indices(n, rank, world):
     return idx[rank:total:world], per
 
 
+# diagnostics of the collectives of one process: every all_gather_rows call appends (rows per rank, bytes per rank, seconds
+# from "this rank's rows are ready" to "gathered rows are here" — i.e. wait for the slowest rank + the transfer). The timing
+# synchronises the device; it is switched on by bench.py / tests only (COLLECTIVE_LOG = []), never in the product path.
+COLLECTIVE_LOG = None
+
+
 def all_gather_rows(local, n_total, world, backend_device=None):
     """local (per, S) rows of this rank (rank-strided shard) -> (n_total, S) rows in dataset order, on every rank.
     One all_gather_into_tensor (RCCL over xGMI on the GPU node; gloo in the CPU tests)."""
     if world == 1:
         return local[:n_total]
     per = local.shape[0]
+    log = COLLECTIVE_LOG
+    if log is not None:
+        import time
+        if local.is_cuda:
+            torch.cuda.synchronize(local.device)
+        t0 = time.perf_counter()
     gathered = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     if local.is_cuda and dist.get_backend() == 'gloo':       # gloo dry runs on GPU tensors: gather through the host
         g = torch.empty(gathered.shape, dtype=local.dtype)
@@ -108,6 +120,11 @@ def all_gather_rows(local, n_total, world, backend_device=None):
         gathered.copy_(g)
     else:
         dist.all_gather_into_tensor(gathered, local.contiguous())
+    if log is not None:
+        if local.is_cuda:
+            torch.cuda.synchronize(local.device)
+        log.append({'rows_per_rank': per, 'bytes_per_rank': local.numel() * local.element_size(),
+                    'seconds': time.perf_counter() - t0, 'backend': dist.get_backend()})
     # gathered[r*per + k] = global index k*world + r  -> interleave back and drop the wrap-around padding
     out = gathered.view(world, per, *local.shape[1:]).transpose(0, 1).reshape(world * per, *local.shape[1:])
     return out[:n_total]

@@ -49,8 +49,7 @@ class per_frame_batchnorm(object):
         for m in self.model.modules():
             if isinstance(m, nn.BatchNorm1d) and m.training:
                 def fwd(x, _m=m):
-                    r = groups.ragged.get(x.data_ptr())
-                    return frame_batch_norm_1d(x, _m, G, r if (r is not None and r[-1] == x.shape[0]) else None)
+                    return frame_batch_norm_1d(x, _m, G, groups.noted(x))
                 self.patched.append(m)
                 m.forward = fwd
             elif isinstance(m, nn.BatchNorm2d) and m.training:

@@ -132,3 +132,40 @@ def test_ddp_second_step_two_ranks_averages_gradients(tmp_path):
     assert torch.equal(g0, g1)                                               # the all-reduce left identical gradients
     rel = float((g0 - ref).norm() / ref.norm())
     assert rel < 2e-3, rel              # = mean of the two single-rank gradients (MIOpen weight-gradient kernels use atomics)
+
+
+def test_bench_two_rank_dry_run_prints_the_contract_line(tmp_path):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per process, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* from the environment), except that both ranks share the one device of this box and the process
+    group is gloo (CRB_DIST_BACKEND; RCCL needs one GPU per rank): DDP training steps, the rank-strided scoring shard, the
+    records all-gather and the stage-2 embedding all-gather all execute, rank 0 prints ONE JSON line with the whole-job
+    numbers and the per-rank diagnostics the first real SCALE run will need."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CRB_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    pool = 64
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29541', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--scoring-pool', str(pool), '--scoring-repeats', '1', '--pvrcnn-steps', '0', '--bf16x3-steps', '0',
+           '--no-cpu-baseline']
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak' and d['higher_is_better']
+    assert d['config']['global_batch'] == 32 and d['config']['parallelism'] == 'dp2'
+    assert abs(d['value'] - 32 * 2 / (d['ms_per_step'] * 2 / 1e3)) < 1e-2 * d['value']
+    assert len(d['ms_per_step_device_per_rank']) == 2 and all(v > 0 for v in d['ms_per_step_device_per_rank'])
+    sc = d['crb_scoring']
+    assert sc['config']['frames_per_gpu'] == pool // 2 and sc['config']['pool_frames'] == pool and sc['config']['n_gpus'] == 2
+    assert len(sc['per_rank_seconds']['loader_pass']) == 2
+    coll = sc['collectives']
+    strides = {c['bytes_per_rank'] // c['rows_per_rank'] for c in coll}
+    assert len(coll) >= 3 and all(c['backend'] == 'gloo' for c in coll)
+    assert sc['record_bytes_per_frame'] in strides                      # the stage-1 records all-gather
+    assert 4 * 65536 in strides                                         # the stage-2 (256 x 256) embedding all-gather
+    assert d['cpu_baseline'] is None and d['vs_baseline'] is None
