@@ -180,7 +180,8 @@ def cpu_baseline(args):
     from oracle.second_cpu import second_step_cpu
     # bounded sample: a few frames on at most 32 host threads (256-thread runs of this small problem are slower:
     # the first bench run took 152 s for 2 frames on 256 threads vs 8 s/frame on 8)
-    cores = min(os.cpu_count() or 1, 32)
+    from pcdet.utils.common_utils import effective_cpu_count
+    cores = min(effective_cpu_count(), 32)               # cgroup quota / affinity aware (the GPU pod: 16 of 256 threads)
     torch.set_num_threads(cores)
     os.environ['OMP_NUM_THREADS'] = str(cores)
     try:
@@ -295,7 +296,12 @@ def crb_scoring_bench(args, rank, world, device):
     pool = SyntheticDataset(num_frames=n, first_frame=5000, n_points=args.points, training=False)
     lab = SyntheticDataset(num_frames=2, n_points=args.points)
     model = build_network(cfg.MODEL, 3, pool).to(device)
-    workers = max(2, min(48, (os.cpu_count() or 8) // max(world, 1) - 2))
+    from pcdet.utils.common_utils import effective_cpu_count
+    # loader workers: the CPUs this process may use (cgroup quota / affinity, not os.cpu_count()), shared by the ranks, two
+    # left for the process that feeds the GPU
+    workers = max(2, min(48, effective_cpu_count() // max(world, 1) - 2))
+    host_threads = torch.get_num_threads()
+    torch.set_num_threads(2)                              # the main process: collate / pinned copies only, the workers get the cores
     strat = build_strategy('crb', model, build_synthetic_dataloader(lab, 2),
                            build_synthetic_dataloader(pool, bs, workers=workers), rank, '/tmp', cfg)
     mine, per = scoring.shard_indices(n, rank, world)
@@ -344,6 +350,7 @@ def crb_scoring_bench(args, rank, world, device):
     strat.grad_embeddings_batched(mine[:bs], warm, strat.stage2_batch)          # MIOpen train-mode solver search
     _, dt_sel = timed(lambda: strat.select_from_records(rec))
     strat.close()
+    torch.set_num_threads(host_threads)
     coll, scoring.COLLECTIVE_LOG = scoring.COLLECTIVE_LOG, None
     sel_round = {'stage2_s': round(strat.timings['stage2_s'], 3),
                  'stage2_grad_embeddings_s': round(strat.timings['stage2_embed_s'], 3),
@@ -426,6 +433,10 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
+    from pcdet.utils.common_utils import effective_cpu_count
+    # torch sizes its intra-op pool by os.cpu_count() (128 threads on the 256-thread host) although the pod may use 16 cores:
+    # every host-side copy / concat then spins 128 threads on 16 cores, next to the loader workers
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), effective_cpu_count() // max(world, 1))))
     ndev = torch.cuda.device_count()
     dev_idx = local_rank % ndev          # one process per GPU; the modulo only matters for the single-GPU gloo dry run
     torch.cuda.set_device(dev_idx)

@@ -74,12 +74,79 @@ class CRBSampling(Strategy):
         return torch.cat(rows, 0)
 
     def upload_pool_batches(self, frame_indices, batch_size):
-        """host batches of the given pool frames (read ahead by the loader's workers) -> device batches, one at a time"""
+        """host batches of the given pool frames (read ahead by the loader's workers) -> device batches, one at a time.
+        A batch is staged in pinned host memory and copied on a side stream while the consumer is still enqueueing /
+        running the previous batch (one batch ahead): the upload neither blocks the Python thread (a pageable `.cuda()`
+        does) nor sits in the compute stream."""
+        dev = next(self.detector.parameters()).device
+        if dev.type != 'cuda':
+            for batch in self.iter_pool_batches(frame_indices, batch_size):
+                batch['point_frame_counts_host'] = np.diff(batch['point_frame_offsets']).tolist()
+                load_data_to_gpu(batch)
+                batch['point_frame_offsets'] = batch['point_frame_offsets'].int()
+                yield batch
+            return
+        side = getattr(self, '_upload_stream', None)
+        if side is None or side.device != dev:
+            side = self._upload_stream = torch.cuda.Stream(device=dev)
+        staged = None
         for batch in self.iter_pool_batches(frame_indices, batch_size):
-            batch['point_frame_counts_host'] = np.diff(batch['point_frame_offsets']).tolist()
-            load_data_to_gpu(batch)
-            batch['point_frame_offsets'] = batch['point_frame_offsets'].int()
-            yield batch
+            nxt = self._stage_batch(self._pin_batch(batch), dev, side)
+            self._pin_ring['events'][nxt[2]['_pin_slot']] = nxt[1]
+            if staged is not None:
+                yield self._finish_staged(staged, dev)
+            staged = nxt
+        if staged is not None:
+            yield self._finish_staged(staged, dev)
+
+    def _pin_batch(self, batch):
+        """numpy batch -> same keys, arrays copied into pinned host buffers of the dtypes the device path wants. The pinned
+        buffers are a ring of 3 slots per key, grown on demand and reused (a fresh pinned allocation per batch costs tens
+        of milliseconds of page pinning); a slot is reused only after the copy that read it has completed."""
+        from ..models import _HOST_ONLY_KEYS, _INT_KEYS
+        ring = getattr(self, '_pin_ring', None)
+        if ring is None:
+            ring = self._pin_ring = {'slot': 0, 'bufs': [dict(), dict(), dict()], 'events': [None, None, None]}
+        k = ring['slot']
+        ring['slot'] = (k + 1) % 3
+        if ring['events'][k] is not None:
+            ring['events'][k].synchronize()                              # the H2D copies out of this slot are done
+        out = {'point_frame_counts_host': np.diff(batch['point_frame_offsets']).tolist(), '_pin_slot': k}
+        for key, val in batch.items():
+            if isinstance(val, np.ndarray) and key not in _HOST_ONLY_KEYS:
+                dt = torch.int32 if (key in _INT_KEYS or key == 'point_frame_offsets') else torch.float32
+                buf = ring['bufs'][k].get(key)
+                if buf is None or buf.dtype != dt or buf.numel() < val.size:
+                    buf = ring['bufs'][k][key] = torch.empty((max(val.size, 1) * 5 // 4,), dtype=dt, pin_memory=True)
+                host = buf[:val.size].view(val.shape)
+                host.copy_(torch.from_numpy(val))
+                out[key] = host
+            else:
+                out[key] = val
+        return out
+
+    @staticmethod
+    def _stage_batch(pinned, dev, side):
+        """pinned host batch -> device tensors, copies issued on `side`"""
+        out = {}
+        with torch.cuda.stream(side):
+            for key, val in pinned.items():
+                if key == '_pin_slot':
+                    continue
+                out[key] = val.to(dev, non_blocking=True) if (torch.is_tensor(val) and not val.is_cuda) else val
+            done = torch.cuda.Event()
+            done.record(side)
+        return out, done, pinned, side
+
+    @staticmethod
+    def _finish_staged(staged, dev):
+        out, done, pinned, side = staged
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_event(done)
+        for v in out.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(cur)
+        return out
 
     def score_pool(self, frame_indices, batch_size):
         """-> (len(frame_indices), layout.stride) device tensor of per-frame records; the GT point statistics the caller

@@ -17,6 +17,62 @@ class _ListBatchSampler:
         return len(self.batches)
 
 
+def _single_threaded_worker(worker_id):
+    """loader workers are the parallelism: one BLAS / OpenMP thread each (numpy's BLAS otherwise starts a thread per core in
+    every worker — 48 workers on a 256-thread host ran 2.3x slower per frame than one worker alone)"""
+    import torch
+    torch.set_num_threads(1)
+    try:
+        from threadpoolctl import threadpool_limits
+        global _BLAS_LIMIT
+        _BLAS_LIMIT = threadpool_limits(limits=1)               # kept referenced for the life of the worker
+    except Exception:
+        pass
+
+
+def merge_collated(parts):
+    """collated sub-batches (DatasetTemplate.collate_batch layout, consecutive frames) -> the batch collate_batch would have
+    produced for all their frames at once"""
+    import numpy as np
+    if len(parts) == 1:
+        return parts[0]
+    out, base = {}, 0
+    keys = parts[0].keys()
+    sizes = [p['batch_size'] for p in parts]
+    for key in keys:
+        vals = [p[key] for p in parts]
+        if key == 'batch_size':
+            out[key] = int(sum(sizes))
+        elif key in ('points', 'voxel_coords'):
+            shifted, base = [], 0
+            for v, b in zip(vals, sizes):
+                v = v.copy() if base else v
+                if base:
+                    v[:, 0] += base
+                shifted.append(v)
+                base += b
+            out[key] = np.concatenate(shifted, axis=0)
+        elif key == 'point_frame_offsets':
+            offs, base = [vals[0]], int(vals[0][-1])
+            for v in vals[1:]:
+                offs.append(v[1:] + base)
+                base += int(v[-1])
+            out[key] = np.concatenate(offs).astype(np.int32)
+        elif key == 'gt_boxes':
+            mx = max(v.shape[1] for v in vals)
+            g = np.zeros((sum(sizes), mx, vals[0].shape[-1]), dtype=np.float32)
+            r = 0
+            for v in vals:
+                g[r:r + v.shape[0], :v.shape[1]] = v
+                r += v.shape[0]
+            out[key] = g
+        elif isinstance(vals[0], np.ndarray):
+            out[key] = np.concatenate(vals, axis=0)
+        else:
+            out[key] = vals[0]
+    return out
+
+
 class Strategy:
     def __init__(self, model, labelled_loader, unlabelled_loader, rank, active_label_dir, cfg):
         self.cfg = cfg
@@ -37,12 +93,17 @@ class Strategy:
         else:
             self.pairs = list(zip(ds.frame_ids, ds.infos))
 
+    POOL_SUB_BATCH = 2        # frames per loader work item
+
     def iter_pool_batches(self, frame_indices, batch_size):
         """host batches (collated like the loader's) of the given pool frames, in order. Frames are read and collated by as
         many DataLoader workers as the caller gave `unlabelled_loader` (the reference iterates that loader itself,
         crb_sampling.py:72-80), so reading / decoding the next frames overlaps the GPU work on the current ones; with
-        num_workers == 0 the frames are read inline. The worker processes are started once per strategy and reused by every
-        call (stage 1, stage 2, ...): forking them costs 2-3 s each time."""
+        num_workers == 0 the frames are read inline. A work item is a SUB-batch of POOL_SUB_BATCH frames, merged here: with
+        whole batches as work items every worker starts on a batch of its own and the first one is complete only after a
+        worker has read 16 frames alone (1.3 s of an idle GPU at the start of every pass on the synthetic pool), with
+        single frames the per-item cost of the result queue dominates. The worker processes are started once per strategy
+        and reused by every call (stage 1, stage 2, ...): forking them costs 2-3 s each time."""
         ds = self.unlabelled_set
         frame_indices = list(frame_indices)
         workers = int(getattr(self.unlabelled_loader, 'num_workers', 0) or 0)
@@ -50,14 +111,22 @@ class Strategy:
             workers = 0                     # a host-voxelising dataset calls the HIP voxelizer: not from forked workers
         batches = [frame_indices[s:s + batch_size] for s in range(0, len(frame_indices), batch_size)]
         if workers > 0 and len(batches) > 1:
+            sub = max(1, min(self.POOL_SUB_BATCH, batch_size))
+            items, per_batch = [], []
+            for chunk in batches:
+                parts = [chunk[s:s + sub] for s in range(0, len(chunk), sub)]
+                items += parts
+                per_batch.append(len(parts))
             if getattr(self, '_pool_loader', None) is None:
                 from torch.utils.data import DataLoader
                 self._pool_batches = _ListBatchSampler()
                 self._pool_loader = DataLoader(ds, batch_sampler=self._pool_batches, num_workers=workers,
-                                               collate_fn=ds.collate_batch, pin_memory=False, prefetch_factor=2,
-                                               persistent_workers=True)
-            self._pool_batches.batches = batches
-            yield from self._pool_loader
+                                               collate_fn=ds.collate_batch, pin_memory=False, prefetch_factor=4,
+                                               persistent_workers=True, worker_init_fn=_single_threaded_worker)
+            self._pool_batches.batches = items
+            it = iter(self._pool_loader)
+            for k in per_batch:
+                yield merge_collated([next(it) for _ in range(k)])
             return
         for chunk in batches:
             yield ds.collate_batch([ds[i] for i in chunk])

@@ -32,6 +32,35 @@ def rotate_points_along_z(points, angle):
     return out.numpy() if is_numpy else out
 
 
+def effective_cpu_count():
+    """CPUs this process may actually use: the smallest of os.cpu_count(), the scheduler affinity mask and the cgroup CPU
+    quota (a container on a 256-thread host with cpu.max = 16 cores gets 16: sizing worker pools by os.cpu_count() there
+    makes 48 workers fight over 16 cores and starves the process that feeds the GPU)"""
+    import math
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:                       # cgroup v2: "<quota> <period>" or "max <period>"
+            q, p = f.read().split()[:2]
+        if q != 'max':
+            n = min(n, max(1, int(math.floor(int(q) / int(p)))))
+    except (OSError, ValueError):
+        try:                                                            # cgroup v1
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:
+                q = int(f.read())
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                p = int(f.read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def mask_points_by_range(points, limit_range):
     return (points[:, 0] >= limit_range[0]) & (points[:, 0] <= limit_range[3]) & \
            (points[:, 1] >= limit_range[1]) & (points[:, 1] <= limit_range[4])
@@ -40,7 +69,7 @@ def mask_points_by_range(points, limit_range):
 def get_voxel_centers(voxel_coords, downsample_times, voxel_size, point_cloud_range):
     """voxel_coords (N,3) [z,y,x] -> centers (N,3) xyz (common_utils.py:63-80)"""
     assert voxel_coords.shape[1] == 3
-    centers = voxel_coords[:, [2, 1, 0]].float()
+    centers = voxel_coords.flip(1).float()          # (a python index list would be uploaded per call: a host sync)
     vs = device_constant(voxel_size, centers.device) * downsample_times
     pc_min = device_constant(point_cloud_range[0:3], centers.device)
     return (centers + 0.5) * vs + pc_min
