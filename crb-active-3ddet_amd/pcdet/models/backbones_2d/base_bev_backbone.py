@@ -12,6 +12,28 @@ from ...utils.linear_rows import LinearRows, rows_view, rows_to_nchw
 
 ROWS_TRAIN = True      # BatchNorm2d+ReLU pairs through the fused row kernels when the activations are channels_last
 ROWS_GEMM = True       # kernel-1 stride-1 up-sampling branch (ConvTranspose2d 1x1) as a row GEMM on the channels_last map
+# OPT-IN (CRB_WINOGRAD=1 or set the flag): the stride-1 3x3 convolutions (10 of the 12 of the KITTI / Waymo configs) as
+# hand-written F(2x2,3x3) Winograd on the f32 MFMA (crbhip.winograd) instead of MIOpen's implicit GEMM: forward (in eval with
+# BatchNorm folded into the transformed weights and bias + ReLU in the kernel's epilogue: one launch per layer) and input
+# gradient; the weight gradient stays on MIOpen. Results equal the direct convolution up to f32 rounding of the transforms
+# (4e-7 of the output scale against an f64 convolution; MIOpen's own error there is 1.2e-6). MIOpen stays the default.
+WINOGRAD = __import__('os').environ.get('CRB_WINOGRAD', '0') == '1'
+
+
+def _wino_fold(w, shift):
+    """fold_conv_bn transform: folded conv weight (Cout,Cin,3,3) -> U (16,Cin,Cout) of the Winograd kernel, bias"""
+    from crbhip import winograd
+    return winograd.weights_forward(w), shift.contiguous()
+
+
+def _wino_ok(conv, x, pad=None):
+    if not WINOGRAD or not isinstance(conv, nn.Conv2d) or not x.is_cuda or x.dtype != torch.float32:
+        return False
+    from crbhip import winograd
+    p = tuple(conv.padding) if pad is None else tuple(pad)
+    return conv.kernel_size == (3, 3) and conv.stride == (1, 1) and p == (1, 1) and conv.dilation == (1, 1) and \
+        conv.groups == 1 and conv.padding_mode == 'zeros' and winograd.supported(conv.in_channels, conv.out_channels) and \
+        x.is_contiguous(memory_format=torch.channels_last)
 
 
 def _bn(c):
@@ -72,6 +94,12 @@ class BaseBEVBackbone(nn.Module):
             if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
                 bn = mods[i + 1]
                 relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                if _wino_ok(m, x, pad):
+                    from crbhip import winograd
+                    U, shift = fold_conv_bn(m, bn, _wino_fold)
+                    x = winograd.conv3x3_U(x, U, shift, relu)
+                    i += 3 if relu else 2
+                    continue
                 rows_ok = x.is_cuda and x.is_contiguous(memory_format=torch.channels_last) and m.bias is None
                 if rows_ok:
                     y = m(x) if pad is None else torch.nn.functional.conv2d(x, m.weight, None, m.stride, pad, m.dilation,
@@ -125,6 +153,11 @@ class BaseBEVBackbone(nn.Module):
             y, used = BaseBEVBackbone._pad_conv(mods, i, x)
             if used:
                 x, i = y, i + used
+                continue
+            if _wino_ok(m, x):
+                from crbhip import winograd
+                x = winograd.conv3x3(x, m.weight, m.bias)
+                i += 1
                 continue
             if isinstance(m, nn.BatchNorm2d) and isinstance(nxt, nn.ReLU) and \
                     x.is_contiguous(memory_format=torch.channels_last) and \

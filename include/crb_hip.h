@@ -460,6 +460,21 @@ int crb_assign_targets(const float* anchors, const int32_t* anchor_cls, int A, c
                        const float* unmatched_thr, int32_t* labels, float* reg_targets, float* reg_weights,
                        void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * a7 (stretch)  3x3 stride-1 pad-1 convolution on channels_last maps as Winograd F(2x2,3x3) on the f32 MFMA
+ * replaces: torch.nn.Conv2d(C, C, 3, padding=1) of the BEV backbone (pcdet/models/backbones_2d/base_bev_backbone.py:24-41;
+ *           cuDNN in the reference, MIOpen's f32 implicit GEMM here) for the stride-1 layers whose channel counts pass
+ *           crb_winograd_supported (Cin % 32 == 0, Cout % 128 == 0). OPT-IN on the Python side: results differ from a direct
+ *           convolution by f32 rounding of the transforms (<= 1e-5 of the output scale on unit-scale data, tested).
+ * x (N,H,W,Cin) f32 NHWC, y (N,H,W,Cout); weights first through crb_winograd_weights: g (3,3,Cin,Cout) [ky][kx][ci][co]
+ * -> U (16,Cin,Cout) (crb_winograd_weights_bytes). The input gradient of the same layer is the same call on dy with
+ * g'[ky][kx][co][ci] = w[co][ci][2-ky][2-kx]. bias (Cout) or NULL, relu 0/1: epilogue on the output. */
+int crb_winograd_supported(int cin, int cout);
+int64_t crb_winograd_weights_bytes(int cin, int cout);
+int crb_winograd_weights(const float* g, float* U, int cin, int cout, void* stream);
+int crb_conv3x3_winograd_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
+                              const float* bias, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,8 @@ extern "C" {
 /* A/B of the sort key of crb_mask_sort_chunks: 2 (default) = mask bits re-ranked by frequency inside the chunk, 1 = by the
  * geometry of a 3x3x3 kernel (corners, edges, faces, centre), 0 = numeric mask order */
 int crb_mask_sort_set_rank_bits(int mode);
+/* measurement builds of the Winograd convolution (wrong results): 1 = no MFMAs, 2 = no staging of the next chunk */
+int crb_winograd_set_mode(int mode);
 /* measurement builds of crb_tables_finish's chunk pass (wrong tables by design): bit 0 = no sort, bit 1 = no packed-index fill,
  * bit 2 = no pair lists */
 int crb_tables_set_skip(int bits);
