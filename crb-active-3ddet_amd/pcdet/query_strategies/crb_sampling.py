@@ -66,49 +66,102 @@ class CRBSampling(Strategy):
             batch = dict(batch)
             if getattr(model, 'pfe', None) is not None and hasattr(model.pfe, 'prefetch_keypoints'):
                 model.pfe.prefetch_keypoints(batch)          # FPS on a side stream, as PVRCNN.forward does
+            valid = batch.pop('_valid_frames', None)
             for mod in _chain(model):
                 batch = mod(batch)
-            rows.append(scoring.pack_records(crb_frame_records(model, batch), self.layout))
+            rec = scoring.pack_records(crb_frame_records(model, batch), self.layout)
+            rows.append(rec if valid is None else rec[:valid])          # a padded tail batch: its repeats are dropped
         if not rows:
             return torch.zeros((0, self.layout.stride), dtype=torch.float32, device=next(model.parameters()).device)
         return torch.cat(rows, 0)
 
+    PAD_TAIL_BATCH = True
+
     def upload_pool_batches(self, frame_indices, batch_size):
         """host batches of the given pool frames (read ahead by the loader's workers) -> device batches, one at a time.
+        A short last batch is padded to `batch_size` with repeats of its last frame and marked '_valid_frames' (consumers drop
+        the repeats): a new batch size is a new problem for every dense layer and MIOpen's solver search for it costs seconds
+        the first time a process meets it (11.6 s instead of 5.8 s for the 3,000-frame pool = 187 batches of 16 + one of 8).
         A batch is staged in pinned host memory and copied on a side stream while the consumer is still enqueueing /
         running the previous batch (one batch ahead): the upload neither blocks the Python thread (a pageable `.cuda()`
         does) nor sits in the compute stream."""
         dev = next(self.detector.parameters()).device
+        frame_indices = list(frame_indices)
+        n_valid_tail = len(frame_indices) % batch_size
+        if self.PAD_TAIL_BATCH and n_valid_tail and len(frame_indices) > batch_size:
+            frame_indices = frame_indices + [frame_indices[-1]] * (batch_size - n_valid_tail)
+        else:
+            n_valid_tail = 0
+        n_batches = (len(frame_indices) + batch_size - 1) // batch_size
         if dev.type != 'cuda':
-            for batch in self.iter_pool_batches(frame_indices, batch_size):
+            for k, batch in enumerate(self.iter_pool_batches(frame_indices, batch_size)):
                 batch['point_frame_counts_host'] = np.diff(batch['point_frame_offsets']).tolist()
                 load_data_to_gpu(batch)
                 batch['point_frame_offsets'] = batch['point_frame_offsets'].int()
+                if n_valid_tail and k == n_batches - 1:
+                    batch['_valid_frames'] = n_valid_tail
                 yield batch
             return
         side = getattr(self, '_upload_stream', None)
         if side is None or side.device != dev:
             side = self._upload_stream = torch.cuda.Stream(device=dev)
-        staged = None
-        for batch in self.iter_pool_batches(frame_indices, batch_size):
-            nxt = self._stage_batch(self._pin_batch(batch), dev, side)
-            self._pin_ring['events'][nxt[2]['_pin_slot']] = nxt[1]
+        # host side of the pipeline on its own thread: receive the workers' sub-batches, merge them and copy into pinned
+        # memory (memcpy-bound work that releases the GIL) while the main thread issues the H2D copies and the 13 ms of kernel
+        # launches of a 16-frame pass — on a busy host the serial version let the GPU run dry (254 instead of 535 frames/s)
+        import queue
+        import threading
+        q = queue.Queue(maxsize=2)
+        stop = threading.Event()
+
+        def producer():
+            try:
+                for batch in self.iter_pool_batches(frame_indices, batch_size):
+                    item = self._pin_batch(batch)
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.05)
+                            break
+                        except queue.Full:
+                            continue
+                    if stop.is_set():
+                        return
+                q.put(None)
+            except BaseException as e:                                  # surfaced in the consumer
+                q.put(e)
+        th = threading.Thread(target=producer, name='crb-pool-upload', daemon=True)
+        th.start()
+        try:
+            staged, k = None, 0
+            while True:
+                item = q.get()
+                if isinstance(item, BaseException):
+                    raise item
+                if item is None:
+                    break
+                nxt = self._stage_batch(item, dev, side)
+                self._pin_ring['events'][item['_pin_slot']] = nxt[1]
+                if n_valid_tail and k == n_batches - 1:
+                    nxt[0]['_valid_frames'] = n_valid_tail
+                k += 1
+                if staged is not None:
+                    yield self._finish_staged(staged, dev)
+                staged = nxt
             if staged is not None:
                 yield self._finish_staged(staged, dev)
-            staged = nxt
-        if staged is not None:
-            yield self._finish_staged(staged, dev)
+        finally:
+            stop.set()
+            th.join(timeout=5)
 
     def _pin_batch(self, batch):
         """numpy batch -> same keys, arrays copied into pinned host buffers of the dtypes the device path wants. The pinned
-        buffers are a ring of 3 slots per key, grown on demand and reused (a fresh pinned allocation per batch costs tens
+        buffers are a ring of 6 slots per key, grown on demand and reused (a fresh pinned allocation per batch costs tens
         of milliseconds of page pinning); a slot is reused only after the copy that read it has completed."""
         from ..models import _HOST_ONLY_KEYS, _INT_KEYS
         ring = getattr(self, '_pin_ring', None)
         if ring is None:
-            ring = self._pin_ring = {'slot': 0, 'bufs': [dict(), dict(), dict()], 'events': [None, None, None]}
+            ring = self._pin_ring = {'slot': 0, 'bufs': [dict() for _ in range(6)], 'events': [None] * 6}
         k = ring['slot']
-        ring['slot'] = (k + 1) % 3
+        ring['slot'] = (k + 1) % 6
         if ring['events'][k] is not None:
             ring['events'][k].synchronize()                              # the H2D copies out of this slot are done
         out = {'point_frame_counts_host': np.diff(batch['point_frame_offsets']).tolist(), '_pin_slot': k}
