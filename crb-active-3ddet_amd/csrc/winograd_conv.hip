@@ -8,12 +8,16 @@
 //   M[xi] = V[xi] U[xi]      16 independent (tiles x Cin) x (Cin x Cout) products on v_mfma_f32_32x32x2_f32
 //   Y     = A^T M A          per tile and output channel, in registers on the accumulators
 //
-// One workgroup = 32 consecutive 2x2-output tiles (raster order over the batch) x 128 output channels; each of its 4 waves
-// owns 32 output channels for ALL 16 xi — 16 accumulators of 32x32 = 256 accumulator registers, one wave per SIMD — so the
-// output transform needs no exchange: a lane holds the same (tile, channel) element of all 16 M[xi]. Cin is walked in chunks
-// of 32 channels: the 4x4 patches of the next chunk are fetched while the current chunk's 256 MFMAs per wave run, transformed
-// and written to the other half of the LDS double buffer between the chunks; U is read straight from L2 (1 MB at 128x128),
-// one dword per lane and MFMA, prefetched one k-step ahead. Optional epilogue on the output: + bias, ReLU.
+// One workgroup = 64 consecutive 2x2-output tiles (raster order over the batch) x 64 output channels; its 4 waves form a
+// 2 x 2 grid (32 tiles x 32 channels each) and every wave keeps ALL 16 xi of its block — 16 accumulators of 32x32 = 256
+// accumulator registers, one wave per SIMD — so the output transform needs no exchange: a lane holds the same (tile, channel)
+// element of all 16 M[xi]. Cin is walked in chunks of CC = 8 channels, double-buffered in LDS (V 32 KB + U 32 KB per buffer):
+// while the current chunk's MFMAs run, waves 0,1 have the next chunk's 4x4 patches in flight (a lane pair covers a tile: the
+// low lane bit selects the channel quad, 16-byte loads from clamped addresses, out-of-map elements zeroed by a select) and
+// waves 2,3 the next chunk's U rows; the staged values are transformed / stored after the MFMA block, then one barrier.
+// (Measured variants: U straight from L2 per MFMA 4.5 ms, per-wave role branches around the MFMA block 4.8 ms (spills), every
+// wave transforming patches 1.58 ms; this layout 1.125 ms per 128->128 @ 16x200x176 call — DESIGN §6.)
+// Optional epilogue on the output: + bias, ReLU.
 #include "crb_common.h"
 #include "../../include/crb_hip.h"
 
