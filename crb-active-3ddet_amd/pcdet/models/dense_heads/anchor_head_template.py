@@ -11,6 +11,9 @@ from .target_assigner.anchor_generator import AnchorGenerator
 from .target_assigner.axis_aligned_target_assigner import AxisAlignedTargetAssigner
 
 
+FUSED_LOSS = True     # RPN losses through crb_rpn_loss_forward / _backward for device tensors; False = the torch restatement
+
+
 class AnchorHeadTemplate(nn.Module):
     def __init__(self, model_cfg, num_class, class_names, grid_size, point_cloud_range, predict_boxes_when_training):
         super().__init__()
@@ -138,10 +141,55 @@ class AnchorHeadTemplate(nn.Module):
             dir_loss = dir_loss.sum() / B if reduce else dir_loss.sum(-1).sum(-1)
             dir_loss = dir_loss * self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS['dir_weight']
             box_loss = box_loss + dir_loss
-            tb['rpn_loss_dir'] = (dir_loss if reduce else dir_loss[0]).detach()
+            # reduce=False: the reference sums the (B,A) direction loss over BOTH axes (anchor_head_template.py:219-225), i.e.
+            # every frame's box loss carries the direction loss of the whole batch; kept as it is
+            tb['rpn_loss_dir'] = dir_loss.detach()
         return box_loss, tb
 
+    def _fused_loss_cfg(self):
+        """CrbRpnLossCfg for the HIP loss kernels, or None when this head's loss configuration is not the one they implement
+        (focal classification + WeightedSmoothL1Loss with 7 code weights + optional direction cross entropy)"""
+        if getattr(self, '_rpn_loss_cfg', None) is None:
+            from crbhip import rpn_loss as _rl
+            ok = (type(self.reg_loss_func) is loss_utils.WeightedSmoothL1Loss and self.box_coder.code_size == 7
+                  and type(self.cls_loss_func) is loss_utils.SigmoidFocalClassificationLoss and self.num_class <= 8
+                  and self.reg_loss_func.code_weights is not None and self.model_cfg.get('NUM_DIR_BINS', 2) <= 8)
+            if not ok:
+                self._rpn_loss_cfg = False
+            else:
+                lw = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
+                self._rpn_loss_cfg = _rl.make_cfg(
+                    self.num_class, self.model_cfg.get('NUM_DIR_BINS', 2), self.reg_loss_func.code_weights.tolist(),
+                    lw['cls_weight'], lw['loc_weight'], lw.get('dir_weight', 0.0), self.model_cfg.get('DIR_OFFSET', 0.0),
+                    alpha=self.cls_loss_func.alpha, gamma=self.cls_loss_func.gamma, beta=self.reg_loss_func.beta)
+        return self._rpn_loss_cfg or None
+
+    def get_loss_fused(self, cfg, reduce=True):
+        """get_cls_layer_loss + get_box_reg_layer_loss as one forward and one backward HIP launch (csrc/rpn_loss.hip):
+        same three losses (sum of the same per-anchor terms, normalised by the frame's positives), same tb_dict"""
+        from crbhip import rpn_loss as _rl
+        d = self.forward_ret_dict
+        B = int(d['cls_preds'].shape[0])
+        anchors = self._flat_anchors().reshape(-1, 7)
+        per_frame = _rl.rpn_loss(d['cls_preds'], d['box_preds'], d.get('dir_cls_preds', None), d['box_cls_labels'],
+                                 d['box_reg_targets'], anchors, cfg)                       # (B,3)
+        parts = per_frame.sum(0) / B if reduce else per_frame.t()                           # (3) or (3,B)
+        cls_loss, loc_loss = parts[0], parts[1]
+        dir_loss = parts[2] if reduce else parts[2].sum()       # reduce=False: summed over the frames as well, as the reference does
+        first = (lambda v: v) if reduce else (lambda v: v[0])
+        tb = {'rpn_loss_cls': first(cls_loss).detach(), 'rpn_loss_loc': first(loc_loss).detach()}
+        rpn_loss = cls_loss + loc_loss
+        if d.get('dir_cls_preds', None) is not None:
+            tb['rpn_loss_dir'] = dir_loss.detach()
+            rpn_loss = rpn_loss + dir_loss
+        tb['rpn_loss'] = first(rpn_loss).detach()
+        return rpn_loss, tb
+
     def get_loss(self, reduce=True):
+        if FUSED_LOSS and self.forward_ret_dict['cls_preds'].is_cuda:
+            cfg = self._fused_loss_cfg()
+            if cfg is not None:
+                return self.get_loss_fused(cfg, reduce=reduce)
         cls_loss, tb = self.get_cls_layer_loss(reduce=reduce)
         box_loss, tb_box = self.get_box_reg_layer_loss(reduce=reduce)
         tb.update(tb_box)

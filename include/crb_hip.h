@@ -461,6 +461,36 @@ int crb_assign_targets(const float* anchors, const int32_t* anchor_cls, int A, c
                        void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * a11  RPN losses of the anchor head: sigmoid focal classification + weighted smooth-L1 regression (with the sine
+ *      difference of the heading) + direction-bin cross entropy, forward and gradient
+ * replaces: AnchorHeadTemplate.get_cls_layer_loss / add_sin_difference / get_direction_target / get_box_reg_layer_loss
+ *           (pcdet/models/dense_heads/anchor_head_template.py:101-214), SigmoidFocalClassificationLoss,
+ *           WeightedSmoothL1Loss, WeightedCrossEntropyLoss (pcdet/utils/loss_utils.py:9-188)
+ * cls_preds (B,A,num_class) logits, box_preds (B,A,7), dir_preds (B,A,num_dir_bins) or NULL (no direction classifier),
+ * labels (B,A) i32 {-1 ignored, 0 background, c > 0 class; num_class == 1: any c > 0 is the class}, reg_targets (B,A,7) as
+ * written by crb_assign_targets (NaN entries = "no target": zero loss and gradient), anchors (A,7) (heading column only).
+ * forward : loss (B,3) = per frame {cls, loc, dir} losses, each = weight * sum over anchors / max(npos,1); npos (B) f32 =
+ *           positives of the frame. The reference's scalar losses are loss.sum(0) / B; its reduce=False variants are the rows.
+ * backward: gradient of sum_b sum_k grad_loss[b,k] * loss[b,k] w.r.t. the three prediction tensors (every element written).
+ * Sums are taken in a fixed order: bit-reproducible. Limits: num_class <= 8, num_dir_bins <= 8 (else CRB_ERR_ARG).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct CrbRpnLossCfg {
+  float alpha, gamma;            /* focal loss (0.25, 2.0) */
+  float beta;                    /* smooth-L1 knee (1/9) */
+  float dir_offset;              /* MODEL.DENSE_HEAD.DIR_OFFSET */
+  float code_weights[7];         /* LOSS_CONFIG.LOSS_WEIGHTS.code_weights */
+  float cls_weight, loc_weight, dir_weight;
+  int32_t num_class, num_dir_bins;
+} CrbRpnLossCfg;
+int64_t crb_rpn_loss_workspace_bytes(int B, int A);
+int crb_rpn_loss_forward(const float* cls_preds, const float* box_preds, const float* dir_preds, const int32_t* labels,
+                         const float* reg_targets, const float* anchors, int B, int A, const CrbRpnLossCfg* cfg,
+                         float* loss, float* npos, void* workspace, int64_t workspace_bytes, void* stream);
+int crb_rpn_loss_backward(const float* cls_preds, const float* box_preds, const float* dir_preds, const int32_t* labels,
+                          const float* reg_targets, const float* anchors, int B, int A, const CrbRpnLossCfg* cfg,
+                          const float* npos, const float* grad_loss, float* d_cls, float* d_box, float* d_dir, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a7 (stretch)  3x3 stride-1 pad-1 convolution on channels_last maps as Winograd F(2x2,3x3) on the f32 MFMA
  * replaces: torch.nn.Conv2d(C, C, 3, padding=1) of the BEV backbone (pcdet/models/backbones_2d/base_bev_backbone.py:24-41;
  *           cuDNN in the reference, MIOpen's f32 implicit GEMM here) for the stride-1 layers whose channel counts pass

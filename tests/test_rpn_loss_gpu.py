@@ -1,0 +1,140 @@
+"""GPU: RPN losses as HIP kernels (csrc/rpn_loss.hip, crb_rpn_loss_forward / _backward through the C-ABI) against
+(1) the golden written by the reference's own AnchorHeadSingle (tests/golden/ref_anchor_head.npz: losses and the gradient that
+reaches the head's input) and (2) the torch restatement of the reference's loss classes — itself pinned by the same golden on the
+CPU (tests/test_golden_dense.py) — on inputs with ignored anchors, frames without positives, NaN targets, one class, no
+direction classifier. Tolerances: per-frame losses 5e-6 relative (a sum of ~1e5 f32 terms taken in a different order),
+gradients 2e-6 of the tensor's largest entry + 1e-5 relative (same formulas, different rounding of exp / log1p)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _small_head(num_class=3, direction=True):
+    from pcdet.model_cfgs import second_cfg
+    from pcdet.models.dense_heads import AnchorHeadSingle
+    cfg = second_cfg().MODEL.DENSE_HEAD
+    names = ['Car', 'Pedestrian', 'Cyclist'][:num_class]
+    if num_class != 3:
+        cfg.ANCHOR_GENERATOR_CONFIG = [c for c in cfg.ANCHOR_GENERATOR_CONFIG if c['class_name'] in names]
+    if not direction:
+        cfg.USE_DIRECTION_CLASSIFIER = None
+    return AnchorHeadSingle(cfg, input_channels=24, num_class=num_class, class_names=names,
+                            grid_size=np.array([176, 160, 40]),
+                            point_cloud_range=np.array([0, -8, -3, 17.6, 8, 1], np.float32),
+                            predict_boxes_when_training=True)
+
+
+def _close(a, b, what):
+    a, b = a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy()
+    tol = 2e-6 * np.abs(b).max() + 1e-5 * np.abs(b)
+    bad = np.abs(a - b) > tol
+    assert not bad.any(), '%s: %d entries off, worst %.3e (scale %.3e)' % (what, bad.sum(), np.abs(a - b).max(),
+                                                                           np.abs(b).max())
+
+
+def test_fused_rpn_loss_reproduces_the_reference_golden():
+    dev = torch.device('cuda', 0)
+    z = np.load(os.path.join(G, 'ref_anchor_head.npz'))
+    g = {k: z[k] for k in z.files}
+    head = _small_head()
+    head.load_state_dict({k[len('head_state/'):]: torch.from_numpy(v) for k, v in g.items()
+                          if k.startswith('head_state/')})
+    head = head.to(dev).train()
+    feats = torch.from_numpy(g['head_feats']).to(dev).requires_grad_(True)
+    head({'spatial_features_2d': feats, 'gt_boxes': torch.from_numpy(g['head_gt']).to(dev), 'batch_size': feats.shape[0]})
+    assert head._fused_loss_cfg() is not None
+    np.testing.assert_array_equal(head.forward_ret_dict['box_cls_labels'].cpu().numpy(), g['head_labels'].astype(np.int32))
+    loss, tb = head.get_loss()
+    got = np.array([float(loss.detach()), float(tb['rpn_loss_cls']), float(tb['rpn_loss_loc']), float(tb['rpn_loss_dir'])])
+    np.testing.assert_allclose(got, g['head_loss'], rtol=5e-6)
+    loss.backward()
+    ref = g['head_feats_grad']
+    err = np.abs(feats.grad.cpu().numpy() - ref)
+    assert (err <= 1e-4 * np.abs(ref) + 2e-6 * np.abs(ref).max()).all(), err.max()
+
+
+def _random_case(head, B, dev, seed, empty_frame=None, nan_targets=False):
+    from pcdet.datasets.synthetic import kitti_batch      # noqa: F401  (not used: boxes are drawn here on the small range)
+    rs = np.random.RandomState(seed)
+    A_loc = head.num_anchors_per_location
+    ny, nx = head.anchors[0].shape[1], head.anchors[0].shape[2]
+    gt = np.zeros((B, 12, 8), np.float32)
+    for b in range(B):
+        if b == empty_frame:
+            continue
+        n = rs.randint(8, 13)
+        gt[b, :n, 0] = rs.uniform(1, 16.5, n)
+        gt[b, :n, 1] = rs.uniform(-7, 7, n)
+        gt[b, :n, 2] = rs.uniform(-1.5, -0.5, n)
+        cls = rs.randint(1, head.num_class + 1, n)
+        sizes = np.array([[3.9, 1.6, 1.56], [0.8, 0.6, 1.73], [1.76, 0.6, 1.73]], np.float32)
+        gt[b, :n, 3:6] = sizes[cls - 1] * rs.uniform(0.85, 1.15, (n, 3))
+        gt[b, :n, 6] = rs.uniform(-np.pi, np.pi, n)
+        gt[b, :n, 7] = cls
+    t = head.assign_targets(gt_boxes=torch.from_numpy(gt).to(dev))
+    if nan_targets:
+        pos = (t['box_cls_labels'] > 0).nonzero()
+        pick = pos[:: max(1, pos.shape[0] // 7)]
+        t['box_reg_targets'][pick[:, 0], pick[:, 1], pick[:, 0] % 7] = float('nan')
+    mk = lambda c, s: (torch.from_numpy(rs.standard_normal((B, ny, nx, A_loc * c)).astype(np.float32)) * s).to(dev)
+    preds = {'cls_preds': mk(head.num_class, 2.0), 'box_preds': mk(7, 0.4),
+             'dir_cls_preds': mk(2, 1.5) if head.conv_dir_cls is not None else None}
+    return t, preds
+
+
+def _run(head, targets, preds, fused, reduce, weights):
+    from pcdet.models.dense_heads import anchor_head_template as aht
+    leaves = {k: (v.clone().requires_grad_(True) if v is not None else None) for k, v in preds.items()}
+    head.forward_ret_dict = dict(targets)
+    head.forward_ret_dict.update(leaves)
+    old = aht.FUSED_LOSS
+    aht.FUSED_LOSS = fused
+    try:
+        loss, tb = head.get_loss(reduce=reduce)
+    finally:
+        aht.FUSED_LOSS = old
+    (loss * weights).sum().backward() if not reduce else loss.backward()
+    return loss.detach(), tb, {k: v.grad for k, v in leaves.items() if v is not None}
+
+
+@pytest.mark.parametrize('case', ['three_classes', 'frame_without_gt', 'nan_targets', 'one_class', 'no_direction',
+                                  'per_frame'])
+def test_fused_rpn_loss_equals_the_torch_restatement(case):
+    dev = torch.device('cuda', 0)
+    head = _small_head(num_class=1 if case == 'one_class' else 3, direction=case != 'no_direction').to(dev).train()
+    B = 3
+    targets, preds = _random_case(head, B, dev, seed=11, empty_frame=1 if case == 'frame_without_gt' else None,
+                                  nan_targets=case == 'nan_targets')
+    lab = targets['box_cls_labels']
+    assert (lab > 0).sum() > 8 and (lab < 0).sum() > 0
+    reduce = case != 'per_frame'
+    w = torch.tensor([0.7, -1.3, 2.1], device=dev)
+    l_f, tb_f, g_f = _run(head, targets, preds, True, reduce, w)
+    l_t, tb_t, g_t = _run(head, targets, preds, False, reduce, w)
+    np.testing.assert_allclose(l_f.cpu().numpy(), l_t.cpu().numpy(), rtol=5e-6)
+    assert set(tb_f) == set(tb_t)
+    for k in tb_t:
+        np.testing.assert_allclose(float(tb_f[k]), float(tb_t[k]), rtol=5e-6, atol=1e-9)
+    for k in g_t:
+        assert torch.isfinite(g_f[k]).all()
+        _close(g_f[k], g_t[k], k)
+    # bit-reproducible
+    l_2, _, g_2 = _run(head, targets, preds, True, reduce, w)
+    assert torch.equal(l_2, l_f) and all(torch.equal(g_2[k], g_f[k]) for k in g_f)
+
+
+def test_fused_rpn_loss_rejects_host_tensors_and_bad_sizes():
+    from crbhip import rpn_loss, CrbHipError
+    cfg = rpn_loss.make_cfg(3, 2, [1] * 7, 1.0, 2.0, 0.2, 0.78539)
+    z = lambda *s: torch.zeros(*s)
+    with pytest.raises(CrbHipError):
+        rpn_loss.rpn_loss(z(1, 4, 3), z(1, 4, 7), z(1, 4, 2), z(1, 4).int(), z(1, 4, 7), z(4, 7), cfg)
+    d = torch.device('cuda', 0)
+    with pytest.raises(CrbHipError):
+        rpn_loss.rpn_loss(z(1, 4, 3).to(d), z(1, 5, 7).to(d), z(1, 4, 2).to(d), z(1, 4).int().to(d), z(1, 4, 7).to(d),
+                          z(4, 7).to(d), cfg)
