@@ -5,6 +5,23 @@ from ._lib import lib, check, ptr, cur_stream, require_cuda
 
 
 FUSE_RUNNING = __import__('os').environ.get('CRB_BN_FUSE_RUNNING', '1') == '1'
+# finalize inside the statistics launch ("last block done" tickets, include/crb_hip.h): 2 launches per call instead of 3
+TICKETS = __import__('os').environ.get('CRB_BN_TICKETS', '1') == '1'
+_ticket_areas = {}
+
+
+def _scratch(dev, wsb):
+    """(workspace, ticket area or None) for one crb_bn_* call on the current stream of `dev`. The ticket area is one zeroed
+    int32 tensor per (device, stream), handed to every call enqueued on that stream: the kernels leave it zero and stream
+    order keeps consecutive calls apart."""
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    if not TICKETS:
+        return ws, None
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    t = _ticket_areas.get(key)
+    if t is None:
+        t = _ticket_areas[key] = torch.zeros((lib.crb_bn_ticket_ints(),), dtype=torch.int32, device=dev)
+    return ws, t
 
 
 # ---- per-frame statistics ------------------------------------------------------------------------------------------
@@ -101,11 +118,11 @@ class _BNReLUTrain(torch.autograd.Function):
         var = torch.empty_like(mean)
         invstd = torch.empty_like(mean)
         wsb = lib.crb_bn_workspace_bytes(n, C)
-        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        ws, tk = _scratch(dev, wsb)
         g, b = gamma.contiguous().float(), beta.contiguous().float()
         check(lib.crb_bn_relu_forward(ptr(x), n, C, ptr(g), ptr(b), float(eps), int(relu), ptr(z), 0, ptr(mean), ptr(var),
                                       ptr(invstd), ptr(running_mean), ptr(running_var), float(momentum), ptr(ws), wsb,
-                                      cur_stream(dev)), 'crb_bn_relu_forward')
+                                      ptr(tk), cur_stream(dev)), 'crb_bn_relu_forward')
         ctx.save_for_backward(x, mean, invstd, g, b)
         ctx.relu = int(relu)
         ctx.mark_non_differentiable(mean, var)
@@ -121,9 +138,9 @@ class _BNReLUTrain(torch.autograd.Function):
         dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
         dbeta = torch.empty_like(dgamma)
         wsb = lib.crb_bn_workspace_bytes(n, C)
-        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        ws, tk = _scratch(dev, wsb)
         check(lib.crb_bn_relu_backward(ptr(x), ptr(dz), 0, n, C, ptr(mean), ptr(invstd), ptr(g), ptr(b), ctx.relu, ptr(dx),
-                                       ptr(dgamma), ptr(dbeta), ptr(ws), wsb, cur_stream(dev)), 'crb_bn_relu_backward')
+                                       ptr(dgamma), ptr(dbeta), ptr(ws), wsb, ptr(tk), cur_stream(dev)), 'crb_bn_relu_backward')
         return dx, dgamma, dbeta, None, None, None, None, None
 
 
@@ -211,11 +228,11 @@ class _BNReLUConcatTrain(torch.autograd.Function):
             mean = torch.empty((C,), dtype=torch.float32, device=dev)
             var, invstd = torch.empty_like(mean), torch.empty_like(mean)
             wsb = lib.crb_bn_workspace_bytes(n, C)
-            ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+            ws, tk = _scratch(dev, wsb)
             g, b = gamma.contiguous().float(), beta.contiguous().float()
             zptr = ctypes.c_void_p(out.data_ptr() + 4 * col)
             check(lib.crb_bn_relu_forward(ptr(x), n, C, ptr(g), ptr(b), float(eps), int(relu), zptr, total, ptr(mean),
-                                          ptr(var), ptr(invstd), ptr(rm), ptr(rv), float(mom), ptr(ws), wsb,
+                                          ptr(var), ptr(invstd), ptr(rm), ptr(rv), float(mom), ptr(ws), wsb, ptr(tk),
                                           cur_stream(dev)), 'crb_bn_relu_forward')
             saved += [x, mean, invstd, g, b]
             col += C
@@ -237,10 +254,10 @@ class _BNReLUConcatTrain(torch.autograd.Function):
             dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
             dbeta = torch.empty_like(dgamma)
             wsb = lib.crb_bn_workspace_bytes(n, C)
-            ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+            ws, tk = _scratch(dev, wsb)
             dzp = ctypes.c_void_p(dz.data_ptr() + 4 * col)
             check(lib.crb_bn_relu_backward(ptr(x), dzp, total, n, C, ptr(mean), ptr(invstd), ptr(g), ptr(b), ctx.relu,
-                                           ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), wsb, cur_stream(dev)),
+                                           ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), wsb, ptr(tk), cur_stream(dev)),
                   'crb_bn_relu_backward')
             grads += [dx, dgamma, dbeta, None, None, None, None]
             col += C
@@ -297,12 +314,12 @@ class _BNReLUMaxConcatTrain(torch.autograd.Function):
             var, invstd = torch.empty_like(mean), torch.empty_like(mean)
             arg = torch.empty((M, C), dtype=torch.int32, device=dev)
             wsb = lib.crb_bn_workspace_bytes(M * ns, C)
-            ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+            ws, tk = _scratch(dev, wsb)
             g, b = gamma.contiguous().float(), beta.contiguous().float()
             zptr = ctypes.c_void_p(out.data_ptr() + 4 * col)
             check(lib.crb_bn_relu_max_forward(ptr(x), M, ns, C, ptr(g), ptr(b), float(eps), zptr, total, ptr(arg),
                                               ptr(mean), ptr(var), ptr(invstd), ptr(rm), ptr(rv), float(mom), ptr(ws), wsb,
-                                              cur_stream(dev)), 'crb_bn_relu_max_forward')
+                                              ptr(tk), cur_stream(dev)), 'crb_bn_relu_max_forward')
             saved += [x, mean, invstd, g, b, arg]
             col += C
         ctx.save_for_backward(*saved)
@@ -323,10 +340,10 @@ class _BNReLUMaxConcatTrain(torch.autograd.Function):
             dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
             dbeta = torch.empty_like(dgamma)
             wsb = lib.crb_bn_workspace_bytes(M * ns, C)
-            ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+            ws, tk = _scratch(dev, wsb)
             gp = ctypes.c_void_p(gz.data_ptr() + 4 * col)
             check(lib.crb_bn_relu_max_backward(ptr(x), gp, total, ptr(arg), M, ns, C, ptr(mean), ptr(invstd), ptr(g), ptr(b),
-                                               ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), wsb, cur_stream(dev)),
+                                               ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), wsb, ptr(tk), cur_stream(dev)),
                   'crb_bn_relu_max_backward')
             grads += [dx, None, dgamma, dbeta, None, None, None, None]
             col += C

@@ -23,19 +23,131 @@ static inline int bn_rows_per_block(int64_t n) {
   return (int)r;
 }
 
+// traversal order of the four streaming passes (bit 0: statistics passes walk the rows from the end, bit 1: apply passes do);
+// the partial of a row range is stored at the range's index either way, so the finalize order and every result are unchanged.
+// Default 2: the apply passes walk from the end — what the statistics pass read last is what the 256 MB Infinity Cache still
+// holds (tools/time_bn.py: 144 MB forward 116 -> 103 us, 288 MB 167.6 -> 165.2 us, larger tensors unchanged)
+CRB_KNOB g_bn_order = 2;
+
+// ---- finalize inside the statistics launch ("last block done" tickets) --------------------------------------------
+// The per-block partials used to be summed by a launch of their own (bn_finalize_kernel: 52 launches of ~12 us per SECOND
+// step). With a ticket area the statistics kernels do it themselves, in two levels and in exactly the order of
+// bn_finalize_kernel (bit-identical results): block k belongs to group k % 32; the LAST block of a group to finish sums the
+// group's partials k, k+32, ... in double (what one of the 32 `part` lanes of bn_finalize_kernel does), the LAST group to
+// finish adds the 32 group sums in group order and writes the statistics. Visibility across workgroups / XCDs: every block
+// fences its partial stores before taking its ticket (device-scope release: L2 write-back), the finalizing block fences
+// again before reading (acquire: L2 invalidate). tickets[0] counts groups, tickets[1 + g] the blocks of group g; whoever
+// finishes a counter resets it, so the area is zero again when the kernel ends.
+constexpr int BN_GROUPS = 32;
+struct BnFinal {
+  int* tickets;        // 1 + BN_GROUPS ints, zero on entry; nullptr = separate finalize launch
+  double* group;       // BN_GROUPS x 2C doubles of scratch
+  float* o0;           // forward: mean      backward: dbeta
+  float* o1;           // forward: var       backward: dgamma
+  float* o2;           // forward: invstd
+  float* running_mean;
+  float* running_var;
+  float momentum, eps;
+  int64_t n;
+  int bwd;
+};
+
+__device__ __forceinline__ void st_agent(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent4(float* p, f4 v) {
+  st_agent(p, v[0]);
+  st_agent(p + 1, v[1]);
+  st_agent(p + 2, v[2]);
+  st_agent(p + 3, v[3]);
+}
+
+__device__ __forceinline__ void bn_ticket_finalize(const float* partial, int nblk, int C, int blk, const BnFinal& f) {
+  __shared__ int s_role;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's partial stores are acknowledged ...
+  __syncthreads();                                         // ... for every thread of the block, before the ticket is taken
+  const int ngroups = nblk < BN_GROUPS ? nblk : BN_GROUPS;
+  const int grp = blk % BN_GROUPS;
+  const int members = (nblk - grp + BN_GROUPS - 1) / BN_GROUPS;
+  if (threadIdx.x == 0)
+    s_role = __hip_atomic_fetch_add(&f.tickets[1 + grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1 ? 1 : 0;
+  __syncthreads();
+  if (!s_role) return;
+  const int C2 = 2 * C;
+  for (int i = threadIdx.x; i < C2; i += 256) {
+    double a = 0.0;
+    int k = grp;
+    for (; k + 7 * BN_GROUPS < nblk; k += 8 * BN_GROUPS) {      // 8 loads in flight, added in order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = __hip_atomic_load(partial + (int64_t)(k + u * BN_GROUPS) * C2 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += (double)v[u];
+    }
+    for (; k < nblk; k += BN_GROUPS)
+      a += (double)__hip_atomic_load(partial + (int64_t)k * C2 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(f.group + (int64_t)grp * C2 + i, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&f.tickets[1 + grp], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_role = __hip_atomic_fetch_add(&f.tickets[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1 ? 2 : 0;
+  }
+  __syncthreads();
+  if (s_role != 2) return;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double a = 0.0, b = 0.0;
+    int g = 0;
+    for (; g + 7 < ngroups; g += 8) {
+      double va[8], vb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        va[u] = __hip_atomic_load(f.group + (int64_t)(g + u) * C2 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        vb[u] = __hip_atomic_load(f.group + (int64_t)(g + u) * C2 + C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a += va[u]; b += vb[u]; }
+    }
+    for (; g < ngroups; ++g) {
+      a += __hip_atomic_load(f.group + (int64_t)g * C2 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      b += __hip_atomic_load(f.group + (int64_t)g * C2 + C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!f.bwd) {
+      const double m = a / (double)f.n;
+      double v = b / (double)f.n - m * m;
+      if (v < 0.0) v = 0.0;
+      f.o0[c] = (float)m;
+      f.o1[c] = (float)v;
+      f.o2[c] = (float)(1.0 / sqrt(v + (double)f.eps));
+      if (f.running_mean) {
+        const float unbiased = (float)(f.n > 1 ? v * ((double)f.n / (double)(f.n - 1)) : v);
+        f.running_mean[c] = f.running_mean[c] * (1.f - f.momentum) + f.momentum * (float)m;
+        f.running_var[c] = f.running_var[c] * (1.f - f.momentum) + f.momentum * unbiased;
+      }
+    } else {
+      f.o0[c] = (float)a;
+      f.o1[c] = (float)b;
+    }
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(&f.tickets[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // partial[(blk * 2 + which) * C + c]; which 0: sum a, 1: sum b
 template <bool BWD>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          int64_t n, int C, int relu, int rows_per_block,
-                                                         int64_t ld_dz, float* __restrict__ partial) {
+                                                         int64_t ld_dz, float* __restrict__ partial, int reversed, BnFinal fin) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f4* red = reinterpret_cast<f4*>(smem);               // 2 * 256 f4
   const int c4n = C >> 2;                              // float4 columns
   const int tc = threadIdx.x % c4n, tr = threadIdx.x / c4n;
   const int rlanes = 256 / c4n;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int blk = reversed ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+  const int64_t r0 = (int64_t)blk * rows_per_block;
   const int64_t r1 = min(n, r0 + rows_per_block);
   f4 a = (f4){0, 0, 0, 0}, b = (f4){0, 0, 0, 0};
   f4 mu, is, ga, be;
@@ -68,9 +180,15 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   __syncthreads();
   if (tr == 0) {
     for (int k = 1; k < rlanes; ++k) { a += red[k * c4n + tc]; b += red[256 + k * c4n + tc]; }
-    *reinterpret_cast<f4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * C + tc * 4) = a;
-    *reinterpret_cast<f4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * C + tc * 4) = b;
+    if (fin.tickets) {
+      st_agent4(partial + ((int64_t)blk * 2 + 0) * C + tc * 4, a);
+      st_agent4(partial + ((int64_t)blk * 2 + 1) * C + tc * 4, b);
+    } else {
+      *reinterpret_cast<f4*>(partial + ((int64_t)blk * 2 + 0) * C + tc * 4) = a;
+      *reinterpret_cast<f4*>(partial + ((int64_t)blk * 2 + 1) * C + tc * 4) = b;
+    }
   }
+  if (fin.tickets) bn_ticket_finalize(partial, gridDim.x, C, blk, fin);
 }
 
 // forward finalize: mean, biased var, invstd ; backward finalize: dbeta, dgamma.
@@ -116,8 +234,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ z, int64_t total4,
-                                                       int C, int relu, int64_t ld_z) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                       int C, int relu, int64_t ld_z, int reversed) {
+  const int64_t t = (int64_t)(reversed ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * 256 + threadIdx.x;
   if (t >= total4) return;
   const int c = (int)((t * 4) % C);
   const f4 v = *reinterpret_cast<const f4*>(x + t * 4);
@@ -136,8 +254,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ dbeta, const float* __restrict__ dgamma,
                                                            float* __restrict__ dx, int64_t total4, int C, float inv_n,
-                                                           int relu, int64_t ld_dz) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                           int relu, int64_t ld_dz, int reversed) {
+  const int64_t t = (int64_t)(reversed ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * 256 + threadIdx.x;
   if (t >= total4) return;
   const int c = (int)((t * 4) % C);
   const f4 v = *reinterpret_cast<const f4*>(x + t * 4);
@@ -194,7 +312,7 @@ __global__ __launch_bounds__(256) void bn_max_partial_kernel(const float* __rest
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              int64_t groups, int ns, int C, int groups_per_block,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial, BnFinal fin) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f4* red = reinterpret_cast<f4*>(smem);
   const int c4n = C >> 2;
@@ -224,9 +342,15 @@ __global__ __launch_bounds__(256) void bn_max_partial_kernel(const float* __rest
   __syncthreads();
   if (tr == 0) {
     for (int k = 1; k < rlanes; ++k) { a += red[k * c4n + tc]; b += red[256 + k * c4n + tc]; }
-    *reinterpret_cast<f4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * C + c) = a;
-    *reinterpret_cast<f4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * C + c) = b;
+    if (fin.tickets) {
+      st_agent4(partial + ((int64_t)blockIdx.x * 2 + 0) * C + c, a);
+      st_agent4(partial + ((int64_t)blockIdx.x * 2 + 1) * C + c, b);
+    } else {
+      *reinterpret_cast<f4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * C + c) = a;
+      *reinterpret_cast<f4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * C + c) = b;
+    }
   }
+  if (fin.tickets) bn_ticket_finalize(partial, gridDim.x, C, blockIdx.x, fin);
 }
 
 __global__ __launch_bounds__(256) void bn_max_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gz,
@@ -412,13 +536,35 @@ __global__ __launch_bounds__(256) void bn_relu_max_frames_kernel(const float* __
 
 static inline int bn_blocks(int64_t n) { return crb_cdiv(n, bn_rows_per_block(n)); }
 
-extern "C" int64_t crb_bn_workspace_bytes(int64_t n, int C) { return (int64_t)bn_blocks(n) * 2 * C * 4 + 256; }
+// per-block partials (256-B aligned) + the group sums of the ticket finalize
+static inline int64_t bn_partial_bytes(int64_t n, int C) { return crb_align_up((int64_t)bn_blocks(n) * 2 * C * 4, 256); }
+extern "C" int64_t crb_bn_workspace_bytes(int64_t n, int C) {
+  return bn_partial_bytes(n, C) + (int64_t)BN_GROUPS * 2 * C * 8 + 256;
+}
+extern "C" int crb_bn_ticket_ints(void) { return 1 + BN_GROUPS; }
+
+static inline BnFinal bn_final(int32_t* tickets, void* workspace, int64_t n, int C, int bwd, float* o0, float* o1, float* o2,
+                               float* running_mean, float* running_var, float momentum, float eps) {
+  BnFinal f;
+  f.tickets = tickets;
+  f.group = reinterpret_cast<double*>(static_cast<char*>(workspace) + bn_partial_bytes(n, C));
+  f.o0 = o0;
+  f.o1 = o1;
+  f.o2 = o2;
+  f.running_mean = running_mean;
+  f.running_var = running_var;
+  f.momentum = momentum;
+  f.eps = eps;
+  f.n = n;
+  f.bwd = bwd;
+  return f;
+}
 
 // training forward. mean/var/invstd (C) out. z may alias x? no: x is kept for backward.
 extern "C" int crb_bn_relu_forward(const float* x, int64_t n, int C, const float* gamma, const float* beta, float eps,
                                    int relu, float* z, int64_t z_row_stride, float* mean, float* var, float* invstd,
                                    float* running_mean, float* running_var, float momentum, void* workspace,
-                                   int64_t workspace_bytes, void* stream) {
+                                   int64_t workspace_bytes, int32_t* tickets, void* stream) {
   const int64_t ld_z = z_row_stride > 0 ? z_row_stride : C;
   if (ld_z < C || (ld_z & 3)) return CRB_ERR_ARG;
   if (n <= 0 || C <= 0 || (C & 3) || C > 1024 || (256 % (C >> 2) && (C >> 2) < 256)) return CRB_ERR_ARG;
@@ -427,12 +573,14 @@ extern "C" int crb_bn_relu_forward(const float* x, int64_t n, int C, const float
   const int nblk = bn_blocks(n);
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(nblk), dim3(256), 2 * 256 * 16, st, x, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, n, C, relu, bn_rows_per_block(n), (int64_t)C, partial);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, eps, 0, mean, var,
-                     invstd, running_mean, running_var, momentum);
+                     nullptr, nullptr, n, C, relu, bn_rows_per_block(n), (int64_t)C, partial, g_bn_order & 1,
+                     bn_final(tickets, workspace, n, C, 0, mean, var, invstd, running_mean, running_var, momentum, eps));
+  if (!tickets)
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, eps, 0, mean, var,
+                       invstd, running_mean, running_var, momentum);
   const int64_t total4 = n * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, z,
-                     total4, C, relu, ld_z);
+                     total4, C, relu, ld_z, (g_bn_order >> 1) & 1);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
@@ -447,14 +595,15 @@ extern "C" int crb_bn_relu_apply(const float* x, int64_t n, int C, const float* 
   if (n == 0) return CRB_OK;
   const int64_t total4 = n * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd,
-                     gamma, beta, z, total4, C, relu, ld_z);
+                     gamma, beta, z, total4, C, relu, ld_z, 0);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
 
 extern "C" int crb_bn_relu_backward(const float* x, const float* dz, int64_t dz_row_stride, int64_t n, int C, const float* mean,
                                     const float* invstd, const float* gamma, const float* beta, int relu, float* dx,
-                                    float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, void* stream) {
+                                    float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, int32_t* tickets,
+                                    void* stream) {
   if (n <= 0 || C <= 0 || (C & 3) || C > 1024 || (256 % (C >> 2) && (C >> 2) < 256)) return CRB_ERR_ARG;
   if (workspace_bytes < crb_bn_workspace_bytes(n, C) - 256 || !workspace) return CRB_ERR_WORKSPACE;
   const int64_t ld_dz = dz_row_stride > 0 ? dz_row_stride : C;
@@ -463,12 +612,14 @@ extern "C" int crb_bn_relu_backward(const float* x, const float* dz, int64_t dz_
   const int nblk = bn_blocks(n);
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(bn_partial_kernel<true>, dim3(nblk), dim3(256), 2 * 256 * 16, st, x, dz, mean, invstd, gamma, beta, n,
-                     C, relu, bn_rows_per_block(n), ld_dz, partial);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, 0.f, 1, dbeta, dgamma,
-                     (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f);
+                     C, relu, bn_rows_per_block(n), ld_dz, partial, g_bn_order & 1,
+                     bn_final(tickets, workspace, n, C, 1, dbeta, dgamma, nullptr, nullptr, nullptr, 0.f, 0.f));
+  if (!tickets)
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, 0.f, 1, dbeta, dgamma,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f);
   const int64_t total4 = n * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, dz, mean, invstd, gamma, beta,
-                     dbeta, dgamma, dx, total4, C, 1.0f / (float)n, relu, ld_dz);
+                     dbeta, dgamma, dx, total4, C, 1.0f / (float)n, relu, ld_dz, (g_bn_order >> 1) & 1);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
@@ -479,7 +630,7 @@ extern "C" int crb_bn_relu_backward(const float* x, const float* dz, int64_t dz_
 extern "C" int crb_bn_relu_max_forward(const float* x, int64_t groups, int ns, int C, const float* gamma, const float* beta,
                                        float eps, float* zmax, int64_t out_row_stride, int32_t* arg, float* mean, float* var,
                                        float* invstd, float* running_mean, float* running_var, float momentum,
-                                       void* workspace, int64_t workspace_bytes, void* stream) {
+                                       void* workspace, int64_t workspace_bytes, int32_t* tickets, void* stream) {
   const int64_t n = groups * ns;
   const int64_t ld = out_row_stride > 0 ? out_row_stride : C;
   if (ld < C || (ld & 3) || ns <= 0) return CRB_ERR_ARG;
@@ -489,9 +640,11 @@ extern "C" int crb_bn_relu_max_forward(const float* x, int64_t groups, int ns, i
   const int nblk = bn_blocks(n);
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(nblk), dim3(256), 2 * 256 * 16, st, x, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, n, C, 1, bn_rows_per_block(n), (int64_t)C, partial);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, eps, 0, mean, var,
-                     invstd, running_mean, running_var, momentum);
+                     nullptr, nullptr, n, C, 1, bn_rows_per_block(n), (int64_t)C, partial, 0,
+                     bn_final(tickets, workspace, n, C, 0, mean, var, invstd, running_mean, running_var, momentum, eps));
+  if (!tickets)
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, eps, 0, mean, var,
+                       invstd, running_mean, running_var, momentum);
   const int glanes = 256 / (C >> 2) > 0 ? 256 / (C >> 2) : 1;
   hipLaunchKernelGGL(bn_relu_max_kernel, dim3(crb_cdiv(groups, glanes)), dim3(256), 0, st, x, mean, invstd, gamma, beta,
                      groups, ns, C, zmax, ld, arg);
@@ -503,7 +656,7 @@ extern "C" int crb_bn_relu_max_forward(const float* x, int64_t groups, int ns, i
 extern "C" int crb_bn_relu_max_backward(const float* x, const float* gz, int64_t gz_row_stride, const int32_t* arg,
                                         int64_t groups, int ns, int C, const float* mean, const float* invstd,
                                         const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
-                                        void* workspace, int64_t workspace_bytes, void* stream) {
+                                        void* workspace, int64_t workspace_bytes, int32_t* tickets, void* stream) {
   const int64_t n = groups * ns;
   const int64_t ld = gz_row_stride > 0 ? gz_row_stride : C;
   if (ld < C || (ld & 3) || ns <= 0) return CRB_ERR_ARG;
@@ -515,9 +668,11 @@ extern "C" int crb_bn_relu_max_backward(const float* x, const float* gz, int64_t
   const int nblk = crb_cdiv(groups, gpb);                       // <= bn_blocks(n): fits the same workspace
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(bn_max_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * 16, st, x, gz, ld, arg, mean, invstd, gamma,
-                     beta, groups, ns, C, gpb, partial);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, 0.f, 1, dbeta, dgamma,
-                     (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f);
+                     beta, groups, ns, C, gpb, partial,
+                     bn_final(tickets, workspace, n, C, 1, dbeta, dgamma, nullptr, nullptr, nullptr, 0.f, 0.f));
+  if (!tickets)
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, 0.f, 1, dbeta, dgamma,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f);
   const int64_t total4 = n * C / 4;
   hipLaunchKernelGGL(bn_max_bwd_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, gz, ld, arg, mean, invstd,
                      gamma, beta, dbeta, dgamma, dx, total4, ns, C, 1.0f / (float)n);
@@ -628,3 +783,9 @@ extern "C" int crb_bn_relu_max_forward_frames(const float* x, int n_frames, int6
   return CRB_OK;
 }
 
+#ifdef CRB_MEASURE
+extern "C" int crb_bn_set_order(int bits) {
+  g_bn_order = bits;
+  return CRB_OK;
+}
+#endif

@@ -403,12 +403,18 @@ int crb_density_greedy(const float* densities, const int32_t* labels, int n_cand
  *           (C/4) divides 256 (C = 16,32,64,128,...). Training forward returns batch mean / biased var / invstd;
  *           running_mean / running_var (nullable) are updated in the same launch: r = (1-momentum) r + momentum batch,
  *           variance unbiased (n/(n-1)), as nn.BatchNorm does.
+ *           tickets (nullable): crb_bn_ticket_ints() int32 in device memory, ZERO before the first call and left zero by
+ *           every call; with it the statistics launch also reduces its per-block partials ("last block done", same
+ *           summation order: bit-identical results) and a call is two launches instead of three. One ticket area serves
+ *           any number of calls on ONE stream (stream order keeps them apart); calls that may run concurrently on
+ *           different streams need their own. NULL = the partials are reduced by a launch of their own.
  * ---------------------------------------------------------------------------------------------- */
 int64_t crb_bn_workspace_bytes(int64_t n, int C);
+int crb_bn_ticket_ints(void);
 int crb_bn_relu_forward(const float* x, int64_t n, int C, const float* gamma, const float* beta, float eps,
                         int relu, float* z, int64_t z_row_stride, float* mean, float* var, float* invstd,
                         float* running_mean, float* running_var, float momentum, void* workspace,
-                        int64_t workspace_bytes, void* stream);
+                        int64_t workspace_bytes, int32_t* tickets, void* stream);
 int crb_bn_relu_apply(const float* x, int64_t n, int C, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int relu, float* z, int64_t z_row_stride, void* stream);
 /* z_row_stride / dz_row_stride (floats, 0 = C): z may be a channel slice of a wider row-major buffer (the BEV backbone
@@ -416,7 +422,8 @@ int crb_bn_relu_apply(const float* x, int64_t n, int C, const float* mean, const
  * slices of its gradient: no torch.cat copy, no .contiguous() copies of the gradient slices). */
 int crb_bn_relu_backward(const float* x, const float* dz, int64_t dz_row_stride, int64_t n, int C, const float* mean,
                          const float* invstd, const float* gamma, const float* beta, int relu, float* dx,
-                         float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, void* stream);
+                         float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, int32_t* tickets,
+                         void* stream);
 /* training BatchNorm + ReLU over groups*ns rows followed by the max over every group of ns consecutive rows: the tail of
  * a StackSAModuleMSG scale (pointnet2_modules.py:96-103: BatchNorm2d, ReLU, F.max_pool2d over nsample) on the row-major
  * (M*nsample, C) layout. The normalised matrix is not materialised: zmax (groups, out_row_stride; 0 = C) and
@@ -425,11 +432,11 @@ int crb_bn_relu_backward(const float* x, const float* dz, int64_t dz_row_stride,
 int crb_bn_relu_max_forward(const float* x, int64_t groups, int ns, int C, const float* gamma, const float* beta, float eps,
                             float* zmax, int64_t out_row_stride, int32_t* arg, float* mean, float* var, float* invstd,
                             float* running_mean, float* running_var, float momentum, void* workspace,
-                            int64_t workspace_bytes, void* stream);
+                            int64_t workspace_bytes, int32_t* tickets, void* stream);
 int crb_bn_relu_max_backward(const float* x, const float* gz, int64_t gz_row_stride, const int32_t* arg, int64_t groups,
                              int ns, int C, const float* mean, const float* invstd, const float* gamma, const float* beta,
                              float* dx, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
-                             void* stream);
+                             int32_t* tickets, void* stream);
 /* Per-frame statistics (batched CRB stage 2: G frames per train-mode pass, every BatchNorm layer normalising each frame
  * with that frame's own batch statistics like G bs=1 passes, crb_sampling.py:174-212): four launches for all frames
  * (partial sums / finalize / running update / apply, a frame's rows cut into the blocks a single-frame call would use and

@@ -35,6 +35,9 @@ int crb_sparse_conv_set_wgrad_splits(int splits);    /* measurement knob: workgr
 int crb_sparse_conv_set_wgrad_debug(void* dev_buf_u64x4_per_wg); /* measurement runs: per-workgroup {start, end, HW_ID, XCC_ID | steps<<32} of the v2 wgrad; NULL = off */
 int crb_sparse_conv_set_wgrad_mode(int mode);        /* measurement builds of the 64x64 wgrad: 1 = no MFMAs, 2 = no gather pipeline (results are wrong by design), 0 = normal */
 int crb_sparse_conv_set_wgrad_v1(int on);            /* measurement knob: 1 = the v1 (16x16x4, register-gather) wgrad kernel for every shape */
+/* traversal order of the BatchNorm passes: bit 0 = statistics passes from the last row range to the first, bit 1 = apply passes
+ * (results unchanged; A/B of how much of the second read of a tensor the 256 MB Infinity Cache serves) */
+int crb_bn_set_order(int bits);
 
 #ifdef __cplusplus
 }

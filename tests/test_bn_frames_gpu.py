@@ -63,3 +63,39 @@ def test_frames_max_forward_equals_single_frame_calls(dev):
     assert torch.equal(out, ref)
     for a, b in zip(bns_a, bns_b):
         assert torch.equal(a.running_mean, b.running_mean) and torch.equal(a.running_var, b.running_var)
+
+
+@pytest.mark.parametrize('n,C', [(563200, 128), (70001, 16), (4097, 256), (31, 64), (190000, 64)])
+def test_ticket_finalize_is_bit_identical_to_the_separate_finalize_launch(dev, n, C):
+    """crb_bn_relu_forward / _backward with a ticket area (the statistics launch reduces its own partials: last block of each
+    of 32 groups, then the last group) against the same calls with tickets = NULL (bn_finalize_kernel): outputs, batch and
+    running statistics and all three gradients bit-identical — the summation order is the same — over repeated calls that
+    share one ticket area, which is zero again after every call."""
+    from crbhip import bnrelu
+    g = torch.Generator(device=dev).manual_seed(n % 977)
+    x = torch.randn(n, C, device=dev, generator=g) * 1.7 + 0.3
+    dz = torch.randn(n, C, device=dev, generator=g)
+
+    def run(tickets):
+        old = bnrelu.TICKETS
+        bnrelu.TICKETS = tickets
+        try:
+            bn = _bn(C, dev, 5)
+            outs = []
+            for _ in range(3):
+                xl = x.clone().requires_grad_(True)
+                z = bnrelu.bn_relu(xl, bn, True)
+                z.backward(dz)
+                outs.append((z.detach(), xl.grad, bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(),
+                             bn.running_var.clone()))
+                bn.weight.grad = bn.bias.grad = None
+            return outs
+        finally:
+            bnrelu.TICKETS = old
+    a, b = run(True), run(False)
+    for ra, rb in zip(a, b):
+        for ta, tb in zip(ra, rb):
+            assert torch.equal(ta, tb)
+    assert len(bnrelu._ticket_areas) >= 1
+    for t in bnrelu._ticket_areas.values():
+        assert int(t.abs().sum()) == 0
