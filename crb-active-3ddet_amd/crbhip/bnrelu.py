@@ -108,8 +108,9 @@ def supported(x, bn):
 
 class _BNReLUTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu, running_mean=None, running_var=None, momentum=0.0):
+    def forward(ctx, x, gamma, beta, eps, relu, running_mean=None, running_var=None, momentum=0.0, nbt=None):
         require_cuda(x, gamma, beta)
+        ctx.set_materialize_grads(False)          # mean / var carry no gradient: no zero tensors made for them in backward
         x = x.contiguous()
         n, C = x.shape
         dev = x.device
@@ -121,8 +122,8 @@ class _BNReLUTrain(torch.autograd.Function):
         ws, tk = _scratch(dev, wsb)
         g, b = gamma.contiguous().float(), beta.contiguous().float()
         check(lib.crb_bn_relu_forward(ptr(x), n, C, ptr(g), ptr(b), float(eps), int(relu), ptr(z), 0, ptr(mean), ptr(var),
-                                      ptr(invstd), ptr(running_mean), ptr(running_var), float(momentum), ptr(ws), wsb,
-                                      ptr(tk), cur_stream(dev)), 'crb_bn_relu_forward')
+                                      ptr(invstd), ptr(running_mean), ptr(running_var), ptr(nbt), float(momentum), ptr(ws),
+                                      wsb, ptr(tk), cur_stream(dev)), 'crb_bn_relu_forward')
         ctx.save_for_backward(x, mean, invstd, g, b)
         ctx.relu = int(relu)
         ctx.mark_non_differentiable(mean, var)
@@ -141,7 +142,18 @@ class _BNReLUTrain(torch.autograd.Function):
         ws, tk = _scratch(dev, wsb)
         check(lib.crb_bn_relu_backward(ptr(x), ptr(dz), 0, n, C, ptr(mean), ptr(invstd), ptr(g), ptr(b), ctx.relu, ptr(dx),
                                        ptr(dgamma), ptr(dbeta), ptr(ws), wsb, ptr(tk), cur_stream(dev)), 'crb_bn_relu_backward')
-        return dx, dgamma, dbeta, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def _counter(bn):
+    """bn.num_batches_tracked for the kernels to increment, or None after incrementing it here (not an int64 device scalar)"""
+    t = bn.num_batches_tracked
+    if t is not None and t.is_cuda and t.dtype == torch.int64 and t.numel() == 1:
+        return t
+    if t is not None:
+        with torch.no_grad():
+            t += 1
+    return None
 
 
 def bn_relu(x, bn, relu=True):
@@ -155,14 +167,14 @@ def bn_relu(x, bn, relu=True):
         with frame_groups(1):
             return torch.cat([bn_relu(x[a:b], bn, relu) for a, b in zip(off[:-1], off[1:]) if b > a], 0)
     if bn.training:
-        with torch.no_grad():
-            bn.num_batches_tracked += 1
         if FUSE_RUNNING and bn.momentum is not None and bn.running_mean.is_contiguous() and \
                 bn.running_var.is_contiguous():
-            # the running statistics are updated inside the finalize launch of the forward
+            # the running statistics and the batch counter are updated inside the statistics launch of the forward
             z, mean, var = _BNReLUTrain.apply(x, bn.weight, bn.bias, bn.eps, relu, bn.running_mean, bn.running_var,
-                                              float(bn.momentum))
+                                              float(bn.momentum), _counter(bn))
             return z
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
         z, mean, var = _BNReLUTrain.apply(x, bn.weight, bn.bias, bn.eps, relu)
         with torch.no_grad():                      # cumulative moving average (momentum=None): factor known on the host
             m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
@@ -232,7 +244,7 @@ class _BNReLUConcatTrain(torch.autograd.Function):
             g, b = gamma.contiguous().float(), beta.contiguous().float()
             zptr = ctypes.c_void_p(out.data_ptr() + 4 * col)
             check(lib.crb_bn_relu_forward(ptr(x), n, C, ptr(g), ptr(b), float(eps), int(relu), zptr, total, ptr(mean),
-                                          ptr(var), ptr(invstd), ptr(rm), ptr(rv), float(mom), ptr(ws), wsb, ptr(tk),
+                                          ptr(var), ptr(invstd), ptr(rm), ptr(rv), None, float(mom), ptr(ws), wsb, ptr(tk),
                                           cur_stream(dev)), 'crb_bn_relu_forward')
             saved += [x, mean, invstd, g, b]
             col += C
@@ -318,7 +330,7 @@ class _BNReLUMaxConcatTrain(torch.autograd.Function):
             g, b = gamma.contiguous().float(), beta.contiguous().float()
             zptr = ctypes.c_void_p(out.data_ptr() + 4 * col)
             check(lib.crb_bn_relu_max_forward(ptr(x), M, ns, C, ptr(g), ptr(b), float(eps), zptr, total, ptr(arg),
-                                              ptr(mean), ptr(var), ptr(invstd), ptr(rm), ptr(rv), float(mom), ptr(ws), wsb,
+                                              ptr(mean), ptr(var), ptr(invstd), ptr(rm), ptr(rv), None, float(mom), ptr(ws), wsb,
                                               ptr(tk), cur_stream(dev)), 'crb_bn_relu_max_forward')
             saved += [x, mean, invstd, g, b, arg]
             col += C

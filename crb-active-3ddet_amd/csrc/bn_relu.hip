@@ -47,6 +47,7 @@ struct BnFinal {
   float* o2;           // forward: invstd
   float* running_mean;
   float* running_var;
+  long long* num_batches_tracked;   // forward: += 1 by the finalizing thread (nn.BatchNorm's counter), nullable
   float momentum, eps;
   int64_t n;
   int bwd;
@@ -131,7 +132,10 @@ __device__ __forceinline__ void bn_ticket_finalize(const float* partial, int nbl
       f.o1[c] = (float)b;
     }
   }
-  if (threadIdx.x == 0) __hip_atomic_store(&f.tickets[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&f.tickets[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (f.num_batches_tracked) *f.num_batches_tracked += 1;
+  }
 }
 
 // partial[(blk * 2 + which) * C + c]; which 0: sum a, 1: sum b
@@ -198,8 +202,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float eps, int bwd, float* __restrict__ o0,
                                                           float* __restrict__ o1, float* __restrict__ o2,
                                                           float* __restrict__ running_mean,
-                                                          float* __restrict__ running_var, float momentum) {
+                                                          float* __restrict__ running_var, float momentum,
+                                                          long long* __restrict__ num_batches_tracked = nullptr) {
   __shared__ double sa[32][8], sb[32][8];
+  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
   const int cl = threadIdx.x & 7, part = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cl;
   double a = 0.0, b = 0.0;
@@ -544,7 +550,8 @@ extern "C" int64_t crb_bn_workspace_bytes(int64_t n, int C) {
 extern "C" int crb_bn_ticket_ints(void) { return 1 + BN_GROUPS; }
 
 static inline BnFinal bn_final(int32_t* tickets, void* workspace, int64_t n, int C, int bwd, float* o0, float* o1, float* o2,
-                               float* running_mean, float* running_var, float momentum, float eps) {
+                               float* running_mean, float* running_var, float momentum, float eps,
+                               int64_t* num_batches_tracked = nullptr) {
   BnFinal f;
   f.tickets = tickets;
   f.group = reinterpret_cast<double*>(static_cast<char*>(workspace) + bn_partial_bytes(n, C));
@@ -553,6 +560,7 @@ static inline BnFinal bn_final(int32_t* tickets, void* workspace, int64_t n, int
   f.o2 = o2;
   f.running_mean = running_mean;
   f.running_var = running_var;
+  f.num_batches_tracked = reinterpret_cast<long long*>(num_batches_tracked);
   f.momentum = momentum;
   f.eps = eps;
   f.n = n;
@@ -563,8 +571,8 @@ static inline BnFinal bn_final(int32_t* tickets, void* workspace, int64_t n, int
 // training forward. mean/var/invstd (C) out. z may alias x? no: x is kept for backward.
 extern "C" int crb_bn_relu_forward(const float* x, int64_t n, int C, const float* gamma, const float* beta, float eps,
                                    int relu, float* z, int64_t z_row_stride, float* mean, float* var, float* invstd,
-                                   float* running_mean, float* running_var, float momentum, void* workspace,
-                                   int64_t workspace_bytes, int32_t* tickets, void* stream) {
+                                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                                   void* workspace, int64_t workspace_bytes, int32_t* tickets, void* stream) {
   const int64_t ld_z = z_row_stride > 0 ? z_row_stride : C;
   if (ld_z < C || (ld_z & 3)) return CRB_ERR_ARG;
   if (n <= 0 || C <= 0 || (C & 3) || C > 1024 || (256 % (C >> 2) && (C >> 2) < 256)) return CRB_ERR_ARG;
@@ -574,10 +582,11 @@ extern "C" int crb_bn_relu_forward(const float* x, int64_t n, int C, const float
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(nblk), dim3(256), 2 * 256 * 16, st, x, nullptr, nullptr, nullptr,
                      nullptr, nullptr, n, C, relu, bn_rows_per_block(n), (int64_t)C, partial, g_bn_order & 1,
-                     bn_final(tickets, workspace, n, C, 0, mean, var, invstd, running_mean, running_var, momentum, eps));
+                     bn_final(tickets, workspace, n, C, 0, mean, var, invstd, running_mean, running_var, momentum, eps,
+                              num_batches_tracked));
   if (!tickets)
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, eps, 0, mean, var,
-                       invstd, running_mean, running_var, momentum);
+                       invstd, running_mean, running_var, momentum, reinterpret_cast<long long*>(num_batches_tracked));
   const int64_t total4 = n * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, z,
                      total4, C, relu, ld_z, (g_bn_order >> 1) & 1);
@@ -629,8 +638,9 @@ extern "C" int crb_bn_relu_backward(const float* x, const float* dz, int64_t dz_
 // attaining the max. workspace: crb_bn_workspace_bytes(groups * ns, C).
 extern "C" int crb_bn_relu_max_forward(const float* x, int64_t groups, int ns, int C, const float* gamma, const float* beta,
                                        float eps, float* zmax, int64_t out_row_stride, int32_t* arg, float* mean, float* var,
-                                       float* invstd, float* running_mean, float* running_var, float momentum,
-                                       void* workspace, int64_t workspace_bytes, int32_t* tickets, void* stream) {
+                                       float* invstd, float* running_mean, float* running_var,
+                                       int64_t* num_batches_tracked, float momentum, void* workspace,
+                                       int64_t workspace_bytes, int32_t* tickets, void* stream) {
   const int64_t n = groups * ns;
   const int64_t ld = out_row_stride > 0 ? out_row_stride : C;
   if (ld < C || (ld & 3) || ns <= 0) return CRB_ERR_ARG;
@@ -641,10 +651,11 @@ extern "C" int crb_bn_relu_max_forward(const float* x, int64_t groups, int ns, i
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(nblk), dim3(256), 2 * 256 * 16, st, x, nullptr, nullptr, nullptr,
                      nullptr, nullptr, n, C, 1, bn_rows_per_block(n), (int64_t)C, partial, 0,
-                     bn_final(tickets, workspace, n, C, 0, mean, var, invstd, running_mean, running_var, momentum, eps));
+                     bn_final(tickets, workspace, n, C, 0, mean, var, invstd, running_mean, running_var, momentum, eps,
+                              num_batches_tracked));
   if (!tickets)
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, eps, 0, mean, var,
-                       invstd, running_mean, running_var, momentum);
+                       invstd, running_mean, running_var, momentum, reinterpret_cast<long long*>(num_batches_tracked));
   const int glanes = 256 / (C >> 2) > 0 ? 256 / (C >> 2) : 1;
   hipLaunchKernelGGL(bn_relu_max_kernel, dim3(crb_cdiv(groups, glanes)), dim3(256), 0, st, x, mean, invstd, gamma, beta,
                      groups, ns, C, zmax, ld, arg);

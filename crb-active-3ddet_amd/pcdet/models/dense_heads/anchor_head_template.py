@@ -173,16 +173,24 @@ class AnchorHeadTemplate(nn.Module):
         anchors = self._flat_anchors().reshape(-1, 7)
         per_frame = _rl.rpn_loss(d['cls_preds'], d['box_preds'], d.get('dir_cls_preds', None), d['box_cls_labels'],
                                  d['box_reg_targets'], anchors, cfg)                       # (B,3)
-        parts = per_frame.sum(0) / B if reduce else per_frame.t()                           # (3) or (3,B)
-        cls_loss, loc_loss = parts[0], parts[1]
-        dir_loss = parts[2] if reduce else parts[2].sum()       # reduce=False: summed over the frames as well, as the reference does
-        first = (lambda v: v) if reduce else (lambda v: v[0])
-        tb = {'rpn_loss_cls': first(cls_loss).detach(), 'rpn_loss_loc': first(loc_loss).detach()}
+        has_dir = d.get('dir_cls_preds', None) is not None
+        if reduce:
+            parts = per_frame.sum(0) / B                                # (3) = the reference's three scalars
+            det = parts.detach()
+            tb = {'rpn_loss_cls': det[0], 'rpn_loss_loc': det[1]}
+            rpn_loss = parts.sum() if has_dir else parts[:2].sum()      # one reduction node in the graph, no per-term selects
+            if has_dir:
+                tb['rpn_loss_dir'] = det[2]
+            tb['rpn_loss'] = rpn_loss.detach()
+            return rpn_loss, tb
+        cls_loss, loc_loss = per_frame[:, 0], per_frame[:, 1]
+        tb = {'rpn_loss_cls': cls_loss[0].detach(), 'rpn_loss_loc': loc_loss[0].detach()}
         rpn_loss = cls_loss + loc_loss
-        if d.get('dir_cls_preds', None) is not None:
+        if has_dir:
+            dir_loss = per_frame[:, 2].sum()       # reduce=False: summed over the frames as well, as the reference does
             tb['rpn_loss_dir'] = dir_loss.detach()
             rpn_loss = rpn_loss + dir_loss
-        tb['rpn_loss'] = first(rpn_loss).detach()
+        tb['rpn_loss'] = rpn_loss[0].detach()
         return rpn_loss, tb
 
     def get_loss(self, reduce=True):

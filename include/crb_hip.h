@@ -402,7 +402,7 @@ int crb_density_greedy(const float* densities, const int32_t* labels, int n_cand
  *           (pcdet/models/backbones_3d/spconv_backbone.py:21-25,73). x,z,dx,dz (n,C) f32, C % 4 == 0 and
  *           (C/4) divides 256 (C = 16,32,64,128,...). Training forward returns batch mean / biased var / invstd;
  *           running_mean / running_var (nullable) are updated in the same launch: r = (1-momentum) r + momentum batch,
- *           variance unbiased (n/(n-1)), as nn.BatchNorm does.
+ *           variance unbiased (n/(n-1)), as nn.BatchNorm does; num_batches_tracked (nullable, one int64) += 1 likewise.
  *           tickets (nullable): crb_bn_ticket_ints() int32 in device memory, ZERO before the first call and left zero by
  *           every call; with it the statistics launch also reduces its per-block partials ("last block done", same
  *           summation order: bit-identical results) and a call is two launches instead of three. One ticket area serves
@@ -413,8 +413,8 @@ int64_t crb_bn_workspace_bytes(int64_t n, int C);
 int crb_bn_ticket_ints(void);
 int crb_bn_relu_forward(const float* x, int64_t n, int C, const float* gamma, const float* beta, float eps,
                         int relu, float* z, int64_t z_row_stride, float* mean, float* var, float* invstd,
-                        float* running_mean, float* running_var, float momentum, void* workspace,
-                        int64_t workspace_bytes, int32_t* tickets, void* stream);
+                        float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                        void* workspace, int64_t workspace_bytes, int32_t* tickets, void* stream);
 int crb_bn_relu_apply(const float* x, int64_t n, int C, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int relu, float* z, int64_t z_row_stride, void* stream);
 /* z_row_stride / dz_row_stride (floats, 0 = C): z may be a channel slice of a wider row-major buffer (the BEV backbone
@@ -431,8 +431,8 @@ int crb_bn_relu_backward(const float* x, const float* dz, int64_t dz_row_stride,
  * (groups, gz_row_stride) and writes the dense dx. workspace: crb_bn_workspace_bytes(groups*ns, C). */
 int crb_bn_relu_max_forward(const float* x, int64_t groups, int ns, int C, const float* gamma, const float* beta, float eps,
                             float* zmax, int64_t out_row_stride, int32_t* arg, float* mean, float* var, float* invstd,
-                            float* running_mean, float* running_var, float momentum, void* workspace,
-                            int64_t workspace_bytes, int32_t* tickets, void* stream);
+                            float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                            void* workspace, int64_t workspace_bytes, int32_t* tickets, void* stream);
 int crb_bn_relu_max_backward(const float* x, const float* gz, int64_t gz_row_stride, const int32_t* arg, int64_t groups,
                              int ns, int C, const float* mean, const float* invstd, const float* gamma, const float* beta,
                              float* dx, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,

@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Which host op launches the small torch kernels of a SECOND training step (fills, copies, integer adds ...): one step
+under torch.profiler with Python stacks, kernels grouped by (kernel name, innermost repo frame)."""
+import os, sys, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'crb-active-3ddet_amd'))
+import numpy as np, torch
+
+if __name__ == '__main__':
+    import bench
+    from pcdet.datasets import SyntheticDataset
+    from pcdet.model_cfgs import second_cfg
+    from pcdet.models import build_network
+    sys.argv = [sys.argv[0]]
+    args = bench.parse()
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    model = build_network(second_cfg().MODEL, 3, SyntheticDataset(num_frames=2, n_points=args.points)).to(dev).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01, fused=True)
+    batches = bench.make_batches(args, 0, dev)
+
+    def step(i):
+        opt.zero_grad(set_to_none=True)
+        ret, tb, _ = model(dict(batches[i % len(batches)]))
+        loss = ret['loss'].mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+        opt.step()
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        step(3)
+        torch.cuda.synchronize()
+    ev = prof.events()
+    rows = collections.defaultdict(lambda: [0, 0.0])
+    for e in ev:
+        if e.device_type != torch.autograd.DeviceType.CPU or not e.name.startswith('aten::'):
+            continue
+        dt = e.self_device_time_total
+        if dt <= 0 or dt > 20:
+            continue
+        chain, q = [], e.cpu_parent
+        while q is not None and len(chain) < 4:
+            chain.append(q.name[:48])
+            q = q.cpu_parent
+        where = ' <- '.join(chain) if chain else '(top level)'
+        r = rows[(e.name, where)]
+        r[0] += 1
+        r[1] += dt
+    out = sorted(rows.items(), key=lambda kv: -kv[1][1])
+    print('aten ops with < 20 us of own device time: %d, %.3f ms' % (sum(v[0] for _, v in out), sum(v[1] for _, v in out) / 1e3))
+    for (op, where), (n, us) in out[:70]:
+        print('%4d x %6.1f us  %-28s %s' % (n, us / n, op, where))
