@@ -270,7 +270,8 @@ struct ConvEpilogue {
   int relu;
 };
 
-template <int CIN, int COUT, bool NOMFMA = false, bool REMAP = true, bool TIMING = false, bool COMPACT = false>
+template <int CIN, int COUT, bool NOMFMA = false, bool REMAP = true, bool TIMING = false, bool COMPACT = false,
+          bool ROWC = false>
 __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                                const int* __restrict__ nbr, const int* __restrict__ perm,
                                                                float* __restrict__ Y, int n_out, int K, int ntiles,
@@ -280,6 +281,7 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
                                                                                               nullptr, 0.f, 0},
                                                                const int* __restrict__ tile_order = nullptr) {
   static_assert(CIN % 16 == 0 && COUT % 16 == 0, "v2 needs whole float4 k-groups and unmasked column blocks");
+  static_assert(!ROWC || CIN == 64, "row-contiguous gathers: a lane group owns 64 B of a 256-B row");
   constexpr int NB = (COUT + 15) / 16;
   constexpr int WS = NB * 16;
   constexpr int KS = CIN / 16;                      // k-groups of 16 channels (4 MFMA k-steps each)
@@ -387,10 +389,30 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
   // Loads are issued unconditionally (invalid rows read row 0 and are zeroed by a select at use): every path through a
   // phase then issues the same number of VMEM loads, so the compiler's in-order vmcnt bookkeeping can leave the prefetch
   // outstanding across the phase instead of draining it at the next control-flow join.
+  // ROWC (CIN = 64): the four lanes of a quad (rows 4q..4q+3 of the tile, same lane group g) read the SAME row per
+  // instruction — 64 contiguous bytes, channels 16g..16g+15 of row 4q+i in instruction i — instead of four rows at one
+  // channel offset: a quarter of the cache-line look-ups per instruction. Lane j then holds piece j of the four rows and
+  // needs the four pieces of row j: a 4x4 transpose of 16-byte elements inside the quad, done on the fly in the MFMA block
+  // (two DPP exchange stages per dword). The channel a lane group feeds to MFMA step (s, t) becomes 16g + 4s + t (it was
+  // 16s + 4g + t); B is read from the matching W row, so the products and their order per output element are unchanged.
   auto load_a = [&](f32x4 (&a)[KS], const float* xbase, int r) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(xbase + (int64_t)(r < 0 ? 0 : r) * CIN + 4 * g);
+    if constexpr (ROWC) {
+      const int rr = r < 0 ? 0 : r;
+      const int j = lane & 3;
+      const int r0q = __builtin_amdgcn_mov_dpp(rr, 0x00, 0xf, 0xf, true);      // quad_perm [i,i,i,i]: row of lane 4q+i
+      const int r1q = __builtin_amdgcn_mov_dpp(rr, 0x55, 0xf, 0xf, true);
+      const int r2q = __builtin_amdgcn_mov_dpp(rr, 0xAA, 0xf, 0xf, true);
+      const int r3q = __builtin_amdgcn_mov_dpp(rr, 0xFF, 0xf, 0xf, true);
+      const float* base = xbase + 16 * g + 4 * j;
+      a[0] = *reinterpret_cast<const f32x4*>(base + (int64_t)r0q * CIN);
+      a[1] = *reinterpret_cast<const f32x4*>(base + (int64_t)r1q * CIN);
+      a[2] = *reinterpret_cast<const f32x4*>(base + (int64_t)r2q * CIN);
+      a[3] = *reinterpret_cast<const f32x4*>(base + (int64_t)r3q * CIN);
+    } else {
+      const f32x4* src = reinterpret_cast<const f32x4*>(xbase + (int64_t)(r < 0 ? 0 : r) * CIN + 4 * g);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) a[s] = src[4 * s];
+      for (int s = 0; s < KS; ++s) a[s] = src[4 * s];
+    }
   };
   auto load_b = [&](float (&b)[4][NB], const float* wl, int s) {
 #pragma unroll
@@ -400,8 +422,54 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
       for (int nb = 0; nb < NB; ++nb) b[t][nb] = src[nb];
     }
   };
+  // dword t of the four raw pieces v[0..3] (piece i = row 4q+i) -> m[s] = dword t of piece s of THIS lane's row
+  auto quad_transpose = [&](const f32x4 (&v)[KS], int t, float (&m)[4]) {
+    const bool odd = lane & 1, hi = lane & 2;
+    auto x1 = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true)); };
+    auto x2 = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true)); };
+    // every exchange is evaluated by ALL lanes before the selects (a DPP read under a lane-dependent branch would see its
+    // source lanes switched off)
+    const float p0 = x1(v[0][t]), p1 = x1(v[1][t]), p2 = x1(v[2][t]), p3 = x1(v[3][t]);
+    const float n0 = odd ? p1 : v[0][t];
+    const float n1 = odd ? v[1][t] : p0;
+    const float n2 = odd ? p3 : v[2][t];
+    const float n3 = odd ? v[3][t] : p2;
+    const float q0 = x2(n0), q1 = x2(n1), q2 = x2(n2), q3 = x2(n3);
+    m[0] = hi ? q2 : n0;
+    m[1] = hi ? q3 : n1;
+    m[2] = hi ? n2 : q0;
+    m[3] = hi ? n3 : q1;
+  };
   auto mfma_block = [&](const f32x4 (&a)[KS], bool valid, const float* wl) {
-    if constexpr (NOMFMA) {                          // measurement build: staging chain only (result is garbage)
+    if constexpr (ROWC && !NOMFMA) {
+      // t-major: the exchange of dword t+1 and the B reads of step t+1 have no dependence on the 16 MFMAs of step t
+      float m[2][4];
+      float b[2][4][NB];
+      auto load_bt = [&](float (&bb)[4][NB], int t) {
+#pragma unroll
+        for (int sgrp = 0; sgrp < 4; ++sgrp) {
+          const float* src = wl + (16 * g + 4 * sgrp + t) * WS + li * NB;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) bb[sgrp][nb] = src[nb];
+        }
+      };
+      quad_transpose(a, 0, m[0]);
+      load_bt(b[0], 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t + 1 < 4) {
+          quad_transpose(a, t + 1, m[(t + 1) & 1]);
+          load_bt(b[(t + 1) & 1], t + 1);
+        }
+#pragma unroll
+        for (int sgrp = 0; sgrp < 4; ++sgrp) {
+          const float av = valid ? m[t & 1][sgrp] : 0.f;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[t & 1][sgrp][nb], acc[nb], 0, 0, 0);
+        }
+      }
+    } else if constexpr (NOMFMA) {                          // measurement build: staging chain only (result is garbage)
 #pragma unroll
       for (int s = 0; s < KS; ++s) acc[0][0] += valid ? a[s][0] + wl[(16 * s + 4 * g) * WS + li * NB] : 0.f;
     } else if constexpr (BDB) {
@@ -1342,6 +1410,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 CRB_KNOB g_subt_override = 0;     // 0 = heuristic; 1/2/4 force (A/B measurements)
+#ifdef CRB_MEASURE
+static int g_fwd_rowc = 0;        // 1 = row-contiguous gathers + in-quad transpose at CIN = 64 (compact-table kernel)
+#endif
 
 template <int CIN, int COUT, int SUBT>
 int launch_fwd_subt(const float* X, const float* W, const int* nbr, const int* perm, float* Y, int64_t n_out, int K,
@@ -1410,6 +1481,19 @@ int launch_fwd_compact(const float* X, const float* W, const unsigned* cmask, co
     const int ntiles = crb_cdiv(n_out, 64);
     const int grid = ((ntiles + 7) / 8) * 8;
     size_t lds = 2 * sizeof(float) * CIN * (((COUT + 15) / 16) * 16) + sizeof(int) * 64 * K + 16;
+#ifdef CRB_MEASURE
+    // measured variant, not in the product library (tools/ab_knob.py crb_sparse_conv_set_rowc: 162.5 vs 147.2 us at L3, 110.6
+    // vs 100.0 us at L4 — the cache-line look-ups it saves are not on this kernel's critical path, its ~100 extra DPP / select
+    // / address operations per phase and their hazards are)
+    if constexpr (CIN == 64) {
+      if (g_fwd_rowc) {
+        hipLaunchKernelGGL((sparse_conv_fwd2_kernel<CIN, COUT, false, true, false, true, true>), dim3(grid), dim3(256), lds, st,
+                           X, W, packed, perm, Y, (int)n_out, K, ntiles, cmask, cbase, ep, tile_order);
+        CRB_CHECK_LAUNCH();
+        return CRB_OK;
+      }
+    }
+#endif
     hipLaunchKernelGGL((sparse_conv_fwd2_kernel<CIN, COUT, false, true, false, true>), dim3(grid), dim3(256), lds, st, X, W,
                        packed, perm, Y, (int)n_out, K, ntiles, cmask, cbase, ep, tile_order);
     CRB_CHECK_LAUNCH();
@@ -1512,6 +1596,11 @@ extern "C" int crb_sparse_conv_supported(int cin, int cout) {
 }
 
 #ifdef CRB_MEASURE
+extern "C" int crb_sparse_conv_set_rowc(int on) {
+  g_fwd_rowc = on ? 1 : 0;
+  return CRB_OK;
+}
+
 extern "C" int crb_sparse_conv_set_subtiles(int subt) {
   // 0 = default (v2 where the shape allows, else v1); 1,2,4 = v1 with that many row tiles per wave; 8 = v2 (A/B runs)
   g_subt_override = (subt == 1 || subt == 2 || subt == 4 || subt == 8 || subt == 9 || subt == 16 || subt == 32) ? subt : 0;

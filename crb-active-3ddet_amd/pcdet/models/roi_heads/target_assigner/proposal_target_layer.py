@@ -49,7 +49,8 @@ class ProposalTargetLayer(nn.Module):
         last = torch.where(nonzero, idx, torch.zeros_like(idx)).max(dim=1, keepdim=True)[0]
         valid = idx <= last
         iou = iou3d_nms_utils.boxes_iou3d_gpu(rois.reshape(B * R, 7)[:, 0:7], gt_boxes.reshape(B * G, -1)[:, 0:7])
-        iou = iou.view(B, R, B, G)[torch.arange(B), :, torch.arange(B)]                     # (B,R,G) block diagonal
+        ar = torch.arange(B, device=rois.device)
+        iou = iou.view(B, R, B, G)[ar, :, ar]                                               # (B,R,G) block diagonal
         same = (roi_labels[:, :, None] == gt_boxes[:, None, :, -1].long()) & valid[:, None, :]
         iou = torch.where(same, iou, iou.new_full((), -1.0))
         mx, arg = iou.max(dim=2)

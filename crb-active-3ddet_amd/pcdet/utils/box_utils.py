@@ -5,13 +5,26 @@ import torch
 from . import common_utils
 
 
+_CONSTANTS = {}
+
+
+def _constant(like, key, values):
+    """small constant tensor on like's device / dtype, uploaded once (a new_tensor(list) per call is a pageable host-to-device
+    copy = a host synchronisation in the middle of a training step)"""
+    k = (key, like.device, like.dtype)
+    t = _CONSTANTS.get(k)
+    if t is None:
+        t = _CONSTANTS[k] = like.new_tensor(values)
+    return t
+
+
 def boxes_to_corners_3d(boxes3d):
     """(N,7) -> (N,8,3) corner order of box_utils.py:58-80"""
     boxes3d, is_numpy = common_utils.check_numpy_to_torch(boxes3d)
-    template = boxes3d.new_tensor((
-        [1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1],
-        [1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1],
-    )) / 2
+    template = _constant(boxes3d, 'corner_template', (
+        [0.5, 0.5, -0.5], [0.5, -0.5, -0.5], [-0.5, -0.5, -0.5], [-0.5, 0.5, -0.5],
+        [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [-0.5, -0.5, 0.5], [-0.5, 0.5, 0.5],
+    ))
     corners3d = boxes3d[:, None, 3:6].repeat(1, 8, 1) * template[None, :, :]
     corners3d = common_utils.rotate_points_along_z(corners3d.view(-1, 8, 3), boxes3d[:, 6]).view(-1, 8, 3)
     corners3d += boxes3d[:, None, 0:3]
@@ -21,7 +34,7 @@ def boxes_to_corners_3d(boxes3d):
 def enlarge_box3d(boxes3d, extra_width=(0, 0, 0)):
     boxes3d, is_numpy = common_utils.check_numpy_to_torch(boxes3d)
     large = boxes3d.clone()
-    large[:, 3:6] += boxes3d.new_tensor(extra_width)[None, :]
+    large[:, 3:6] += _constant(boxes3d, ('extra_width',) + tuple(float(w) for w in extra_width), extra_width)[None, :]
     return large
 
 

@@ -26,6 +26,9 @@ int crb_sparse_conv_bf16x3_set_mode(int mode);
 /* kernel-variant knob for A/B measurements only: 0 = default (v2 kernel where Cin,Cout are multiples of 16 and Cin <= 64,
  * else v1); 1|2|4 = v1 with 64*subt rows per workgroup; 8 = v2. Results are identical up to f32 summation order. */
 int crb_sparse_conv_set_subtiles(int subt);
+/* A/B: 1 = row-contiguous gathers + in-quad DPP transpose in the compact-table kernel at Cin = 64 (same products, another
+ * grouping of the channels over the MFMA steps: equal to f32 rounding, not bit-equal) */
+int crb_sparse_conv_set_rowc(int on);
 /* measurement builds: after launches under crb_sparse_conv_set_subtiles(32) (64x64 kernel with s_memtime accounting), copy the
  * 16 accumulated counters to host memory and clear them: [0] waves [1] total cycles [2] prologue [3] load issue [4] MFMA
  * block [5] W store [6] barrier wait [7] epilogue [8] phases [9] phases with MFMA work [10] W fetch issue [11] row-index

@@ -10,15 +10,19 @@ import numpy as np, torch
 if __name__ == '__main__':
     import bench
     from pcdet.datasets import SyntheticDataset
-    from pcdet.model_cfgs import second_cfg
+    from pcdet.model_cfgs import second_cfg, pv_rcnn_cfg
     from pcdet.models import build_network
+    which = sys.argv[1] if len(sys.argv) > 1 else 'second'
     sys.argv = [sys.argv[0]]
     args = bench.parse()
     dev = torch.device('cuda', 0)
     torch.manual_seed(0)
-    model = build_network(second_cfg().MODEL, 3, SyntheticDataset(num_frames=2, n_points=args.points)).to(dev).train()
+    cfg = pv_rcnn_cfg() if which == 'pvrcnn' else second_cfg()
+    model = build_network(cfg.MODEL, 3, SyntheticDataset(num_frames=2, n_points=args.points)).to(dev).train()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01, fused=True)
     batches = bench.make_batches(args, 0, dev)
+    for b in batches:
+        b['point_frame_counts_host'] = np.diff(b['point_frame_offsets'].cpu().numpy()).tolist()
 
     def step(i):
         opt.zero_grad(set_to_none=True)
@@ -43,7 +47,7 @@ if __name__ == '__main__':
         if dt <= 0 or dt > 20:
             continue
         chain, q = [], e.cpu_parent
-        while q is not None and len(chain) < 4:
+        while q is not None and len(chain) < 5:
             chain.append(q.name[:48])
             q = q.cpu_parent
         where = ' <- '.join(chain) if chain else '(top level)'
@@ -52,5 +56,5 @@ if __name__ == '__main__':
         r[1] += dt
     out = sorted(rows.items(), key=lambda kv: -kv[1][1])
     print('aten ops with < 20 us of own device time: %d, %.3f ms' % (sum(v[0] for _, v in out), sum(v[1] for _, v in out) / 1e3))
-    for (op, where), (n, us) in out[:70]:
+    for (op, where), (n, us) in out[:110]:
         print('%4d x %6.1f us  %-28s %s' % (n, us / n, op, where))
