@@ -168,10 +168,11 @@ __global__ __launch_bounds__(256) void pairwise_kernel(const float* __restrict__
 template <bool ROTATED>
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ counts,
                                                       int nmax, float thresh, unsigned long long* __restrict__ mask,
-                                                      int col_blocks) {
+                                                      int col_blocks, int nlimit, const int* __restrict__ done) {
   const int row_blk = blockIdx.y, col_blk = blockIdx.x, f = blockIdx.z;
   if (row_blk > col_blk) return;                       // never read by the greedy scan
-  const int n = counts ? min(counts[f], nmax) : nmax;
+  if (done && done[f]) return;                         // the prefix stage already holds this frame's result
+  const int n = min(counts ? min(counts[f], nmax) : nmax, nlimit);
   if (row_blk * 64 >= n || col_blk * 64 >= n) return;
   const float* fb = boxes + (int64_t)f * nmax * 7;
   __shared__ float cb[64 * 7];
@@ -217,9 +218,12 @@ constexpr int kMaxWordsPerLane = 8;   // up to 64*8*64 = 32768 boxes
 
 __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
                                                       const int* __restrict__ counts, int nmax, int col_blocks,
-                                                      int max_keep, int* __restrict__ keep, int* __restrict__ num_keep) {
+                                                      int max_keep, int* __restrict__ keep, int* __restrict__ num_keep,
+                                                      int nlimit, int* __restrict__ done, int prefix_stage) {
   const int f = blockIdx.x, lane = threadIdx.x;
-  const int n = counts ? min(counts[f], nmax) : nmax;
+  if (done && !prefix_stage && done[f]) return;
+  const int n_all = counts ? min(counts[f], nmax) : nmax;
+  const int n = min(n_all, nlimit);
   const unsigned long long* fm = mask + (int64_t)f * nmax * col_blocks;
   int* fk = keep + (int64_t)f * max_keep;
   unsigned long long rem[kMaxWordsPerLane];
@@ -257,7 +261,12 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
     }
   }
   for (int k = nk + lane; k < max_keep; k += 64) fk[k] = -1;
-  if (lane == 0) num_keep[f] = nk;
+  if (lane == 0) {
+    num_keep[f] = nk;
+    // prefix stage: the greedy pick of box i depends on the kept boxes before i only, so the first max_keep picks among the
+    // first nlimit boxes ARE the answer once max_keep is reached (or the frame has no further box)
+    if (prefix_stage) done[f] = (nk >= max_keep || n_all <= nlimit) ? 1 : 0;
+  }
 }
 
 }  // namespace
@@ -275,9 +284,19 @@ extern "C" int crb_boxes_pairwise(const float* boxes_a, int64_t na, const float*
   return CRB_OK;
 }
 
+// prefix stage of the batched NMS: with max_keep << nmax (training proposals: 512 of 9,000, threshold 0.8 — nearly every box
+// survives, the scan is over after ~600 rows) only the leading block of the suppression matrix is ever read. Stage A computes
+// and scans the first nms_prefix(..) boxes; frames that reached max_keep there (or have no more boxes) are final, the full
+// matrix is computed only for the others (their workgroups of stage B leave at once otherwise). Same picks by construction.
+static inline int nms_prefix(int64_t nmax, int max_keep) {
+  int64_t p = ((int64_t)max_keep * 2 + 63) / 64 * 64;
+  if (p < 1024) p = 1024;
+  return nmax >= 2 * p ? (int)p : 0;                   // 0 = single stage
+}
+
 extern "C" int64_t crb_nms_workspace_bytes(int B, int64_t nmax) {
   int64_t cb = (nmax + 63) / 64;
-  return (int64_t)B * nmax * cb * 8 + 256;
+  return crb_align_up((int64_t)B * nmax * cb * 8, 256) + crb_align_up((int64_t)B * 4, 256) + 256;
 }
 
 extern "C" int crb_nms_batched(const float* boxes_sorted, const int32_t* counts, int B, int64_t nmax, float thresh,
@@ -294,12 +313,30 @@ extern "C" int crb_nms_batched(const float* boxes_sorted, const int32_t* counts,
   if (workspace_bytes < crb_nms_workspace_bytes(B, nmax) - 256 || !workspace) return CRB_ERR_WORKSPACE;
   const int cb = (int)((nmax + 63) / 64);
   unsigned long long* mask = (unsigned long long*)workspace;
+  int* done = reinterpret_cast<int*>(static_cast<char*>(workspace) + crb_align_up((int64_t)B * nmax * cb * 8, 256));
+  const int prefix = nms_prefix(nmax, max_keep);
+  if (prefix) {
+    const int cbp = prefix / 64;
+    dim3 gp(cbp, cbp, B);
+    if (rotated)
+      hipLaunchKernelGGL(nms_mask_kernel<true>, gp, dim3(64), 0, st, boxes_sorted, counts, (int)nmax, thresh, mask, cb, prefix,
+                         (const int*)nullptr);
+    else
+      hipLaunchKernelGGL(nms_mask_kernel<false>, gp, dim3(64), 0, st, boxes_sorted, counts, (int)nmax, thresh, mask, cb, prefix,
+                         (const int*)nullptr);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, st, mask, counts, (int)nmax, cb, max_keep, keep, num_keep, prefix,
+                       done, 1);
+  }
+  const int* done_in = prefix ? done : nullptr;
   dim3 grid(cb, cb, B);
   if (rotated)
-    hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(64), 0, st, boxes_sorted, counts, (int)nmax, thresh, mask, cb);
+    hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(64), 0, st, boxes_sorted, counts, (int)nmax, thresh, mask, cb,
+                       (int)nmax, done_in);
   else
-    hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(64), 0, st, boxes_sorted, counts, (int)nmax, thresh, mask, cb);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, st, mask, counts, (int)nmax, cb, max_keep, keep, num_keep);
+    hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(64), 0, st, boxes_sorted, counts, (int)nmax, thresh, mask, cb,
+                       (int)nmax, done_in);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, st, mask, counts, (int)nmax, cb, max_keep, keep, num_keep,
+                     (int)nmax, prefix ? done : (int*)nullptr, 0);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

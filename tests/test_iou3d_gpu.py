@@ -95,6 +95,43 @@ def test_nms_normal_and_batched_padded(dev):
     np.testing.assert_array_equal(idx.cpu().numpy()[valid.cpu().numpy()], r)
 
 
+def test_batched_nms_prefix_stage_gives_the_full_scan_picks(dev):
+    """max_keep << nmax (training proposals: 512 of 9,000): crb_nms_batched first scans the leading 1,024 boxes and computes the
+    full suppression matrix only for frames that have not reached max_keep there. Three frames in one call: (0) spread boxes —
+    final after the prefix stage; (1) ~25 objects with 160 jittered copies each — far fewer than max_keep survive the prefix,
+    the full stage decides; (2) fewer boxes than the prefix. Picks identical to the oracle's sequential NMS."""
+    from pcdet.ops.iou3d_nms import iou3d_nms_utils as U
+    rng = np.random.default_rng(11)
+    N, keep_n, thresh = 4096, 128, 0.3
+    frames = []
+    b0, s0 = detection_boxes(rng, N, n_obj=1500)
+    frames.append(b0[np.argsort(-s0, kind='stable')])
+    centres, _ = detection_boxes(rng, 25, n_obj=25)
+    b1 = np.repeat(centres, 164, axis=0)[:N].copy()
+    b1[:, :2] += rng.normal(0, 0.15, (N, 2)).astype(np.float32)
+    b1[:, 6] += rng.normal(0, 0.05, N).astype(np.float32)
+    frames.append(b1[rng.permutation(N)])
+    b2, s2 = detection_boxes(rng, N, n_obj=300)
+    frames.append(b2[np.argsort(-s2, kind='stable')])
+    counts = np.array([N, N, 900], np.int32)
+    boxes = np.zeros((3, N, 7), np.float32)
+    refs = []
+    for f, b in enumerate(frames):
+        ok = _margin_safe(b[:counts[f]], thresh)
+        bb = b[:counts[f]][ok]
+        counts[f] = len(bb)
+        boxes[f, :len(bb)] = bb
+        refs.append(oracle.nms(bb, thresh)[:keep_n])
+    assert len(refs[0]) == keep_n and refs[0][-1] < 1024            # frame 0 is decided inside the prefix
+    assert len(refs[1]) < keep_n or refs[1][-1] >= 1024            # frame 1 needs rows beyond it
+    keep, num = U.nms_batched(_t(boxes, dev), _t(counts, dev), thresh, keep_n, rotated=True)
+    keep, num = keep.cpu().numpy(), num.cpu().numpy()
+    for f in range(3):
+        assert num[f] == len(refs[f]), (f, num[f], len(refs[f]))
+        np.testing.assert_array_equal(keep[f, :num[f]], refs[f])
+        assert (keep[f, num[f]:] == -1).all()
+
+
 def test_model_nms_utils_contract(dev):
     """class_agnostic_nms / multi_classes_nms (model_nms_utils.py:6-66): selected indices refer to the INPUT arrays, scores come
     back with them, per-class results are concatenated in class order — checked against the oracle NMS applied to the
