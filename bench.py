@@ -74,10 +74,10 @@ def make_batches(args, rank, device, first=0):
 
 def pmc_traffic(cin, cout):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (bench.py cannot collect counters on itself:
-    they come from `bash tools/pmc_sparse_conv.sh`, summarised in profiles/r01_pmc_sparse_conv_fwd.json); None if the
+    they come from `bash tools/pmc_sparse_conv.sh`, summarised in profiles/r0N_pmc_sparse_conv_fwd.json, newest round first); None if the
     summary is for another kernel instance"""
     d = None
-    for name in ('r02_pmc_sparse_conv_fwd.json', 'r01_pmc_sparse_conv_fwd.json'):
+    for name in ('r03_pmc_sparse_conv_fwd.json', 'r02_pmc_sparse_conv_fwd.json', 'r01_pmc_sparse_conv_fwd.json'):
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', name)))
             break
