@@ -97,6 +97,7 @@ def _frames_forward(x, off, bn, relu, out=None, col=0):
                                          ptr(bn.bias.contiguous().float()), float(bn.eps), int(relu), zp, ld,
                                          ptr(bn.running_mean), ptr(bn.running_var), float(bn.momentum), ptr(ws), wsb,
                                          cur_stream(x.device)), 'crb_bn_relu_forward_frames')
+    _touch(bn.running_mean, bn.running_var)
     return z
 
 
@@ -124,6 +125,7 @@ class _BNReLUTrain(torch.autograd.Function):
         check(lib.crb_bn_relu_forward(ptr(x), n, C, ptr(g), ptr(b), float(eps), int(relu), ptr(z), 0, ptr(mean), ptr(var),
                                       ptr(invstd), ptr(running_mean), ptr(running_var), ptr(nbt), float(momentum), ptr(ws),
                                       wsb, ptr(tk), cur_stream(dev)), 'crb_bn_relu_forward')
+        _touch(running_mean, running_var, nbt)
         ctx.save_for_backward(x, mean, invstd, g, b)
         ctx.relu = int(relu)
         ctx.mark_non_differentiable(mean, var)
@@ -143,6 +145,28 @@ class _BNReLUTrain(torch.autograd.Function):
         check(lib.crb_bn_relu_backward(ptr(x), ptr(dz), 0, n, C, ptr(mean), ptr(invstd), ptr(g), ptr(b), ctx.relu, ptr(dx),
                                        ptr(dgamma), ptr(dbeta), ptr(ws), wsb, ptr(tk), cur_stream(dev)), 'crb_bn_relu_backward')
         return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def _touch(*tensors):
+    """tensors a kernel wrote through their raw pointers (running statistics, the batch counter): bump their version counters
+    as an in-place torch op would — the eval-time caches (folded Conv+BN weights, rsqrt(running_var + eps)) are keyed on them"""
+    ts = [t for t in tensors if t is not None]
+    if ts:
+        torch._C._autograd._unsafe_set_version_counter(ts, [t._version + 1 for t in ts])
+
+
+def _invstd(bn):
+    """rsqrt(running_var + eps) of an eval-mode BatchNorm, cached on the module and keyed on the buffer's address and version
+    (load_state_dict / a training step / .to() change the key): two tiny launches per layer and batch otherwise"""
+    rv = bn.running_var
+    key = (rv.data_ptr(), rv._version, float(bn.eps))
+    hit = bn.__dict__.get('_crb_invstd')
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    with torch.no_grad():
+        val = torch.rsqrt(rv + bn.eps)
+    bn.__dict__['_crb_invstd'] = (key, val)
+    return val
 
 
 def _counter(bn):
@@ -185,7 +209,7 @@ def bn_relu(x, bn, relu=True):
         z = torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
         return torch.relu(z) if relu else z
     x = x.contiguous()
-    invstd = torch.rsqrt(bn.running_var + bn.eps)
+    invstd = _invstd(bn)
     z = torch.empty_like(x)
     check(lib.crb_bn_relu_apply(ptr(x), n, C, ptr(bn.running_mean.contiguous()), ptr(invstd), ptr(bn.weight.contiguous()),
                                 ptr(bn.bias.contiguous()), int(relu), ptr(z), 0, cur_stream(x.device)), 'crb_bn_relu_apply')
@@ -198,7 +222,7 @@ def bn_apply_(x, bn, relu=True):
     require_cuda(x)
     n, C = x.shape
     assert x.is_contiguous()
-    invstd = torch.rsqrt(bn.running_var + bn.eps)
+    invstd = _invstd(bn)
     check(lib.crb_bn_relu_apply(ptr(x), n, C, ptr(bn.running_mean.contiguous()), ptr(invstd), ptr(bn.weight.contiguous()),
                                 ptr(bn.bias.contiguous()), int(relu), ptr(x), 0, cur_stream(x.device)), 'crb_bn_relu_apply')
     return x
@@ -211,7 +235,7 @@ def bn_apply_into(x, bn, relu, out, col):
     require_cuda(x, out)
     n, C = x.shape
     assert x.is_contiguous() and out.is_contiguous() and out.shape[0] == n and col + C <= out.shape[1]
-    invstd = torch.rsqrt(bn.running_var + bn.eps)
+    invstd = _invstd(bn)
     check(lib.crb_bn_relu_apply(ptr(x), n, C, ptr(bn.running_mean.contiguous()), ptr(invstd), ptr(bn.weight.contiguous()),
                                 ptr(bn.bias.contiguous()), int(relu), ctypes.c_void_p(out.data_ptr() + 4 * col),
                                 out.shape[1], cur_stream(x.device)), 'crb_bn_relu_apply')
@@ -246,6 +270,7 @@ class _BNReLUConcatTrain(torch.autograd.Function):
             check(lib.crb_bn_relu_forward(ptr(x), n, C, ptr(g), ptr(b), float(eps), int(relu), zptr, total, ptr(mean),
                                           ptr(var), ptr(invstd), ptr(rm), ptr(rv), None, float(mom), ptr(ws), wsb, ptr(tk),
                                           cur_stream(dev)), 'crb_bn_relu_forward')
+            _touch(rm, rv)
             saved += [x, mean, invstd, g, b]
             col += C
         ctx.save_for_backward(*saved)
@@ -332,6 +357,7 @@ class _BNReLUMaxConcatTrain(torch.autograd.Function):
             check(lib.crb_bn_relu_max_forward(ptr(x), M, ns, C, ptr(g), ptr(b), float(eps), zptr, total, ptr(arg),
                                               ptr(mean), ptr(var), ptr(invstd), ptr(rm), ptr(rv), None, float(mom), ptr(ws), wsb,
                                               ptr(tk), cur_stream(dev)), 'crb_bn_relu_max_forward')
+            _touch(rm, rv)
             saved += [x, mean, invstd, g, b, arg]
             col += C
         ctx.save_for_backward(*saved)
@@ -389,6 +415,7 @@ def bn_relu_max_concat(xs, nss, bns):
                                                          ptr(bn.running_mean), ptr(bn.running_var), float(bn.momentum),
                                                          ptr(ws), wsb, cur_stream(x.device)),
                       'crb_bn_relu_max_forward_frames')
+                _touch(bn.running_mean, bn.running_var)
                 col += C
             return out
         with frame_groups(1):

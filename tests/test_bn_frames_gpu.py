@@ -99,3 +99,28 @@ def test_ticket_finalize_is_bit_identical_to_the_separate_finalize_launch(dev, n
     assert len(bnrelu._ticket_areas) >= 1
     for t in bnrelu._ticket_areas.values():
         assert int(t.abs().sum()) == 0
+
+
+def test_kernel_side_updates_of_the_running_statistics_invalidate_the_eval_caches(dev):
+    """the running statistics and the batch counter are written by the kernels through raw pointers; their version counters are
+    bumped like an in-place torch op would, so what is cached for eval mode on (address, version) — rsqrt(running_var + eps),
+    folded Conv+BN weights — is rebuilt after a training step: eval output equals torch's own BatchNorm on the updated buffers"""
+    from crbhip import bnrelu
+    C = 64
+    bn = _bn(C, dev, 3)
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.randn(5000, C, device=dev, generator=g) * 3 + 1
+    bn.eval()
+    with torch.no_grad():
+        z0 = bnrelu.bn_relu(x, bn, True)                       # fills the eval cache
+    v0 = (bn.running_mean._version, bn.running_var._version, int(bn.num_batches_tracked))
+    bn.train()
+    bnrelu.bn_relu(x.clone().requires_grad_(True), bn, True)  # one training forward: kernels update the buffers
+    assert bn.running_mean._version > v0[0] and bn.running_var._version > v0[1]
+    assert int(bn.num_batches_tracked) == v0[2] + 1
+    bn.eval()
+    with torch.no_grad():
+        z1 = bnrelu.bn_relu(x, bn, True)
+        ref = torch.relu(torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps))
+    assert not torch.equal(z0, z1)
+    assert float((z1 - ref).abs().max()) <= 1e-5 * float(ref.abs().max())

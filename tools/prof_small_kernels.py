@@ -17,6 +17,18 @@ if __name__ == '__main__':
     args = bench.parse()
     dev = torch.device('cuda', 0)
     torch.manual_seed(0)
+    if which == 'score':
+        from pcdet.datasets import build_synthetic_dataloader
+        from pcdet.query_strategies import build_strategy
+        cfg = pv_rcnn_cfg()
+        pool = SyntheticDataset(num_frames=48, first_frame=5000, n_points=20000, training=False)
+        lab = SyntheticDataset(num_frames=2, n_points=20000)
+        model = build_network(cfg.MODEL, 3, pool).to(dev)
+        strat = build_strategy('crb', model, build_synthetic_dataloader(lab, 2), build_synthetic_dataloader(pool, 16), 0, '/tmp', cfg)
+        sb = list(strat.upload_pool_batches(list(range(48)), 16))
+        strat.score_device_batches(sb[:2])
+        torch.cuda.synchronize()
+        step = lambda i: strat.score_device_batches(sb[2:3])
     cfg = pv_rcnn_cfg() if which == 'pvrcnn' else second_cfg()
     model = build_network(cfg.MODEL, 3, SyntheticDataset(num_frames=2, n_points=args.points)).to(dev).train()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01, fused=True)
@@ -24,13 +36,15 @@ if __name__ == '__main__':
     for b in batches:
         b['point_frame_counts_host'] = np.diff(b['point_frame_offsets'].cpu().numpy()).tolist()
 
-    def step(i):
+    def train_step(i):
         opt.zero_grad(set_to_none=True)
         ret, tb, _ = model(dict(batches[i % len(batches)]))
         loss = ret['loss'].mean()
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
         opt.step()
+    if which != 'score':
+        step = train_step
     for i in range(3):
         step(i)
     torch.cuda.synchronize()
