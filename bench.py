@@ -50,6 +50,10 @@ def parse():
                     help='unlabeled pool size of the CRB stage-1 scoring measurement (BASELINE configs[3]: 3,000 frames, '
                          'rank-strided shard per GPU; 0 = skip)')
     ap.add_argument('--scoring-repeats', type=int, default=3)
+    ap.add_argument('--scoring-batch', type=int, default=64,
+                    help='frames per scoring batch: an eval-mode pass scores every frame on its own, the batch size is the '
+                         "caller's loader setting; ~4 ms of every pass are per-batch costs (table plan, small launches, idle): "
+                         '16 -> 545, 32 -> 596, 64 -> 624, 128 -> 618 frames/s')
     ap.add_argument('--pvrcnn-steps', type=int, default=12, help='PV-RCNN fwd+bwd+AdamW steps (configs[2]; 0 = skip)')
     return ap.parse_args()
 
@@ -294,7 +298,7 @@ def crb_scoring_bench(args, rank, world, device):
     torch.manual_seed(0)
     cfg = pv_rcnn_cfg()
     n = args.scoring_pool
-    bs = 16
+    bs = args.scoring_batch
     pool = SyntheticDataset(num_frames=n, first_frame=5000, n_points=args.points, training=False)
     lab = SyntheticDataset(num_frames=2, n_points=args.points)
     model = build_network(cfg.MODEL, 3, pool).to(device)
@@ -375,7 +379,8 @@ def crb_scoring_bench(args, rank, world, device):
             'value': round(n / med, 3), 'unit': 'frames/s',
             'config': {'workload': 'BASELINE configs[3]: pool of %d synthetic KITTI frames x %d pts, rank-strided shard of %d '
                                    'frames per GPU, batches of %d resident in HBM' % (n, args.points, per, bs),
-                       'pool_frames': n, 'frames_per_gpu': per, 'n_gpus': world, 'repeats': len(times)},
+                       'pool_frames': n, 'frames_per_gpu': per, 'n_gpus': world, 'repeats': len(times),
+                       'frames_per_batch': bs},
             'seconds': _pctl(times), 'seconds_all': [round(t, 3) for t in times],
             'through_loader': {'value': round(n / dt_loader, 3), 'unit': 'frames/s', 'seconds': round(dt_loader, 3),
                                'loader_workers': workers,

@@ -29,6 +29,17 @@ if __name__ == '__main__':
         strat.score_device_batches(sb[:2])
         torch.cuda.synchronize()
         step = lambda i: strat.score_device_batches(sb[2:3])
+        # module-level attribution: every top-level module of the chain and the record packing run under a named range
+        from torch.profiler import record_function
+        from pcdet.query_strategies import crb_sampling as _cs
+        for name, mod in model.named_children():
+            mod.register_forward_pre_hook(lambda m, a, _n=name: m.__dict__.__setitem__('_rf', record_function('MOD:' + _n).__enter__()))
+            mod.register_forward_hook(lambda m, a, o: m.__dict__.pop('_rf').__exit__(None, None, None))
+        _orig = _cs.crb_frame_records
+        def _wrapped(*a, **k):
+            with record_function('MOD:crb_frame_records'):
+                return _orig(*a, **k)
+        _cs.crb_frame_records = _wrapped
     cfg = pv_rcnn_cfg() if which == 'pvrcnn' else second_cfg()
     model = build_network(cfg.MODEL, 3, SyntheticDataset(num_frames=2, n_points=args.points)).to(dev).train()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01, fused=True)
@@ -62,8 +73,18 @@ if __name__ == '__main__':
             continue
         chain, q = [], e.cpu_parent
         while q is not None and len(chain) < 5:
+            if q.name.startswith('MOD:'):
+                chain = [q.name]
+                break
             chain.append(q.name[:48])
             q = q.cpu_parent
+        if which == 'score' and chain and not chain[0].startswith('MOD:'):
+            q2 = e.cpu_parent
+            while q2 is not None:
+                if q2.name.startswith('MOD:'):
+                    chain = [q2.name]
+                    break
+                q2 = q2.cpu_parent
         where = ' <- '.join(chain) if chain else '(top level)'
         r = rows[(e.name, where)]
         r[0] += 1
