@@ -50,6 +50,7 @@ def parse():
                     help='unlabeled pool size of the CRB stage-1 scoring measurement (BASELINE configs[3]: 3,000 frames, '
                          'rank-strided shard per GPU; 0 = skip)')
     ap.add_argument('--scoring-repeats', type=int, default=3)
+    ap.add_argument('--stage2-batch', type=int, default=0, help='frames per train-mode stage-2 pass (0 = ACTIVE_CONFIG.STAGE2_BATCH)')
     ap.add_argument('--scoring-batch', type=int, default=64,
                     help='frames per scoring batch: an eval-mode pass scores every frame on its own, the batch size is the '
                          "caller's loader setting; ~4 ms of every pass are per-batch costs (table plan, small launches, idle): "
@@ -361,8 +362,11 @@ def crb_scoring_bench(args, rank, world, device):
     # embeddings — 16 frames per train-mode pass with per-frame BatchNorm statistics, frames re-read through the loader —
     # k-means++ to K2 N = 300 prototypes with the device restatement of sklearn's seeding, greedy KDE balance to N = 100)
     strat.prototype = 'kmeans++_device'
+    if args.stage2_batch > 0:
+        strat.stage2_batch = args.stage2_batch
     warm = strat.score_pool(mine[:bs], bs)
-    strat.grad_embeddings_batched(mine[:bs], warm, strat.stage2_batch)          # MIOpen train-mode solver search
+    strat.grad_embeddings_batched(mine[:max(bs, strat.stage2_batch)][:strat.stage2_batch], warm[:strat.stage2_batch],
+                                  strat.stage2_batch)                              # MIOpen train-mode solver search
     _, dt_sel = timed(lambda: strat.select_from_records(rec))
     strat.close()
     torch.set_num_threads(host_threads)
