@@ -31,6 +31,12 @@ MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense f32-input MFMA (exac
 MFMA_BF16_PEAK_TF = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
+# gradient buckets of the DDP wrappers: SECOND has 21 MB of gradients, i.e. ONE default (25 MB) bucket whose all-reduce would
+# start after the last backward kernel; 4 MB buckets go out while the BEV backbone's backward is still running (xGMI ring:
+# ~30-50 us of latency per call, hidden) and leave only the sparse backbone's ~3 MB for the end of the step
+DDP_BUCKET_MB = 4
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -413,7 +419,8 @@ def pvrcnn_bench(args, rank, world, device):
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01, fused=True)
     net = model
     if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=True)
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=True,
+                                                        bucket_cap_mb=DDP_BUCKET_MB)
     batches = make_batches(args, rank, device, first=20000)
     for b in batches:
         b['point_frame_counts_host'] = np.diff(b['point_frame_offsets'].cpu().numpy()).tolist()
@@ -490,7 +497,8 @@ def main():
     opt = torch.optim.AdamW(model.parameters(), lr=3e-3, weight_decay=0.01, betas=(0.9, 0.99), fused=True)   # one multi-tensor kernel (0.23 vs 0.42 ms for the 84 tensors)
     net = model
     if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_idx], gradient_as_bucket_view=True)
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_idx], gradient_as_bucket_view=True,
+                                                        bucket_cap_mb=DDP_BUCKET_MB)
     batches = make_batches(args, rank, device)
 
     def step(i, optimizer=True):
