@@ -24,6 +24,7 @@ class AnchorHeadSingle(AnchorHeadTemplate):
             self.conv_dir_cls = nn.Conv2d(input_channels, n * self.model_cfg.NUM_DIR_BINS, kernel_size=1)
         else:
             self.conv_dir_cls = None
+        self.lazy_box_decode = False      # set by a detector whose RoI head reads the RPN boxes through proposal_layer only
         self.init_weights()
 
     def init_weights(self):
@@ -64,11 +65,19 @@ class AnchorHeadSingle(AnchorHeadTemplate):
         if self.training:
             self.forward_ret_dict.update(self.assign_targets(gt_boxes=data_dict['gt_boxes']))
         if not self.training or self.predict_boxes_when_training:
-            batch_cls_preds, batch_box_preds = self.generate_predicted_boxes(
-                batch_size=data_dict['batch_size'], cls_preds=cls_preds, box_preds=box_preds,
-                dir_cls_preds=dir_cls_preds)
+            B = data_dict['batch_size']
             data_dict['rpn_preds'] = cls_preds
-            data_dict['batch_cls_preds'] = batch_cls_preds
-            data_dict['batch_box_preds'] = batch_box_preds
             data_dict['cls_preds_normalized'] = False
+            if self.lazy_box_decode:
+                # a RoI head follows: its proposal layer decodes the top-k anchors it keeps (batch_box_decoder), the other
+                # ~200,000 boxes per frame are never formed
+                data_dict['batch_cls_preds'] = cls_preds.view(B, -1, self.num_class).float()
+                data_dict['batch_box_decoder'] = lambda idx: self.generate_predicted_boxes(
+                    batch_size=B, cls_preds=cls_preds, box_preds=box_preds, dir_cls_preds=dir_cls_preds, anchor_idx=idx)[1]
+                data_dict.pop('batch_box_preds', None)
+            else:
+                batch_cls_preds, batch_box_preds = self.generate_predicted_boxes(
+                    batch_size=B, cls_preds=cls_preds, box_preds=box_preds, dir_cls_preds=dir_cls_preds)
+                data_dict['batch_cls_preds'] = batch_cls_preds
+                data_dict['batch_box_preds'] = batch_box_preds
         return data_dict

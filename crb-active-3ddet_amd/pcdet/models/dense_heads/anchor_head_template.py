@@ -205,16 +205,27 @@ class AnchorHeadTemplate(nn.Module):
         tb['rpn_loss'] = (rpn_loss if reduce else rpn_loss[0]).detach()
         return rpn_loss, tb
 
-    def generate_predicted_boxes(self, batch_size, cls_preds, box_preds, dir_cls_preds=None):
-        """cls (B,H,W,C1), box (B,H,W,C2), dir (B,H,W,C3) -> (B,A,num_class), (B,A,7+C)  (anchor_head_template.py:238-285)"""
+    def generate_predicted_boxes(self, batch_size, cls_preds, box_preds, dir_cls_preds=None, anchor_idx=None):
+        """cls (B,H,W,C1), box (B,H,W,C2), dir (B,H,W,C3) -> (B,A,num_class), (B,A,7+C)  (anchor_head_template.py:238-285).
+        anchor_idx (B,k) long: decode ONLY those anchors -> (B,A,num_class), (B,k,7+C) — the rows the full decode would hold at
+        these indices (the decode is elementwise per anchor). A two-stage detector reads the RPN boxes through the proposal
+        layer's top-k alone: 9,000 (training) / 1,024 (test) of the 211,200 anchors per frame."""
         anchors = self._flat_anchors()
         A = anchors.view(-1, anchors.shape[-1]).shape[0]
-        batch_anchors = anchors.view(1, -1, anchors.shape[-1]).expand(batch_size, -1, -1)
         batch_cls_preds = cls_preds.view(batch_size, A, -1).float()
-        batch_box_preds = self.box_coder.decode_torch(box_preds.view(batch_size, A, -1), batch_anchors)
-        if dir_cls_preds is not None:
+        raw = box_preds.view(batch_size, A, -1)
+        dirs = dir_cls_preds.view(batch_size, A, -1) if dir_cls_preds is not None else None
+        if anchor_idx is None:
+            batch_anchors = anchors.view(1, -1, anchors.shape[-1]).expand(batch_size, -1, -1)
+        else:
+            batch_anchors = anchors.view(-1, anchors.shape[-1])[anchor_idx]                               # (B,k,7)
+            raw = torch.gather(raw, 1, anchor_idx[..., None].expand(-1, -1, raw.shape[-1]))
+            if dirs is not None:
+                dirs = torch.gather(dirs, 1, anchor_idx[..., None].expand(-1, -1, dirs.shape[-1]))
+        batch_box_preds = self.box_coder.decode_torch(raw, batch_anchors)
+        if dirs is not None:
             dir_offset, dir_limit_offset = self.model_cfg.DIR_OFFSET, self.model_cfg.DIR_LIMIT_OFFSET
-            dir_labels = torch.max(dir_cls_preds.view(batch_size, A, -1), dim=-1)[1]
+            dir_labels = torch.max(dirs, dim=-1)[1]
             period = 2 * np.pi / self.model_cfg.NUM_DIR_BINS
             dir_rot = common_utils.limit_period(batch_box_preds[..., 6] - dir_offset, dir_limit_offset, period)
             rot = dir_rot + dir_offset + period * dir_labels.to(batch_box_preds.dtype)

@@ -16,6 +16,9 @@ from ..backbones_3d import pfe, vfe
 from ..model_utils import model_nms_utils
 
 
+LAZY_BOX_DECODE = True
+
+
 class Detector3DTemplate(nn.Module):
     def __init__(self, model_cfg, num_class, dataset):
         super().__init__()
@@ -91,6 +94,10 @@ class Detector3DTemplate(nn.Module):
         for name in self.module_topology:
             module, info = getattr(self, 'build_%s' % name)(model_info_dict=info)
             self.add_module(name, module)
+        if getattr(self, 'roi_head', None) is not None and hasattr(getattr(self, 'dense_head', None), 'lazy_box_decode'):
+            # two-stage detector: the RPN boxes are read by the RoI head's proposal layer only (its top-k), post-processing
+            # reads the RoI head's own boxes — the dense head need not decode all anchors (LAZY_BOX_DECODE = False: it does)
+            self.dense_head.lazy_box_decode = LAZY_BOX_DECODE
         from ..backbones_2d.map_to_bev import height_compression
         if height_compression.CHANNELS_LAST:
             import torch as _torch

@@ -45,20 +45,24 @@ class RoIHeadTemplate(nn.Module):
             return batch_dict
         if nms_config.MULTI_CLASSES_NMS:
             raise NotImplementedError
-        box_preds, cls_preds = batch_dict['batch_box_preds'], batch_dict['batch_cls_preds']
+        box_preds, cls_preds = batch_dict.get('batch_box_preds', None), batch_dict['batch_cls_preds']
         assert cls_preds.dim() == 3 and batch_dict.get('batch_index', None) is None
         B, A = cls_preds.shape[0], cls_preds.shape[1]
         post = nms_config.NMS_POST_MAXSIZE
         scores, labels = torch.max(cls_preds, dim=2)
         k = min(nms_config.NMS_PRE_MAXSIZE, A)
         top_scores, top_idx = torch.topk(scores, k=k, dim=1)                       # sorted descending
-        top_boxes = torch.gather(box_preds, 1, top_idx[..., None].expand(-1, -1, box_preds.shape[-1]))
+        if box_preds is None:           # the dense head left the decode to us: only the k anchors kept here become boxes
+            top_boxes = batch_dict['batch_box_decoder'](top_idx)
+        else:
+            top_boxes = torch.gather(box_preds, 1, top_idx[..., None].expand(-1, -1, box_preds.shape[-1]))
         keep, _ = iou3d_nms_utils.nms_batched(top_boxes[..., 0:7].contiguous(), None, nms_config.NMS_THRESH, post,
                                               rotated=(nms_config.NMS_TYPE == 'nms_gpu'))
         valid = keep >= 0
-        sel = torch.gather(top_idx, 1, keep.clamp(min=0).long())                   # indices into the anchors
-        vf = valid[..., None].to(box_preds.dtype)
-        rois = torch.gather(box_preds, 1, sel[..., None].expand(-1, -1, box_preds.shape[-1])) * vf
+        kept = keep.clamp(min=0).long()
+        sel = torch.gather(top_idx, 1, kept)                                       # indices into the anchors
+        vf = valid[..., None].to(top_boxes.dtype)
+        rois = torch.gather(top_boxes, 1, kept[..., None].expand(-1, -1, top_boxes.shape[-1])) * vf
         roi_scores = torch.gather(scores, 1, sel) * valid.to(scores.dtype)
         roi_labels = torch.gather(labels, 1, sel) * valid.long()
         full = torch.gather(cls_preds, 1, sel[..., None].expand(-1, -1, cls_preds.shape[-1])) * vf

@@ -105,7 +105,15 @@ def test_proposal_layer_matches_oracle_nms(model, dev):
     with torch.no_grad():
         for mod in model.module_list[:-1]:
             b = mod(b)
-        cls, box = b['batch_cls_preds'].clone(), b['batch_box_preds'].clone()
+        # the dense head of a two-stage detector leaves the box decode to the proposal layer (its top-k anchors only):
+        # the full decode, made here, is what the selected rows must equal bit for bit
+        assert 'batch_box_preds' not in b and 'batch_box_decoder' in b
+        fr = model.dense_head.forward_ret_dict
+        cls, box = model.dense_head.generate_predicted_boxes(batch_size=2, cls_preds=fr['cls_preds'], box_preds=fr['box_preds'],
+                                                             dir_cls_preds=fr['dir_cls_preds'])
+        assert torch.equal(cls, b['batch_cls_preds'])
+        probe = torch.stack([torch.randperm(box.shape[1], device=dev)[:777] for _ in range(2)])
+        assert torch.equal(b['batch_box_decoder'](probe), torch.gather(box, 1, probe[..., None].expand(-1, -1, 7)))
         cfg = model.roi_head.model_cfg.NMS_CONFIG['TEST']
         out = model.roi_head.proposal_layer(dict(b), cfg)
     for f in range(2):

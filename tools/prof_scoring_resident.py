@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""The resident CRB stage-1 scoring pass alone, for rocprofv3 kernel traces: 8 batches of 16 frames scored back to back after
-a warm-up.  rocprofv3 --kernel-trace --output-format csv -d /tmp/p -o sc -- python tools/prof_scoring_resident.py ;
+"""The resident CRB stage-1 scoring pass alone, for rocprofv3 kernel traces: 8 batches of B frames (argv[1], default 16) scored
+back to back after a warm-up.  rocprofv3 --kernel-trace --output-format csv -d /tmp/p -o sc -- python tools/prof_scoring_resident.py ;
 PROF_MARKER=vox_insert PROF_GAPS=30 python tools/prof_summary.py /tmp/p/*/sc_kernel_trace.csv 4"""
 import os
 import sys
@@ -17,11 +17,12 @@ if __name__ == '__main__':
     dev = torch.device('cuda', 0)
     torch.manual_seed(0)
     cfg = pv_rcnn_cfg()
-    pool = SyntheticDataset(num_frames=160, first_frame=5000, n_points=20000, training=False)
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    pool = SyntheticDataset(num_frames=10 * B, first_frame=5000, n_points=20000, training=False)
     lab = SyntheticDataset(num_frames=2, n_points=20000)
     model = build_network(cfg.MODEL, 3, pool).to(dev)
-    strat = build_strategy('crb', model, build_synthetic_dataloader(lab, 2), build_synthetic_dataloader(pool, 16), 0, '/tmp', cfg)
-    batches = list(strat.upload_pool_batches(list(range(160)), 16))
+    strat = build_strategy('crb', model, build_synthetic_dataloader(lab, 2), build_synthetic_dataloader(pool, B, workers=12), 0, '/tmp', cfg)
+    batches = list(strat.upload_pool_batches(list(range(10 * B)), B))
     strat.score_device_batches(batches[:2])
     torch.cuda.synchronize()
     strat.score_device_batches(batches[2:])
