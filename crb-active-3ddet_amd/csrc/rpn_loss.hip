@@ -53,7 +53,9 @@ __device__ __forceinline__ void focal_term(float x, bool t, float alpha, float g
   }
   loss = aw * ptg * bce;
   const float dpt = t ? -p * (1.0f - p) : p * (1.0f - p);
-  const float dbce = t ? p - 1.0f : p;
+  // d bce / dx = [x >= 0] - t - sign(x) e^-|x| / (1 + e^-|x|) as autograd differentiates the reference's expression
+  // (clamp(x, min=0) - x t + log1p(exp(-|x|))): p - t everywhere except at x == 0 exactly, where sign(0) = 0 leaves 1 - t
+  const float dbce = x == 0.0f ? (t ? 0.0f : 1.0f) : (t ? p - 1.0f : p);
   d = aw * (ptg1 * dpt * bce + ptg * dbce);
 }
 

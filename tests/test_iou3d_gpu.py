@@ -132,6 +132,27 @@ def test_batched_nms_prefix_stage_gives_the_full_scan_picks(dev):
         assert (keep[f, num[f]:] == -1).all()
 
 
+def test_batched_nms_at_the_training_proposal_size_prefix_equals_single_stage(dev):
+    """9,000 score-sorted boxes per frame, 512 kept, threshold 0.8 (the training proposal layer of PV-RCNN): the prefix stage must
+    return the picks of the single-stage scan — obtained from the same entry point with max_keep = N, which switches the prefix
+    stage off — for frames with few and with many overlaps"""
+    from pcdet.ops.iou3d_nms import iou3d_nms_utils as U
+    rng = np.random.default_rng(21)
+    N = 9000
+    boxes = np.zeros((3, N, 7), np.float32)
+    for f, n_obj in enumerate((3000, 150, 30)):
+        b, s = detection_boxes(rng, N, n_obj=n_obj)
+        boxes[f] = b[np.argsort(-s, kind='stable')]
+    counts = np.array([N, N, 7000], np.int32)
+    kp, nump = U.nms_batched(_t(boxes, dev), _t(counts, dev), 0.8, 512, rotated=True)
+    kf, numf = U.nms_batched(_t(boxes, dev), _t(counts, dev), 0.8, N, rotated=True)
+    kp, nump, kf, numf = kp.cpu().numpy(), nump.cpu().numpy(), kf.cpu().numpy(), numf.cpu().numpy()
+    for f in range(3):
+        k = min(512, numf[f])
+        assert nump[f] == k
+        np.testing.assert_array_equal(kp[f, :k], kf[f, :k])
+
+
 def test_model_nms_utils_contract(dev):
     """class_agnostic_nms / multi_classes_nms (model_nms_utils.py:6-66): selected indices refer to the INPUT arrays, scores come
     back with them, per-class results are concatenated in class order — checked against the oracle NMS applied to the
