@@ -101,6 +101,11 @@ def _frames_forward(x, off, bn, relu, out=None, col=0):
     return z
 
 
+def frame_groups_active():
+    """inside a frame_groups(G > 1) context: BatchNorm layers keep per-frame statistics (batched CRB stage 2)"""
+    return _GROUPS is not None and _GROUPS.G > 1
+
+
 def supported(x, bn):
     C = x.shape[1]
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 2 and C % 4 == 0 and

@@ -627,8 +627,9 @@ extern "C" int crb_bn_relu_backward(const float* x, const float* dz, int64_t dz_
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, 0.f, 1, dbeta, dgamma,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f);
   const int64_t total4 = n * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, dz, mean, invstd, gamma, beta,
-                     dbeta, dgamma, dx, total4, C, 1.0f / (float)n, relu, ld_dz, (g_bn_order >> 1) & 1);
+  if (dx)                      // dx == NULL: the reduced gradients only (the consumer applies the BatchNorm backward itself)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, dz, mean, invstd, gamma, beta,
+                       dbeta, dgamma, dx, total4, C, 1.0f / (float)n, relu, ld_dz, (g_bn_order >> 1) & 1);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

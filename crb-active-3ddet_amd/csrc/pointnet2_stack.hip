@@ -697,7 +697,21 @@ __global__ __launch_bounds__(256) void group_affine_rows_kernel(int B, int64_t M
 // they cost 1.5 ms).
 // H is a template parameter: with a run-time H the index arithmetic (e / H, e % H per element) made the kernel VALU-bound
 // (~3000 instructions per thread, 2.4 ms at the RoI-grid shape for 1.8 GB of input).
-template <int H>
+// BN: grad_out is the gradient w.r.t. z = relu(batchnorm(y)) of the layer's output y (the rows `y_rows`) and the BatchNorm
+// backward is applied while the slab is loaded — dy = gamma invstd (d - dbeta/n - xhat dgamma/n), d = dz [z > 0], exactly
+// bn_bwd_apply_kernel's arithmetic — so the (M*nsample, H) gradient of y is never written and read back.
+struct GroupBn {
+  const float* y_rows;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  const float* dbeta;
+  const float* dgamma;
+  float inv_n;
+};
+
+template <int H, bool BN = false>
 __global__ __launch_bounds__(256) void group_affine_rows_grad_kernel(int B, int64_t MP, int ns,
                                                                      const int* __restrict__ xyz_cnt,
                                                                      const int* __restrict__ new_cnt,
@@ -705,7 +719,8 @@ __global__ __launch_bounds__(256) void group_affine_rows_grad_kernel(int B, int6
                                                                      const unsigned char* __restrict__ empty,
                                                                      const float* __restrict__ rel,
                                                                      const float* __restrict__ grad_out,
-                                                                     float* __restrict__ grad_P, float* __restrict__ part) {
+                                                                     float* __restrict__ grad_P, float* __restrict__ part,
+                                                                     GroupBn bn = GroupBn{}) {
   constexpr int H4 = H / 4, NPLANE = 256 / H4, NROW = 256 / H < 1 ? 1 : 256 / H;
   __shared__ __attribute__((aligned(16))) float slab[64 * H];
   __shared__ float wred[4 * H4 * 12];
@@ -734,10 +749,30 @@ __global__ __launch_bounds__(256) void group_affine_rows_grad_kernel(int B, int6
   const gf4* src = reinterpret_cast<const gf4*>(grad_out + p0 * H);
   gf4* slab4 = reinterpret_cast<gf4*>(slab);
   gf4 v[64 / NPLANE];
+  gf4 mu, is, ga, be, db, dg;
+  if constexpr (BN) {
+    mu = *reinterpret_cast<const gf4*>(bn.mean + 4 * c4);
+    is = *reinterpret_cast<const gf4*>(bn.invstd + 4 * c4);
+    ga = *reinterpret_cast<const gf4*>(bn.gamma + 4 * c4);
+    be = *reinterpret_cast<const gf4*>(bn.beta + 4 * c4);
+    db = *reinterpret_cast<const gf4*>(bn.dbeta + 4 * c4);
+    dg = *reinterpret_cast<const gf4*>(bn.dgamma + 4 * c4);
+  }
 #pragma unroll
   for (int i = 0; i < 64 / NPLANE; ++i) {
     const int pl = plane + i * NPLANE;
     v[i] = pl < npl ? src[pl * H4 + c4] : (gf4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (BN) {
+      if (pl < npl) {
+        const gf4 yv = reinterpret_cast<const gf4*>(bn.y_rows + p0 * H)[pl * H4 + c4];
+        const gf4 xh = (yv - mu) * is;
+        const gf4 z = ga * xh + be;
+        gf4 d = v[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = z[k] > 0.f ? d[k] : 0.f;
+        v[i] = ga * is * (d - db * bn.inv_n - xh * (dg * bn.inv_n));
+      }
+    }
     slab4[pl * H4 + c4] = v[i];
   }
   __syncthreads();
@@ -1167,6 +1202,33 @@ extern "C" int crb_group_affine_rows_stack(int B, int64_t M, int H, int nsample,
 
 extern "C" int64_t crb_group_affine_rows_grad_blocks(int64_t M, int nsample) { return crb_cdiv(M * nsample, 64); }
 
+// the same with the BatchNorm(+ReLU) backward of the layer's output folded in: grad_z (M*nsample, H) is the gradient w.r.t.
+// relu(batchnorm(y)), y (M*nsample, H) the layer's output, dbeta / dgamma the reduced BatchNorm gradients
+// (crb_bn_relu_backward with dx = NULL computes them)
+extern "C" int crb_group_affine_rows_grad_bn_stack(int B, int64_t M, int H, int nsample, const int32_t* xyz_batch_cnt,
+                                                   const int32_t* new_xyz_batch_cnt, const int32_t* idx,
+                                                   const uint8_t* empty_mask, const float* rel, const float* grad_z,
+                                                   const float* y, const float* mean, const float* invstd, const float* gamma,
+                                                   const float* beta, const float* dbeta, const float* dgamma,
+                                                   float* grad_P /* pre-zeroed */, float* part, void* stream) {
+  if (B <= 0 || M < 0 || H <= 0 || nsample <= 0 || !y || !mean || !invstd || !gamma || !beta || !dbeta || !dgamma)
+    return CRB_ERR_ARG;
+  if (H != 16 && H != 32 && H != 64 && H != 128) return CRB_ERR_UNSUPPORTED;
+  if (M == 0) return CRB_OK;
+  const int64_t MP = M * nsample;
+  const dim3 grid(crb_cdiv(MP, 64));
+  hipStream_t st = (hipStream_t)stream;
+  const GroupBn bn{y, mean, invstd, gamma, beta, dbeta, dgamma, 1.0f / (float)MP};
+#define CRB_GA_CASE(HH)                                                                                              \
+  if (H == HH)                                                                                                       \
+    hipLaunchKernelGGL((group_affine_rows_grad_kernel<HH, true>), grid, dim3(256), 0, st, B, MP, nsample, xyz_batch_cnt, \
+                       new_xyz_batch_cnt, idx, empty_mask, rel, grad_z, grad_P, part, bn);
+  CRB_GA_CASE(16) CRB_GA_CASE(32) CRB_GA_CASE(64) CRB_GA_CASE(128)
+#undef CRB_GA_CASE
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
 extern "C" int crb_group_affine_rows_grad_stack(int B, int64_t M, int H, int nsample, const int32_t* xyz_batch_cnt,
                                                 const int32_t* new_xyz_batch_cnt, const int32_t* idx,
                                                 const uint8_t* empty_mask, const float* rel, const float* grad_out,
@@ -1179,8 +1241,8 @@ extern "C" int crb_group_affine_rows_grad_stack(int B, int64_t M, int H, int nsa
   hipStream_t st = (hipStream_t)stream;
 #define CRB_GA_CASE(HH)                                                                                              \
   if (H == HH)                                                                                                       \
-    hipLaunchKernelGGL(group_affine_rows_grad_kernel<HH>, grid, dim3(256), 0, st, B, MP, nsample, xyz_batch_cnt,     \
-                       new_xyz_batch_cnt, idx, empty_mask, rel, grad_out, grad_P, part);
+    hipLaunchKernelGGL((group_affine_rows_grad_kernel<HH, false>), grid, dim3(256), 0, st, B, MP, nsample, xyz_batch_cnt, \
+                       new_xyz_batch_cnt, idx, empty_mask, rel, grad_out, grad_P, part, GroupBn{});
   CRB_GA_CASE(16) CRB_GA_CASE(32) CRB_GA_CASE(64) CRB_GA_CASE(128)
 #undef CRB_GA_CASE
   CRB_CHECK_LAUNCH();

@@ -27,6 +27,7 @@ FUSED_SA_EVAL = True   # inference: group + 2-layer MLP + max in one HIP kernel 
 ROWS_TRAIN = True      # training: row-major grouped matrix -> GEMM + fused BN/ReLU row kernels -> max (no MIOpen BN2d / transposes)
 SPLIT_FIRST_LAYER = True   # training rows path: layer 1 = gather of per-source-point products + offset term (no grouped matrix)
 FUSED_BN_MAX = True        # training rows path: last BatchNorm+ReLU, max over nsample and the concat of the scales in one op
+FUSED_FIRST_BN = True      # training rows path: first conv + BatchNorm + ReLU as one node, BN backward inside the gradient kernel
 FUSED_GROUP = True     # one HIP launch builds the (1, 3+C, M, ns) MLP input (False: QueryAndGroup + permute copy)
 
 
@@ -157,6 +158,15 @@ class StackSAModuleMSG(nn.Module):
                                                                 new_xyz, new_xyz_batch_cnt, features, ball=ball)   # (M*ns, 3+C)
                 for i in range(0, len(mods), 3):
                     conv, bn = mods[i], mods[i + 1]
+                    if i == 0 and split and FUSED_FIRST_BN and (i + 3 < len(mods) or not fuse_max) and bn.training and \
+                            bn.momentum is not None and M > 0 and not bnrelu.frame_groups_active() and \
+                            bn.running_mean.is_contiguous() and bn.running_var.is_contiguous():
+                        # first conv + its BatchNorm + ReLU as one autograd node: the BatchNorm backward is applied inside the
+                        # gather-scatter gradient kernel (no (M*ns, H) gradient of the conv output in HBM)
+                        x = pointnet2_utils.grouped_first_layer_bn_relu(grouper.radius, grouper.nsample, xyz, xyz_batch_cnt,
+                                                                        new_xyz, new_xyz_batch_cnt, features,
+                                                                        conv.weight.flatten(1), bn, ball=ball)
+                        continue
                     if i == 0 and split:
                         x = pointnet2_utils.grouped_first_layer_rows(grouper.radius, grouper.nsample, xyz, xyz_batch_cnt,
                                                                      new_xyz, new_xyz_batch_cnt, features,

@@ -226,6 +226,81 @@ class GroupedFirstLayerRows(Function):
         return None, None, None, None, gf, None, None, gw
 
 
+class GroupedFirstLayerBNReLU(Function):
+    """relu(batchnorm(GroupedFirstLayerRows(...))) in training mode as ONE autograd node: forward = the two launches' worth of
+    kernels the separate ops run; backward reduces dgamma / dbeta (crb_bn_relu_backward with dx = NULL) and hands them to
+    crb_group_affine_rows_grad_bn_stack, which applies the BatchNorm backward while it loads the gradient slab — the
+    (M*nsample, H) gradient of the layer's output (1.8 GB at the RoI-grid shape) is neither written nor read."""
+
+    @staticmethod
+    def forward(ctx, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx, empty, weight, gamma, beta, eps,
+                running_mean, running_var, momentum, nbt):
+        from crbhip import bnrelu
+        require_cuda(xyz, new_xyz, features, idx, weight, gamma, beta)
+        M, ns = idx.shape
+        H = weight.shape[0]
+        B = xyz_batch_cnt.shape[0]
+        dev = xyz.device
+        xc, nc = _i32(xyz_batch_cnt), _i32(new_xyz_batch_cnt)
+        em = empty.to(torch.uint8).contiguous()
+        idx = idx.contiguous()
+        feats = features.contiguous().float()
+        w1x = weight[:, :3].t().contiguous()
+        w1f = weight[:, 3:].contiguous()
+        P = feats @ w1f.t()
+        y = torch.empty((M * ns, H), dtype=torch.float32, device=dev)
+        rel = torch.empty((M * ns, 3), dtype=torch.float32, device=dev)
+        check(lib.crb_group_affine_rows_stack(B, M, H, ns, ptr(xyz.contiguous()), ptr(xc), ptr(P), ptr(new_xyz.contiguous()),
+                                              ptr(nc), ptr(idx), ptr(em), ptr(w1x), ptr(y), ptr(rel), cur_stream(dev)),
+              'crb_group_affine_rows_stack')
+        n = M * ns
+        z = torch.empty_like(y)
+        mean = torch.empty((H,), dtype=torch.float32, device=dev)
+        var, invstd = torch.empty_like(mean), torch.empty_like(mean)
+        wsb = lib.crb_bn_workspace_bytes(n, H)
+        ws, tk = bnrelu._scratch(dev, wsb)
+        g, b = gamma.contiguous().float(), beta.contiguous().float()
+        check(lib.crb_bn_relu_forward(ptr(y), n, H, ptr(g), ptr(b), float(eps), 1, ptr(z), 0, ptr(mean), ptr(var), ptr(invstd),
+                                      ptr(running_mean), ptr(running_var), ptr(nbt), float(momentum), ptr(ws), wsb, ptr(tk),
+                                      cur_stream(dev)), 'crb_bn_relu_forward')
+        bnrelu._touch(running_mean, running_var, nbt)
+        ctx.meta = (B, M, H, ns, xc, nc, idx, em)
+        ctx.save_for_backward(feats, w1f, rel, y, mean, invstd, g, b)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        from crbhip import bnrelu
+        B, M, H, ns, xc, nc, idx, em = ctx.meta
+        feats, w1f, rel, y, mean, invstd, g, b = ctx.saved_tensors
+        dev = gz.device
+        gz = gz.contiguous().float()
+        n = M * ns
+        dgamma = torch.empty((H,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty_like(dgamma)
+        wsb = lib.crb_bn_workspace_bytes(n, H)
+        ws, tk = bnrelu._scratch(dev, wsb)
+        check(lib.crb_bn_relu_backward(ptr(y), ptr(gz), 0, n, H, ptr(mean), ptr(invstd), ptr(g), ptr(b), 1, None, ptr(dgamma),
+                                       ptr(dbeta), ptr(ws), wsb, ptr(tk), cur_stream(dev)), 'crb_bn_relu_backward')
+        gP = torch.zeros((feats.shape[0], H), dtype=torch.float32, device=dev)
+        part = torch.empty((int(lib.crb_group_affine_rows_grad_blocks(M, ns)), 3, H), dtype=torch.float32, device=dev)
+        check(lib.crb_group_affine_rows_grad_bn_stack(B, M, H, ns, ptr(xc), ptr(nc), ptr(idx), ptr(em), ptr(rel), ptr(gz), ptr(y),
+                                                      ptr(mean), ptr(invstd), ptr(g), ptr(b), ptr(dbeta), ptr(dgamma), ptr(gP),
+                                                      ptr(part), cur_stream(dev)), 'crb_group_affine_rows_grad_bn_stack')
+        gf = gP @ w1f if ctx.needs_input_grad[4] else None
+        gw = torch.cat([part.sum(0).t(), gP.t() @ feats], dim=1) if ctx.needs_input_grad[7] else None
+        return None, None, None, None, gf, None, None, gw, dgamma, dbeta, None, None, None, None, None
+
+
+def grouped_first_layer_bn_relu(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, weight, bn, ball=None):
+    """training-mode relu(bn(first bias-free 1x1 conv of a StackSAModuleMSG scale on the ball-query groups)) -> (M*nsample, H);
+    bn: nn.BatchNorm2d / 1d in training mode with a momentum (running statistics and the batch counter are updated)"""
+    from crbhip import bnrelu
+    idx, empty = ball if ball is not None else ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+    return GroupedFirstLayerBNReLU.apply(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx, empty, weight, bn.weight,
+                                         bn.bias, bn.eps, bn.running_mean, bn.running_var, float(bn.momentum), bnrelu._counter(bn))
+
+
 def grouped_first_layer_rows(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, weight, ball=None):
     """first bias-free 1x1 conv of a StackSAModuleMSG scale applied to the ball-query groups -> (M*nsample, H)"""
     idx, empty = ball if ball is not None else ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)

@@ -327,6 +327,16 @@ int crb_group_affine_rows_stack(int B, int64_t M, int H, int nsample, const floa
                                 const int32_t* idx, const uint8_t* empty_mask, const float* W1x, float* out, float* rel,
                                 void* stream);
 int64_t crb_group_affine_rows_grad_blocks(int64_t M, int nsample);
+/* the grad entry with the BatchNorm(+ReLU) backward of the layer's output folded into its slab loads (the BatchNorm2d + ReLU
+ * that follow the first conv of a shared MLP, pointnet2_modules.py:94-99): grad_z = gradient w.r.t. relu(batchnorm(y)),
+ * y = the forward's `out`, mean / invstd the batch statistics, dbeta / dgamma the reduced gradients (crb_bn_relu_backward with
+ * dx = NULL): dy = gamma invstd (d - dbeta/n - xhat dgamma/n), d = grad_z [z > 0], n = M*nsample, is formed in registers — the
+ * (M*nsample, H) gradient of y is neither written nor read. */
+int crb_group_affine_rows_grad_bn_stack(int B, int64_t M, int H, int nsample, const int32_t* xyz_batch_cnt,
+                                        const int32_t* new_xyz_batch_cnt, const int32_t* idx, const uint8_t* empty_mask,
+                                        const float* rel, const float* grad_z, const float* y, const float* mean,
+                                        const float* invstd, const float* gamma, const float* beta, const float* dbeta,
+                                        const float* dgamma, float* grad_P, float* part, void* stream);
 int crb_group_affine_rows_grad_stack(int B, int64_t M, int H, int nsample, const int32_t* xyz_batch_cnt,
                                      const int32_t* new_xyz_batch_cnt, const int32_t* idx, const uint8_t* empty_mask,
                                      const float* rel, const float* grad_out, float* grad_P, float* part, void* stream);
@@ -420,6 +430,7 @@ int crb_bn_relu_apply(const float* x, int64_t n, int C, const float* mean, const
 /* z_row_stride / dz_row_stride (floats, 0 = C): z may be a channel slice of a wider row-major buffer (the BEV backbone
  * writes its two up-sampled branches straight into the concatenated (N*H*W, 512) map, and their backward reads the matching
  * slices of its gradient: no torch.cat copy, no .contiguous() copies of the gradient slices). */
+/* dx may be NULL: only dgamma / dbeta are computed (a consumer that applies the BatchNorm backward while it reads dz) */
 int crb_bn_relu_backward(const float* x, const float* dz, int64_t dz_row_stride, int64_t n, int C, const float* mean,
                          const float* invstd, const float* gamma, const float* beta, int relu, float* dx,
                          float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, int32_t* tickets,

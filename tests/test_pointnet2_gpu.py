@@ -452,3 +452,44 @@ def test_grouped_ball_query_equals_ungrouped(dev):
         (ia, ea), (ib, eb) = U.ball_query_pair(*args)
         (ja, fa), (jb, fb) = U.ball_query_pair(*args, group=216)
         assert torch.equal(ia, ja) and torch.equal(ib, jb) and torch.equal(ea, fa) and torch.equal(eb, fb)
+
+
+def test_first_layer_bn_relu_as_one_node_equals_the_separate_ops(dev):
+    """StackSAModuleMSG in training mode with FUSED_FIRST_BN (first conv + BatchNorm + ReLU as one autograd node, the BatchNorm
+    backward applied inside crb_group_affine_rows_grad_bn_stack) against the same module with the separate ops: outputs and
+    running statistics bit-identical (the forward kernels are the same), every gradient to 1e-5 of its largest entry (the
+    scatter into the per-source-point gradient uses float atomics in both paths: last-bit run-to-run differences)."""
+    import copy
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_modules as pm
+    torch.manual_seed(5)
+    B, n, m, C = 2, 3000, 700, 16
+    xyz = torch.rand(B * n, 3, device=dev) * torch.tensor([20.0, 20.0, 3.0], device=dev)
+    new_xyz = xyz.view(B, n, 3)[:, :m].reshape(-1, 3).contiguous() + 0.05
+    cnt, ncnt = torch.full((B,), n, dtype=torch.int32, device=dev), torch.full((B,), m, dtype=torch.int32, device=dev)
+    feats = torch.randn(B * n, C, device=dev)
+    mod_a = pm.StackSAModuleMSG(radii=[0.8, 1.6], nsamples=[16, 16], mlps=[[C, 32, 32], [C, 64, 64]], use_xyz=True,
+                                pool_method='max_pool').to(dev).train()
+    mod_b = copy.deepcopy(mod_a)
+    gout = torch.randn(B * m, 96, device=dev)
+
+    def run(mod, fused):
+        old = pm.FUSED_FIRST_BN
+        pm.FUSED_FIRST_BN = fused
+        try:
+            f = feats.clone().requires_grad_(True)
+            _, out = mod(xyz, cnt, new_xyz, ncnt, f)
+            out.backward(gout)
+        finally:
+            pm.FUSED_FIRST_BN = old
+        return out.detach(), f.grad, {k: p.grad for k, p in mod.named_parameters()}, {k: v.clone() for k, v in mod.named_buffers()}
+    oa, fa, pa, ba = run(mod_a, True)
+    ob, fb, pb, bb = run(mod_b, False)
+    assert torch.equal(oa, ob)
+    for k in bb:
+        assert torch.equal(ba[k], bb[k]), k
+    def close(x, y, what):
+        assert float((x - y).abs().max()) <= 1e-5 * float(y.abs().max()) + 1e-9, (what, float((x - y).abs().max()), float(y.abs().max()))
+    close(fa, fb, 'features')
+    for k in pb:
+        assert pa[k] is not None, k
+        close(pa[k], pb[k], k)
