@@ -594,6 +594,49 @@ extern "C" int crb_bn_relu_forward(const float* x, int64_t n, int C, const float
   return CRB_OK;
 }
 
+// statistics from slab sums written by the producer of x: slab (nslab, 2, C) = column sums of x and x^2 over consecutive row
+// slabs (crb_group_affine_rows_stats_stack: 64 rows each). Block b of the usual statistics grid adds the slabs of its share in
+// index order into the usual partial layout and the ticket finalize (or the finalize launch) follows as in the forward above.
+__global__ __launch_bounds__(256) void bn_slab_partial_kernel(const float* __restrict__ slab, int64_t nslab, int C,
+                                                              float* __restrict__ partial, BnFinal fin) {
+  const int nblk = gridDim.x, blk = blockIdx.x;
+  const int64_t per = (nslab + nblk - 1) / nblk;
+  const int64_t s0 = (int64_t)blk * per, s1 = min(nslab, s0 + per);
+  const int C2 = 2 * C;
+  for (int i = threadIdx.x; i < C2; i += 256) {
+    float a = 0.f;
+    for (int64_t k = s0; k < s1; ++k) a += slab[k * C2 + i];
+    if (fin.tickets) st_agent(partial + (int64_t)blk * C2 + i, a);
+    else partial[(int64_t)blk * C2 + i] = a;
+  }
+  if (fin.tickets) bn_ticket_finalize(partial, nblk, C, blk, fin);
+}
+
+extern "C" int crb_bn_relu_forward_partials(const float* x, int64_t n, int C, const float* slab_sums, int64_t n_slabs,
+                                            const float* gamma, const float* beta, float eps, int relu, float* z,
+                                            int64_t z_row_stride, float* mean, float* var, float* invstd, float* running_mean,
+                                            float* running_var, int64_t* num_batches_tracked, float momentum, void* workspace,
+                                            int64_t workspace_bytes, int32_t* tickets, void* stream) {
+  const int64_t ld_z = z_row_stride > 0 ? z_row_stride : C;
+  if (ld_z < C || (ld_z & 3) || !slab_sums || n_slabs <= 0) return CRB_ERR_ARG;
+  if (n <= 0 || C <= 0 || (C & 3) || C > 1024 || (256 % (C >> 2) && (C >> 2) < 256)) return CRB_ERR_ARG;
+  if (workspace_bytes < crb_bn_workspace_bytes(n, C) - 256 || !workspace) return CRB_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)(n_slabs < bn_blocks(n) ? n_slabs : bn_blocks(n));
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL(bn_slab_partial_kernel, dim3(nblk), dim3(256), 0, st, slab_sums, n_slabs, C, partial,
+                     bn_final(tickets, workspace, n, C, 0, mean, var, invstd, running_mean, running_var, momentum, eps,
+                              num_batches_tracked));
+  if (!tickets)
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, eps, 0, mean, var,
+                       invstd, running_mean, running_var, momentum, reinterpret_cast<long long*>(num_batches_tracked));
+  const int64_t total4 = n * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, z,
+                     total4, C, relu, ld_z, (g_bn_order >> 1) & 1);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
 // inference forward with given statistics (mean, invstd)
 extern "C" int crb_bn_relu_apply(const float* x, int64_t n, int C, const float* mean, const float* invstd,
                                  const float* gamma, const float* beta, int relu, float* z, int64_t z_row_stride,

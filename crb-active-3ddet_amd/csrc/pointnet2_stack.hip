@@ -630,7 +630,10 @@ __global__ __launch_bounds__(256) void group_affine_rows_kernel(int B, int64_t M
                                                                 const int* __restrict__ new_cnt, const int* __restrict__ idx,
                                                                 const unsigned char* __restrict__ empty,
                                                                 const float* __restrict__ W1x /* (3,H) */,
-                                                                float* __restrict__ out, float* __restrict__ rel) {
+                                                                float* __restrict__ out, float* __restrict__ rel,
+                                                                float* __restrict__ stat = nullptr) {
+  // stat (blocks, 2, H), HT > 0 only: this slab's column sums of out and out^2 — the statistics pass of the BatchNorm that
+  // follows then reads 2 H floats per 64 rows instead of the rows themselves (crb_bn_relu_forward_partials)
   __shared__ int srow[64];
   __shared__ float sd[64][3];
   const int64_t p0 = (int64_t)blockIdx.x * 64;
@@ -661,6 +664,7 @@ __global__ __launch_bounds__(256) void group_affine_rows_kernel(int B, int64_t M
     const int c4 = threadIdx.x % H4, plane = threadIdx.x / H4, c = c4 * 4;
     const gf4 w0 = *reinterpret_cast<const gf4*>(W1x + c), w1 = *reinterpret_cast<const gf4*>(W1x + H + c),
               w2 = *reinterpret_cast<const gf4*>(W1x + 2 * H + c);
+    gf4 s1 = (gf4){0.f, 0.f, 0.f, 0.f}, s2 = (gf4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 64 / NPLANE; ++i) {
       const int pl = plane + i * NPLANE;
@@ -674,6 +678,41 @@ __global__ __launch_bounds__(256) void group_affine_rows_kernel(int B, int64_t M
         for (int k = 0; k < 4; ++k) v[k] = fmaf(w2[k], dz, fmaf(w1[k], dy, fmaf(w0[k], dx, v[k])));
       }
       *reinterpret_cast<gf4*>(dst + pl * H + c) = v;
+      s1 += v;
+      s2 += v * v;
+    }
+    if (stat) {                                              // wave-uniform
+      __shared__ float sred[4][2][HT > 0 ? HT : 4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float a = s1[k], b = s2[k];
+#pragma unroll
+        for (int off = H4; off < 64; off <<= 1) {            // lanes of a wave with the same c4 sit H4 apart
+          a += __shfl_xor(a, off);
+          b += __shfl_xor(b, off);
+        }
+        s1[k] = a;
+        s2[k] = b;
+      }
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      if (lane < H4 && H4 <= 64) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          sred[wave][0][lane * 4 + k] = s1[k];
+          sred[wave][1][lane * 4 + k] = s2[k];
+        }
+      }
+      __syncthreads();
+      // H4 <= 64: every wave holds all H4 column groups (waves differ in their planes); fixed order over the 4 waves
+      for (int e = threadIdx.x; e < 2 * H; e += 256) {
+        const int which = e / H, ch = e % H;
+        float acc = 0.f;
+        if (H4 <= 64) {
+#pragma unroll
+          for (int w = 0; w < 4; ++w) acc += sred[w][which][ch];
+        }
+        stat[((int64_t)blockIdx.x * 2 + which) * H + ch] = acc;
+      }
     }
   } else {
     const int H = Hrt;
@@ -1177,19 +1216,19 @@ extern "C" int crb_query_group_rows_grad_stack(int B, int64_t M, int C, int nsam
   return CRB_OK;
 }
 
-extern "C" int crb_group_affine_rows_stack(int B, int64_t M, int H, int nsample, const float* xyz,
-                                           const int32_t* xyz_batch_cnt, const float* P, const float* new_xyz,
-                                           const int32_t* new_xyz_batch_cnt, const int32_t* idx,
-                                           const uint8_t* empty_mask, const float* W1x, float* out, float* rel,
-                                           void* stream) {
+static int group_affine_rows_launch(int B, int64_t M, int H, int nsample, const float* xyz, const int32_t* xyz_batch_cnt,
+                                    const float* P, const float* new_xyz, const int32_t* new_xyz_batch_cnt,
+                                    const int32_t* idx, const uint8_t* empty_mask, const float* W1x, float* out, float* rel,
+                                    float* stat, void* stream) {
   if (B <= 0 || M < 0 || H <= 0 || nsample <= 0) return CRB_ERR_ARG;
+  if (stat && H != 16 && H != 32 && H != 64 && H != 128) return CRB_ERR_UNSUPPORTED;
   if (M == 0) return CRB_OK;
   const int64_t MP = M * nsample;
   const dim3 grid(crb_cdiv(MP, 64));
   hipStream_t st = (hipStream_t)stream;
 #define CRB_GAF(HT)                                                                                                    \
   hipLaunchKernelGGL(group_affine_rows_kernel<HT>, grid, dim3(256), 0, st, B, MP, H, nsample, xyz, xyz_batch_cnt, P,  \
-                     new_xyz, new_xyz_batch_cnt, idx, empty_mask, W1x, out, rel)
+                     new_xyz, new_xyz_batch_cnt, idx, empty_mask, W1x, out, rel, stat)
   if (H == 16) CRB_GAF(16);
   else if (H == 32) CRB_GAF(32);
   else if (H == 64) CRB_GAF(64);
@@ -1198,6 +1237,27 @@ extern "C" int crb_group_affine_rows_stack(int B, int64_t M, int H, int nsample,
 #undef CRB_GAF
   CRB_CHECK_LAUNCH();
   return CRB_OK;
+}
+
+extern "C" int crb_group_affine_rows_stack(int B, int64_t M, int H, int nsample, const float* xyz,
+                                           const int32_t* xyz_batch_cnt, const float* P, const float* new_xyz,
+                                           const int32_t* new_xyz_batch_cnt, const int32_t* idx,
+                                           const uint8_t* empty_mask, const float* W1x, float* out, float* rel,
+                                           void* stream) {
+  return group_affine_rows_launch(B, M, H, nsample, xyz, xyz_batch_cnt, P, new_xyz, new_xyz_batch_cnt, idx, empty_mask, W1x, out,
+                                  rel, nullptr, stream);
+}
+
+// the same, also writing stat (crb_group_affine_rows_grad_blocks(M, nsample), 2, H): per 64-row slab the column sums of out and
+// of out^2, in the layout crb_bn_relu_forward_partials reads (H in {16, 32, 64, 128})
+extern "C" int crb_group_affine_rows_stats_stack(int B, int64_t M, int H, int nsample, const float* xyz,
+                                                 const int32_t* xyz_batch_cnt, const float* P, const float* new_xyz,
+                                                 const int32_t* new_xyz_batch_cnt, const int32_t* idx,
+                                                 const uint8_t* empty_mask, const float* W1x, float* out, float* rel,
+                                                 float* stat, void* stream) {
+  if (!stat) return CRB_ERR_ARG;
+  return group_affine_rows_launch(B, M, H, nsample, xyz, xyz_batch_cnt, P, new_xyz, new_xyz_batch_cnt, idx, empty_mask, W1x, out,
+                                  rel, stat, stream);
 }
 
 extern "C" int64_t crb_group_affine_rows_grad_blocks(int64_t M, int nsample) { return crb_cdiv(M * nsample, 64); }

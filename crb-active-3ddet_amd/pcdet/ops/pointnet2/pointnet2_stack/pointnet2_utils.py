@@ -226,6 +226,9 @@ class GroupedFirstLayerRows(Function):
         return None, None, None, None, gf, None, None, gw
 
 
+FIRST_LAYER_SLAB_STATS = __import__('os').environ.get('CRB_SLAB_STATS', '1') == '1'    # GroupedFirstLayerBNReLU: BatchNorm statistics from slab sums written by the producer kernel
+
+
 class GroupedFirstLayerBNReLU(Function):
     """relu(batchnorm(GroupedFirstLayerRows(...))) in training mode as ONE autograd node: forward = the two launches' worth of
     kernels the separate ops run; backward reduces dgamma / dbeta (crb_bn_relu_backward with dx = NULL) and hands them to
@@ -250,9 +253,6 @@ class GroupedFirstLayerBNReLU(Function):
         P = feats @ w1f.t()
         y = torch.empty((M * ns, H), dtype=torch.float32, device=dev)
         rel = torch.empty((M * ns, 3), dtype=torch.float32, device=dev)
-        check(lib.crb_group_affine_rows_stack(B, M, H, ns, ptr(xyz.contiguous()), ptr(xc), ptr(P), ptr(new_xyz.contiguous()),
-                                              ptr(nc), ptr(idx), ptr(em), ptr(w1x), ptr(y), ptr(rel), cur_stream(dev)),
-              'crb_group_affine_rows_stack')
         n = M * ns
         z = torch.empty_like(y)
         mean = torch.empty((H,), dtype=torch.float32, device=dev)
@@ -260,9 +260,25 @@ class GroupedFirstLayerBNReLU(Function):
         wsb = lib.crb_bn_workspace_bytes(n, H)
         ws, tk = bnrelu._scratch(dev, wsb)
         g, b = gamma.contiguous().float(), beta.contiguous().float()
-        check(lib.crb_bn_relu_forward(ptr(y), n, H, ptr(g), ptr(b), float(eps), 1, ptr(z), 0, ptr(mean), ptr(var), ptr(invstd),
-                                      ptr(running_mean), ptr(running_var), ptr(nbt), float(momentum), ptr(ws), wsb, ptr(tk),
-                                      cur_stream(dev)), 'crb_bn_relu_forward')
+        if FIRST_LAYER_SLAB_STATS and H in (16, 32, 64, 128):
+            # the producer writes the column sums of every 64-row slab: the BatchNorm's statistics pass reads those (2 H floats
+            # per 64 rows) instead of the (M*ns, H) rows
+            nslab = int(lib.crb_group_affine_rows_grad_blocks(M, ns))
+            stat = torch.empty((nslab, 2, H), dtype=torch.float32, device=dev)
+            check(lib.crb_group_affine_rows_stats_stack(B, M, H, ns, ptr(xyz.contiguous()), ptr(xc), ptr(P),
+                                                        ptr(new_xyz.contiguous()), ptr(nc), ptr(idx), ptr(em), ptr(w1x), ptr(y),
+                                                        ptr(rel), ptr(stat), cur_stream(dev)), 'crb_group_affine_rows_stats_stack')
+            check(lib.crb_bn_relu_forward_partials(ptr(y), n, H, ptr(stat), nslab, ptr(g), ptr(b), float(eps), 1, ptr(z), 0,
+                                                   ptr(mean), ptr(var), ptr(invstd), ptr(running_mean), ptr(running_var),
+                                                   ptr(nbt), float(momentum), ptr(ws), wsb, ptr(tk), cur_stream(dev)),
+                  'crb_bn_relu_forward_partials')
+        else:
+            check(lib.crb_group_affine_rows_stack(B, M, H, ns, ptr(xyz.contiguous()), ptr(xc), ptr(P), ptr(new_xyz.contiguous()),
+                                                  ptr(nc), ptr(idx), ptr(em), ptr(w1x), ptr(y), ptr(rel), cur_stream(dev)),
+                  'crb_group_affine_rows_stack')
+            check(lib.crb_bn_relu_forward(ptr(y), n, H, ptr(g), ptr(b), float(eps), 1, ptr(z), 0, ptr(mean), ptr(var),
+                                          ptr(invstd), ptr(running_mean), ptr(running_var), ptr(nbt), float(momentum), ptr(ws),
+                                          wsb, ptr(tk), cur_stream(dev)), 'crb_bn_relu_forward')
         bnrelu._touch(running_mean, running_var, nbt)
         ctx.meta = (B, M, H, ns, xc, nc, idx, em)
         ctx.save_for_backward(feats, w1f, rel, y, mean, invstd, g, b)

@@ -326,6 +326,13 @@ int crb_group_affine_rows_stack(int B, int64_t M, int H, int nsample, const floa
                                 const float* P, const float* new_xyz, const int32_t* new_xyz_batch_cnt,
                                 const int32_t* idx, const uint8_t* empty_mask, const float* W1x, float* out, float* rel,
                                 void* stream);
+/* forward that also writes stat (crb_group_affine_rows_grad_blocks(M,nsample), 2, H): the column sums of out and out^2 of every
+ * 64-row slab — the statistics pass of the BatchNorm that follows (crb_bn_relu_forward_partials) then reads those instead of
+ * the (M*nsample, H) rows. H in {16, 32, 64, 128}. */
+int crb_group_affine_rows_stats_stack(int B, int64_t M, int H, int nsample, const float* xyz, const int32_t* xyz_batch_cnt,
+                                      const float* P, const float* new_xyz, const int32_t* new_xyz_batch_cnt,
+                                      const int32_t* idx, const uint8_t* empty_mask, const float* W1x, float* out, float* rel,
+                                      float* stat, void* stream);
 int64_t crb_group_affine_rows_grad_blocks(int64_t M, int nsample);
 /* the grad entry with the BatchNorm(+ReLU) backward of the layer's output folded into its slab loads (the BatchNorm2d + ReLU
  * that follow the first conv of a shared MLP, pointnet2_modules.py:94-99): grad_z = gradient w.r.t. relu(batchnorm(y)),
@@ -425,6 +432,13 @@ int crb_bn_relu_forward(const float* x, int64_t n, int C, const float* gamma, co
                         int relu, float* z, int64_t z_row_stride, float* mean, float* var, float* invstd,
                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                         void* workspace, int64_t workspace_bytes, int32_t* tickets, void* stream);
+/* training forward whose statistics come from slab sums the producer of x wrote (slab_sums (n_slabs, 2, C): column sums of x
+ * and x^2 over consecutive row slabs covering all n rows): same outputs as crb_bn_relu_forward up to the rounding of another
+ * summation order, without the statistics pass over x. */
+int crb_bn_relu_forward_partials(const float* x, int64_t n, int C, const float* slab_sums, int64_t n_slabs, const float* gamma,
+                                 const float* beta, float eps, int relu, float* z, int64_t z_row_stride, float* mean, float* var,
+                                 float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                 float momentum, void* workspace, int64_t workspace_bytes, int32_t* tickets, void* stream);
 int crb_bn_relu_apply(const float* x, int64_t n, int C, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int relu, float* z, int64_t z_row_stride, void* stream);
 /* z_row_stride / dz_row_stride (floats, 0 = C): z may be a channel slice of a wider row-major buffer (the BEV backbone

@@ -469,7 +469,7 @@ def test_first_layer_bn_relu_as_one_node_equals_the_separate_ops(dev):
     feats = torch.randn(B * n, C, device=dev)
     mod_a = pm.StackSAModuleMSG(radii=[0.8, 1.6], nsamples=[16, 16], mlps=[[C, 32, 32], [C, 64, 64]], use_xyz=True,
                                 pool_method='max_pool').to(dev).train()
-    mod_b = copy.deepcopy(mod_a)
+    mod_b, mod_b0 = copy.deepcopy(mod_a), copy.deepcopy(mod_a)
     gout = torch.randn(B * m, 96, device=dev)
 
     def run(mod, fused):
@@ -482,13 +482,22 @@ def test_first_layer_bn_relu_as_one_node_equals_the_separate_ops(dev):
         finally:
             pm.FUSED_FIRST_BN = old
         return out.detach(), f.grad, {k: p.grad for k, p in mod.named_parameters()}, {k: v.clone() for k, v in mod.named_buffers()}
-    oa, fa, pa, ba = run(mod_a, True)
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as pu
     ob, fb, pb, bb = run(mod_b, False)
+    pu.FIRST_LAYER_SLAB_STATS = False            # same statistics kernels as the separate ops: bit-identical forward
+    try:
+        oa, fa, pa, ba = run(copy.deepcopy(mod_b0), True)
+    finally:
+        pu.FIRST_LAYER_SLAB_STATS = True
     assert torch.equal(oa, ob)
     for k in bb:
         assert torch.equal(ba[k], bb[k]), k
+    oa, fa, pa, ba = run(mod_a, True)            # statistics from the producer's slab sums: another summation order
     def close(x, y, what):
         assert float((x - y).abs().max()) <= 1e-5 * float(y.abs().max()) + 1e-9, (what, float((x - y).abs().max()), float(y.abs().max()))
+    close(oa, ob, 'output')
+    for k in bb:
+        close(ba[k].float(), bb[k].float(), k)
     close(fa, fb, 'features')
     for k in pb:
         assert pa[k] is not None, k
