@@ -10,6 +10,7 @@ import torch.nn as nn
 from ....ops.pointnet2.pointnet2_stack import pointnet2_modules as pointnet2_stack_modules
 from ....ops.pointnet2.pointnet2_stack import pointnet2_utils as pointnet2_stack_utils
 from ....utils import common_utils
+from ....utils.fc_rows import fc_rows
 
 
 def bilinear_interpolate_torch(im, x, y):
@@ -190,6 +191,6 @@ class VoxelSetAbstraction(nn.Module):
                 new_xyz_batch_cnt=new_xyz_batch_cnt))
         point_features = torch.cat(feats, dim=-1)
         batch_dict['point_features_before_fusion'] = point_features.view(-1, point_features.shape[-1])
-        batch_dict['point_features'] = self.vsa_point_feature_fusion(point_features.view(-1, point_features.shape[-1]))
+        batch_dict['point_features'] = fc_rows(self.vsa_point_feature_fusion, point_features.view(-1, point_features.shape[-1]))
         batch_dict['point_coords'] = keypoints
         return batch_dict

@@ -3,6 +3,7 @@ import torch
 
 from ...utils import box_utils
 from .point_head_template import PointHeadTemplate
+from ...utils.fc_rows import fc_rows
 
 
 class PointHeadSimple(PointHeadTemplate):
@@ -31,7 +32,7 @@ class PointHeadSimple(PointHeadTemplate):
             feats = batch_dict['point_features_before_fusion']
         else:
             feats = batch_dict['point_features']
-        preds = self.cls_layers(feats)
+        preds = fc_rows(self.cls_layers, feats)
         ret = {'point_cls_preds': preds}
         batch_dict['point_cls_scores'], _ = torch.sigmoid(preds).max(dim=-1)
         if self.training:

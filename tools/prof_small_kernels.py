@@ -69,7 +69,8 @@ if __name__ == '__main__':
         if e.device_type != torch.autograd.DeviceType.CPU or not e.name.startswith('aten::'):
             continue
         dt = e.self_device_time_total
-        if dt <= 0 or dt > 20:
+        lo, hi = (float(os.environ.get('PROF_MIN_US', '0')), float(os.environ.get('PROF_MAX_US', '20')))
+        if dt <= lo or dt > hi:
             continue
         chain, q = [], e.cpu_parent
         while q is not None and len(chain) < 5:
@@ -90,6 +91,6 @@ if __name__ == '__main__':
         r[0] += 1
         r[1] += dt
     out = sorted(rows.items(), key=lambda kv: -kv[1][1])
-    print('aten ops with < 20 us of own device time: %d, %.3f ms' % (sum(v[0] for _, v in out), sum(v[1] for _, v in out) / 1e3))
+    print('aten ops with own device time in (PROF_MIN_US, PROF_MAX_US] = (0, 20] by default: %d, %.3f ms' % (sum(v[0] for _, v in out), sum(v[1] for _, v in out) / 1e3))
     for (op, where), (n, us) in out[:110]:
         print('%4d x %6.1f us  %-28s %s' % (n, us / n, op, where))
