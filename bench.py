@@ -48,9 +48,10 @@ def parse():
     ap.add_argument('--pool', type=int, default=2, help='distinct resident batches cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--nchw', action='store_true', help='A/B: NCHW memory format for the dense BEV part')
-    ap.add_argument('--bf16x3-steps', type=int, default=6, help='extra steps under the opt-in split-bf16 gather-GEMM (second roofline); 0 = skip')
-    ap.add_argument('--winograd-steps', type=int, default=8, help='extra steps (and one resident scoring pass) with the opt-in F(2x2,3x3) '
-                    'Winograd kernel for the stride-1 3x3 BEV convolutions instead of MIOpen (reported beside `value`); 0 = skip')
+    ap.add_argument('--bf16x3-steps', type=int, default=0, help='extra steps under the opt-in split-bf16 gather-GEMM (second roofline); 0 = skip')
+    ap.add_argument('--miopen-steps', type=int, default=6, help='A/B: extra steps (and one resident scoring pass) with MIOpen\'s implicit GEMM '
+                    'for the stride-1 3x3 BEV convolutions instead of the hand-written Winograd kernel that `value` runs (CRB_WINOGRAD=0; '
+                    'reported beside `value`); 0 = skip')
     ap.add_argument('--cpu-frames', type=int, default=16, help='BASELINE configs[0]: 16 frames, one CPU fwd+bwd step')
     ap.add_argument('--scoring-pool', type=int, default=3000,
                     help='unlabeled pool size of the CRB stage-1 scoring measurement (BASELINE configs[3]: 3,000 frames, '
@@ -355,15 +356,15 @@ def crb_scoring_bench(args, rank, world, device):
         times.append(dt)
     med = float(np.median(times))
     assert rec.shape[0] == n and len(strat.bbox_records) == n
-    wino_s = None
-    if getattr(args, 'winograd_steps', 0) > 0:
+    miopen_s = None
+    if getattr(args, 'miopen_steps', 0) > 0:
         from pcdet.models.backbones_2d import base_bev_backbone as bev
-        bev.WINOGRAD = True
+        keep_flag, bev.WINOGRAD = bev.WINOGRAD, False
         try:
             strat.score_device_batches(kept[:2])
-            _, wino_s = timed(lambda: strat.stage1(device_batches=kept))
+            _, miopen_s = timed(lambda: strat.stage1(device_batches=kept))
         finally:
-            bev.WINOGRAD = False
+            bev.WINOGRAD = keep_flag
     # the rest of one selection round at the reference's KITTI budget (SURVEY §8d metric 2: K1 N = 500 frames get gradient
     # embeddings — 16 frames per train-mode pass with per-frame BatchNorm statistics, frames re-read through the loader —
     # k-means++ to K2 N = 300 prototypes with the device restatement of sklearn's seeding, greedy KDE balance to N = 100)
@@ -397,10 +398,10 @@ def crb_scoring_bench(args, rank, world, device):
                                'note': 'one pass, frames generated + collated by the loader workers and uploaded inside '
                                        'the timed region'},
             'selection_round': sel_round,
-            'winograd': None if wino_s is None else {
-                'value': round(n / wino_s, 3), 'unit': 'frames/s', 'seconds': round(wino_s, 3),
-                'note': 'one resident pass with the opt-in Winograd kernel for the stride-1 3x3 BEV convolutions (BatchNorm '
-                        'folded, ReLU in the epilogue: one launch per layer); MIOpen is the default and what `value` runs'},
+            'miopen_convs': None if miopen_s is None else {
+                'value': round(n / miopen_s, 3), 'unit': 'frames/s', 'seconds': round(miopen_s, 3),
+                'note': 'A/B: one resident pass with MIOpen\'s implicit GEMM for the stride-1 3x3 BEV convolutions (CRB_WINOGRAD=0) '
+                        'instead of the hand-written Winograd kernel (BatchNorm folded, bias + ReLU in its epilogue) that `value` runs'},
             'per_rank_seconds': {'loader_pass': rank_seconds[0], 'resident_passes': rank_seconds[1:1 + len(times)],
                                  'note': 'each rank\'s own time for the pass (its scoring + the all-gather it waits in), before the closing barrier'},
             'collectives': [dict(c, seconds=round(c['seconds'], 5)) for c in coll],
@@ -560,27 +561,28 @@ def main():
         finally:
             args.steps = keep
             spconv_mirror.set_arithmetic(model, 'f32')
-    # OPT-IN Winograd F(2x2,3x3) for the stride-1 3x3 convolutions of the BEV backbone (crbhip.winograd; MIOpen stays the
-    # default and is what `value` runs): the same training loop for a few more steps
-    wino = None
-    if args.winograd_steps > 0:
+    # A/B: the same training loop for a few more steps with MIOpen's implicit GEMM for the stride-1 3x3 convolutions of the BEV
+    # backbone (CRB_WINOGRAD=0) instead of the hand-written Winograd F(2x2,3x3) kernel (crbhip.winograd) that `value` runs
+    miopen = None
+    if args.miopen_steps > 0:
         from pcdet.models.backbones_2d import base_bev_backbone as bev
-        bev.WINOGRAD = True
+        keep_flag, bev.WINOGRAD = bev.WINOGRAD, False
         try:
             step(0)
             step(1)
             keep = args.steps
-            args.steps = args.winograd_steps
+            args.steps = args.miopen_steps
             dtw, per_step_w, loss_w = timed_steps(True, None)
-            wino = {'frames_per_s': round(args.batch * world * args.winograd_steps / dtw, 3),
-                    'ms_per_step': round(1e3 * dtw / args.winograd_steps, 3), 'steps': args.winograd_steps,
-                    'ms_per_step_device': _pctl(per_step_w), 'final_loss': round(float(loss_w.item()), 4),
-                    'note': 'same training loop, the 10 stride-1 3x3 BEV convolutions (forward + input gradient) on the '
-                            'hand-written Winograd F(2x2,3x3) f32 MFMA kernel instead of MIOpen\'s implicit GEMM; weight '
-                            'gradients stay on MIOpen; opt-in (CRB_WINOGRAD=1), never part of `value`'}
+            miopen = {'frames_per_s': round(args.batch * world * args.miopen_steps / dtw, 3),
+                      'ms_per_step': round(1e3 * dtw / args.miopen_steps, 3), 'steps': args.miopen_steps,
+                      'ms_per_step_device': _pctl(per_step_w), 'final_loss': round(float(loss_w.item()), 4),
+                      'winograd_default': bool(keep_flag),
+                      'note': 'A/B, not `value`: same training loop with the 11 stride-1 3x3 BEV convolutions (forward + input '
+                              'gradient) on MIOpen\'s implicit GEMM (CRB_WINOGRAD=0) instead of the hand-written Winograd '
+                              'F(2x2,3x3) f32 MFMA kernel; weight gradients are MIOpen\'s in both'}
         finally:
             args.steps = keep
-            bev.WINOGRAD = False
+            bev.WINOGRAD = keep_flag
     frames = args.batch * world * args.steps
     out = {
         'metric': 'frames/s SECOND fwd+bwd, KITTI 20k-pt clouds' if args.kind == 'kitti' else
@@ -607,7 +609,7 @@ def main():
     if rank == 0:
         out['crb_scoring'] = score
         out['pvrcnn'] = pv
-        out['winograd'] = wino
+        out['miopen_convs'] = miopen
         roof, table = roofline_from_profile(prof, overhead_ms)
         out['roofline'] = roof
         out['kernel_table'] = table

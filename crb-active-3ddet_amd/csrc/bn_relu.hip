@@ -34,9 +34,10 @@ CRB_KNOB g_bn_order = 2;
 // step). With a ticket area the statistics kernels do it themselves, in two levels and in exactly the order of
 // bn_finalize_kernel (bit-identical results): block k belongs to group k % 32; the LAST block of a group to finish sums the
 // group's partials k, k+32, ... in double (what one of the 32 `part` lanes of bn_finalize_kernel does), the LAST group to
-// finish adds the 32 group sums in group order and writes the statistics. Visibility across workgroups / XCDs: every block
-// fences its partial stores before taking its ticket (device-scope release: L2 write-back), the finalizing block fences
-// again before reading (acquire: L2 invalidate). tickets[0] counts groups, tickets[1 + g] the blocks of group g; whoever
+// finish adds the 32 group sums in group order and writes the statistics. Visibility across workgroups / XCDs: the values
+// that cross workgroups (partials, group sums) are written with agent-scope relaxed atomic stores (`sc1`, write-through) and
+// read with agent-scope relaxed atomic loads (`sc1`, L1 bypassed); every thread waits for the acknowledgement of its stores
+// (s_waitcnt vmcnt(0)) before the block's barrier and ticket. tickets[0] counts groups, tickets[1 + g] the blocks of group g; whoever
 // finishes a counter resets it, so the area is zero again when the kernel ends.
 constexpr int BN_GROUPS = 32;
 struct BnFinal {
@@ -65,8 +66,13 @@ __device__ __forceinline__ void st_agent4(float* p, f4 v) {
 
 __device__ __forceinline__ void bn_ticket_finalize(const float* partial, int nblk, int C, int blk, const BnFinal& f) {
   __shared__ int s_role;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's partial stores are acknowledged ...
-  __syncthreads();                                         // ... for every thread of the block, before the ticket is taken
+  // The partials were stored write-through (agent-scope relaxed atomic stores = `sc1` stores) and are read with `sc1` loads
+  // (L1 bypassed): the valid "sc1 both sides" hand-off of MI355X_MICROARCH.md §inter-workgroup visibility. What that form
+  // needs before the flag is that every store of every wave has been ACKNOWLEDGED: a workgroup-scope release fence emits no
+  // s_waitcnt vmcnt(0) on gfx950 and s_barrier does not drain stores, so each thread drains its own queue
+  // explicitly (inline asm: the compiler cannot drop it), then the barrier, then thread 0 takes the ticket.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   const int ngroups = nblk < BN_GROUPS ? nblk : BN_GROUPS;
   const int grp = blk % BN_GROUPS;
   const int members = (nblk - grp + BN_GROUPS - 1) / BN_GROUPS;
@@ -90,7 +96,7 @@ __device__ __forceinline__ void bn_ticket_finalize(const float* partial, int nbl
       a += (double)__hip_atomic_load(partial + (int64_t)k * C2 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(f.group + (int64_t)grp * C2 + i, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the group sums (sc1 stores) are acknowledged before the group ticket
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_store(&f.tickets[1 + grp], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

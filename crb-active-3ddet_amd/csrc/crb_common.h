@@ -203,33 +203,52 @@ __device__ __forceinline__ uint32_t crb_hash_find(const long long* __restrict__ 
 // collision moves on by whole groups — eight interleaved open-addressing tables, one per key % 8, that share the group hash.
 // Keys are linear site indices with x fastest, so the 3 x-neighbours a kernel row looks up fall into ONE 64-byte line of
 // keys most of the time (a separate hash per site touched 27 lines per row: the level-1 SubM table took 115 us).
+// A residue class that fills ALL of its capacity/8 slots (a wall at constant x with W % 8 == 0: every key shares key % 8)
+// spills into the next residue class after one full round, and a lookup that met no empty slot in a round follows it there
+// (the table is quiescent when it is searched): probing always terminates, an over-full class costs time, never a hang
+// (ADVICE r03). crb_hash_capacity additionally sizes small tables so that no class can fill up at all.
 __device__ __forceinline__ uint32_t crb_ghash_insert(long long* __restrict__ keys, uint32_t mask, int64_t key) {
-  const uint32_t gmask = mask >> 3, sub = (uint32_t)(key & 7);
-  uint32_t g = crb_hash64(key >> 3) & gmask;
-  while (true) {
-    const uint32_t slot = (g << 3) | sub;
-    long long prev = (long long)atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)CRB_HASH_EMPTY,
-                                          (unsigned long long)key);
-    if (prev == CRB_HASH_EMPTY || prev == (long long)key) return slot;
-    g = (g + 1) & gmask;
+  const uint32_t gmask = mask >> 3;
+  uint32_t sub = (uint32_t)(key & 7);
+  const uint32_t g0 = crb_hash64(key >> 3) & gmask;
+  for (int round = 0; round < 8; ++round, sub = (sub + 1) & 7) {
+    uint32_t g = g0;
+    do {
+      const uint32_t slot = (g << 3) | sub;
+      long long prev = (long long)atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)CRB_HASH_EMPTY,
+                                            (unsigned long long)key);
+      if (prev == CRB_HASH_EMPTY || prev == (long long)key) return slot;
+      g = (g + 1) & gmask;
+    } while (g != g0);
   }
+  return 0xffffffffu;          // table completely full: capacity > number of keys is the caller's contract
 }
 
 __device__ __forceinline__ uint32_t crb_ghash_find(const long long* __restrict__ keys, uint32_t mask, int64_t key) {
-  const uint32_t gmask = mask >> 3, sub = (uint32_t)(key & 7);
-  uint32_t g = crb_hash64(key >> 3) & gmask;
-  while (true) {
-    const uint32_t slot = (g << 3) | sub;
-    const long long k = keys[slot];
-    if (k == (long long)key) return slot;
-    if (k == CRB_HASH_EMPTY) return 0xffffffffu;
-    g = (g + 1) & gmask;
+  const uint32_t gmask = mask >> 3;
+  uint32_t sub = (uint32_t)(key & 7);
+  const uint32_t g0 = crb_hash64(key >> 3) & gmask;
+  for (int round = 0; round < 8; ++round, sub = (sub + 1) & 7) {
+    uint32_t g = g0;
+    do {
+      const uint32_t slot = (g << 3) | sub;
+      const long long k = keys[slot];
+      if (k == (long long)key) return slot;
+      if (k == CRB_HASH_EMPTY) return 0xffffffffu;
+      g = (g + 1) & gmask;
+    } while (g != g0);
   }
+  return 0xffffffffu;
 }
 
 static inline int64_t crb_hash_capacity(int64_t n) {
   int64_t c = 1024;
   while (c < 2 * n) c <<= 1;
+  // the x-grouped tables split the capacity into 8 residue classes of c / 8 slots: up to 128 Ki keys give every class room
+  // for ALL keys (c / 8 > n: a one-residue input cannot fill its class; <= 16 MB of keys + 8 MB of values); above that a full
+  // class spills (crb_ghash_insert)
+  if (n <= (1 << 17))
+    while (c < 8 * n + 8) c <<= 1;
   return c;
 }
 

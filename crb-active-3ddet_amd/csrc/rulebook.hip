@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void hash_build_kernel(const int* __restrict__
   int4 c = *reinterpret_cast<const int4*>(coords + (int64_t)i * 4);
   uint32_t slot = crb_ghash_insert(hkeys, hmask, lin_index(c.x, c.y, c.z, c.w, s));
   // duplicate coordinates: the smallest row wins (deterministic)
-  atomicMin(&hvals[slot], i);
+  if (slot != 0xffffffffu) atomicMin(&hvals[slot], i);
 }
 
 // Sort the rows of every chunk of SORT_CHUNK consecutive rows by their neighbour mask, descending (stable: ties keep row

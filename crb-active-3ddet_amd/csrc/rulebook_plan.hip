@@ -311,27 +311,35 @@ __global__ __launch_bounds__(256) void table_rows_kernel(RowsArgs a) {
     }
     if (a.mode == 0) {
       const uint32_t gmask = a.hmask >> 3;
-      uint32_t g[R];
+      uint32_t g[R], g0[R], sub[R];                   // sub: residue class being probed, bits 3.. = finished rounds (crb_ghash_find)
       bool open[R];
       bool any = false;
 #pragma unroll
       for (int it = 0; it < R; ++it) {
         open[it] = tgt[it] >= 0;
-        g[it] = crb_hash64(tgt[it] >> 3) & gmask;
+        g0[it] = g[it] = crb_hash64(tgt[it] >> 3) & gmask;
+        sub[it] = (uint32_t)(tgt[it] & 7);
         r[it] = -1;
         any |= open[it];
       }
       while (any) {                                   // one probe of every open lookup per trip, loads back to back
         long long kq[R];
 #pragma unroll
-        for (int it = 0; it < R; ++it) kq[it] = open[it] ? a.hkeys[(g[it] << 3) | (uint32_t)(tgt[it] & 7)] : 0;
+        for (int it = 0; it < R; ++it) kq[it] = open[it] ? a.hkeys[(g[it] << 3) | (sub[it] & 7u)] : 0;
         any = false;
 #pragma unroll
         for (int it = 0; it < R; ++it) {
           if (!open[it]) continue;
-          if (kq[it] == (long long)tgt[it]) { r[it] = (int)((g[it] << 3) | (uint32_t)(tgt[it] & 7)); open[it] = false; }
+          if (kq[it] == (long long)tgt[it]) { r[it] = (int)((g[it] << 3) | (sub[it] & 7u)); open[it] = false; }
           else if (kq[it] == CRB_HASH_EMPTY) open[it] = false;
-          else { g[it] = (g[it] + 1) & gmask; any = true; }
+          else {
+            g[it] = (g[it] + 1) & gmask;
+            if (g[it] == g0[it]) {                    // a full residue class: the insert spilled into the next one
+              sub[it] = ((sub[it] + 1) & 7u) | ((sub[it] & ~7u) + 8u);
+              if ((sub[it] >> 3) >= 8u) { open[it] = false; continue; }
+            }
+            any = true;
+          }
         }
       }
 #pragma unroll

@@ -1,0 +1,605 @@
+// 3x3 stride-1 pad-1 convolution on channels_last (NHWC) maps as Winograd F(2x2, 3x3) on the f32 MFMA, second design (round 4)
+// (row a7 of SURVEY §8: the BEV backbone's 3x3 convolutions, pcdet/models/backbones_2d/base_bev_backbone.py:24-41).
+//
+// What the first design (winograd_conv.hip) taught: with all 16 xi of a 32x32 block in one wave (256 accumulators) a SIMD holds
+// ONE wave, so the input transform, the LDS stores, the prologue and the output transform all stop the matrix pipe, and every
+// 4x4 patch was fetched by the tile that owns it (4x the map through the texture addresser): 1.125 ms where the MFMAs need 0.47.
+//
+// This design:
+//   * workgroup = 512 threads = 8 waves = TWO waves per SIMD, 128 accumulators each (16 xi x 2 blocks of v_mfma_f32_16x16x4_f32):
+//     one wave's transforms / LDS traffic / epilogue run under the other's MFMAs.
+//   * workgroup tile = 64 tiles (16 tile rows x 4 tile columns of ONE spatial block; tile rows run over the whole batch,
+//     a block may straddle images) x 64 output channels; wave = 32 tiles x 16 channels x 16 xi.
+//   * the raw input block (<= 51 pixel rows x 10 pixels x 8 channels of the chunk) and the chunk's U block come in by LDS-DMA
+//     (global_load_lds_dwordx4: no staging registers, every map element crosses the texture path once per workgroup instead of
+//     four times); the transform V = B^T d B reads the raw block from LDS (one (tile, channel) per thread and chunk: 16 ds_read_b32,
+//     32 VALU, 16 ds_write_b32) - conflict-free through an even/odd pixel-column split of the raw rows.
+//   * U is the MFMA's A operand (rows = output channels), V the B operand (columns = tiles): a lane ends with 4 CONSECUTIVE output
+//     channels of one tile, so Y = A^T M A happens in registers and goes out as 16-byte stores.
+//   * operands are read with ds_read_b128 (two xi x two k-steps per read) from [xi pair][row][channel pair slot][xi parity][2]
+//     images whose 16-byte slot index is XORed with 3*((row>>3)&1): conflict-free for the four 16-lane groups a b128 read is
+//     served in, without padding (ds_read_b64 pairs get merged into ds_read2st64_b64 by the compiler: half rate and a different
+//     banking). U is stored in global memory as that LDS image, chunk by chunk (crb_winograd2_weights): its LDS-DMA is a linear copy.
+//   * pipeline per chunk of 8 input channels: 8 stages of [piece of the transform raw(n+1) -> V(n+1) | operand reads | 8 MFMAs on
+//     V(n), U(n)], before the last stage's MFMAs [wait DMA + LDS, one barrier, issue DMA: U(n+2), raw(n+3)]; V, U and raw are double-buffered: 2 x 32 + 2 x 32 + 2 x 16 KB = all 160 KB of LDS.
+#include <type_traits>
+#include "crb_common.h"
+#include "../../include/crb_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int TB_ROWS = 16, TB_COLS = 4;     // tile block: 16 tile rows x 4 tile columns
+constexpr int WG_TILES = TB_ROWS * TB_COLS;  // 64
+constexpr int WG_K = 64;                     // output channels per workgroup
+constexpr int CC = 8;                        // input channels per chunk
+constexpr int V_FLOATS = 16 * WG_TILES * CC; // 8192 = 32 KB
+constexpr int U_FLOATS = 16 * WG_K * CC;     // 8192 = 32 KB
+constexpr int RAW_ROW_FLOATS = 2 * (TB_COLS + 1) * CC;   // [parity][5 pixel pairs][8 channels] = 80
+constexpr int RAW_FLOATS = 4096;             // 1024 DMA slots of 16 bytes (two per thread) = 51 raw rows: 2*16 + 2*(1 + 8 boundaries)
+constexpr int LDS_FLOATS = 2 * V_FLOATS + 2 * U_FLOATS + 2 * RAW_FLOATS;
+constexpr int NT = 512;
+
+__device__ float g_wino_zero_page[64];       // source of out-of-map pixels (zero-initialised, never written)
+
+// operand image of one chunk (V: row = tile, U: row = output channel): float index of (xi, row, channel c of the chunk)
+__host__ __device__ __forceinline__ constexpr int img_index(int xi, int row, int c) {
+  return (xi >> 1) * (64 * 16) + row * 16 + (((c >> 1) ^ (((row >> 3) & 1) * 3)) << 2) + ((xi & 1) << 1) + (c & 1);
+}
+
+// g (3,3,Cin,Cout) -> U in LDS-image order: [cout block of 64][chunk of 8 ci][img_index(xi, co & 63, ci & 7)]
+__global__ __launch_bounds__(256) void winograd2_weights_kernel(const float* __restrict__ g, float* __restrict__ U, int cin,
+                                                                int cout) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per = (int64_t)cin * cout;
+  if (t >= per) return;
+  const int ci = (int)(t / cout), co = (int)(t - (int64_t)ci * cout);
+  float w[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) w[a][b] = g[(a * 3 + b) * per + t];
+  float tmp[4][3];                 // G g
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    tmp[0][b] = w[0][b];
+    tmp[1][b] = 0.5f * (w[0][b] + w[1][b] + w[2][b]);
+    tmp[2][b] = 0.5f * (w[0][b] - w[1][b] + w[2][b]);
+    tmp[3][b] = w[2][b];
+  }
+  const int nch = cin / CC;
+  const int cb = co / WG_K, col = co - cb * WG_K;
+  float* dst = U + (int64_t)(cb * nch + ci / CC) * U_FLOATS;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float u0 = tmp[r][0], u1 = 0.5f * (tmp[r][0] + tmp[r][1] + tmp[r][2]),
+                u2 = 0.5f * (tmp[r][0] - tmp[r][1] + tmp[r][2]), u3 = tmp[r][2];
+    dst[img_index(r * 4 + 0, col, ci & 7)] = u0;
+    dst[img_index(r * 4 + 1, col, ci & 7)] = u1;
+    dst[img_index(r * 4 + 2, col, ci & 7)] = u2;
+    dst[img_index(r * 4 + 3, col, ci & 7)] = u3;
+  }
+}
+
+// the same image straight from an nn.Conv2d weight (Cout,Cin,3,3) with arbitrary element strides (contiguous or channels_last):
+// mode 0 = forward (kernel input channels = Cin), mode 1 = input gradient: the convolution dy -> dx has the flipped, transposed
+// weights g'[ky][kx][co][ci] = w[co][ci][2-ky][2-kx] (kernel input channels = Cout, output channels = Cin)
+__global__ __launch_bounds__(256) void winograd2_weights_conv_kernel(const float* __restrict__ w, int64_t so, int64_t si,
+                                                                     int64_t sky, int64_t skx, float* __restrict__ U,
+                                                                     int kin, int kout, int mode) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)kin * kout) return;
+  const int ci = (int)(t / kout), co = (int)(t - (int64_t)ci * kout);      // kernel-side input / output channel
+  float g[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      g[a][b] = mode == 0 ? w[co * so + ci * si + a * sky + b * skx] : w[ci * so + co * si + (2 - a) * sky + (2 - b) * skx];
+  float tmp[4][3];                 // G g
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    tmp[0][b] = g[0][b];
+    tmp[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+    tmp[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+    tmp[3][b] = g[2][b];
+  }
+  const int nch = kin / CC;
+  const int cb = co / WG_K, col = co - cb * WG_K;
+  float* dst = U + (int64_t)(cb * nch + ci / CC) * U_FLOATS;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    dst[img_index(r * 4 + 0, col, ci & 7)] = tmp[r][0];
+    dst[img_index(r * 4 + 1, col, ci & 7)] = 0.5f * (tmp[r][0] + tmp[r][1] + tmp[r][2]);
+    dst[img_index(r * 4 + 2, col, ci & 7)] = 0.5f * (tmp[r][0] - tmp[r][1] + tmp[r][2]);
+    dst[img_index(r * 4 + 3, col, ci & 7)] = tmp[r][2];
+  }
+}
+
+struct Wino2Args {
+  const float* x;      // (N,H,W,Cin)
+  const float* U;      // crb_winograd2_weights image
+  float* y;            // (N,H,W,Cout)
+  const float* bias;   // (Cout) or null
+  int N, H, W, cin, cout, relu;
+  int th, tw;          // tiles per column / row = ceil(H/2), ceil(W/2)
+  int RT;              // tile rows over the batch = N * th
+  int tw4;             // tile-column blocks = ceil(tw / 4)
+  int nblocks;         // spatial blocks = ceil(RT / 16) * tw4
+  int ncb;             // cout / 64
+  int persistent;      // 1: gridDim.x workgroups share the units as contiguous ranges; 0: one unit per workgroup
+};
+
+// one 16-byte LDS-DMA per lane: LDS destination = wave-uniform base + lane * 16
+__device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// MODE (measurement builds): 1 = no MFMAs, 2 = no transform (V never written), 3 = no DMA after the prologue (all three: wrong
+// results); 4 = correct results + per-workgroup stamps {s_memtime at start, after the prologue, after the chunks (incl. the
+// output transforms), cycles parked at the chunk barriers, wall_clock64 at start and end, XCC id, units} in g_wino2_dbg; 5 = every raw slot copies the zero page (no map traffic), 6 = U always from the first chunk (both wrong)
+__device__ unsigned long long* g_wino2_dbg = nullptr;
+
+// 16 bytes through the scalar cache (wave-uniform address): the bias of a unit must not go through the vector memory counter,
+// where waiting for it would also wait for the LDS-DMA in flight
+__device__ __forceinline__ f32x4 sload4(const float* p) {
+  f32x4 r;
+  asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+  return r;
+}
+
+// A unit = (spatial block of 16 x 4 tiles, block of 64 output channels); units are numbered with the channel block fastest.
+// A workgroup owns a contiguous range of units and runs ALL their chunks as one software pipeline (the DMA of the next unit's
+// first chunks goes out under the last chunks of the current one: no prologue per unit). Walking from unit to unit needs no
+// division: (cb, bc, R0, n0, ty0) advance incrementally.
+struct UnitPos {
+  int cb, bc, R0, n0, ty0;     // channel block, tile-column block, first tile row over the batch = image n0, row ty0 of it
+};
+__device__ __forceinline__ void unit_next(UnitPos& u, const Wino2Args& a) {
+  if (++u.cb < a.ncb) return;
+  u.cb = 0;
+  if (++u.bc < a.tw4) return;
+  u.bc = 0;
+  u.R0 += TB_ROWS;
+  u.ty0 += TB_ROWS;
+  while (u.ty0 >= a.th) { u.ty0 -= a.th; ++u.n0; }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const Vb = lds;
+  float* const Ub = lds + 2 * V_FLOATS;
+  float* const Rb = lds + 2 * V_FLOATS + 2 * U_FLOATS;
+  const int T = threadIdx.x, lane = T & 63, wave = T >> 6;
+  unsigned long long stamp[6], tm_stage06 = 0, tm_stage7 = 0, tm_book = 0, tm_epi = 0;
+  if (MODE == 4) { stamp[0] = __builtin_amdgcn_s_memtime(); stamp[4] = wall_clock64(); stamp[3] = 0; }
+
+  // ---- the unit range of this workgroup
+  const int nunits = a.nblocks * a.ncb;
+  int u_first, u_end;
+  if (a.persistent) {
+    u_first = (int)((int64_t)blockIdx.x * nunits / gridDim.x);
+    u_end = (int)((int64_t)(blockIdx.x + 1) * nunits / gridDim.x);
+  } else {
+    // consecutive workgroup ids alternate XCDs (id % 8): the channel blocks of one spatial block run back to back on ONE XCD, so
+    // that the later ones read the input block from that L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tbl = slot / a.ncb, cb = slot - tbl * a.ncb;
+    const int tb = tbl * 8 + xcd;
+    u_first = tb < a.nblocks ? tb * a.ncb + cb : 0;
+    u_end = tb < a.nblocks ? u_first + 1 : 0;
+  }
+  if (u_first >= u_end) return;
+  const int nch = a.cin / CC;
+  const int total = (u_end - u_first) * nch;      // chunks of this workgroup
+  UnitPos first;
+  {
+    const int tb = u_first / a.ncb;
+    first.cb = u_first - tb * a.ncb;
+    const int br = tb / a.tw4;
+    first.bc = tb - br * a.tw4;
+    first.R0 = br * TB_ROWS;
+    first.n0 = first.R0 / a.th;
+    first.ty0 = first.R0 - first.n0 * a.th;
+  }
+  // image and tile row inside the image of tile row t of the block at u (rows past the batch: the last valid row)
+  auto row_of = [&](const UnitPos& u, int t, int& n, int& ty) {
+    t = min(t, a.RT - 1 - u.R0);
+    n = u.n0;
+    ty = u.ty0 + t;
+    while (ty >= a.th) { ty -= a.th; ++n; }
+    return t;
+  };
+
+  // ---- transform role: one (tile, channel) per thread and chunk
+  const int t_ch = T & 7, t_tile = T >> 3, t_tr = t_tile >> 2, t_tc = t_tile & 3;
+  const int v_off = img_index(0, t_tile, t_ch);
+  UnitPos tu = first;          // unit of the chunk the transform works on (one chunk ahead of the MFMAs)
+  int tc = 0, raw_off;
+  auto t_setup = [&]() {
+    int n, ty;
+    const int trc = row_of(tu, t_tr, n, ty);  // rows past the batch: any valid row, results never stored
+    raw_off = (2 * trc + 2 * (n - tu.n0)) * RAW_ROW_FLOATS + t_tc * CC + t_ch;
+  };
+  t_setup();
+  auto t_advance = [&]() {
+    if (++tc < nch) return;
+    tc = 0;
+    const int R0 = tu.R0;
+    unit_next(tu, a);
+    if (tu.R0 != R0) t_setup();
+  };
+
+  // ---- DMA role. raw: slots q = T, T + 512 (16 bytes each): q -> (raw row, parity, pixel pair, channel half); runs three chunks
+  //      ahead of the MFMAs. U: 4 x 16 bytes per thread, two chunks ahead.
+  UnitPos ru = first, uu = first;
+  int rc = 0, uc = 0, r_issued = 0, u_issued = 0;
+  const float* rsrc[2];
+  int rstep[2];
+  // sources of the two slots of this thread for the block at u. touch = false: the 16 bytes a slot copies (chunk 0), step = one
+  // chunk; touch = true (line prefetch): ONE lane per pixel (the channel-half-0 slot) gets the pixel's first channel, every other
+  // lane the zero page
+  auto slot_sources = [&](const UnitPos& u, const float* (&src)[2], int (&step)[2], bool touch) {
+    int rr[2], yy[2] = {-1, -1}, nn[2] = {0, 0};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) rr[s] = (T + NT * s) / 20;
+    int n = u.n0, ty = u.ty0;
+    for (int t = 0; t < TB_ROWS && u.R0 + t < a.RT; ++t) {    // raw rows rbt .. rbt + 3 hold pixel rows 2 ty - 1 .. 2 ty + 2 of image n
+      const int rbt = 2 * t + 2 * (n - u.n0);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        if (rr[s] >= rbt && rr[s] < rbt + 4) { nn[s] = n; yy[s] = 2 * ty - 1 + (rr[s] - rbt); }
+      if (++ty == a.th) { ty = 0; ++n; }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int rem = (T + NT * s) - rr[s] * 20;
+      const int par = rem / 10, rem2 = rem - par * 10;
+      const int xh = rem2 >> 1, half = rem2 & 1;
+      const int xx = 8 * u.bc - 1 + 2 * xh + par;
+      const bool ok = yy[s] >= 0 && yy[s] < a.H && xx >= 0 && xx < a.W && MODE != 5 && !(touch && half);   // unclaimed rows keep yy = -1
+      src[s] = ok ? a.x + (((int64_t)nn[s] * a.H + yy[s]) * a.W + xx) * a.cin + half * 4 : g_wino_zero_page;
+      step[s] = ok ? CC : 0;
+    }
+  };
+  auto r_setup = [&]() { slot_sources(ru, rsrc, rstep, false); };
+  r_setup();
+  const float* usrc = a.U + (int64_t)uu.cb * nch * U_FLOATS + T * 4;
+  auto issue_raw = [&]() {                                    // chunk r_issued -> raw buffer r_issued & 1
+    float* buf = Rb + (r_issued & 1) * RAW_FLOATS;
+    glds16(rsrc[0], buf + wave * 256);
+    glds16(rsrc[1], buf + (NT + wave * 64) * 4);              // slots past the block's rows copy the zero page (inside the buffer)
+    ++r_issued;
+  };
+  auto r_advance = [&]() {                                    // after issue_raw: move the sources to the next chunk
+    if (++rc < nch) {
+      rsrc[0] += rstep[0];
+      rsrc[1] += rstep[1];
+      return;
+    }
+    rc = 0;
+    const int R0 = ru.R0, bc = ru.bc;
+    unit_next(ru, a);
+    if (ru.R0 != R0 || ru.bc != bc) r_setup();
+    else {                                                    // same spatial block, next channel block: back to channel 0
+      rsrc[0] -= (nch - 1) * rstep[0];
+      rsrc[1] -= (nch - 1) * rstep[1];
+    }
+  };
+  auto issue_u = [&]() {                                      // chunk u_issued -> U buffer u_issued & 1
+    float* buf = Ub + (u_issued & 1) * U_FLOATS;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) glds16(usrc + k * NT * 4, buf + (k * NT + wave * 64) * 4);
+    ++u_issued;
+  };
+  auto u_advance = [&]() {
+    if (MODE == 6) return;
+    if (++uc < nch) { usrc += U_FLOATS; return; }
+    uc = 0;
+    unit_next(uu, a);
+    usrc = a.U + (int64_t)uu.cb * nch * U_FLOATS + T * 4;
+  };
+
+  // ---- MFMA role: wave = 32 tiles (wt) x 16 output channels (wk) x 16 xi
+  const int wt = wave >> 2, wk = wave & 3;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int a_off = img_index(0, wk * 16 + l15, 2 * kq);        // U image: A operand, rows = output channels
+  const int b_off = img_index(0, wt * 32 + l15, 2 * kq);        // V image: B operand, columns = tiles (second block + 16 rows)
+  f32x4 acc[16][2];
+  auto acc_clear = [&]() {
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+      acc[xi][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc[xi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  acc_clear();
+  auto wait_all_and_barrier = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+
+  // ---- output transform of a finished unit on the accumulators: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]; lane = tile l15 of
+  //      the wave's block, 4 consecutive output channels; then the accumulators start the next unit at zero
+  UnitPos eu = first;
+  int ec = 0;
+  auto unit_epilogue = [&]() {
+    const int k = eu.cb * WG_K + wk * 16 + 4 * kq;
+    f32x4 bias = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+      const float* bp = a.bias + eu.cb * WG_K + __builtin_amdgcn_readfirstlane(wk) * 16;
+      const f32x4 b0 = sload4(bp), b1 = sload4(bp + 4), b2 = sload4(bp + 8), b3 = sload4(bp + 12);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bias[e] = kq == 0 ? b0[e] : kq == 1 ? b1[e] : kq == 2 ? b2[e] : b3[e];
+    }
+#pragma unroll
+    for (int tbk = 0; tbk < 2; ++tbk) {
+      const int tile = wt * 32 + tbk * 16 + l15;
+      const int Rg = eu.R0 + (tile >> 2);
+      const int tx = eu.bc * TB_COLS + (tile & 3);
+      int n2, ty2;
+      row_of(eu, tile >> 2, n2, ty2);
+      f32x4 t0[4], t1[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        t0[s] = acc[0 * 4 + s][tbk] + acc[1 * 4 + s][tbk] + acc[2 * 4 + s][tbk];
+        t1[s] = acc[1 * 4 + s][tbk] - acc[2 * 4 + s][tbk] - acc[3 * 4 + s][tbk];
+      }
+      f32x4 y00 = t0[0] + t0[1] + t0[2] + bias, y01 = t0[1] - t0[2] - t0[3] + bias;
+      f32x4 y10 = t1[0] + t1[1] + t1[2] + bias, y11 = t1[1] - t1[2] - t1[3] + bias;
+      if (a.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          y00[e] = fmaxf(y00[e], 0.f); y01[e] = fmaxf(y01[e], 0.f);
+          y10[e] = fmaxf(y10[e], 0.f); y11[e] = fmaxf(y11[e], 0.f);
+        }
+      }
+      if (Rg < a.RT && tx < a.tw) {
+        const int oy = 2 * ty2, ox = 2 * tx;
+        float* yo = a.y + (((int64_t)n2 * a.H + oy) * a.W + ox) * a.cout + k;
+        const bool x1 = ox + 1 < a.W, y1 = oy + 1 < a.H;
+        *reinterpret_cast<f32x4*>(yo) = y00;
+        if (x1) *reinterpret_cast<f32x4*>(yo + a.cout) = y01;
+        if (y1) *reinterpret_cast<f32x4*>(yo + (int64_t)a.W * a.cout) = y10;
+        if (x1 && y1) *reinterpret_cast<f32x4*>(yo + (int64_t)a.W * a.cout + a.cout) = y11;
+      }
+    }
+    acc_clear();
+    unit_next(eu, a);
+  };
+
+  // ---- one chunk as 8 stages (one xi pair each), pinned by sched_barriers so that a wave's instruction stream alternates
+  //      [a piece of the transform of the next chunk | 3 operand reads of the NEXT pair | 8 MFMAs]: the LDS / VALU work of the
+  //      transform sits in the shadow of the wave's own MFMAs (and of the SIMD's other wave), not in front of the whole chunk.
+  //      transform pieces: stage 0 raw reads d (16), stages 1-2 column pass t = B^T d, stages 3-6 one row of t B + its 4 stores.
+  float d[4][4], t[4][4];
+  auto t_load = [&](const float* raw) {
+    const float* p = raw + raw_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[i][j] = p[i * RAW_ROW_FLOATS + (j & 1) * (RAW_ROW_FLOATS / 2) + (j >> 1) * CC];
+  };
+  auto t_cols = [&](int j) {        // B^T d, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+    t[0][j] = d[0][j] - d[2][j];
+    t[1][j] = d[1][j] + d[2][j];
+    t[2][j] = d[2][j] - d[1][j];
+    t[3][j] = d[1][j] - d[3][j];
+  };
+  auto t_row = [&](float* V, int i) {
+    float* o = V + v_off;
+    o[img_index(i * 4 + 0, 0, 0)] = t[i][0] - t[i][2];
+    o[img_index(i * 4 + 1, 0, 0)] = t[i][1] + t[i][2];
+    o[img_index(i * 4 + 2, 0, 0)] = t[i][2] - t[i][1];
+    o[img_index(i * 4 + 3, 0, 0)] = t[i][1] - t[i][3];
+  };
+  auto transform = [&](const float* raw, float* V) {
+    t_load(raw);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t_cols(j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t_row(V, i);
+  };
+  f32x4 ua[2], v0[2], v1[2];
+  auto op_read = [&](const float* V, const float* U, int xp, int slot) {
+    ua[slot] = *reinterpret_cast<const f32x4*>(U + xp * 1024 + a_off);
+    v0[slot] = *reinterpret_cast<const f32x4*>(V + xp * 1024 + b_off);
+    v1[slot] = *reinterpret_cast<const f32x4*>(V + xp * 1024 + b_off + 16 * 16);
+  };
+  auto mfma_pair = [&](int xp, int slot) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int xi = 2 * xp + h;
+      if (MODE == 1) {
+        acc[xi][0][0] += ua[slot][2 * h] * v0[slot][2 * h] + ua[slot][2 * h + 1] * v0[slot][2 * h + 1];
+        acc[xi][1][0] += ua[slot][2 * h] * v1[slot][2 * h] + ua[slot][2 * h + 1] * v1[slot][2 * h + 1];
+      } else {
+        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[slot][2 * h], v0[slot][2 * h], acc[xi][0], 0, 0, 0);
+        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[slot][2 * h], v1[slot][2 * h], acc[xi][1], 0, 0, 0);
+        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[slot][2 * h + 1], v0[slot][2 * h + 1], acc[xi][0], 0, 0, 0);
+        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[slot][2 * h + 1], v1[slot][2 * h + 1], acc[xi][1], 0, 0, 0);
+      }
+    }
+  };
+  // chunk g of the workgroup. DO_U / DO_RAW / DO_T: compile-time (integral_constant) switches of the peeled tail
+  auto chunk = [&](int g, auto do_u, auto do_raw, auto do_t) {
+    const int cur = g & 1, nxt = cur ^ 1;
+    const float* V = Vb + cur * V_FLOATS;
+    const float* U = Ub + cur * U_FLOATS;
+    float* Vn = Vb + nxt * V_FLOATS;
+    unsigned long long tm0 = 0, tm1 = 0;
+    if (MODE == 4) tm0 = __builtin_amdgcn_s_memtime();
+    constexpr bool T_ON = decltype(do_t)::value && MODE != 2;       // (the first pair's operands were read by the previous chunk)
+#pragma unroll
+    for (int xp = 0; xp < 8; ++xp) {
+      if (T_ON) {                                                 // LDS stores ahead of the next pair's reads: the wait for the
+        if (xp == 0) t_load(Rb + nxt * RAW_FLOATS);               // reads (in-order LDS) then never waits for a younger store
+        if (xp == 1) { t_cols(0); t_cols(1); }
+        if (xp == 2) { t_cols(2); t_cols(3); }
+        if (xp >= 3 && xp < 7) t_row(Vn, xp - 3);
+      }
+      if (xp == 1) {
+        // bookkeeping here, under this stage's MFMAs (at the end of a chunk it cost ~280 cycles with the matrix pipe idle): the
+        // DMA sources move on from what the PREVIOUS chunk's last stage issued, the transform from what stage 0 just read
+        if (MODE != 3) { u_advance(); r_advance(); }
+        t_advance();
+      }
+      if (xp < 7) op_read(V, U, xp + 1, (xp + 1) & 1);
+      // the barrier sits BEFORE the last pair's MFMAs (their operands are in registers, V(g+1) is complete): the waves meet
+      // with 8 MFMAs each still to issue, so the matrix pipe keeps running while the DMA of chunks g+2 (U) / g+3 (raw) - into
+      // the buffers nobody reads any more - and the next chunk's first reads go out
+      if (xp == 7) {
+        if (MODE == 4) {                                          // time parked at the wait + barrier (stamp[3] accumulates)
+          const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+          wait_all_and_barrier();
+          tm1 = __builtin_amdgcn_s_memtime();
+          stamp[3] += tm1 - t0;
+          tm_stage06 += t0 - tm0;
+        } else
+        wait_all_and_barrier();
+        if (MODE != 3) {
+          if (decltype(do_u)::value) issue_u();
+          if (decltype(do_raw)::value) issue_raw();
+        }
+      }
+      mfma_pair(xp, xp & 1);
+      // the next chunk's first operands go out right behind the last MFMAs (V(g+1), U(g+1) are valid after the barrier): their
+      // latency and the bookkeeping below run under those MFMAs instead of in front of the next chunk's
+      if (xp == 7 && decltype(do_t)::value) op_read(Vn, Ub + nxt * U_FLOATS, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (MODE == 4) { tm0 = __builtin_amdgcn_s_memtime(); tm_stage7 += tm0 - tm1; }
+    if (MODE == 4) { tm1 = __builtin_amdgcn_s_memtime(); tm_book += tm1 - tm0; }
+    if (++ec == nch) { ec = 0; unit_epilogue(); }
+    if (MODE == 4) tm_epi += __builtin_amdgcn_s_memtime() - tm1;
+  };
+  using std::true_type;
+  using std::false_type;
+
+  // ---- prologue (once per workgroup): raw(0), raw(1), U(0) in one round trip, raw(0) -> V(0), then U(1), raw(2) go out: chunk g
+  //      runs with U(g+1), raw(g+2) in flight and sends U(g+2), raw(g+3) after its barrier
+  issue_raw(); r_advance();
+  if (total > 1) { issue_raw(); r_advance(); }
+  issue_u(); u_advance();
+  wait_all_and_barrier();
+  transform(Rb, Vb); t_advance();
+  wait_all_and_barrier();
+  if (total > 1) issue_u();                   // (chunk 0 moves the sources on in its stage 1)
+  if (total > 2) issue_raw();
+  op_read(Vb, Ub, 0, 0);
+  if (MODE == 4) stamp[1] = __builtin_amdgcn_s_memtime();
+
+  // ---- chunks: the steady state is one body without DMA / transform conditions, the last three chunks are peeled
+  int g = 0;
+  for (; g + 3 < total; ++g) chunk(g, true_type{}, true_type{}, true_type{});
+  if (g + 2 < total) { chunk(g, true_type{}, false_type{}, true_type{}); ++g; }        // 1 .. 3 chunks left
+  if (g + 1 < total) { chunk(g, false_type{}, false_type{}, true_type{}); ++g; }
+  chunk(g, false_type{}, false_type{}, false_type{});
+  if (MODE == 4) stamp[2] = __builtin_amdgcn_s_memtime();
+  if (MODE == 4 && g_wino2_dbg && T == 0) {
+    stamp[5] = wall_clock64();
+    unsigned long long* o = g_wino2_dbg + (int64_t)blockIdx.x * 16;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = stamp[i];
+    o[6] = __builtin_amdgcn_s_getreg(0x14 | (0 << 6) | (3 << 11));  // XCC_ID (hwreg 20, 4 bits)
+    o[7] = (unsigned long long)(u_end - u_first);
+    o[8] = tm_stage06; o[9] = tm_stage7; o[10] = tm_book; o[11] = tm_epi;
+  }
+}
+
+}  // namespace
+
+CRB_KNOB g_wino2_persistent = 1; // 1: one workgroup per CU over a range of units (measured 4 - 8 % faster); 0: one unit per workgroup
+CRB_KNOB g_wino2_mode = 0;      // measurement builds: 1 = no MFMAs, 2 = no transform, 3 = no DMA in the loop
+#ifdef CRB_MEASURE
+extern "C" int crb_winograd2_set_mode(int mode) { g_wino2_mode = (mode >= 1 && mode <= 6) ? mode : 0; return CRB_OK; }
+extern "C" int crb_winograd2_set_persistent(int on) { g_wino2_persistent = on ? 1 : 0; return CRB_OK; }
+// mode 4: 16 uint64 per workgroup (device buffer of the caller, NULL = off)
+extern "C" int crb_winograd2_set_debug(void* dev_buf) {
+  unsigned long long* p = (unsigned long long*)dev_buf;
+  CRB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wino2_dbg), &p, sizeof(p)));
+  return CRB_OK;
+}
+#endif
+
+// H >= 5: a block of 16 tile rows crosses at most 5 image boundaries (44 raw rows = 880 slots; slots 896.. are the junk corner)
+extern "C" int crb_winograd2_supported(int cin, int cout, int H, int W) {
+  return (cin > 0 && cout > 0 && cin % CC == 0 && cout % WG_K == 0 && H >= 5 && W >= 1) ? 1 : 0;
+}
+
+extern "C" int64_t crb_winograd2_weights_bytes(int cin, int cout) { return (int64_t)16 * cin * cout * 4; }
+
+// g (3,3,Cin,Cout) f32 (ky, kx, input channel, output channel) -> U image of crb_conv3x3_winograd2_nhwc
+extern "C" int crb_winograd2_weights(const float* g, float* U, int cin, int cout, void* stream) {
+  if (!crb_winograd2_supported(cin, cout, 5, 1)) return CRB_ERR_UNSUPPORTED;
+  const int64_t per = (int64_t)cin * cout;
+  hipLaunchKernelGGL(winograd2_weights_kernel, dim3(crb_cdiv(per, 256)), dim3(256), 0, (hipStream_t)stream, g, U, cin, cout);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+// w = nn.Conv2d weight (Cout,Cin,3,3) f32 with element strides (so, si, sky, skx); mode 0: U of the forward convolution
+// (Cin -> Cout), mode 1: U of the input-gradient convolution (Cout -> Cin)
+extern "C" int crb_winograd2_weights_conv(const float* w, int64_t so, int64_t si, int64_t sky, int64_t skx, float* U, int conv_cin,
+                                          int conv_cout, int mode, void* stream) {
+  const int kin = mode ? conv_cout : conv_cin, kout = mode ? conv_cin : conv_cout;
+  if (!crb_winograd2_supported(kin, kout, 5, 1)) return CRB_ERR_UNSUPPORTED;
+  const int64_t per = (int64_t)kin * kout;
+  hipLaunchKernelGGL(winograd2_weights_conv_kernel, dim3(crb_cdiv(per, 256)), dim3(256), 0, (hipStream_t)stream, w, so, si, sky, skx,
+                     U, kin, kout, mode ? 1 : 0);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_conv3x3_winograd2_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
+                                          const float* bias, int relu, void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0) return CRB_ERR_ARG;
+  if (!crb_winograd2_supported(cin, cout, H, W)) return CRB_ERR_UNSUPPORTED;
+  Wino2Args a;
+  a.x = x; a.U = U; a.y = y; a.bias = bias;
+  a.N = N; a.H = H; a.W = W; a.cin = cin; a.cout = cout; a.relu = relu;
+  a.th = (H + 1) / 2; a.tw = (W + 1) / 2;
+  const int64_t rt = (int64_t)N * a.th;
+  if (rt >= (1LL << 30) || (int64_t)N * H * W * (cin > cout ? cin : cout) >= (1LL << 40)) return CRB_ERR_ARG;
+  a.RT = (int)rt;
+  a.tw4 = (a.tw + TB_COLS - 1) / TB_COLS;
+  const int64_t nb = (int64_t)((rt + TB_ROWS - 1) / TB_ROWS) * a.tw4;
+  if (nb >= (1LL << 26)) return CRB_ERR_ARG;
+  a.nblocks = (int)nb;
+  a.ncb = cout / WG_K;
+  const size_t lds = LDS_FLOATS * sizeof(float);
+  auto kern = winograd2_kernel<0>;
+#ifdef CRB_MEASURE
+  if (g_wino2_mode == 1) kern = winograd2_kernel<1>;
+  if (g_wino2_mode == 2) kern = winograd2_kernel<2>;
+  if (g_wino2_mode == 3) kern = winograd2_kernel<3>;
+  if (g_wino2_mode == 4) kern = winograd2_kernel<4>;
+  if (g_wino2_mode == 5) kern = winograd2_kernel<5>;
+  if (g_wino2_mode == 6) kern = winograd2_kernel<6>;
+#endif
+  static bool attr_done = false;
+  if (!attr_done || g_wino2_mode) {
+    CRB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  // persistent workgroups: one per CU (all of the LDS each), every one runs a contiguous range of units as one pipeline
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    CRB_HIP(hipGetDevice(&dev));
+    CRB_HIP(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int64_t units = nb * a.ncb;
+  a.persistent = g_wino2_persistent;
+  const int64_t grid = a.persistent ? (units < n_cu ? units : n_cu) : ((nb + 7) / 8) * 8 * a.ncb;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, (hipStream_t)stream, a);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}

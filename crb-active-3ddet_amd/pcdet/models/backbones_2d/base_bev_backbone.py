@@ -1,5 +1,5 @@
-"""BaseBEVBackbone (pcdet/models/backbones_2d/base_bev_backbone.py:6-112): dense 2-D convs; stays on the stock
-PyTorch-ROCm / MIOpen path (not a hand-written kernel). Same module tree => same state_dict keys."""
+"""BaseBEVBackbone (pcdet/models/backbones_2d/base_bev_backbone.py:6-112): dense 2-D convs. Same module tree => same
+state_dict keys. The stride-1 3x3 convolutions run on the hand-written Winograd kernel (below), the rest on MIOpen."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -12,18 +12,19 @@ from ...utils.linear_rows import LinearRows, rows_view, rows_to_nchw
 
 ROWS_TRAIN = True      # BatchNorm2d+ReLU pairs through the fused row kernels when the activations are channels_last
 ROWS_GEMM = True       # kernel-1 stride-1 up-sampling branch (ConvTranspose2d 1x1) as a row GEMM on the channels_last map
-# OPT-IN (CRB_WINOGRAD=1 or set the flag): the stride-1 3x3 convolutions (10 of the 12 of the KITTI / Waymo configs) as
-# hand-written F(2x2,3x3) Winograd on the f32 MFMA (crbhip.winograd) instead of MIOpen's implicit GEMM: forward (in eval with
-# BatchNorm folded into the transformed weights and bias + ReLU in the kernel's epilogue: one launch per layer) and input
-# gradient; the weight gradient stays on MIOpen. Results equal the direct convolution up to f32 rounding of the transforms
-# (4e-7 of the output scale against an f64 convolution; MIOpen's own error there is 1.2e-6). MIOpen stays the default.
-WINOGRAD = __import__('os').environ.get('CRB_WINOGRAD', '0') == '1'
+# The stride-1 3x3 convolutions (11 of the 12 of the KITTI config) run as hand-written F(2x2,3x3) Winograd on the f32 MFMA
+# (crbhip.winograd, csrc/winograd_conv2.hip) instead of MIOpen's implicit GEMM: forward (in eval with BatchNorm folded into the
+# transformed weights and bias + ReLU in the kernel's epilogue: one launch per layer) and input gradient; the weight gradient
+# stays on MIOpen. Results equal the direct convolution up to f32 rounding of the transforms (4e-7 of the output scale against an
+# f64 convolution; MIOpen's own error there is 1.2e-6). Round 4: 0.77 ms per 128->128 @ 16x200x176 call against MIOpen's 1.41 —
+# the default; CRB_WINOGRAD=0 (or the flag) gives the MIOpen path back.
+WINOGRAD = __import__('os').environ.get('CRB_WINOGRAD', '1') != '0'
 
 
 def _wino_fold(w, shift):
-    """fold_conv_bn transform: folded conv weight (Cout,Cin,3,3) -> U (16,Cin,Cout) of the Winograd kernel, bias"""
+    """fold_conv_bn transform: folded conv weight (Cout,Cin,3,3) -> weight image of the Winograd kernel, bias"""
     from crbhip import winograd
-    return winograd.weights_forward(w), shift.contiguous()
+    return winograd.weights_forward2(w), shift.contiguous()
 
 
 def _wino_ok(conv, x, pad=None):
@@ -32,7 +33,8 @@ def _wino_ok(conv, x, pad=None):
     from crbhip import winograd
     p = tuple(conv.padding) if pad is None else tuple(pad)
     return conv.kernel_size == (3, 3) and conv.stride == (1, 1) and p == (1, 1) and conv.dilation == (1, 1) and \
-        conv.groups == 1 and conv.padding_mode == 'zeros' and winograd.supported(conv.in_channels, conv.out_channels) and \
+        conv.groups == 1 and conv.padding_mode == 'zeros' and \
+        winograd.supported2(conv.in_channels, conv.out_channels, x.shape[2], x.shape[3]) and \
         x.is_contiguous(memory_format=torch.channels_last)
 
 
@@ -97,7 +99,7 @@ class BaseBEVBackbone(nn.Module):
                 if _wino_ok(m, x, pad):
                     from crbhip import winograd
                     U, shift = fold_conv_bn(m, bn, _wino_fold)
-                    x = winograd.conv3x3_U(x, U, shift, relu)
+                    x = winograd.conv3x3_U2(x, U, shift, relu)
                     i += 3 if relu else 2
                     continue
                 rows_ok = x.is_cuda and x.is_contiguous(memory_format=torch.channels_last) and m.bias is None
@@ -136,6 +138,9 @@ class BaseBEVBackbone(nn.Module):
             c = mods[i + 1]
             pd = m.padding
             if c.padding == (0, 0) and c.padding_mode == 'zeros' and pd[0] == pd[1] and pd[2] == pd[3]:
+                if _wino_ok(c, x, (pd[2], pd[0])):
+                    from crbhip import winograd
+                    return winograd.conv3x3(x, c.weight, c.bias), 2
                 return torch.nn.functional.conv2d(x, c.weight, c.bias, c.stride, (pd[2], pd[0]), c.dilation, c.groups), 2
         return None, 0
 

@@ -537,6 +537,22 @@ int crb_winograd_weights(const float* g, float* U, int cin, int cout, void* stre
 int crb_conv3x3_winograd_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
                               const float* bias, int relu, void* stream);
 
+/* a7, second design (round 4): the same convolution with two waves per SIMD (128 accumulators each), the raw input block and
+ * the weight block brought into LDS by LDS-DMA once per workgroup and chunk, the input transform read from LDS; workgroup =
+ * 16 x 4 tiles of one spatial block x 64 output channels (csrc/winograd_conv2.hip). Same operands as above except the weight
+ * image: crb_winograd2_weights writes U in the order the kernel's LDS-DMA copies it ([Cout/64][Cin/8][LDS image of a chunk]),
+ * crb_winograd2_weights_bytes floats*4. crb_winograd2_supported: Cin % 8 == 0, Cout % 64 == 0, H >= 5. */
+int crb_winograd2_supported(int cin, int cout, int H, int W);
+int64_t crb_winograd2_weights_bytes(int cin, int cout);
+int crb_winograd2_weights(const float* g, float* U, int cin, int cout, void* stream);
+/* the same image straight from an nn.Conv2d weight (Cout,Cin,3,3) with element strides (so, si, sky, skx) — contiguous or
+ * channels_last, no permuted copy: mode 0 = forward (Cin -> Cout), mode 1 = input gradient (the convolution dy -> dx with the
+ * flipped, transposed weights: Cout -> Cin) */
+int crb_winograd2_weights_conv(const float* w, int64_t so, int64_t si, int64_t sky, int64_t skx, float* U, int conv_cin,
+                               int conv_cout, int mode, void* stream);
+int crb_conv3x3_winograd2_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
+                               const float* bias, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

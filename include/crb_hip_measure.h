@@ -16,6 +16,12 @@ extern "C" {
 int crb_mask_sort_set_rank_bits(int mode);
 /* measurement builds of the Winograd convolution (wrong results): 1 = no MFMAs, 2 = no staging of the next chunk */
 int crb_winograd_set_mode(int mode);
+/* measurement builds of the second Winograd design (wrong results): 1 = no MFMAs, 2 = no input transform, 3 = no LDS-DMA in the loop; 4, 5 below */
+int crb_winograd2_set_mode(int mode);
+/* mode 4 (correct results + stamps) writes 16 uint64 per workgroup {s_memtime: start, after prologue, after chunks, end; wall_clock64 (100 MHz): start, end; XCC id; -}; mode 5 = barrier after the last pair's MFMAs (A/B). NULL = off */
+int crb_winograd2_set_debug(void* dev_buf_u64x16_per_wg);
+/* A/B: 1 = persistent workgroups (one per CU, contiguous unit ranges, one pipeline), 0 = one unit per workgroup (default) */
+int crb_winograd2_set_persistent(int on);
 /* measurement builds of crb_tables_finish's chunk pass (wrong tables by design): bit 0 = no sort, bit 1 = no packed-index fill,
  * bit 2 = no pair lists */
 int crb_tables_set_skip(int bits);

@@ -38,7 +38,8 @@ def test_product_library_exports_no_measurement_entry_point():
 def test_abi_version_and_pure_host_queries():
     import crbhip
     assert crbhip.lib.crb_abi_version() >= 1
-    assert crbhip.lib.crb_hash_capacity_for(1000) == 2048
+    assert crbhip.lib.crb_hash_capacity_for(1000) == 8192          # small tables: every key % 8 class holds all keys
+    assert crbhip.lib.crb_hash_capacity_for(300000) == 1048576
     assert crbhip.lib.crb_voxelize_workspace_bytes(20000, 1, 16000, 5) > 0
     assert crbhip.lib.crb_sparse_conv_supported(64, 64) == 1
     assert crbhip.lib.crb_sparse_conv_supported(7, 9) == 0

@@ -39,6 +39,27 @@ def test_subm_rulebook_exact(dev, clustered):
         np.testing.assert_array_equal(pin[pstart[o]:pstart[o + 1]], nbr[i, o])
 
 
+@pytest.mark.parametrize('n', [300, 140000])
+def test_site_hash_survives_inputs_whose_sites_share_one_x_residue(dev, n):
+    """the x-grouped site hash keeps one sub-table per key % 8; with W % 8 == 0 a wall at x = 0 (mod 8) puts every
+    key into ONE of them. 300 sites used to overflow the 128 slots a 1,024-slot table gave a residue class (endless probe =
+    GPU hang); 140,000 sites (> 128 Ki: the table is sized 2n overall, the class holds 65,536) exercise the spill into the
+    next class. Tables stay bit-exact (planned chain and single-table route)."""
+    from crbhip import sparse
+    rng = np.random.default_rng(77)
+    shape = [41, 1600, 1408]
+    z = rng.integers(0, shape[0], 3 * n)
+    y = rng.integers(0, shape[1], 3 * n)
+    x = 8 * rng.integers(0, 6, 3 * n)                       # 6 planes, all x = 0 (mod 8): neighbours in y / z only
+    lin = np.unique((z * shape[1] + y) * shape[2] + x)[:n]
+    rng.shuffle(lin)
+    coords = np.stack([np.zeros_like(lin), lin // (shape[1] * shape[2]), (lin // shape[2]) % shape[1], lin % shape[2]], 1).astype(np.int32)
+    assert len(coords) == n and (coords[:, 3] % 8 == 0).all()
+    rb = sparse.subm_rulebook(_t(coords, dev), shape, [3, 3, 3])
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(rb.nbr.cpu().numpy(), oracle.subm_nbr(coords, shape, [3, 3, 3]))
+
+
 @pytest.mark.parametrize('ks,st,pd', [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)),
                                       ((3, 1, 1), (2, 1, 1), (0, 0, 0))])
 def test_spconv_rulebook_exact(dev, ks, st, pd):
