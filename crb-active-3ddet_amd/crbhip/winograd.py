@@ -110,6 +110,34 @@ def conv3x3_U(x, U, bias=None, relu=False):
     return y
 
 
+def wgrad_supported(cin, cout, H, W):
+    return bool(lib.crb_winograd2_wgrad_supported(int(cin), int(cout), int(H), int(W)))
+
+
+_WGRAD_WS = {}
+
+
+def conv3x3_wgrad(x, dy, like):
+    """x (N,Cin,H,W), dy (N,Cout,H,W) f32 channels_last -> gradient of the nn.Conv2d weight (Cout,Cin,3,3) in the memory layout
+    of `like` (crb_winograd2_wgrad: both operands transformed inside the kernel, dW = G^T dU G)"""
+    require_cuda(x, dy)
+    xv, gv = _nhwc(x.float()), _nhwc(dy.float())
+    N, H, W, cin = xv.shape
+    cout = gv.shape[3]
+    if gv.shape[:3] != xv.shape[:3] or not wgrad_supported(cin, cout, H, W):
+        raise CrbHipError('no Winograd weight-gradient instance for %d -> %d channels' % (cin, cout))
+    dw = torch.empty_like(like, dtype=torch.float32)
+    nbytes = int(lib.crb_winograd2_wgrad_workspace_bytes(cin, cout))
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
+    ws = _WGRAD_WS.get(key)                      # one per (device, stream): every call on a stream is ordered behind the last
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = _WGRAD_WS[key] = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+    so, si, sky, skx = dw.stride()
+    check(lib.crb_winograd2_wgrad(xv.data_ptr(), gv.data_ptr(), dw.data_ptr(), so, si, sky, skx, N, H, W, cin, cout, ptr(ws),
+                                  ws.numel() * 4, cur_stream(x.device)), 'crb_winograd2_wgrad')
+    return dw
+
+
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -124,18 +152,25 @@ class _Conv3x3(torch.autograd.Function):
         wino_dx = ctx.needs_input_grad[0] and supported2(weight.shape[0], weight.shape[1], x.shape[2], x.shape[3])
         if wino_dx:
             dx = conv3x3_U2(dy, weights_input_grad2(weight))
-        if ctx.needs_input_grad[1] or (ctx.needs_input_grad[0] and not wino_dx):
+        wino_dw = WGRAD and ctx.needs_input_grad[1] and wgrad_supported(weight.shape[1], weight.shape[0], x.shape[2], x.shape[3])
+        if wino_dw:
+            dw = conv3x3_wgrad(x, dy, weight)
+        if (ctx.needs_input_grad[1] and not wino_dw) or (ctx.needs_input_grad[0] and not wino_dx):
             gi, gw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                             [ctx.needs_input_grad[0] and not wino_dx,
-                                                             ctx.needs_input_grad[1], False])
-            dw = gw if ctx.needs_input_grad[1] else None
+                                                             ctx.needs_input_grad[1] and not wino_dw, False])
+            dw = gw if (ctx.needs_input_grad[1] and not wino_dw) else dw
             dx = gi if (ctx.needs_input_grad[0] and not wino_dx) else dx
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum((0, 2, 3))
         return dx, dw, db
 
 
+WGRAD = __import__('os').environ.get('CRB_WINOGRAD_WGRAD', '1') != '0'      # 0: weight gradients on MIOpen (A/B)
+
+
 def conv3x3(x, weight, bias=None):
-    """differentiable 3x3 stride-1 pad-1 convolution: forward and input gradient on the Winograd kernel, weight gradient on
-    MIOpen (aten.convolution_backward). Callers check `supported2(Cin, Cout, H, W)` first."""
+    """differentiable 3x3 stride-1 pad-1 convolution: forward, input gradient and weight gradient on the Winograd kernels
+    (weight gradient on MIOpen where crb_winograd2_wgrad has no instance: channel counts not multiples of 64).
+    Callers check `supported2(Cin, Cout, H, W)` first."""
     return _Conv3x3.apply(x, weight, bias)

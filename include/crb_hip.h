@@ -553,6 +553,19 @@ int crb_winograd2_weights_conv(const float* w, int64_t so, int64_t si, int64_t s
 int crb_conv3x3_winograd2_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
                                const float* bias, int relu, void* stream);
 
+/* a7 backward: weight gradient of the same convolution in the Winograd domain (csrc/winograd_wgrad.hip):
+ * dU[xi][ci][co] = sum over tiles of (B^T d B)[xi][ci] * (A dY A^T)[xi][co] as 16 MFMA GEMMs whose two operands are both
+ * produced by transforms inside the kernel, partial sums per range of tiles in the workspace, then dW = G^T dU G added up in
+ * range order in double (bit-reproducible).
+ * replaces: aten.convolution_backward(..., output_mask = [False, True, False]) = MIOpen's f32 implicit-GEMM wrw kernels for
+ *           torch.nn.Conv2d(C, C, 3, padding=1) of pcdet/models/backbones_2d/base_bev_backbone.py:24-41.
+ * x (N,H,W,Cin), dy (N,H,W,Cout) f32 NHWC; dw = gradient of the nn.Conv2d weight (Cout,Cin,3,3), written with that tensor's
+ * element strides (so, si, sky, skx); Cin % 64 == 0, Cout % 64 == 0. */
+int crb_winograd2_wgrad_supported(int cin, int cout, int H, int W);
+int64_t crb_winograd2_wgrad_workspace_bytes(int cin, int cout);
+int crb_winograd2_wgrad(const float* x, const float* dy, float* dw, int64_t so, int64_t si, int64_t sky, int64_t skx,
+                        int N, int H, int W, int cin, int cout, void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

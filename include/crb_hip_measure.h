@@ -22,6 +22,8 @@ int crb_winograd2_set_mode(int mode);
 int crb_winograd2_set_debug(void* dev_buf_u64x16_per_wg);
 /* A/B: 1 = persistent workgroups (one per CU, contiguous unit ranges, one pipeline), 0 = one unit per workgroup (default) */
 int crb_winograd2_set_persistent(int on);
+/* measurement builds of the Winograd weight gradient (wrong results): 1 = no MFMAs, 2 = no transforms, 3 = no DMA / gradient loads in the loop */
+int crb_winograd2_wgrad_set_mode(int mode);
 /* measurement builds of crb_tables_finish's chunk pass (wrong tables by design): bit 0 = no sort, bit 1 = no packed-index fill,
  * bit 2 = no pair lists */
 int crb_tables_set_skip(int bits);

@@ -79,6 +79,34 @@ def test_winograd_conv_matches_direct_convolution(dev, N, C, K, H, W):
             assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize('N,C,K,H,W', [(2, 64, 64, 9, 11), (1, 128, 64, 40, 31), (3, 64, 192, 7, 5), (2, 128, 128, 37, 29), (16, 64, 64, 50, 44),
+                                        (1, 64, 64, 1, 1), (5, 256, 128, 12, 9)])
+def test_winograd_weight_gradient_matches_f64(dev, N, C, K, H, W):
+    """crb_winograd2_wgrad (dU = sum over tiles of V (x) M as MFMA GEMMs, dW = G^T dU G) against the f64 weight gradient of the
+    direct convolution: <= 2e-5 of the largest entry (observed 1.3e-7; MIOpen's wrw: 1.4e-7 .. 4e-7). Odd sizes: half tiles and
+    partial chunks (2 x 4 tiles); 1 x 1 maps: all-padding patches; 16 x 64 x 50 x 44: more chunks than ranges, (1, ...): fewer
+    (empty ranges write zero partials). Bit-equal reruns; the gradient lands in the weight's own memory layout."""
+    from crbhip import winograd
+    torch.manual_seed(N * 100 + C + K + H)
+    assert winograd.wgrad_supported(C, K, H, W)
+    x = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(N, K, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(K, C, 3, 3, device=dev)
+    w64 = w.double().requires_grad_(True)
+    F.conv2d(x.double(), w64, None, padding=1).backward(dy.double())
+    want = w64.grad
+    for like in (w, w.contiguous(memory_format=torch.channels_last)):
+        got = winograd.conv3x3_wgrad(x, dy, like)
+        assert got.shape == w.shape and got.stride() == like.stride()
+        assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+        assert torch.equal(got, winograd.conv3x3_wgrad(x, dy, like))
+    # the autograd node uses it
+    if winograd.supported2(C, K, H, W):
+        wg = w.clone().requires_grad_(True)
+        winograd.conv3x3(x, wg, None).backward(dy)
+        assert torch.equal(wg.grad, winograd.conv3x3_wgrad(x, dy, w))
+
+
 def test_winograd_kernel_reports_what_it_cannot_run(dev):
     from crbhip import winograd
     assert not winograd.supported2(128, 128, 4, 40)          # H < 5: a block of 16 tile rows would cross > 5 image boundaries
