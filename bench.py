@@ -58,6 +58,8 @@ def parse():
                          'rank-strided shard per GPU; 0 = skip)')
     ap.add_argument('--scoring-repeats', type=int, default=3)
     ap.add_argument('--stage2-batch', type=int, default=0, help='frames per train-mode stage-2 pass (0 = ACTIVE_CONFIG.STAGE2_BATCH)')
+    ap.add_argument('--scoring-batch-ref', type=int, default=16, help='second scoring measurement at the reference\'s evaluation batch size '
+                    '(reported as crb_scoring.at_reference_batch; 0 = skip)')
     ap.add_argument('--scoring-batch', type=int, default=64,
                     help='frames per scoring batch: an eval-mode pass scores every frame on its own, the batch size is the '
                          "caller's loader setting; ~4 ms of every pass are per-batch costs (table plan, small launches, idle): "
@@ -356,6 +358,18 @@ def crb_scoring_bench(args, rank, world, device):
         times.append(dt)
     med = float(np.median(times))
     assert rec.shape[0] == n and len(strat.bbox_records) == n
+    # the same pool at the reference's evaluation batch size (16 frames per batch: tools/cfgs/*/pv_rcnn_active_crb.yaml
+    # BATCH_SIZE_PER_GPU / paper supp. B): the frames are re-batched by one untimed loader pass, then resident passes
+    ref_bs, at_ref = getattr(args, 'scoring_batch_ref', 0), None
+    if ref_bs > 0 and ref_bs != bs:
+        kept_ref = list(strat.upload_pool_batches(mine, ref_bs))
+        strat.score_device_batches(kept_ref[:2])
+        t_ref = [timed(lambda: strat.stage1(device_batches=kept_ref))[1] for _ in range(2)]
+        at_ref = {'value': round(n / float(np.median(t_ref)), 3), 'unit': 'frames/s', 'frames_per_batch': ref_bs,
+                  'seconds_all': [round(t, 3) for t in t_ref],
+                  'note': 'resident passes at the reference\'s evaluation batch size; `value` above uses --scoring-batch frames per '
+                          'batch (an eval-mode pass scores every frame on its own: the batch size is the caller\'s loader setting)'}
+        del kept_ref
     miopen_s = None
     if getattr(args, 'miopen_steps', 0) > 0:
         from pcdet.models.backbones_2d import base_bev_backbone as bev
@@ -397,6 +411,7 @@ def crb_scoring_bench(args, rank, world, device):
                                'loader_workers': workers,
                                'note': 'one pass, frames generated + collated by the loader workers and uploaded inside '
                                        'the timed region'},
+            'at_reference_batch': at_ref,
             'selection_round': sel_round,
             'miopen_convs': None if miopen_s is None else {
                 'value': round(n / miopen_s, 3), 'unit': 'frames/s', 'seconds': round(miopen_s, 3),

@@ -962,6 +962,219 @@ def gen_glue(out):
     assert (out['ph_labels'] == -1).sum() > 3 and (out['ph_labels'] == 1).sum() > 10
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# configs[2] at the detector level: the reference's own PVRCNN (pcdet/models/detectors/pv_rcnn.py:9-43) — every module of
+# build_networks() and get_training_loss() — on the CPU; the compiled ops and spconv are answered by the oracle.
+# ---------------------------------------------------------------------------------------------------------------------
+PV_KEYPOINTS = 256
+PV_POINTS = 8000
+PV_FIRST_FRAME = 40
+# gradients stored (one per module of the detector) and the slice of each that is kept (the whole tensors would be 30 MB)
+PV_GRADS = {'backbone_3d.conv_input.0.weight': np.s_[:], 'backbone_3d.conv3.1.0.weight': np.s_[:16],
+            'backbone_2d.blocks.0.1.weight': np.s_[:24], 'pfe.SA_layers.3.mlps.1.0.weight': np.s_[:],
+            'roi_head.shared_fc_layer.0.weight': np.s_[:, :384], 'point_head.cls_layers.0.weight': np.s_[:64],
+            'dense_head.conv_box.weight': np.s_[:], 'roi_head.roi_grid_pool_layer.mlps.0.0.weight': np.s_[:]}
+PV_SMALL = ('dense_head.conv_cls.weight', 'dense_head.conv_box.weight', 'dense_head.conv_dir_cls.weight')
+
+
+def pv_seeded_state(module):
+    """seeded_state(module, 71) with the three prediction convolutions of the dense head scaled by 0.05: proposals stay close
+    to their anchors (sane box sizes) and the classification loss of random weights stays O(10) instead of O(1000)"""
+    sd = seeded_state(module, 71)
+    for k in PV_SMALL:
+        sd[k] = sd[k] * 0.05
+    return sd
+
+
+def _install_spconv_oracle(oracle):
+    """spconv.pytorch as the reference's backbone / map_to_bev use it (spconv_backbone.py:8-157, height_compression.py:20-24),
+    answered by the oracle's restated semantics (sparse_conv_oracle.c: rulebooks, forward, input and weight gradient) wrapped
+    as autograd Functions; strided outputs in ascending linear (b,z,y,x) order. spconv itself is not in the reference tree."""
+    from oracle.second_cpu import _OracleConv
+
+    class SparseConvTensor:
+        def __init__(self, features, indices, spatial_shape, batch_size):
+            self.features, self.indices = features, indices
+            self.spatial_shape, self.batch_size = [int(v) for v in spatial_shape], int(batch_size)
+            self.rulebooks = {}
+
+        def replace_feature(self, f):
+            t = SparseConvTensor(f, self.indices, self.spatial_shape, self.batch_size)
+            t.rulebooks = self.rulebooks
+            return t
+
+        def dense(self):
+            c = self.indices.long()
+            d, h, w = self.spatial_shape
+            out = torch.zeros(self.batch_size, d, h, w, self.features.shape[1])
+            out = out.index_put((c[:, 0], c[:, 1], c[:, 2], c[:, 3]), self.features)
+            return out.permute(0, 4, 1, 2, 3).contiguous()
+
+    class SparseConvolution(torch.nn.Module):
+        def __init__(self, cin, cout, k, stride=1, padding=0, bias=True, indice_key=None, subm=False):
+            super().__init__()
+            assert not bias
+            t3 = lambda v: [int(v)] * 3 if np.isscalar(v) else [int(x) for x in v]
+            self.kernel_size, self.stride, self.padding, self.subm, self.indice_key = t3(k), t3(stride), t3(padding), subm, indice_key
+            self.weight = torch.nn.Parameter(torch.zeros(cout, *self.kernel_size, cin))      # spconv 2.x layout
+
+        def forward(self, x):
+            coords = x.indices.numpy()
+            K = int(np.prod(self.kernel_size))
+            if self.subm:
+                if self.indice_key not in x.rulebooks:
+                    x.rulebooks[self.indice_key] = oracle.subm_nbr(coords, x.spatial_shape, self.kernel_size)
+                nbr, out = x.rulebooks[self.indice_key], x
+            else:
+                oc, oshape = oracle.spconv_out(coords, x.spatial_shape, self.kernel_size, self.stride, self.padding)
+                nbr = oracle.spconv_nbr(coords, x.spatial_shape, oc, self.kernel_size, self.stride, self.padding)
+                out = SparseConvTensor(None, torch.from_numpy(oc), oshape, x.batch_size)
+            w = self.weight.reshape(self.weight.shape[0], K, -1).permute(1, 2, 0).contiguous()           # (K, Cin, Cout)
+            return out.replace_feature(_OracleConv.apply(x.features, w, nbr, len(coords)))
+
+    class SubMConv3d(SparseConvolution):
+        def __init__(self, cin, cout, k, stride=1, padding=0, bias=True, indice_key=None, **kw):
+            super().__init__(cin, cout, k, 1, padding, bias, indice_key, subm=True)
+
+    class SparseConv3d(SparseConvolution):
+        def __init__(self, cin, cout, k, stride=1, padding=0, bias=True, indice_key=None, **kw):
+            super().__init__(cin, cout, k, stride, padding, bias, indice_key, subm=False)
+
+    class SparseSequential(torch.nn.Sequential):
+        def forward(self, x):
+            for m in self:
+                x = m(x) if isinstance(m, (SparseConvolution, SparseSequential)) else x.replace_feature(m(x.features))
+            return x
+
+    spp = sys.modules['spconv.pytorch']
+    spp.SparseConvTensor, spp.SubMConv3d, spp.SparseConv3d = SparseConvTensor, SubMConv3d, SparseConv3d
+    spp.SparseSequential, spp.SparseModule = SparseSequential, torch.nn.Module
+    spp.conv.SparseConvolution = SparseConvolution
+
+
+def pvrcnn_detector_inputs():
+    """two synthetic KITTI frames of tests/synth.py (the generator the GPU tests use), PV_POINTS points each"""
+    import importlib.util                       # by path: the name `pcdet` is the reference's package in this process
+    spec = importlib.util.spec_from_file_location(
+        'crb_synthetic', os.path.join(os.path.dirname(os.path.dirname(OUT)), 'crb-active-3ddet_amd', 'pcdet', 'datasets', 'synthetic.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.kitti_batch(PV_FIRST_FRAME, 2, PV_POINTS)
+
+
+def pvrcnn_model_cfg():
+    """MODEL section of the reference's pv_rcnn_active_crb.yaml with the two changes the golden needs: 256 keypoints (CPU time)
+    and no dropout in the RoI head (DP_RATIO 0: train-mode dropout draws are not reproducible across implementations)"""
+    import yaml
+    y = yaml.safe_load(open(os.path.join(REF, 'tools/cfgs/active-kitti_models/pv_rcnn_active_crb.yaml')))
+    m = EasyDict(y['MODEL'])
+    m.PFE.NUM_KEYPOINTS = PV_KEYPOINTS
+    m.ROI_HEAD.DP_RATIO = 0.0
+    return m, y['CLASS_NAMES']
+
+
+def gen_pvrcnn_detector(out):
+    """ref_pvrcnn_detector.npz: one training step of the reference's PVRCNN on two frames — loss, every tb_dict entry, the
+    second-stage outputs and eight parameter gradients (one per module of the detector). The RoI sampler's indices
+    (proposal_target_layer.py:116-160: np.random / CPU torch.randint draws) are recorded and stored: the test injects them."""
+    oracle = _install_cpu_ops()
+    _install_pointnet2_ops(oracle)
+    _install_spconv_oracle(oracle)
+    from pcdet.config import cfg as ref_cfg
+    model_cfg, class_names = pvrcnn_model_cfg()
+    ref_cfg.CLASS_NAMES = class_names
+    ref_cfg.MODEL = model_cfg
+    from pcdet.models import build_network
+    from pcdet.models.roi_heads.target_assigner.proposal_target_layer import ProposalTargetLayer
+    pcr, vs = np.array(PP_PCR, np.float32), np.array(PP_VOXEL, np.float32)
+    grid = np.round((pcr[3:6] - pcr[0:3]) / vs).astype(np.int64)
+
+    class Dataset:
+        pass
+    ds = Dataset()
+    ds.class_names, ds.grid_size, ds.point_cloud_range, ds.voxel_size = class_names, grid, pcr, list(vs)
+    ds.depth_downsample_factor = None
+    ds.point_feature_encoder = EasyDict(num_point_features=4)
+    torch.manual_seed(0)
+    model = build_network(model_cfg=model_cfg, num_class=3, dataset=ds)
+    model.load_state_dict(pv_seeded_state(model))
+    model.train()
+    out['pv_keys'] = np.array(sorted(model.state_dict().keys()))
+
+    pts, off, gt0 = pvrcnn_detector_inputs()
+    B = len(off) - 1
+    voxels, coords, npts, _ = oracle.voxelize_batch(pts, off, pcr[:3], vs, grid, 16000, 5)
+    bidx = np.repeat(np.arange(B, dtype=np.float32), np.diff(off))
+
+    def make_batch(gt):
+        return {'points': torch.from_numpy(np.concatenate([bidx[:, None], pts], 1)), 'voxels': torch.from_numpy(voxels.copy()),
+                'voxel_coords': torch.from_numpy(coords.astype(np.float32)), 'voxel_num_points': torch.from_numpy(npts.astype(np.float32)),
+                'gt_boxes': torch.from_numpy(gt.copy()), 'batch_size': B,
+                'frame_id': np.array(['%06d' % (PV_FIRST_FRAME + i) for i in range(B)])}
+    # pass 1 (no gradients): the proposals of the randomly initialised first stage. Ground truth is an INPUT: boxes are placed
+    # on some of those proposals (slightly moved / scaled / turned, class = the proposal's label) so that the second stage has
+    # foreground RoIs and its regression / corner losses are exercised; the forward pass up to the proposals does not read them.
+    captured = {}
+    orig_pl = model.roi_head.proposal_layer
+
+    def capture(bd, nms_config):
+        bd = orig_pl(bd, nms_config=nms_config)
+        captured['rois'], captured['labels'] = bd['rois'].detach().clone(), bd['roi_labels'].detach().clone()
+        return bd
+    model.roi_head.proposal_layer = capture
+    np.random.seed(5); torch.manual_seed(5)
+    with torch.no_grad():
+        model(make_batch(gt0))
+    model.roi_head.proposal_layer = orig_pl
+    rng = np.random.default_rng(77)
+    gt = np.zeros((B, 10, 8), np.float32)
+    for b in range(B):
+        k = 0
+        for r, lab in zip(captured['rois'][b].numpy(), captured['labels'][b].numpy()):
+            ok = (r[3:6] > 0.3).all() and (r[3:6] < 8).all() and 1 < r[0] < 69 and abs(r[1]) < 39 and -2.5 < r[2] < 0.5
+            if ok and all(np.hypot(*(r[:2] - g[:2])) > 3.0 for g in gt[b, :k]):
+                gt[b, k, :7] = r + np.concatenate([rng.uniform(-0.06, 0.06, 3), r[3:6] * rng.uniform(-0.04, 0.04, 3), rng.uniform(-0.04, 0.04, 1)])
+                gt[b, k, 7] = lab
+                k += 1
+            if k == 8:
+                break
+        assert k >= 4, k
+    out['pv_gt'] = gt
+    model.load_state_dict(pv_seeded_state(model))        # (pass 1 advanced the running statistics)
+    batch = make_batch(gt)
+    sampled = []
+    orig = ProposalTargetLayer.subsample_rois
+
+    def recording(self, max_overlaps):
+        idx = orig(self, max_overlaps)
+        sampled.append(idx.clone())
+        return idx
+    ProposalTargetLayer.subsample_rois = recording
+    np.random.seed(5)
+    torch.manual_seed(5)
+    try:
+        ret, tb, _ = model(batch)
+    finally:
+        ProposalTargetLayer.subsample_rois = orig
+    loss = ret['loss']
+    model.zero_grad()
+    loss.backward()
+    out['pv_loss'] = np.array([float(loss.detach())])
+    out['pv_tb_keys'] = np.array(sorted(tb.keys()))
+    out['pv_tb_vals'] = np.array([float(tb[k]) for k in sorted(tb.keys())], np.float64)
+    out['pv_sampled'] = np.stack([_np(s) for s in sampled]).astype(np.int64)
+    out['pv_rcnn_cls'], out['pv_rcnn_reg'] = _np(ret['rcnn_cls']), _np(ret['rcnn_reg'])
+    out['pv_rcnn_cls_gt'], out['pv_rcnn_reg_gt'] = _np(ret['rcnn_cls_gt']), _np(ret['rcnn_reg_gt'])
+    out['pv_rois'] = _np(model.roi_head.forward_ret_dict['rois'])
+    params = dict(model.named_parameters())
+    for n, sl in PV_GRADS.items():
+        out['pv_grad/' + n] = _np(params[n].grad)[sl].copy()
+        out['pv_gradmax/' + n] = np.array([float(params[n].grad.abs().max())])
+    print('  loss %.5f' % float(loss), {k: round(float(v), 5) for k, v in tb.items()})
+    print('  voxels', len(coords), 'sampled', out['pv_sampled'].shape, 'fg rois', int((out['pv_rcnn_cls_gt'] > 0.5).sum()))
+    assert np.isfinite(out['pv_loss']).all() and all(np.abs(out['pv_grad/' + n]).max() > 0 for n in PV_GRADS)
+
+
 if __name__ == '__main__':
     import_reference()
     only = sys.argv[1:] 
@@ -969,7 +1182,7 @@ if __name__ == '__main__':
                      ('ref_strategies.npz', gen_strategies), ('ref_data_processor.npz', gen_data_processor),
                      ('ref_post_processing.npz', gen_post_processing), ('ref_glue.npz', gen_glue),
                      ('ref_badge.npz', gen_badge), ('ref_partA2.npz', gen_partA2),
-                     ('ref_point_path.npz', gen_point_path)):
+                     ('ref_point_path.npz', gen_point_path), ('ref_pvrcnn_detector.npz', gen_pvrcnn_detector)):
         if only and name not in only:
             continue
         d = {}
