@@ -17,6 +17,11 @@ class ProposalTargetLayer(nn.Module):
         super().__init__()
         self.roi_sampler_cfg = roi_sampler_cfg
         self.generator = None          # optional torch.Generator for reproducible draws
+        # parity tests against a reference run whose np.random / torch.randint draws were recorded: use these RoIs instead of
+        # drawing. injected_indices (B, ROI_PER_IMAGE) long = positions in the proposal list; injected_rois (B, ROI_PER_IMAGE, 7)
+        # = the boxes themselves, looked up in the proposal list (proposals with EQUAL scores have no defined order: topk)
+        self.injected_indices = None
+        self.injected_rois = None
 
     def forward(self, batch_dict, uniforms=None):
         cfg = self.roi_sampler_cfg
@@ -70,7 +75,16 @@ class ProposalTargetLayer(nn.Module):
                                                   gt_boxes.reshape(B * G, -1)[:, 0:7])
             iou = iou.view(B, -1, B, G)[torch.arange(B), :, torch.arange(B)]
             max_overlaps, gt_assignment = iou.max(dim=2)
-        sampled = self.subsample_rois_batched(max_overlaps, uniforms)                     # (B, ROI_PER_IMAGE)
+        if self.injected_rois is not None:
+            inj = self.injected_rois.to(rois.device, rois.dtype)
+            dist = (rois[:, None, :, :7] - inj[:, :, None, :7]).abs().amax(-1)                # (B, P, R)
+            best, sampled = dist.min(dim=2)
+            assert float(best.max()) < 1e-3, 'an injected RoI is not among the proposals'
+        elif self.injected_indices is not None:
+            sampled = self.injected_indices.to(max_overlaps.device).long()
+            assert sampled.shape == (B, cfg.ROI_PER_IMAGE)
+        else:
+            sampled = self.subsample_rois_batched(max_overlaps, uniforms)                 # (B, ROI_PER_IMAGE)
         g = lambda t: torch.gather(t, 1, sampled)
         batch_rois = torch.gather(rois, 1, sampled[..., None].expand(-1, -1, rois.shape[-1]))
         assign = g(gt_assignment)

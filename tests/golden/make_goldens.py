@@ -1150,12 +1150,32 @@ def gen_pvrcnn_detector(out):
         sampled.append(idx.clone())
         return idx
     ProposalTargetLayer.subsample_rois = recording
+    inter = {}
+    orig_pool = model.roi_head.roi_grid_pool
+
+    def pool_capture(bd):
+        inter['point_features'] = bd['point_features'].detach().clone()
+        inter['point_cls_scores'] = bd['point_cls_scores'].detach().clone()
+        inter['point_coords'] = bd['point_coords'].detach().clone()
+        p = orig_pool(bd)
+        inter['pooled'] = p.detach().clone()
+        return p
+    model.roi_head.roi_grid_pool = pool_capture
+    model.roi_head.proposal_layer = capture
     np.random.seed(5)
     torch.manual_seed(5)
     try:
         ret, tb, _ = model(batch)
     finally:
         ProposalTargetLayer.subsample_rois = orig
+        model.roi_head.roi_grid_pool, model.roi_head.proposal_layer = orig_pool, orig_pl
+    # intermediate results (first-stage proposals before sampling, keypoints, RoI-grid pooled features: a failing comparison
+    # of the second-stage outputs can be traced to the module that differs)
+    out['pv_proposals'], out['pv_proposal_labels'] = _np(captured['rois']), _np(captured['labels'])
+    out['pv_point_coords'] = _np(inter['point_coords'])
+    out['pv_point_features'] = _np(inter['point_features'])[:, :32].copy()
+    out['pv_point_cls_scores'] = _np(inter['point_cls_scores'])
+    out['pv_pooled'] = _np(inter['pooled'])[:, ::27, :16].copy()          # (256 RoIs, 8 of 216 grid points, 16 of 128 channels)
     loss = ret['loss']
     model.zero_grad()
     loss.backward()

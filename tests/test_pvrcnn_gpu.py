@@ -235,3 +235,82 @@ def test_dense_half_before_pfe_schedule_gives_identical_outputs(model, dev):
             assert torch.equal(a, b), (k, float((a - b).abs().max()))
         else:       # RoI-head outputs: 1.6e-8 apart once in a full-suite run (equal when the test runs alone); cause not isolated
             assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max())), (k, float((a - b).abs().max()))
+
+
+def test_train_step_matches_the_reference_detector(dev):
+    """configs[2] at the detector level: ONE training step of the mirror's PVRCNN against tests/golden/ref_pvrcnn_detector.npz,
+    written by the reference's own PVRCNN (pcdet/models/detectors/pv_rcnn.py:9-43 — every module of build_networks() and
+    get_training_loss(): rpn + point + rcnn losses) on the CPU with the compiled ops and spconv answered by the oracle
+    (make_goldens.py:gen_pvrcnn_detector; MODEL section of the reference's pv_rcnn_active_crb.yaml with 256 keypoints and
+    DP_RATIO 0). Same seeded weights by parameter name, same two synthetic frames, the reference's recorded RoI-sampler indices
+    injected (proposal_target_layer.py:116-160 draws from np.random / CPU torch.randint).
+    Tolerances: loss and the tb_dict entries 2e-4 relative (f32 sums in another order through train-mode BatchNorm over ~13k
+    voxels / 2 x 256 keypoints), second-stage outputs 2e-3 of their largest magnitude, parameter gradients 2e-2 of their
+    largest entry (the backward through the BEV backbone's 11 train-mode BatchNorm layers amplifies f32 rounding to several
+    1e-3 at B = 2 on any implementation: tests/test_winograd_gpu.py)."""
+    import os
+    from golden.make_goldens import PV_FIRST_FRAME, PV_GRADS, PV_KEYPOINTS, PV_POINTS, pv_seeded_state
+    from pcdet.datasets import SyntheticDataset
+    from pcdet.model_cfgs import pv_rcnn_cfg
+    from pcdet.models import build_network
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_pvrcnn_detector.npz'))
+    cfg = pv_rcnn_cfg().MODEL
+    cfg.PFE.NUM_KEYPOINTS = PV_KEYPOINTS
+    cfg.POINT_HEAD.NUM_KEYPOINTS = PV_KEYPOINTS
+    cfg.ROI_HEAD.DP_RATIO = 0.0
+    torch.manual_seed(0)
+    model = build_network(cfg, 3, SyntheticDataset(num_frames=2))
+    assert sorted(model.state_dict().keys()) == list(G['pv_keys'])               # the reference's parameter / buffer names
+    model.load_state_dict(pv_seeded_state(model))
+    model.to(dev).train()
+    b, _, _, _ = _batch(dev, PV_FIRST_FRAME, 2, PV_POINTS)
+    b['gt_boxes'] = torch.from_numpy(G['pv_gt']).to(dev)
+    # the reference's sampled RoIs as boxes (equal-score proposals have no defined order, a few neighbours come out swapped)
+    ref_sampled = np.take_along_axis(G['pv_proposals'], G['pv_sampled'][:, :, None], axis=1)
+    model.roi_head.proposal_target_layer.injected_rois = torch.from_numpy(ref_sampled)
+    inter = {}
+    head = model.roi_head
+    orig_pl, orig_pool = head.proposal_layer, head.roi_grid_pool
+
+    def pl(bd, nms_config):
+        t = orig_pl(bd, nms_config=nms_config)
+        inter['proposals'], inter['labels'] = bd['rois'].detach().clone(), bd['roi_labels'].detach().clone()
+        return t
+
+    def pool(bd):
+        inter['pf'], inter['ps'], inter['pc'] = bd['point_features'].detach(), bd['point_cls_scores'].detach(), bd['point_coords'].detach()
+        inter['pooled'] = orig_pool(bd)
+        return inter['pooled']
+    head.proposal_layer, head.roi_grid_pool = pl, pool
+    ret, tb, _ = model(b)
+    head.proposal_layer, head.roi_grid_pool = orig_pl, orig_pool
+    model.zero_grad(set_to_none=True)
+    ret['loss'].backward()
+    torch.cuda.synchronize()
+    # module by module: first-stage proposals (as a set per frame: equal scores have no order), keypoints (FPS picks: exact),
+    # keypoint features and scores, RoI-grid pooled features of the sampled RoIs
+    pr, want_pr = inter['proposals'].cpu().numpy(), G['pv_proposals']
+    for f in range(2):
+        dist = np.abs(pr[f][:, None, :] - want_pr[f][None, :, :]).max(-1)              # (512, 512) L-inf box distances
+        assert dist.min(0).max() <= 5e-4 and dist.min(1).max() <= 5e-4    # box coordinates up to 70 m: 5e-4 = 7e-6 relative
+    assert (np.abs(pr - want_pr).max(-1) > 1e-3).sum() <= 16            # ... and in the same order except for a few ties
+    np.testing.assert_array_equal(inter['pc'].cpu().numpy(), G['pv_point_coords'])
+    _rel = lambda got, want: float(np.abs(got - want).max() / np.abs(want).max())
+    assert _rel(inter['pf'].cpu().numpy()[:, :32], G['pv_point_features']) <= 1e-4
+    assert _rel(inter['ps'].cpu().numpy(), G['pv_point_cls_scores']) <= 1e-5
+    assert _rel(inter['pooled'].detach().cpu().numpy()[:, ::27, :16], G['pv_pooled']) <= 3e-4
+    np.testing.assert_allclose(float(ret['loss']), float(G['pv_loss'][0]), rtol=2e-4)
+    assert sorted(tb.keys()) == list(G['pv_tb_keys'])
+    for k, want in zip(G['pv_tb_keys'], G['pv_tb_vals']):
+        np.testing.assert_allclose(float(tb[k]), want, rtol=2e-4, atol=2e-5, err_msg=str(k))
+    for k, name in (('rcnn_cls', 'pv_rcnn_cls'), ('rcnn_reg', 'pv_rcnn_reg'), ('rcnn_cls_gt', 'pv_rcnn_cls_gt'), ('rcnn_reg_gt', 'pv_rcnn_reg_gt')):
+        got, want = ret[k].detach().float().cpu().numpy().reshape(G[name].shape), G[name]
+        assert np.abs(got - want).max() <= 2e-3 * max(1e-6, np.abs(want).max()), (k, np.abs(got - want).max(), np.abs(want).max())
+    np.testing.assert_allclose(model.roi_head.forward_ret_dict['rois'].cpu().numpy(), G['pv_rois'], rtol=0, atol=2e-4)
+    params = dict(model.named_parameters())
+    for n, sl in PV_GRADS.items():
+        got, want = params[n].grad.cpu().numpy()[sl], G['pv_grad/' + n]
+        scale = float(G['pv_gradmax/' + n][0])
+        err = float(np.abs(got - want).max()) / scale
+        print('%-48s gradient error %.2e of its largest entry' % (n, err))
+        assert err <= 2e-2, (n, err)
