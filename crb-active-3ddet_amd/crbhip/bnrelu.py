@@ -112,6 +112,26 @@ def supported(x, bn):
             256 % (C // 4) == 0 and bn.affine and bn.track_running_stats)
 
 
+# When set to a list, the training BatchNorm(+ReLU) op appends (kind, n rows, C, ev0, ev1) with HIP events on the launch stream
+# (kind 'bn_fwd' | 'bn_bwd'); bench.py reads them for the kernel table (algorithmic bytes: 3 / 5 passes of 4 n C).
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _prof_end(e0, *rec):
+    if e0 is not None and PROFILE is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.append(rec + (e0, e1))
+
+
 class _BNReLUTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, relu, running_mean=None, running_var=None, momentum=0.0, nbt=None):
@@ -127,9 +147,11 @@ class _BNReLUTrain(torch.autograd.Function):
         wsb = lib.crb_bn_workspace_bytes(n, C)
         ws, tk = _scratch(dev, wsb)
         g, b = gamma.contiguous().float(), beta.contiguous().float()
+        e0 = _prof_begin()
         check(lib.crb_bn_relu_forward(ptr(x), n, C, ptr(g), ptr(b), float(eps), int(relu), ptr(z), 0, ptr(mean), ptr(var),
                                       ptr(invstd), ptr(running_mean), ptr(running_var), ptr(nbt), float(momentum), ptr(ws),
                                       wsb, ptr(tk), cur_stream(dev)), 'crb_bn_relu_forward')
+        _prof_end(e0, 'bn_fwd', n, C)
         _touch(running_mean, running_var, nbt)
         ctx.save_for_backward(x, mean, invstd, g, b)
         ctx.relu = int(relu)
@@ -147,8 +169,10 @@ class _BNReLUTrain(torch.autograd.Function):
         dbeta = torch.empty_like(dgamma)
         wsb = lib.crb_bn_workspace_bytes(n, C)
         ws, tk = _scratch(dev, wsb)
+        e0 = _prof_begin()
         check(lib.crb_bn_relu_backward(ptr(x), ptr(dz), 0, n, C, ptr(mean), ptr(invstd), ptr(g), ptr(b), ctx.relu, ptr(dx),
                                        ptr(dgamma), ptr(dbeta), ptr(ws), wsb, ptr(tk), cur_stream(dev)), 'crb_bn_relu_backward')
+        _prof_end(e0, 'bn_bwd', n, C)
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 

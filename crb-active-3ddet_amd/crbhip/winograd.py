@@ -11,6 +11,27 @@ import torch
 from ._lib import lib, check, ptr, cur_stream, require_cuda, CrbHipError
 
 
+# When set to a list, every Winograd launch appends (kind, cin, cout, N, H, W, ev0, ev1) with HIP events on the launch stream
+# (torch's current stream IS the stream handed to the C-ABI); bench.py reads them for the roofline / kernel table.
+# kind: 'wino_conv' (forward and input gradient: the same kernel) | 'wino_wgrad' (both launches of crb_winograd2_wgrad)
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _prof_end(e0, *rec):
+    if e0 is not None and PROFILE is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.append(rec + (e0, e1))
+
+
 def supported(cin, cout):
     return bool(lib.crb_winograd_supported(int(cin), int(cout)))
 
@@ -82,9 +103,11 @@ def conv3x3_U2(x, U, bias=None, relu=False):
     if ucin != cin or not supported2(cin, cout, H, W):
         raise CrbHipError('no Winograd (2) instance for %d -> %d channels on a %d x %d map' % (cin, cout, H, W))
     y = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    e0 = _prof_begin()
     check(lib.crb_conv3x3_winograd2_nhwc(xv.data_ptr(), ptr(U), y.data_ptr(), N, H, W, cin, cout,
                                          ptr(bias.contiguous().float()) if bias is not None else None, int(bool(relu)),
                                          cur_stream(x.device)), 'crb_conv3x3_winograd2_nhwc')
+    _prof_end(e0, 'wino_conv', cin, cout, N, H, W)
     return y
 
 
@@ -133,8 +156,10 @@ def conv3x3_wgrad(x, dy, like):
     if ws is None or ws.numel() * 4 < nbytes:
         ws = _WGRAD_WS[key] = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
     so, si, sky, skx = dw.stride()
+    e0 = _prof_begin()
     check(lib.crb_winograd2_wgrad(xv.data_ptr(), gv.data_ptr(), dw.data_ptr(), so, si, sky, skx, N, H, W, cin, cout, ptr(ws),
                                   ws.numel() * 4, cur_stream(x.device)), 'crb_winograd2_wgrad')
+    _prof_end(e0, 'wino_wgrad', cin, cout, N, H, W)
     return dw
 
 
