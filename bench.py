@@ -567,6 +567,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
+    miopen_db = 'shared'
+    if world > 1 and 'MIOPEN_USER_DB_PATH' not in os.environ:
+        # N ranks searching MIOpen solvers for the same new shapes would all write ONE user find-db / kernel cache: a db and a
+        # cache per rank (set before the first convolution creates MIOpen's handle). The Winograd kernels left MIOpen only the
+        # stride-2 3x3 convolution, the 2x2 transposed convolution and the up-sampling GEMMs
+        os.environ['MIOPEN_USER_DB_PATH'] = '/tmp/crb_miopen_db_rank%d' % local_rank
+        os.environ.setdefault('MIOPEN_CUSTOM_CACHE_DIR', '/tmp/crb_miopen_cache_rank%d' % local_rank)
+        os.makedirs(os.environ['MIOPEN_USER_DB_PATH'], exist_ok=True)
+        os.makedirs(os.environ['MIOPEN_CUSTOM_CACHE_DIR'], exist_ok=True)
+        miopen_db = 'per rank'
     from pcdet.utils.common_utils import effective_cpu_count
     # torch sizes its intra-op pool by os.cpu_count() (128 threads on the 256-thread host) although the pod may use 16 cores:
     # every host-side copy / concat then spins 128 threads on 16 cores, next to the loader workers
@@ -646,8 +656,11 @@ def main():
         rank_step_ms.append([round(v, 3) for v in _all_ranks(float(np.median(per_step)), world, device)])
         return _max_over_ranks(dt, world, device), per_step, loss
 
+    t_warm = time.perf_counter()
     for i in range(args.warmup):
         step(i)
+    torch.cuda.synchronize()
+    warm_s = _all_ranks(time.perf_counter() - t_warm, world, device)     # solver search + allocator + table caches, per rank
     overhead_ms = event_pair_overhead_ms() if rank == 0 else 0.0
     prof = [] if rank == 0 else None
     dt, per_step, loss = timed_steps(True, prof)
@@ -705,6 +718,7 @@ def main():
                    'final_loss': round(float(loss.item()), 4)},
         'ms_per_step_device': _pctl(per_step),
         'ms_per_step_device_per_rank': rank_step_ms[0],
+        'warmup_seconds_per_rank': [round(v, 3) for v in warm_s], 'miopen_user_db': miopen_db,
         'fwd_bwd_only': {'value': round(frames / dt_nopt, 3), 'unit': 'frames/s',
                          'ms_per_step': round(1e3 * dt_nopt / args.steps, 3), 'ms_per_step_device': _pctl(per_step_nopt),
                          'note': 'same %d steps without grad-clip / optimizer' % args.steps},

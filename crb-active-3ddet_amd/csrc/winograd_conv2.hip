@@ -133,14 +133,15 @@ struct Wino2Args {
 };
 
 // one 16-byte LDS-DMA per lane: LDS destination = wave-uniform base + lane * 16
+template <int AUX = 0>
 __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
 }
 
 // MODE (measurement builds): 1 = no MFMAs, 2 = no transform (V never written), 3 = no DMA after the prologue (all three: wrong
 // results); 4 = correct results + per-workgroup stamps {s_memtime at start, after the prologue, after the chunks (incl. the
-// output transforms), cycles parked at the chunk barriers, wall_clock64 at start and end, XCC id, units} in g_wino2_dbg; 5 = every raw slot copies the zero page (no map traffic), 6 = U always from the first chunk (both wrong)
+// output transforms), cycles parked at the chunk barriers, wall_clock64 at start and end, XCC id, units} in g_wino2_dbg; 5 = every raw slot copies the zero page (no map traffic), 6 = U always from the first chunk (both wrong); 7 / 8 / 9 = nt (non-temporal) LDS-DMA for U / raw / both (correct results, A/B)
 __device__ unsigned long long* g_wino2_dbg = nullptr;
 
 // 16 bytes through the scalar cache (wave-uniform address): the bias of a unit must not go through the vector memory counter,
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   float* const Vb = lds;
   float* const Ub = lds + 2 * V_FLOATS;
   float* const Rb = lds + 2 * V_FLOATS + 2 * U_FLOATS;
+  constexpr int U_AUX = (MODE == 7 || MODE == 9) ? 2 : 0, RAW_AUX = (MODE == 8 || MODE == 9) ? 2 : 0;   // A/B: nt (streaming) DMA
   const int T = threadIdx.x, lane = T & 63, wave = T >> 6;
   unsigned long long stamp[6], tm_stage06 = 0, tm_stage7 = 0, tm_book = 0, tm_epi = 0;
   if (MODE == 4) { stamp[0] = __builtin_amdgcn_s_memtime(); stamp[4] = wall_clock64(); stamp[3] = 0; }
@@ -271,8 +273,8 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   const float* usrc = a.U + (int64_t)uu.cb * nch * U_FLOATS + T * 4;
   auto issue_raw = [&]() {                                    // chunk r_issued -> raw buffer r_issued & 1
     float* buf = Rb + (r_issued & 1) * RAW_FLOATS;
-    glds16(rsrc[0], buf + wave * 256);
-    glds16(rsrc[1], buf + (NT + wave * 64) * 4);              // slots past the block's rows copy the zero page (inside the buffer)
+    glds16<RAW_AUX>(rsrc[0], buf + wave * 256);
+    glds16<RAW_AUX>(rsrc[1], buf + (NT + wave * 64) * 4);              // slots past the block's rows copy the zero page (inside the buffer)
     ++r_issued;
   };
   auto r_advance = [&]() {                                    // after issue_raw: move the sources to the next chunk
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   auto issue_u = [&]() {                                      // chunk u_issued -> U buffer u_issued & 1
     float* buf = Ub + (u_issued & 1) * U_FLOATS;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) glds16(usrc + k * NT * 4, buf + (k * NT + wave * 64) * 4);
+    for (int k = 0; k < 4; ++k) glds16<U_AUX>(usrc + k * NT * 4, buf + (k * NT + wave * 64) * 4);
     ++u_issued;
   };
   auto u_advance = [&]() {
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
 CRB_KNOB g_wino2_persistent = 1; // 1: one workgroup per CU over a range of units (measured 4 - 8 % faster); 0: one unit per workgroup
 CRB_KNOB g_wino2_mode = 0;      // measurement builds: 1 = no MFMAs, 2 = no transform, 3 = no DMA in the loop
 #ifdef CRB_MEASURE
-extern "C" int crb_winograd2_set_mode(int mode) { g_wino2_mode = (mode >= 1 && mode <= 6) ? mode : 0; return CRB_OK; }
+extern "C" int crb_winograd2_set_mode(int mode) { g_wino2_mode = (mode >= 1 && mode <= 9) ? mode : 0; return CRB_OK; }
 extern "C" int crb_winograd2_set_persistent(int on) { g_wino2_persistent = on ? 1 : 0; return CRB_OK; }
 // mode 4: 16 uint64 per workgroup (device buffer of the caller, NULL = off)
 extern "C" int crb_winograd2_set_debug(void* dev_buf) {
@@ -581,6 +583,9 @@ extern "C" int crb_conv3x3_winograd2_nhwc(const float* x, const float* U, float*
   if (g_wino2_mode == 4) kern = winograd2_kernel<4>;
   if (g_wino2_mode == 5) kern = winograd2_kernel<5>;
   if (g_wino2_mode == 6) kern = winograd2_kernel<6>;
+  if (g_wino2_mode == 7) kern = winograd2_kernel<7>;
+  if (g_wino2_mode == 8) kern = winograd2_kernel<8>;
+  if (g_wino2_mode == 9) kern = winograd2_kernel<9>;
 #endif
   static bool attr_done = false;
   if (!attr_done || g_wino2_mode) {

@@ -134,6 +134,48 @@ def test_ddp_second_step_two_ranks_averages_gradients(tmp_path):
     assert rel < 2e-3, rel              # = mean of the two single-rank gradients (MIOpen weight-gradient kernels use atomics)
 
 
+def _syncbn_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    dev = _setup(rank, world, port)
+    from pcdet.datasets import SyntheticDataset
+    from pcdet.datasets.synthetic import kitti_batch
+    from pcdet.model_cfgs import second_cfg
+    from pcdet.models import build_network
+    torch.manual_seed(0)
+    model = build_network(second_cfg().MODEL, 3, SyntheticDataset(num_frames=2))
+    model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model).to(dev)       # tools/train.py:168-169 (--sync_bn)
+    n_sync = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in model.modules())
+    model.train()
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+    pts, off, gt = kitti_batch(3100 + 2 * rank, 2, 6000)
+    bidx = np.repeat(np.arange(2, dtype=np.float32), np.diff(off))
+    b = {'points': torch.from_numpy(np.concatenate([bidx[:, None], pts], 1)).to(dev),
+         'point_frame_offsets': torch.from_numpy(off).to(dev), 'gt_boxes': torch.from_numpy(gt).to(dev), 'batch_size': 2}
+    ret, _, _ = net(b)
+    loss = ret['loss'].mean()
+    loss.backward()
+    g = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None]).double()
+    rm = model.backbone_2d.blocks[0][2].running_mean.detach().double().cpu()
+    torch.save({'loss': float(loss), 'grads': g.cpu(), 'n_sync': n_sync, 'running_mean': rm}, os.path.join(out_dir, 'sbn_r%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_converted_mirror_trains_on_two_ranks(tmp_path):
+    """`--sync_bn` of the reference's tools/train.py:168-169: SyncBatchNorm.convert_sync_batchnorm on the mirror replaces every
+    BatchNorm1d / 2d; the fused BatchNorm pattern matches of the sparse / BEV modules (isinstance BatchNorm1d / 2d) then do not
+    apply and the layers run as torch's SyncBatchNorm (statistics all-gathered over the ranks). One DDP step on two ranks:
+    finite loss, identical all-reduced gradients, identical running statistics (the synchronised batch statistics)."""
+    out = str(tmp_path)
+    _run(_syncbn_worker, 2, (out,))
+    r0, r1 = torch.load(os.path.join(out, 'sbn_r0.pt')), torch.load(os.path.join(out, 'sbn_r1.pt'))
+    assert r0['n_sync'] == r1['n_sync'] and r0['n_sync'] >= 12 + 12                 # 12 sparse + 12 BEV layers at least
+    assert np.isfinite(r0['loss']) and np.isfinite(r1['loss'])
+    assert torch.isfinite(r0['grads']).all() and float(r0['grads'].abs().sum()) > 0
+    assert torch.equal(r0['grads'], r1['grads'])
+    torch.testing.assert_close(r0['running_mean'], r1['running_mean'], rtol=0, atol=0)
+
+
 def test_bench_two_rank_dry_run_prints_the_contract_line(tmp_path):
     """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per process, RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* from the environment), except that both ranks share the one device of this box and the process
@@ -169,3 +211,6 @@ def test_bench_two_rank_dry_run_prints_the_contract_line(tmp_path):
     assert sc['record_bytes_per_frame'] in strides                      # the stage-1 records all-gather
     assert 4 * 65536 in strides                                         # the stage-2 (256 x 256) embedding all-gather
     assert d['cpu_baseline'] is None and d['vs_baseline'] is None
+    # first-real-run hygiene: every rank searched MIOpen solvers in its own user db, warm-up time is reported per rank
+    assert len(d['warmup_seconds_per_rank']) == 2 and all(v > 0 for v in d['warmup_seconds_per_rank'])
+    assert d['miopen_user_db'] == 'per rank'

@@ -76,6 +76,13 @@ if __name__ == '__main__':
                 tm.append(timeit(lambda: winograd.conv3x3_U2(x, U2, b))[0])
             lib.crb_winograd2_set_mode(0)
             print('   measurement builds: no MFMAs %.0f us, no transform %.0f us, no DMA in the loop %.0f us, raw from the zero page %.0f us, U from one chunk %.0f us' % tuple(tm), flush=True)
+            abn = {0: [], 7: [], 8: [], 9: []}
+            for _ in range(3):
+                for mode in abn:
+                    lib.crb_winograd2_set_mode(mode)
+                    abn[mode].append(timeit(lambda: winograd.conv3x3_U2(x, U2, b), it=15, warm=3)[0])
+            lib.crb_winograd2_set_mode(0)
+            print('   A/B LDS-DMA cache policy default / U nt / raw nt / both nt: %s us' % ' / '.join(str(['%.0f' % v for v in abn[m]]) for m in abn), flush=True)
             ab = {0: [], 1: []}
             for _ in range(3):
                 for mode in (0, 1):
