@@ -32,7 +32,7 @@ if __name__ == '__main__':
     quick = '--quick' in sys.argv
     dev = torch.device('cuda', 0)
     torch.manual_seed(0)
-    small = ((2, 128, 128, 37, 29), (3, 64, 64, 7, 5), (2, 8, 64, 9, 11), (1, 256, 128, 40, 31), (20, 24, 64, 5, 9), (7, 16, 128, 6, 4))
+    small = ((2, 128, 128, 37, 29), (3, 64, 64, 33, 17), (5, 32, 192, 31, 9), (2, 128, 64, 40, 31), (3, 64, 64, 7, 5), (2, 8, 64, 9, 11), (1, 256, 128, 40, 31), (20, 24, 64, 5, 9), (7, 16, 128, 6, 4))
     big = ((16, 128, 128, 200, 176), (16, 256, 256, 100, 88), (16, 256, 128, 200, 176))
     for (N, C, K, H, W) in small + big:
         x = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
