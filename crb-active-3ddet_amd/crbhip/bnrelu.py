@@ -24,6 +24,15 @@ def _scratch(dev, wsb):
     return ws, t
 
 
+def _bn_check(rc, what):
+    """check() for the calls that were handed a ticket area: the kernels leave the area zero only when they ran to the end. After
+    a failed / skipped launch the counters may be anything and every later call on the stream would finalize too early or never
+    (ADVICE r03): drop the areas, the next call starts from fresh zeroed ones."""
+    if rc != 0:
+        _ticket_areas.clear()
+    check(rc, what)
+
+
 # ---- per-frame statistics ------------------------------------------------------------------------------------------
 # CRB stage 2 runs the detector in train mode on ONE frame at a time (crb_sampling.py:174-212): every BatchNorm layer
 # normalises with that frame's own statistics. To batch G frames per pass with the same values, the training-mode entry
@@ -148,7 +157,7 @@ class _BNReLUTrain(torch.autograd.Function):
         ws, tk = _scratch(dev, wsb)
         g, b = gamma.contiguous().float(), beta.contiguous().float()
         e0 = _prof_begin()
-        check(lib.crb_bn_relu_forward(ptr(x), n, C, ptr(g), ptr(b), float(eps), int(relu), ptr(z), 0, ptr(mean), ptr(var),
+        _bn_check(lib.crb_bn_relu_forward(ptr(x), n, C, ptr(g), ptr(b), float(eps), int(relu), ptr(z), 0, ptr(mean), ptr(var),
                                       ptr(invstd), ptr(running_mean), ptr(running_var), ptr(nbt), float(momentum), ptr(ws),
                                       wsb, ptr(tk), cur_stream(dev)), 'crb_bn_relu_forward')
         _prof_end(e0, 'bn_fwd', n, C)
@@ -170,7 +179,7 @@ class _BNReLUTrain(torch.autograd.Function):
         wsb = lib.crb_bn_workspace_bytes(n, C)
         ws, tk = _scratch(dev, wsb)
         e0 = _prof_begin()
-        check(lib.crb_bn_relu_backward(ptr(x), ptr(dz), 0, n, C, ptr(mean), ptr(invstd), ptr(g), ptr(b), ctx.relu, ptr(dx),
+        _bn_check(lib.crb_bn_relu_backward(ptr(x), ptr(dz), 0, n, C, ptr(mean), ptr(invstd), ptr(g), ptr(b), ctx.relu, ptr(dx),
                                        ptr(dgamma), ptr(dbeta), ptr(ws), wsb, ptr(tk), cur_stream(dev)), 'crb_bn_relu_backward')
         _prof_end(e0, 'bn_bwd', n, C)
         return dx, dgamma, dbeta, None, None, None, None, None, None
@@ -180,8 +189,17 @@ def _touch(*tensors):
     """tensors a kernel wrote through their raw pointers (running statistics, the batch counter): bump their version counters
     as an in-place torch op would — the eval-time caches (folded Conv+BN weights, rsqrt(running_var + eps)) are keyed on them"""
     ts = [t for t in tensors if t is not None]
-    if ts:
+    if not ts:
+        return
+    try:
         torch._C._autograd._unsafe_set_version_counter(ts, [t._version + 1 for t in ts])
+    except (TypeError, AttributeError):             # other torch builds: (tensor, int) signature or no such private hook
+        for t in ts:
+            try:
+                torch._C._autograd._unsafe_set_version_counter(t, t._version + 1)
+            except (TypeError, AttributeError):
+                with torch.no_grad():
+                    t.add_(0)                       # one tiny launch per buffer, same effect on the version counter
 
 
 def _invstd(bn):
@@ -296,7 +314,7 @@ class _BNReLUConcatTrain(torch.autograd.Function):
             ws, tk = _scratch(dev, wsb)
             g, b = gamma.contiguous().float(), beta.contiguous().float()
             zptr = ctypes.c_void_p(out.data_ptr() + 4 * col)
-            check(lib.crb_bn_relu_forward(ptr(x), n, C, ptr(g), ptr(b), float(eps), int(relu), zptr, total, ptr(mean),
+            _bn_check(lib.crb_bn_relu_forward(ptr(x), n, C, ptr(g), ptr(b), float(eps), int(relu), zptr, total, ptr(mean),
                                           ptr(var), ptr(invstd), ptr(rm), ptr(rv), None, float(mom), ptr(ws), wsb, ptr(tk),
                                           cur_stream(dev)), 'crb_bn_relu_forward')
             _touch(rm, rv)
@@ -322,7 +340,7 @@ class _BNReLUConcatTrain(torch.autograd.Function):
             wsb = lib.crb_bn_workspace_bytes(n, C)
             ws, tk = _scratch(dev, wsb)
             dzp = ctypes.c_void_p(dz.data_ptr() + 4 * col)
-            check(lib.crb_bn_relu_backward(ptr(x), dzp, total, n, C, ptr(mean), ptr(invstd), ptr(g), ptr(b), ctx.relu,
+            _bn_check(lib.crb_bn_relu_backward(ptr(x), dzp, total, n, C, ptr(mean), ptr(invstd), ptr(g), ptr(b), ctx.relu,
                                            ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), wsb, ptr(tk), cur_stream(dev)),
                   'crb_bn_relu_backward')
             grads += [dx, dgamma, dbeta, None, None, None, None]
@@ -383,7 +401,7 @@ class _BNReLUMaxConcatTrain(torch.autograd.Function):
             ws, tk = _scratch(dev, wsb)
             g, b = gamma.contiguous().float(), beta.contiguous().float()
             zptr = ctypes.c_void_p(out.data_ptr() + 4 * col)
-            check(lib.crb_bn_relu_max_forward(ptr(x), M, ns, C, ptr(g), ptr(b), float(eps), zptr, total, ptr(arg),
+            _bn_check(lib.crb_bn_relu_max_forward(ptr(x), M, ns, C, ptr(g), ptr(b), float(eps), zptr, total, ptr(arg),
                                               ptr(mean), ptr(var), ptr(invstd), ptr(rm), ptr(rv), None, float(mom), ptr(ws), wsb,
                                               ptr(tk), cur_stream(dev)), 'crb_bn_relu_max_forward')
             _touch(rm, rv)
@@ -409,7 +427,7 @@ class _BNReLUMaxConcatTrain(torch.autograd.Function):
             wsb = lib.crb_bn_workspace_bytes(M * ns, C)
             ws, tk = _scratch(dev, wsb)
             gp = ctypes.c_void_p(gz.data_ptr() + 4 * col)
-            check(lib.crb_bn_relu_max_backward(ptr(x), gp, total, ptr(arg), M, ns, C, ptr(mean), ptr(invstd), ptr(g), ptr(b),
+            _bn_check(lib.crb_bn_relu_max_backward(ptr(x), gp, total, ptr(arg), M, ns, C, ptr(mean), ptr(invstd), ptr(g), ptr(b),
                                                ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), wsb, ptr(tk), cur_stream(dev)),
                   'crb_bn_relu_max_backward')
             grads += [dx, None, dgamma, dbeta, None, None, None, None]

@@ -149,6 +149,16 @@ class AnchorHeadTemplate(nn.Module):
     def _fused_loss_cfg(self):
         """CrbRpnLossCfg for the HIP loss kernels, or None when this head's loss configuration is not the one they implement
         (focal classification + WeightedSmoothL1Loss with 7 code weights + optional direction cross entropy)"""
+        lw = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
+        cw = getattr(self.reg_loss_func, 'code_weights', None)
+        # the struct is cached, keyed on every value it snapshots (a load_state_dict, a config edit between active-learning rounds
+        # or a test that flips a weight must not be ignored by the fused path: ADVICE r03)
+        key = (self.num_class, self.model_cfg.get('NUM_DIR_BINS', 2), lw['cls_weight'], lw['loc_weight'], lw.get('dir_weight', 0.0),
+               self.model_cfg.get('DIR_OFFSET', 0.0), getattr(self.cls_loss_func, 'alpha', None), getattr(self.cls_loss_func, 'gamma', None),
+               getattr(self.reg_loss_func, 'beta', None), None if cw is None else (cw.data_ptr(), cw._version),
+               type(self.reg_loss_func), type(self.cls_loss_func))
+        if getattr(self, '_rpn_loss_key', None) != key:
+            self._rpn_loss_key, self._rpn_loss_cfg = key, None
         if getattr(self, '_rpn_loss_cfg', None) is None:
             from crbhip import rpn_loss as _rl
             ok = (type(self.reg_loss_func) is loss_utils.WeightedSmoothL1Loss and self.box_coder.code_size == 7
@@ -157,7 +167,6 @@ class AnchorHeadTemplate(nn.Module):
             if not ok:
                 self._rpn_loss_cfg = False
             else:
-                lw = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
                 self._rpn_loss_cfg = _rl.make_cfg(
                     self.num_class, self.model_cfg.get('NUM_DIR_BINS', 2), self.reg_loss_func.code_weights.tolist(),
                     lw['cls_weight'], lw['loc_weight'], lw.get('dir_weight', 0.0), self.model_cfg.get('DIR_OFFSET', 0.0),

@@ -113,21 +113,24 @@ class CRBSampling(Strategy):
         q = queue.Queue(maxsize=2)
         stop = threading.Event()
 
+        def put(item):
+            """hand `item` to the consumer unless it has gone away (generator closed early: `stop`); never blocks for good"""
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
         def producer():
             try:
                 for batch in self.iter_pool_batches(frame_indices, batch_size):
-                    item = self._pin_batch(batch)
-                    while not stop.is_set():
-                        try:
-                            q.put(item, timeout=0.05)
-                            break
-                        except queue.Full:
-                            continue
-                    if stop.is_set():
+                    if not put(self._pin_batch(batch)):
                         return
-                q.put(None)
+                put(None)
             except BaseException as e:                                  # surfaced in the consumer
-                q.put(e)
+                put(e)
         th = threading.Thread(target=producer, name='crb-pool-upload', daemon=True)
         th.start()
         try:
@@ -150,7 +153,9 @@ class CRBSampling(Strategy):
                 yield self._finish_staged(staged, dev)
         finally:
             stop.set()
-            th.join(timeout=5)
+            th.join(timeout=30)
+            if th.is_alive():                       # still inside next() of the shared loader iterator: never reuse that iterator
+                self._pool_loader = None
 
     def _pin_batch(self, batch):
         """numpy batch -> same keys, arrays copied into pinned host buffers of the dtypes the device path wants. The pinned
