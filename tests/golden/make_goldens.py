@@ -969,11 +969,19 @@ def gen_glue(out):
 PV_KEYPOINTS = 256
 PV_POINTS = 8000
 PV_FIRST_FRAME = 40
+# kind -> (reference yaml, point cloud range, voxel size, point features, points per frame, voxel cap)
+PV_KINDS = {'kitti': ('tools/cfgs/active-kitti_models/pv_rcnn_active_crb.yaml', [0.0, -40.0, -3.0, 70.4, 40.0, 1.0], [0.05, 0.05, 0.1], 4, 8000, 16000),
+            'waymo': ('tools/cfgs/active-waymo_models/pv_rcnn_active_crb.yaml', [-75.2, -75.2, -2.0, 75.2, 75.2, 4.0], [0.1, 0.1, 0.15], 5, 24000, 150000)}
 # gradients stored (one per module of the detector) and the slice of each that is kept (the whole tensors would be 30 MB)
 PV_GRADS = {'backbone_3d.conv_input.0.weight': np.s_[:], 'backbone_3d.conv3.1.0.weight': np.s_[:16],
             'backbone_2d.blocks.0.1.weight': np.s_[:24], 'pfe.SA_layers.3.mlps.1.0.weight': np.s_[:],
             'roi_head.shared_fc_layer.0.weight': np.s_[:, :384], 'point_head.cls_layers.0.weight': np.s_[:64],
             'dense_head.conv_box.weight': np.s_[:], 'roi_head.roi_grid_pool_layer.mlps.0.0.weight': np.s_[:]}
+def pv_grads(kind='kitti'):
+    """PV_GRADS for the configuration: the Waymo PFE has two voxel-source SA layers (x_conv3, x_conv4), not four"""
+    return {(k.replace('SA_layers.3.', 'SA_layers.1.') if kind == 'waymo' else k): v for k, v in PV_GRADS.items()}
+
+
 PV_SMALL = ('dense_head.conv_cls.weight', 'dense_head.conv_box.weight', 'dense_head.conv_dir_cls.weight')
 
 
@@ -1052,28 +1060,30 @@ def _install_spconv_oracle(oracle):
     spp.conv.SparseConvolution = SparseConvolution
 
 
-def pvrcnn_detector_inputs():
-    """two synthetic KITTI frames of tests/synth.py (the generator the GPU tests use), PV_POINTS points each"""
+def pvrcnn_detector_inputs(kind='kitti'):
+    """two synthetic frames of tests/synth.py (the generator the GPU tests use): KITTI-shaped, or Waymo-shaped (360 degrees,
+    5 point features)"""
     import importlib.util                       # by path: the name `pcdet` is the reference's package in this process
     spec = importlib.util.spec_from_file_location(
         'crb_synthetic', os.path.join(os.path.dirname(os.path.dirname(OUT)), 'crb-active-3ddet_amd', 'pcdet', 'datasets', 'synthetic.py'))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.kitti_batch(PV_FIRST_FRAME, 2, PV_POINTS)
+    return mod.kitti_batch(PV_FIRST_FRAME, 2, PV_KINDS[kind][4], waymo=(kind == 'waymo'))
 
 
-def pvrcnn_model_cfg():
-    """MODEL section of the reference's pv_rcnn_active_crb.yaml with the two changes the golden needs: 256 keypoints (CPU time)
-    and no dropout in the RoI head (DP_RATIO 0: train-mode dropout draws are not reproducible across implementations)"""
+def pvrcnn_model_cfg(kind='kitti'):
+    """MODEL section of the reference's pv_rcnn_active_crb.yaml (KITTI or Waymo) with the two changes the golden needs: 256
+    keypoints (CPU time) and no dropout in the RoI head (DP_RATIO 0: train-mode dropout draws are not reproducible across
+    implementations)"""
     import yaml
-    y = yaml.safe_load(open(os.path.join(REF, 'tools/cfgs/active-kitti_models/pv_rcnn_active_crb.yaml')))
+    y = yaml.safe_load(open(os.path.join(REF, PV_KINDS[kind][0])))
     m = EasyDict(y['MODEL'])
     m.PFE.NUM_KEYPOINTS = PV_KEYPOINTS
     m.ROI_HEAD.DP_RATIO = 0.0
     return m, y['CLASS_NAMES']
 
 
-def gen_pvrcnn_detector(out):
+def gen_pvrcnn_detector(out, kind='kitti'):
     """ref_pvrcnn_detector.npz: one training step of the reference's PVRCNN on two frames — loss, every tb_dict entry, the
     second-stage outputs and eight parameter gradients (one per module of the detector). The RoI sampler's indices
     (proposal_target_layer.py:116-160: np.random / CPU torch.randint draws) are recorded and stored: the test injects them."""
@@ -1081,12 +1091,13 @@ def gen_pvrcnn_detector(out):
     _install_pointnet2_ops(oracle)
     _install_spconv_oracle(oracle)
     from pcdet.config import cfg as ref_cfg
-    model_cfg, class_names = pvrcnn_model_cfg()
+    model_cfg, class_names = pvrcnn_model_cfg(kind)
+    _, pcr_l, vs_l, n_feat, _, max_vox = PV_KINDS[kind]
     ref_cfg.CLASS_NAMES = class_names
     ref_cfg.MODEL = model_cfg
     from pcdet.models import build_network
     from pcdet.models.roi_heads.target_assigner.proposal_target_layer import ProposalTargetLayer
-    pcr, vs = np.array(PP_PCR, np.float32), np.array(PP_VOXEL, np.float32)
+    pcr, vs = np.array(pcr_l, np.float32), np.array(vs_l, np.float32)
     grid = np.round((pcr[3:6] - pcr[0:3]) / vs).astype(np.int64)
 
     class Dataset:
@@ -1094,16 +1105,16 @@ def gen_pvrcnn_detector(out):
     ds = Dataset()
     ds.class_names, ds.grid_size, ds.point_cloud_range, ds.voxel_size = class_names, grid, pcr, list(vs)
     ds.depth_downsample_factor = None
-    ds.point_feature_encoder = EasyDict(num_point_features=4)
+    ds.point_feature_encoder = EasyDict(num_point_features=n_feat)
     torch.manual_seed(0)
     model = build_network(model_cfg=model_cfg, num_class=3, dataset=ds)
     model.load_state_dict(pv_seeded_state(model))
     model.train()
     out['pv_keys'] = np.array(sorted(model.state_dict().keys()))
 
-    pts, off, gt0 = pvrcnn_detector_inputs()
+    pts, off, gt0 = pvrcnn_detector_inputs(kind)
     B = len(off) - 1
-    voxels, coords, npts, _ = oracle.voxelize_batch(pts, off, pcr[:3], vs, grid, 16000, 5)
+    voxels, coords, npts, _ = oracle.voxelize_batch(pts, off, pcr[:3], vs, grid, max_vox, 5)
     bidx = np.repeat(np.arange(B, dtype=np.float32), np.diff(off))
 
     def make_batch(gt):
@@ -1131,7 +1142,8 @@ def gen_pvrcnn_detector(out):
     for b in range(B):
         k = 0
         for r, lab in zip(captured['rois'][b].numpy(), captured['labels'][b].numpy()):
-            ok = (r[3:6] > 0.3).all() and (r[3:6] < 8).all() and 1 < r[0] < 69 and abs(r[1]) < 39 and -2.5 < r[2] < 0.5
+            ok = (r[3:6] > 0.3).all() and (r[3:6] < 8).all() and pcr[0] + 1 < r[0] < pcr[3] - 1 and pcr[1] + 1 < r[1] < pcr[4] - 1 and \
+                pcr[2] + 0.5 < r[2] < pcr[5] - 0.5
             if ok and all(np.hypot(*(r[:2] - g[:2])) > 3.0 for g in gt[b, :k]):
                 gt[b, k, :7] = r + np.concatenate([rng.uniform(-0.06, 0.06, 3), r[3:6] * rng.uniform(-0.04, 0.04, 3), rng.uniform(-0.04, 0.04, 1)])
                 gt[b, k, 7] = lab
@@ -1187,12 +1199,12 @@ def gen_pvrcnn_detector(out):
     out['pv_rcnn_cls_gt'], out['pv_rcnn_reg_gt'] = _np(ret['rcnn_cls_gt']), _np(ret['rcnn_reg_gt'])
     out['pv_rois'] = _np(model.roi_head.forward_ret_dict['rois'])
     params = dict(model.named_parameters())
-    for n, sl in PV_GRADS.items():
+    for n, sl in pv_grads(kind).items():
         out['pv_grad/' + n] = _np(params[n].grad)[sl].copy()
         out['pv_gradmax/' + n] = np.array([float(params[n].grad.abs().max())])
     print('  loss %.5f' % float(loss), {k: round(float(v), 5) for k, v in tb.items()})
     print('  voxels', len(coords), 'sampled', out['pv_sampled'].shape, 'fg rois', int((out['pv_rcnn_cls_gt'] > 0.5).sum()))
-    assert np.isfinite(out['pv_loss']).all() and all(np.abs(out['pv_grad/' + n]).max() > 0 for n in PV_GRADS)
+    assert np.isfinite(out['pv_loss']).all() and all(np.abs(out['pv_grad/' + n]).max() > 0 for n in pv_grads(kind))
 
 
 if __name__ == '__main__':
@@ -1202,7 +1214,8 @@ if __name__ == '__main__':
                      ('ref_strategies.npz', gen_strategies), ('ref_data_processor.npz', gen_data_processor),
                      ('ref_post_processing.npz', gen_post_processing), ('ref_glue.npz', gen_glue),
                      ('ref_badge.npz', gen_badge), ('ref_partA2.npz', gen_partA2),
-                     ('ref_point_path.npz', gen_point_path), ('ref_pvrcnn_detector.npz', gen_pvrcnn_detector)):
+                     ('ref_point_path.npz', gen_point_path), ('ref_pvrcnn_detector.npz', gen_pvrcnn_detector),
+                     ('ref_pvrcnn_detector_waymo.npz', lambda d: gen_pvrcnn_detector(d, 'waymo'))):
         if only and name not in only:
             continue
         d = {}

@@ -237,33 +237,42 @@ def test_dense_half_before_pfe_schedule_gives_identical_outputs(model, dev):
             assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max())), (k, float((a - b).abs().max()))
 
 
-def test_train_step_matches_the_reference_detector(dev):
+@pytest.mark.parametrize('kind', ['kitti', 'waymo'])
+def test_train_step_matches_the_reference_detector(dev, kind):
     """configs[2] at the detector level: ONE training step of the mirror's PVRCNN against tests/golden/ref_pvrcnn_detector.npz,
     written by the reference's own PVRCNN (pcdet/models/detectors/pv_rcnn.py:9-43 — every module of build_networks() and
     get_training_loss(): rpn + point + rcnn losses) on the CPU with the compiled ops and spconv answered by the oracle
     (make_goldens.py:gen_pvrcnn_detector; MODEL section of the reference's pv_rcnn_active_crb.yaml with 256 keypoints and
-    DP_RATIO 0). Same seeded weights by parameter name, same two synthetic frames, the reference's recorded RoI-sampler indices
+    DP_RATIO 0). kind = 'waymo': the reference's active-waymo_models/pv_rcnn_active_crb.yaml on Waymo-shaped frames (5 point
+    features, 0.1 x 0.1 x 0.15 m voxels over +-75.2 m, bev / x_conv3 / x_conv4 / raw_points sources) against
+    ref_pvrcnn_detector_waymo.npz. Same seeded weights by parameter name, same two synthetic frames, the reference's recorded RoI-sampler indices
     injected (proposal_target_layer.py:116-160 draws from np.random / CPU torch.randint).
     Tolerances: loss and the tb_dict entries 2e-4 relative (f32 sums in another order through train-mode BatchNorm over ~13k
     voxels / 2 x 256 keypoints), second-stage outputs 2e-3 of their largest magnitude, parameter gradients 2e-2 of their
     largest entry (the backward through the BEV backbone's 11 train-mode BatchNorm layers amplifies f32 rounding to several
     1e-3 at B = 2 on any implementation: tests/test_winograd_gpu.py)."""
     import os
-    from golden.make_goldens import PV_FIRST_FRAME, PV_GRADS, PV_KEYPOINTS, PV_POINTS, pv_seeded_state
+    from golden.make_goldens import PV_FIRST_FRAME, PV_KEYPOINTS, PV_KINDS, pv_grads, pv_seeded_state
     from pcdet.datasets import SyntheticDataset
     from pcdet.model_cfgs import pv_rcnn_cfg
     from pcdet.models import build_network
-    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_pvrcnn_detector.npz'))
-    cfg = pv_rcnn_cfg().MODEL
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
+                             'ref_pvrcnn_detector%s.npz' % ('' if kind == 'kitti' else '_' + kind)))
+    n_points = PV_KINDS[kind][4]
+    cfg = pv_rcnn_cfg(kind).MODEL
     cfg.PFE.NUM_KEYPOINTS = PV_KEYPOINTS
     cfg.POINT_HEAD.NUM_KEYPOINTS = PV_KEYPOINTS
     cfg.ROI_HEAD.DP_RATIO = 0.0
     torch.manual_seed(0)
-    model = build_network(cfg, 3, SyntheticDataset(num_frames=2))
+    model = build_network(cfg, 3, SyntheticDataset(num_frames=2, kind=kind, n_points=n_points))
     assert sorted(model.state_dict().keys()) == list(G['pv_keys'])               # the reference's parameter / buffer names
     model.load_state_dict(pv_seeded_state(model))
     model.to(dev).train()
-    b, _, _, _ = _batch(dev, PV_FIRST_FRAME, 2, PV_POINTS)
+    pts, off, _ = kitti_batch(PV_FIRST_FRAME, 2, n_points, waymo=(kind == 'waymo'))
+    bidx = np.repeat(np.arange(2, dtype=np.float32), np.diff(off))
+    b = {'points': torch.from_numpy(np.concatenate([bidx[:, None], pts], 1)).to(dev), 'point_frame_offsets': torch.from_numpy(off).to(dev),
+         'batch_size': 2, 'point_frame_counts_host': np.diff(off).tolist(),
+         'frame_id': np.array(['%06d' % (PV_FIRST_FRAME + i) for i in range(2)])}
     b['gt_boxes'] = torch.from_numpy(G['pv_gt']).to(dev)
     # the reference's sampled RoIs as boxes (equal-score proposals have no defined order, a few neighbours come out swapped)
     ref_sampled = np.take_along_axis(G['pv_proposals'], G['pv_sampled'][:, :, None], axis=1)
@@ -308,7 +317,7 @@ def test_train_step_matches_the_reference_detector(dev):
         assert np.abs(got - want).max() <= 2e-3 * max(1e-6, np.abs(want).max()), (k, np.abs(got - want).max(), np.abs(want).max())
     np.testing.assert_allclose(model.roi_head.forward_ret_dict['rois'].cpu().numpy(), G['pv_rois'], rtol=0, atol=2e-4)
     params = dict(model.named_parameters())
-    for n, sl in PV_GRADS.items():
+    for n, sl in pv_grads(kind).items():
         got, want = params[n].grad.cpu().numpy()[sl], G['pv_grad/' + n]
         scale = float(G['pv_gradmax/' + n][0])
         err = float(np.abs(got - want).max()) / scale
