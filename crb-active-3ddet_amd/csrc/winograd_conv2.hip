@@ -439,8 +439,16 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
     constexpr bool T_ON = decltype(do_t)::value && MODE != 2;       // (the first pair's operands were read by the previous chunk)
 #pragma unroll
     for (int xp = 0; xp < 8; ++xp) {
-      if (T_ON) {                                                 // LDS stores ahead of the next pair's reads: the wait for the
-        if (xp == 0) t_load(Rb + nxt * RAW_FLOATS);               // reads (in-order LDS) then never waits for a younger store
+      // the next pair's operands FIRST, pinned: left to the scheduler the three reads sink to the end of the stage and the next
+      // stage opens with s_waitcnt lgkmcnt(0) one MFMA behind them - the LDS latency exposed eight times per chunk
+      // - and an explicit wait for everything OLDER than these three reads (the compiler's own choice here is lgkmcnt(0))
+      if (xp < 7) {
+        op_read(V, U, xp + 1, (xp + 1) & 1);
+        __builtin_amdgcn_s_waitcnt(0xC37F);    // lgkmcnt(3)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (T_ON) {
+        if (xp == 0) t_load(Rb + nxt * RAW_FLOATS);
         if (xp == 1) { t_cols(0); t_cols(1); }
         if (xp == 2) { t_cols(2); t_cols(3); }
         if (xp >= 3 && xp < 7) t_row(Vn, xp - 3);
@@ -451,7 +459,6 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
         if (MODE != 3) { u_advance(); r_advance(); }
         t_advance();
       }
-      if (xp < 7) op_read(V, U, xp + 1, (xp + 1) & 1);
       // the barrier sits BEFORE the last pair's MFMAs (their operands are in registers, V(g+1) is complete): the waves meet
       // with 8 MFMAs each still to issue, so the matrix pipe keeps running while the DMA of chunks g+2 (U) / g+3 (raw) - into
       // the buffers nobody reads any more - and the next chunk's first reads go out
@@ -469,10 +476,13 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
           if (decltype(do_raw)::value) issue_raw();
         }
       }
+      // the next chunk's first operands go out ahead of the last MFMAs (V(g+1), U(g+1) are valid after the barrier, slot 0 is
+      // free): their latency runs under those MFMAs instead of in front of the next chunk's
+      if (xp == 7 && decltype(do_t)::value) {
+        op_read(Vn, Ub + nxt * U_FLOATS, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       mfma_pair(xp, xp & 1);
-      // the next chunk's first operands go out right behind the last MFMAs (V(g+1), U(g+1) are valid after the barrier): their
-      // latency and the bookkeeping below run under those MFMAs instead of in front of the next chunk's
-      if (xp == 7 && decltype(do_t)::value) op_read(Vn, Ub + nxt * U_FLOATS, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (MODE == 4) { tm0 = __builtin_amdgcn_s_memtime(); tm_stage7 += tm0 - tm1; }
@@ -497,6 +507,9 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   if (MODE == 4) stamp[1] = __builtin_amdgcn_s_memtime();
 
   // ---- chunks: the steady state is one body without DMA / transform conditions, the last three chunks are peeled
+  // (lgkmcnt(0) as an instruction the compiler's wait-count pass sees: with a scalar load possibly outstanding at the loop header
+  // it turns every partial lgkmcnt wait in the body into lgkmcnt(0))
+  __builtin_amdgcn_s_waitcnt(0xC07F);
   int g = 0;
   for (; g + 3 < total; ++g) chunk(g, true_type{}, true_type{}, true_type{});
   if (g + 2 < total) { chunk(g, true_type{}, false_type{}, true_type{}); ++g; }        // 1 .. 3 chunks left

@@ -58,6 +58,7 @@ struct WgradArgs {
   const float* x;      // (N,H,W,Cin)
   const float* dy;     // (N,H,W,Cout)
   float* part;         // (ranges, nci * nco blocks, 16, 64 ci, 64 co)
+  const float* zero;   // g_wgrad_zero_page (as an argument: every use of the symbol itself costs a scalar load + wait)
   int N, H, W, cin, cout;
   int th, tw;          // tiles per column / row
   int tw4;             // chunk columns per image = ceil(tw / 4)
@@ -81,7 +82,9 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) 
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// MODE (measurement builds, wrong results): 1 = no MFMAs, 2 = no transforms, 3 = no DMA in the loop
+// MODE (measurement builds): 1 = no MFMAs, 2 = no transforms, 3 = no DMA in the loop (wrong results); 4 = correct results + cycle
+// accounting per wave in g_wgrad_dbg (8 uint64 per wave): {total, stages 0-6, parked at wait + barrier, last stage, chunks}
+__device__ unsigned long long* g_wgrad_dbg = nullptr;
 template <int MODE>
 __global__ __launch_bounds__(NT, 2) void winograd2_wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -151,26 +154,38 @@ __global__ __launch_bounds__(NT, 2) void winograd2_wgrad_kernel(WgradArgs a) {
   const float* const dyblk = a.dy + cob * BLK;
   ChunkPos dpos = first;                       // next chunk of the DMA
   int d_buf = 0;                               // its buffer (chunk index mod 3)
-  auto issue_dma = [&]() {
-    float* xbuf = Xb + d_buf * RAWX_FLOATS;
-    float* gbuf = Gb + d_buf * RAWG_FLOATS;
+  // source addresses = chunk origin (scalar) + a per-thread constant, as 32-bit element offsets (the host bounds the maps);
+  // prep_dma forms the three addresses of the next chunk among the MFMAs of stage 5, issue_dma behind the barrier is three
+  // instructions (measured: with the addresses formed behind the barrier - 64-bit multiplies under divergent branches and a
+  // scalar load of the zero page's address per slot - the last stage took 1,330 cycles instead of the 512 of its MFMAs)
+  int lo_x[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) lo_x[s] = ((s_r[s] - 1) * a.W + (s_c[s] - 1)) * a.cin + s_q[s] * 4;
+  const int lo_g = (gs_r * a.W + gs_c) * a.cout + gs_q * 4;
+  const float* psrc[3];
+  auto pick = [&](bool ok, const float* in_map) {      // ok ? in_map : zero page, as mask arithmetic: no divergent branches
+    const uint64_t m = ok ? ~0ULL : 0ULL;
+    return reinterpret_cast<const float*>((reinterpret_cast<uint64_t>(in_map) & m) | (reinterpret_cast<uint64_t>(a.zero) & ~m));
+  };
+  auto prep_dma = [&]() {
     const bool img = dpos.n < a.N;
+    const int y0 = 4 * dpos.p, x0 = 8 * dpos.bc;
+    const int origin = (dpos.n * a.H + y0) * a.W + x0;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int y = 4 * dpos.p - 1 + s_r[s], xx = 8 * dpos.bc - 1 + s_c[s];
-      const bool ok = img && s_r[s] < 6 && y >= 0 && y < a.H && xx >= 0 && xx < a.W;
-      const float* src = ok ? xblk + (((int64_t)dpos.n * a.H + y) * a.W + xx) * a.cin + s_q[s] * 4 : g_wgrad_zero_page;
-      glds16(src, xbuf + (NT * s + wave * 64) * 4);
+      const int y = y0 - 1 + s_r[s], xx = x0 - 1 + s_c[s];
+      const bool ok = img & (s_r[s] < 6) & ((unsigned)y < (unsigned)a.H) & ((unsigned)xx < (unsigned)a.W);
+      psrc[s] = pick(ok, xblk + (origin * a.cin + lo_x[s]));
     }
-    {
-      // output pixel (4 p + r, 8 bc + c): rows / columns past the map (odd sizes, partial chunks) read zeros
-      const int y = 4 * dpos.p + gs_r, xx = 8 * dpos.bc + gs_c;
-      const bool ok = img && y < a.H && xx < a.W;
-      const float* src = ok ? dyblk + (((int64_t)dpos.n * a.H + y) * a.W + xx) * a.cout + gs_q * 4 : g_wgrad_zero_page;
-      glds16(src, gbuf + wave * 64 * 4);
-    }
-    d_buf = d_buf == 2 ? 0 : d_buf + 1;
+    // output pixel (4 p + r, 8 bc + c): rows / columns past the map (odd sizes, partial chunks) read zeros
+    psrc[2] = pick(img & (y0 + gs_r < a.H) & (x0 + gs_c < a.W), dyblk + (origin * a.cout + lo_g));
     chunk_next(dpos, a);
+  };
+  auto issue_dma = [&]() {
+    glds16(psrc[0], Xb + d_buf * RAWX_FLOATS + (wave * 64) * 4);
+    glds16(psrc[1], Xb + d_buf * RAWX_FLOATS + (NT + wave * 64) * 4);
+    glds16(psrc[2], Gb + d_buf * RAWG_FLOATS + wave * 64 * 4);
+    d_buf = d_buf == 2 ? 0 : d_buf + 1;
   };
   auto wait_older_and_barrier = [&]() {        // everything but the three youngest vector-memory operations (the last chunk issued)
     asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
@@ -251,14 +266,25 @@ __global__ __launch_bounds__(NT, 2) void winograd2_wgrad_kernel(WgradArgs a) {
   // chunk g + 1 from raw input g + 1 (stage 0), the lane's gradient values of chunk g + 1 (stage 6); at the barrier the raw blocks
   // of chunk g + 2 have landed (issued two barriers ago) and chunk g + 4's DMA goes out into the buffers of chunk g + 1
   int gbuf = 0;                                // raw buffer of chunk g
+  unsigned long long cyc[4] = {0, 0, 0, 0};
+  const unsigned long long cyc_start = MODE == 4 ? __builtin_amdgcn_s_memtime() : 0ULL;
   auto chunk = [&](int g, auto do_issue, auto do_t) {
     const int cur = g & 1, nxt = cur ^ 1;
     const int gb1 = gbuf == 2 ? 0 : gbuf + 1;  // raw buffer of chunk g + 1
     const float* V = Vb + cur * IMG_FLOATS;
     float* Vn = Vb + nxt * IMG_FLOATS;
     constexpr bool T_ON = decltype(do_t)::value && MODE != 2;
+    unsigned long long c0 = 0, c1 = 0;
+    if (MODE == 4) c0 = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int xp = 0; xp < 8; ++xp) {
+      // the next pair's B operands FIRST, pinned (left to the scheduler they sink to the end of the stage: latency exposed)
+      // and an explicit wait for everything OLDER than these two reads (the compiler's own choice here is lgkmcnt(0))
+      if (xp < 7) {
+        op_read(V, xp + 1, (xp + 1) & 1);
+        __builtin_amdgcn_s_waitcnt(0xC27F);    // lgkmcnt(2)
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (T_ON) {
         if (xp == 0) v_load(Xb + gb1 * RAWX_FLOATS);
         if (xp == 1) { v_cols(0); v_cols(1); }
@@ -268,28 +294,40 @@ __global__ __launch_bounds__(NT, 2) void winograd2_wgrad_kernel(WgradArgs a) {
       // the lane's gradient values of chunk g + 1 (landed since the previous barrier), BEFORE this chunk's barrier: behind it
       // the DMA of chunk g + 4 overwrites both raw buffers of chunk g + 1
       if (xp == 6 && decltype(do_t)::value) g_load(Gb + gb1 * RAWG_FLOATS);
-      if (xp < 7) op_read(V, xp + 1, (xp + 1) & 1);
+      if (xp == 5 && MODE != 3 && decltype(do_issue)::value) prep_dma();
       if (xp == 7) {
+        if (MODE == 4) { c1 = __builtin_amdgcn_s_memtime(); cyc[1] += c1 - c0; }
+        if (MODE == 4) {
+          asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+          const unsigned long long cw = __builtin_amdgcn_s_memtime();
+          cyc[0] += cw - c1;
+        }
         wait_older_and_barrier();
+        if (MODE == 4) { c0 = __builtin_amdgcn_s_memtime(); cyc[2] += c0 - c1; }
         if (MODE != 3 && decltype(do_issue)::value) issue_dma();
+        if (decltype(do_t)::value) {           // the next chunk's first operands, ahead of the last MFMAs (slot 0 is free)
+          op_read(Vn, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       mfma_pair(xp, xp & 1);
-      if (xp == 7 && decltype(do_t)::value) {
-        op_read(Vn, 0, 0);
-        if (MODE != 2) m_cols();                // (the MFMAs above have read their operands)
-      }
+      if (xp == 7 && decltype(do_t)::value && MODE != 2) m_cols();   // (the MFMAs above have read their operands)
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (MODE == 4) cyc[3] += __builtin_amdgcn_s_memtime() - c0;
     gbuf = gb1;
   };
   using std::true_type;
   using std::false_type;
 
   // ---- prologue: chunks 0, 1 land; chunk 0 -> V(0) and the lane's M(0) while chunks 2, 3 go out
+  prep_dma();
   issue_dma();
+  prep_dma();
   issue_dma();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  prep_dma();
   issue_dma();                                   // chunk 2 -> buffer 2
   g_load(Gb);
   m_cols();
@@ -300,10 +338,14 @@ __global__ __launch_bounds__(NT, 2) void winograd2_wgrad_kernel(WgradArgs a) {
   for (int i = 0; i < 4; ++i) v_row(Vb, i);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  prep_dma();
   issue_dma();                                   // chunk 3 -> buffer 0 (chunk 0's raw blocks are consumed)
   op_read(Vb, 0, 0);
 
   // chunk g's barrier issues chunk g + 4 (past the range: another range's chunk or zeros, never used - the count stays 3)
+  // (lgkmcnt(0) as an instruction the compiler's wait-count pass sees: with a scalar load possibly outstanding at the loop header
+  // it turns every partial lgkmcnt wait in the body into lgkmcnt(0))
+  __builtin_amdgcn_s_waitcnt(0xC07F);
   int g = 0;
   for (; g + 1 < total; ++g) chunk(g, true_type{}, true_type{});
   chunk(g, false_type{}, false_type{});
@@ -315,6 +357,11 @@ __global__ __launch_bounds__(NT, 2) void winograd2_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int cbk = 0; cbk < 2; ++cbk)
       *reinterpret_cast<f32x4*>(out + (xi * BLK + wt * 32 + cbk * 16 + l15) * BLK + wk * 16 + 4 * kq) = acc[xi][cbk];
+  if (MODE == 4 && g_wgrad_dbg && lane == 0) {
+    unsigned long long* o = g_wgrad_dbg + ((int64_t)blockIdx.x * 8 + wave) * 8;
+    o[0] = __builtin_amdgcn_s_memtime() - cyc_start;
+    o[1] = cyc[1]; o[2] = cyc[2]; o[3] = cyc[3]; o[4] = (unsigned long long)total; o[5] = cyc[0];
+  }
 }
 
 // dW[co][ci][ky][kx] = (G^T dU[.][ci][co] G)[ky][kx], dU = sum over the ranges in range order (double), written with the element
@@ -368,7 +415,12 @@ __host__ int wgrad_ranges(int nblk) {
 
 CRB_KNOB g_wgrad2_mode = 0;     // measurement builds: 1 = no MFMAs, 2 = no transforms, 3 = no DMA in the loop
 #ifdef CRB_MEASURE
-extern "C" int crb_winograd2_wgrad_set_mode(int mode) { g_wgrad2_mode = (mode >= 1 && mode <= 3) ? mode : 0; return CRB_OK; }
+extern "C" int crb_winograd2_wgrad_set_mode(int mode) { g_wgrad2_mode = (mode >= 1 && mode <= 4) ? mode : 0; return CRB_OK; }
+extern "C" int crb_winograd2_wgrad_set_debug(void* dev_buf) {       // mode 4: 8 waves x 8 uint64 per workgroup, NULL = off
+  unsigned long long* p = (unsigned long long*)dev_buf;
+  CRB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_dbg), &p, sizeof(p)));
+  return CRB_OK;
+}
 #endif
 
 extern "C" int crb_winograd2_wgrad_supported(int cin, int cout, int H, int W) {
@@ -388,9 +440,11 @@ extern "C" int crb_winograd2_wgrad(const float* x, const float* dy, float* dw, i
   if (N <= 0 || H <= 0 || W <= 0) return CRB_ERR_ARG;
   if (!crb_winograd2_wgrad_supported(cin, cout, H, W)) return CRB_ERR_UNSUPPORTED;
   if (workspace_bytes < crb_winograd2_wgrad_workspace_bytes(cin, cout) || !workspace) return CRB_ERR_WORKSPACE;
-  if ((int64_t)N * H * W * (cin > cout ? cin : cout) >= (1LL << 40)) return CRB_ERR_ARG;
+  if (((int64_t)N * H + 8) * (W + 16) * (cin > cout ? cin : cout) >= (1LL << 31)) return CRB_ERR_ARG;   // 32-bit element offsets
+  static const float* zero_page = nullptr;
+  if (!zero_page) CRB_HIP(hipGetSymbolAddress((void**)&zero_page, HIP_SYMBOL(g_wgrad_zero_page)));
   WgradArgs a;
-  a.x = x; a.dy = dy; a.part = (float*)workspace;
+  a.x = x; a.dy = dy; a.part = (float*)workspace; a.zero = zero_page;
   a.N = N; a.H = H; a.W = W; a.cin = cin; a.cout = cout;
   a.th = (H + 1) / 2; a.tw = (W + 1) / 2;
   a.tw4 = (a.tw + 3) / 4;
@@ -407,6 +461,7 @@ extern "C" int crb_winograd2_wgrad(const float* x, const float* dy, float* dw, i
   if (g_wgrad2_mode == 1) kern = winograd2_wgrad_kernel<1>;
   if (g_wgrad2_mode == 2) kern = winograd2_wgrad_kernel<2>;
   if (g_wgrad2_mode == 3) kern = winograd2_wgrad_kernel<3>;
+  if (g_wgrad2_mode == 4) kern = winograd2_wgrad_kernel<4>;
 #endif
   static bool attr_done = false;
   if (!attr_done || g_wgrad2_mode) {
