@@ -413,20 +413,22 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
     v0[slot] = *reinterpret_cast<const f32x4*>(V + xp * 1024 + b_off);
     v1[slot] = *reinterpret_cast<const f32x4*>(V + xp * 1024 + b_off + 16 * 16);
   };
+  // the 8 MFMAs of an xi pair in k-step-major order: the two MFMAs of one accumulator are four instructions apart (two apart,
+  // a wave that has the matrix pipe to itself waits for the first one's result: measured 768 -> 748 us per 128->128 call)
   auto mfma_pair = [&](int xp, int slot) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int xi = 2 * xp + h;
-      if (MODE == 1) {
-        acc[xi][0][0] += ua[slot][2 * h] * v0[slot][2 * h] + ua[slot][2 * h + 1] * v0[slot][2 * h + 1];
-        acc[xi][1][0] += ua[slot][2 * h] * v1[slot][2 * h] + ua[slot][2 * h + 1] * v1[slot][2 * h + 1];
-      } else {
-        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[slot][2 * h], v0[slot][2 * h], acc[xi][0], 0, 0, 0);
-        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[slot][2 * h], v1[slot][2 * h], acc[xi][1], 0, 0, 0);
-        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[slot][2 * h + 1], v0[slot][2 * h + 1], acc[xi][0], 0, 0, 0);
-        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[slot][2 * h + 1], v1[slot][2 * h + 1], acc[xi][1], 0, 0, 0);
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int xi = 2 * xp + h;
+        if (MODE == 1) {
+          acc[xi][0][0] += ua[slot][2 * h + e] * v0[slot][2 * h + e];
+          acc[xi][1][0] += ua[slot][2 * h + e] * v1[slot][2 * h + e];
+        } else {
+          acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[slot][2 * h + e], v0[slot][2 * h + e], acc[xi][0], 0, 0, 0);
+          acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[slot][2 * h + e], v1[slot][2 * h + e], acc[xi][1], 0, 0, 0);
+        }
       }
-    }
   };
   // chunk g of the workgroup. DO_U / DO_RAW / DO_T: compile-time (integral_constant) switches of the peeled tail
   auto chunk = [&](int g, auto do_u, auto do_raw, auto do_t) {
@@ -439,16 +441,8 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
     constexpr bool T_ON = decltype(do_t)::value && MODE != 2;       // (the first pair's operands were read by the previous chunk)
 #pragma unroll
     for (int xp = 0; xp < 8; ++xp) {
-      // the next pair's operands FIRST, pinned: left to the scheduler the three reads sink to the end of the stage and the next
-      // stage opens with s_waitcnt lgkmcnt(0) one MFMA behind them - the LDS latency exposed eight times per chunk
-      // - and an explicit wait for everything OLDER than these three reads (the compiler's own choice here is lgkmcnt(0))
-      if (xp < 7) {
-        op_read(V, U, xp + 1, (xp + 1) & 1);
-        __builtin_amdgcn_s_waitcnt(0xC37F);    // lgkmcnt(3)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (T_ON) {
-        if (xp == 0) t_load(Rb + nxt * RAW_FLOATS);
+      if (T_ON) {                                                 // LDS stores ahead of the next pair's reads: the wait for the
+        if (xp == 0) t_load(Rb + nxt * RAW_FLOATS);               // reads (in-order LDS) then never waits for a younger store
         if (xp == 1) { t_cols(0); t_cols(1); }
         if (xp == 2) { t_cols(2); t_cols(3); }
         if (xp >= 3 && xp < 7) t_row(Vn, xp - 3);
@@ -459,6 +453,7 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
         if (MODE != 3) { u_advance(); r_advance(); }
         t_advance();
       }
+      if (xp < 7) op_read(V, U, xp + 1, (xp + 1) & 1);
       // the barrier sits BEFORE the last pair's MFMAs (their operands are in registers, V(g+1) is complete): the waves meet
       // with 8 MFMAs each still to issue, so the matrix pipe keeps running while the DMA of chunks g+2 (U) / g+3 (raw) - into
       // the buffers nobody reads any more - and the next chunk's first reads go out
@@ -476,13 +471,10 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
           if (decltype(do_raw)::value) issue_raw();
         }
       }
-      // the next chunk's first operands go out ahead of the last MFMAs (V(g+1), U(g+1) are valid after the barrier, slot 0 is
-      // free): their latency runs under those MFMAs instead of in front of the next chunk's
-      if (xp == 7 && decltype(do_t)::value) {
-        op_read(Vn, Ub + nxt * U_FLOATS, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
       mfma_pair(xp, xp & 1);
+      // the next chunk's first operands go out right behind the last MFMAs (V(g+1), U(g+1) are valid after the barrier): their
+      // latency and the bookkeeping below run under those MFMAs instead of in front of the next chunk's
+      if (xp == 7 && decltype(do_t)::value) op_read(Vn, Ub + nxt * U_FLOATS, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (MODE == 4) { tm0 = __builtin_amdgcn_s_memtime(); tm_stage7 += tm0 - tm1; }
@@ -507,9 +499,6 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   if (MODE == 4) stamp[1] = __builtin_amdgcn_s_memtime();
 
   // ---- chunks: the steady state is one body without DMA / transform conditions, the last three chunks are peeled
-  // (lgkmcnt(0) as an instruction the compiler's wait-count pass sees: with a scalar load possibly outstanding at the loop header
-  // it turns every partial lgkmcnt wait in the body into lgkmcnt(0))
-  __builtin_amdgcn_s_waitcnt(0xC07F);
   int g = 0;
   for (; g + 3 < total; ++g) chunk(g, true_type{}, true_type{}, true_type{});
   if (g + 2 < total) { chunk(g, true_type{}, false_type{}, true_type{}); ++g; }        // 1 .. 3 chunks left
