@@ -525,6 +525,7 @@ def pvrcnn_bench(args, rank, world, device):
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=True,
                                                         bucket_cap_mb=DDP_BUCKET_MB)
     batches = make_batches(args, rank, device, first=20000)
+    torch.cuda.reset_peak_memory_stats()         # (the peak of THIS leg: until r04 the field carried the earlier legs' peak)
     for b in batches:
         b['point_frame_counts_host'] = np.diff(b['point_frame_offsets'].cpu().numpy()).tolist()
 
@@ -663,7 +664,9 @@ def main():
     warm_s = _all_ranks(time.perf_counter() - t_warm, world, device)     # solver search + allocator + table caches, per rank
     overhead_ms = event_pair_overhead_ms() if rank == 0 else 0.0
     prof = [] if rank == 0 else None
+    torch.cuda.reset_peak_memory_stats()
     dt, per_step, loss = timed_steps(True, prof)
+    peak_main = torch.cuda.max_memory_allocated()
     # the same step without grad-clip / AdamW ("one optimizer-less loss.backward() step"); not profiled
     dt_nopt, per_step_nopt, _ = timed_steps(False, None)
     # OPT-IN split-bf16 gather-GEMM (spconv.pytorch.set_arithmetic(model, 'bf16x3')): a few more steps of the same training loop with
@@ -697,9 +700,9 @@ def main():
                       'ms_per_step': round(1e3 * dtw / args.miopen_steps, 3), 'steps': args.miopen_steps,
                       'ms_per_step_device': _pctl(per_step_w), 'final_loss': round(float(loss_w.item()), 4),
                       'winograd_default': bool(keep_flag),
-                      'note': 'A/B, not `value`: same training loop with the 11 stride-1 3x3 BEV convolutions (forward + input '
-                              'gradient) on MIOpen\'s implicit GEMM (CRB_WINOGRAD=0) instead of the hand-written Winograd '
-                              'F(2x2,3x3) f32 MFMA kernel; weight gradients are MIOpen\'s in both'}
+                      'note': 'A/B, not `value`: same training loop with the 11 stride-1 3x3 BEV convolutions (forward, input '
+                              'gradient and weight gradient) on MIOpen\'s implicit GEMM (CRB_WINOGRAD=0) instead of the '
+                              'hand-written Winograd F(2x2,3x3) f32 MFMA kernels'}
         finally:
             args.steps = keep
             bev.WINOGRAD = keep_flag
@@ -716,7 +719,7 @@ def main():
                    'global_batch': args.batch * world, 'points_per_frame': args.points,
                    'parallelism': 'dp%d' % world, 'optimizer': 'grad-clip + fused AdamW in the timed region',
                    'final_loss': round(float(loss.item()), 4)},
-        'ms_per_step_device': _pctl(per_step),
+        'ms_per_step_device': _pctl(per_step), 'peak_mem_GB': round(peak_main / 2 ** 30, 1),
         'ms_per_step_device_per_rank': rank_step_ms[0],
         'warmup_seconds_per_rank': [round(v, 3) for v in warm_s], 'miopen_user_db': miopen_db,
         'fwd_bwd_only': {'value': round(frames / dt_nopt, 3), 'unit': 'frames/s',
