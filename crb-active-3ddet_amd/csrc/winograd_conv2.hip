@@ -38,7 +38,8 @@ constexpr int CC = 8;                        // input channels per chunk
 constexpr int V_FLOATS = 16 * WG_TILES * CC; // 8192 = 32 KB
 constexpr int U_FLOATS = 16 * WG_K * CC;     // 8192 = 32 KB
 constexpr int RAW_ROW_FLOATS = 2 * (TB_COLS + 1) * CC;   // [parity][5 pixel pairs][8 channels] = 80
-constexpr int RAW_FLOATS = 4096;             // 1024 DMA slots of 16 bytes (two per thread) = 51 raw rows: 2*16 + 2*(1 + 8 boundaries)
+constexpr int RAW_WAVE_FLOATS = 512;        // a wave's PRIVATE raw region: the 6 pixel rows of its two tile rows (480 floats) + 8 junk slots
+constexpr int RAW_FLOATS = 8 * RAW_WAVE_FLOATS;   // 4096 = 16 KB: 1024 DMA slots of 16 bytes, two per thread
 constexpr int LDS_FLOATS = 2 * V_FLOATS + 2 * U_FLOATS + 2 * RAW_FLOATS;
 constexpr int NT = 512;
 
@@ -124,7 +125,8 @@ struct Wino2Args {
   float* y;            // (N,H,W,Cout)
   const float* bias;   // (Cout) or null
   int N, H, W, cin, cout, relu;
-  int th, tw;          // tiles per column / row = ceil(H/2), ceil(W/2)
+  int th, tw;          // tile rows per image rounded UP TO EVEN (a wave's two tile rows never straddle two images; the phantom
+                       // row of an odd count is computed and not stored), tiles per row = ceil(W/2)
   int RT;              // tile rows over the batch = N * th
   int tw4;             // tile-column blocks = ceil(tw / 4)
   int nblocks;         // spatial blocks = ceil(RT / 16) * tw4
@@ -220,21 +222,11 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   // ---- transform role: one (tile, channel) per thread and chunk
   const int t_ch = T & 7, t_tile = T >> 3, t_tr = t_tile >> 2, t_tc = t_tile & 3;
   const int v_off = img_index(0, t_tile, t_ch);
-  UnitPos tu = first;          // unit of the chunk the transform works on (one chunk ahead of the MFMAs)
-  int tc = 0, raw_off;
-  auto t_setup = [&]() {
-    int n, ty;
-    const int trc = row_of(tu, t_tr, n, ty);  // rows past the batch: any valid row, results never stored
-    raw_off = (2 * trc + 2 * (n - tu.n0)) * RAW_ROW_FLOATS + t_tc * CC + t_ch;
-  };
-  t_setup();
-  auto t_advance = [&]() {
-    if (++tc < nch) return;
-    tc = 0;
-    const int R0 = tu.R0;
-    unit_next(tu, a);
-    if (tu.R0 != R0) t_setup();
-  };
+  // the wave's tiles are tile rows 2 wave, 2 wave + 1 of the block; its raw rows live in its OWN region of the raw buffer (local row
+  // r = pixel row 2 ty - 1 + r of the first tile row's image; the second tile row starts at local row 2): written by this wave's
+  // DMA, read by this wave's transform - no other wave waits for them
+  const int raw_off = wave * RAW_WAVE_FLOATS + (2 * (t_tr & 1)) * RAW_ROW_FLOATS + t_tc * CC + t_ch;
+  auto t_advance = [&]() {};
 
   // ---- DMA role. raw: slots q = T, T + 512 (16 bytes each): q -> (raw row, parity, pixel pair, channel half); runs three chunks
   //      ahead of the MFMAs. U: 4 x 16 bytes per thread, two chunks ahead.
@@ -246,25 +238,20 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   // chunk; touch = true (line prefetch): ONE lane per pixel (the channel-half-0 slot) gets the pixel's first channel, every other
   // lane the zero page
   auto slot_sources = [&](const UnitPos& u, const float* (&src)[2], int (&step)[2], bool touch) {
-    int rr[2], yy[2] = {-1, -1}, nn[2] = {0, 0};
-#pragma unroll
-    for (int s = 0; s < 2; ++s) rr[s] = (T + NT * s) / 20;
-    int n = u.n0, ty = u.ty0;
-    for (int t = 0; t < TB_ROWS && u.R0 + t < a.RT; ++t) {    // raw rows rbt .. rbt + 3 hold pixel rows 2 ty - 1 .. 2 ty + 2 of image n
-      const int rbt = 2 * t + 2 * (n - u.n0);
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-        if (rr[s] >= rbt && rr[s] < rbt + 4) { nn[s] = n; yy[s] = 2 * ty - 1 + (rr[s] - rbt); }
-      if (++ty == a.th) { ty = 0; ++n; }
-    }
+    // the wave's first tile row: image n, row ty of it (th is even: both tile rows of the wave are rows ty, ty + 1 of image n)
+    int n = u.n0, ty = u.ty0 + 2 * wave;
+    while (ty >= a.th) { ty -= a.th; ++n; }
+    const bool rows_in_batch = u.R0 + 2 * wave < a.RT;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int rem = (T + NT * s) - rr[s] * 20;
+      const int q = lane + 64 * s;                           // slot of the wave's region: (local row 0..5 | junk, parity, pair, half)
+      const int rr = q / 20, rem = q - rr * 20;
       const int par = rem / 10, rem2 = rem - par * 10;
       const int xh = rem2 >> 1, half = rem2 & 1;
+      const int yy = 2 * ty - 1 + rr;
       const int xx = 8 * u.bc - 1 + 2 * xh + par;
-      const bool ok = yy[s] >= 0 && yy[s] < a.H && xx >= 0 && xx < a.W && MODE != 5 && !(touch && half);   // unclaimed rows keep yy = -1
-      src[s] = ok ? a.x + (((int64_t)nn[s] * a.H + yy[s]) * a.W + xx) * a.cin + half * 4 : g_wino_zero_page;
+      const bool ok = rows_in_batch && rr < 6 && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && MODE != 5 && !(touch && half);
+      src[s] = ok ? a.x + (((int64_t)n * a.H + yy) * a.W + xx) * a.cin + half * 4 : g_wino_zero_page;
       step[s] = ok ? CC : 0;
     }
   };
@@ -272,9 +259,9 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   r_setup();
   const float* usrc = a.U + (int64_t)uu.cb * nch * U_FLOATS + T * 4;
   auto issue_raw = [&]() {                                    // chunk r_issued -> raw buffer r_issued & 1
-    float* buf = Rb + (r_issued & 1) * RAW_FLOATS;
-    glds16<RAW_AUX>(rsrc[0], buf + wave * 256);
-    glds16<RAW_AUX>(rsrc[1], buf + (NT + wave * 64) * 4);              // slots past the block's rows copy the zero page (inside the buffer)
+    float* buf = Rb + (r_issued & 1) * RAW_FLOATS + wave * RAW_WAVE_FLOATS;
+    glds16<RAW_AUX>(rsrc[0], buf);
+    glds16<RAW_AUX>(rsrc[1], buf + 256);                     // lanes 56..63: junk slots (zero page -> the tail of the region)
     ++r_issued;
   };
   auto r_advance = [&]() {                                    // after issue_raw: move the sources to the next chunk
@@ -361,7 +348,7 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
           y10[e] = fmaxf(y10[e], 0.f); y11[e] = fmaxf(y11[e], 0.f);
         }
       }
-      if (Rg < a.RT && tx < a.tw) {
+      if (Rg < a.RT && tx < a.tw && 2 * ty2 < a.H) {                // (2 ty2 >= H: the phantom tile row of an odd row count)
         const int oy = 2 * ty2, ox = 2 * tx;
         float* yo = a.y + (((int64_t)n2 * a.H + oy) * a.W + ox) * a.cout + k;
         const bool x1 = ox + 1 < a.W, y1 = oy + 1 < a.H;
@@ -453,23 +440,32 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
         if (MODE != 3) { u_advance(); r_advance(); }
         t_advance();
       }
+      // raw block of chunk g + 3 into the wave's own region of the buffer stage 0 just read (lgkmcnt(0): those reads have
+      // returned). Private regions: no other wave's progress matters, the copy has two chunks to land, and the wait in front of
+      // the barrier below leaves it in flight (vmcnt(2): loads return in order, these two instructions are the youngest)
+      if (xp == 2 && MODE != 3 && decltype(do_raw)::value) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_raw();
+      }
       if (xp < 7) op_read(V, U, xp + 1, (xp + 1) & 1);
       // the barrier sits BEFORE the last pair's MFMAs (their operands are in registers, V(g+1) is complete): the waves meet
       // with 8 MFMAs each still to issue, so the matrix pipe keeps running while the DMA of chunks g+2 (U) / g+3 (raw) - into
       // the buffers nobody reads any more - and the next chunk's first reads go out
       if (xp == 7) {
-        if (MODE == 4) {                                          // time parked at the wait + barrier (stamp[3] accumulates)
-          const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        unsigned long long t0 = 0;
+        if (MODE == 4) t0 = __builtin_amdgcn_s_memtime();         // time parked at the wait + barrier (stamp[3] accumulates)
+        if (decltype(do_raw)::value && MODE != 3) {
+          asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        } else {
           wait_all_and_barrier();
+        }
+        if (MODE == 4) {
           tm1 = __builtin_amdgcn_s_memtime();
           stamp[3] += tm1 - t0;
           tm_stage06 += t0 - tm0;
-        } else
-        wait_all_and_barrier();
-        if (MODE != 3) {
-          if (decltype(do_u)::value) issue_u();
-          if (decltype(do_raw)::value) issue_raw();
         }
+        if (MODE != 3 && decltype(do_u)::value) issue_u();
       }
       mfma_pair(xp, xp & 1);
       // the next chunk's first operands go out right behind the last MFMAs (V(g+1), U(g+1) are valid after the barrier): their
@@ -486,7 +482,7 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   using std::false_type;
 
   // ---- prologue (once per workgroup): raw(0), raw(1), U(0) in one round trip, raw(0) -> V(0), then U(1), raw(2) go out: chunk g
-  //      runs with U(g+1), raw(g+2) in flight and sends U(g+2), raw(g+3) after its barrier
+  //      sends raw(g+3) in its stage 2 (two chunks of lead) and U(g+2) after its barrier (one chunk: U comes from the XCD's L2)
   issue_raw(); r_advance();
   if (total > 1) { issue_raw(); r_advance(); }
   issue_u(); u_advance();
@@ -567,7 +563,7 @@ extern "C" int crb_conv3x3_winograd2_nhwc(const float* x, const float* U, float*
   Wino2Args a;
   a.x = x; a.U = U; a.y = y; a.bias = bias;
   a.N = N; a.H = H; a.W = W; a.cin = cin; a.cout = cout; a.relu = relu;
-  a.th = (H + 1) / 2; a.tw = (W + 1) / 2;
+  a.th = (((H + 1) / 2) + 1) & ~1; a.tw = (W + 1) / 2;
   const int64_t rt = (int64_t)N * a.th;
   if (rt >= (1LL << 30) || (int64_t)N * H * W * (cin > cout ? cin : cout) >= (1LL << 40)) return CRB_ERR_ARG;
   a.RT = (int)rt;

@@ -88,10 +88,10 @@ if __name__ == '__main__':
                 for mode in (0, 1):
                     lib.crb_winograd2_set_persistent(mode)
                     ab[mode].append(timeit(lambda: winograd.conv3x3_U2(x, U2, b), it=15, warm=3)[0])
-            lib.crb_winograd2_set_persistent(0)
+            lib.crb_winograd2_set_persistent(1)
             print('   A/B one unit per workgroup / persistent: %s / %s us' % (['%.0f' % v for v in ab[0]], ['%.0f' % v for v in ab[1]]), flush=True)
             # per-workgroup stamps
-            th, tw = (H + 1) // 2, (W + 1) // 2
+            th, tw = (((H + 1) // 2) + 1) & ~1, (W + 1) // 2
             nb = ((N * th + 15) // 16) * ((tw + 3) // 4)
             grid = ((nb + 7) // 8) * 8 * (K // 64)
             dbg = torch.zeros((max(grid, 256), 16), dtype=torch.int64, device=dev)
@@ -103,7 +103,6 @@ if __name__ == '__main__':
                 winograd.conv3x3_U2(x, U2, b)
             torch.cuda.synchronize()
             lib.crb_winograd2_set_mode(0)
-            lib.crb_winograd2_set_persistent(0)
             lib.crb_winograd2_set_debug(None)
             d = dbg.cpu().numpy().astype(np.int64)
             d = d[d[:, 0] != 0]
