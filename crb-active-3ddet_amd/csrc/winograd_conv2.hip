@@ -178,7 +178,7 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   float* const Ub = lds + 2 * V_FLOATS;
   float* const Rb = lds + 2 * V_FLOATS + 2 * U_FLOATS;
   constexpr int U_AUX = (MODE == 7 || MODE == 9) ? 2 : 0, RAW_AUX = (MODE == 8 || MODE == 9) ? 2 : 0;   // A/B: nt (streaming) DMA
-  const int T = threadIdx.x, lane = T & 63, wave = T >> 6;
+  const int T = threadIdx.x, lane = T & 63, wave = __builtin_amdgcn_readfirstlane(T >> 6);     // (wave: a scalar for the compiler)
   unsigned long long stamp[6], tm_stage06 = 0, tm_stage7 = 0, tm_book = 0, tm_epi = 0;
   if (MODE == 4) { stamp[0] = __builtin_amdgcn_s_memtime(); stamp[4] = wall_clock64(); stamp[3] = 0; }
 
@@ -366,31 +366,38 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   //      [a piece of the transform of the next chunk | 3 operand reads of the NEXT pair | 8 MFMAs]: the LDS / VALU work of the
   //      transform sits in the shadow of the wave's own MFMAs (and of the SIMD's other wave), not in front of the whole chunk.
   //      transform pieces: stage 0 raw reads d (16), stages 1-2 column pass t = B^T d, stages 3-6 one row of t B + its 4 stores.
-  float d[4][4], t[4][4];
+  // packed f32: a register pair holds two columns (j, j + 1) of a patch row; the column pass is 8 v_pk_add_f32, a row of
+  // t B is two more with operand selects / negations folded in (32 scalar adds before: every vector instruction issued beside
+  // the MFMAs costs matrix-pipe time). Bit-identical to the scalar form (a - b = a + (-b)).
+  f32x2 dp[4][2], tp[4][2];
   auto t_load = [&](const float* raw) {
     const float* p = raw + raw_off;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d[i][j] = p[i * RAW_ROW_FLOATS + (j & 1) * (RAW_ROW_FLOATS / 2) + (j >> 1) * CC];
+      for (int h = 0; h < 2; ++h)       // columns 2 h, 2 h + 1: pixel pair h of parity 0 / 1
+        dp[i][h] = (f32x2){p[i * RAW_ROW_FLOATS + h * CC], p[i * RAW_ROW_FLOATS + (RAW_ROW_FLOATS / 2) + h * CC]};
   };
-  auto t_cols = [&](int j) {        // B^T d, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-    t[0][j] = d[0][j] - d[2][j];
-    t[1][j] = d[1][j] + d[2][j];
-    t[2][j] = d[2][j] - d[1][j];
-    t[3][j] = d[1][j] - d[3][j];
+  auto t_cols = [&](int h) {        // B^T d, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], columns 2 h and 2 h + 1
+    tp[0][h] = dp[0][h] - dp[2][h];
+    tp[1][h] = dp[1][h] + dp[2][h];
+    tp[2][h] = dp[2][h] - dp[1][h];
+    tp[3][h] = dp[1][h] - dp[3][h];
   };
   auto t_row = [&](float* V, int i) {
     float* o = V + v_off;
-    o[img_index(i * 4 + 0, 0, 0)] = t[i][0] - t[i][2];
-    o[img_index(i * 4 + 1, 0, 0)] = t[i][1] + t[i][2];
-    o[img_index(i * 4 + 2, 0, 0)] = t[i][2] - t[i][1];
-    o[img_index(i * 4 + 3, 0, 0)] = t[i][1] - t[i][3];
+    f32x2 o01, o23;                 // (t0 - t2, t1 + t2), (t2 - t1, t1 - t3) with (t0, t1) = tp[i][0], (t2, t3) = tp[i][1]
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(o01) : "v"(tp[i][0]), "v"(tp[i][1]));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(o23) : "v"(tp[i][0]), "v"(tp[i][1]));
+    o[img_index(i * 4 + 0, 0, 0)] = o01[0];
+    o[img_index(i * 4 + 1, 0, 0)] = o01[1];
+    o[img_index(i * 4 + 2, 0, 0)] = o23[0];
+    o[img_index(i * 4 + 3, 0, 0)] = o23[1];
   };
   auto transform = [&](const float* raw, float* V) {
     t_load(raw);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) t_cols(j);
+    t_cols(0);
+    t_cols(1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) t_row(V, i);
   };
@@ -430,8 +437,8 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
     for (int xp = 0; xp < 8; ++xp) {
       if (T_ON) {                                                 // LDS stores ahead of the next pair's reads: the wait for the
         if (xp == 0) t_load(Rb + nxt * RAW_FLOATS);               // reads (in-order LDS) then never waits for a younger store
-        if (xp == 1) { t_cols(0); t_cols(1); }
-        if (xp == 2) { t_cols(2); t_cols(3); }
+        if (xp == 1) t_cols(0);
+        if (xp == 2) t_cols(1);
         if (xp >= 3 && xp < 7) t_row(Vn, xp - 3);
       }
       if (xp == 1) {
@@ -469,7 +476,8 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
       }
       mfma_pair(xp, xp & 1);
       // the next chunk's first operands go out right behind the last MFMAs (V(g+1), U(g+1) are valid after the barrier): their
-      // latency and the bookkeeping below run under those MFMAs instead of in front of the next chunk's
+      // latency and the bookkeeping below run under those MFMAs instead of in front of the next chunk's. (Measured the other way
+      // round - reads, MFMAs, then the DMA of U(g+2) - +3.5 %: the copy loses lead time it needs before the next barrier.)
       if (xp == 7 && decltype(do_t)::value) op_read(Vn, Ub + nxt * U_FLOATS, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
