@@ -590,6 +590,129 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
   }
 }
 
+// ---- low-channel forward (round 4): C_in in {4, 16}, C_out = 16 on the compact table ------------------------------------------
+// The phase kernel above pays per kernel offset present in a 64-row tile: a 1 KB W[o] hand-over through LDS, a barrier, a
+// dependent gather - at 3.5 neighbours per row that is ~10 dependent phases of 4 MFMAs per tile: latency-bound (17 / 25 us at
+// level 1 against 4 - 6 us for a copy of the same bytes, profiles/r04_lowchannel_floor.txt). Here all K weight matrices (27.6 KB
+// at 16 x 16) are either read from L1 / L2 where they stay hot (WLDS = false: 4 waves per workgroup, one tile per wave, no barrier
+// at all - the product instance) or RESIDENT in LDS in MFMA B-operand order for a 16-wave workgroup (WLDS = true, measurement
+// builds). A wave owns 16-row tiles end to end and walks only the offsets present in ITS 16 rows (wave-uniform OR of the masks),
+// NB offsets per round: index reads from the wave's LDS copy of the tile's packed indices, gathers (16 bytes per lane =
+// channels 4 kq .. 4 kq + 3 of the row), W[o], 4 MFMAs (1 MFMA at C_in = 4).
+// Measured (tools/lowchannel_floor.py): 4 -> 16 20.1 us (v1 kernel on the (N,K) table 25.4), 16 -> 16 28.5 us (phase kernel
+// 17.2): three dependent round trips per tile (masks / bases -> packed indices -> rows) bound it, not the weights; the product
+// uses it for C_in = 4 only.
+// Products and their order per output element are those of sparse_conv_fwd2_kernel (offsets ascending, channel 4 kq + t at
+// MFMA step t): results are bit-identical to it.
+template <int CIN, int NB, bool WLDS>
+__global__ __launch_bounds__(WLDS ? 1024 : 256) void sparse_conv_fwd_lc_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                                  const unsigned* __restrict__ cmask,
+                                                                  const int* __restrict__ cbase, const int* __restrict__ packed,
+                                                                  const int* __restrict__ perm, float* __restrict__ Y, int n_out,
+                                                                  int K, int ntiles, ConvEpilogue ep) {
+  static_assert(CIN == 4 || CIN == 16, "low-channel instance");
+  constexpr int COUT = 16, WO = CIN * COUT;     // floats per offset
+  constexpr int TILE_INTS = 16 * 32 + 16;       // packed indices of 16 rows (<= 16 K) + the 16 output rows
+  extern __shared__ __attribute__((aligned(16))) float lc_lds[];
+  float* const Wl = lc_lds;
+  const int T = threadIdx.x, lane = T & 63, wave = __builtin_amdgcn_readfirstlane(T >> 6), nw = blockDim.x >> 6;
+  int* const my = reinterpret_cast<int*>(lc_lds + (WLDS ? ((K * WO + 3) & ~3) : 0)) + wave * TILE_INTS;
+  // weights in B-operand order. C_in = 16: [o][kq][co][t] = W[o][4 kq + t][co]: lane (co, kq) reads its four steps as ONE 16-byte
+  // read at lane * 16 bytes (conflict-free); C_in = 4: [o][kq][co] = W[o][kq][co]
+  if constexpr (WLDS) {
+    for (int e = T; e < K * WO; e += blockDim.x) {
+      const int o = e / WO, r = e - o * WO, ci = r >> 4, co = r & 15;
+      const int d = CIN == 16 ? o * WO + (((ci >> 2) * 16 + co) << 2) + (ci & 3) : o * WO + ci * 16 + co;
+      Wl[d] = W[e];
+    }
+    __syncthreads();
+  }
+  const int i = lane & 15, kq = lane >> 4;
+  const int t0 = (int)((int64_t)blockIdx.x * ntiles / gridDim.x), t1 = (int)((int64_t)(blockIdx.x + 1) * ntiles / gridDim.x);
+  for (int t = t0 + wave; t < t1; t += nw) {
+    const int row0 = t * 16, srow = row0 + i;
+    const bool live = srow < n_out;
+    const unsigned mask = live ? cmask[srow] : 0u;
+    const int base = cbase[live ? srow : n_out];
+    const int b0 = __builtin_amdgcn_readfirstlane(base);                     // lane 0: row0 < n_out always
+    const int b1 = cbase[min(row0 + 16, n_out)];                             // wave-uniform address
+    for (int e = lane; e < b1 - b0; e += 64) my[e] = packed[b0 + e];
+    if (kq == 0) my[16 * 32 + i] = live ? (perm ? perm[srow] : srow) : -1;
+    // offsets present in the tile: OR over the 16 rows (every 16-lane row of the wave holds the same 16 masks)
+    unsigned U = mask;
+    U |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)U, 0x128, 0xf, 0xf, false);   // row_ror:8
+    U |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)U, 0x124, 0xf, 0xf, false);
+    U |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)U, 0x122, 0xf, 0xf, false);
+    U |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)U, 0x121, 0xf, 0xf, false);
+    unsigned Us = (unsigned)__builtin_amdgcn_readfirstlane((int)U);
+    const int rel = base - b0;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // NB offsets per round: their index reads, then their gathers, are in flight TOGETHER (one offset per round made a tile a
+    // chain of |U| dependent LDS + L2 round trips: 34 us per launch against 17 for the phase kernel)
+    while (Us) {
+      int o[NB];
+      bool ov[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {                                         // scalar: the next NB set bits
+        ov[j] = Us != 0;
+        o[j] = ov[j] ? __builtin_ctz(Us) : 0;
+        Us = Us & (Us - 1);
+      }
+      bool has[NB];
+      int idx[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        has[j] = ov[j] && ((mask >> o[j]) & 1u);
+        const int rank = __popc(mask & ((1u << o[j]) - 1u));
+        idx[j] = my[has[j] ? rel + rank : 0];                                // (the wave's own LDS writes: executed in order)
+      }
+      if constexpr (CIN == 16) {
+        f32x4 av[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) av[j] = *reinterpret_cast<const f32x4*>(X + (int64_t)(has[j] ? idx[j] : 0) * CIN + 4 * kq);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          if (ov[j]) {                                                       // wave-uniform
+            f32x4 bv;
+            if constexpr (WLDS) bv = *reinterpret_cast<const f32x4*>(Wl + o[j] * WO + lane * 4);
+            else {                                                           // W[o][4 kq + t][co] from L1 / L2 (27 KB, hot)
+              const float* wp = W + o[j] * WO + (4 * kq) * 16 + i;
+              bv = (f32x4){wp[0], wp[16], wp[32], wp[48]};
+            }
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(has[j] ? av[j][tt] : 0.f, bv[tt], acc, 0, 0, 0);
+          }
+        }
+      } else {
+        float av[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) av[j] = X[(int64_t)(has[j] ? idx[j] : 0) * CIN + kq];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          if (ov[j]) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(has[j] ? av[j] : 0.f, WLDS ? Wl[o[j] * WO + lane] : W[o[j] * WO + lane], acc, 0, 0, 0);
+      }
+    }
+    if (ep.mean != nullptr) {                          // wave-uniform; arithmetic order of bn_apply_kernel (as sparse_conv_fwd2_kernel)
+      const float mu = ep.mean[i], is = rsqrtf(ep.var[i] + ep.eps), ga = ep.gamma[i], be = ep.beta[i];
+      const float bi = ep.bias ? ep.bias[i] : 0.f;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        float v = acc[rg];
+        if (ep.bias) v = v + bi;
+        v = ga * ((v - mu) * is) + be;
+        acc[rg] = (ep.relu && !(v > 0.f)) ? 0.f : v;
+      }
+    }
+    // accumulator register rg = tile row 4 kq + rg, column = output channel i
+    const int4 orow = *reinterpret_cast<const int4*>(my + 16 * 32 + 4 * kq);
+    if (orow.x >= 0) Y[(int64_t)orow.x * COUT + i] = acc[0];
+    if (orow.y >= 0) Y[(int64_t)orow.y * COUT + i] = acc[1];
+    if (orow.z >= 0) Y[(int64_t)orow.z * COUT + i] = acc[2];
+    if (orow.w >= 0) Y[(int64_t)orow.w * COUT + i] = acc[3];
+  }
+}
+
 // one 32-bit neighbour mask per row (bit o set <=> nbr[row][o] >= 0); sort key for the row permutation
 __global__ __launch_bounds__(256) void nbr_mask_kernel(const int* __restrict__ nbr, int n, int K, int* __restrict__ mask) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1410,6 +1533,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 CRB_KNOB g_subt_override = 0;     // 0 = heuristic; 1/2/4 force (A/B measurements)
+CRB_KNOB g_fwd_lowchannel = 1;    // sparse_conv_fwd_lc_kernel: 1 = for C_in = 4 (product); measurement builds: 0 / 2 / >= 16, see launch_fwd_compact
 #ifdef CRB_MEASURE
 static int g_fwd_rowc = 0;        // 1 = row-contiguous gathers + in-quad transpose at CIN = 64 (compact-table kernel)
 #endif
@@ -1477,6 +1601,31 @@ template <int CIN, int COUT>
 int launch_fwd_compact(const float* X, const float* W, const unsigned* cmask, const int* cbase, const int* packed,
                        const int* perm, const int* tile_order, float* Y, int64_t n_out, int K, hipStream_t st,
                        ConvEpilogue ep = ConvEpilogue{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0}) {
+  if constexpr ((CIN == 4 || CIN == 16) && COUT == 16) {
+    // g_fwd_lowchannel: 1 (product) = the low-channel kernel for C_in = 4 only (20.1 us against 25.4 for the v1 kernel on the
+    // (N,K) table; at 16 -> 16 it measured 28.5 us against 17.2 for the phase kernel: profiles/r04_lowchannel_floor.txt);
+    // measurement builds: 0 = never, 2 = both shapes, >= 16 = both shapes with the weights resident in LDS, that many workgroups
+    const bool use_lc = g_fwd_lowchannel >= 2 || (g_fwd_lowchannel == 1 && CIN == 4);
+    if (use_lc) {
+      const int ntiles = crb_cdiv(n_out, 16);
+      if (g_fwd_lowchannel < 16) {                           // weights from L1 / L2, one tile per wave, 4 waves per workgroup
+        const int grid = crb_cdiv(ntiles, 4);
+        hipLaunchKernelGGL((sparse_conv_fwd_lc_kernel<CIN, 8, false>), dim3(grid), dim3(256), sizeof(int) * 4 * (16 * 32 + 16), st, X,
+                           W, cmask, cbase, packed, perm, Y, (int)n_out, K, ntiles, ep);
+      } else {
+#ifdef CRB_MEASURE
+        int grid = crb_cdiv(ntiles, 16);                     // >= one tile per wave
+        if (grid > g_fwd_lowchannel) grid = g_fwd_lowchannel;
+        const size_t lds = sizeof(float) * ((K * CIN * COUT + 3) & ~3) + sizeof(int) * 16 * (16 * 32 + 16);
+        CRB_HIP(hipFuncSetAttribute((const void*)sparse_conv_fwd_lc_kernel<CIN, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        hipLaunchKernelGGL((sparse_conv_fwd_lc_kernel<CIN, 8, true>), dim3(grid), dim3(1024), lds, st, X, W, cmask, cbase, packed, perm,
+                           Y, (int)n_out, K, ntiles, ep);
+#endif
+      }
+      CRB_CHECK_LAUNCH();
+      return CRB_OK;
+    }
+  }
   if constexpr (CIN % 16 == 0 && COUT % 16 == 0 && CIN <= 64) {
     const int ntiles = crb_cdiv(n_out, 64);
     const int grid = ((ntiles + 7) / 8) * 8;
@@ -1600,6 +1749,10 @@ extern "C" int crb_sparse_conv_set_rowc(int on) {
   g_fwd_rowc = on ? 1 : 0;
   return CRB_OK;
 }
+extern "C" int crb_sparse_conv_set_lowchannel(int v) {               // 1 = product default; 0 / 2 / >= 16: launch_fwd_compact
+  g_fwd_lowchannel = v < 0 ? 1 : v;
+  return CRB_OK;
+}
 
 extern "C" int crb_sparse_conv_set_subtiles(int subt) {
   // 0 = default (v2 where the shape allows, else v1); 1,2,4 = v1 with that many row tiles per wave; 8 = v2 (A/B runs)
@@ -1681,6 +1834,7 @@ extern "C" int crb_sparse_conv_wgrad_occupancy(int cin, int cout) {
 }
 
 extern "C" int crb_sparse_conv_compact_supported(int cin, int cout) {
+  if (cin == 4 && cout == 16) return 1;                     // low-channel instance (sparse_conv_fwd_lc_kernel)
   return (cin % 16 == 0 && cout % 16 == 0 && cin <= 64 && crb_sparse_conv_supported(cin, cout)) ? 1 : 0;
 }
 

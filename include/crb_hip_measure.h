@@ -37,6 +37,9 @@ int crb_sparse_conv_set_subtiles(int subt);
 /* A/B: 1 = row-contiguous gathers + in-quad DPP transpose in the compact-table kernel at Cin = 64 (same products, another
  * grouping of the channels over the MFMA steps: equal to f32 rounding, not bit-equal) */
 int crb_sparse_conv_set_rowc(int on);
+/* low-channel forward kernel (C_in in {4,16}, C_out = 16): 1 = product default (C_in = 4 only), 0 = never, 2 = both shapes,
+ * >= 16 = both shapes with the weights resident in LDS and that many 16-wave workgroups (A/B) */
+int crb_sparse_conv_set_lowchannel(int v);
 /* measurement builds: after launches under crb_sparse_conv_set_subtiles(32) (64x64 kernel with s_memtime accounting), copy the
  * 16 accumulated counters to host memory and clear them: [0] waves [1] total cycles [2] prologue [3] load issue [4] MFMA
  * block [5] W store [6] barrier wait [7] epilogue [8] phases [9] phases with MFMA work [10] W fetch issue [11] row-index

@@ -596,7 +596,7 @@ def test_compact_table_is_the_sorted_table_and_gives_identical_results(dev, kind
         assert torch.equal(full_rows, nat[perm.long()]) and sorted(perm.cpu().tolist()) == list(range(n))
         n_in = rb.n_in if w_ == 'nbr' else rb.n_out
         ct_plain = sparse.CompactTable(ct.cmask, ct.cbase, ct.packed, ct.perm, ct.n, ct.K, None)
-        for cin, cout in ((16, 16), (16, 32), (32, 16), (32, 32), (32, 64), (64, 64), (64, 128)):
+        for cin, cout in ((4, 16), (16, 16), (16, 32), (32, 16), (32, 32), (32, 64), (64, 64), (64, 128)):
             assert lib.crb_sparse_conv_compact_supported(cin, cout) == 1
             x = torch.randn(n_in, cin, device=dev)
             w = torch.randn(27, cin, cout, device=dev) / 8
@@ -604,7 +604,7 @@ def test_compact_table_is_the_sorted_table_and_gives_identical_results(dev, kind
             b = sparse._conv_forward_raw(x, w, ct, n)
             c = sparse._conv_forward_raw(x, w, ct_plain, n)
             assert torch.equal(a, b) and torch.equal(a, c), (cin, cout, float((a - b).abs().max()))
-    assert lib.crb_sparse_conv_compact_supported(4, 16) == 0 and lib.crb_sparse_conv_compact_supported(128, 64) == 0
+    assert lib.crb_sparse_conv_compact_supported(5, 16) == 0 and lib.crb_sparse_conv_compact_supported(128, 64) == 0
     # natural row order (no permutation) and an all-empty table
     ct0 = sparse._compact(rb.nbr, None, 27)
     assert torch.equal(ct0.to_nbr(), rb.nbr)

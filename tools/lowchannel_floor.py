@@ -8,6 +8,7 @@ launches), algorithmic bytes, and three floors measured in the same 
   empty     an empty-ish launch (fill of 256 floats): the launch + dispatch floor
 usage: python tools/lowchannel_floor.py"""
 import os
+os.environ.setdefault('CRB_MEASURE_LIB', '1')     # A/B knob of the low-channel kernel (include/crb_hip_measure.h)
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'crb-active-3ddet_amd'))
@@ -32,7 +33,7 @@ def timeit(fn, warm=300, rounds=12, per=40):
 
 
 if __name__ == '__main__':
-    from crbhip import sparse, voxel
+    from crbhip import sparse, voxel, lib
     from pcdet.datasets.synthetic import kitti_batch, KITTI_RANGE, KITTI_VOXEL
     dev = torch.device('cuda', 0)
     pts, off, _ = kitti_batch(0, 16)
@@ -73,6 +74,21 @@ if __name__ == '__main__':
                     % (level, cin, cout, n, P, P / n, balg / 1e6, flops / 1e9, t_k, balg / t_k / 1e3, 100 * balg / t_k / 1e3 / 8000,
                        flops / t_k / 1e6, 100 * flops / t_k / 1e6 / 157.3, t_copy, balg / t_copy / 1e3, t_g, t_empty))
             print(line, flush=True)
+            if cout == 16:
+                # round 4: resident-weights kernel (sparse_conv_fwd_lc_kernel) against the phase kernels it replaces, same inputs
+                lib.crb_sparse_conv_set_lowchannel(2)
+                y_new = sparse._conv_forward_raw(x, w, table, n)
+                lib.crb_sparse_conv_set_lowchannel(0)
+                old_table = table if cin == 16 else rb.sorted_table('nbr')
+                y_old = sparse._conv_forward_raw(x, w, old_table, n)
+                t_old = timeit(lambda: sparse._conv_forward_raw(x, w, old_table, n))
+                grids = {}
+                for g in (2, 256, 512):
+                    lib.crb_sparse_conv_set_lowchannel(g)
+                    grids[g] = timeit(lambda: sparse._conv_forward_raw(x, w, table, n), warm=100, rounds=8, per=40)
+                lib.crb_sparse_conv_set_lowchannel(1)
+                print('   product path %.1f us | phase / v1 kernel %.1f us; low-channel kernel bit-equal to it: %s; weights from L2 + one tile per wave / grid cap 256 / 512 workgroups: %s us'
+                      % (t_k, t_old, bool(torch.equal(y_new, y_old)), ' / '.join('%.1f' % grids[g] for g in grids)), flush=True)
             if cin >= 32:
                 prs = rb.pairs()
                 t_w = timeit(lambda: sparse._conv_wgrad_raw(x, dy, prs, 27), warm=100, rounds=8, per=20)
