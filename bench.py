@@ -150,9 +150,10 @@ def other_kernel_rows(prof, overhead_ms=0.0):
                 pairs_cache[pid] = int(pstart[-1].item())
             P = pairs_cache[pid]
             add(('sparse_wgrad', cin, cout), ms, 4.0 * n_in * cin + 4.0 * n_out * cout + 8.0 * P + 4.0 * K * cin * cout, 2.0 * P * cin * cout)
-        elif kind in ('bn_fwd', 'bn_bwd'):
+        elif kind in ('bn_fwd', 'bn_bwd', 'bn_stats'):
             _, n, C = rec[:3]
-            add(('batchnorm_relu_' + kind[3:], C, 'rows>=1M' if n >= (1 << 20) else 'rows<1M'), ms, (3.0 if kind == 'bn_fwd' else 5.0) * 4.0 * n * C, 0.0)
+            passes = {'bn_fwd': 3.0, 'bn_bwd': 5.0, 'bn_stats': 1.0}[kind]      # bn_stats: statistics pass only, the apply lives in the next convolution's input transform
+            add(('batchnorm_relu_' + kind[3:], C, 'rows>=1M' if n >= (1 << 20) else 'rows<1M'), ms, passes * 4.0 * n * C, 0.0)
     rows = {}
     for k, v in agg.items():
         name = '_'.join(str(x) for x in k)

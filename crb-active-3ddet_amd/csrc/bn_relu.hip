@@ -594,8 +594,9 @@ extern "C" int crb_bn_relu_forward(const float* x, int64_t n, int C, const float
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, eps, 0, mean, var,
                        invstd, running_mean, running_var, momentum, reinterpret_cast<long long*>(num_batches_tracked));
   const int64_t total4 = n * C / 4;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, z,
-                     total4, C, relu, ld_z, (g_bn_order >> 1) & 1);
+  if (z)                                       // z == NULL: statistics (and running statistics) only
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, z,
+                       total4, C, relu, ld_z, (g_bn_order >> 1) & 1);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
@@ -637,8 +638,9 @@ extern "C" int crb_bn_relu_forward_partials(const float* x, int64_t n, int C, co
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, eps, 0, mean, var,
                        invstd, running_mean, running_var, momentum, reinterpret_cast<long long*>(num_batches_tracked));
   const int64_t total4 = n * C / 4;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, z,
-                     total4, C, relu, ld_z, (g_bn_order >> 1) & 1);
+  if (z)                                       // z == NULL: statistics (and running statistics) only
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, z,
+                       total4, C, relu, ld_z, (g_bn_order >> 1) & 1);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
@@ -850,3 +852,26 @@ extern "C" int crb_bn_set_order(int bits) {
   return CRB_OK;
 }
 #endif
+
+// (scale, shift) per channel of a training-mode BatchNorm whose statistics are known: z = scale * x + shift, interleaved (C, 2):
+// what crb_conv3x3_winograd2_bnrelu_nhwc / crb_winograd2_wgrad_bnrelu apply inside their input transforms
+namespace {
+__global__ __launch_bounds__(256) void bn_affine_table_kernel(const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, int C,
+                                                              float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float s = gamma[c] * invstd[c];
+  out[2 * c] = s;
+  out[2 * c + 1] = beta[c] - mean[c] * s;
+}
+}  // namespace
+
+extern "C" int crb_bn_affine_table(const float* mean, const float* invstd, const float* gamma, const float* beta, int C, float* out,
+                                   void* stream) {
+  if (C <= 0 || !mean || !invstd || !gamma || !beta || !out) return CRB_ERR_ARG;
+  hipLaunchKernelGGL(bn_affine_table_kernel, dim3(crb_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, mean, invstd, gamma, beta, C,
+                     out);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}

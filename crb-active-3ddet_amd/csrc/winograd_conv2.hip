@@ -124,6 +124,7 @@ struct Wino2Args {
   const float* U;      // crb_winograd2_weights image
   float* y;            // (N,H,W,Cout)
   const float* bias;   // (Cout) or null
+  const float* affine; // AFFINE instances: (Cin, 2) = per input channel (scale, shift): the kernel convolves relu(scale * x + shift)
   int N, H, W, cin, cout, relu;
   int th, tw;          // tile rows per image rounded UP TO EVEN (a wave's two tile rows never straddle two images; the phantom
                        // row of an odd count is computed and not stored), tiles per row = ceil(W/2)
@@ -171,7 +172,11 @@ __device__ __forceinline__ void unit_next(UnitPos& u, const Wino2Args& a) {
   while (u.ty0 >= a.th) { u.ty0 -= a.th; ++u.n0; }
 }
 
-template <int MODE>
+// AFFINE: the input of the convolution is relu(scale[c] * x + shift[c]) (the previous layer's BatchNorm + ReLU, never written to
+// memory), zero outside the map like any padded input: applied by the input transform to the 16 values it reads, times a 0 / 1
+// mask of the patch positions inside the map. The 8 (scale, shift) pairs of a chunk travel in four of the eight junk slots of the
+// wave's second raw DMA instruction: no extra instruction, no extra counter to wait for.
+template <int MODE, bool AFFINE = false>
 __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const Vb = lds;
@@ -226,7 +231,36 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   // r = pixel row 2 ty - 1 + r of the first tile row's image; the second tile row starts at local row 2): written by this wave's
   // DMA, read by this wave's transform - no other wave waits for them
   const int raw_off = wave * RAW_WAVE_FLOATS + (2 * (t_tr & 1)) * RAW_ROW_FLOATS + t_tc * CC + t_ch;
-  auto t_advance = [&]() {};
+  const int sb_off = wave * RAW_WAVE_FLOATS + 6 * RAW_ROW_FLOATS + 2 * t_ch;     // AFFINE: (scale, shift) of the thread's channel
+  // AFFINE: mk[i][h] = 1 where patch row i and columns 2 h, 2 h + 1 are inside the map (per unit of the transform, which runs one
+  // chunk ahead of the MFMAs)
+  UnitPos tu = first;
+  int tc = 0;
+  f32x2 mk[4][2];
+  auto t_setup = [&]() {
+    int n = tu.n0, ty = tu.ty0 + t_tr;
+    while (ty >= a.th) { ty -= a.th; ++n; }
+    const int x0 = 2 * (tu.bc * TB_COLS + t_tc) - 1;
+    float cv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cv[j] = (x0 + j >= 0 && x0 + j < a.W) ? 1.f : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int yy = 2 * ty - 1 + i;
+      const float rv = (yy >= 0 && yy < a.H) ? 1.f : 0.f;
+      mk[i][0] = (f32x2){rv * cv[0], rv * cv[1]};
+      mk[i][1] = (f32x2){rv * cv[2], rv * cv[3]};
+    }
+  };
+  if (AFFINE) t_setup();
+  auto t_advance = [&]() {
+    if (!AFFINE) return;
+    if (++tc < nch) return;
+    tc = 0;
+    const int R0 = tu.R0, bc = tu.bc;
+    unit_next(tu, a);
+    if (tu.R0 != R0 || tu.bc != bc) t_setup();
+  };
 
   // ---- DMA role. raw: slots q = T, T + 512 (16 bytes each): q -> (raw row, parity, pixel pair, channel half); runs three chunks
   //      ahead of the MFMAs. U: 4 x 16 bytes per thread, two chunks ahead.
@@ -253,6 +287,10 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
       const bool ok = rows_in_batch && rr < 6 && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && MODE != 5 && !(touch && half);
       src[s] = ok ? a.x + (((int64_t)n * a.H + yy) * a.W + xx) * a.cin + half * 4 : g_wino_zero_page;
       step[s] = ok ? CC : 0;
+      if (AFFINE && q >= 120 && q < 124) {                   // junk slots 0..3: channels 2 p, 2 p + 1 of the chunk as (s, b, s, b)
+        src[s] = a.affine + (q - 120) * 4;
+        step[s] = 2 * CC;
+      }
     }
   };
   auto r_setup = [&]() { slot_sources(ru, rsrc, rstep, false); };
@@ -377,6 +415,14 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)       // columns 2 h, 2 h + 1: pixel pair h of parity 0 / 1
         dp[i][h] = (f32x2){p[i * RAW_ROW_FLOATS + h * CC], p[i * RAW_ROW_FLOATS + (RAW_ROW_FLOATS / 2) + h * CC]};
+    if (AFFINE) {                     // (in this stage: the masks belong to the transform's unit, which stage 1 moves on)
+      const f32x2 sbv = *reinterpret_cast<const f32x2*>(raw + sb_off);
+      const f32x2 ss = (f32x2){sbv[0], sbv[0]}, bb = (f32x2){sbv[1], sbv[1]}, zero = (f32x2){0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) dp[i][h] = __builtin_elementwise_max(__builtin_elementwise_fma(dp[i][h], ss, bb), zero) * mk[i][h];
+    }
   };
   auto t_cols = [&](int h) {        // B^T d, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], columns 2 h and 2 h + 1
     tp[0][h] = dp[0][h] - dp[2][h];
@@ -564,12 +610,12 @@ extern "C" int crb_winograd2_weights_conv(const float* w, int64_t so, int64_t si
   return CRB_OK;
 }
 
-extern "C" int crb_conv3x3_winograd2_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
-                                          const float* bias, int relu, void* stream) {
+static int winograd2_launch(const float* x, const float* affine, const float* U, float* y, int N, int H, int W, int cin, int cout,
+                            const float* bias, int relu, void* stream) {
   if (N <= 0 || H <= 0 || W <= 0) return CRB_ERR_ARG;
   if (!crb_winograd2_supported(cin, cout, H, W)) return CRB_ERR_UNSUPPORTED;
   Wino2Args a;
-  a.x = x; a.U = U; a.y = y; a.bias = bias;
+  a.x = x; a.U = U; a.y = y; a.bias = bias; a.affine = affine;
   a.N = N; a.H = H; a.W = W; a.cin = cin; a.cout = cout; a.relu = relu;
   a.th = (((H + 1) / 2) + 1) & ~1; a.tw = (W + 1) / 2;
   const int64_t rt = (int64_t)N * a.th;
@@ -593,10 +639,11 @@ extern "C" int crb_conv3x3_winograd2_nhwc(const float* x, const float* U, float*
   if (g_wino2_mode == 8) kern = winograd2_kernel<8>;
   if (g_wino2_mode == 9) kern = winograd2_kernel<9>;
 #endif
-  static bool attr_done = false;
-  if (!attr_done || g_wino2_mode) {
+  if (affine) kern = winograd2_kernel<0, true>;
+  static bool attr_done[2] = {false, false};
+  if (!attr_done[affine ? 1 : 0] || g_wino2_mode) {
     CRB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
+    attr_done[affine ? 1 : 0] = true;
   }
   // persistent workgroups: one per CU (all of the LDS each), every one runs a contiguous range of units as one pipeline
   static int n_cu = 0;
@@ -613,4 +660,17 @@ extern "C" int crb_conv3x3_winograd2_nhwc(const float* x, const float* U, float*
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, (hipStream_t)stream, a);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
+}
+
+extern "C" int crb_conv3x3_winograd2_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
+                                          const float* bias, int relu, void* stream) {
+  return winograd2_launch(x, nullptr, U, y, N, H, W, cin, cout, bias, relu, stream);
+}
+
+// y = conv3x3(relu(scale[c] * x + shift[c])) with zero padding of the ACTIVATED map: affine (Cin, 2) f32 = (scale, shift) per input
+// channel. The previous layer's training-mode BatchNorm + ReLU applied inside the input transform: its output is never stored.
+extern "C" int crb_conv3x3_winograd2_bnrelu_nhwc(const float* x, const float* affine, const float* U, float* y, int N, int H, int W,
+                                                 int cin, int cout, const float* bias, int relu, void* stream) {
+  if (!affine) return CRB_ERR_ARG;
+  return winograd2_launch(x, affine, U, y, N, H, W, cin, cout, bias, relu, stream);
 }

@@ -58,6 +58,7 @@ struct WgradArgs {
   const float* x;      // (N,H,W,Cin)
   const float* dy;     // (N,H,W,Cout)
   float* part;         // (ranges, nci * nco blocks, 16, 64 ci, 64 co)
+  const float* affine; // AFFINE instances: (Cin, 2) per input channel (scale, shift): the layer's input is relu(scale * x + shift)
   const float* zero;   // g_wgrad_zero_page (as an argument: every use of the symbol itself costs a scalar load + wait)
   int N, H, W, cin, cout;
   int th, tw;          // tiles per column / row
@@ -85,13 +86,16 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) 
 // MODE (measurement builds): 1 = no MFMAs, 2 = no transforms, 3 = no DMA in the loop (wrong results); 4 = correct results + cycle
 // accounting per wave in g_wgrad_dbg (8 uint64 per wave): {total, stages 0-6, parked at wait + barrier, last stage, chunks}
 __device__ unsigned long long* g_wgrad_dbg = nullptr;
-template <int MODE>
+// AFFINE: the convolution's input was relu(scale[c] * x + shift[c]) (applied by the forward kernel's input transform, never stored):
+// the V transform applies the same to the values it reads, times the 0 / 1 mask of the patch positions inside the map (scalars:
+// a wave transforms one tile)
+template <int MODE, bool AFFINE = false>
 __global__ __launch_bounds__(NT, 2) void winograd2_wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const Vb = lds;                       // V images (B operand), two buffers
   float* const Xb = lds + 2 * IMG_FLOATS;      // raw input blocks, three buffers
   float* const Gb = Xb + 3 * RAWX_FLOATS;      // raw output-gradient blocks, three buffers
-  const int T = threadIdx.x, lane = T & 63, wave = T >> 6;
+  const int T = threadIdx.x, lane = T & 63, wave = __builtin_amdgcn_readfirstlane(T >> 6);       // (a scalar for the compiler)
 
   // ---- block and range of this workgroup: the nci * nco blocks of ONE range read the same maps: same XCD (id % 8)
   const int nblk = a.nci * a.nco;
@@ -193,52 +197,91 @@ __global__ __launch_bounds__(NT, 2) void winograd2_wgrad_kernel(WgradArgs a) {
   };
 
   // ---- V transform
-  float d[4][4], t[4][4];
+  // packed f32 (as the forward kernel's transform): a register pair = columns (2 h, 2 h + 1) of a patch row, 8 + 8 v_pk_add_f32
+  // instead of 32 adds and the moves that packed the store operands
+  f32x2 dp[4][2], tp[4][2];
+  ChunkPos vpos = first;                       // AFFINE: chunk the transform works on (one ahead of the MFMAs)
+  f32x2 sc2 = (f32x2){1.f, 1.f}, sh2 = (f32x2){0.f, 0.f};
+  if (AFFINE) {
+    const f32x2 sb = *reinterpret_cast<const f32x2*>(a.affine + (cib * BLK + lane) * 2);
+    sc2 = (f32x2){sb[0], sb[0]};
+    sh2 = (f32x2){sb[1], sb[1]};
+  }
   auto v_load = [&](const float* raw) {
     const float* p = raw + raw_off;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d[i][j] = p[(i * 10 + j) * BLK];
+      for (int h = 0; h < 2; ++h) dp[i][h] = (f32x2){p[(i * 10 + 2 * h) * BLK], p[(i * 10 + 2 * h + 1) * BLK]};
   };
-  auto v_cols = [&](int j) {        // B^T d, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-    t[0][j] = d[0][j] - d[2][j];
-    t[1][j] = d[1][j] + d[2][j];
-    t[2][j] = d[2][j] - d[1][j];
-    t[3][j] = d[1][j] - d[3][j];
+  // AFFINE: activation of the column pair h, in the stage that consumes it (placed behind the reads in stage 0 it made the wave
+  // wait for them there, in front of that stage's MFMAs: +80 us per call). Patch positions outside the map are zero padding of
+  // the ACTIVATED map: 0 / 1 factors (scalars: a wave transforms one tile; branch-free - a branch splits the stage's basic block)
+  float cm[4], rm[4];
+  auto v_act_setup = [&]() {
+    const int y0 = 4 * vpos.p - 1 + 2 * t_tr, x0 = 8 * vpos.bc - 1 + 2 * t_tc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cm[j] = (x0 + j >= 0 && x0 + j < a.W) ? 1.f : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rm[i] = (y0 + i >= 0 && y0 + i < a.H) ? 1.f : 0.f;
+    chunk_next(vpos, a);
   };
-  auto v_row = [&](float* V, int i) {          // xi = 4 i .. 4 i + 3 as two (even, odd) pairs
-    *reinterpret_cast<f32x2*>(V + img_off + imgb_index(i * 4 + 0, 0, 0)) = (f32x2){t[i][0] - t[i][2], t[i][1] + t[i][2]};
-    *reinterpret_cast<f32x2*>(V + img_off + imgb_index(i * 4 + 2, 0, 0)) = (f32x2){t[i][2] - t[i][1], t[i][1] - t[i][3]};
+  auto v_act = [&](int h) {
+    const f32x2 zero = (f32x2){0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      dp[i][h] = __builtin_elementwise_max(__builtin_elementwise_fma(dp[i][h], sc2, sh2), zero) * (f32x2){rm[i] * cm[2 * h], rm[i] * cm[2 * h + 1]};
+  };
+  auto v_cols = [&](int h) {        // B^T d, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], columns 2 h and 2 h + 1
+    if (AFFINE) {
+      if (h == 0) v_act_setup();
+      v_act(h);
+    }
+    tp[0][h] = dp[0][h] - dp[2][h];
+    tp[1][h] = dp[1][h] + dp[2][h];
+    tp[2][h] = dp[2][h] - dp[1][h];
+    tp[3][h] = dp[1][h] - dp[3][h];
+  };
+  auto v_row = [&](float* V, int i) {          // xi = 4 i .. 4 i + 3 as two (even, odd) pairs: (t0 - t2, t1 + t2), (t2 - t1, t1 - t3)
+    f32x2 o01, o23;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(o01) : "v"(tp[i][0]), "v"(tp[i][1]));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(o23) : "v"(tp[i][0]), "v"(tp[i][1]));
+    *reinterpret_cast<f32x2*>(V + img_off + imgb_index(i * 4 + 0, 0, 0)) = o01;
+    *reinterpret_cast<f32x2*>(V + img_off + imgb_index(i * 4 + 2, 0, 0)) = o23;
   };
 
-  // ---- M = A dY A^T in registers. gq[e][a][b]: gradient of tile 2 kq + e at pixel (a, b); mi[e][i][b] = (A dY)[i][b],
-  //      A = [1 0; 1 1; 1 -1; 0 -1]; M[i][j] = (mi[i][0], mi[i][0] + mi[i][1], mi[i][0] - mi[i][1], -mi[i][1])[j]
-  float gq[2][2][2], mi[2][4][2];
+  // ---- M = A dY A^T in registers, packed f32 and with the two negations of A folded into the accumulators' final sign.
+  //      gp[e][r] = gradient of tile 2 kq + e at pixel row r, columns (0, 1). A = [1 0; 1 1; 1 -1; 0 -1]:
+  //      (A dY)[i] = (g0, g0 + g1, g0 - g1, -g1)[i] -> mip[e][i] = (g0, g0 + g1, g0 - g1, +g1): row 3 carries the opposite sign;
+  //      M[i][j] = (a, a + b, a - b, -b)[j] with (a, b) = (A dY)[i] -> (mip[i][0], ms[i][0], ms[i][1], +mip[i][1]): column 3
+  //      carries the opposite sign. Accumulator xi = 4 i + j therefore holds sign(i) sign(j) dU, sign(3) = -1: xi = 3, 7, 11, 12,
+  //      13, 14 are negated when the partial is stored. 12 packed instructions per chunk, none between the MFMAs (it was 48
+  //      scalar ones, most of them feeding the next MFMA directly).
+  f32x2 gp[2][2], mip[2][4], ms[2][4];
   auto g_load = [&](const float* G) {
     const float* p = G + g_off;
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) gq[e][r][c] = p[(r * 8 + 2 * e + c) * BLK];
+      for (int r = 0; r < 2; ++r) gp[e][r] = (f32x2){p[(r * 8 + 2 * e) * BLK], p[(r * 8 + 2 * e + 1) * BLK]};
   };
   auto m_cols = [&]() {
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
+    for (int e = 0; e < 2; ++e) {
+      mip[e][0] = gp[e][0];
+      mip[e][1] = gp[e][0] + gp[e][1];
+      mip[e][2] = gp[e][0] - gp[e][1];
+      mip[e][3] = gp[e][1];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        mi[e][0][b] = gq[e][0][b];
-        mi[e][1][b] = gq[e][0][b] + gq[e][1][b];
-        mi[e][2][b] = gq[e][0][b] - gq[e][1][b];
-        mi[e][3][b] = -gq[e][1][b];
-      }
+      for (int i = 0; i < 4; ++i)               // (a + b, a - b) from (a, b)
+        asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(ms[e][i]) : "v"(mip[e][i]));
+    }
   };
   auto m_val = [&](int e, int xi) {
     const int i = xi >> 2, j = xi & 3;
-    return j == 0 ? mi[e][i][0] : j == 1 ? mi[e][i][0] + mi[e][i][1] : j == 2 ? mi[e][i][0] - mi[e][i][1] : -mi[e][i][1];
+    return j == 0 ? mip[e][i][0] : j == 1 ? ms[e][i][0] : j == 2 ? ms[e][i][1] : mip[e][i][1];
   };
+  auto acc_sign = [](int xi) { return (((xi >> 2) == 3) != ((xi & 3) == 3)) ? -1.f : 1.f; };
 
   // ---- MFMA pieces (as winograd_conv2.hip: 8 stages = xi pairs, the B operands of the next pair read one stage ahead)
   f32x4 v0[2], v1[2];
@@ -284,8 +327,8 @@ __global__ __launch_bounds__(NT, 2) void winograd2_wgrad_kernel(WgradArgs a) {
     for (int xp = 0; xp < 8; ++xp) {
       if (T_ON) {
         if (xp == 0) v_load(Xb + gb1 * RAWX_FLOATS);
-        if (xp == 1) { v_cols(0); v_cols(1); }
-        if (xp == 2) { v_cols(2); v_cols(3); }
+        if (xp == 1) v_cols(0);
+        if (xp == 2) v_cols(1);
         if (xp >= 3 && xp < 7) v_row(Vn, xp - 3);
       }
       // the lane's gradient values of chunk g + 1 (landed since the previous barrier), BEFORE this chunk's barrier: behind it
@@ -329,8 +372,8 @@ __global__ __launch_bounds__(NT, 2) void winograd2_wgrad_kernel(WgradArgs a) {
   g_load(Gb);
   m_cols();
   v_load(Xb);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) v_cols(j);
+  v_cols(0);
+  v_cols(1);
 #pragma unroll
   for (int i = 0; i < 4; ++i) v_row(Vb, i);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -350,7 +393,7 @@ __global__ __launch_bounds__(NT, 2) void winograd2_wgrad_kernel(WgradArgs a) {
   for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
     for (int cbk = 0; cbk < 2; ++cbk)
-      *reinterpret_cast<f32x4*>(out + (xi * BLK + wt * 32 + cbk * 16 + l15) * BLK + wk * 16 + 4 * kq) = acc[xi][cbk];
+      *reinterpret_cast<f32x4*>(out + (xi * BLK + wt * 32 + cbk * 16 + l15) * BLK + wk * 16 + 4 * kq) = acc[xi][cbk] * acc_sign(xi);
   if (MODE == 4 && g_wgrad_dbg && lane == 0) {
     unsigned long long* o = g_wgrad_dbg + ((int64_t)blockIdx.x * 8 + wave) * 8;
     o[0] = __builtin_amdgcn_s_memtime() - cyc_start;
@@ -427,10 +470,9 @@ extern "C" int64_t crb_winograd2_wgrad_workspace_bytes(int cin, int cout) {
   return (int64_t)wgrad_ranges(nblk) * nblk * 16 * BLK * BLK * 4;
 }
 
-// x (N,H,W,Cin), dy (N,H,W,Cout) f32 NHWC -> dw = gradient of the nn.Conv2d weight (Cout,Cin,3,3), written with the element
-// strides (so, si, sky, skx) of that tensor. workspace: crb_winograd2_wgrad_workspace_bytes(cin, cout).
-extern "C" int crb_winograd2_wgrad(const float* x, const float* dy, float* dw, int64_t so, int64_t si, int64_t sky, int64_t skx,
-                                   int N, int H, int W, int cin, int cout, void* workspace, int64_t workspace_bytes, void* stream) {
+static int winograd2_wgrad_launch(const float* x, const float* affine, const float* dy, float* dw, int64_t so, int64_t si,
+                                  int64_t sky, int64_t skx, int N, int H, int W, int cin, int cout, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
   if (N <= 0 || H <= 0 || W <= 0) return CRB_ERR_ARG;
   if (!crb_winograd2_wgrad_supported(cin, cout, H, W)) return CRB_ERR_UNSUPPORTED;
   if (workspace_bytes < crb_winograd2_wgrad_workspace_bytes(cin, cout) || !workspace) return CRB_ERR_WORKSPACE;
@@ -438,7 +480,7 @@ extern "C" int crb_winograd2_wgrad(const float* x, const float* dy, float* dw, i
   static const float* zero_page = nullptr;
   if (!zero_page) CRB_HIP(hipGetSymbolAddress((void**)&zero_page, HIP_SYMBOL(g_wgrad_zero_page)));
   WgradArgs a;
-  a.x = x; a.dy = dy; a.part = (float*)workspace; a.zero = zero_page;
+  a.x = x; a.dy = dy; a.part = (float*)workspace; a.zero = zero_page; a.affine = affine;
   a.N = N; a.H = H; a.W = W; a.cin = cin; a.cout = cout;
   a.th = (H + 1) / 2; a.tw = (W + 1) / 2;
   a.tw4 = (a.tw + 3) / 4;
@@ -457,10 +499,11 @@ extern "C" int crb_winograd2_wgrad(const float* x, const float* dy, float* dw, i
   if (g_wgrad2_mode == 3) kern = winograd2_wgrad_kernel<3>;
   if (g_wgrad2_mode == 4) kern = winograd2_wgrad_kernel<4>;
 #endif
-  static bool attr_done = false;
-  if (!attr_done || g_wgrad2_mode) {
+  if (affine) kern = winograd2_wgrad_kernel<0, true>;
+  static bool attr_done[2] = {false, false};
+  if (!attr_done[affine ? 1 : 0] || g_wgrad2_mode) {
     CRB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
+    attr_done[affine ? 1 : 0] = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.nranges * nblk)), dim3(NT), lds, (hipStream_t)stream, a);
   CRB_CHECK_LAUNCH();
@@ -469,4 +512,19 @@ extern "C" int crb_winograd2_wgrad(const float* x, const float* dy, float* dw, i
                      (const float*)workspace, a.nranges, a.nci, a.nco, dw, so, si, sky, skx, cin, cout);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
+}
+
+// x (N,H,W,Cin), dy (N,H,W,Cout) f32 NHWC -> dw = gradient of the nn.Conv2d weight (Cout,Cin,3,3), written with the element
+// strides (so, si, sky, skx) of that tensor. workspace: crb_winograd2_wgrad_workspace_bytes(cin, cout).
+extern "C" int crb_winograd2_wgrad(const float* x, const float* dy, float* dw, int64_t so, int64_t si, int64_t sky, int64_t skx,
+                                   int N, int H, int W, int cin, int cout, void* workspace, int64_t workspace_bytes, void* stream) {
+  return winograd2_wgrad_launch(x, nullptr, dy, dw, so, si, sky, skx, N, H, W, cin, cout, workspace, workspace_bytes, stream);
+}
+
+// the same for a layer whose input was relu(scale[c] * x + shift[c]) (crb_conv3x3_winograd2_bnrelu_nhwc): affine (Cin, 2)
+extern "C" int crb_winograd2_wgrad_bnrelu(const float* x, const float* affine, const float* dy, float* dw, int64_t so, int64_t si,
+                                          int64_t sky, int64_t skx, int N, int H, int W, int cin, int cout, void* workspace,
+                                          int64_t workspace_bytes, void* stream) {
+  if (!affine) return CRB_ERR_ARG;
+  return winograd2_wgrad_launch(x, affine, dy, dw, so, si, sky, skx, N, H, W, cin, cout, workspace, workspace_bytes, stream);
 }

@@ -439,6 +439,12 @@ int crb_bn_relu_forward_partials(const float* x, int64_t n, int C, const float* 
                                  const float* beta, float eps, int relu, float* z, int64_t z_row_stride, float* mean, float* var,
                                  float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                  float momentum, void* workspace, int64_t workspace_bytes, int32_t* tickets, void* stream);
+/* z == NULL in crb_bn_relu_forward / crb_bn_relu_forward_partials: statistics only (mean / var / invstd, running statistics and the
+ * batch counter as usual), no apply pass — for a consumer that applies the normalisation itself:
+ * crb_bn_affine_table writes (scale, shift) = (gamma * invstd, beta - mean * gamma * invstd) per channel, interleaved (C, 2), the
+ * table crb_conv3x3_winograd2_bnrelu_nhwc / crb_winograd2_wgrad_bnrelu take. */
+int crb_bn_affine_table(const float* mean, const float* invstd, const float* gamma, const float* beta, int C, float* out_c2,
+                        void* stream);
 int crb_bn_relu_apply(const float* x, int64_t n, int C, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int relu, float* z, int64_t z_row_stride, void* stream);
 /* z_row_stride / dz_row_stride (floats, 0 = C): z may be a channel slice of a wider row-major buffer (the BEV backbone
@@ -565,6 +571,21 @@ int crb_winograd2_wgrad_supported(int cin, int cout, int H, int W);
 int64_t crb_winograd2_wgrad_workspace_bytes(int cin, int cout);
 int crb_winograd2_wgrad(const float* x, const float* dy, float* dw, int64_t so, int64_t si, int64_t sky, int64_t skx,
                         int N, int H, int W, int cin, int cout, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* a7, training: Conv2d(3x3, padding 1) applied to relu(BatchNorm(x)) of the PREVIOUS layer without storing that activation:
+ * the three modules `nn.BatchNorm2d -> nn.ReLU -> nn.Conv2d` of one `blocks[k]` Sequential
+ * (pcdet/models/backbones_2d/base_bev_backbone.py:31-41) as one forward launch. affine (Cin, 2) = (scale, shift) per input
+ * channel from crb_bn_affine_table (batch statistics of x: crb_bn_relu_forward with z == NULL). The input transform computes
+ * relu(scale * x + shift) on the values it reads and zeroes the patch positions outside the map (zero padding is applied to
+ * the ACTIVATED map, as nn.Conv2d(padding=1) after nn.ReLU does). crb_winograd2_wgrad_bnrelu is the weight gradient of that
+ * layer: its V transform applies the same activation to x. The input gradient is crb_conv3x3_winograd2_nhwc on the flipped
+ * weights as before (it is the gradient with respect to the activated map; BatchNorm + ReLU backward follows:
+ * crb_bn_relu_backward on x). Same shape limits as the plain entry points. */
+int crb_conv3x3_winograd2_bnrelu_nhwc(const float* x, const float* affine, const float* U, float* y, int N, int H, int W,
+                                      int cin, int cout, const float* bias, int relu, void* stream);
+int crb_winograd2_wgrad_bnrelu(const float* x, const float* affine, const float* dy, float* dw, int64_t so, int64_t si,
+                               int64_t sky, int64_t skx, int N, int H, int W, int cin, int cout, void* workspace,
+                               int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

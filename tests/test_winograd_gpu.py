@@ -203,3 +203,73 @@ def test_bev_backbone_gradients_are_as_accurate_as_the_miopen_path(dev, monkeypa
     for n, e_m, e_w in zip(['output', 'input gradient'] + names, errs[False], errs[True]):
         print('%-22s relative L2 error vs f64: MIOpen path %.2e, Winograd path %.2e' % (n, e_m, e_w))
         assert max(e_w, e_m) <= (1e-5 if n == 'output' else 2e-2), (n, e_m, e_w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 64, 64, 37, 29), (3, 128, 64, 12, 21), (1, 64, 128, 8, 5)])
+def test_bnrelu_conv_equals_batchnorm_relu_then_conv(dev, shape):
+    """BatchNorm2d (training) -> ReLU -> Conv2d(3x3, pad 1) as ONE op (statistics pass + activation inside the Winograd input
+    transform, crb_conv3x3_winograd2_bnrelu_nhwc / crb_winograd2_wgrad_bnrelu) against the three modules in f64: output, the
+    gradients of the input, of gamma / beta and of the weight, running statistics and the batch counter. Odd sizes: the zero
+    padding must be applied to the ACTIVATED map (relu(shift) != 0 outside the map would leak into the border tiles)."""
+    from crbhip import winograd
+    N, C, K, H, W = shape
+    torch.manual_seed(5)
+    x = (torch.randn(N, C, H, W, device=dev) * 1.5 + 0.3).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).to(dev).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    conv = torch.nn.Conv2d(C, K, 3, padding=1, bias=False).to(dev)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    assert winograd.bnrelu_conv_supported(C, K, H, W)
+    gout = torch.randn(N, K, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    y = winograd.bnrelu_conv3x3(x, bn, conv.weight)
+    (y * gout).sum().backward()
+    got = [y.detach(), x.grad, bn.weight.grad, bn.bias.grad, conv.weight.grad, bn.running_mean.clone(), bn.running_var.clone()]
+    assert int(bn.num_batches_tracked) == 1
+    x64 = x.detach().double().requires_grad_(True)
+    bn64 = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).to(dev).double().train()
+    bn64.weight.data, bn64.bias.data = bn.weight.data.double(), bn.bias.data.double()
+    conv64 = torch.nn.Conv2d(C, K, 3, padding=1, bias=False).to(dev).double()
+    conv64.weight.data = conv.weight.data.double()
+    y64 = conv64(torch.relu(bn64(x64)))
+    (y64 * gout.double()).sum().backward()
+    ref = [y64.detach(), x64.grad, bn64.weight.grad, bn64.bias.grad, conv64.weight.grad, bn64.running_mean, bn64.running_var]
+    for name, a, r, tol in zip(['output', 'input gradient', 'gamma gradient', 'beta gradient', 'weight gradient', 'running mean',
+                                'running var'], got, ref, [2e-6, 2e-5, 2e-5, 2e-5, 5e-6, 1e-6, 1e-6]):
+        err = float((a.double() - r).abs().max() / r.abs().max())
+        assert err <= tol, (name, err)
+
+
+@pytest.mark.gpu
+def test_bev_backbone_with_fused_batchnorm_apply_matches_the_default_path(dev, monkeypatch):
+    """the opt-in CRB_WINOGRAD_BN=1 path of BaseBEVBackbone (BatchNorm2d -> ReLU -> Conv2d as one op) against the default path of
+    the same network: training output, input gradient, one weight gradient per block, running statistics - equal to f32 rounding
+    through the stack (both paths are compared with each other, bounds as the f64 comparison above)."""
+    import copy
+    from pcdet.config import EasyDict
+    from pcdet.models.backbones_2d import base_bev_backbone as bb
+    from crbhip import winograd
+    torch.manual_seed(9)
+    cfg = EasyDict({'LAYER_NUMS': [3, 3], 'LAYER_STRIDES': [1, 2], 'NUM_FILTERS': [128, 256], 'UPSAMPLE_STRIDES': [1, 2],
+                    'NUM_UPSAMPLE_FILTERS': [256, 256]})
+    net = bb.BaseBEVBackbone(cfg, 256).to(dev).train()
+    B, H, W = 2, 52, 44
+    x0 = (torch.randn(B, 256, H, W, device=dev) * (torch.rand(B, 1, H, W, device=dev) < 0.2)).contiguous(memory_format=torch.channels_last)
+    gout = torch.randn(B, 512, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    outs = {}
+    for flag in (False, True):
+        monkeypatch.setattr(winograd, 'BN_FUSED', flag)
+        model = copy.deepcopy(net)
+        x = x0.clone().requires_grad_(True)
+        y = model({'spatial_features': x})['spatial_features_2d']
+        (y * gout).sum().backward()
+        p = dict(model.named_parameters())
+        outs[flag] = [y.detach(), x.grad, p['blocks.0.4.weight'].grad, p['blocks.1.7.weight'].grad, p['blocks.0.5.weight'].grad,
+                      model.blocks[0][5].running_mean.clone(), model.blocks[1][8].running_var.clone()]
+    for name, a, b, tol in zip(['output', 'input gradient', 'conv weight gradient (block 0)', 'conv weight gradient (block 1)',
+                                'gamma gradient', 'running mean', 'running var'], outs[False], outs[True],
+                               [1e-5, 2e-2, 2e-2, 2e-2, 2e-2, 1e-5, 1e-5]):
+        err = float((a - b).norm() / b.norm())
+        assert err <= tol, (name, err)
