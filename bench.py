@@ -187,9 +187,16 @@ def dominant_roofline(prof, overhead_ms, gather_roof, gather_table):
     if best is None or g_ms >= best_ms:
         return gather_roof, None, table
     name, r, v = best
+    traffic, traffic_src = None, 'no committed PMC summary for this kernel instance'
+    try:
+        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r04_pmc_winograd2.json')))
+        if pm.get('shape') and ('_'.join(str(x) for x in pm['shape'])) in name:
+            traffic, traffic_src = pm['traffic_bytes_per_launch'], pm['source']
+    except (OSError, ValueError, KeyError):
+        pass
     roof = {'bound': 'mfma', 'kernel': 'winograd2_kernel / winograd2_wgrad_kernel: %s (F(2x2,3x3) f32 MFMA, BEV backbone 3x3 convolutions)' % name,
             'achieved': r['TFLOPs'], 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s', 'frac': r['mfma_f32_frac'],
-            'traffic': None, 'traffic_source': 'profiles/r04_pmc_sq_winograd2_*.txt hold the FETCH_SIZE / WRITE_SIZE passes of this kernel (separate runs)',
+            'traffic': traffic, 'traffic_source': traffic_src,
             'avg_launch_us': r['avg_us'], 'launches': r['launches'], 'event_pair_overhead_us': round(1e3 * overhead_ms, 2),
             'alg_flops_per_launch': round(v['flops'] / v['n']), 'alg_bytes_per_launch': round(v['bytes'] / v['n']),
             'hbm_GBps_alg': r['GBps_alg'], 'hbm_frac': r['hbm_frac'], 'direct_equivalent_TFLOPs': r.get('direct_equivalent_TFLOPs'),

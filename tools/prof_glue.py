@@ -46,6 +46,22 @@ def main():
         step()
     torch.cuda.synchronize()
     from torch.profiler import profile, ProfilerActivity
+    # module scopes (the profiler delivers no Python stacks on this stack): every module's forward runs inside a record_function
+    scopes = {}
+
+    def pre(name):
+        def f(mod, inp):
+            rf = torch.autograd.profiler.record_function('mod:' + name)
+            rf.__enter__()
+            scopes.setdefault(id(mod), []).append(rf)
+        return f
+
+    def post(mod, inp, out):
+        scopes[id(mod)].pop().__exit__(None, None, None)
+    for name, m in model.named_modules():
+        if name:
+            m.register_forward_pre_hook(pre(name))
+            m.register_forward_hook(post)
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
         step()
         torch.cuda.synchronize()
@@ -65,6 +81,12 @@ def main():
             if ('crb-active-3ddet_amd/' in fr) and ('torch/' not in fr):
                 site = fr.split('crb-active-3ddet_amd/')[-1]
                 break
+        if site is None:
+            p = e.cpu_parent
+            while p is not None and not p.name.startswith('mod:'):
+                p = p.cpu_parent
+            if p is not None:
+                site = 'forward of ' + p.name[4:] + ' | ' + e.name.replace('aten::', '')
         if site is None:
             p = e
             while p is not None and not p.name.startswith('autograd::engine::evaluate_function'):
