@@ -13,6 +13,7 @@ Extra objects on the JSON line: `roofline` (dominant hand-written kernel: subm g
 stream inside the timed region, algorithmic bytes per SURVEY §8d) and `cpu_baseline` (oracle CPU port on a bounded
 sample; rank 0, N=1 only)."""
 import argparse
+import gc
 import json
 import os
 import sys
@@ -533,7 +534,6 @@ def pvrcnn_bench(args, rank, world, device):
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=True,
                                                         bucket_cap_mb=DDP_BUCKET_MB)
     batches = make_batches(args, rank, device, first=20000)
-    torch.cuda.reset_peak_memory_stats()         # (the peak of THIS leg: until r04 the field carried the earlier legs' peak)
     for b in batches:
         b['point_frame_counts_host'] = np.diff(b['point_frame_offsets'].cpu().numpy()).tolist()
 
@@ -548,6 +548,9 @@ def pvrcnn_bench(args, rank, world, device):
     for i in range(3):
         step(i)
     torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()         # (after the warm-up: MIOpen's solver search allocates workspaces the steps never see again)
+    gc.collect()
+    gc.freeze()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -670,6 +673,11 @@ def main():
         step(i)
     torch.cuda.synchronize()
     warm_s = _all_ranks(time.perf_counter() - t_warm, world, device)     # solver search + allocator + table caches, per rank
+    # everything alive after warm-up (model, optimizer state, caches, the interpreter's own objects) leaves the garbage collector's
+    # generations: a full collection inside a timed step then scans only what the steps themselves created (observed without it:
+    # two 8 - 12 ms holes per 8 steps in the kernel trace, step-time p90 50 ms against a 44 ms median)
+    gc.collect()
+    gc.freeze()
     overhead_ms = event_pair_overhead_ms() if rank == 0 else 0.0
     prof = [] if rank == 0 else None
     torch.cuda.reset_peak_memory_stats()
@@ -734,7 +742,16 @@ def main():
                          'ms_per_step': round(1e3 * dt_nopt / args.steps, 3), 'ms_per_step_device': _pctl(per_step_nopt),
                          'note': 'same %d steps without grad-clip / optimizer' % args.steps},
     }
+    # the kernel tables come out of the event records NOW: the records hold the rulebook tables of every profiled step (device
+    # memory: until r04 they stayed alive through the later legs and sat in their peak-memory numbers, 12 GB of the "40.9 GB")
+    roof_pack = None
+    if rank == 0:
+        roof_g, table_g = roofline_from_profile(prof, overhead_ms)
+        roof_pack = dominant_roofline(prof, overhead_ms, roof_g, table_g)
+        roof3_pack = roofline_from_profile(prof3, overhead_ms, 'bf16x3') if dt3 is not None else None
+    prof = prof3 = None
     del opt, net, model, batches
+    gc.collect()
     torch.cuda.empty_cache()
     pv = pvrcnn_bench(args, rank, world, device) if (args.pvrcnn_steps > 0 and args.kind == 'kitti') else None
     score = crb_scoring_bench(args, rank, world, device) if (args.scoring_pool > 0 and args.kind == 'kitti') else None
@@ -742,14 +759,13 @@ def main():
         out['crb_scoring'] = score
         out['pvrcnn'] = pv
         out['miopen_convs'] = miopen
-        roof, table = roofline_from_profile(prof, overhead_ms)
-        roof, gather_roof, table = dominant_roofline(prof, overhead_ms, roof, table)
+        roof, gather_roof, table = roof_pack
         out['roofline'] = roof
         if gather_roof is not None:
             out['roofline_gather_gemm'] = gather_roof
         out['kernel_table'] = table
         if dt3 is not None:
-            roof3, table3 = roofline_from_profile(prof3, overhead_ms, 'bf16x3')
+            roof3, table3 = roof3_pack
             out['roofline_bf16x3'] = roof3
             out['bf16x3'] = {'frames_per_s': round(args.batch * world * args.bf16x3_steps / dt3, 3),
                              'ms_per_step': round(1e3 * dt3 / args.bf16x3_steps, 3), 'steps': args.bf16x3_steps,
