@@ -484,6 +484,11 @@ def crb_scoring_bench(args, rank, world, device):
     warm = strat.score_pool(mine[:bs], bs)
     strat.grad_embeddings_batched(mine[:max(bs, strat.stage2_batch)][:strat.stage2_batch], warm[:strat.stage2_batch],
                                   strat.stage2_batch)                              # MIOpen train-mode solver search
+    # (the float64 batched GEMM of the device k-means++ loads its library kernels on first use: 0.9 s inside stage 2 in one run,
+    # 88 s in a fresh process - warmed like MIOpen's solver search above, on a matrix of the timed shape)
+    k1n = min(int(strat.k1 * strat.cfg.ACTIVE_TRAIN.SELECT_NUMS), rec.shape[0])
+    if k1n >= 8:
+        scoring.kmeans_plusplus_device(torch.randn(k1n, 65536, device=device), 8, random_state=0)
     _, dt_sel = timed(lambda: strat.select_from_records(rec))
     strat.close()
     torch.set_num_threads(host_threads)
