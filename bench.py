@@ -151,9 +151,11 @@ def other_kernel_rows(prof, overhead_ms=0.0):
                 pairs_cache[pid] = int(pstart[-1].item())
             P = pairs_cache[pid]
             add(('sparse_wgrad', cin, cout), ms, 4.0 * n_in * cin + 4.0 * n_out * cout + 8.0 * P + 4.0 * K * cin * cout, 2.0 * P * cin * cout)
-        elif kind in ('bn_fwd', 'bn_bwd', 'bn_stats'):
+        elif kind in ('bn_fwd', 'bn_bwd', 'bn_stats', 'bn_apply'):
             _, n, C = rec[:3]
-            passes = {'bn_fwd': 3.0, 'bn_bwd': 5.0, 'bn_stats': 1.0}[kind]      # bn_stats: statistics pass only, the apply lives in the next convolution's input transform
+            # bn_stats: statistics pass only (the apply lives in the next convolution's input transform, opt-in); bn_apply: apply
+            # pass only (the statistics came from the producing convolution's epilogue)
+            passes = {'bn_fwd': 3.0, 'bn_bwd': 5.0, 'bn_stats': 1.0, 'bn_apply': 2.0}[kind]
             add(('batchnorm_relu_' + kind[3:], C, 'rows>=1M' if n >= (1 << 20) else 'rows<1M'), ms, passes * 4.0 * n * C, 0.0)
     rows = {}
     for k, v in agg.items():

@@ -143,7 +143,7 @@ def _prof_end(e0, *rec):
 
 class _BNReLUTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu, running_mean=None, running_var=None, momentum=0.0, nbt=None):
+    def forward(ctx, x, gamma, beta, eps, relu, running_mean=None, running_var=None, momentum=0.0, nbt=None, slabs=None):
         require_cuda(x, gamma, beta)
         ctx.set_materialize_grads(False)          # mean / var carry no gradient: no zero tensors made for them in backward
         x = x.contiguous()
@@ -157,10 +157,19 @@ class _BNReLUTrain(torch.autograd.Function):
         ws, tk = _scratch(dev, wsb)
         g, b = gamma.contiguous().float(), beta.contiguous().float()
         e0 = _prof_begin()
-        _bn_check(lib.crb_bn_relu_forward(ptr(x), n, C, ptr(g), ptr(b), float(eps), int(relu), ptr(z), 0, ptr(mean), ptr(var),
-                                      ptr(invstd), ptr(running_mean), ptr(running_var), ptr(nbt), float(momentum), ptr(ws),
-                                      wsb, ptr(tk), cur_stream(dev)), 'crb_bn_relu_forward')
-        _prof_end(e0, 'bn_fwd', n, C)
+        if slabs is not None:
+            # statistics from the slab sums the producer of x wrote (the Winograd forward kernel's epilogue): no pass over x for them
+            sl = slabs.contiguous()
+            _bn_check(lib.crb_bn_relu_forward_partials(ptr(x), n, C, ptr(sl), sl.shape[0], ptr(g), ptr(b), float(eps), int(relu),
+                                                       ptr(z), 0, ptr(mean), ptr(var), ptr(invstd), ptr(running_mean),
+                                                       ptr(running_var), ptr(nbt), float(momentum), ptr(ws), wsb, ptr(tk),
+                                                       cur_stream(dev)), 'crb_bn_relu_forward_partials')
+            _prof_end(e0, 'bn_apply', n, C)
+        else:
+            _bn_check(lib.crb_bn_relu_forward(ptr(x), n, C, ptr(g), ptr(b), float(eps), int(relu), ptr(z), 0, ptr(mean), ptr(var),
+                                              ptr(invstd), ptr(running_mean), ptr(running_var), ptr(nbt), float(momentum), ptr(ws),
+                                              wsb, ptr(tk), cur_stream(dev)), 'crb_bn_relu_forward')
+            _prof_end(e0, 'bn_fwd', n, C)
         _touch(running_mean, running_var, nbt)
         ctx.save_for_backward(x, mean, invstd, g, b)
         ctx.relu = int(relu)
@@ -182,7 +191,7 @@ class _BNReLUTrain(torch.autograd.Function):
         _bn_check(lib.crb_bn_relu_backward(ptr(x), ptr(dz), 0, n, C, ptr(mean), ptr(invstd), ptr(g), ptr(b), ctx.relu, ptr(dx),
                                        ptr(dgamma), ptr(dbeta), ptr(ws), wsb, ptr(tk), cur_stream(dev)), 'crb_bn_relu_backward')
         _prof_end(e0, 'bn_bwd', n, C)
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def _touch(*tensors):
@@ -227,7 +236,7 @@ def _counter(bn):
     return None
 
 
-def bn_relu(x, bn, relu=True):
+def bn_relu(x, bn, relu=True, slabs=None):
     """x (N,C) cuda f32; bn: nn.BatchNorm1d. Same semantics as relu(bn(x)) incl. the running-statistics update
     (momentum, unbiased running variance, num_batches_tracked)."""
     n, C = x.shape
@@ -242,7 +251,7 @@ def bn_relu(x, bn, relu=True):
                 bn.running_var.is_contiguous():
             # the running statistics and the batch counter are updated inside the statistics launch of the forward
             z, mean, var = _BNReLUTrain.apply(x, bn.weight, bn.bias, bn.eps, relu, bn.running_mean, bn.running_var,
-                                              float(bn.momentum), _counter(bn))
+                                              float(bn.momentum), _counter(bn), slabs)
             return z
         with torch.no_grad():
             bn.num_batches_tracked += 1

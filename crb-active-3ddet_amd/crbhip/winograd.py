@@ -297,3 +297,52 @@ def bnrelu_conv3x3(x, bn, weight):
     from crbhip import bnrelu
     return _BnReluConv3x3.apply(x, bn.weight, bn.bias, bn.eps, bn.running_mean, bn.running_var, float(bn.momentum),
                                 bnrelu._counter(bn), weight)
+
+
+# statistics of the following BatchNorm from the convolution's epilogue (training): CRB_WINOGRAD_STATS=0 switches it off (A/B)
+STATS = __import__('os').environ.get('CRB_WINOGRAD_STATS', '1') != '0'
+
+
+class _Conv3x3Stats(torch.autograd.Function):
+    """_Conv3x3 without bias whose forward also returns the slab sums of y and y^2 (crb_conv3x3_winograd2_stats_nhwc) for
+    crb_bn_relu_forward_partials: the BatchNorm that follows launches no statistics pass over y"""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        require_cuda(x, weight)
+        ctx.save_for_backward(x, weight)
+        xv = _nhwc(x.float())
+        N, H, W, cin = xv.shape
+        cout = weight.shape[0]
+        U = weights_forward2(weight)
+        y = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        stats = torch.empty((int(lib.crb_winograd2_stats_slabs(N, H, W)), 2, cout), dtype=torch.float32, device=x.device)
+        e0 = _prof_begin()
+        check(lib.crb_conv3x3_winograd2_stats_nhwc(xv.data_ptr(), ptr(U), y.data_ptr(), ptr(stats), N, H, W, cin, cout,
+                                                   cur_stream(x.device)), 'crb_conv3x3_winograd2_stats_nhwc')
+        _prof_end(e0, 'wino_conv', cin, cout, N, H, W)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _ds):
+        x, weight = ctx.saved_tensors
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if supported2(weight.shape[0], weight.shape[1], x.shape[2], x.shape[3]):
+                dx = conv3x3_U2(dy, weights_input_grad2(weight))
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            if WGRAD and wgrad_supported(weight.shape[1], weight.shape[0], x.shape[2], x.shape[3]):
+                dw = conv3x3_wgrad(x, dy, weight)
+            else:
+                dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1]
+        return dx, dw
+
+
+def conv3x3_stats(x, weight):
+    """(y, slab sums) of the bias-free 3x3 stride-1 pad-1 convolution; pass the sums to crbhip.bnrelu.bn_relu(..., slabs=)"""
+    return _Conv3x3Stats.apply(x, weight)

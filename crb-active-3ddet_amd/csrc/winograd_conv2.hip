@@ -124,6 +124,9 @@ struct Wino2Args {
   const float* U;      // crb_winograd2_weights image
   float* y;            // (N,H,W,Cout)
   const float* bias;   // (Cout) or null
+  float* stats;        // null, or (2 * spatial blocks, 2, Cout): per (spatial block, half of its 64 tiles) the column sums of y and y^2
+                       // over the outputs inside the map - the slab sums crb_bn_relu_forward_partials takes (training: the following
+                       // BatchNorm's statistics pass over y disappears)
   const float* affine; // AFFINE instances: (Cin, 2) = per input channel (scale, shift): the kernel convolves relu(scale * x + shift)
   int N, H, W, cin, cout, relu;
   int th, tw;          // tile rows per image rounded UP TO EVEN (a wave's two tile rows never straddle two images; the phantom
@@ -364,6 +367,7 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) bias[e] = kq == 0 ? b0[e] : kq == 1 ? b1[e] : kq == 2 ? b2[e] : b3[e];
     }
+    f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = (f32x4){0.f, 0.f, 0.f, 0.f};     // a.stats: this lane's sums over its 8 outputs
 #pragma unroll
     for (int tbk = 0; tbk < 2; ++tbk) {
       const int tile = wt * 32 + tbk * 16 + l15;
@@ -394,6 +398,35 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
         if (x1) *reinterpret_cast<f32x4*>(yo + a.cout) = y01;
         if (y1) *reinterpret_cast<f32x4*>(yo + (int64_t)a.W * a.cout) = y10;
         if (x1 && y1) *reinterpret_cast<f32x4*>(yo + (int64_t)a.W * a.cout + a.cout) = y11;
+        if (a.stats) {                                                // fixed order: (0,0), (0,1), (1,0), (1,1) of tile block 0, then 1
+          const float m01 = x1 ? 1.f : 0.f, m10 = y1 ? 1.f : 0.f, m11 = (x1 && y1) ? 1.f : 0.f;
+          s1 = s1 + y00; s2 = s2 + y00 * y00;
+          s1 = s1 + y01 * m01; s2 = s2 + (y01 * y01) * m01;
+          s1 = s1 + y10 * m10; s2 = s2 + (y10 * y10) * m10;
+          s1 = s1 + y11 * m11; s2 = s2 + (y11 * y11) * m11;
+        }
+      }
+    }
+    if (a.stats) {
+      // sum over the 16 tiles of the lane row (rotations inside the row: every lane ends with the total, fixed order), one lane per
+      // row writes its four channels: slab = (spatial block, wt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float u = s1[e], v = s2[e];
+#define CRB_ROW_ROR_ADD(x, ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false))
+        CRB_ROW_ROR_ADD(u, 0x128); CRB_ROW_ROR_ADD(v, 0x128);       // row_ror:8
+        CRB_ROW_ROR_ADD(u, 0x124); CRB_ROW_ROR_ADD(v, 0x124);
+        CRB_ROW_ROR_ADD(u, 0x122); CRB_ROW_ROR_ADD(v, 0x122);
+        CRB_ROW_ROR_ADD(u, 0x121); CRB_ROW_ROR_ADD(v, 0x121);
+#undef CRB_ROW_ROR_ADD
+        s1[e] = u;
+        s2[e] = v;
+      }
+      if (l15 == 0) {
+        const int64_t blk = (int64_t)(eu.R0 / TB_ROWS) * a.tw4 + eu.bc;
+        float* so = a.stats + ((blk * 2 + wt) * 2) * a.cout + k;
+        *reinterpret_cast<f32x4*>(so) = s1;
+        *reinterpret_cast<f32x4*>(so + a.cout) = s2;
       }
     }
     acc_clear();
@@ -611,11 +644,11 @@ extern "C" int crb_winograd2_weights_conv(const float* w, int64_t so, int64_t si
 }
 
 static int winograd2_launch(const float* x, const float* affine, const float* U, float* y, int N, int H, int W, int cin, int cout,
-                            const float* bias, int relu, void* stream) {
+                            const float* bias, int relu, void* stream, float* stats = nullptr) {
   if (N <= 0 || H <= 0 || W <= 0) return CRB_ERR_ARG;
   if (!crb_winograd2_supported(cin, cout, H, W)) return CRB_ERR_UNSUPPORTED;
   Wino2Args a;
-  a.x = x; a.U = U; a.y = y; a.bias = bias; a.affine = affine;
+  a.x = x; a.U = U; a.y = y; a.bias = bias; a.affine = affine; a.stats = stats;
   a.N = N; a.H = H; a.W = W; a.cin = cin; a.cout = cout; a.relu = relu;
   a.th = (((H + 1) / 2) + 1) & ~1; a.tw = (W + 1) / 2;
   const int64_t rt = (int64_t)N * a.th;
@@ -673,4 +706,19 @@ extern "C" int crb_conv3x3_winograd2_bnrelu_nhwc(const float* x, const float* af
                                                  int cin, int cout, const float* bias, int relu, void* stream) {
   if (!affine) return CRB_ERR_ARG;
   return winograd2_launch(x, affine, U, y, N, H, W, cin, cout, bias, relu, stream);
+}
+
+// training forward that also writes the slab sums of its output for the BatchNorm that follows: stats (crb_winograd2_stats_slabs, 2,
+// Cout) f32 = column sums of y and y^2 per (spatial block of 16 x 4 tiles, half of its tiles), every slab written exactly once
+// (no atomics, fixed order inside: bit-reproducible) -> crb_bn_relu_forward_partials(y, n, Cout, stats, slabs, ...)
+extern "C" int64_t crb_winograd2_stats_slabs(int N, int H, int W) {
+  if (N <= 0 || H <= 0 || W <= 0) return 0;
+  const int64_t th = (((H + 1) / 2) + 1) & ~1, tw4 = ((W + 1) / 2 + TB_COLS - 1) / TB_COLS;
+  return 2 * ((N * th + TB_ROWS - 1) / TB_ROWS) * tw4;
+}
+
+extern "C" int crb_conv3x3_winograd2_stats_nhwc(const float* x, const float* U, float* y, float* stats, int N, int H, int W, int cin,
+                                                int cout, void* stream) {
+  if (!stats) return CRB_ERR_ARG;
+  return winograd2_launch(x, nullptr, U, y, N, H, W, cin, cout, nullptr, 0, stream, stats);
 }

@@ -140,9 +140,22 @@ class BaseBEVBackbone(nn.Module):
             if c.padding == (0, 0) and c.padding_mode == 'zeros' and pd[0] == pd[1] and pd[2] == pd[3]:
                 if _wino_ok(c, x, (pd[2], pd[0])):
                     from crbhip import winograd
-                    return winograd.conv3x3(x, c.weight, c.bias), 2
+                    return BaseBEVBackbone._wino_conv(c, x, mods[i + 2] if i + 2 < len(mods) else None), 2
                 return torch.nn.functional.conv2d(x, c.weight, c.bias, c.stride, (pd[2], pd[0]), c.dilation, c.groups), 2
         return None, 0
+
+    @staticmethod
+    def _wino_conv(conv, x, nxt):
+        """stride-1 3x3 convolution on the Winograd kernels; when a training-mode BatchNorm2d follows (and the conv has no bias) the
+        forward kernel also writes the slab sums of its output (crb_conv3x3_winograd2_stats_nhwc), attached to the result for
+        _run_rows_train: that BatchNorm launches no statistics pass"""
+        from crbhip import winograd
+        if winograd.STATS and conv.bias is None and isinstance(nxt, nn.BatchNorm2d) and nxt.training and \
+                nxt.momentum is not None and bnrelu.FUSE_RUNNING and torch.is_grad_enabled() and not bnrelu.frame_groups_active():
+            y, slabs = winograd.conv3x3_stats(x, conv.weight)
+            y._crb_bn_slabs = slabs
+            return y
+        return winograd.conv3x3(x, conv.weight, conv.bias)
 
     @staticmethod
     def _run_rows_train(seq, x):
@@ -160,8 +173,7 @@ class BaseBEVBackbone(nn.Module):
                 x, i = y, i + used
                 continue
             if _wino_ok(m, x):
-                from crbhip import winograd
-                x = winograd.conv3x3(x, m.weight, m.bias)
+                x = BaseBEVBackbone._wino_conv(m, x, nxt)
                 i += 1
                 continue
             if isinstance(m, nn.BatchNorm2d) and isinstance(nxt, nn.ReLU) and \
@@ -182,7 +194,8 @@ class BaseBEVBackbone(nn.Module):
                         continue
                 n, c, h, w_ = x.shape
                 rows = x.permute(0, 2, 3, 1).reshape(n * h * w_, c)
-                x = bnrelu.bn_relu(rows, m, relu=True).view(n, h, w_, c).permute(0, 3, 1, 2)
+                slabs = getattr(x, '_crb_bn_slabs', None)           # written by the Winograd forward kernel that produced x
+                x = bnrelu.bn_relu(rows, m, relu=True, slabs=slabs).view(n, h, w_, c).permute(0, 3, 1, 2)
                 i += 2
             else:
                 x = m(x)

@@ -559,6 +559,15 @@ int crb_winograd2_weights_conv(const float* w, int64_t so, int64_t si, int64_t s
 int crb_conv3x3_winograd2_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
                                const float* bias, int relu, void* stream);
 
+/* training forward that also hands the following BatchNorm its statistics: stats (crb_winograd2_stats_slabs(N,H,W), 2, Cout) f32 =
+ * column sums of y and y^2 per slab of outputs (a slab = half of the 64 tiles of one 16 x 4-tile spatial block; outputs outside
+ * the map are not counted), every slab written exactly once, no atomics. Feed them to crb_bn_relu_forward_partials(y, N*H*W,
+ * Cout, stats, slabs, ...): the BatchNorm's own statistics pass over y (pcdet/models/backbones_2d/base_bev_backbone.py:31-41,
+ * nn.BatchNorm2d in training mode) is not launched. No bias, no ReLU (the Conv2d layers of the backbone have neither). */
+int64_t crb_winograd2_stats_slabs(int N, int H, int W);
+int crb_conv3x3_winograd2_stats_nhwc(const float* x, const float* U, float* y, float* stats, int N, int H, int W, int cin, int cout,
+                                     void* stream);
+
 /* a7 backward: weight gradient of the same convolution in the Winograd domain (csrc/winograd_wgrad.hip):
  * dU[xi][ci][co] = sum over tiles of (B^T d B)[xi][ci] * (A dY A^T)[xi][co] as 16 MFMA GEMMs whose two operands are both
  * produced by transforms inside the kernel, partial sums per range of tiles in the workspace, then dW = G^T dU G added up in

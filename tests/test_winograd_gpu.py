@@ -273,3 +273,55 @@ def test_bev_backbone_with_fused_batchnorm_apply_matches_the_default_path(dev, m
                                [1e-5, 2e-2, 2e-2, 2e-2, 2e-2, 1e-5, 1e-5]):
         err = float((a - b).norm() / b.norm())
         assert err <= tol, (name, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 64, 64, 37, 29), (3, 16, 128, 12, 21), (16, 128, 128, 40, 36)])
+def test_forward_kernel_writes_the_slab_sums_of_its_output(dev, shape):
+    """crb_conv3x3_winograd2_stats_nhwc: same output as the plain kernel (bit-equal), and the slab sums add up to the column sums
+    of y and y^2 over the map (odd sizes: outputs of border tiles outside the map are not counted); bit-equal on a rerun"""
+    from crbhip import winograd
+    N, C, K, H, W = shape
+    torch.manual_seed(11)
+    x = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(K, C, 3, 3, device=dev) / np.sqrt(9 * C)).contiguous(memory_format=torch.channels_last)
+    y, st = winograd.conv3x3_stats(x, w)
+    y2, st2 = winograd.conv3x3_stats(x, w)
+    assert torch.equal(y, winograd.conv3x3(x, w)) and torch.equal(st, st2) and torch.equal(y, y2)
+    ref1 = y.double().sum((0, 2, 3))
+    ref2 = (y.double() ** 2).sum((0, 2, 3))
+    got = st.double().sum(0)
+    assert float((got[0] - ref1).abs().max() / ref2.sqrt().max()) < 1e-5
+    assert float((got[1] - ref2).abs().max() / ref2.max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_bev_backbone_statistics_from_the_epilogue_match_the_statistics_pass(dev, monkeypatch):
+    """BaseBEVBackbone in training with the BatchNorm statistics taken from the convolution epilogues (default) against the same
+    network with the BatchNorm's own statistics pass (CRB_WINOGRAD_STATS=0): output, input gradient, a weight gradient and the
+    running statistics agree to the rounding of another summation order"""
+    import copy
+    from pcdet.config import EasyDict
+    from pcdet.models.backbones_2d import base_bev_backbone as bb
+    from crbhip import winograd
+    torch.manual_seed(13)
+    cfg = EasyDict({'LAYER_NUMS': [3, 3], 'LAYER_STRIDES': [1, 2], 'NUM_FILTERS': [128, 256], 'UPSAMPLE_STRIDES': [1, 2],
+                    'NUM_UPSAMPLE_FILTERS': [256, 256]})
+    net = bb.BaseBEVBackbone(cfg, 256).to(dev).train()
+    B, H, W = 2, 52, 44
+    x0 = (torch.randn(B, 256, H, W, device=dev) * (torch.rand(B, 1, H, W, device=dev) < 0.2)).contiguous(memory_format=torch.channels_last)
+    gout = torch.randn(B, 512, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    outs = {}
+    for flag in (False, True):
+        monkeypatch.setattr(winograd, 'STATS', flag)
+        model = copy.deepcopy(net)
+        x = x0.clone().requires_grad_(True)
+        y = model({'spatial_features': x})['spatial_features_2d']
+        (y * gout).sum().backward()
+        p = dict(model.named_parameters())
+        outs[flag] = [y.detach(), x.grad, p['blocks.0.4.weight'].grad, model.blocks[0][5].running_mean.clone(),
+                      model.blocks[1][8].running_var.clone()]
+    for name, a, b, tol in zip(['output', 'input gradient', 'conv weight gradient', 'running mean', 'running var'], outs[False],
+                               outs[True], [1e-5, 2e-2, 2e-2, 1e-5, 1e-5]):
+        err = float((a - b).norm() / b.norm())
+        assert err <= tol, (name, err)
