@@ -29,6 +29,41 @@ def bilinear_interpolate_torch(im, x, y):
     return (im[y0, x0] * wa[:, None] + im[y1, x0] * wb[:, None] + im[y0, x1] * wc[:, None] + im[y1, x1] * wd[:, None])
 
 
+BEV_INTERP_KERNEL = True   # crb_bev_interpolate_forward / _backward (one launch each) instead of the torch expression below
+
+
+class _BevInterpolate(torch.autograd.Function):
+    """bilinear lookup of the channels_last BEV map at the keypoints: same operations in the same order as the torch expression of
+    interpolate_from_bev_features (bit-identical forward); backward adds the four weighted copies of the gradient into the map
+    gradient with float atomics (the torch path: four sort-based index_put calls, 35 launches per step)"""
+
+    @staticmethod
+    def forward(ctx, bev, keypoints, x_min, y_min, vx, vy, stride):
+        from crbhip import lib, check, ptr, cur_stream, require_cuda
+        require_cuda(bev, keypoints)
+        if not bev.is_contiguous(memory_format=torch.channels_last):
+            bev = bev.contiguous(memory_format=torch.channels_last)
+        B, C, H, W = bev.shape
+        M = keypoints.shape[0]
+        out = torch.empty((M, C), dtype=torch.float32, device=bev.device)
+        check(lib.crb_bev_interpolate_forward(bev.data_ptr(), B, H, W, C, ptr(keypoints), M, x_min, y_min, vx, vy, stride, ptr(out),
+                                              cur_stream(bev.device)), 'crb_bev_interpolate_forward')
+        ctx.save_for_backward(keypoints)
+        ctx.geom = (B, C, H, W, x_min, y_min, vx, vy, stride)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from crbhip import lib, check, ptr, cur_stream
+        keypoints, = ctx.saved_tensors
+        B, C, H, W, x_min, y_min, vx, vy, stride = ctx.geom
+        dout = dout.contiguous().float()
+        dbev = torch.zeros((B, H, W, C), dtype=torch.float32, device=dout.device).permute(0, 3, 1, 2)       # channels_last (B,C,H,W)
+        check(lib.crb_bev_interpolate_backward(ptr(dout), B, H, W, C, ptr(keypoints), keypoints.shape[0], x_min, y_min, vx, vy, stride,
+                                               dbev.data_ptr(), cur_stream(dout.device)), 'crb_bev_interpolate_backward')
+        return dbev, None, None, None, None, None, None
+
+
 def _batch_counts(bs_idx, batch_size):
     return common_utils.batch_counts(bs_idx, batch_size)
 
@@ -73,6 +108,11 @@ class VoxelSetAbstraction(nn.Module):
 
     def interpolate_from_bev_features(self, keypoints, bev_features, batch_size, bev_stride):
         """keypoints (M,4) [b,x,y,z], bev (B,C,H,W) -> (M,C); one gather over all frames"""
+        if BEV_INTERP_KERNEL and bev_features.is_cuda and bev_features.dtype == torch.float32 and bev_features.shape[1] % 4 == 0 \
+                and keypoints.dtype == torch.float32:
+            return _BevInterpolate.apply(bev_features, keypoints.contiguous(), float(self.point_cloud_range[0]),
+                                         float(self.point_cloud_range[1]), float(self.voxel_size[0]), float(self.voxel_size[1]),
+                                         float(bev_stride))
         x = (keypoints[:, 1] - self.point_cloud_range[0]) / self.voxel_size[0] / bev_stride
         y = (keypoints[:, 2] - self.point_cloud_range[1]) / self.voxel_size[1] / bev_stride
         B, C, H, W = bev_features.shape

@@ -596,6 +596,22 @@ int crb_winograd2_wgrad_bnrelu(const float* x, const float* affine, const float*
                                int64_t sky, int64_t skx, int N, int H, int W, int cin, int cout, void* workspace,
                                int64_t workspace_bytes, void* stream);
 
+/* a19: bilinear lookup of the BEV feature map at the keypoints.
+ * replaces: VoxelSetAbstraction.interpolate_from_bev_features + bilinear_interpolate_torch
+ *           (pcdet/models/backbones_3d/pfe/voxel_set_abstraction.py:176-207, :11-44): per frame four advanced-index gathers of
+ *           the (H, W, C) map, four weights from the clamped corner coordinates, a weighted sum; autograd's backward = four
+ *           index_put(accumulate) calls.
+ * bev (B,H,W,C) f32 NHWC (= the channels_last (B,C,H,W) map), C % 4 == 0; keypoints (M,4) f32 [frame, x, y, z];
+ * u = ((x - x_min) * (1 / voxel_x)) * (1 / bev_stride) in f32 (what torch's division of a tensor by a host scalar computes, twice,
+ * as the reference writes it), corners floor(u), floor(u) + 1 clamped into the
+ * map, weights from the CLAMPED corners, products added left to right: bit-identical to the torch expression. out (M,C).
+ * backward: dbev (B,H,W,C) must be ZERO on entry; the four weighted copies of dout are added with float atomics (keypoints that
+ * share a cell: sums in arrival order). */
+int crb_bev_interpolate_forward(const float* bev, int B, int H, int W, int C, const float* keypoints, int64_t M, float x_min,
+                                float y_min, float voxel_x, float voxel_y, float bev_stride, float* out, void* stream);
+int crb_bev_interpolate_backward(const float* dout, int B, int H, int W, int C, const float* keypoints, int64_t M, float x_min,
+                                 float y_min, float voxel_x, float voxel_y, float bev_stride, float* dbev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -502,3 +502,39 @@ def test_first_layer_bn_relu_as_one_node_equals_the_separate_ops(dev):
     for k in pb:
         assert pa[k] is not None, k
         close(pa[k], pb[k], k)
+
+
+@pytest.mark.gpu
+def test_bev_interpolation_kernel_equals_the_torch_expression(dev):
+    """crb_bev_interpolate_forward / _backward against the torch restatement of interpolate_from_bev_features it replaces (itself
+    pinned by tests/golden/ref_glue.npz): forward bit-equal (same operations, same order), map gradient to atomic-order rounding;
+    keypoints on and outside the map border exercise the clamped corners"""
+    from pcdet.models.backbones_3d.pfe import voxel_set_abstraction as vsa
+    torch.manual_seed(3)
+    B, C, H, W, M = 3, 64, 25, 22, 4000
+    bev = torch.randn(B, C, H, W, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rng = [0.0, -40.0, -3.0, 70.4, 40.0, 1.0]
+    kp = torch.empty(M, 4, device=dev)
+    kp[:, 0] = torch.randint(0, B, (M,), device=dev).float()
+    kp[:, 1] = torch.rand(M, device=dev) * 74.0 - 2.0          # some left / right of the map
+    kp[:, 2] = torch.rand(M, device=dev) * 84.0 - 42.0
+    kp[:, 3] = 0.0
+    kp[:8, 1] = torch.tensor([0.0, 70.4, 70.39, 0.4, 3.2, 35.2, 70.4, 0.0], device=dev)
+    kp[:8, 2] = torch.tensor([-40.0, 40.0, 39.99, -39.6, 0.0, 0.0, -40.0, 40.0], device=dev)
+
+    class Host(object):
+        point_cloud_range, voxel_size = rng, [0.05, 0.05, 0.1]
+    g = torch.randn(M, C, device=dev)
+    outs = {}
+    for flag in (False, True):
+        vsa.BEV_INTERP_KERNEL = flag
+        try:
+            bev.grad = None
+            out = vsa.VoxelSetAbstraction.interpolate_from_bev_features(Host(), kp, bev, B, 8 * (70.4 / 0.05 / 8 / W))
+            (out * g).sum().backward()
+            outs[flag] = (out.detach().clone(), bev.grad.clone())
+        finally:
+            vsa.BEV_INTERP_KERNEL = True
+    assert torch.equal(outs[True][0], outs[False][0])
+    err = float((outs[True][1] - outs[False][1]).abs().max() / outs[False][1].abs().max())
+    assert err < 1e-5, err
