@@ -8,12 +8,16 @@
 // This design:
 //   * workgroup = 512 threads = 8 waves = TWO waves per SIMD, 128 accumulators each (16 xi x 2 blocks of v_mfma_f32_16x16x4_f32):
 //     one wave's transforms / LDS traffic / epilogue run under the other's MFMAs.
-//   * workgroup tile = 64 tiles (16 tile rows x 4 tile columns of ONE spatial block; tile rows run over the whole batch,
-//     a block may straddle images) x 64 output channels; wave = 32 tiles x 16 channels x 16 xi.
-//   * the raw input block (<= 51 pixel rows x 10 pixels x 8 channels of the chunk) and the chunk's U block come in by LDS-DMA
-//     (global_load_lds_dwordx4: no staging registers, every map element crosses the texture path once per workgroup instead of
-//     four times); the transform V = B^T d B reads the raw block from LDS (one (tile, channel) per thread and chunk: 16 ds_read_b32,
-//     32 VALU, 16 ds_write_b32) - conflict-free through an even/odd pixel-column split of the raw rows.
+//   * workgroup tile = 64 tiles (16 tile rows x 4 tile columns of ONE spatial block; tile rows run over the whole batch with
+//     the rows of an image rounded up to an even count, so a WAVE's two tile rows are always rows ty, ty + 1 of one image)
+//     x 64 output channels; wave = 32 tiles x 16 channels x 16 xi.
+//   * raw input and weights come in by LDS-DMA (global_load_lds_dwordx4: no staging registers, a map element crosses the texture
+//     path once or twice per workgroup instead of four times). Every wave copies the 6 pixel rows x 10 pixels x 8 channels of
+//     ITS two tile rows into a private 2 KB region of the raw buffer (written by this wave's DMA, read by this wave's transform:
+//     no other wave waits for it, the copy is issued two chunks ahead and is left in flight across the barrier, vmcnt(2)); the
+//     chunk's 32 KB U block is shared (one chunk ahead). The transform V = B^T d B reads the raw rows from LDS (one (tile,
+//     channel) per thread and chunk: 16 ds_read_b32, 16 packed-f32 operations, 16 ds_write_b32) - conflict-free through an
+//     even/odd pixel-column split of the raw rows.
 //   * U is the MFMA's A operand (rows = output channels), V the B operand (columns = tiles): a lane ends with 4 CONSECUTIVE output
 //     channels of one tile, so Y = A^T M A happens in registers and goes out as 16-byte stores.
 //   * operands are read with ds_read_b128 (two xi x two k-steps per read) from [xi pair][row][channel pair slot][xi parity][2]
@@ -21,7 +25,10 @@
 //     served in, without padding (ds_read_b64 pairs get merged into ds_read2st64_b64 by the compiler: half rate and a different
 //     banking). U is stored in global memory as that LDS image, chunk by chunk (crb_winograd2_weights): its LDS-DMA is a linear copy.
 //   * pipeline per chunk of 8 input channels: 8 stages of [piece of the transform raw(n+1) -> V(n+1) | operand reads | 8 MFMAs on
-//     V(n), U(n)], before the last stage's MFMAs [wait DMA + LDS, one barrier, issue DMA: U(n+2), raw(n+3)]; V, U and raw are double-buffered: 2 x 32 + 2 x 32 + 2 x 16 KB = all 160 KB of LDS.
+//     V(n), U(n)], raw(n+3) issued in stage 2, before the last stage's MFMAs [wait for everything but raw(n+3), one barrier, issue
+//     U(n+2)]; V, U and raw are double-buffered: 2 x 32 + 2 x 32 + 2 x 16 KB = all 160 KB of LDS.
+//   * optional: the slab sums of y and y^2 for the BatchNorm that follows (epilogue, a.stats), the previous layer's BatchNorm +
+//     ReLU applied inside the input transform (AFFINE instances, opt-in).
 #include <type_traits>
 #include "crb_common.h"
 #include "../../include/crb_hip.h"

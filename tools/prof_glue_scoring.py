@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Torch-native (at::native / rocclr) kernel launches of ONE CRB stage-1 scoring pass (eval-mode PV-RCNN + 5 MC-dropout head passes +
+records), attributed to the module scope that launched them (record_function per module; ops outside any module forward are listed
+by op name).  usage: python tools/prof_glue_scoring.py [frames per batch = 16] [--top N]"""
+import collections
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'crb-active-3ddet_amd'))
+import torch  # noqa: E402
+
+if __name__ == '__main__':
+    from pcdet.datasets import SyntheticDataset, build_synthetic_dataloader
+    from pcdet.model_cfgs import pv_rcnn_cfg
+    from pcdet.models import build_network
+    from pcdet.query_strategies import build_strategy
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    cfg = pv_rcnn_cfg()
+    B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16
+    top = int(sys.argv[sys.argv.index('--top') + 1]) if '--top' in sys.argv else 60
+    pool = SyntheticDataset(num_frames=4 * B, first_frame=5000, n_points=20000, training=False)
+    lab = SyntheticDataset(num_frames=2, n_points=20000)
+    model = build_network(cfg.MODEL, 3, pool).to(dev)
+    strat = build_strategy('crb', model, build_synthetic_dataloader(lab, 2), build_synthetic_dataloader(pool, B, workers=4), 0, '/tmp', cfg)
+    batches = list(strat.upload_pool_batches(list(range(4 * B)), B))
+    strat.score_device_batches(batches[:2])
+    torch.cuda.synchronize()
+    scopes = {}
+
+    def pre(name):
+        def f(mod, inp):
+            rf = torch.autograd.profiler.record_function('mod:' + name)
+            rf.__enter__()
+            scopes.setdefault(id(mod), []).append(rf)
+        return f
+
+    def post(mod, inp, out):
+        scopes[id(mod)].pop().__exit__(None, None, None)
+    for name, m in model.named_modules():
+        if name:
+            m.register_forward_pre_hook(pre(name))
+            m.register_forward_hook(post)
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        strat.score_device_batches(batches[2:3])
+        torch.cuda.synchronize()
+    native = lambda n: ('at::native' in n) or ('rocclr' in n) or n.startswith('Memcpy') or n.startswith('Memset')
+    by_site = collections.defaultdict(lambda: [0, 0.0, collections.Counter()])
+    total = [0, 0.0]
+    for e in prof.events():
+        ks = [k for k in getattr(e, 'kernels', []) if native(k.name)]
+        if not ks or any(getattr(c, 'kernels', None) for c in e.cpu_children):
+            continue
+        p = e.cpu_parent
+        while p is not None and not p.name.startswith('mod:'):
+            p = p.cpu_parent
+        site = ('in ' + p.name[4:]) if p is not None else 'outside the modules'
+        rec = by_site[site]
+        rec[0] += len(ks)
+        rec[1] += sum(k.duration for k in ks)
+        rec[2][e.name.replace('aten::', '')] += len(ks)
+        total[0] += len(ks)
+        total[1] += sum(k.duration for k in ks)
+    print('scoring pass of %d frames: %d torch-native kernel launches, %.2f ms of device time' % (B, total[0], total[1] / 1e3))
+    for site, (n, us, ops) in sorted(by_site.items(), key=lambda kv: -kv[1][0])[:top]:
+        print('%4d launches %7.1f us  %-46s [%s]' % (n, us, site[:46], ', '.join('%s x%d' % (k, v) for k, v in ops.most_common(9))))
