@@ -450,6 +450,13 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   f32x2 dp[4][2], tp[4][2];
   auto t_load = [&](const float* raw) {
     const float* p = raw + raw_off;
+    if (MODE == 12) {                   // measurement: no raw reads (the transform works on whatever the registers hold)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(dp[i][h]));
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -475,6 +482,10 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
     f32x2 o01, o23;                 // (t0 - t2, t1 + t2), (t2 - t1, t1 - t3) with (t0, t1) = tp[i][0], (t2, t3) = tp[i][1]
     asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(o01) : "v"(tp[i][0]), "v"(tp[i][1]));
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(o23) : "v"(tp[i][0]), "v"(tp[i][1]));
+    if (MODE == 13) {                   // measurement: no V stores (results computed, kept alive, not written)
+      asm volatile("" :: "v"(o01), "v"(o23));
+      return;
+    }
     o[img_index(i * 4 + 0, 0, 0)] = o01[0];
     o[img_index(i * 4 + 1, 0, 0)] = o01[1];
     o[img_index(i * 4 + 2, 0, 0)] = o23[0];
@@ -530,8 +541,8 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
       if (xp == 1) {
         // bookkeeping here, under this stage's MFMAs (at the end of a chunk it cost ~280 cycles with the matrix pipe idle): the
         // DMA sources move on from what the PREVIOUS chunk's last stage issued, the transform from what stage 0 just read
-        if (MODE != 3) { u_advance(); r_advance(); }
-        t_advance();
+        if (MODE != 3 && MODE != 11) { u_advance(); r_advance(); }      // (MODE 11: sources never move on: wrong results, timing of the bookkeeping)
+        if (MODE != 11) t_advance();
       }
       // raw block of chunk g + 3 into the wave's own region of the buffer stage 0 just read (lgkmcnt(0): those reads have
       // returned). Private regions: no other wave's progress matters, the copy has two chunks to land, and the wait in front of
@@ -558,7 +569,7 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
           stamp[3] += tm1 - t0;
           tm_stage06 += t0 - tm0;
         }
-        if (MODE != 3 && decltype(do_u)::value) issue_u();
+        if (MODE != 3 && MODE != 10 && decltype(do_u)::value) issue_u();      // (MODE 10: no U copies in the loop, wrong results)
       }
       mfma_pair(xp, xp & 1);
       // the next chunk's first operands go out right behind the last MFMAs (V(g+1), U(g+1) are valid after the barrier): their
@@ -611,7 +622,7 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
 CRB_KNOB g_wino2_persistent = 1; // 1: one workgroup per CU over a range of units (measured 4 - 8 % faster); 0: one unit per workgroup
 CRB_KNOB g_wino2_mode = 0;      // measurement builds: 1 = no MFMAs, 2 = no transform, 3 = no DMA in the loop
 #ifdef CRB_MEASURE
-extern "C" int crb_winograd2_set_mode(int mode) { g_wino2_mode = (mode >= 1 && mode <= 9) ? mode : 0; return CRB_OK; }
+extern "C" int crb_winograd2_set_mode(int mode) { g_wino2_mode = (mode >= 1 && mode <= 13) ? mode : 0; return CRB_OK; }
 extern "C" int crb_winograd2_set_persistent(int on) { g_wino2_persistent = on ? 1 : 0; return CRB_OK; }
 // mode 4: 16 uint64 per workgroup (device buffer of the caller, NULL = off)
 extern "C" int crb_winograd2_set_debug(void* dev_buf) {
@@ -678,6 +689,10 @@ static int winograd2_launch(const float* x, const float* affine, const float* U,
   if (g_wino2_mode == 7) kern = winograd2_kernel<7>;
   if (g_wino2_mode == 8) kern = winograd2_kernel<8>;
   if (g_wino2_mode == 9) kern = winograd2_kernel<9>;
+  if (g_wino2_mode == 10) kern = winograd2_kernel<10>;
+  if (g_wino2_mode == 11) kern = winograd2_kernel<11>;
+  if (g_wino2_mode == 12) kern = winograd2_kernel<12>;
+  if (g_wino2_mode == 13) kern = winograd2_kernel<13>;
 #endif
   if (affine) kern = winograd2_kernel<0, true>;
   static bool attr_done[2] = {false, false};

@@ -71,11 +71,11 @@ if __name__ == '__main__':
         print(line, flush=True)
         if not quick:
             tm = []
-            for mode in (1, 2, 3, 5, 6):
+            for mode in (1, 2, 3, 5, 6, 10, 11, 12, 13):
                 lib.crb_winograd2_set_mode(mode)
                 tm.append(timeit(lambda: winograd.conv3x3_U2(x, U2, b))[0])
             lib.crb_winograd2_set_mode(0)
-            print('   measurement builds: no MFMAs %.0f us, no transform %.0f us, no DMA in the loop %.0f us, raw from the zero page %.0f us, U from one chunk %.0f us' % tuple(tm), flush=True)
+            print('   measurement builds: no MFMAs %.0f us, no transform %.0f us, no DMA in the loop %.0f us, raw from the zero page %.0f us, U from one chunk %.0f us, no U copies in the loop %.0f us, no source bookkeeping %.0f us, transform without its raw reads %.0f us, transform without its V stores %.0f us' % tuple(tm), flush=True)
             abn = {0: [], 7: [], 8: [], 9: []}
             for _ in range(3):
                 for mode in abn:
