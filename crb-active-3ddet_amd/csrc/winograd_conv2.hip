@@ -51,6 +51,15 @@ constexpr int LDS_FLOATS = 2 * V_FLOATS + 2 * U_FLOATS + 2 * RAW_FLOATS;
 constexpr int NT = 512;
 
 __device__ float g_wino_zero_page[64];       // source of out-of-map pixels (zero-initialised, never written)
+// CUs that a long-running kernel on ANOTHER stream holds right now (crb_cu_reservation: the farthest-point sampling of PV-RCNN keeps
+// one CU per frame for ~5 ms on its side stream). A persistent launch = one workgroup per CU: with 16 CUs taken, 16 of its 256
+// workgroups wait for a CU and run their whole unit range after the others (0.73 -> 0.94 ms per call, measured in the scoring pass
+// at 16 frames per batch). The first workgroup of a launch latches the number (one word per launch in a small ring, compare-and-swap:
+// every workgroup of the launch sees the same value), the launch spreads its units over gridDim - busy workgroups and the last
+// `busy` workgroups - the ones that were still waiting for a CU - exit at once.
+__device__ int g_cu_busy = 0;
+__device__ unsigned g_cu_latch[64];
+__global__ void cu_busy_set_kernel(int v) { __hip_atomic_store(&g_cu_busy, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // operand image of one chunk (V: row = tile, U: row = output channel): float index of (xi, row, channel c of the chunk)
 __host__ __device__ __forceinline__ constexpr int img_index(int xi, int row, int c) {
@@ -143,6 +152,7 @@ struct Wino2Args {
   int nblocks;         // spatial blocks = ceil(RT / 16) * tw4
   int ncb;             // cout / 64
   int persistent;      // 1: gridDim.x workgroups share the units as contiguous ranges; 0: one unit per workgroup
+  unsigned seq;        // launch sequence number (24 bits, never 0) for the busy-CU latch; 0 = ignore g_cu_busy
 };
 
 // one 16-byte LDS-DMA per lane: LDS destination = wave-uniform base + lane * 16
@@ -201,8 +211,29 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   const int nunits = a.nblocks * a.ncb;
   int u_first, u_end;
   if (a.persistent) {
-    u_first = (int)((int64_t)blockIdx.x * nunits / gridDim.x);
-    u_end = (int)((int64_t)(blockIdx.x + 1) * nunits / gridDim.x);
+    int G = gridDim.x;
+    if (a.seq) {
+      if (T == 0) {
+        unsigned* L = g_cu_latch + (a.seq & 63u);
+        unsigned v = __hip_atomic_load(L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), mine;
+        for (;;) {
+          if ((v >> 8) == a.seq) { mine = v & 255u; break; }
+          const int b = __hip_atomic_load(&g_cu_busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned busy = (unsigned)min(max(b, 0), 255);
+          const unsigned seen = atomicCAS(L, v, (a.seq << 8) | busy);
+          if (seen == v) { mine = busy; break; }
+          v = seen;
+        }
+        Rb[6 * RAW_ROW_FLOATS] = __uint_as_float(mine);         // (junk tail of wave 0's raw region: no DMA has been issued yet)
+      }
+      __syncthreads();
+      const int busy = (int)__float_as_uint(Rb[6 * RAW_ROW_FLOATS]);
+      __syncthreads();
+      G = max(1, (int)gridDim.x - __builtin_amdgcn_readfirstlane(busy));
+      if ((int)blockIdx.x >= G) return;
+    }
+    u_first = (int)((int64_t)blockIdx.x * nunits / G);
+    u_end = (int)((int64_t)(blockIdx.x + 1) * nunits / G);
   } else {
     // consecutive workgroup ids alternate XCDs (id % 8): the channel blocks of one spatial block run back to back on ONE XCD, so
     // that the later ones read the input block from that L2
@@ -711,6 +742,10 @@ static int winograd2_launch(const float* x, const float* affine, const float* U,
   }
   const int64_t units = nb * a.ncb;
   a.persistent = g_wino2_persistent;
+  static unsigned launch_seq = 0;
+  launch_seq = (launch_seq + 1) & 0xffffffu;
+  if (!launch_seq) launch_seq = 1;
+  a.seq = launch_seq;
   const int64_t grid = a.persistent ? (units < n_cu ? units : n_cu) : ((nb + 7) / 8) * 8 * a.ncb;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, (hipStream_t)stream, a);
   CRB_CHECK_LAUNCH();
@@ -743,4 +778,14 @@ extern "C" int crb_conv3x3_winograd2_stats_nhwc(const float* x, const float* U, 
                                                 int cout, void* stream) {
   if (!stats) return CRB_ERR_ARG;
   return winograd2_launch(x, nullptr, U, y, N, H, W, cin, cout, nullptr, 0, stream, stats);
+}
+
+// cus > 0: a kernel that will hold `cus` CUs for milliseconds is about to be launched on `stream` (call right before it, same
+// stream); cus = 0: it has finished (call right after it, same stream). Persistent launches on other streams (the Winograd forward
+// kernel) then spread their work over the CUs that are left instead of queueing a workgroup behind every taken one.
+extern "C" int crb_cu_reservation(int cus, void* stream) {
+  if (cus < 0) return CRB_ERR_ARG;
+  hipLaunchKernelGGL(cu_busy_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, cus);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
 }

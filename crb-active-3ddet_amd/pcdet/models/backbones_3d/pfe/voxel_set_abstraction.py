@@ -193,7 +193,13 @@ class VoxelSetAbstraction(nn.Module):
             side = self._kp_stream = torch.cuda.Stream(device=pts.device)
         side.wait_stream(main)
         with torch.cuda.stream(side), torch.no_grad():
+            from crbhip import lib, check, cur_stream
+            # one CU per frame is taken for the ~5 ms of the sampling: the persistent Winograd launches of the BEV backbone on the main
+            # stream spread their units over the other CUs meanwhile (crb_cu_reservation; scoring at 16 frames per batch: 0.92 ->
+            # 0.78 ms per convolution while the sampling runs)
+            check(lib.crb_cu_reservation(int(batch_dict['batch_size']), cur_stream(pts.device)), 'crb_cu_reservation')
             kp = self.get_sampled_points(batch_dict)
+            check(lib.crb_cu_reservation(0, cur_stream(pts.device)), 'crb_cu_reservation')
             done = torch.cuda.Event()
             done.record(side)
         pts.record_stream(side)

@@ -596,6 +596,13 @@ int crb_winograd2_wgrad_bnrelu(const float* x, const float* affine, const float*
                                int64_t sky, int64_t skx, int N, int H, int W, int cin, int cout, void* workspace,
                                int64_t workspace_bytes, void* stream);
 
+/* Scheduling hint, no reference counterpart: PV-RCNN's keypoint sampling (crb_furthest_point_sampling_stack on a side stream under
+ * the backbones) holds one CU per frame for ~5 ms while the persistent one-workgroup-per-CU Winograd launches of the BEV backbone
+ * run on the main stream. crb_cu_reservation(cus, stream) right before such a kernel, crb_cu_reservation(0, stream) right after it
+ * (same stream: two one-thread launches): the Winograd forward launches in between spread their units over (CUs - cus)
+ * workgroups instead of leaving `cus` workgroups queued behind the taken CUs. Results do not depend on it. */
+int crb_cu_reservation(int cus, void* stream);
+
 /* a19: bilinear lookup of the BEV feature map at the keypoints.
  * replaces: VoxelSetAbstraction.interpolate_from_bev_features + bilinear_interpolate_torch
  *           (pcdet/models/backbones_3d/pfe/voxel_set_abstraction.py:176-207, :11-44): per frame four advanced-index gathers of

@@ -325,3 +325,21 @@ def test_bev_backbone_statistics_from_the_epilogue_match_the_statistics_pass(dev
                                outs[True], [1e-5, 2e-2, 2e-2, 1e-5, 1e-5]):
         err = float((a - b).norm() / b.norm())
         assert err <= tol, (name, err)
+
+
+@pytest.mark.gpu
+def test_results_do_not_depend_on_the_cu_reservation(dev):
+    """crb_cu_reservation(n): the persistent forward launch spreads its units over (CUs - n) workgroups; outputs are bit-equal for
+    any n (every unit is computed by exactly one workgroup, whichever), including n >= the number of CUs"""
+    from crbhip import winograd, lib, check, cur_stream
+    torch.manual_seed(17)
+    x = torch.randn(4, 64, 60, 44, device=dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(128, 64, 3, 3, device=dev) / 24).contiguous(memory_format=torch.channels_last)
+    ref = winograd.conv3x3(x, w)
+    try:
+        for n in (16, 100, 255, 4000):
+            check(lib.crb_cu_reservation(n, cur_stream(dev)), 'crb_cu_reservation')
+            assert torch.equal(winograd.conv3x3(x, w), ref), n
+    finally:
+        check(lib.crb_cu_reservation(0, cur_stream(dev)), 'crb_cu_reservation')
+    assert torch.equal(winograd.conv3x3(x, w), ref)
