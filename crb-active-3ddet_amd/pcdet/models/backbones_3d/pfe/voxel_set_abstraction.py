@@ -198,8 +198,10 @@ class VoxelSetAbstraction(nn.Module):
             # stream spread their units over the other CUs meanwhile (crb_cu_reservation; scoring at 16 frames per batch: 0.92 ->
             # 0.78 ms per convolution while the sampling runs)
             check(lib.crb_cu_reservation(int(batch_dict['batch_size']), cur_stream(pts.device)), 'crb_cu_reservation')
-            kp = self.get_sampled_points(batch_dict)
-            check(lib.crb_cu_reservation(0, cur_stream(pts.device)), 'crb_cu_reservation')
+            try:
+                kp = self.get_sampled_points(batch_dict)
+            finally:                                  # (a reservation left standing costs speed only, never results)
+                check(lib.crb_cu_reservation(0, cur_stream(pts.device)), 'crb_cu_reservation')
             done = torch.cuda.Event()
             done.record(side)
         pts.record_stream(side)
