@@ -191,12 +191,14 @@ def dominant_roofline(prof, overhead_ms, gather_roof, gather_table):
         return gather_roof, None, table
     name, r, v = best
     traffic, traffic_src = None, 'no committed PMC summary for this kernel instance'
-    try:
-        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r04_pmc_winograd2.json')))
-        if pm.get('shape') and ('_'.join(str(x) for x in pm['shape'])) in name:
-            traffic, traffic_src = pm['traffic_bytes_per_launch'], pm['source']
-    except (OSError, ValueError, KeyError):
-        pass
+    for pmc in ('r05_pmc_winograd2.json', 'r04_pmc_winograd2.json'):          # newest committed PMC summary of this kernel
+        try:
+            pm = json.load(open(os.path.join(ROOT, 'profiles', pmc)))
+            if pm.get('shape') and ('_'.join(str(x) for x in pm['shape'])) in name:
+                traffic, traffic_src = pm['traffic_bytes_per_launch'], pm['source']
+                break
+        except (OSError, ValueError, KeyError):
+            continue
     roof = {'bound': 'mfma', 'kernel': 'winograd2_kernel / winograd2_wgrad_kernel: %s (F(2x2,3x3) f32 MFMA, BEV backbone 3x3 convolutions)' % name,
             'achieved': r['TFLOPs'], 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s', 'frac': r['mfma_f32_frac'],
             'traffic': traffic, 'traffic_source': traffic_src,
@@ -646,6 +648,7 @@ def main():
         return loss
 
     rank_step_ms = []          # per timed_steps call: every rank's median device time per step
+    rank_wall_ms = []          # ... and every rank's own wall time per step (before the closing barrier)
 
     def timed_steps(optimizer, profile):
         """-> wall seconds for EXACTLY args.steps steps (barrier + synchronize on both sides, max over ranks) and the
@@ -664,10 +667,12 @@ def main():
             loss = step(i, optimizer)
             marks[i + 1].record()
         torch.cuda.synchronize()
+        own = time.perf_counter() - t0                                  # this rank's own steps, before it waits for the others
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        rank_wall_ms.append([round(1e3 * v / args.steps, 3) for v in _all_ranks(own, world, device)])
         sp.PROFILE = None
         wino_mod.PROFILE = None
         bn_mod.PROFILE = None
@@ -743,7 +748,7 @@ def main():
                    'parallelism': 'dp%d' % world, 'optimizer': 'grad-clip + fused AdamW in the timed region',
                    'final_loss': round(float(loss.item()), 4)},
         'ms_per_step_device': _pctl(per_step), 'peak_mem_GB': round(peak_main / 2 ** 30, 1),
-        'ms_per_step_device_per_rank': rank_step_ms[0],
+        'ms_per_step_device_per_rank': rank_step_ms[0], 'ms_per_step_per_rank': rank_wall_ms[0],
         'warmup_seconds_per_rank': [round(v, 3) for v in warm_s], 'miopen_user_db': miopen_db,
         'fwd_bwd_only': {'value': round(frames / dt_nopt, 3), 'unit': 'frames/s',
                          'ms_per_step': round(1e3 * dt_nopt / args.steps, 3), 'ms_per_step_device': _pctl(per_step_nopt),
@@ -763,13 +768,40 @@ def main():
     pv = pvrcnn_bench(args, rank, world, device) if (args.pvrcnn_steps > 0 and args.kind == 'kitti') else None
     score = crb_scoring_bench(args, rank, world, device) if (args.scoring_pool > 0 and args.kind == 'kitti') else None
     if rank == 0:
-        out['crb_scoring'] = score
-        out['pvrcnn'] = pv
-        out['miopen_convs'] = miopen
         roof, gather_roof, table = roof_pack
+        # the numbers a reader looks for first, once at the head of the line and once at its very end (a log tail keeps the end)
+        wino = {k: v for k, v in table.items() if k.startswith('winograd')}
+        headline = {
+            'second_frames_per_s': out['value'], 'second_ms_per_step': out['ms_per_step'],
+            'frames_per_s_per_gpu': round(out['value'] / world, 3),
+            'crb_scoring_frames_per_s': None if score is None else score['value'],
+            'crb_scoring_frames_per_batch': None if score is None else score['config']['frames_per_batch'],
+            'crb_scoring_at_reference_batch': None if score is None or not score.get('at_reference_batch') else score['at_reference_batch']['value'],
+            'crb_scoring_through_loader': None if score is None else score['through_loader']['value'],
+            'crb_stages_2_3_s': None if score is None else score['selection_round']['stages_2_3_s'],
+            'pvrcnn_frames_per_s': None if pv is None else pv['value'], 'pvrcnn_ms_per_step': None if pv is None else pv['ms_per_step'],
+            'pvrcnn_peak_mem_GB': None if pv is None else pv['peak_mem_GB'],
+            'miopen_convs_frames_per_s': None if miopen is None else miopen['frames_per_s'],
+            'roofline_frac': None if roof is None else roof['frac'],
+            'winograd_mfma_f32_frac': {k: v.get('mfma_f32_frac') for k, v in wino.items()},
+            'winograd_avg_us': {k: v.get('avg_us') for k, v in wino.items()},
+            'gather_gemm_frac': None if gather_roof is None else gather_roof.get('frac'),
+        }
+        first = {k: out[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                     'vs_baseline', 'dtype', 'data', 'config')}
+        first['headline'] = headline
+        first.update({k: v for k, v in out.items() if k not in first})
+        out = first
         out['roofline'] = roof
         if gather_roof is not None:
             out['roofline_gather_gemm'] = gather_roof
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args)
+        else:
+            out['cpu_baseline'] = None
+        out['crb_scoring'] = score
+        out['pvrcnn'] = pv
+        out['miopen_convs'] = miopen
         out['kernel_table'] = table
         if dt3 is not None:
             roof3, table3 = roof3_pack
@@ -780,10 +812,7 @@ def main():
                              'kernel_table': table3,
                              'note': 'same training loop, gather-GEMM fwd+dgrad of the C>=32 layers under the opt-in '
                                      'split-bf16 contract (wgrad, BEV backbone and heads unchanged, f32)'}
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args)
-        else:
-            out['cpu_baseline'] = None
+        out['summary'] = headline
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -72,6 +72,14 @@ def _load():
 lib = _load()
 
 
+def require_measure(name):
+    """entry points that live in the measurement library only (include/crb_hip_measure.h): first Winograd design, split-bf16
+    gather-GEMM, kernel-variant knobs. The product library does not carry them."""
+    if not hasattr(lib, name) or not MEASURE:
+        raise CrbHipError('%s is part of the measurement library only (include/crb_hip_measure.h): set CRB_MEASURE_LIB=1 before '
+                          'importing crbhip (tools/ do); the product library libcrbhip.so does not carry it' % name)
+
+
 # Tensors whose address went into the argument list of the call being assembled. `ptr(x.contiguous())` or `ptr(_i32(cnt))`
 # may be handed a temporary: without a reference it is freed the moment ptr() returns and the caching allocator can give
 # the same block to the next temporary of the SAME argument list. They are released once the launch call has returned

@@ -13,13 +13,16 @@ def grid_size_xyz(point_cloud_range, voxel_size):
 
 
 def voxelize(points, frame_offsets, point_cloud_range, voxel_size, max_voxels, max_points,
-             want_voxels=True, want_mean=False, grid_xyz=None):
+             want_voxels=True, want_mean=False, grid_xyz=None, lazy=False):
     """Batched point->voxel grouping on the GPU.
 
     points (n, C) f32 cuda, frames concatenated; frame_offsets (B+1) int32 cuda.
     Returns dict(voxels (M,max_points,C) | None, coords (M,4) i32 [b,z,y,x], num_points (M) i32,
                  mean (M,C) | None, counts (B) python list)  with M = sum of per-frame kept voxels.
     One host read-back of B+1 ints (the row count is data dependent).
+    lazy=True: NO read-back - the tensors come back at their capacity together with `counts_dev` (B+1 i32 on the device, the last
+    entry = M) and `pending`=True; the consumer (crbhip.sparse.build_rulebooks(..., n_dev=...)) reads M back together with its own
+    counts and slices (one synchronisation per batch instead of two).
     """
     require_cuda(points, frame_offsets)
     assert points.dtype == torch.float32 and points.dim() == 2
@@ -43,6 +46,8 @@ def voxelize(points, frame_offsets, point_cloud_range, voxel_size, max_voxels, m
                           max_voxels, max_points, ptr(voxels), ptr(coords), ptr(num_points), ptr(mean), ptr(counts),
                           ptr(ws), ws_bytes, cur_stream(dev))
     check(rc, 'crb_voxelize')
+    if lazy:
+        return dict(voxels=voxels, coords=coords, num_points=num_points, mean=mean, counts=None, counts_dev=counts, pending=True)
     counts_h = counts.cpu().tolist()          # the one sync
     M = counts_h[-1]
     return dict(voxels=voxels[:M] if want_voxels else None, coords=coords[:M], num_points=num_points[:M],

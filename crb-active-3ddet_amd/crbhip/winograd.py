@@ -33,11 +33,15 @@ def _prof_end(e0, *rec):
 
 
 def supported(cin, cout):
-    return bool(lib.crb_winograd_supported(int(cin), int(cout)))
+    """first design (round 3): measurement library only since round 5"""
+    from ._lib import MEASURE
+    return bool(MEASURE and lib.crb_winograd_supported(int(cin), int(cout)))
 
 
 def transform_weights(g):
     """g (3,3,Cin,Cout) contiguous [ky][kx][ci][co] -> U (16,Cin,Cout)"""
+    from ._lib import require_measure
+    require_measure('crb_winograd_weights')
     require_cuda(g)
     cin, cout = g.shape[2], g.shape[3]
     U = torch.empty((16, cin, cout), dtype=torch.float32, device=g.device)
@@ -94,6 +98,22 @@ def weights_input_grad2(weight):
     return _weights_conv2(weight, 1)
 
 
+_FWD_WS = {}
+
+
+def _fwd_workspace(device):
+    """workspace of the forward launches on (device, current stream): arrival counters + partial outputs of the split tail units
+    (crb_winograd2_workspace_bytes; zero before its first use, every launch leaves the counters zero). One per stream: launches
+    that may run concurrently must not share it."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _FWD_WS.get(key)
+    if ws is None:
+        with torch.cuda.device(device):
+            nbytes = int(lib.crb_winograd2_workspace_bytes())
+        ws = _FWD_WS[key] = torch.zeros((max(nbytes, 4) // 4,), dtype=torch.float32, device=device)
+    return ws
+
+
 def conv3x3_U2(x, U, bias=None, relu=False):
     """x (N,Cin,H,W) f32 channels_last, U = weights_forward2(...) -> y (N,Cout,H,W) channels_last (second kernel)"""
     require_cuda(x, U)
@@ -103,10 +123,11 @@ def conv3x3_U2(x, U, bias=None, relu=False):
     if ucin != cin or not supported2(cin, cout, H, W):
         raise CrbHipError('no Winograd (2) instance for %d -> %d channels on a %d x %d map' % (cin, cout, H, W))
     y = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    ws = _fwd_workspace(x.device)
     e0 = _prof_begin()
-    check(lib.crb_conv3x3_winograd2_nhwc(xv.data_ptr(), ptr(U), y.data_ptr(), N, H, W, cin, cout,
-                                         ptr(bias.contiguous().float()) if bias is not None else None, int(bool(relu)),
-                                         cur_stream(x.device)), 'crb_conv3x3_winograd2_nhwc')
+    check(lib.crb_conv3x3_winograd2_ws_nhwc(xv.data_ptr(), ptr(U), y.data_ptr(), N, H, W, cin, cout,
+                                            ptr(bias.contiguous().float()) if bias is not None else None, int(bool(relu)),
+                                            ptr(ws), ws.numel() * 4, cur_stream(x.device)), 'crb_conv3x3_winograd2_ws_nhwc')
     _prof_end(e0, 'wino_conv', cin, cout, N, H, W)
     return y
 
@@ -119,7 +140,9 @@ def _nhwc(x):
 
 
 def conv3x3_U(x, U, bias=None, relu=False):
-    """x (N,Cin,H,W) f32 channels_last, U (16,Cin,Cout) -> y (N,Cout,H,W) channels_last"""
+    """x (N,Cin,H,W) f32 channels_last, U (16,Cin,Cout) -> y (N,Cout,H,W) channels_last (first design: measurement library)"""
+    from ._lib import require_measure
+    require_measure('crb_conv3x3_winograd_nhwc')
     require_cuda(x, U)
     xv = _nhwc(x.float())
     N, H, W, cin = xv.shape
@@ -201,104 +224,6 @@ def conv3x3(x, weight, bias=None):
     return _Conv3x3.apply(x, weight, bias)
 
 
-# OPT-IN (CRB_WINOGRAD_BN=1): BatchNorm2d -> ReLU -> Conv2d(3x3) of the BEV backbone's blocks as one op in training (the activation
-# applied inside the convolution's input transforms, never stored). Measured on the SECOND bs=16 step: 44.5 ms against 43.4 ms
-# for the separate BatchNorm apply pass (the statistics pass still runs: 137 -> 65 us per 128-channel layer; the weight-gradient
-# kernel pays +80 us per call for re-applying the activation to its input, the forward kernel +25 us), peak memory 20.1 against
-# 22.1 GB. Off by default: slower; kept for memory-bound configurations and as the base for statistics in the epilogue.
-BN_FUSED = __import__('os').environ.get('CRB_WINOGRAD_BN', '0') == '1'
-
-
-def bnrelu_conv_supported(cin, cout, H, W):
-    return bool(supported2(cin, cout, H, W) and supported2(cout, cin, H, W) and wgrad_supported(cin, cout, H, W))
-
-
-class _BnReluConv3x3(torch.autograd.Function):
-    """conv3x3(relu(batchnorm(x))) in TRAINING mode with the activation never stored: the statistics pass of the BatchNorm
-    (crb_bn_relu_forward with z = NULL: mean / invstd, running statistics, batch counter), a (scale, shift) table, and the Winograd
-    forward kernel applying relu(scale * x + shift) inside its input transform (crb_conv3x3_winograd2_bnrelu_nhwc). Backward: input
-    gradient of the convolution by the Winograd kernel as always (= gradient of the activated map), weight gradient by
-    crb_winograd2_wgrad_bnrelu (its V transform re-applies the activation to x), then the BatchNorm + ReLU backward on x
-    (crb_bn_relu_backward: the ReLU mask is recomputed from x)."""
-
-    @staticmethod
-    def forward(ctx, x, gamma, beta, eps, running_mean, running_var, momentum, nbt, weight):
-        from crbhip import bnrelu
-        require_cuda(x, gamma, beta, weight)
-        ctx.set_materialize_grads(False)
-        xv = _nhwc(x.float())
-        N, H, W, cin = xv.shape
-        cout = weight.shape[0]
-        n = N * H * W
-        dev = x.device
-        mean = torch.empty((cin,), dtype=torch.float32, device=dev)
-        var, invstd = torch.empty_like(mean), torch.empty_like(mean)
-        wsb = lib.crb_bn_workspace_bytes(n, cin)
-        ws, tk = bnrelu._scratch(dev, wsb)
-        g, b = gamma.contiguous().float(), beta.contiguous().float()
-        e0 = bnrelu._prof_begin()
-        bnrelu._bn_check(lib.crb_bn_relu_forward(xv.data_ptr(), n, cin, ptr(g), ptr(b), float(eps), 1, None, 0, ptr(mean), ptr(var),
-                                                 ptr(invstd), ptr(running_mean), ptr(running_var), ptr(nbt), float(momentum),
-                                                 ptr(ws), wsb, ptr(tk), cur_stream(dev)), 'crb_bn_relu_forward')
-        bnrelu._prof_end(e0, 'bn_stats', n, cin)
-        bnrelu._touch(running_mean, running_var, nbt)
-        affine = torch.empty((cin, 2), dtype=torch.float32, device=dev)
-        check(lib.crb_bn_affine_table(ptr(mean), ptr(invstd), ptr(g), ptr(b), cin, ptr(affine), cur_stream(dev)),
-              'crb_bn_affine_table')
-        U = weights_forward2(weight)
-        y = torch.empty((N, cout, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-        e0 = _prof_begin()
-        check(lib.crb_conv3x3_winograd2_bnrelu_nhwc(xv.data_ptr(), ptr(affine), ptr(U), y.data_ptr(), N, H, W, cin, cout, None, 0,
-                                                    cur_stream(dev)), 'crb_conv3x3_winograd2_bnrelu_nhwc')
-        _prof_end(e0, 'wino_conv', cin, cout, N, H, W)
-        ctx.save_for_backward(x, mean, invstd, g, b, affine, weight)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        from crbhip import bnrelu
-        x, mean, invstd, g, b, affine, weight = ctx.saved_tensors
-        dev = x.device
-        xv, gv = _nhwc(x.float()), _nhwc(dy.float())
-        N, H, W, cin = xv.shape
-        cout = weight.shape[0]
-        n = N * H * W
-        dz = conv3x3_U2(dy, weights_input_grad2(weight))                    # gradient of the activated map (N,Cin,H,W)
-        dw = None
-        if ctx.needs_input_grad[8]:
-            dw = torch.empty_like(weight, dtype=torch.float32)
-            nbytes = int(lib.crb_winograd2_wgrad_workspace_bytes(cin, cout))
-            key = (dev, torch.cuda.current_stream(dev).cuda_stream)
-            ws = _WGRAD_WS.get(key)
-            if ws is None or ws.numel() * 4 < nbytes:
-                ws = _WGRAD_WS[key] = torch.empty((nbytes // 4,), dtype=torch.float32, device=dev)
-            so, si, sky, skx = dw.stride()
-            e0 = _prof_begin()
-            check(lib.crb_winograd2_wgrad_bnrelu(xv.data_ptr(), ptr(affine), gv.data_ptr(), dw.data_ptr(), so, si, sky, skx, N, H, W,
-                                                 cin, cout, ptr(ws), ws.numel() * 4, cur_stream(dev)), 'crb_winograd2_wgrad_bnrelu')
-            _prof_end(e0, 'wino_wgrad', cin, cout, N, H, W)
-        dzv = _nhwc(dz)
-        dx = torch.empty_like(x, memory_format=torch.channels_last)
-        dgamma = torch.empty((cin,), dtype=torch.float32, device=dev)
-        dbeta = torch.empty_like(dgamma)
-        wsb = lib.crb_bn_workspace_bytes(n, cin)
-        ws2, tk = bnrelu._scratch(dev, wsb)
-        e0 = bnrelu._prof_begin()
-        bnrelu._bn_check(lib.crb_bn_relu_backward(xv.data_ptr(), dzv.data_ptr(), 0, n, cin, ptr(mean), ptr(invstd), ptr(g), ptr(b), 1,
-                                                  _nhwc(dx).data_ptr(), ptr(dgamma), ptr(dbeta), ptr(ws2), wsb, ptr(tk),
-                                                  cur_stream(dev)), 'crb_bn_relu_backward')
-        bnrelu._prof_end(e0, 'bn_bwd', n, cin)
-        return dx, dgamma, dbeta, None, None, None, None, None, dw
-
-
-def bnrelu_conv3x3(x, bn, weight):
-    """conv3x3(relu(bn(x)), weight) for a training-mode nn.BatchNorm2d with momentum (running statistics and the batch counter are
-    updated), x (N,C,H,W) f32 channels_last. Callers check `bnrelu_conv_supported(Cin, Cout, H, W)` first."""
-    from crbhip import bnrelu
-    return _BnReluConv3x3.apply(x, bn.weight, bn.bias, bn.eps, bn.running_mean, bn.running_var, float(bn.momentum),
-                                bnrelu._counter(bn), weight)
-
-
 # statistics of the following BatchNorm from the convolution's epilogue (training): CRB_WINOGRAD_STATS=0 switches it off (A/B)
 STATS = __import__('os').environ.get('CRB_WINOGRAD_STATS', '1') != '0'
 
@@ -318,8 +243,9 @@ class _Conv3x3Stats(torch.autograd.Function):
         y = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         stats = torch.empty((int(lib.crb_winograd2_stats_slabs(N, H, W)), 2, cout), dtype=torch.float32, device=x.device)
         e0 = _prof_begin()
+        ws = _fwd_workspace(x.device)
         check(lib.crb_conv3x3_winograd2_stats_nhwc(xv.data_ptr(), ptr(U), y.data_ptr(), ptr(stats), N, H, W, cin, cout,
-                                                   cur_stream(x.device)), 'crb_conv3x3_winograd2_stats_nhwc')
+                                                   ptr(ws), ws.numel() * 4, cur_stream(x.device)), 'crb_conv3x3_winograd2_stats_nhwc')
         _prof_end(e0, 'wino_conv', cin, cout, N, H, W)
         ctx.mark_non_differentiable(stats)
         return y, stats

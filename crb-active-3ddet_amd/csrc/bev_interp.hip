@@ -3,7 +3,10 @@
 // NHWC map, four weights from the CLAMPED corner coordinates (as the reference forms them), products added left to right - the
 // same operations in the same order as the torch expression the mirror used until round 4 (bit-identical forward), in ONE launch
 // instead of ~20; backward: the four weighted copies of the output gradient added into the map gradient (float atomics: several
-// keypoints share a cell) in one launch instead of four sort-based index_put (35 launches, 1.36 ms per PV-RCNN step).
+// keypoints share a cell) in one launch instead of four sort-based index_put (35 launches, 1.36 ms per PV-RCNN step). The atomics add
+// in arrival order: the map gradient is reproducible to f32 rounding, not bit for bit (the host mirror takes the sort-based torch
+// path when torch.use_deterministic_algorithms is on). A keypoint whose frame index is outside [0, B) reads nothing (its output row
+// is zero) and adds nothing.
 #include "crb_common.h"
 #include "../../include/crb_hip.h"
 
@@ -14,9 +17,10 @@ namespace {
 struct BevCorner {
   int64_t r00, r10, r01, r11;      // float offsets of the four rows: (y0,x0), (y1,x0), (y0,x1), (y1,x1)
   float wa, wb, wc, wd;
+  bool ok;                         // frame index inside [0, B)
 };
 
-__device__ __forceinline__ BevCorner bev_corners(const float* __restrict__ kp, int H, int W, int C, float x_min, float y_min,
+__device__ __forceinline__ BevCorner bev_corners(const float* __restrict__ kp, int B, int H, int W, int C, float x_min, float y_min,
                                                  float vx, float vy, float stride) {
   const int b = (int)kp[0];
   // torch divides a tensor by a host scalar as a multiplication with the scalar's f32 reciprocal: the same here, twice
@@ -27,11 +31,12 @@ __device__ __forceinline__ BevCorner bev_corners(const float* __restrict__ kp, i
   const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x1, 0), W - 1);
   const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y1, 0), H - 1);
   BevCorner c;
+  c.ok = b >= 0 && b < B;
   c.wa = ((float)x1c - x) * ((float)y1c - y);
   c.wb = ((float)x1c - x) * (y - (float)y0c);
   c.wc = (x - (float)x0c) * ((float)y1c - y);
   c.wd = (x - (float)x0c) * (y - (float)y0c);
-  const int64_t base = (int64_t)b * H;
+  const int64_t base = (int64_t)(c.ok ? b : 0) * H;
   c.r00 = ((base + y0c) * W + x0c) * C;
   c.r10 = ((base + y1c) * W + x0c) * C;
   c.r01 = ((base + y0c) * W + x1c) * C;
@@ -41,28 +46,33 @@ __device__ __forceinline__ BevCorner bev_corners(const float* __restrict__ kp, i
 
 // one thread per (keypoint, channel quad)
 __global__ __launch_bounds__(256) void bev_interp_fwd_kernel(const float* __restrict__ bev, const float* __restrict__ kps, int64_t M,
-                                                             int H, int W, int C, float x_min, float y_min, float vx, float vy,
+                                                             int B, int H, int W, int C, float x_min, float y_min, float vx, float vy,
                                                              float stride, float* __restrict__ out) {
   const int q = C >> 2;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= M * q) return;
   const int64_t m = t / q;
   const int c4 = (int)(t - m * q) * 4;
-  const BevCorner c = bev_corners(kps + m * 4, H, W, C, x_min, y_min, vx, vy, stride);
+  const BevCorner c = bev_corners(kps + m * 4, B, H, W, C, x_min, y_min, vx, vy, stride);
+  if (!c.ok) {
+    *reinterpret_cast<f32x4*>(out + m * C + c4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    return;
+  }
   const f32x4 a = *reinterpret_cast<const f32x4*>(bev + c.r00 + c4), b = *reinterpret_cast<const f32x4*>(bev + c.r10 + c4);
   const f32x4 d = *reinterpret_cast<const f32x4*>(bev + c.r01 + c4), e = *reinterpret_cast<const f32x4*>(bev + c.r11 + c4);
   *reinterpret_cast<f32x4*>(out + m * C + c4) = ((a * c.wa + b * c.wb) + d * c.wc) + e * c.wd;
 }
 
 __global__ __launch_bounds__(256) void bev_interp_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ kps, int64_t M,
-                                                             int H, int W, int C, float x_min, float y_min, float vx, float vy,
+                                                             int B, int H, int W, int C, float x_min, float y_min, float vx, float vy,
                                                              float stride, float* __restrict__ dbev) {
   const int q = C >> 2;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= M * q) return;
   const int64_t m = t / q;
   const int c4 = (int)(t - m * q) * 4;
-  const BevCorner c = bev_corners(kps + m * 4, H, W, C, x_min, y_min, vx, vy, stride);
+  const BevCorner c = bev_corners(kps + m * 4, B, H, W, C, x_min, y_min, vx, vy, stride);
+  if (!c.ok) return;
   const f32x4 g = *reinterpret_cast<const f32x4*>(dout + m * C + c4);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -82,7 +92,7 @@ extern "C" int crb_bev_interpolate_forward(const float* bev, int B, int H, int W
     return CRB_ERR_ARG;
   if (M == 0) return CRB_OK;
   hipLaunchKernelGGL(bev_interp_fwd_kernel, dim3((unsigned)crb_cdiv(M * (C >> 2), 256)), dim3(256), 0, (hipStream_t)stream, bev,
-                     keypoints, M, H, W, C, x_min, y_min, voxel_x, voxel_y, bev_stride, out);
+                     keypoints, M, B, H, W, C, x_min, y_min, voxel_x, voxel_y, bev_stride, out);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
@@ -94,7 +104,7 @@ extern "C" int crb_bev_interpolate_backward(const float* dout, int B, int H, int
     return CRB_ERR_ARG;
   if (M == 0) return CRB_OK;
   hipLaunchKernelGGL(bev_interp_bwd_kernel, dim3((unsigned)crb_cdiv(M * (C >> 2), 256)), dim3(256), 0, (hipStream_t)stream, dout,
-                     keypoints, M, H, W, C, x_min, y_min, voxel_x, voxel_y, bev_stride, dbev);
+                     keypoints, M, B, H, W, C, x_min, y_min, voxel_x, voxel_y, bev_stride, dbev);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

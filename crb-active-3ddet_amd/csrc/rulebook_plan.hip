@@ -57,9 +57,11 @@ __device__ __forceinline__ int rank_lookup(const uint2* __restrict__ rank, int64
 // ------------------------------------------------------------------------------------------------ chain of output sets
 
 // level 1 (from the coordinate list, atomics): outputs reached by one input site — per axis the taps k with (c + p - k) % s == 0
-__global__ __launch_bounds__(256) void chain_mark_coords_kernel(const int* __restrict__ coords, int n, ConvGeom g, Shape3 so,
-                                                                uint32_t* __restrict__ bitmap) {
+// (n_dev != nullptr: the row count lives on the device - the voxel generator's total, not read back yet; n is then the capacity)
+__global__ __launch_bounds__(256) void chain_mark_coords_kernel(const int* __restrict__ coords, int n, const int* __restrict__ n_dev,
+                                                                ConvGeom g, Shape3 so, uint32_t* __restrict__ bitmap) {
   const int j = blockIdx.x * 256 + threadIdx.x;
+  if (n_dev) n = min(n, *n_dev);
   if (j >= n) return;
   const int4 c = *reinterpret_cast<const int4*>(coords + (int64_t)j * 4);
   for (int kz = 0; kz < g.kd; ++kz) {
@@ -681,9 +683,9 @@ extern "C" int64_t crb_spconv_padded_words(int B, const int32_t* out_shape_dhw) 
 static inline ConvGeom geom_of(const int32_t* g9) { return ConvGeom{g9[0], g9[1], g9[2], g9[3], g9[4], g9[5], g9[6], g9[7], g9[8]}; }
 static inline Shape3 shape_of(const int32_t* s) { return Shape3{s[0], s[1], s[2]}; }
 
-extern "C" int crb_spconv_chain_mark(const int32_t* coords, int64_t n, int B, const int32_t* in_shape_dhw, int n_levels,
-                                     const int32_t* geoms, const int32_t* out_shapes, const int64_t* word_off,
-                                     uint32_t* bitmap_all, int32_t* tile_sums_all, int32_t* counts_dev, void* stream) {
+static int chain_mark_impl(const int32_t* coords, int64_t n, const int32_t* n_dev, int B, const int32_t* in_shape_dhw, int n_levels,
+                           const int32_t* geoms, const int32_t* out_shapes, const int64_t* word_off, uint32_t* bitmap_all,
+                           int32_t* tile_sums_all, int32_t* counts_dev, void* stream) {
   if (n < 0 || B <= 0 || n_levels < 1 || n_levels > 8) return CRB_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   for (int l = 0; l <= n_levels; ++l)
@@ -696,7 +698,7 @@ extern "C" int crb_spconv_chain_mark(const int32_t* coords, int64_t n, int B, co
   // level 1: zero-fill + input-stationary marking from the coordinate list + tile popcounts
   CRB_HIP(hipMemsetAsync(bitmap_all + word_off[0], 0, (size_t)(word_off[1] - word_off[0]) * 4, st));
   if (n > 0)
-    hipLaunchKernelGGL(chain_mark_coords_kernel, dim3(crb_cdiv(n, 256)), dim3(256), 0, st, coords, (int)n, geom_of(geoms),
+    hipLaunchKernelGGL(chain_mark_coords_kernel, dim3(crb_cdiv(n, 256)), dim3(256), 0, st, coords, (int)n, n_dev, geom_of(geoms),
                        shape_of(out_shapes), bitmap_all + word_off[0]);
   hipLaunchKernelGGL(chain_mark_bitmap_kernel, dim3(sa.tile_off[1] - sa.tile_off[0]), dim3(1024), 0, st,
                      (const uint32_t*)nullptr, shape_of(out_shapes), geom_of(geoms), shape_of(out_shapes), B,
@@ -710,6 +712,24 @@ extern "C" int crb_spconv_chain_mark(const int32_t* coords, int64_t n, int B, co
   CRB_CHECK_LAUNCH();
   (void)in_shape_dhw;
   return CRB_OK;
+}
+
+extern "C" int crb_spconv_chain_mark(const int32_t* coords, int64_t n, int B, const int32_t* in_shape_dhw, int n_levels,
+                                     const int32_t* geoms, const int32_t* out_shapes, const int64_t* word_off,
+                                     uint32_t* bitmap_all, int32_t* tile_sums_all, int32_t* counts_dev, void* stream) {
+  return chain_mark_impl(coords, n, nullptr, B, in_shape_dhw, n_levels, geoms, out_shapes, word_off, bitmap_all, tile_sums_all,
+                         counts_dev, stream);
+}
+
+// the same with the input row count still on the device: coords holds n_cap rows of which the first *n_dev are valid (the voxel
+// generator's coordinate buffer and its total, crb_voxelize's counts[B]) - the chain can be marked and counted BEFORE the host
+// knows the voxel count, and ONE read-back then returns it together with the level sizes
+extern "C" int crb_spconv_chain_mark_lazy(const int32_t* coords, int64_t n_cap, const int32_t* n_dev, int B, const int32_t* in_shape_dhw,
+                                          int n_levels, const int32_t* geoms, const int32_t* out_shapes, const int64_t* word_off,
+                                          uint32_t* bitmap_all, int32_t* tile_sums_all, int32_t* counts_dev, void* stream) {
+  if (!n_dev) return CRB_ERR_ARG;
+  return chain_mark_impl(coords, n_cap, n_dev, B, in_shape_dhw, n_levels, geoms, out_shapes, word_off, bitmap_all, tile_sums_all,
+                         counts_dev, stream);
 }
 
 extern "C" int crb_spconv_chain_emit(int B, int n_levels, const int32_t* out_shapes, const int64_t* word_off,

@@ -19,6 +19,7 @@
 // converted to hi/lo bf16 in registers when the phase starts (VALU, idle otherwise). A wave owns TPW 16-row tiles that
 // share every B fragment read from LDS (at 16 rows per wave the kernel would be LDS-read-bound: 16 KB of W per 16 rows and
 // phase against 96 MFMA cycles).
+#ifdef CRB_MEASURE   // the opt-in split-bf16 gather-GEMM (round 2): it buys nothing on the default path; MEASUREMENT library only since round 5
 #include "crb_common.h"
 #include "../../include/crb_hip.h"
 
@@ -400,3 +401,5 @@ extern "C" int crb_sparse_conv_forward_bf16x3(const float* X, const float* W, co
 #undef X_
   return CRB_ERR_UNSUPPORTED;
 }
+
+#endif  // CRB_MEASURE

@@ -18,6 +18,7 @@
 // (Measured variants: U straight from L2 per MFMA 4.5 ms, per-wave role branches around the MFMA block 4.8 ms (spills), every
 // wave transforming patches 1.58 ms; this layout 1.125 ms per 128->128 @ 16x200x176 call — DESIGN §6.)
 // Optional epilogue on the output: + bias, ReLU.
+#ifdef CRB_MEASURE   // the first Winograd design (round 3): A/B reference of tools/, MEASUREMENT library only since round 5
 #include "crb_common.h"
 #include "../../include/crb_hip.h"
 
@@ -273,3 +274,5 @@ extern "C" int crb_conv3x3_winograd_nhwc(const float* x, const float* U, float* 
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
+
+#endif  // CRB_MEASURE

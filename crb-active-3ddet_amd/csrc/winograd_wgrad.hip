@@ -30,6 +30,7 @@
 // Every workgroup writes its partial dU block (256 KB); crb_winograd2_wgrad's second kernel adds the partials of a block in
 // range order in double and applies G^T . G: bit-reproducible.
 #include <type_traits>
+#include <atomic>
 #include "crb_common.h"
 #include "../../include/crb_hip.h"
 
@@ -477,8 +478,18 @@ static int winograd2_wgrad_launch(const float* x, const float* affine, const flo
   if (!crb_winograd2_wgrad_supported(cin, cout, H, W)) return CRB_ERR_UNSUPPORTED;
   if (workspace_bytes < crb_winograd2_wgrad_workspace_bytes(cin, cout) || !workspace) return CRB_ERR_WORKSPACE;
   if (((int64_t)N * H + 8) * (W + 16) * (cin > cout ? cin : cout) >= (1LL << 31)) return CRB_ERR_ARG;   // 32-bit element offsets
-  static const float* zero_page = nullptr;
-  if (!zero_page) CRB_HIP(hipGetSymbolAddress((void**)&zero_page, HIP_SYMBOL(g_wgrad_zero_page)));
+  // per-device state (a process may drive several devices, from several threads): the zero page's address and the "dynamic LDS
+  // attribute set" flags belong to the device the call runs on
+  static std::atomic<const float*> zero_pages[64];
+  static std::atomic<unsigned> attr_done[64];
+  int dev = 0;
+  CRB_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return CRB_ERR_ARG;
+  const float* zero_page = zero_pages[dev].load(std::memory_order_acquire);
+  if (!zero_page) {
+    CRB_HIP(hipGetSymbolAddress((void**)&zero_page, HIP_SYMBOL(g_wgrad_zero_page)));
+    zero_pages[dev].store(zero_page, std::memory_order_release);
+  }
   WgradArgs a;
   a.x = x; a.dy = dy; a.part = (float*)workspace; a.zero = zero_page; a.affine = affine;
   a.N = N; a.H = H; a.W = W; a.cin = cin; a.cout = cout;
@@ -499,11 +510,10 @@ static int winograd2_wgrad_launch(const float* x, const float* affine, const flo
   if (g_wgrad2_mode == 3) kern = winograd2_wgrad_kernel<3>;
   if (g_wgrad2_mode == 4) kern = winograd2_wgrad_kernel<4>;
 #endif
-  if (affine) kern = winograd2_wgrad_kernel<0, true>;
-  static bool attr_done[2] = {false, false};
-  if (!attr_done[affine ? 1 : 0] || g_wgrad2_mode) {
+  const unsigned bit = 1u << (g_wgrad2_mode & 7);
+  if (!(attr_done[dev].load(std::memory_order_acquire) & bit)) {
     CRB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done[affine ? 1 : 0] = true;
+    attr_done[dev].fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.nranges * nblk)), dim3(NT), lds, (hipStream_t)stream, a);
   CRB_CHECK_LAUNCH();
@@ -519,12 +529,4 @@ static int winograd2_wgrad_launch(const float* x, const float* affine, const flo
 extern "C" int crb_winograd2_wgrad(const float* x, const float* dy, float* dw, int64_t so, int64_t si, int64_t sky, int64_t skx,
                                    int N, int H, int W, int cin, int cout, void* workspace, int64_t workspace_bytes, void* stream) {
   return winograd2_wgrad_launch(x, nullptr, dy, dw, so, si, sky, skx, N, H, W, cin, cout, workspace, workspace_bytes, stream);
-}
-
-// the same for a layer whose input was relu(scale[c] * x + shift[c]) (crb_conv3x3_winograd2_bnrelu_nhwc): affine (Cin, 2)
-extern "C" int crb_winograd2_wgrad_bnrelu(const float* x, const float* affine, const float* dy, float* dw, int64_t so, int64_t si,
-                                          int64_t sky, int64_t skx, int N, int H, int W, int cin, int cout, void* workspace,
-                                          int64_t workspace_bytes, void* stream) {
-  if (!affine) return CRB_ERR_ARG;
-  return winograd2_wgrad_launch(x, affine, dy, dw, so, si, sky, skx, N, H, W, cin, cout, workspace, workspace_bytes, stream);
 }

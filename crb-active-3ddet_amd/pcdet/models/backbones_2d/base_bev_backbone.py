@@ -179,19 +179,6 @@ class BaseBEVBackbone(nn.Module):
             if isinstance(m, nn.BatchNorm2d) and isinstance(nxt, nn.ReLU) and \
                     x.is_contiguous(memory_format=torch.channels_last) and \
                     bnrelu.supported(x.new_empty((2, x.shape[1])), m):
-                conv = mods[i + 2] if i + 2 < len(mods) else None
-                if conv is not None and m.training and m.momentum is not None and bnrelu.FUSE_RUNNING and \
-                        not bnrelu.frame_groups_active() and m.running_mean.is_contiguous() and m.running_var.is_contiguous() and \
-                        _wino_ok(conv, x) and conv.bias is None and x.shape[1] == conv.in_channels:
-                    from crbhip import winograd
-                    if winograd.BN_FUSED and winograd.WGRAD and \
-                            winograd.bnrelu_conv_supported(conv.in_channels, conv.out_channels, x.shape[2], x.shape[3]):
-                        # OPT-IN (CRB_WINOGRAD_BN=1, off by default: measured slower): BatchNorm2d -> ReLU -> Conv2d(3x3) as one
-                        # op - statistics pass, then the activation is applied inside the convolution's input transform
-                        # (forward and weight gradient) and never written
-                        x = winograd.bnrelu_conv3x3(x, m, conv.weight)
-                        i += 3
-                        continue
                 n, c, h, w_ = x.shape
                 rows = x.permute(0, 2, 3, 1).reshape(n * h * w_, c)
                 slabs = getattr(x, '_crb_bn_slabs', None)           # written by the Winograd forward kernel that produced x

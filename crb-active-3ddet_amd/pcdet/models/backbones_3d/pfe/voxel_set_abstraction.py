@@ -108,8 +108,11 @@ class VoxelSetAbstraction(nn.Module):
 
     def interpolate_from_bev_features(self, keypoints, bev_features, batch_size, bev_stride):
         """keypoints (M,4) [b,x,y,z], bev (B,C,H,W) -> (M,C); one gather over all frames"""
-        if BEV_INTERP_KERNEL and bev_features.is_cuda and bev_features.dtype == torch.float32 and bev_features.shape[1] % 4 == 0 \
-                and keypoints.dtype == torch.float32:
+        # (the kernel's backward adds with float atomics in arrival order: under torch.use_deterministic_algorithms the torch
+        # expression below - sort-based index_put in backward, bit-reproducible - is what runs)
+        det = torch.are_deterministic_algorithms_enabled() and torch.is_grad_enabled() and bev_features.requires_grad
+        if BEV_INTERP_KERNEL and not det and bev_features.is_cuda and bev_features.dtype == torch.float32 and \
+                bev_features.shape[1] % 4 == 0 and keypoints.dtype == torch.float32:
             return _BevInterpolate.apply(bev_features, keypoints.contiguous(), float(self.point_cloud_range[0]),
                                          float(self.point_cloud_range[1]), float(self.voxel_size[0]), float(self.voxel_size[1]),
                                          float(bev_stride))
@@ -197,11 +200,17 @@ class VoxelSetAbstraction(nn.Module):
             # one CU per frame is taken for the ~5 ms of the sampling: the persistent Winograd launches of the BEV backbone on the main
             # stream spread their units over the other CUs meanwhile (crb_cu_reservation; scoring at 16 frames per batch: 0.92 ->
             # 0.78 ms per convolution while the sampling runs)
-            check(lib.crb_cu_reservation(int(batch_dict['batch_size']), cur_stream(pts.device)), 'crb_cu_reservation')
+            # (only the farthest-point sampler holds CUs for milliseconds; at most a quarter of the device is announced - the kernel
+            # itself lets at most half of a launch's workgroups give way)
+            fps = self.model_cfg.get('SAMPLE_METHOD', 'FPS') == 'FPS'
+            held = min(int(batch_dict['batch_size']), torch.cuda.get_device_properties(pts.device).multi_processor_count // 4)
+            if fps:
+                check(lib.crb_cu_reservation(held, cur_stream(pts.device)), 'crb_cu_reservation')
             try:
                 kp = self.get_sampled_points(batch_dict)
             finally:                                  # (a reservation left standing costs speed only, never results)
-                check(lib.crb_cu_reservation(0, cur_stream(pts.device)), 'crb_cu_reservation')
+                if fps:
+                    check(lib.crb_cu_reservation(0, cur_stream(pts.device)), 'crb_cu_reservation')
             done = torch.cuda.Event()
             done.record(side)
         pts.record_stream(side)

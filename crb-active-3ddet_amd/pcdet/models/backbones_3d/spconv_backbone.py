@@ -52,6 +52,8 @@ class SparseBasicBlock(spconv.SparseModule):
 
 
 class _Backbone8xBase(nn.Module):
+    ACCEPTS_LAZY_VOXELS = True       # forward() reads the voxel count back together with its table plan's level sizes
+
     def _finish(self, batch_dict, out, feats):
         batch_dict.update({'encoded_spconv_tensor': out, 'encoded_spconv_tensor_stride': 8})
         batch_dict.update({'multi_scale_3d_features': dict(zip(('x_conv1', 'x_conv2', 'x_conv3', 'x_conv4'), feats))})
@@ -59,14 +61,23 @@ class _Backbone8xBase(nn.Module):
         return batch_dict
 
     def forward(self, batch_dict):
+        n_dev = batch_dict.get('voxel_count_dev', None)          # lazily voxelized batch: capacity buffers, row count on the device
+        if n_dev is not None and not PLAN_INDICES:
+            from .vfe.mean_vfe import finish_lazy_voxels
+            finish_lazy_voxels(batch_dict)
+            n_dev = None
         voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
         x = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords.int().contiguous(),
                                     spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
         if PLAN_INDICES:
-            # all rulebooks first: one host read-back for the four strided output sets instead of a sync per strided layer
+            # all rulebooks first: one host read-back for the four strided output sets instead of a sync per strided layer (and
+            # for the voxel count of a lazily voxelized batch: x is cut to its rows by the plan)
             from crbhip import bnrelu
             plan_indices([self.conv_input, self.conv1, self.conv2, self.conv3, self.conv4, self.conv_out], x,
-                         with_frame_offsets=bnrelu.active_groups() is not None)
+                         with_frame_offsets=bnrelu.active_groups() is not None, n_dev=n_dev)
+            if n_dev is not None:
+                from .vfe.mean_vfe import finish_lazy_voxels
+                finish_lazy_voxels(batch_dict, x.indices.shape[0])
         x = self.conv_input(x)
         x1 = self.conv1(x)
         x2 = self.conv2(x1)

@@ -11,6 +11,25 @@ import torch
 from crbhip import voxel as _vx
 from .vfe_template import VFETemplate
 
+# The voxel count stays on the device until the 3-D backbone's table plan reads it back together with the sizes of its strided
+# levels (one synchronisation per batch instead of two: crbhip.voxel.voxelize(lazy=True), crb_spconv_chain_mark_lazy). The batch
+# then carries the generator's CAPACITY buffers + 'voxel_count_dev'; finish_lazy_voxels() gives any earlier consumer the cut tensors.
+# Only on request of the caller ('_lazy_voxel_count' in the batch: the detector's module loop sets it when its 3-D backbone plans its
+# tables): a direct call of the module returns cut tensors as the reference's does.
+LAZY_VOXEL_COUNT = __import__('os').environ.get('CRB_LAZY_VOXEL_COUNT', '1') != '0'
+
+
+def finish_lazy_voxels(batch_dict, n=None):
+    """cut the capacity buffers of a lazily voxelized batch to their rows (n from the caller's read-back, or read it back here)"""
+    cnt = batch_dict.pop('voxel_count_dev', None)
+    if cnt is None:
+        return batch_dict
+    if n is None:
+        n = int(cnt.cpu()[0])
+    for k in ('voxel_coords', 'voxel_num_points', 'voxel_features'):
+        batch_dict[k] = batch_dict[k][:n]
+    return batch_dict
+
 
 class MeanVFE(VFETemplate):
     def __init__(self, model_cfg, num_point_features, voxel_size=None, point_cloud_range=None, grid_size=None,
@@ -39,7 +58,9 @@ class MeanVFE(VFETemplate):
         xyzf = pts[:, 1:].contiguous()
         mv = self.max_voxels['train' if self.training else 'test']
         r = _vx.voxelize(xyzf, off, self.point_cloud_range, self.voxel_size, mv, self.max_points_per_voxel,
-                         want_voxels=False, want_mean=True, grid_xyz=self.grid_size)
+                         want_voxels=False, want_mean=True, grid_xyz=self.grid_size, lazy=LAZY_VOXEL_COUNT and bool(batch_dict.get('_lazy_voxel_count', False)))
+        if r.get('pending'):
+            batch_dict['voxel_count_dev'] = r['counts_dev'][B:B + 1]
         batch_dict['voxel_coords'] = r['coords']
         batch_dict['voxel_num_points'] = r['num_points']
         batch_dict['voxel_features'] = r['mean']

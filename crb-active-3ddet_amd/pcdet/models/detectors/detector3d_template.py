@@ -43,6 +43,8 @@ class Detector3DTemplate(nn.Module):
         pfe_mod = getattr(self, 'pfe', None)
         if pfe_mod is not None and hasattr(pfe_mod, 'prefetch_keypoints'):
             pfe_mod.prefetch_keypoints(batch_dict)             # FPS on a side stream, joined inside the PFE
+        if getattr(getattr(self, 'backbone_3d', None), 'ACCEPTS_LAZY_VOXELS', False) and 'voxels' not in batch_dict:
+            batch_dict['_lazy_voxel_count'] = True             # one read-back for the voxel count + the table plan (mean_vfe.py)
         for stage in self.scheduled_modules():
             batch_dict = stage(batch_dict)
         return batch_dict

@@ -189,6 +189,8 @@ def set_arithmetic(module, arithmetic):
     SparseConvolution below `module`; returns the number of layers touched"""
     if arithmetic not in _sp.ARITHMETICS:
         raise ValueError('arithmetic must be one of %s' % (_sp.ARITHMETICS,))
+    if arithmetic == 'bf16x3':
+        _sp._bf16x3_supported(64, 64)            # (measurement library only since round 5: raises in a product process)
     n = 0
     for m in module.modules():
         if isinstance(m, SparseConvolution):
@@ -197,7 +199,7 @@ def set_arithmetic(module, arithmetic):
     return n
 
 
-def plan_indices(modules, input, with_frame_offsets=False):
+def plan_indices(modules, input, with_frame_offsets=False, n_dev=None):
     """Build the rulebooks of every (non 1x1, non inverse) SparseConvolution found in `modules` (in module order, as the
     forward pass will meet them) BEFORE the first feature kernel runs, and leave them in input.indice_dict under their
     indice_key: crbhip.sparse.build_rulebooks takes the whole chain — the output sets of all strided layers are marked and
@@ -206,7 +208,9 @@ def plan_indices(modules, input, with_frame_offsets=False):
     middle of the forward pass.
     Precondition (checked): the convs that carry a new indice_key form one linear chain starting at `input` — every strided
     conv consumes the output set of the strided conv before it. A tensor on which some of the strided keys already exist
-    is left alone: the forward pass then builds what is missing layer by layer."""
+    is left alone: the forward pass then builds what is missing layer by layer.
+    n_dev (1,) i32 cuda: input.features / input.indices are the voxel generator's capacity buffers and the row count is still on
+    the device; the chain's read-back returns it and the tensor is cut to its rows here (input.indices.shape[0] afterwards)."""
     convs = []
     for root in modules:
         for m in root.modules():
@@ -214,8 +218,16 @@ def plan_indices(modules, input, with_frame_offsets=False):
                     m.indice_key is not None:
                 convs.append(m)
     have = [m.indice_key in input.indice_dict for m in convs if not m.subm]
+
+    def cut(n):
+        input.indices = input.indices[:n]
+        input.features = input.features[:n]
+        return n
     if any(have) and not all(have):
-        return input                              # partially planned tensor: no assumption about where the chain stands
+        # partially planned tensor: no assumption about where the chain stands
+        if n_dev is not None:
+            cut(int(n_dev.cpu()[0]))
+        return input
     specs, todo, seen = [], [], set(input.indice_dict.keys())
     shape = list(input.spatial_shape)
     geom_of = {}
@@ -236,11 +248,17 @@ def plan_indices(modules, input, with_frame_offsets=False):
                 todo.append(key)
         if not m.subm:
             shape = _sp.conv_out_shape(shape, g[1], g[2], g[3])
+    n_rows = None
     if specs and not (have and all(have)):
         books = _sp.build_rulebooks(input.indices, list(input.spatial_shape), input.batch_size, specs,
-                                    want_grad=torch.is_grad_enabled())
+                                    want_grad=torch.is_grad_enabled(), n_dev=n_dev)
+        if n_dev is not None:
+            books, n_rows = books
+            cut(n_rows)
         for key, rb in zip(todo, books):
             input.indice_dict[key] = rb
+    elif n_dev is not None:
+        n_rows = cut(int(n_dev.cpu()[0]))
     # (all strided keys present, SubM keys missing: each is built on its level by the forward pass)
     if with_frame_offsets:
         # rows per frame of the input and of every strided level (sparse rows are frame-sorted): ONE read-back. Used by the

@@ -98,7 +98,9 @@ int crb_nbr_permute(const int32_t* nbr, const int32_t* perm, int64_t n, int K, i
  * perm[i] of nbr; perm NULL = identity), cbase (n+1) i32 = exclusive prefix of the masks' popcounts, packed (>= cbase[n],
  * caller allocates n*K) = the present neighbour indices row after row, offsets ascending. 8 + 4 P/n bytes per row instead
  * of 4 K. crb_sparse_conv_forward_compact is crb_sparse_conv_forward on that table (bit-identical results); shapes for
- * which crb_sparse_conv_compact_supported() is 0 keep the (n,K) table. */
+ * which crb_sparse_conv_compact_supported() is 0 keep the (n,K) table. Supported: the phase kernel's shapes (Cin, Cout multiples of
+ * 16, Cin <= 64) and, since round 4, the low-channel forward instance (Cin, Cout) = (4, 16) of the KITTI input layer (a wave owns a
+ * 16-row tile end to end). */
 int crb_sparse_conv_compact_supported(int cin, int cout);
 int64_t crb_nbr_compact_workspace_bytes(int64_t n);
 int crb_nbr_compact(const int32_t* nbr, const int32_t* perm, int64_t n, int K, uint32_t* cmask, int32_t* cbase,
@@ -124,6 +126,13 @@ int64_t crb_spconv_padded_words(int B, const int32_t* out_shape_dhw);
 int crb_spconv_chain_mark(const int32_t* coords, int64_t n, int B, const int32_t* in_shape_dhw, int n_levels,
                           const int32_t* geoms, const int32_t* out_shapes, const int64_t* word_off, uint32_t* bitmap_all,
                           int32_t* tile_sums_all, int32_t* counts_dev, void* stream);
+/* the same with the input row count still on the device: coords holds n_cap rows of which the first *n_dev are valid (the voxel
+ * generator's coordinate buffer and its total, crb_voxelize's counts[B]). The chain is marked and counted before the host knows
+ * the voxel count; ONE read-back then returns it together with the level sizes (the reference path synchronises twice here:
+ * Point2VoxelCPU3d returns host arrays, spconv's indice generation returns host-side counts per strided layer). */
+int crb_spconv_chain_mark_lazy(const int32_t* coords, int64_t n_cap, const int32_t* n_dev, int B, const int32_t* in_shape_dhw,
+                               int n_levels, const int32_t* geoms, const int32_t* out_shapes, const int64_t* word_off,
+                               uint32_t* bitmap_all, int32_t* tile_sums_all, int32_t* counts_dev, void* stream);
 int crb_spconv_chain_emit(int B, int n_levels, const int32_t* out_shapes, const int64_t* word_off,
                           const uint32_t* bitmap_all, const int32_t* tile_sums_all, void* rank_all,
                           int32_t* const* out_coords, const int64_t* n_out, void* stream);
@@ -184,22 +193,6 @@ int crb_sparse_conv_forward_compact_bn(const float* X, const float* W, const uin
                                        const float* running_mean, const float* running_var, float eps, int relu,
                                        void* stream);
 
-/* OPT-IN arithmetic contract "bf16x3" for the same gather-GEMM (exact f32 above stays the default): every operand is split
- * into two bf16 values, x = x_hi + x_lo (+ a residual <= 2^-18 |x|), and a product is taken as x_lo*w_hi + x_hi*w_lo +
- * x_hi*w_hi on the bf16 MFMA (products exact, f32 accumulation; x_lo*w_lo dropped). Stated bound, checked by
- * tests/test_spconv_gpu.py: |y - y_exact| <= 2^-16 * sum |x||w| over the gathered products of the output element (plus
- * f32 accumulation error). bf16 keeps the f32 exponent range: no scaling, no overflow case of its own. Model-level reading
- * (tests/test_second_gpu.py): a SECOND training step reproduces the f32 loss to 2e-6 and the dense-head gradients to 4e-5,
- * the weight gradients of the sparse backbone — sums that cancel to ~1e-3 of their terms — to 1-4 % of their largest entry. Needs the compact
- * table of crb_nbr_compact; workspace >= crb_sparse_conv_bf16x3_workspace_bytes (holds the split copy of W). n_in = rows of
- * X (the gathers are bounds-checked buffer loads; n_in*cin*4 must stay below 2^31).
- * No reference counterpart: spconv-cu113 v2.1.21 multiplies in f32 (or fp16 under AMP, which the reference does not use). */
-int crb_sparse_conv_bf16x3_supported(int cin, int cout);
-int64_t crb_sparse_conv_bf16x3_workspace_bytes(int K, int cin, int cout);
-int crb_sparse_conv_forward_bf16x3(const float* X, const float* W, const uint32_t* cmask, const int32_t* cbase,
-                                   const int32_t* packed, const int32_t* perm, const int32_t* tile_order, float* Y,
-                                   int64_t n_in, int64_t n_out, int K, int cin, int cout, void* workspace,
-                                   int64_t workspace_bytes, void* stream);
 int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, const int32_t* perm, float* Y,
                             int64_t n_out, int K, int cin, int cout, void* stream);
 /* dW (K,cin,cout) = sum over pairs X[pin]^T dY[pout] */
@@ -529,25 +522,17 @@ int crb_rpn_loss_backward(const float* cls_preds, const float* box_preds, const 
                           const float* npos, const float* grad_loss, float* d_cls, float* d_box, float* d_dir, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * a7 (stretch)  3x3 stride-1 pad-1 convolution on channels_last maps as Winograd F(2x2,3x3) on the f32 MFMA
+ * a7  3x3 stride-1 pad-1 convolution on channels_last maps as Winograd F(2x2,3x3) on the f32 MFMA (csrc/winograd_conv2.hip)
  * replaces: torch.nn.Conv2d(C, C, 3, padding=1) of the BEV backbone (pcdet/models/backbones_2d/base_bev_backbone.py:24-41;
- *           cuDNN in the reference, MIOpen's f32 implicit GEMM here) for the stride-1 layers whose channel counts pass
- *           crb_winograd_supported (Cin % 32 == 0, Cout % 128 == 0). OPT-IN on the Python side: results differ from a direct
- *           convolution by f32 rounding of the transforms (<= 1e-5 of the output scale on unit-scale data, tested).
- * x (N,H,W,Cin) f32 NHWC, y (N,H,W,Cout); weights first through crb_winograd_weights: g (3,3,Cin,Cout) [ky][kx][ci][co]
- * -> U (16,Cin,Cout) (crb_winograd_weights_bytes). The input gradient of the same layer is the same call on dy with
- * g'[ky][kx][co][ci] = w[co][ci][2-ky][2-kx]. bias (Cout) or NULL, relu 0/1: epilogue on the output. */
-int crb_winograd_supported(int cin, int cout);
-int64_t crb_winograd_weights_bytes(int cin, int cout);
-int crb_winograd_weights(const float* g, float* U, int cin, int cout, void* stream);
-int crb_conv3x3_winograd_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
-                              const float* bias, int relu, void* stream);
-
-/* a7, second design (round 4): the same convolution with two waves per SIMD (128 accumulators each), the raw input block and
- * the weight block brought into LDS by LDS-DMA once per workgroup and chunk, the input transform read from LDS; workgroup =
- * 16 x 4 tiles of one spatial block x 64 output channels (csrc/winograd_conv2.hip). Same operands as above except the weight
- * image: crb_winograd2_weights writes U in the order the kernel's LDS-DMA copies it ([Cout/64][Cin/8][LDS image of a chunk]),
- * crb_winograd2_weights_bytes floats*4. crb_winograd2_supported: Cin % 8 == 0, Cout % 64 == 0, H >= 5. */
+ *           MIOpen's f32 implicit GEMM on this stack). 2.25x fewer multiplications than the direct convolution, results equal to
+ *           it up to f32 rounding of the transforms (4e-7 of the output scale against an f64 convolution).
+ * x (N,H,W,Cin) f32 NHWC, y (N,H,W,Cout); bias (Cout) or NULL, relu 0/1: epilogue on the output. The input gradient of the same
+ * layer is the same call on dy with the flipped, transposed weights. Two waves per SIMD (128 accumulators each), the raw input
+ * block and the weight block brought into LDS by LDS-DMA once per workgroup and chunk, the input transform read from LDS;
+ * workgroup = 16 x 4 tiles of one spatial block x 64 output channels. Weight image: crb_winograd2_weights writes U in the order
+ * the kernel's LDS-DMA copies it ([Cout/64][Cin/8][LDS image of a chunk]), crb_winograd2_weights_bytes floats*4.
+ * crb_winograd2_supported: Cin % 8 == 0, Cout % 64 == 0, H >= 5. (The first design of round 3, crb_conv3x3_winograd_nhwc, lives in
+ * the measurement library: include/crb_hip_measure.h.) */
 int crb_winograd2_supported(int cin, int cout, int H, int W);
 int64_t crb_winograd2_weights_bytes(int cin, int cout);
 int crb_winograd2_weights(const float* g, float* U, int cin, int cout, void* stream);
@@ -558,15 +543,26 @@ int crb_winograd2_weights_conv(const float* w, int64_t so, int64_t si, int64_t s
                                int conv_cout, int mode, void* stream);
 int crb_conv3x3_winograd2_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
                                const float* bias, int relu, void* stream);
+/* Round 5: the launch is one workgroup per CU over a FIXED decomposition of the units (16 x 4 tiles x 64 output channels): every
+ * workgroup takes units / CUs whole units; the units that are left over (a whole extra round for a fraction of a round's work)
+ * are split along the INPUT channels into S parts, one part per workgroup, partial outputs in `workspace`, added in part order
+ * by the workgroup that arrives last at the unit's counter (deterministic; those units sum their input channels in another
+ * order than the call without a workspace). workspace: crb_winograd2_workspace_bytes() bytes on the current device, ZERO
+ * before its first use (every launch leaves the counters zero), not shared by launches that may run concurrently (one per
+ * stream). Results do not depend on crb_cu_reservation. */
+int64_t crb_winograd2_workspace_bytes(void);
+int crb_conv3x3_winograd2_ws_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
+                                  const float* bias, int relu, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* training forward that also hands the following BatchNorm its statistics: stats (crb_winograd2_stats_slabs(N,H,W), 2, Cout) f32 =
  * column sums of y and y^2 per slab of outputs (a slab = half of the 64 tiles of one 16 x 4-tile spatial block; outputs outside
  * the map are not counted), every slab written exactly once, no atomics. Feed them to crb_bn_relu_forward_partials(y, N*H*W,
  * Cout, stats, slabs, ...): the BatchNorm's own statistics pass over y (pcdet/models/backbones_2d/base_bev_backbone.py:31-41,
- * nn.BatchNorm2d in training mode) is not launched. No bias, no ReLU (the Conv2d layers of the backbone have neither). */
+ * nn.BatchNorm2d in training mode) is not launched. No bias, no ReLU (the Conv2d layers of the backbone have neither).
+ * workspace: as crb_conv3x3_winograd2_ws_nhwc (NULL = tail units not split). */
 int64_t crb_winograd2_stats_slabs(int N, int H, int W);
 int crb_conv3x3_winograd2_stats_nhwc(const float* x, const float* U, float* y, float* stats, int N, int H, int W, int cin, int cout,
-                                     void* stream);
+                                     void* workspace, int64_t workspace_bytes, void* stream);
 
 /* a7 backward: weight gradient of the same convolution in the Winograd domain (csrc/winograd_wgrad.hip):
  * dU[xi][ci][co] = sum over tiles of (B^T d B)[xi][ci] * (A dY A^T)[xi][co] as 16 MFMA GEMMs whose two operands are both
@@ -581,26 +577,12 @@ int64_t crb_winograd2_wgrad_workspace_bytes(int cin, int cout);
 int crb_winograd2_wgrad(const float* x, const float* dy, float* dw, int64_t so, int64_t si, int64_t sky, int64_t skx,
                         int N, int H, int W, int cin, int cout, void* workspace, int64_t workspace_bytes, void* stream);
 
-/* a7, training: Conv2d(3x3, padding 1) applied to relu(BatchNorm(x)) of the PREVIOUS layer without storing that activation:
- * the three modules `nn.BatchNorm2d -> nn.ReLU -> nn.Conv2d` of one `blocks[k]` Sequential
- * (pcdet/models/backbones_2d/base_bev_backbone.py:31-41) as one forward launch. affine (Cin, 2) = (scale, shift) per input
- * channel from crb_bn_affine_table (batch statistics of x: crb_bn_relu_forward with z == NULL). The input transform computes
- * relu(scale * x + shift) on the values it reads and zeroes the patch positions outside the map (zero padding is applied to
- * the ACTIVATED map, as nn.Conv2d(padding=1) after nn.ReLU does). crb_winograd2_wgrad_bnrelu is the weight gradient of that
- * layer: its V transform applies the same activation to x. The input gradient is crb_conv3x3_winograd2_nhwc on the flipped
- * weights as before (it is the gradient with respect to the activated map; BatchNorm + ReLU backward follows:
- * crb_bn_relu_backward on x). Same shape limits as the plain entry points. */
-int crb_conv3x3_winograd2_bnrelu_nhwc(const float* x, const float* affine, const float* U, float* y, int N, int H, int W,
-                                      int cin, int cout, const float* bias, int relu, void* stream);
-int crb_winograd2_wgrad_bnrelu(const float* x, const float* affine, const float* dy, float* dw, int64_t so, int64_t si,
-                               int64_t sky, int64_t skx, int N, int H, int W, int cin, int cout, void* workspace,
-                               int64_t workspace_bytes, void* stream);
-
 /* Scheduling hint, no reference counterpart: PV-RCNN's keypoint sampling (crb_furthest_point_sampling_stack on a side stream under
  * the backbones) holds one CU per frame for ~5 ms while the persistent one-workgroup-per-CU Winograd launches of the BEV backbone
  * run on the main stream. crb_cu_reservation(cus, stream) right before such a kernel, crb_cu_reservation(0, stream) right after it
  * (same stream: two one-thread launches): the Winograd forward launches in between spread their units over (CUs - cus)
- * workgroups instead of leaving `cus` workgroups queued behind the taken CUs. Results do not depend on it. */
+ * workgroups instead of leaving `cus` workgroups queued behind the taken CUs (at most half of a launch's workgroups give way).
+ * Results do not depend on it. */
 int crb_cu_reservation(int cus, void* stream);
 
 /* a19: bilinear lookup of the BEV feature map at the keypoints.

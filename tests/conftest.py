@@ -28,3 +28,12 @@ def pytest_collection_modifyitems(config, items):
 def dev():
     import torch
     return torch.device('cuda', 0)
+
+
+def require_measure_lib():
+    """kernels that live in the measurement library only (first Winograd design, split-bf16 gather-GEMM): their tests run in a
+    process that loaded libcrbhip_measure.so (CRB_MEASURE_LIB=1 before importing crbhip) - see
+    tests/test_measure_lib_gpu.py, which starts that process; in the normal test process they are skipped"""
+    import crbhip
+    if not crbhip._lib.MEASURE:
+        pytest.skip('measurement-library kernel: covered by tests/test_measure_lib_gpu.py in its own process')

@@ -59,6 +59,38 @@ def test_all_gather_rows_two_ranks_gloo(n):
         np.testing.assert_array_equal(full, exp)          # every rank holds the whole pool in dataset order
 
 
+@pytest.mark.parametrize('n', [3000, 2999, 5])
+def test_all_gather_rows_eight_ranks_gloo(n):
+    """BASELINE configs[3] at its real rank count: 8 ranks, the 3,000-frame pool (375 frames per rank, no padding), a pool that does
+    not divide (2,999: one wrap-around duplicate, dropped after the gather - pcdet/datasets/__init__.py:40), and a pool smaller
+    than the world (5 frames on 8 ranks: three ranks score only wrap-around frames). Every rank ends with the whole pool in dataset
+    order; the shard of rank r is r, r + 8, ... exactly as the reference's eval DistributedSampler deals the frames."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'crb-active-3ddet_amd'))
+    from pcdet.query_strategies import scoring
+    world = 8
+    per = (n + world - 1) // world
+    seen = []
+    for r in range(world):
+        idx, p = scoring.shard_indices(n, r, world)
+        assert p == per and len(idx) == per
+        assert idx == [(r + k * world) if (r + k * world) < n else (r + k * world) - n for k in range(per)]
+        seen += idx
+    assert sorted(set(seen)) == list(range(n))                       # every frame is scored by some rank
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + n) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    exp = np.array([[i, 2 * i + 1] for i in range(n)], np.float32)
+    assert sorted(r for r, _ in res) == list(range(world))
+    for rank, full in res:
+        np.testing.assert_array_equal(full, exp)
+
+
 def test_density_prior_matches_reference_formula():
     from pcdet.query_strategies import scoring
     rng = np.random.default_rng(0)

@@ -202,6 +202,11 @@ def test_bench_two_rank_dry_run_prints_the_contract_line(tmp_path):
     assert d['config']['global_batch'] == 32 and d['config']['parallelism'] == 'dp2'
     assert abs(d['value'] - 32 * 2 / (d['ms_per_step'] * 2 / 1e3)) < 1e-2 * d['value']
     assert len(d['ms_per_step_device_per_rank']) == 2 and all(v > 0 for v in d['ms_per_step_device_per_rank'])
+    assert len(d['ms_per_step_per_rank']) == 2 and all(0 < v <= 1.05 * d['ms_per_step'] for v in d['ms_per_step_per_rank'])
+    # the headline numbers sit at the head of the line and again at its very end (a log tail keeps the end)
+    assert list(d.keys())[-1] == 'summary' and d['summary'] == d['headline']
+    assert d['summary']['second_frames_per_s'] == d['value'] and abs(d['summary']['frames_per_s_per_gpu'] * 2 - d['value']) < 1e-2
+    assert d['summary']['crb_scoring_frames_per_s'] == d['crb_scoring']['value']
     sc = d['crb_scoring']
     assert sc['config']['frames_per_gpu'] == pool // 2 and sc['config']['pool_frames'] == pool and sc['config']['n_gpus'] == 2
     assert len(sc['per_rank_seconds']['loader_pass']) == 2

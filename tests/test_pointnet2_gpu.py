@@ -538,3 +538,51 @@ def test_bev_interpolation_kernel_equals_the_torch_expression(dev):
     assert torch.equal(outs[True][0], outs[False][0])
     err = float((outs[True][1] - outs[False][1]).abs().max() / outs[False][1].abs().max())
     assert err < 1e-5, err
+
+
+@pytest.mark.gpu
+def test_bev_interpolation_ignores_rows_of_no_frame_and_honours_deterministic_mode(dev):
+    """a keypoint row whose frame index is outside [0, B) (a padded row) reads nothing - its output is zero - and adds
+    nothing to the map gradient (the round-4 kernel indexed the map with it); under torch.use_deterministic_algorithms the
+    sort-based torch path runs (bit-reproducible map gradient) instead of the kernel's float atomics"""
+    from pcdet.models.backbones_3d.pfe import voxel_set_abstraction as vsa
+    torch.manual_seed(5)
+    B, C, H, W, M = 2, 32, 25, 22, 600
+    bev = torch.randn(B, C, H, W, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    kp = torch.empty(M, 4, device=dev)
+    kp[:, 0] = torch.randint(0, B, (M,), device=dev).float()
+    kp[:, 1] = torch.rand(M, device=dev) * 70.4
+    kp[:, 2] = torch.rand(M, device=dev) * 80.0 - 40.0
+    kp[:, 3] = 0.0
+    bad = torch.tensor([3, 77, 401], device=dev)
+    kp2 = kp.clone()
+    kp2[bad, 0] = torch.tensor([-1.0, float(B), 1000.0], device=dev)
+
+    class Host(object):
+        point_cloud_range, voxel_size = [0.0, -40.0, -3.0, 70.4, 40.0, 1.0], [0.05, 0.05, 0.1]
+    stride = 8 * (70.4 / 0.05 / 8 / W)
+    g = torch.randn(M, C, device=dev)
+    out = vsa.VoxelSetAbstraction.interpolate_from_bev_features(Host(), kp2, bev, B, stride)
+    (out * g).sum().backward()
+    grad_bad = bev.grad.clone()
+    assert float(out[bad].abs().max()) == 0.0
+    keep = torch.ones(M, dtype=torch.bool, device=dev)
+    keep[bad] = False
+    bev.grad = None
+    out_ok = vsa.VoxelSetAbstraction.interpolate_from_bev_features(Host(), kp[keep], bev, B, stride)
+    (out_ok * g[keep]).sum().backward()
+    assert torch.equal(out[keep], out_ok)
+    assert float((grad_bad - bev.grad).abs().max()) <= 1e-5 * float(bev.grad.abs().max())
+    # deterministic mode: the torch path, twice the same bits
+    grads = []
+    torch.use_deterministic_algorithms(True)
+    try:
+        for _ in range(2):
+            bev.grad = None
+            o = vsa.VoxelSetAbstraction.interpolate_from_bev_features(Host(), kp, bev, B, stride)
+            assert not isinstance(o.grad_fn, vsa._BevInterpolate._backward_cls)
+            (o * g).sum().backward()
+            grads.append(bev.grad.clone())
+    finally:
+        torch.use_deterministic_algorithms(False)
+    assert torch.equal(grads[0], grads[1])

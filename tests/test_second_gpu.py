@@ -228,6 +228,8 @@ def test_second_step_under_the_bf16x3_contract_stays_close_to_f32(dev):
     (measured 1.4e-2 .. 3.5e-2): they are sums over ~10^5 rows that cancel to ~10^-3 of their terms (BatchNorm makes the
     loss invariant to the scale and shift of every conv output), so a 2^-17 perturbation of the activations shows up ~100x
     larger there, the same factor by which it exceeds f32's own 2^-24 rounding. That is what the contract costs."""
+    from conftest import require_measure_lib
+    require_measure_lib()
     import spconv.pytorch as spconv
     from pcdet.datasets import SyntheticDataset
     from pcdet.model_cfgs import second_cfg
@@ -260,3 +262,42 @@ def test_second_step_under_the_bf16x3_contract_stays_close_to_f32(dev):
     for n, a, b in zip(names, res['f32'][1], res['bf16x3'][1]):
         tol = 1e-3 if n.startswith('dense_head') else 5e-2
         assert float((a - b).abs().max()) <= tol * float(a.abs().max()), (n, float((a - b).abs().max()), float(a.abs().max()))
+
+
+def test_lazy_voxel_count_gives_the_same_step_with_one_read_back_less(dev, monkeypatch):
+    """the detector's module loop leaves the voxel count on the device (crb_voxelize, lazy) until the 3-D
+    backbone's table plan reads it back together with the sizes of its strided levels (crb_spconv_chain_mark_lazy): same tables,
+    same loss, same gradients, bit for bit, and one host synchronisation per batch instead of two in the sparse phase."""
+    import warnings
+    from pcdet.datasets import SyntheticDataset
+    from pcdet.model_cfgs import second_cfg
+    from pcdet.models import build_network
+    from pcdet.models.backbones_3d.vfe import mean_vfe
+    torch.manual_seed(0)
+    model = build_network(second_cfg().MODEL, 3, SyntheticDataset(num_frames=2)).to(dev).train()
+    pts, off, gt = kitti_batch(3, 2)
+    res = {}
+    for lazy in (False, True):
+        monkeypatch.setattr(mean_vfe, 'LAZY_VOXEL_COUNT', lazy)
+        model.zero_grad(set_to_none=True)
+        b = _dev_batch(dev, pts, off, gt)
+        torch.cuda.synchronize()
+        syncs = []
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter('always')
+            torch.cuda.set_sync_debug_mode('warn')
+            try:
+                bd = model.vfe(dict(b, _lazy_voxel_count=True))
+                n_cap = bd['voxel_coords'].shape[0]
+                bd = model.backbone_3d(bd)
+            finally:
+                torch.cuda.set_sync_debug_mode('default')
+            syncs = [w for w in rec if 'synchroniz' in str(w.message).lower()]
+        assert 'voxel_count_dev' not in bd and bd['voxel_coords'].shape[0] == bd['voxel_features'].shape[0] <= n_cap
+        ret, tb, _ = model(_dev_batch(dev, pts, off, gt))
+        ret['loss'].backward()
+        res[lazy] = (len(syncs), bd['voxel_coords'].clone(), bd['encoded_spconv_tensor'].features.detach().clone(),
+                     float(ret['loss'].detach()), model.backbone_3d.conv_input[0].weight.grad.clone())
+    assert res[True][0] == 1 and res[True][0] < res[False][0], (res[True][0], res[False][0])     # (one blocking copy: the merged read-back)
+    assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
+    assert res[True][3] == res[False][3] and torch.equal(res[True][4], res[False][4])

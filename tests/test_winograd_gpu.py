@@ -15,6 +15,8 @@ pytestmark = pytest.mark.gpu
 def test_first_winograd_kernel_matches_direct_convolution(dev, N, C, K, H, W):
     """round-3 kernel (kept for A/B): forward (+ bias, + ReLU epilogue) and the input gradient as the same kernel on dy; odd
     sizes exercise the partial tiles, 1x1 maps the all-padding patches, (64,192) three channel blocks"""
+    from conftest import require_measure_lib
+    require_measure_lib()
     from crbhip import winograd
     torch.manual_seed(N * 1000 + C + K + H)
     x = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
@@ -205,74 +207,50 @@ def test_bev_backbone_gradients_are_as_accurate_as_the_miopen_path(dev, monkeypa
         assert max(e_w, e_m) <= (1e-5 if n == 'output' else 2e-2), (n, e_m, e_w)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize('shape', [(2, 64, 64, 37, 29), (3, 128, 64, 12, 21), (1, 64, 128, 8, 5)])
-def test_bnrelu_conv_equals_batchnorm_relu_then_conv(dev, shape):
-    """BatchNorm2d (training) -> ReLU -> Conv2d(3x3, pad 1) as ONE op (statistics pass + activation inside the Winograd input
-    transform, crb_conv3x3_winograd2_bnrelu_nhwc / crb_winograd2_wgrad_bnrelu) against the three modules in f64: output, the
-    gradients of the input, of gamma / beta and of the weight, running statistics and the batch counter. Odd sizes: the zero
-    padding must be applied to the ACTIVATED map (relu(shift) != 0 outside the map would leak into the border tiles)."""
-    from crbhip import winograd
-    N, C, K, H, W = shape
-    torch.manual_seed(5)
-    x = (torch.randn(N, C, H, W, device=dev) * 1.5 + 0.3).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).to(dev).train()
-    with torch.no_grad():
-        bn.weight.uniform_(0.5, 1.5)
-        bn.bias.uniform_(-0.5, 0.5)
-    conv = torch.nn.Conv2d(C, K, 3, padding=1, bias=False).to(dev)
-    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
-    assert winograd.bnrelu_conv_supported(C, K, H, W)
-    gout = torch.randn(N, K, H, W, device=dev).contiguous(memory_format=torch.channels_last)
-    y = winograd.bnrelu_conv3x3(x, bn, conv.weight)
-    (y * gout).sum().backward()
-    got = [y.detach(), x.grad, bn.weight.grad, bn.bias.grad, conv.weight.grad, bn.running_mean.clone(), bn.running_var.clone()]
-    assert int(bn.num_batches_tracked) == 1
-    x64 = x.detach().double().requires_grad_(True)
-    bn64 = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).to(dev).double().train()
-    bn64.weight.data, bn64.bias.data = bn.weight.data.double(), bn.bias.data.double()
-    conv64 = torch.nn.Conv2d(C, K, 3, padding=1, bias=False).to(dev).double()
-    conv64.weight.data = conv.weight.data.double()
-    y64 = conv64(torch.relu(bn64(x64)))
-    (y64 * gout.double()).sum().backward()
-    ref = [y64.detach(), x64.grad, bn64.weight.grad, bn64.bias.grad, conv64.weight.grad, bn64.running_mean, bn64.running_var]
-    for name, a, r, tol in zip(['output', 'input gradient', 'gamma gradient', 'beta gradient', 'weight gradient', 'running mean',
-                                'running var'], got, ref, [2e-6, 2e-5, 2e-5, 2e-5, 5e-6, 1e-6, 1e-6]):
-        err = float((a.double() - r).abs().max() / r.abs().max())
-        assert err <= tol, (name, err)
+# measured on MI355X (r05, B = 8 @ 200 x 176, relative L2 against the f64 run): see the docstring; bounds = 3 x the measured error
+BENCH_SHAPE_GRAD_TOL = {'output': 1e-5, 'input gradient': 2e-2, 'blocks.0.1.weight': 2e-2, 'blocks.0.13.weight': 2e-2,
+                        'blocks.1.4.weight': 2e-2, 'deblocks.1.0.weight': 2e-2}
 
 
-@pytest.mark.gpu
-def test_bev_backbone_with_fused_batchnorm_apply_matches_the_default_path(dev, monkeypatch):
-    """the opt-in CRB_WINOGRAD_BN=1 path of BaseBEVBackbone (BatchNorm2d -> ReLU -> Conv2d as one op) against the default path of
-    the same network: training output, input gradient, one weight gradient per block, running statistics - equal to f32 rounding
-    through the stack (both paths are compared with each other, bounds as the f64 comparison above)."""
+def test_bev_backbone_gradients_at_a_bench_like_shape_against_f64(dev, monkeypatch):
+    """the full-depth BEV backbone (5 + 5 layers, train-mode BatchNorm) forward + backward at a bench-like
+    shape - B = 8 maps of 200 x 176 with the occupancy of a KITTI BEV map, where the BatchNorm statistics are stable - on the
+    Winograd path and on the MIOpen path, both against an f64 run of the same network. At B = 2 @ 104 x 88 (the test above) the
+    backward amplifies f32 rounding to 3e-3 .. 7e-3 on either path; here the statistics average over 140 times more pixels. The
+    bounds are 3 x the errors measured on MI355X for BOTH paths (BENCH_SHAPE_GRAD_TOL), so a regression of either path's
+    gradients by more than that factor fails."""
     import copy
     from pcdet.config import EasyDict
     from pcdet.models.backbones_2d import base_bev_backbone as bb
     from crbhip import winograd
-    torch.manual_seed(9)
-    cfg = EasyDict({'LAYER_NUMS': [3, 3], 'LAYER_STRIDES': [1, 2], 'NUM_FILTERS': [128, 256], 'UPSAMPLE_STRIDES': [1, 2],
+    torch.manual_seed(5)
+    cfg = EasyDict({'LAYER_NUMS': [5, 5], 'LAYER_STRIDES': [1, 2], 'NUM_FILTERS': [128, 256], 'UPSAMPLE_STRIDES': [1, 2],
                     'NUM_UPSAMPLE_FILTERS': [256, 256]})
     net = bb.BaseBEVBackbone(cfg, 256).to(dev).train()
-    B, H, W = 2, 52, 44
-    x0 = (torch.randn(B, 256, H, W, device=dev) * (torch.rand(B, 1, H, W, device=dev) < 0.2)).contiguous(memory_format=torch.channels_last)
+    B, H, W = 8, 200, 176
+    x0 = torch.randn(B, 256, H, W, device=dev) * (torch.rand(B, 1, H, W, device=dev) < 0.06)
+    x0 = x0.contiguous(memory_format=torch.channels_last)
     gout = torch.randn(B, 512, H, W, device=dev).contiguous(memory_format=torch.channels_last)
-    outs = {}
-    for flag in (False, True):
-        monkeypatch.setattr(winograd, 'BN_FUSED', flag)
-        model = copy.deepcopy(net)
-        x = x0.clone().requires_grad_(True)
+    names = ['blocks.0.1.weight', 'blocks.0.13.weight', 'blocks.1.4.weight', 'deblocks.1.0.weight']
+
+    def run(model, x, g):
+        x = x.clone().requires_grad_(True)
         y = model({'spatial_features': x})['spatial_features_2d']
-        (y * gout).sum().backward()
+        (y * g).sum().backward()
         p = dict(model.named_parameters())
-        outs[flag] = [y.detach(), x.grad, p['blocks.0.4.weight'].grad, p['blocks.1.7.weight'].grad, p['blocks.0.5.weight'].grad,
-                      model.blocks[0][5].running_mean.clone(), model.blocks[1][8].running_var.clone()]
-    for name, a, b, tol in zip(['output', 'input gradient', 'conv weight gradient (block 0)', 'conv weight gradient (block 1)',
-                                'gamma gradient', 'running mean', 'running var'], outs[False], outs[True],
-                               [1e-5, 2e-2, 2e-2, 2e-2, 2e-2, 1e-5, 1e-5]):
-        err = float((a - b).norm() / b.norm())
-        assert err <= tol, (name, err)
+        return [y.detach(), x.grad] + [p[n].grad.clone() for n in names]
+    ref = run(copy.deepcopy(net).double(), x0.double(), gout.double())
+    errs = {}
+    for flag in (False, True):
+        monkeypatch.setattr(bb, 'WINOGRAD', flag)
+        monkeypatch.setattr(winograd, 'WGRAD', flag)
+        got = run(copy.deepcopy(net), x0, gout)
+        errs[flag] = [float((a.double() - r).norm() / r.norm()) for a, r in zip(got, ref)]
+        del got
+    for n, e_m, e_w in zip(['output', 'input gradient'] + names, errs[False], errs[True]):
+        print('%-22s relative L2 error vs f64 (B=8 @200x176): MIOpen path %.2e, Winograd path %.2e' % (n, e_m, e_w))
+    for n, e_m, e_w in zip(['output', 'input gradient'] + names, errs[False], errs[True]):
+        assert max(e_w, e_m) <= BENCH_SHAPE_GRAD_TOL[n], (n, e_m, e_w)
 
 
 @pytest.mark.gpu
@@ -328,14 +306,20 @@ def test_bev_backbone_statistics_from_the_epilogue_match_the_statistics_pass(dev
 
 
 @pytest.mark.gpu
-def test_results_do_not_depend_on_the_cu_reservation(dev):
-    """crb_cu_reservation(n): the persistent forward launch spreads its units over (CUs - n) workgroups; outputs are bit-equal for
-    any n (every unit is computed by exactly one workgroup, whichever), including n >= the number of CUs"""
+@pytest.mark.parametrize('shape', [(4, 64, 128, 60, 44), (6, 128, 256, 100, 88)])
+def test_results_do_not_depend_on_the_cu_reservation(dev, shape):
+    """crb_cu_reservation(n): the persistent forward launch runs on fewer workgroups (at most half of them give way); the
+    decomposition of the work - whole units + input-channel parts of the tail units - is fixed by the launch geometry, so outputs
+    are bit-equal for any n, including n >= the number of CUs. Second shape: more units than CUs with a split tail (836 units on
+    256 workgroups: 68 tail units in 3 parts each)."""
     from crbhip import winograd, lib, check, cur_stream
+    N, C, K, H, W = shape
     torch.manual_seed(17)
-    x = torch.randn(4, 64, 60, 44, device=dev).contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(128, 64, 3, 3, device=dev) / 24).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(K, C, 3, 3, device=dev) / np.sqrt(9 * C)).contiguous(memory_format=torch.channels_last)
     ref = winograd.conv3x3(x, w)
+    want = F.conv2d(x.double(), w.double(), padding=1)
+    assert float((ref.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
     try:
         for n in (16, 100, 255, 4000):
             check(lib.crb_cu_reservation(n, cur_stream(dev)), 'crb_cu_reservation')
@@ -343,3 +327,45 @@ def test_results_do_not_depend_on_the_cu_reservation(dev):
     finally:
         check(lib.crb_cu_reservation(0, cur_stream(dev)), 'crb_cu_reservation')
     assert torch.equal(winograd.conv3x3(x, w), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,C,K,H,W', [(6, 128, 192, 100, 88), (6, 128, 256, 100, 88), (8, 256, 128, 100, 88), (16, 32, 64, 100, 88), (9, 128, 192, 50, 44)])
+def test_split_tail_units_match_f64_and_are_reproducible(dev, N, C, K, H, W):
+    """launches with more units than workgroups: the units left over after units / CUs whole rounds are split along the input
+    channels over the workgroups (partial outputs in the workspace, added in part order by the last workgroup to arrive at the
+    unit's counter). Against f64 at the kernel-level bar (1e-5 of the output scale; the split units sum their channels in another
+    order), with bias + ReLU and with the BatchNorm slab sums (both come after the reduction), 20 reruns bit-equal (the counters
+    are left zero by every launch; which workgroup arrives last changes from run to run, the order of the additions does not);
+    units / tail / parts of the five shapes on 256 CUs: 627 / 115 / 2, 836 / 68 / 3, 550 / 38 / 6, 550 / 38 / 1 (Cin = 32: four
+    chunks per unit - too few to split, >= 4 chunks per part: the tail runs whole), 270 / 14 / 4; the call without a workspace
+    (tail not split) agrees to rounding."""
+    from crbhip import winograd, lib, check, ptr, cur_stream
+    torch.manual_seed(N + C + K)
+    x = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(K, C, 3, 3, device=dev) / np.sqrt(9 * C)).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(K, device=dev)
+    want = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    scale = float(want.abs().max())
+    U = winograd.weights_forward2(w)
+    y = winograd.conv3x3_U2(x, U, b)
+    assert float((y.double() - want).abs().max()) <= 1e-5 * scale
+    for _ in range(20):
+        assert torch.equal(winograd.conv3x3_U2(x, U, b), y)
+    assert torch.equal(winograd.conv3x3_U2(x, U, b, relu=True), torch.relu(y))
+    # the entry point without a workspace: tail units whole
+    y0 = torch.empty_like(y)
+    xv = x.permute(0, 2, 3, 1)
+    check(lib.crb_conv3x3_winograd2_nhwc(xv.data_ptr(), ptr(U), y0.data_ptr(), N, H, W, C, K, ptr(b), 0, cur_stream(dev)), 'crb_conv3x3_winograd2_nhwc')
+    assert float((y0.double() - want).abs().max()) <= 1e-5 * scale
+    assert float((y0 - y).abs().max()) <= 2e-6 * scale
+    # slab sums come after the reduction
+    ys, st = winograd.conv3x3_stats(x, w)
+    assert torch.equal(ys, winograd.conv3x3_U2(x, U))
+    got = st.double().sum(0)
+    ref1, ref2 = ys.double().sum((0, 2, 3)), (ys.double() ** 2).sum((0, 2, 3))
+    assert float((got[0] - ref1).abs().max() / ref2.sqrt().max()) < 1e-5
+    assert float((got[1] - ref2).abs().max() / ref2.max()) < 1e-5
+    # the workspace's counters are zero again
+    ws = winograd._fwd_workspace(dev)
+    assert int(ws[:1024].view(torch.int32).abs().sum()) == 0

@@ -71,33 +71,37 @@ if __name__ == '__main__':
         print(line, flush=True)
         if not quick:
             tm = []
-            for mode in (1, 2, 3, 5, 6, 10, 11, 12, 13):
+            for mode in (1, 2, 3):
                 lib.crb_winograd2_set_mode(mode)
                 tm.append(timeit(lambda: winograd.conv3x3_U2(x, U2, b))[0])
             lib.crb_winograd2_set_mode(0)
-            print('   measurement builds: no MFMAs %.0f us, no transform %.0f us, no DMA in the loop %.0f us, raw from the zero page %.0f us, U from one chunk %.0f us, no U copies in the loop %.0f us, no source bookkeeping %.0f us, transform without its raw reads %.0f us, transform without its V stores %.0f us' % tuple(tm), flush=True)
-            abn = {0: [], 7: [], 8: [], 9: []}
-            for _ in range(3):
-                for mode in abn:
-                    lib.crb_winograd2_set_mode(mode)
-                    abn[mode].append(timeit(lambda: winograd.conv3x3_U2(x, U2, b), it=15, warm=3)[0])
-            lib.crb_winograd2_set_mode(0)
-            print('   A/B LDS-DMA cache policy default / U nt / raw nt / both nt: %s us' % ' / '.join(str(['%.0f' % v for v in abn[m]]) for m in abn), flush=True)
-            ab = {0: [], 1: []}
-            for _ in range(3):
-                for mode in (0, 1):
-                    lib.crb_winograd2_set_persistent(mode)
-                    ab[mode].append(timeit(lambda: winograd.conv3x3_U2(x, U2, b), it=15, warm=3)[0])
-            lib.crb_winograd2_set_persistent(1)
-            print('   A/B one unit per workgroup / persistent: %s / %s us' % (['%.0f' % v for v in ab[0]], ['%.0f' % v for v in ab[1]]), flush=True)
+            print('   measurement builds: no MFMAs %.0f us, no transform %.0f us, no DMA in the loop %.0f us' % tuple(tm), flush=True)
+        ab = {0: [], 1: []}
+        for _ in range(3):
+            for mode in (0, 1):
+                lib.crb_winograd2_set_split(mode)
+                ab[mode].append(timeit(lambda: winograd.conv3x3_U2(x, U2, b), it=15, warm=3)[0])
+        lib.crb_winograd2_set_split(1)
+        print('   A/B tail units whole / split along the input channels: %s / %s us' % (['%.0f' % v for v in ab[0]], ['%.0f' % v for v in ab[1]]), flush=True)
+        # same-box A/B: the round-4 kernel (measurement library only) | this kernel
+        from crbhip import check, ptr, cur_stream
+        y4 = torch.empty_like(y)
+        xv = x.permute(0, 2, 3, 1)
+
+        def r04():
+            check(lib.crb_conv3x3_winograd2_nhwc_r04(xv.data_ptr(), ptr(U2), y4.data_ptr(), N, H, W, C, K, ptr(b), 0, cur_stream(dev)), 'r04')
+        r04()
+        same = bool(torch.equal(y4, y))
+        abk = {'r04': [], 'r05': []}
+        for _ in range(3):
+            abk['r04'].append(timeit(r04, it=15, warm=3)[0])
+            abk['r05'].append(timeit(lambda: winograd.conv3x3_U2(x, U2, b), it=15, warm=3)[0])
+        print('   A/B kernels (interleaved): %s; r04 output bit-equal to r05: %s' % (', '.join('%s %s us' % (k, ['%.0f' % v for v in vs]) for k, vs in abk.items()), same), flush=True)
+        if not quick:
             # per-workgroup stamps
-            th, tw = (((H + 1) // 2) + 1) & ~1, (W + 1) // 2
-            nb = ((N * th + 15) // 16) * ((tw + 3) // 4)
-            grid = ((nb + 7) // 8) * 8 * (K // 64)
-            dbg = torch.zeros((max(grid, 256), 16), dtype=torch.int64, device=dev)
+            dbg = torch.zeros((256, 16), dtype=torch.int64, device=dev)
             lib.crb_winograd2_set_debug(dbg.data_ptr())
             lib.crb_winograd2_set_mode(4)
-            lib.crb_winograd2_set_persistent(1)
             for _ in range(3):
                 dbg.zero_()
                 winograd.conv3x3_U2(x, U2, b)
@@ -106,17 +110,12 @@ if __name__ == '__main__':
             lib.crb_winograd2_set_debug(None)
             d = dbg.cpu().numpy().astype(np.int64)
             d = d[d[:, 0] != 0]
-            nch = C // 8
-            units = d[:, 7]
+            chunks = np.maximum(d[:, 7], 1)
             pro, loop = d[:, 1] - d[:, 0], d[:, 2] - d[:, 1]
             wall = (d[:, 5] - d[:, 4]) * 10.0          # ns (100 MHz)
             span = (d[:, 5].max() - d[:, 4].min()) * 0.01
             clk = (d[:, 2] - d[:, 0]) / np.maximum(wall, 1.0)
-            parked = d[:, 3] / (units * nch)
-            print('   per chunk (wave 0, with s_memtime overhead): stages 0-6 %.0f, parked %.0f, DMA issue + last stage + first reads %.0f, bookkeeping %.0f, unit epilogue %.0f cycles'
-                  % tuple((d[:, c] / (units * nch)).mean() for c in (8, 3, 9, 10, 11)), flush=True)
-            per_chunk = loop / (units * nch)
-            print('   stamps (%d workgroups, %.2f units each (max %d), %d chunks per unit): prologue %.0f cycles (p90 %.0f), '
-                  'chunks + output transforms %.0f cycles per chunk (p10 %.0f p90 %.0f), of which parked at the barrier %.0f; workgroup wall %.1f us (max %.1f), clock %.2f GHz, kernel span %.0f us'
-                  % (len(d), units.mean(), units.max(), nch, pro.mean(), np.percentile(pro, 90), per_chunk.mean(),
-                     np.percentile(per_chunk, 10), np.percentile(per_chunk, 90), parked.mean(), wall.mean() / 1e3, wall.max() / 1e3, clk.mean(), span), flush=True)
+            print('   stamps (%d workgroups, %.1f chunks of whole units each): prologue %.0f cycles, %.0f cycles per chunk incl. output transforms and '
+                  'the tail part, parked at the barrier %.0f per chunk; workgroup wall %.1f us (max %.1f, min %.1f), clock %.2f GHz, kernel span %.0f us'
+                  % (len(d), chunks.mean(), pro.mean(), (loop / chunks).mean(), (d[:, 3] / chunks).mean(), wall.mean() / 1e3,
+                     wall.max() / 1e3, wall.min() / 1e3, clk.mean(), span), flush=True)
