@@ -98,22 +98,6 @@ def weights_input_grad2(weight):
     return _weights_conv2(weight, 1)
 
 
-_FWD_WS = {}
-
-
-def _fwd_workspace(device):
-    """workspace of the forward launches on (device, current stream): arrival counters + partial outputs of the split tail units
-    (crb_winograd2_workspace_bytes; zero before its first use, every launch leaves the counters zero). One per stream: launches
-    that may run concurrently must not share it."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _FWD_WS.get(key)
-    if ws is None:
-        with torch.cuda.device(device):
-            nbytes = int(lib.crb_winograd2_workspace_bytes())
-        ws = _FWD_WS[key] = torch.zeros((max(nbytes, 4) // 4,), dtype=torch.float32, device=device)
-    return ws
-
-
 def conv3x3_U2(x, U, bias=None, relu=False):
     """x (N,Cin,H,W) f32 channels_last, U = weights_forward2(...) -> y (N,Cout,H,W) channels_last (second kernel)"""
     require_cuda(x, U)
@@ -123,11 +107,10 @@ def conv3x3_U2(x, U, bias=None, relu=False):
     if ucin != cin or not supported2(cin, cout, H, W):
         raise CrbHipError('no Winograd (2) instance for %d -> %d channels on a %d x %d map' % (cin, cout, H, W))
     y = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    ws = _fwd_workspace(x.device)
     e0 = _prof_begin()
-    check(lib.crb_conv3x3_winograd2_ws_nhwc(xv.data_ptr(), ptr(U), y.data_ptr(), N, H, W, cin, cout,
-                                            ptr(bias.contiguous().float()) if bias is not None else None, int(bool(relu)),
-                                            ptr(ws), ws.numel() * 4, cur_stream(x.device)), 'crb_conv3x3_winograd2_ws_nhwc')
+    check(lib.crb_conv3x3_winograd2_nhwc(xv.data_ptr(), ptr(U), y.data_ptr(), N, H, W, cin, cout,
+                                         ptr(bias.contiguous().float()) if bias is not None else None, int(bool(relu)),
+                                         cur_stream(x.device)), 'crb_conv3x3_winograd2_nhwc')
     _prof_end(e0, 'wino_conv', cin, cout, N, H, W)
     return y
 
@@ -243,9 +226,8 @@ class _Conv3x3Stats(torch.autograd.Function):
         y = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         stats = torch.empty((int(lib.crb_winograd2_stats_slabs(N, H, W)), 2, cout), dtype=torch.float32, device=x.device)
         e0 = _prof_begin()
-        ws = _fwd_workspace(x.device)
         check(lib.crb_conv3x3_winograd2_stats_nhwc(xv.data_ptr(), ptr(U), y.data_ptr(), ptr(stats), N, H, W, cin, cout,
-                                                   ptr(ws), ws.numel() * 4, cur_stream(x.device)), 'crb_conv3x3_winograd2_stats_nhwc')
+                                                   cur_stream(x.device)), 'crb_conv3x3_winograd2_stats_nhwc')
         _prof_end(e0, 'wino_conv', cin, cout, N, H, W)
         ctx.mark_non_differentiable(stats)
         return y, stats

@@ -30,17 +30,20 @@
 //   * optional: the slab sums of y and y^2 for the BatchNorm that follows (epilogue, a.stats), the previous layer's BatchNorm +
 //     ReLU applied inside the input transform (AFFINE instances, opt-in).
 //
-// Round 5: split tail. With G0 workgroups (one per CU) every workgroup takes nunits / G0 whole units; the
-// nunits mod G0 units that are left (48 of 4,400 for 128->128 @ 16x200x176: a whole extra round of 256 workgroups for 19 % of a
-// round's work) are split along the INPUT channels into S parts each (S * tail units <= G0, >= 4 chunks per part): every workgroup
-// ends with ONE part as a second run of the same pipeline, writes its partial outputs (after the output transform, which is
-// linear) to the caller's workspace, and the workgroup that arrives last at the unit's counter adds the S partials in part order,
-// then bias / ReLU / stores / slab sums. The decomposition depends on the launch geometry only (not on how many workgroups take
-// part: crb_cu_reservation), so results are bit-reproducible and reservation-independent; launches whose tail cannot be split
-// (S < 2, no workspace) run exactly the round-4 schedule. What was also built and measured SLOWER in round 5 (same-box A/B,
-// profiles/r05_time_winograd2_*.txt): first chunks of a unit with C = 0 MFMAs instead of a zeroing pass (+5 %: two alternating
-// chunk bodies), item walkers generalised over (unit, chunk range) lists (+2 .. 5 %), the output transform overlapped with the
-// next unit's first chunk (does not fit: 128 accumulators + 32 transformed values + the chunk's own registers > 256 per wave).
+// Round 5 - what was built on top of this kernel, measured on the same box against it, and NOT kept (commit
+// 4790d45 has the code, profiles/r05_time_winograd2_v1..v4*.txt the numbers):
+//   * split tail: the nunits mod CUs units of the last, mostly empty round split along the input channels into S parts, one per
+//     workgroup, partial outputs in a workspace, added in part order by the last workgroup to arrive (deterministic, bit-equal
+//     reruns, reservation-independent): -2 .. -3 % where a tail exists - and every form of the chunk loop that carried it (item
+//     walkers over (unit, chunk range) lists: +2 .. 5 %; a second run of the unchanged pipeline for the part: +2.7 % on the
+//     launches with nothing to split, and its two-instance form still +2.7 % for reasons of code placement) cost as much;
+//   * first chunk of a unit with C = 0 MFMAs instead of the zeroing pass: +5 % (two alternating chunk bodies);
+//   * the output transform overlapped with the next unit's first chunk: does not fit (128 accumulators + 32 transformed values +
+//     the chunk's own ~95 registers > 256 per wave at two waves per SIMD: 550 - 680 spill instructions);
+//   * a 64 tiles x 128 channels workgroup tile (DESIGN r04 section 8.1): 64 x 128 x 16 accumulators = 512 KB = the CU's whole
+//     register file.
+// The kernel below is the round-4 kernel; round 5 changed its host side only (per-device launch state, atomic launch sequence,
+// reservation honoured by full-size launches only and clamped to half of the CUs, BatchNorm-apply instances removed).
 #include <atomic>
 #include <type_traits>
 #include "crb_common.h"
@@ -165,11 +168,6 @@ struct Wino2Args {
   int nblocks;         // spatial blocks = ceil(RT / 16) * tw4
   int ncb;             // cout / 64
   int persistent;      // 1: gridDim.x workgroups share the units as contiguous ranges; 0: one unit per workgroup
-  float* part;         // workspace: partial outputs of the split tail units [item][wave][plane 0..31][lane] f32, or null (S = 1)
-  int* ticket;         // workspace: one arrival counter per tail unit; zero before the first launch, every launch leaves it zero
-  int nfull;           // units [0, nfull) are shared as contiguous ranges of whole units (all units when the tail is not split)
-  int ntail;           // units [nfull, nfull + ntail): each split into S parts along the input channels, one part per workgroup
-  int S;
   unsigned seq;        // launch sequence number (24 bits, never 0) for the busy-CU latch; 0 = ignore g_cu_busy
 };
 
@@ -214,11 +212,8 @@ __device__ __forceinline__ void unit_next(UnitPos& u, const Wino2Args& a) {
 // memory), zero outside the map like any padded input: applied by the input transform to the 16 values it reads, times a 0 / 1
 // mask of the patch positions inside the map. The 8 (scale, shift) pairs of a chunk travel in four of the eight junk slots of the
 // wave's second raw DMA instruction: no extra instruction, no extra counter to wait for.
-// SPLIT: the instance for launches whose tail units are split (runs 1.. below); the other instance is the round-4 schedule unchanged
-// (the run loop costs it 1.5 % when there is nothing to split: same-box A/B, profiles/r05_time_winograd2_v3*.txt)
-template <int MODE, bool SPLIT = false>
+template <int MODE, bool AFFINE = false>
 __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
-  constexpr bool AFFINE = false;       // (the BatchNorm-apply-in-the-transform instances of round 4 were measured slower and removed)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const Vb = lds;
   float* const Ub = lds + 2 * V_FLOATS;
@@ -229,7 +224,8 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   if (MODE == 4) { stamp[0] = __builtin_amdgcn_s_memtime(); stamp[4] = wall_clock64(); stamp[3] = 0; }
 
   // ---- the unit range of this workgroup
-  int u_first, u_end, Gw = 1;
+  const int nunits = a.nblocks * a.ncb;
+  int u_first, u_end;
   if (a.persistent) {
     int G = gridDim.x;
     if (a.seq) {
@@ -249,13 +245,11 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
       __syncthreads();
       const int busy = (int)__float_as_uint(Rb[6 * RAW_ROW_FLOATS]);
       __syncthreads();
-      // (at most half of the launch's workgroups give way: a reservation larger than the grid must not funnel it into a few)
-      G = max(((int)gridDim.x + 1) / 2, (int)gridDim.x - __builtin_amdgcn_readfirstlane(busy));
+      G = max(1, (int)gridDim.x - __builtin_amdgcn_readfirstlane(busy));
       if ((int)blockIdx.x >= G) return;
     }
-    Gw = G;
-    u_first = (int)((int64_t)blockIdx.x * a.nfull / G);
-    u_end = (int)((int64_t)(blockIdx.x + 1) * a.nfull / G);
+    u_first = (int)((int64_t)blockIdx.x * nunits / G);
+    u_end = (int)((int64_t)(blockIdx.x + 1) * nunits / G);
   } else {
     // consecutive workgroup ids alternate XCDs (id % 8): the channel blocks of one spatial block run back to back on ONE XCD, so
     // that the later ones read the input block from that L2
@@ -265,21 +259,19 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
     u_first = tb < a.nblocks ? tb * a.ncb + cb : 0;
     u_end = tb < a.nblocks ? u_first + 1 : 0;
   }
-  const int items_tail = (SPLIT && a.persistent) ? a.ntail * a.S : 0;
-  if (u_first >= u_end && (int)blockIdx.x >= items_tail) return;
+  if (u_first >= u_end) return;
   const int nch = a.cin / CC;
-  int total = (u_end - u_first) * nch;            // chunks of the current run of this workgroup
+  const int total = (u_end - u_first) * nch;      // chunks of this workgroup
   UnitPos first;
-  auto set_first = [&](int unit) {
-    const int tb = unit / a.ncb;
-    first.cb = unit - tb * a.ncb;
+  {
+    const int tb = u_first / a.ncb;
+    first.cb = u_first - tb * a.ncb;
     const int br = tb / a.tw4;
     first.bc = tb - br * a.tw4;
     first.R0 = br * TB_ROWS;
     first.n0 = first.R0 / a.th;
     first.ty0 = first.R0 - first.n0 * a.th;
-  };
-  set_first(u_first < u_end ? u_first : 0);
+  }
   // image and tile row inside the image of tile row t of the block at u (rows past the batch: the last valid row)
   auto row_of = [&](const UnitPos& u, int t, int& n, int& ty) {
     t = min(t, a.RT - 1 - u.R0);
@@ -495,123 +487,6 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
     unit_next(eu, a);
   };
 
-  // ---- a part of a split tail unit (round 5). yp[tbk] = (y00, y01, y10, y11) of tile block tbk, same order of the additions as in
-  //      unit_epilogue
-  auto tail_part = [&](int t_unit, int t_part) __attribute__((always_inline)) {
-    f32x4 yp[2][4];
-#pragma unroll
-    for (int tbk = 0; tbk < 2; ++tbk) {
-      f32x4 t0[4], t1[4];
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        t0[s4] = acc[0 * 4 + s4][tbk] + acc[1 * 4 + s4][tbk] + acc[2 * 4 + s4][tbk];
-        t1[s4] = acc[1 * 4 + s4][tbk] - acc[2 * 4 + s4][tbk] - acc[3 * 4 + s4][tbk];
-      }
-      yp[tbk][0] = t0[0] + t0[1] + t0[2];
-      yp[tbk][1] = t0[1] - t0[2] - t0[3];
-      yp[tbk][2] = t1[0] + t1[1] + t1[2];
-      yp[tbk][3] = t1[1] - t1[2] - t1[3];
-    }
-    acc_clear();
-    const int t = t_unit - a.nfull;
-    // plane (tbk * 4 + q) * 4 + e of (item, wave): 64 consecutive floats = the lanes (256-byte stores). Agent-scope atomic stores /
-    // loads (sc1): the parts cross XCDs, whose L2s are not coherent with each other for plain accesses
-    float* mine = a.part + ((int64_t)(t * a.S + t_part) * 8 + wave) * (32 * 64) + lane;
-#pragma unroll
-    for (int tbk = 0; tbk < 2; ++tbk)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          __hip_atomic_store(mine + ((tbk * 4 + q) * 4 + e) * 64, yp[tbk][q][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // every store of every wave is acknowledged before the ticket (s_barrier does not drain stores)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (T == 0) {
-      const int old = __hip_atomic_fetch_add(a.ticket + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (old == a.S - 1) __hip_atomic_store(a.ticket + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (for the next launch)
-      lds[0] = __int_as_float(old);
-    }
-    __syncthreads();
-    const int old = __builtin_amdgcn_readfirstlane(__float_as_int(lds[0]));
-    if (old != a.S - 1) return;
-    const float* p0 = a.part + ((int64_t)(t * a.S) * 8 + wave) * (32 * 64) + lane;
-    for (int p = 0; p < a.S; ++p) {                          // (the part loop outside: yp stays in registers)
-#pragma unroll
-      for (int tbk = 0; tbk < 2; ++tbk)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v = __hip_atomic_load(p0 + ((tbk * 4 + q) * 4 + e) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            yp[tbk][q][e] = p == 0 ? v : yp[tbk][q][e] + v;
-          }
-      p0 += 8 * 32 * 64;
-    }
-    // bias, ReLU, stores, slab sums: unit_epilogue's second half on the summed values (eu = the tail unit)
-    const int k = eu.cb * WG_K + wk * 16 + 4 * kq;
-    f32x4 bias = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (a.bias) {
-      const float* bp = a.bias + eu.cb * WG_K + __builtin_amdgcn_readfirstlane(wk) * 16;
-      const f32x4 b0 = sload4(bp), b1 = sload4(bp + 4), b2 = sload4(bp + 8), b3 = sload4(bp + 12);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bias[e] = kq == 0 ? b0[e] : kq == 1 ? b1[e] : kq == 2 ? b2[e] : b3[e];
-    }
-    f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int tbk = 0; tbk < 2; ++tbk) {
-      const int tile = wt * 32 + tbk * 16 + l15;
-      const int Rg = eu.R0 + (tile >> 2);
-      const int tx = eu.bc * TB_COLS + (tile & 3);
-      int n2, ty2;
-      row_of(eu, tile >> 2, n2, ty2);
-      f32x4 y00 = yp[tbk][0] + bias, y01 = yp[tbk][1] + bias, y10 = yp[tbk][2] + bias, y11 = yp[tbk][3] + bias;
-      if (a.relu) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          y00[e] = fmaxf(y00[e], 0.f); y01[e] = fmaxf(y01[e], 0.f);
-          y10[e] = fmaxf(y10[e], 0.f); y11[e] = fmaxf(y11[e], 0.f);
-        }
-      }
-      if (Rg < a.RT && tx < a.tw && 2 * ty2 < a.H) {
-        const int oy = 2 * ty2, ox = 2 * tx;
-        float* yo = a.y + (((int64_t)n2 * a.H + oy) * a.W + ox) * a.cout + k;
-        const bool x1 = ox + 1 < a.W, y1 = oy + 1 < a.H;
-        *reinterpret_cast<f32x4*>(yo) = y00;
-        if (x1) *reinterpret_cast<f32x4*>(yo + a.cout) = y01;
-        if (y1) *reinterpret_cast<f32x4*>(yo + (int64_t)a.W * a.cout) = y10;
-        if (x1 && y1) *reinterpret_cast<f32x4*>(yo + (int64_t)a.W * a.cout + a.cout) = y11;
-        if (a.stats) {
-          const float m01 = x1 ? 1.f : 0.f, m10 = y1 ? 1.f : 0.f, m11 = (x1 && y1) ? 1.f : 0.f;
-          s1 = s1 + y00; s2 = s2 + y00 * y00;
-          s1 = s1 + y01 * m01; s2 = s2 + (y01 * y01) * m01;
-          s1 = s1 + y10 * m10; s2 = s2 + (y10 * y10) * m10;
-          s1 = s1 + y11 * m11; s2 = s2 + (y11 * y11) * m11;
-        }
-      }
-    }
-    if (a.stats) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float u = s1[e], v = s2[e];
-#define CRB_ROW_ROR_ADD(x, ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false))
-        CRB_ROW_ROR_ADD(u, 0x128); CRB_ROW_ROR_ADD(v, 0x128);
-        CRB_ROW_ROR_ADD(u, 0x124); CRB_ROW_ROR_ADD(v, 0x124);
-        CRB_ROW_ROR_ADD(u, 0x122); CRB_ROW_ROR_ADD(v, 0x122);
-        CRB_ROW_ROR_ADD(u, 0x121); CRB_ROW_ROR_ADD(v, 0x121);
-#undef CRB_ROW_ROR_ADD
-        s1[e] = u;
-        s2[e] = v;
-      }
-      if (l15 == 0) {
-        const int64_t blk = (int64_t)(eu.R0 / TB_ROWS) * a.tw4 + eu.bc;
-        float* so = a.stats + ((blk * 2 + wt) * 2) * a.cout + k;
-        *reinterpret_cast<f32x4*>(so) = s1;
-        *reinterpret_cast<f32x4*>(so + a.cout) = s2;
-      }
-    }
-  };
-
   // ---- one chunk as 8 stages (one xi pair each), pinned by sched_barriers so that a wave's instruction stream alternates
   //      [a piece of the transform of the next chunk | 3 operand reads of the NEXT pair | 8 MFMAs]: the LDS / VALU work of the
   //      transform sits in the shadow of the wave's own MFMAs (and of the SIMD's other wave), not in front of the whole chunk.
@@ -758,34 +633,7 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   using std::true_type;
   using std::false_type;
 
-  // ---- runs of this workgroup: run 0 = its range of whole units (exactly the round-4 pipeline); runs 1.. = one part of a split tail
-  //      unit each (item j = workgroup + (run - 1) G of the tail list: normally one, more only when a CU reservation took workgroups
-  //      out of the launch). A part is a one-unit range whose walkers start c0 chunks into the input channels and stop after cn
-  //      chunks: the chunk code never reaches the unit's end (no output transform inside), the code behind the loop stores the part.
-  for (int run = 0; SPLIT || run < 1; ++run) {
-    int t_unit = -1, t_part = 0, t_c0 = 0;
-    if (SPLIT && run > 0) {
-      const int j = (int)blockIdx.x + (run - 1) * Gw;
-      if (j >= items_tail) break;
-      const int t = j / a.S;
-      t_part = j - t * a.S;
-      t_unit = a.nfull + t;
-      t_c0 = (int)((int64_t)t_part * nch / a.S);
-      total = (int)((int64_t)(t_part + 1) * nch / a.S) - t_c0;
-      set_first(t_unit);
-    } else if (total == 0) {
-      continue;
-    }
-    if (SPLIT && run > 0) {                      // (run 0 starts from the declarations' initial state)
-      ru = first; uu = first; eu = first;
-      rc = uc = ec = 0;
-      r_issued = u_issued = 0;
-      r_setup();
-      rsrc[0] += t_c0 * rstep[0];
-      rsrc[1] += t_c0 * rstep[1];
-      usrc = a.U + ((int64_t)uu.cb * nch + t_c0) * U_FLOATS + T * 4;
-    }
-  // ---- prologue (once per run): raw(0), raw(1), U(0) in one round trip, raw(0) -> V(0), then U(1), raw(2) go out: chunk g
+  // ---- prologue (once per workgroup): raw(0), raw(1), U(0) in one round trip, raw(0) -> V(0), then U(1), raw(2) go out: chunk g
   //      sends raw(g+3) in its stage 2 (two chunks of lead) and U(g+2) after its barrier (one chunk: U comes from the XCD's L2)
   issue_raw(); r_advance();
   if (total > 1) { issue_raw(); r_advance(); }
@@ -796,7 +644,7 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   if (total > 1) issue_u();                   // (chunk 0 moves the sources on in its stage 1)
   if (total > 2) issue_raw();
   op_read(Vb, Ub, 0, 0);
-  if (MODE == 4 && run == 0) stamp[1] = __builtin_amdgcn_s_memtime();
+  if (MODE == 4) stamp[1] = __builtin_amdgcn_s_memtime();
 
   // ---- chunks: the steady state is one body without DMA / transform conditions, the last three chunks are peeled
   int g = 0;
@@ -804,16 +652,6 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   if (g + 2 < total) { chunk(g, true_type{}, false_type{}, true_type{}); ++g; }        // 1 .. 3 chunks left
   if (g + 1 < total) { chunk(g, false_type{}, false_type{}, true_type{}); ++g; }
   chunk(g, false_type{}, false_type{}, false_type{});
-
-    // ---- a part of a split tail unit: Y = A^T M A of the partial sums (linear) -> workspace; the workgroup that arrives last at
-    //      the unit's counter adds the S parts in part order, then bias / ReLU / stores / slab sums as for a whole unit
-    if (SPLIT && run > 0) tail_part(t_unit, t_part);
-    if (SPLIT) {
-      // the next run's prologue overwrites the buffers: every wave is done with them (and with the ticket word)
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-  }
   if (MODE == 4) stamp[2] = __builtin_amdgcn_s_memtime();
   if (MODE == 4 && g_wino2_dbg && T == 0) {
     stamp[5] = wall_clock64();
@@ -828,11 +666,11 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
 
 }  // namespace
 
-CRB_KNOB g_wino2_mode = 0;      // measurement builds: 1 = no MFMAs, 2 = no transform, 3 = no DMA in the loop, 4 = stamps
-CRB_KNOB g_wino2_split = 1;     // 0: tail units are never split (A/B of the split tail)
+CRB_KNOB g_wino2_persistent = 1; // 1: one workgroup per CU over a range of units (measured 4 - 8 % faster); 0: one unit per workgroup
+CRB_KNOB g_wino2_mode = 0;      // measurement builds: 1 = no MFMAs, 2 = no transform, 3 = no DMA in the loop
 #ifdef CRB_MEASURE
-extern "C" int crb_winograd2_set_mode(int mode) { g_wino2_mode = (mode >= 1 && mode <= 4) ? mode : 0; return CRB_OK; }
-extern "C" int crb_winograd2_set_split(int on) { g_wino2_split = on ? 1 : 0; return CRB_OK; }
+extern "C" int crb_winograd2_set_mode(int mode) { g_wino2_mode = (mode >= 1 && mode <= 13) ? mode : 0; return CRB_OK; }
+extern "C" int crb_winograd2_set_persistent(int on) { g_wino2_persistent = on ? 1 : 0; return CRB_OK; }
 // mode 4: 16 uint64 per workgroup (device buffer of the caller, NULL = off)
 extern "C" int crb_winograd2_set_debug(void* dev_buf) {
   unsigned long long* p = (unsigned long long*)dev_buf;
@@ -841,7 +679,7 @@ extern "C" int crb_winograd2_set_debug(void* dev_buf) {
 }
 #endif
 
-// H >= 5: a block of 16 tile rows crosses at most 5 image boundaries
+// H >= 5: a block of 16 tile rows crosses at most 5 image boundaries (44 raw rows = 880 slots; slots 896.. are the junk corner)
 extern "C" int crb_winograd2_supported(int cin, int cout, int H, int W) {
   return (cin > 0 && cout > 0 && cin % CC == 0 && cout % WG_K == 0 && H >= 5 && W >= 1) ? 1 : 0;
 }
@@ -870,11 +708,9 @@ extern "C" int crb_winograd2_weights_conv(const float* w, int64_t so, int64_t si
   return CRB_OK;
 }
 
-// per-device launch state (a process may drive several devices from several threads): CU count, "dynamic LDS attribute set" flags
+// per-device launch state (a process may drive several devices from several threads)
 namespace {
 constexpr int MAX_DEV = 64;
-constexpr int WS_TICKET_BYTES = 4096;                         // 1,024 tail units at most (there are < G0 <= CUs of them)
-constexpr int64_t WS_ITEM_BYTES = 8 * 32 * 64 * 4;            // partial outputs of one part: 64 tiles x 4 outputs x 64 channels f32
 std::atomic<int> g_dev_cus[MAX_DEV];
 std::atomic<unsigned> g_dev_attr[MAX_DEV];                    // bit m: hipFuncSetAttribute done for kernel instance m on this device
 std::atomic<unsigned> g_launch_seq{0};
@@ -893,22 +729,12 @@ int device_cus(int* dev_out) {
 }
 }  // namespace
 
-// workspace of the forward launches on the CURRENT device (one per stream that launches them: launches that may run concurrently must
-// not share it): arrival counters of the split tail units + their partial outputs. Must be ZERO before its first use; every launch
-// leaves the counters zero.
-extern "C" int64_t crb_winograd2_workspace_bytes(void) {
-  int dev = 0;
-  const int n_cu = device_cus(&dev);
-  if (n_cu <= 0) return 0;
-  return WS_TICKET_BYTES + (int64_t)n_cu * WS_ITEM_BYTES;
-}
-
-static int winograd2_launch(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout, const float* bias, int relu,
-                            void* stream, float* stats, void* workspace, int64_t workspace_bytes) {
+static int winograd2_launch(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout, const float* bias,
+                            int relu, void* stream, float* stats = nullptr) {
   if (N <= 0 || H <= 0 || W <= 0) return CRB_ERR_ARG;
   if (!crb_winograd2_supported(cin, cout, H, W)) return CRB_ERR_UNSUPPORTED;
   Wino2Args a;
-  a.x = x; a.U = U; a.y = y; a.bias = bias; a.stats = stats; a.affine = nullptr;
+  a.x = x; a.U = U; a.y = y; a.bias = bias; a.affine = nullptr; a.stats = stats;
   a.N = N; a.H = H; a.W = W; a.cin = cin; a.cout = cout; a.relu = relu;
   a.th = (((H + 1) / 2) + 1) & ~1; a.tw = (W + 1) / 2;
   const int64_t rt = (int64_t)N * a.th;
@@ -921,15 +747,22 @@ static int winograd2_launch(const float* x, const float* U, float* y, int N, int
   a.ncb = cout / WG_K;
   const size_t lds = LDS_FLOATS * sizeof(float);
   int mode = 0;
-#ifdef CRB_MEASURE
-  mode = g_wino2_mode;
-#endif
   auto kern = winograd2_kernel<0>;
 #ifdef CRB_MEASURE
+  mode = g_wino2_mode;
   if (mode == 1) kern = winograd2_kernel<1>;
   if (mode == 2) kern = winograd2_kernel<2>;
   if (mode == 3) kern = winograd2_kernel<3>;
   if (mode == 4) kern = winograd2_kernel<4>;
+  if (mode == 5) kern = winograd2_kernel<5>;
+  if (mode == 6) kern = winograd2_kernel<6>;
+  if (mode == 7) kern = winograd2_kernel<7>;
+  if (mode == 8) kern = winograd2_kernel<8>;
+  if (mode == 9) kern = winograd2_kernel<9>;
+  if (mode == 10) kern = winograd2_kernel<10>;
+  if (mode == 11) kern = winograd2_kernel<11>;
+  if (mode == 12) kern = winograd2_kernel<12>;
+  if (mode == 13) kern = winograd2_kernel<13>;
 #endif
   int dev = 0;
   const int n_cu = device_cus(&dev);
@@ -938,46 +771,15 @@ static int winograd2_launch(const float* x, const float* U, float* y, int N, int
     CRB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     g_dev_attr[dev].fetch_or(1u << mode, std::memory_order_release);
   }
-  // persistent workgroups: one per CU (all of the LDS each). The decomposition is fixed by the launch geometry: every workgroup
-  // takes units / grid whole units, the remaining ntail < grid units are split into S parts each along the input channels
-  // (S * ntail <= grid, every part >= 4 chunks: the DMA runs three chunks ahead), one part per workgroup
+  // persistent workgroups: one per CU (all of the LDS each), every one runs a contiguous range of units as one pipeline
   const int64_t units = nb * a.ncb;
-  const int64_t grid = units < n_cu ? units : n_cu;
-  a.persistent = 1;
-  a.nfull = (int)units;                     // (tail not split: all units as contiguous ranges - the round-4 schedule)
-  a.ntail = 0;
-  a.S = 1;
-  a.part = nullptr;
-  a.ticket = nullptr;
-  const int64_t tail = units - (units / grid) * grid;
-  if (workspace && tail > 0 && g_wino2_split) {
-    int S = (int)(grid / tail);
-    const int nch = cin / CC;
-    if (S > nch / 4) S = nch / 4;
-    if (S > 8) S = 8;
-    if (S >= 2 && tail * 4 <= WS_TICKET_BYTES && workspace_bytes >= WS_TICKET_BYTES + tail * S * WS_ITEM_BYTES) {
-      a.S = S;
-      a.ntail = (int)tail;
-      a.nfull = (int)(units - tail);
-      a.ticket = (int*)workspace;
-      a.part = (float*)((char*)workspace + WS_TICKET_BYTES);
-    }
-  }
-  if (a.S > 1) {
-    kern = winograd2_kernel<0, true>;
-#ifdef CRB_MEASURE
-    if (mode == 1) kern = winograd2_kernel<1, true>;
-    if (mode == 2) kern = winograd2_kernel<2, true>;
-    if (mode == 3) kern = winograd2_kernel<3, true>;
-    if (mode == 4) kern = winograd2_kernel<4, true>;
-#endif
-    if (!(g_dev_attr[dev].load(std::memory_order_acquire) & (1u << (8 + mode)))) {
-      CRB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      g_dev_attr[dev].fetch_or(1u << (8 + mode), std::memory_order_release);
-    }
-  }
+  a.persistent = g_wino2_persistent;
+  const int64_t grid = a.persistent ? (units < n_cu ? units : n_cu) : ((nb + 7) / 8) * 8 * a.ncb;
+  // the busy-CU latch (crb_cu_reservation) is for launches that put a workgroup on EVERY CU: a smaller launch leaves CUs free
+  // anyway, and giving up workgroups there would funnel it into a few. The sequence number is process-wide and
+  // atomic (launches from several host threads / to several devices); slot = seq mod 64 of the device's latch ring.
   unsigned seq = (g_launch_seq.fetch_add(1, std::memory_order_relaxed) + 1) & 0xffffffu;
-  a.seq = seq ? seq : 1;
+  a.seq = (a.persistent && grid == n_cu) ? (seq ? seq : 1) : 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, (hipStream_t)stream, a);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
@@ -985,15 +787,7 @@ static int winograd2_launch(const float* x, const float* U, float* y, int N, int
 
 extern "C" int crb_conv3x3_winograd2_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
                                           const float* bias, int relu, void* stream) {
-  return winograd2_launch(x, U, y, N, H, W, cin, cout, bias, relu, stream, nullptr, nullptr, 0);
-}
-
-// the same with the caller's workspace (crb_winograd2_workspace_bytes, zero before its first use): the tail units of the launch are
-// split over the workgroups. Same results for every call with a workspace, whatever the CU reservation; a call WITHOUT one sums
-// the input channels of the tail units in one piece (other rounding in those units).
-extern "C" int crb_conv3x3_winograd2_ws_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
-                                             const float* bias, int relu, void* workspace, int64_t workspace_bytes, void* stream) {
-  return winograd2_launch(x, U, y, N, H, W, cin, cout, bias, relu, stream, nullptr, workspace, workspace_bytes);
+  return winograd2_launch(x, U, y, N, H, W, cin, cout, bias, relu, stream);
 }
 
 // training forward that also writes the slab sums of its output for the BatchNorm that follows: stats (crb_winograd2_stats_slabs, 2,
@@ -1006,17 +800,19 @@ extern "C" int64_t crb_winograd2_stats_slabs(int N, int H, int W) {
 }
 
 extern "C" int crb_conv3x3_winograd2_stats_nhwc(const float* x, const float* U, float* y, float* stats, int N, int H, int W, int cin,
-                                                int cout, void* workspace, int64_t workspace_bytes, void* stream) {
+                                                int cout, void* stream) {
   if (!stats) return CRB_ERR_ARG;
-  return winograd2_launch(x, U, y, N, H, W, cin, cout, nullptr, 0, stream, stats, workspace, workspace_bytes);
+  return winograd2_launch(x, U, y, N, H, W, cin, cout, nullptr, 0, stream, stats);
 }
 
 // cus > 0: a kernel that will hold `cus` CUs for milliseconds is about to be launched on `stream` (call right before it, same
 // stream); cus = 0: it has finished (call right after it, same stream). Persistent launches on other streams (the Winograd forward
-// kernel) then spread their work over the CUs that are left instead of queueing a workgroup behind every taken one (at most half
-// of a launch's workgroups give way).
+// kernel) then spread their work over the CUs that are left instead of queueing a workgroup behind every taken one.
 extern "C" int crb_cu_reservation(int cus, void* stream) {
   if (cus < 0) return CRB_ERR_ARG;
+  int dev = 0;
+  const int n_cu = device_cus(&dev);
+  if (n_cu > 0 && cus > n_cu / 2) cus = n_cu / 2;             // at most half of the device is announced as taken
   hipLaunchKernelGGL(cu_busy_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, cus);
   CRB_CHECK_LAUNCH();
   return CRB_OK;

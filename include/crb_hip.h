@@ -543,26 +543,14 @@ int crb_winograd2_weights_conv(const float* w, int64_t so, int64_t si, int64_t s
                                int conv_cout, int mode, void* stream);
 int crb_conv3x3_winograd2_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
                                const float* bias, int relu, void* stream);
-/* Round 5: the launch is one workgroup per CU over a FIXED decomposition of the units (16 x 4 tiles x 64 output channels): every
- * workgroup takes units / CUs whole units; the units that are left over (a whole extra round for a fraction of a round's work)
- * are split along the INPUT channels into S parts, one part per workgroup, partial outputs in `workspace`, added in part order
- * by the workgroup that arrives last at the unit's counter (deterministic; those units sum their input channels in another
- * order than the call without a workspace). workspace: crb_winograd2_workspace_bytes() bytes on the current device, ZERO
- * before its first use (every launch leaves the counters zero), not shared by launches that may run concurrently (one per
- * stream). Results do not depend on crb_cu_reservation. */
-int64_t crb_winograd2_workspace_bytes(void);
-int crb_conv3x3_winograd2_ws_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
-                                  const float* bias, int relu, void* workspace, int64_t workspace_bytes, void* stream);
-
 /* training forward that also hands the following BatchNorm its statistics: stats (crb_winograd2_stats_slabs(N,H,W), 2, Cout) f32 =
  * column sums of y and y^2 per slab of outputs (a slab = half of the 64 tiles of one 16 x 4-tile spatial block; outputs outside
  * the map are not counted), every slab written exactly once, no atomics. Feed them to crb_bn_relu_forward_partials(y, N*H*W,
  * Cout, stats, slabs, ...): the BatchNorm's own statistics pass over y (pcdet/models/backbones_2d/base_bev_backbone.py:31-41,
- * nn.BatchNorm2d in training mode) is not launched. No bias, no ReLU (the Conv2d layers of the backbone have neither).
- * workspace: as crb_conv3x3_winograd2_ws_nhwc (NULL = tail units not split). */
+ * nn.BatchNorm2d in training mode) is not launched. No bias, no ReLU (the Conv2d layers of the backbone have neither). */
 int64_t crb_winograd2_stats_slabs(int N, int H, int W);
 int crb_conv3x3_winograd2_stats_nhwc(const float* x, const float* U, float* y, float* stats, int N, int H, int W, int cin, int cout,
-                                     void* workspace, int64_t workspace_bytes, void* stream);
+                                     void* stream);
 
 /* a7 backward: weight gradient of the same convolution in the Winograd domain (csrc/winograd_wgrad.hip):
  * dU[xi][ci][co] = sum over tiles of (B^T d B)[xi][ci] * (A dY A^T)[xi][co] as 16 MFMA GEMMs whose two operands are both
@@ -581,8 +569,8 @@ int crb_winograd2_wgrad(const float* x, const float* dy, float* dw, int64_t so, 
  * the backbones) holds one CU per frame for ~5 ms while the persistent one-workgroup-per-CU Winograd launches of the BEV backbone
  * run on the main stream. crb_cu_reservation(cus, stream) right before such a kernel, crb_cu_reservation(0, stream) right after it
  * (same stream: two one-thread launches): the Winograd forward launches in between spread their units over (CUs - cus)
- * workgroups instead of leaving `cus` workgroups queued behind the taken CUs (at most half of a launch's workgroups give way).
- * Results do not depend on it. */
+ * workgroups instead of leaving `cus` workgroups queued behind the taken CUs. Only launches that put a workgroup on every CU
+ * look at it, and at most half of the CUs are ever announced as taken (a larger `cus` is clamped). Results do not depend on it. */
 int crb_cu_reservation(int cus, void* stream);
 
 /* a19: bilinear lookup of the BEV feature map at the keypoints.

@@ -16,16 +16,12 @@ extern "C" {
 int crb_mask_sort_set_rank_bits(int mode);
 /* measurement builds of the Winograd convolution (wrong results): 1 = no MFMAs, 2 = no staging of the next chunk */
 int crb_winograd_set_mode(int mode);
-/* measurement builds of the second Winograd design (wrong results): 1 = no MFMAs, 2 = no input transform, 3 = no LDS-DMA in the loop; 4 below */
+/* measurement builds of the second Winograd design (wrong results): 1 = no MFMAs, 2 = no input transform, 3 = no LDS-DMA in the loop; 5 .. 13: see csrc/winograd_conv2.hip; 4 below */
 int crb_winograd2_set_mode(int mode);
-/* mode 4 (correct results + stamps) writes 16 uint64 per workgroup {s_memtime: start, after the first prologue, end, cycles parked at the chunk barriers; wall_clock64 (100 MHz): start, end; XCC id; chunks of whole units}. NULL = off */
+/* mode 4 (correct results + stamps) writes 16 uint64 per workgroup {s_memtime: start, after prologue, after chunks, cycles parked at the chunk barriers; wall_clock64 (100 MHz): start, end; XCC id; units; per-stage cycle sums}. NULL = off */
 int crb_winograd2_set_debug(void* dev_buf_u64x16_per_wg);
-/* A/B: 1 (default) = the tail units of a launch with a workspace are split along the input channels, 0 = never */
-int crb_winograd2_set_split(int on);
-/* the round-4 forward kernel (csrc/winograd_conv2_r04.hip, measurement library only): same operands and weight image as
- * crb_conv3x3_winograd2_nhwc, for same-box A/B timings of the round-5 kernel */
-int crb_conv3x3_winograd2_nhwc_r04(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
-                                   const float* bias, int relu, void* stream);
+/* A/B: 1 = persistent workgroups (one per CU, contiguous unit ranges, one pipeline; default), 0 = one unit per workgroup */
+int crb_winograd2_set_persistent(int on);
 /* measurement builds of the Winograd weight gradient (wrong results): 1 = no MFMAs, 2 = no transforms, 3 = no DMA / gradient loads in the loop */
 int crb_winograd2_wgrad_set_mode(int mode);
 /* measurement builds of crb_tables_finish's chunk pass (wrong tables by design): bit 0 = no sort, bit 1 = no packed-index fill,

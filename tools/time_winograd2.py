@@ -76,46 +76,3 @@ if __name__ == '__main__':
                 tm.append(timeit(lambda: winograd.conv3x3_U2(x, U2, b))[0])
             lib.crb_winograd2_set_mode(0)
             print('   measurement builds: no MFMAs %.0f us, no transform %.0f us, no DMA in the loop %.0f us' % tuple(tm), flush=True)
-        ab = {0: [], 1: []}
-        for _ in range(3):
-            for mode in (0, 1):
-                lib.crb_winograd2_set_split(mode)
-                ab[mode].append(timeit(lambda: winograd.conv3x3_U2(x, U2, b), it=15, warm=3)[0])
-        lib.crb_winograd2_set_split(1)
-        print('   A/B tail units whole / split along the input channels: %s / %s us' % (['%.0f' % v for v in ab[0]], ['%.0f' % v for v in ab[1]]), flush=True)
-        # same-box A/B: the round-4 kernel (measurement library only) | this kernel
-        from crbhip import check, ptr, cur_stream
-        y4 = torch.empty_like(y)
-        xv = x.permute(0, 2, 3, 1)
-
-        def r04():
-            check(lib.crb_conv3x3_winograd2_nhwc_r04(xv.data_ptr(), ptr(U2), y4.data_ptr(), N, H, W, C, K, ptr(b), 0, cur_stream(dev)), 'r04')
-        r04()
-        same = bool(torch.equal(y4, y))
-        abk = {'r04': [], 'r05': []}
-        for _ in range(3):
-            abk['r04'].append(timeit(r04, it=15, warm=3)[0])
-            abk['r05'].append(timeit(lambda: winograd.conv3x3_U2(x, U2, b), it=15, warm=3)[0])
-        print('   A/B kernels (interleaved): %s; r04 output bit-equal to r05: %s' % (', '.join('%s %s us' % (k, ['%.0f' % v for v in vs]) for k, vs in abk.items()), same), flush=True)
-        if not quick:
-            # per-workgroup stamps
-            dbg = torch.zeros((256, 16), dtype=torch.int64, device=dev)
-            lib.crb_winograd2_set_debug(dbg.data_ptr())
-            lib.crb_winograd2_set_mode(4)
-            for _ in range(3):
-                dbg.zero_()
-                winograd.conv3x3_U2(x, U2, b)
-            torch.cuda.synchronize()
-            lib.crb_winograd2_set_mode(0)
-            lib.crb_winograd2_set_debug(None)
-            d = dbg.cpu().numpy().astype(np.int64)
-            d = d[d[:, 0] != 0]
-            chunks = np.maximum(d[:, 7], 1)
-            pro, loop = d[:, 1] - d[:, 0], d[:, 2] - d[:, 1]
-            wall = (d[:, 5] - d[:, 4]) * 10.0          # ns (100 MHz)
-            span = (d[:, 5].max() - d[:, 4].min()) * 0.01
-            clk = (d[:, 2] - d[:, 0]) / np.maximum(wall, 1.0)
-            print('   stamps (%d workgroups, %.1f chunks of whole units each): prologue %.0f cycles, %.0f cycles per chunk incl. output transforms and '
-                  'the tail part, parked at the barrier %.0f per chunk; workgroup wall %.1f us (max %.1f, min %.1f), clock %.2f GHz, kernel span %.0f us'
-                  % (len(d), chunks.mean(), pro.mean(), (loop / chunks).mean(), (d[:, 3] / chunks).mean(), wall.mean() / 1e3,
-                     wall.max() / 1e3, wall.min() / 1e3, clk.mean(), span), flush=True)
