@@ -339,10 +339,10 @@ __global__ __launch_bounds__(256) void bn_max_partial_kernel(const float* __rest
   if (tr < rlanes)
     for (int64_t m = m0 + tr; m < m1; m += rlanes) {
       const f4 g = *reinterpret_cast<const f4*>(gz + m * ld_g + c);
-      const int* ar = arg + m * C + c;
+      const int* ar = arg ? arg + m * C + c : nullptr;      // arg == NULL: x holds the selected row of every group (ns = 1)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float v = x[(m * ns + ar[k]) * C + c + k];
+        const float v = x[(m * ns + (ar ? ar[k] : 0)) * C + c + k];
         const float xh = (v - mu[k]) * is[k];
         const float d = (ga[k] * xh + be[k]) > 0.f ? g[k] : 0.f;
         a[k] += d;
@@ -739,6 +739,28 @@ extern "C" int crb_bn_relu_max_backward(const float* x, const float* gz, int64_t
   const int64_t total4 = n * C / 4;
   hipLaunchKernelGGL(bn_max_bwd_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, gz, ld, arg, mean, invstd,
                      gamma, beta, dbeta, dgamma, dx, total4, ns, C, 1.0f / (float)n);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_bn_relu_max_backward_sums(const float* x_sel, const float* gz, int64_t gz_row_stride, int64_t groups, int C,
+                                             const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                             float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
+                                             int32_t* tickets, void* stream) {
+  const int64_t ld = gz_row_stride > 0 ? gz_row_stride : C;
+  if (ld < C || (ld & 3) || !x_sel || !gz) return CRB_ERR_ARG;
+  if (groups <= 0 || C <= 0 || (C & 3) || C > 1024 || 256 % (C >> 2)) return CRB_ERR_ARG;
+  if (workspace_bytes < crb_bn_workspace_bytes(groups, C) - 256 || !workspace) return CRB_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int gpb = bn_rows_per_block(groups);
+  const int nblk = crb_cdiv(groups, gpb);
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL(bn_max_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * 16, st, x_sel, gz, ld, (const int*)nullptr, mean,
+                     invstd, gamma, beta, groups, 1, C, gpb, partial,
+                     bn_final(tickets, workspace, groups, C, 1, dbeta, dgamma, nullptr, nullptr, nullptr, 0.f, 0.f));
+  if (!tickets)
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, groups, 0.f, 1, dbeta, dgamma,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) void group_affine_rows_kernel(int B, int64_t M
         dy = xyz[(int64_t)row * 3 + 1] - new_xyz[(int64_t)m * 3 + 1];
         dz = xyz[(int64_t)row * 3 + 2] - new_xyz[(int64_t)m * 3 + 2];
       }
-      rel[p * 3 + 0] = dx; rel[p * 3 + 1] = dy; rel[p * 3 + 2] = dz;
+      if (rel) { rel[p * 3 + 0] = dx; rel[p * 3 + 1] = dy; rel[p * 3 + 2] = dz; }
     }
     srow[threadIdx.x] = row;
     sd[threadIdx.x][0] = dx; sd[threadIdx.x][1] = dy; sd[threadIdx.x][2] = dz;
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256) void group_affine_rows_kernel(int B, int64_t M
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = fmaf(w2[k], dz, fmaf(w1[k], dy, fmaf(w0[k], dx, v[k])));
       }
-      *reinterpret_cast<gf4*>(dst + pl * H + c) = v;
+      if (out) *reinterpret_cast<gf4*>(dst + pl * H + c) = v;    // out == NULL (with stat): statistics only (sa_mlp_train.hip pass 0)
       s1 += v;
       s2 += v * v;
     }
@@ -740,6 +740,12 @@ __global__ __launch_bounds__(256) void group_affine_rows_kernel(int B, int64_t M
 // backward is applied while the slab is loaded — dy = gamma invstd (d - dbeta/n - xhat dgamma/n), d = dz [z > 0], exactly
 // bn_bwd_apply_kernel's arithmetic — so the (M*nsample, H) gradient of y is never written and read back.
 struct GroupBn {
+  // RECOMP instances (crb_group_affine_rows_grad_bn_recompute_stack): y_rows / rel are not kept by the forward, the kernel forms
+  // them again from xyz, new_xyz, P, W1x exactly like group_affine_rows_kernel
+  const float* xyz;
+  const float* new_xyz;
+  const float* P;
+  const float* W1x;
   const float* y_rows;
   const float* mean;
   const float* invstd;
@@ -750,7 +756,7 @@ struct GroupBn {
   float inv_n;
 };
 
-template <int H, bool BN = false>
+template <int H, bool BN = false, bool RECOMP = false>
 __global__ __launch_bounds__(256) void group_affine_rows_grad_kernel(int B, int64_t MP, int ns,
                                                                      const int* __restrict__ xyz_cnt,
                                                                      const int* __restrict__ new_cnt,
@@ -767,6 +773,7 @@ __global__ __launch_bounds__(256) void group_affine_rows_grad_kernel(int B, int6
   __shared__ int first[64];
   __shared__ float sd[64][3];
   const int64_t p0 = (int64_t)blockIdx.x * 64;
+  int myrow = -1;
   if (threadIdx.x < 64) {
     const int64_t p = p0 + threadIdx.x;
     int row = -1;
@@ -777,11 +784,26 @@ __global__ __launch_bounds__(256) void group_affine_rows_grad_kernel(int B, int6
         int start;
         locate_batch(new_cnt, B, m, xyz_cnt, &start);
         row = start + idx[p];
-        dx = rel[p * 3 + 0]; dy = rel[p * 3 + 1]; dz = rel[p * 3 + 2];
+        myrow = row;
+        if constexpr (RECOMP) {
+          dx = bn.xyz[(int64_t)row * 3 + 0] - bn.new_xyz[(int64_t)m * 3 + 0];
+          dy = bn.xyz[(int64_t)row * 3 + 1] - bn.new_xyz[(int64_t)m * 3 + 1];
+          dz = bn.xyz[(int64_t)row * 3 + 2] - bn.new_xyz[(int64_t)m * 3 + 2];
+        } else {
+          dx = rel[p * 3 + 0]; dy = rel[p * 3 + 1]; dz = rel[p * 3 + 2];
+        }
       }
     }
     srow[threadIdx.x] = row;
     sd[threadIdx.x][0] = dx; sd[threadIdx.x][1] = dy; sd[threadIdx.x][2] = dz;
+  }
+  if constexpr (RECOMP) {
+    // the slab loads below need srow / sd. A slab of empty balls only has nothing to scatter and rel = 0, and its producer
+    // (sa_mlp_train.hip pass C) did not write its rows: zero part, done
+    if (!__syncthreads_or(myrow >= 0)) {
+      for (int e = threadIdx.x; e < 3 * H; e += 256) part[(int64_t)blockIdx.x * 3 * H + e] = 0.f;
+      return;
+    }
   }
   const int npl = (int)min((int64_t)64, MP - p0);
   const int c4 = threadIdx.x % H4, plane = threadIdx.x / H4;
@@ -800,10 +822,26 @@ __global__ __launch_bounds__(256) void group_affine_rows_grad_kernel(int B, int6
 #pragma unroll
   for (int i = 0; i < 64 / NPLANE; ++i) {
     const int pl = plane + i * NPLANE;
-    v[i] = pl < npl ? src[pl * H4 + c4] : (gf4){0.f, 0.f, 0.f, 0.f};
+    bool have = pl < npl;
+    if constexpr (RECOMP) have = have && srow[pl] >= 0;      // rows of empty balls were not written by the producer
+    v[i] = have ? src[pl * H4 + c4] : (gf4){0.f, 0.f, 0.f, 0.f};
     if constexpr (BN) {
-      if (pl < npl) {
-        const gf4 yv = reinterpret_cast<const gf4*>(bn.y_rows + p0 * H)[pl * H4 + c4];
+      if (have) {
+        gf4 yv;
+        if constexpr (RECOMP) {
+          yv = (gf4){0.f, 0.f, 0.f, 0.f};
+          const int row = srow[pl];
+          if (row >= 0) {
+            yv = *reinterpret_cast<const gf4*>(bn.P + (int64_t)row * H + 4 * c4);
+            const gf4 w0 = *reinterpret_cast<const gf4*>(bn.W1x + 4 * c4), w1 = *reinterpret_cast<const gf4*>(bn.W1x + H + 4 * c4),
+                      w2 = *reinterpret_cast<const gf4*>(bn.W1x + 2 * H + 4 * c4);
+            const float dx = sd[pl][0], dy = sd[pl][1], dz = sd[pl][2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) yv[k] = fmaf(w2[k], dz, fmaf(w1[k], dy, fmaf(w0[k], dx, yv[k])));
+          }
+        } else {
+          yv = reinterpret_cast<const gf4*>(bn.y_rows + p0 * H)[pl * H4 + c4];
+        }
         const gf4 xh = (yv - mu) * is;
         const gf4 z = ga * xh + be;
         gf4 d = v[i];
@@ -1222,6 +1260,7 @@ static int group_affine_rows_launch(int B, int64_t M, int H, int nsample, const 
                                     float* stat, void* stream) {
   if (B <= 0 || M < 0 || H <= 0 || nsample <= 0) return CRB_ERR_ARG;
   if (stat && H != 16 && H != 32 && H != 64 && H != 128) return CRB_ERR_UNSUPPORTED;
+  if (!out && !stat) return CRB_ERR_ARG;                     // out == NULL: statistics only (the compile-time-H instances)
   if (M == 0) return CRB_OK;
   const int64_t MP = M * nsample;
   const dim3 grid(crb_cdiv(MP, 64));
@@ -1278,11 +1317,38 @@ extern "C" int crb_group_affine_rows_grad_bn_stack(int B, int64_t M, int H, int 
   const int64_t MP = M * nsample;
   const dim3 grid(crb_cdiv(MP, 64));
   hipStream_t st = (hipStream_t)stream;
-  const GroupBn bn{y, mean, invstd, gamma, beta, dbeta, dgamma, 1.0f / (float)MP};
+  const GroupBn bn{nullptr, nullptr, nullptr, nullptr, y, mean, invstd, gamma, beta, dbeta, dgamma, 1.0f / (float)MP};
 #define CRB_GA_CASE(HH)                                                                                              \
   if (H == HH)                                                                                                       \
     hipLaunchKernelGGL((group_affine_rows_grad_kernel<HH, true>), grid, dim3(256), 0, st, B, MP, nsample, xyz_batch_cnt, \
                        new_xyz_batch_cnt, idx, empty_mask, rel, grad_z, grad_P, part, bn);
+  CRB_GA_CASE(16) CRB_GA_CASE(32) CRB_GA_CASE(64) CRB_GA_CASE(128)
+#undef CRB_GA_CASE
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+// the same without the forward's saved tensors (sa_mlp_train.hip pass D): y and rel are formed again from xyz / new_xyz / P / W1x
+extern "C" int crb_group_affine_rows_grad_bn_recompute_stack(int B, int64_t M, int H, int nsample, const float* xyz,
+                                                             const int32_t* xyz_batch_cnt, const float* P, const float* new_xyz,
+                                                             const int32_t* new_xyz_batch_cnt, const int32_t* idx,
+                                                             const uint8_t* empty_mask, const float* W1x, const float* grad_z,
+                                                             const float* mean, const float* invstd, const float* gamma,
+                                                             const float* beta, const float* dbeta, const float* dgamma,
+                                                             float* grad_P /* pre-zeroed */, float* part, void* stream) {
+  if (B <= 0 || M < 0 || H <= 0 || nsample <= 0 || !xyz || !P || !new_xyz || !W1x || !mean || !invstd || !gamma || !beta ||
+      !dbeta || !dgamma)
+    return CRB_ERR_ARG;
+  if (H != 16 && H != 32 && H != 64 && H != 128) return CRB_ERR_UNSUPPORTED;
+  if (M == 0) return CRB_OK;
+  const int64_t MP = M * nsample;
+  const dim3 grid(crb_cdiv(MP, 64));
+  hipStream_t st = (hipStream_t)stream;
+  const GroupBn bn{xyz, new_xyz, P, W1x, nullptr, mean, invstd, gamma, beta, dbeta, dgamma, 1.0f / (float)MP};
+#define CRB_GA_CASE(HH)                                                                                                    \
+  if (H == HH)                                                                                                             \
+    hipLaunchKernelGGL((group_affine_rows_grad_kernel<HH, true, true>), grid, dim3(256), 0, st, B, MP, nsample, xyz_batch_cnt, \
+                       new_xyz_batch_cnt, idx, empty_mask, (const float*)nullptr, grad_z, grad_P, part, bn);
   CRB_GA_CASE(16) CRB_GA_CASE(32) CRB_GA_CASE(64) CRB_GA_CASE(128)
 #undef CRB_GA_CASE
   CRB_CHECK_LAUNCH();

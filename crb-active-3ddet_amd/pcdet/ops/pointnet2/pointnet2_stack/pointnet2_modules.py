@@ -29,6 +29,9 @@ SPLIT_FIRST_LAYER = True   # training rows path: layer 1 = gather of per-source-
 FUSED_BN_MAX = True        # training rows path: last BatchNorm+ReLU, max over nsample and the concat of the scales in one op
 FUSED_FIRST_BN = True      # training rows path: first conv + BatchNorm + ReLU as one node, BN backward inside the gradient kernel
 FUSED_GROUP = True     # one HIP launch builds the (1, 3+C, M, ns) MLP input (False: QueryAndGroup + permute copy)
+# training, two-layer MLPs: the whole module as one autograd node that keeps no (M*ns, H) activation (csrc/sa_mlp_train.hip:
+# statistics passes recompute the layers from the ball-query indices); CRB_SA_TRAIN_FUSED=0 = the rows path below (A/B)
+FUSED_TRAIN = __import__('os').environ.get('CRB_SA_TRAIN_FUSED', '1') == '1'
 
 
 def build_local_aggregation_module(input_channels, config):
@@ -118,6 +121,24 @@ class StackSAModuleMSG(nn.Module):
                                                    xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, group=query_group)
         return [None] * len(gs)
 
+    def _train_fused_ok(self):
+        """every scale is Conv(1x1, no bias)-BN-ReLU-Conv(1x1, no bias)-BN-ReLU with train-mode BatchNorms and a shape the
+        recompute kernels have (widths 16 / 32 / 64, nsample a multiple of 16); per-frame statistics (batched CRB stage 2) keep
+        the rows path"""
+        if bnrelu.frame_groups_active():
+            return False
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            mods = list(mlp)
+            if len(mods) != 6 or mods[0].bias is not None or mods[3].bias is not None:
+                return False
+            for bn in (mods[1], mods[4]):
+                if not (bn.training and bn.momentum is not None and bn.affine and bn.track_running_stats and
+                        bn.running_mean.is_contiguous() and bn.running_var.is_contiguous()):
+                    return False
+            if not pointnet2_utils.sa_mlp2_train_supported(mods[0].out_channels, mods[3].out_channels, grouper.nsample):
+                return False
+        return True
+
     @staticmethod
     def _rows_ok(mlp, features):
         mods = list(mlp)
@@ -148,6 +169,9 @@ class StackSAModuleMSG(nn.Module):
                 and all(g.use_xyz for g in self.groupers) and all(self._rows_ok(m, features) for m in self.mlps):
             M = new_xyz.shape[0]
             balls = self._balls(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, query_group)
+            if FUSED_TRAIN and self.training and M > 0 and self._train_fused_ok():
+                return new_xyz, pointnet2_utils.sa_mlp2_train_concat(self.groupers, self.mlps, balls, xyz, xyz_batch_cnt, new_xyz,
+                                                                     new_xyz_batch_cnt, features)
             fuse_max = FUSED_BN_MAX and self.training and M > 0 and \
                 all(list(m)[-2].training and list(m)[-2].momentum is not None for m in self.mlps)
             for grouper, mlp, ball in zip(self.groupers, self.mlps, balls):

@@ -323,6 +323,157 @@ def grouped_first_layer_rows(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_x
     return GroupedFirstLayerRows.apply(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx, empty, weight)
 
 
+def sa_mlp2_train_supported(h1, h2, nsample):
+    return bool(lib.crb_sa_mlp2_train_supported(int(h1), int(h2), int(nsample)))
+
+
+class SAMlp2TrainConcat(Function):
+    """Training-mode StackSAModuleMSG body for two-layer shared MLPs, all scales of the module, as ONE autograd node writing
+    one (M, sum h2) matrix (pointnet2_modules.py:90-112: grouping -> Conv-BN-ReLU -> Conv-BN-ReLU -> max over nsample -> cat)
+    with no (M*nsample, h) activation kept or written in the forward: csrc/sa_mlp_train.hip (statistics passes recompute the
+    layers from the ball-query indices). The backward recomputes once more and materialises only the masked gradient of the
+    first layer's activation, one scale at a time.
+    args: xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, then per scale
+      idx, empty, W1 (h1, 3+C), gamma1, beta1, eps1, running_mean1, running_var1, momentum1, counter1,
+      W2 (h2, h1), gamma2, beta2, eps2, running_mean2, running_var2, momentum2, counter2"""
+    PER = 18
+
+    @staticmethod
+    def forward(ctx, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, *args):
+        from crbhip import bnrelu
+        PER = SAMlp2TrainConcat.PER
+        k = len(args) // PER
+        require_cuda(xyz, new_xyz, features)
+        dev = xyz.device
+        B, M = xyz_batch_cnt.shape[0], new_xyz.shape[0]
+        xc, nc = _i32(xyz_batch_cnt), _i32(new_xyz_batch_cnt)
+        xyz_c, new_c = xyz.contiguous().float(), new_xyz.contiguous().float()
+        feats = features.contiguous().float()
+        widths = [args[PER * i + 10].shape[0] for i in range(k)]
+        total = sum(widths)
+        out = torch.empty((M, total), dtype=torch.float32, device=dev)
+        st = cur_stream(dev)
+        saved, meta, col = [feats], [], 0
+        for i in range(k):
+            (idx, empty, W1, g1, b1, eps1, rm1, rv1, mom1, nbt1, W2, g2, b2, eps2, rm2, rv2, mom2, nbt2) = args[PER * i:PER * i + PER]
+            ns = idx.shape[1]
+            h1, h2 = W1.shape[0], W2.shape[0]
+            n = M * ns
+            idx = idx.contiguous()
+            em = empty.view(torch.uint8) if empty.dtype == torch.bool else empty.to(torch.uint8).contiguous()
+            W1 = W1.float()
+            w1x = W1[:, :3].t().contiguous()                   # (3, h1)
+            w1f = W1[:, 3:].contiguous()                       # (h1, C)
+            P = feats @ w1f.t()                                # (N, h1): layer 1 per SOURCE point
+            W2c = W2.contiguous().float()
+            g1c, b1c, g2c, b2c = (t.contiguous().float() for t in (g1, b1, g2, b2))
+
+            def stats(slabs, nslab, C, g, b, eps, rm, rv, nbt, mom):
+                mean = torch.empty((C,), dtype=torch.float32, device=dev)
+                var, invstd = torch.empty_like(mean), torch.empty_like(mean)
+                wsb = lib.crb_bn_workspace_bytes(n, C)
+                ws, tk = bnrelu._scratch(dev, wsb)
+                bnrelu._bn_check(lib.crb_bn_relu_forward_partials(None, n, C, ptr(slabs), nslab, ptr(g), ptr(b), float(eps), 1, None, 0,
+                                                                  ptr(mean), ptr(var), ptr(invstd), ptr(rm), ptr(rv), ptr(nbt),
+                                                                  float(mom), ptr(ws), wsb, ptr(tk), st),
+                                 'crb_bn_relu_forward_partials')
+                bnrelu._touch(rm, rv, nbt)
+                return mean, invstd
+            # pass 0: statistics of y1 (nothing written but the slab sums)
+            nslab = int(lib.crb_group_affine_rows_grad_blocks(M, ns))
+            slab1 = torch.empty((nslab, 2, h1), dtype=torch.float32, device=dev)
+            check(lib.crb_group_affine_rows_stats_stack(B, M, h1, ns, ptr(xyz_c), ptr(xc), ptr(P), ptr(new_c), ptr(nc), ptr(idx),
+                                                        ptr(em), ptr(w1x), None, None, ptr(slab1), st),
+                  'crb_group_affine_rows_stats_stack')
+            mean1, invstd1 = stats(slab1, nslab, h1, g1c, b1c, eps1, rm1, rv1, nbt1, mom1)
+            # pass A: statistics of y2
+            nwave = int(lib.crb_sa_mlp2_train_waves(M))
+            slab2 = torch.empty((nwave, 2, h2), dtype=torch.float32, device=dev)
+            check(lib.crb_sa_mlp2_train_stats(B, M, ns, h1, h2, ptr(xyz_c), ptr(xc), ptr(P), ptr(new_c), ptr(nc), ptr(idx), ptr(em),
+                                              ptr(w1x), ptr(mean1), ptr(invstd1), ptr(g1c), ptr(b1c), ptr(W2c), ptr(slab2), st),
+                  'crb_sa_mlp2_train_stats')
+            mean2, invstd2 = stats(slab2, nwave, h2, g2c, b2c, eps2, rm2, rv2, nbt2, mom2)
+            # pass B: the output
+            arg = torch.empty((M, h2), dtype=torch.int32, device=dev)
+            ysel = torch.empty((M, h2), dtype=torch.float32, device=dev)
+            check(lib.crb_sa_mlp2_train_max(B, M, ns, h1, h2, ptr(xyz_c), ptr(xc), ptr(P), ptr(new_c), ptr(nc), ptr(idx), ptr(em),
+                                            ptr(w1x), ptr(mean1), ptr(invstd1), ptr(g1c), ptr(b1c), ptr(W2c), ptr(mean2),
+                                            ptr(invstd2), ptr(g2c), ptr(b2c), ctypes.c_void_p(out.data_ptr() + 4 * col), total,
+                                            ptr(arg), ptr(ysel), st), 'crb_sa_mlp2_train_max')
+            saved += [idx, em, w1x, w1f, P, W2c, g1c, b1c, g2c, b2c, mean1, invstd1, mean2, invstd2, arg, ysel]
+            meta.append((ns, h1, h2, col))
+            col += h2
+        ctx.meta = (B, M, total, xc, nc, xyz_c, new_c, meta)
+        ctx.save_for_backward(*saved)
+        return out
+
+    @staticmethod
+    def backward(ctx, gz):
+        from crbhip import bnrelu
+        PER = SAMlp2TrainConcat.PER
+        B, M, total, xc, nc, xyz_c, new_c, meta = ctx.meta
+        saved = ctx.saved_tensors
+        feats = saved[0]
+        dev = gz.device
+        st = cur_stream(dev)
+        gz = gz.contiguous().float()
+        gfeat = None
+        grads = []
+        for i, (ns, h1, h2, col) in enumerate(meta):
+            (idx, em, w1x, w1f, P, W2c, g1c, b1c, g2c, b2c, mean1, invstd1, mean2, invstd2, arg, ysel) = saved[1 + 16 * i:17 + 16 * i]
+            n = M * ns
+            gp = ctypes.c_void_p(gz.data_ptr() + 4 * col)
+            # BatchNorm 2: dbeta / dgamma from the M x h2 selected entries
+            d2 = torch.empty((2, h2), dtype=torch.float32, device=dev)
+            wsb = lib.crb_bn_workspace_bytes(M, h2)
+            ws, tk = bnrelu._scratch(dev, wsb)
+            bnrelu._bn_check(lib.crb_bn_relu_max_backward_sums(ptr(ysel), gp, total, M, h2, ptr(mean2), ptr(invstd2), ptr(g2c), ptr(b2c),
+                                                               ptr(d2[1]), ptr(d2[0]), ptr(ws), wsb, ptr(tk), st),
+                             'crb_bn_relu_max_backward_sums')
+            # pass C
+            gz1 = torch.empty((n, h1), dtype=torch.float32, device=dev)
+            d1 = torch.empty((2, h1), dtype=torch.float32, device=dev)
+            dW2 = torch.empty((h2, h1), dtype=torch.float32, device=dev)
+            wsf = int(lib.crb_sa_mlp2_train_backward_workspace_floats(M, h1, h2))
+            wsp = torch.empty((wsf,), dtype=torch.float32, device=dev)
+            check(lib.crb_sa_mlp2_train_backward(B, M, ns, h1, h2, ptr(xyz_c), ptr(xc), ptr(P), ptr(new_c), ptr(nc), ptr(idx), ptr(em),
+                                                 ptr(w1x), ptr(mean1), ptr(invstd1), ptr(g1c), ptr(b1c), ptr(W2c), ptr(mean2),
+                                                 ptr(invstd2), ptr(g2c), ptr(b2c), gp, total, ptr(arg), ptr(d2[0]), ptr(d2[1]),
+                                                 ptr(gz1), ptr(d1), ptr(dW2), ptr(wsp), wsf, st), 'crb_sa_mlp2_train_backward')
+            # pass D: BatchNorm 1 backward inside the scatter kernel of the first layer
+            gP = torch.zeros((feats.shape[0], h1), dtype=torch.float32, device=dev)
+            part = torch.empty((int(lib.crb_group_affine_rows_grad_blocks(M, ns)), 3, h1), dtype=torch.float32, device=dev)
+            check(lib.crb_group_affine_rows_grad_bn_recompute_stack(B, M, h1, ns, ptr(xyz_c), ptr(xc), ptr(P), ptr(new_c), ptr(nc),
+                                                                    ptr(idx), ptr(em), ptr(w1x), ptr(gz1), ptr(mean1), ptr(invstd1),
+                                                                    ptr(g1c), ptr(b1c), ptr(d1[0]), ptr(d1[1]), ptr(gP), ptr(part), st),
+                  'crb_group_affine_rows_grad_bn_recompute_stack')
+            del gz1
+            if ctx.needs_input_grad[4]:
+                gf = gP @ w1f
+                gfeat = gf if gfeat is None else gfeat + gf
+            gW1 = torch.cat([part.sum(0).t(), gP.t() @ feats], dim=1)           # (h1, 3+C)
+            grads += [None, None, gW1, d1[1], d1[0], None, None, None, None, None,
+                      dW2, d2[1], d2[0], None, None, None, None, None]
+        return (None, None, None, None, gfeat) + tuple(grads)
+
+
+def sa_mlp2_train_concat(groupers, mlps, balls, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features):
+    """all scales of a StackSAModuleMSG in training mode through SAMlp2TrainConcat; mlps[i] = Sequential(Conv2d 1x1 (no bias),
+    BatchNorm2d, ReLU, Conv2d 1x1 (no bias), BatchNorm2d, ReLU) with both BatchNorms in training mode -> (M, sum h2)"""
+    from crbhip import bnrelu
+    args = []
+    for grouper, mlp, ball in zip(groupers, mlps, balls):
+        idx, empty = ball if ball is not None else ball_query(grouper.radius, grouper.nsample, xyz, xyz_batch_cnt, new_xyz,
+                                                                new_xyz_batch_cnt)
+        m = list(mlp)
+        for conv, bn in ((m[0], m[1]), (m[3], m[4])):
+            if conv is m[0]:
+                args += [idx, empty]
+            args += [conv.weight.flatten(1), bn.weight, bn.bias, bn.eps, bn.running_mean, bn.running_var, float(bn.momentum),
+                     bnrelu._counter(bn)]
+    return SAMlp2TrainConcat.apply(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, *args)
+
+
 def sa_mlp2_max_supported(h1, h2):
     return bool(lib.crb_sa_mlp2_max_supported(int(h1), int(h2)))
 

@@ -351,6 +351,54 @@ int crb_sa_mlp2_max_stack(int B, int64_t M, int nsample, int h1, int h2, const f
                           const int32_t* new_xyz_batch_cnt, const int32_t* idx, const uint8_t* empty_mask,
                           const float* W1x, const float* b1, const float* W2, const float* b2, float* out,
                           int out_stride, void* stream);
+/* TRAINING-mode fused set abstraction of one radius (round 5): the body of StackSAModuleMSG.forward for a two-layer shared MLP
+ * (pointnet2_modules.py:90-108: Conv2d 1x1 -> BatchNorm2d -> ReLU -> Conv2d 1x1 -> BatchNorm2d -> ReLU -> max_pool2d over nsample;
+ * RoI-grid pooling: pvrcnn_head.py:102-113) without any (M*nsample, h) activation in memory. Train-mode BatchNorm needs the
+ * full-tensor statistics of a layer before the next one can run, so the forward is three recompute passes over the ball-query
+ * result:  (0) crb_group_affine_rows_stats_stack with out = rel = NULL -> slab sums of y1 -> crb_bn_relu_forward_partials(z = NULL);
+ * (A) crb_sa_mlp2_train_stats -> wave_sums (crb_sa_mlp2_train_waves(M), 2, h2): column sums of y2, y2^2 per wave ->
+ * crb_bn_relu_forward_partials(z = NULL);  (B) crb_sa_mlp2_train_max -> out[m*out_row_stride + c] = max over the samples of
+ * relu(bn2(y2)), arg (M,h2) = the sample that attains it (lowest index on ties, as crb_bn_relu_max_forward), y_sel (M,h2) = y2 there.
+ * W1x (3,h1), W2 (h2,h1) = the second conv's weight, P = features @ W1f^T (N,h1), mean / invstd = batch statistics,
+ * gamma / beta = the BatchNorm parameters. h1, h2 in {16,32,64}, nsample a multiple of 16, M*nsample < 2^31. */
+int crb_sa_mlp2_train_supported(int h1, int h2, int nsample);
+int64_t crb_sa_mlp2_train_waves(int64_t M);
+int crb_sa_mlp2_train_stats(int B, int64_t M, int nsample, int h1, int h2, const float* xyz,
+                            const int32_t* xyz_batch_cnt, const float* P, const float* new_xyz,
+                            const int32_t* new_xyz_batch_cnt, const int32_t* idx, const uint8_t* empty_mask,
+                            const float* W1x, const float* mean1, const float* invstd1, const float* gamma1,
+                            const float* beta1, const float* W2, float* wave_sums, void* stream);
+int crb_sa_mlp2_train_max(int B, int64_t M, int nsample, int h1, int h2, const float* xyz,
+                          const int32_t* xyz_batch_cnt, const float* P, const float* new_xyz,
+                          const int32_t* new_xyz_batch_cnt, const int32_t* idx, const uint8_t* empty_mask,
+                          const float* W1x, const float* mean1, const float* invstd1, const float* gamma1,
+                          const float* beta1, const float* W2, const float* mean2, const float* invstd2,
+                          const float* gamma2, const float* beta2, float* out, int64_t out_row_stride, int32_t* arg,
+                          float* y_sel, void* stream);
+/* backward of the above (autograd of the same module lines). Caller first reduces dbeta2 / dgamma2 from the selected entries
+ * (crb_bn_relu_max_backward_sums on y_sel). This pass recomputes y1, z1, y2, forms dy2 (BatchNorm-2 backward of the max's scatter)
+ * in registers, and produces: grad_z1_masked (M*nsample, h1) = (dy2 W2) [z1 > 0], dsums1 (2, h1) = its column sums and its column
+ * sums times xhat1 (dbeta1, dgamma1), dW2 (h2, h1). The first layer's own backward then is
+ * crb_group_affine_rows_grad_bn_recompute_stack. workspace: crb_sa_mlp2_train_backward_workspace_floats(M, h1, h2) floats. */
+int64_t crb_sa_mlp2_train_backward_workspace_floats(int64_t M, int h1, int h2);
+int crb_sa_mlp2_train_backward(int B, int64_t M, int nsample, int h1, int h2, const float* xyz,
+                               const int32_t* xyz_batch_cnt, const float* P, const float* new_xyz,
+                               const int32_t* new_xyz_batch_cnt, const int32_t* idx, const uint8_t* empty_mask,
+                               const float* W1x, const float* mean1, const float* invstd1, const float* gamma1,
+                               const float* beta1, const float* W2, const float* mean2, const float* invstd2,
+                               const float* gamma2, const float* beta2, const float* grad_out,
+                               int64_t grad_row_stride, const int32_t* arg, const float* dbeta2, const float* dgamma2,
+                               float* grad_z1_masked, float* dsums1, float* dW2, float* workspace,
+                               int64_t workspace_floats, void* stream);
+/* crb_group_affine_rows_grad_bn_stack without the saved forward tensors: y (the first conv's output) and rel are recomputed from
+ * xyz / new_xyz / P / W1x exactly as crb_group_affine_rows_stack forms them. */
+int crb_group_affine_rows_grad_bn_recompute_stack(int B, int64_t M, int H, int nsample, const float* xyz,
+                                                  const int32_t* xyz_batch_cnt, const float* P, const float* new_xyz,
+                                                  const int32_t* new_xyz_batch_cnt, const int32_t* idx,
+                                                  const uint8_t* empty_mask, const float* W1x, const float* grad_z,
+                                                  const float* mean, const float* invstd, const float* gamma,
+                                                  const float* beta, const float* dbeta, const float* dgamma, float* grad_P,
+                                                  float* part, void* stream);
 /* xyz (B,n,3) -> out_idx (B,m); first pick is index 0; ties resolved like the reference kernel (see source).
  * temp: (B,n) f32 scratch for the running distances (the reference's `temp` argument); only needed for n > 40960
  * (below that the distances stay in registers) and may be NULL otherwise. */
@@ -461,6 +509,12 @@ int crb_bn_relu_max_backward(const float* x, const float* gz, int64_t gz_row_str
                              int ns, int C, const float* mean, const float* invstd, const float* gamma, const float* beta,
                              float* dx, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
                              int32_t* tickets, void* stream);
+/* the reduction half of crb_bn_relu_max_backward alone, for a caller that kept only the selected entries: x_sel (groups, C) = the
+ * BatchNorm input at each group's arg row (crb_sa_mlp2_train_max's y_sel), gz as above -> dbeta = sum gz [z > 0],
+ * dgamma = sum gz [z > 0] xhat. workspace: crb_bn_workspace_bytes(groups, C). */
+int crb_bn_relu_max_backward_sums(const float* x_sel, const float* gz, int64_t gz_row_stride, int64_t groups, int C,
+                                  const float* mean, const float* invstd, const float* gamma, const float* beta, float* dgamma,
+                                  float* dbeta, void* workspace, int64_t workspace_bytes, int32_t* tickets, void* stream);
 /* Per-frame statistics (batched CRB stage 2: G frames per train-mode pass, every BatchNorm layer normalising each frame
  * with that frame's own batch statistics like G bs=1 passes, crb_sampling.py:174-212): four launches for all frames
  * (partial sums / finalize / running update / apply, a frame's rows cut into the blocks a single-frame call would use and

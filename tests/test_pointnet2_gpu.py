@@ -269,14 +269,16 @@ def test_sa_module_rows_training_path_equals_module_path(dev):
     f2 = f1.detach().clone().requires_grad_(True)
     go = torch.randn(800, c_out, device=dev)
     assert M.ROWS_TRAIN
-    _, a = layer(xyz, xc, new, nc, f1)
-    a.backward(go)
-    M.ROWS_TRAIN = False
+    M.FUSED_TRAIN, fused = False, M.FUSED_TRAIN             # this test pins the rows path; the fused node has its own below
     try:
+        _, a = layer(xyz, xc, new, nc, f1)
+        a.backward(go)
+        M.ROWS_TRAIN = False
         _, b = ref(xyz, xc, new, nc, f2)
         b.backward(go)
     finally:
         M.ROWS_TRAIN = True
+        M.FUSED_TRAIN = fused
     torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
 
     def same_up_to_relu_flips(g1, g2, what):
@@ -291,6 +293,78 @@ def test_sa_module_rows_training_path_equals_module_path(dev):
         same_up_to_relu_flips(p1.grad, p2.grad, n1)
     for (n1, b1), (n2, b2) in zip(layer.named_buffers(), ref.named_buffers()):
         torch.testing.assert_close(b1.float(), b2.float(), rtol=1e-4, atol=1e-5, msg=lambda m, n1=n1: n1 + ': ' + m)
+
+
+@pytest.mark.parametrize('mlps,nsample', [([[32, 32], [64, 64]], [16, 16]), ([[16, 16], [16, 32]], [16, 32]),
+                                          ([[64, 32], [32, 64]], [32, 16])])
+def test_sa_module_fused_training_node_equals_module_and_rows_paths(dev, mlps, nsample):
+    """training, two-layer MLPs: the recompute node (csrc/sa_mlp_train.hip: no (M*ns, H) activation kept) against the
+    Conv2d / BatchNorm2d / max_pool2d modules (outputs 1e-4, gradients up to ReLU flips, running statistics 1e-4) and against the
+    rows path (same arithmetic for layer 1 and the BatchNorms, MFMA instead of rocBLAS for layer 2: outputs 2e-5); bit-equal
+    re-runs; empty balls, two frames, nsample 16 and 32."""
+    import copy
+    from pcdet.config import EasyDict
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_modules as M
+    torch.manual_seed(4)
+    layer, c_out = M.build_local_aggregation_module(20, EasyDict({'MLPS': mlps, 'POOL_RADIUS': [0.8, 1.6], 'NSAMPLE': nsample}))
+    layer = layer.to(dev).train()
+    with torch.no_grad():                                   # BatchNorm parameters away from (1, 0), some gammas negative
+        for m in layer.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(torch.randn_like(m.weight) * 0.5 + 0.8)
+                m.bias.copy_(torch.randn_like(m.bias) * 0.3)
+    ref, rows, again = copy.deepcopy(layer), copy.deepcopy(layer), copy.deepcopy(layer)
+    pts, off, _ = kitti_batch(2, 7, n_points=6000)
+    xyz = _t(np.ascontiguousarray(pts[:, :3]), dev)
+    xc = _t(np.diff(off).astype(np.int32), dev)
+    rng = np.random.default_rng(2)
+    sel = np.concatenate([rng.choice(6000, 500, replace=False), 6000 + rng.choice(6000, 301, replace=False)])
+    new = xyz[torch.from_numpy(sel).to(dev)].contiguous()
+    new[::6] += 55.0
+    nc = torch.tensor([500, 301], dtype=torch.int32, device=dev)
+    feats = [torch.randn(12000, 20, device=dev).requires_grad_(True)]
+    feats += [feats[0].detach().clone().requires_grad_(True) for _ in range(3)]
+    go = torch.randn(801, c_out, device=dev)
+    assert M.ROWS_TRAIN and M.FUSED_TRAIN and layer._train_fused_ok()
+    _, a = layer(xyz, xc, new, nc, feats[0])
+    assert type(a.grad_fn).__name__ == 'SAMlp2TrainConcatBackward'
+    a.backward(go)
+    _, a2 = again(xyz, xc, new, nc, feats[3])
+    a2.backward(go)
+    try:
+        M.FUSED_TRAIN = False
+        _, r = rows(xyz, xc, new, nc, feats[2])
+        r.backward(go)
+        M.ROWS_TRAIN = False
+        _, b = ref(xyz, xc, new, nc, feats[1])
+        b.backward(go)
+    finally:
+        M.ROWS_TRAIN = True
+        M.FUSED_TRAIN = True
+    # re-run: outputs, BatchNorm gradients and the second conv's weight gradient come from ordered partial sums (bit-equal); the
+    # feature gradient and the first conv's weight gradient pass through the float atomics of the scatter into dP (as on the rows
+    # path) and agree to rounding
+    assert torch.equal(a, a2)
+    for (n1, p1), (n2, p2) in zip(layer.named_parameters(), again.named_parameters()):
+        if n1.endswith('.0.weight'):
+            torch.testing.assert_close(p1.grad, p2.grad, rtol=1e-5, atol=1e-5 * float(p2.grad.abs().max()))
+        else:
+            assert torch.equal(p1.grad, p2.grad), n1
+    torch.testing.assert_close(feats[0].grad, feats[3].grad, rtol=1e-5, atol=1e-5 * float(feats[3].grad.abs().max()))
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(a, r, rtol=2e-5, atol=2e-5)
+
+    def same_up_to_relu_flips(g1, g2, what):
+        d, scale = (g1 - g2).abs(), max(1.0, float(g2.abs().max()))
+        assert float(d.median()) < 1e-3 * scale, what
+        assert float((d > 5e-3 * scale).float().mean()) < 0.02, what
+        assert float(d.norm() / g2.norm().clamp_min(1e-12)) < 2e-2, what
+    for other, fo, tag in ((ref, feats[1], 'modules'), (rows, feats[2], 'rows')):
+        same_up_to_relu_flips(feats[0].grad, fo.grad, tag + ': feature grad')
+        for (n1, p1), (n2, p2) in zip(layer.named_parameters(), other.named_parameters()):
+            same_up_to_relu_flips(p1.grad, p2.grad, tag + ': ' + n1)
+        for (n1, b1), (n2, b2) in zip(layer.named_buffers(), other.named_buffers()):
+            torch.testing.assert_close(b1.float(), b2.float(), rtol=1e-4, atol=1e-5, msg=lambda m, n1=n1: tag + ' ' + n1 + ': ' + m)
 
 
 def test_grouped_first_layer_rows_equals_group_then_gemm(dev):
