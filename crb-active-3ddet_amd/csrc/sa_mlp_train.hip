@@ -70,16 +70,6 @@ struct SaTrainArgs {
   float* partW;            // (blocks, H2, H1)
 };
 
-__device__ __forceinline__ int sat_locate(const int* __restrict__ cnt, int B, int64_t i, const int* __restrict__ other_cnt) {
-  int acc = cnt[0], os = 0;
-  for (int k = 1; k < B; ++k) {
-    if (i < acc) break;
-    acc += cnt[k];
-    os += other_cnt[k - 1];
-  }
-  return os;
-}
-
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
@@ -161,46 +151,62 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
   __syncthreads();
 
   const int ns = a.ns, T = ns >> 4;                    // ns is a multiple of 16 (host check)
-  const int64_t M = a.M, nw = (int64_t)gridDim.x * 4, w0 = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t ntile = M * T;
+  const int M = (int)a.M, nw = (int)gridDim.x * 4, w0 = (int)blockIdx.x * 4 + wave;     // M * ns < 2^31 (host check)
 
-  struct StA { int row; float cx, cy, cz; };
-  struct StB { f4 p[MB]; float dx, dy, dz; int row; };
-  auto load_a = [&](int64_t tile) {
+  // software pipeline over this wave's tiles (query w0 + k nw, row tile t): the cursor two tiles ahead ISSUES the loads of the
+  // sample index, the empty flag and the query centre (stage A: nothing it loads is looked at in the same iteration - a wait there
+  // would also wait for the P rows just requested), one tile ahead the source row is formed from them and the P row slice and the
+  // point are requested (stage B). The query index is wave-uniform (scalar register); a wave's queries ascend, so the frame of
+  // the cursor advances with it (first source row of the frame: `start`) instead of being searched per tile.
+  struct Cur { int q, t, b, fend, start; };
+  auto advance = [&](Cur& c) {
+    if (++c.t == T) { c.t = 0; c.q += nw; }
+  };
+  struct StA { int idxv, emp, start; float cx, cy, cz; bool valid; };
+  struct StB { f4 p[MB]; float px, py, pz, cx, cy, cz; int row; };   // the offset px - cx is formed where it is used
+  auto load_a = [&](Cur& c) {
     StA s;
-    s.row = -1; s.cx = s.cy = s.cz = 0.f;
-    if (tile < ntile) {
-      const int64_t q = tile / T;
-      const int t = (int)(tile - q * T);
-      if (!a.empty[q]) s.row = sat_locate(a.new_cnt, a.B, q, a.xyz_cnt) + a.idx[q * ns + 16 * t + r];
-      s.cx = a.new_xyz[q * 3 + 0]; s.cy = a.new_xyz[q * 3 + 1]; s.cz = a.new_xyz[q * 3 + 2];
+    s.idxv = 0; s.emp = 1; s.start = 0; s.cx = s.cy = s.cz = 0.f;
+    const int q = __builtin_amdgcn_readfirstlane(c.q);
+    s.valid = q < M;
+    if (s.valid) {
+      int bb = __builtin_amdgcn_readfirstlane(c.b), fe = __builtin_amdgcn_readfirstlane(c.fend),
+          st = __builtin_amdgcn_readfirstlane(c.start);
+      while (q >= fe && bb + 1 < a.B) {
+        st += a.xyz_cnt[bb];
+        ++bb;
+        fe += a.new_cnt[bb];
+      }
+      c.b = bb; c.fend = fe; c.start = st;
+      s.start = st;
+      s.emp = a.empty[q];
+      s.idxv = a.idx[(int64_t)q * ns + 16 * c.t + r];
+      s.cx = a.new_xyz[(int64_t)q * 3 + 0]; s.cy = a.new_xyz[(int64_t)q * 3 + 1]; s.cz = a.new_xyz[(int64_t)q * 3 + 2];
     }
     return s;
   };
   auto load_b = [&](const StA& s) {
     StB b;
-    b.row = s.row;
-    b.dx = b.dy = b.dz = 0.f;
+    b.row = (s.valid && !s.emp) ? s.start + s.idxv : -1;
+    b.px = b.py = b.pz = 0.f;
+    b.cx = s.cx; b.cy = s.cy; b.cz = s.cz;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) b.p[mb] = f4{0.f, 0.f, 0.f, 0.f};
-    if (s.row >= 0) {
-      const float* src = a.P + (int64_t)s.row * H1 + 4 * g;
+    if (b.row >= 0) {
+      const float* src = a.P + (int64_t)b.row * H1 + 4 * g;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) b.p[mb] = *reinterpret_cast<const f4*>(src + 16 * mb);
-      b.dx = a.xyz[(int64_t)s.row * 3 + 0] - s.cx;
-      b.dy = a.xyz[(int64_t)s.row * 3 + 1] - s.cy;
-      b.dz = a.xyz[(int64_t)s.row * 3 + 2] - s.cz;
+      b.px = a.xyz[(int64_t)b.row * 3 + 0];
+      b.py = a.xyz[(int64_t)b.row * 3 + 1];
+      b.pz = a.xyz[(int64_t)b.row * 3 + 2];
     }
     return b;
-  };
-  auto tile_of = [&](int64_t i) {
-    const int64_t q = w0 + (i / T) * nw;
-    return q < M ? q * T + (i % T) : ntile;
   };
 
   // ---- the tile's arithmetic, shared by the modes
   // layer 1: y1 -> xhat1 -> z1 in the (sample r, channels 16 mb + 4 g + j) layout; live = false: the zero grouped row of an empty ball
   auto layer1 = [&](const StB& b, bool live, f4 (&z1)[MB], f4 (&xh1)[MB]) {
+    const float dx = b.px - b.cx, dy = b.py - b.cy, dz = b.pz - b.cz;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       const int c = 16 * mb + 4 * g;
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
       f4 y = f4{0.f, 0.f, 0.f, 0.f};
       if (live) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) y[k] = fmaf(w2v[k], b.dz, fmaf(w1v[k], b.dy, fmaf(w0v[k], b.dx, b.p[mb][k])));
+        for (int k = 0; k < 4; ++k) y[k] = fmaf(w2v[k], dz, fmaf(w1v[k], dy, fmaf(w0v[k], dx, b.p[mb][k])));
       }
       const f4 mu = *reinterpret_cast<const f4*>(sBn1 + c), is = *reinterpret_cast<const f4*>(sBn1 + H1 + c),
                ga = *reinterpret_cast<const f4*>(sBn1 + 2 * H1 + c), be = *reinterpret_cast<const f4*>(sBn1 + 3 * H1 + c);
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
   // An empty ball's 16 (or 32) rows are equal: z1, y2, z2 are per-launch constants. The forward modes never run them through
   // the MFMA; MODE 2 reduces their whole contribution to one H2-vector per wave (below).
   StB b_zero;
-  b_zero.row = -1; b_zero.dx = b_zero.dy = b_zero.dz = 0.f;
+  b_zero.row = -1; b_zero.px = b_zero.py = b_zero.pz = b_zero.cx = b_zero.cy = b_zero.cz = 0.f;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) b_zero.p[mb] = f4{0.f, 0.f, 0.f, 0.f};
   if constexpr (MODE >= 1) {
@@ -352,14 +358,16 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
     if constexpr (MODE == 1) __syncthreads();
   }
 
-  StA a_nxt = load_a(tile_of(0));
+  Cur cur{w0, 0, 0, a.new_cnt[0], 0};
+  StA a_nxt = load_a(cur);
   StB b_cur = load_b(a_nxt);
-  a_nxt = load_a(tile_of(1));
-  int64_t i = 0;
-  for (int64_t q = w0; q < M; q += nw) {
-    for (int t = 0; t < T; ++t, ++i) {
+  advance(cur);
+  a_nxt = load_a(cur);
+  for (int q = w0; q < M; q += nw) {
+    for (int t = 0; t < T; ++t) {
       StB b_nxt = load_b(a_nxt);
-      a_nxt = load_a(tile_of(i + 2));
+      advance(cur);
+      a_nxt = load_a(cur);
       // MODE 1 carries 48 registers of running maxima: keep the loop-invariant LDS reads (operand image, parameters) inside the
       // loop instead of hoisted into registers (78 spills otherwise)
       if constexpr (MODE == 1) asm volatile("" ::: "memory");
@@ -371,9 +379,9 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
               const int c = 16 * nb + 4 * g;
-              *reinterpret_cast<f4*>(a.out + q * a.ld_out + c) = *reinterpret_cast<const f4*>(sCon + H2 + c);
-              *reinterpret_cast<i4*>(a.arg + q * H2 + c) = i4{0, 0, 0, 0};
-              *reinterpret_cast<f4*>(a.ysel + q * H2 + c) = *reinterpret_cast<const f4*>(sCon + c);
+              *reinterpret_cast<f4*>(a.out + (int64_t)q * a.ld_out + c) = *reinterpret_cast<const f4*>(sCon + H2 + c);
+              *reinterpret_cast<i4*>(a.arg + (int64_t)q * H2 + c) = i4{0, 0, 0, 0};
+              *reinterpret_cast<f4*>(a.ysel + (int64_t)q * H2 + c) = *reinterpret_cast<const f4*>(sCon + c);
             }
           }
         }
@@ -383,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
               const int c = 16 * nb + 4 * g;
-              const f4 gs = *reinterpret_cast<const f4*>(a.gout + q * a.ld_g + c);
+              const f4 gs = *reinterpret_cast<const f4*>(a.gout + (int64_t)q * a.ld_g + c);
               const f4 is = *reinterpret_cast<const f4*>(sBn2 + H2 + c), ga = *reinterpret_cast<const f4*>(sBn2 + 2 * H2 + c);
               f4 d;
 #pragma unroll
@@ -431,9 +439,9 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
 #pragma unroll
               for (int nb = 0; nb < NB; ++nb) {
                 const int c = 16 * nb + 4 * g;
-                *reinterpret_cast<f4*>(a.out + q * a.ld_out + c) = runz[nb];
-                *reinterpret_cast<i4*>(a.arg + q * H2 + c) = abest[nb];
-                *reinterpret_cast<f4*>(a.ysel + q * H2 + c) = ybest[nb];
+                *reinterpret_cast<f4*>(a.out + (int64_t)q * a.ld_out + c) = runz[nb];
+                *reinterpret_cast<i4*>(a.arg + (int64_t)q * H2 + c) = abest[nb];
+                *reinterpret_cast<f4*>(a.ysel + (int64_t)q * H2 + c) = ybest[nb];
               }
             }
 #pragma unroll
@@ -445,8 +453,8 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
             const int c = 16 * nb + 4 * g;
-            const f4 gs = *reinterpret_cast<const f4*>(a.gout + q * a.ld_g + c);
-            const i4 av = *reinterpret_cast<const i4*>(a.arg + q * H2 + c);
+            const f4 gs = *reinterpret_cast<const f4*>(a.gout + (int64_t)q * a.ld_g + c);
+            const i4 av = *reinterpret_cast<const i4*>(a.arg + (int64_t)q * H2 + c);
             const f4 is = *reinterpret_cast<const f4*>(sBn2 + H2 + c), ga = *reinterpret_cast<const f4*>(sBn2 + 2 * H2 + c);
             const f4 db = *reinterpret_cast<const f4*>(sD2 + c), dg = *reinterpret_cast<const f4*>(sD2 + H2 + c);
             f4 d;
@@ -454,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
             for (int k = 0; k < 4; ++k) d[k] = (z2[nb][k] > 0.f && av[k] == smp) ? gs[k] : 0.f;
             dy2[nb] = ga * is * (d - db - xh2[nb] * dg);
           }
-          float* grow = a.gz1 + (q * ns + smp) * H1 + 4 * g;
+          float* grow = a.gz1 + ((int64_t)q * ns + smp) * H1 + 4 * g;
           bwd_tile(dy2, z1, xh1, grow);
         }
       }

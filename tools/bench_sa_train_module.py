@@ -76,6 +76,13 @@ for tag, flag in (('recompute node', True), ('rows path', False)):
     for e in sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:14]:
         print('   %9.1f us  x%-3d %s' % (e.device_time_total / 3, e.count // 3, e.key[:120]))
 M.FUSED_TRAIN = True
+with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    fwd_bwd()
+    torch.cuda.synchronize()
+print('recompute node, launches of one forward+backward in order (us):')
+evs = sorted([e for e in prof.events() if e.device_time_total > 0 and ('sa_train' in e.name or 'group_affine' in e.name)], key=lambda e: e.time_range.start)
+print('   ' + ', '.join('%s %.0f' % (e.name.split('(')[0].split('::')[-1][:34], e.device_time_total) for e in evs))
+print('empty balls: %s of the queries at r = 0.8 / 1.6' % ', '.join('%.3f' % float(bl[1].float().mean()) for bl in layer._balls(xyz, xc, new, nc, G3)))
 a, b = res['recompute node'], res['rows path']
 print('recompute vs rows: output max |diff| %.2e (scale %.2e)' % (float((a[0] - b[0]).abs().max()), float(b[0].abs().max())))
 for k, (x, y) in enumerate(zip(a[1], b[1])):
