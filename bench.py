@@ -48,6 +48,9 @@ def parse():
     ap.add_argument('--kind', default='kitti', choices=['kitti', 'waymo'])
     ap.add_argument('--pool', type=int, default=2, help='distinct resident batches cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-sparse-prefetch', action='store_true',
+                    help='A/B: do not software-pipeline the next batch\'s voxel generator + table-plan marks behind this batch\'s forward '
+                         'pass (Detector3DTemplate.prefetch_sparse); every step then reads the counts back in its sparse phase')
     ap.add_argument('--nchw', action='store_true', help='A/B: NCHW memory format for the dense BEV part')
     ap.add_argument('--bf16x3-steps', type=int, default=0, help='extra steps under the opt-in split-bf16 gather-GEMM (second roofline); 0 = skip')
     ap.add_argument('--miopen-steps', type=int, default=6, help='A/B: extra steps (and one resident scoring pass) with MIOpen\'s implicit GEMM '
@@ -546,9 +549,15 @@ def pvrcnn_bench(args, rank, world, device):
     for b in batches:
         b['point_frame_counts_host'] = np.diff(b['point_frame_offsets'].cpu().numpy()).tolist()
 
+    ahead = {}                                   # step index -> batch dict whose sparse prologue is already enqueued
+
     def step(i):
+        b = ahead.pop(i, None) or dict(batches[i % len(batches)])
         opt.zero_grad(set_to_none=True)
-        ret, tb, _ = net(dict(batches[i % len(batches)]))
+        ret, tb, _ = net(b)
+        if not args.no_sparse_prefetch:          # the next batch's voxel generator + table marks, enqueued before this backward pass
+            ahead.clear()
+            ahead[i + 1] = model.prefetch_sparse(dict(batches[(i + 1) % len(batches)]))
         loss = ret['loss'].mean()
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
@@ -636,10 +645,18 @@ def main():
                                                         bucket_cap_mb=DDP_BUCKET_MB)
     batches = make_batches(args, rank, device)
 
+    ahead = {}                                   # step index -> batch dict whose sparse prologue is already enqueued
+
     def step(i, optimizer=True):
-        b = dict(batches[i % len(batches)])
+        b = ahead.pop(i, None) or dict(batches[i % len(batches)])
         opt.zero_grad(set_to_none=True)
         ret, tb, _ = net(b)
+        if not args.no_sparse_prefetch:
+            # loader-side work of the NEXT step (voxel generator, marking half of the table plan) goes into the queue before this
+            # step's backward pass; its counts reach pinned memory long before the next forward pass asks for them
+            # (Detector3DTemplate.prefetch_sparse). Same work per step, no read-back stall in the sparse phase.
+            ahead.clear()
+            ahead[i + 1] = model.prefetch_sparse(dict(batches[(i + 1) % len(batches)]))
         loss = ret['loss'].mean()
         loss.backward()
         if optimizer:

@@ -296,7 +296,73 @@ def _host_i64(vals):
     return (ctypes.c_int64 * len(vals))(*[int(v) for v in vals])
 
 
-def build_rulebooks(coords, shape, batch_size, specs, want_grad=True, n_dev=None):
+class PendingChain(object):
+    """First half of build_rulebooks(..., n_dev=...) issued AHEAD of time (begin_rulebooks): the output sets of the strided convs are
+    marked and counted on the device and the counts (+ the voxel count) travel to pinned host memory behind an event. The second
+    half (build_rulebooks(pending=...)) waits for the event - long past when the marks were enqueued before a whole backward pass -
+    instead of stalling the host, and with it the launch queue, in the middle of the forward pass."""
+    __slots__ = ('coords', 'shape', 'batch_size', 'specs', 'state', 'host', 'event')
+
+    def counts(self):
+        self.event.synchronize()
+        return self.host.tolist()
+
+
+def _chain_mark(coords, shape, batch_size, strided, n_dev, st):
+    """bitmaps + per-level counts of the chain of strided convs (device only, no read-back) -> state dict"""
+    dev = coords.device
+    L = len(strided)
+    if L > 8:
+        raise CrbHipError('more than 8 strided convs in one chain')
+    geoms, oshapes, cur = [], [], list(shape)
+    for _, ks, sd, pd in strided:
+        o = conv_out_shape(cur, ks, sd, pd)
+        if min(o) <= 0:
+            raise CrbHipError(f'sparse conv output shape {o} is empty')
+        geoms += ks + sd + pd
+        oshapes.append(o)
+        cur = o
+    flat_shapes = _host_i32([v for o in oshapes for v in o])
+    word_off = [0]
+    for o in oshapes:
+        word_off.append(word_off[-1] + lib.crb_spconv_padded_words(batch_size, host_i32x3(o)))
+    woff = _host_i64(word_off)
+    bitmap_all = torch.empty((word_off[-1],), dtype=torch.int32, device=dev)
+    tile_sums = torch.empty((word_off[-1] // 2048,), dtype=torch.int32, device=dev)
+    counts = torch.empty((L,), dtype=torch.int32, device=dev)
+    if n_dev is not None:
+        check(lib.crb_spconv_chain_mark_lazy(ptr(coords), coords.shape[0], ptr(n_dev), batch_size, host_i32x3(shape), L,
+                                             _host_i32(geoms), flat_shapes, woff, ptr(bitmap_all), ptr(tile_sums), ptr(counts), st),
+              'crb_spconv_chain_mark_lazy')
+    else:
+        check(lib.crb_spconv_chain_mark(ptr(coords), coords.shape[0], batch_size, host_i32x3(shape), L, _host_i32(geoms),
+                                        flat_shapes, woff, ptr(bitmap_all), ptr(tile_sums), ptr(counts), st),
+              'crb_spconv_chain_mark')
+    return dict(L=L, oshapes=oshapes, flat_shapes=flat_shapes, word_off=word_off, woff=woff, bitmap_all=bitmap_all,
+                tile_sums=tile_sums, counts=counts)
+
+
+def begin_rulebooks(coords, shape, batch_size, specs, n_dev):
+    """build_rulebooks' device-only first half for a lazily voxelized coordinate set (n_dev (1,) i32 cuda), issued on the current
+    stream with NO host synchronisation -> PendingChain, to be handed to build_rulebooks(pending=...) later (same stream)."""
+    require_cuda(coords)
+    assert coords.dtype == torch.int32 and coords.is_contiguous() and n_dev is not None
+    nspecs = [(s[0], _triple(s[1])) + tuple(_triple(v) for v in s[2:]) for s in specs]
+    strided = [s for s in nspecs if s[0] == 'spconv']
+    if not strided:
+        raise CrbHipError('begin_rulebooks needs at least one strided conv in the chain')
+    p = PendingChain()
+    p.coords, p.shape, p.batch_size, p.specs = coords, list(shape), batch_size, list(specs)
+    p.state = _chain_mark(coords, shape, batch_size, strided, n_dev, cur_stream(coords.device))
+    both = torch.cat([n_dev.view(1), p.state['counts']])
+    p.host = torch.empty((both.shape[0],), dtype=torch.int32, pin_memory=True)
+    p.host.copy_(both, non_blocking=True)
+    p.event = torch.cuda.Event()
+    p.event.record()
+    return p
+
+
+def build_rulebooks(coords, shape, batch_size, specs, want_grad=True, n_dev=None, pending=None):
     """Rulebooks of a CHAIN of sparse convs over one coordinate set, every table finished, in ~3 launches per table and ONE
     host read-back for the whole chain.
 
@@ -310,7 +376,12 @@ def build_rulebooks(coords, shape, batch_size, specs, want_grad=True, n_dev=None
     require_cuda(coords)
     assert coords.dtype == torch.int32 and coords.is_contiguous()
     dev = coords.device
-    lazy = n_dev is not None
+    lazy = n_dev is not None or pending is not None
+    if pending is not None:
+        # pending: the PendingChain of begin_rulebooks() for exactly this coordinate buffer and chain - its marks and counts are used
+        # instead of a new marking pass + read-back (-> (books, N) like the n_dev form)
+        assert pending.coords.data_ptr() == coords.data_ptr() and list(pending.shape) == list(shape) and \
+            pending.batch_size == batch_size and len(pending.specs) == len(specs)
     if lazy and not any(s[0] == 'spconv' for s in specs):
         n_host = int(n_dev.cpu()[0])                     # nothing to merge the read-back with
         return build_rulebooks(coords[:n_host], shape, batch_size, specs, want_grad), n_host
@@ -320,37 +391,21 @@ def build_rulebooks(coords, shape, batch_size, specs, want_grad=True, n_dev=None
     # ---- the chain of output sets: bitmaps -> counts (the read-back) -> coordinates + rank tables
     levels = []                                   # per strided conv: (out_shape, n_out, out_coords, rank pointer)
     if strided:
-        L = len(strided)
-        if L > 8:
-            raise CrbHipError('more than 8 strided convs in one chain')
-        geoms, oshapes, cur = [], [], list(shape)
-        for _, ks, sd, pd in strided:
-            o = conv_out_shape(cur, ks, sd, pd)
-            if min(o) <= 0:
-                raise CrbHipError(f'sparse conv output shape {o} is empty')
-            geoms += ks + sd + pd
-            oshapes.append(o)
-            cur = o
-        flat_shapes = _host_i32([v for o in oshapes for v in o])
-        word_off = [0]
-        for o in oshapes:
-            word_off.append(word_off[-1] + lib.crb_spconv_padded_words(batch_size, host_i32x3(o)))
-        woff = _host_i64(word_off)
-        bitmap_all = torch.empty((word_off[-1],), dtype=torch.int32, device=dev)
-        tile_sums = torch.empty((word_off[-1] // 2048,), dtype=torch.int32, device=dev)
-        counts = torch.empty((L,), dtype=torch.int32, device=dev)
-        if lazy:
-            check(lib.crb_spconv_chain_mark_lazy(ptr(coords), coords.shape[0], ptr(n_dev), batch_size, host_i32x3(shape), L,
-                                                 _host_i32(geoms), flat_shapes, woff, ptr(bitmap_all), ptr(tile_sums), ptr(counts), st),
-                  'crb_spconv_chain_mark_lazy')
-            both = torch.cat([n_dev.view(1), counts]).cpu().tolist()       # voxel count + level sizes: ONE read-back
+        if pending is not None:
+            stt = pending.state
+            both = pending.counts()
             coords = coords[:int(both[0])]
             n_outs = [int(v) for v in both[1:]]
         else:
-            check(lib.crb_spconv_chain_mark(ptr(coords), coords.shape[0], batch_size, host_i32x3(shape), L, _host_i32(geoms),
-                                            flat_shapes, woff, ptr(bitmap_all), ptr(tile_sums), ptr(counts), st),
-                  'crb_spconv_chain_mark')
-            n_outs = [int(v) for v in counts.cpu().tolist()]               # the single read-back of the chain
+            stt = _chain_mark(coords, shape, batch_size, strided, n_dev, st)
+            if lazy:
+                both = torch.cat([n_dev.view(1), stt['counts']]).cpu().tolist()    # voxel count + level sizes: ONE read-back
+                coords = coords[:int(both[0])]
+                n_outs = [int(v) for v in both[1:]]
+            else:
+                n_outs = [int(v) for v in stt['counts'].cpu().tolist()]            # the single read-back of the chain
+        L, oshapes, flat_shapes, word_off, woff = stt['L'], stt['oshapes'], stt['flat_shapes'], stt['word_off'], stt['woff']
+        bitmap_all, tile_sums = stt['bitmap_all'], stt['tile_sums']
         rank_all = torch.empty((word_off[-1], 2), dtype=torch.int32, device=dev)
         out_coords = [torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev) for n in n_outs]
         oc_ptrs = (ctypes.c_void_p * L)(*[c.data_ptr() for c in out_coords])

@@ -60,21 +60,45 @@ class _Backbone8xBase(nn.Module):
         batch_dict.update({'multi_scale_3d_strides': {'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8}})
         return batch_dict
 
+    def _chain(self):
+        return [self.conv_input, self.conv1, self.conv2, self.conv3, self.conv4, self.conv_out]
+
+    def _input_tensor(self, batch_dict):
+        voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
+        return spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords.int().contiguous(),
+                                       spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
+
+    def prefetch(self, batch_dict):
+        """The part of the table plan that needs no host decision, for a LATER forward(batch_dict) on the same stream (the detector's
+        prefetch_sparse: called while the previous batch's backward pass is still to be enqueued): the strided levels of the lazily
+        voxelized batch are marked and counted, the counts go to pinned host memory behind an event. forward() then finds them
+        there instead of stalling the host - and the launch queue behind it - on a read-back in the middle of the sparse phase.
+        No-op for batches that are not lazily voxelized."""
+        n_dev = batch_dict.get('voxel_count_dev', None)
+        if n_dev is None or not PLAN_INDICES or '_sparse_prefetch' in batch_dict:
+            return batch_dict
+        from spconv.pytorch.conv import plan_begin
+        x = self._input_tensor(batch_dict)
+        pending = plan_begin(self._chain(), x, n_dev)
+        if pending is not None:
+            batch_dict['_sparse_prefetch'] = (x, pending)
+        return batch_dict
+
     def forward(self, batch_dict):
         n_dev = batch_dict.get('voxel_count_dev', None)          # lazily voxelized batch: capacity buffers, row count on the device
         if n_dev is not None and not PLAN_INDICES:
             from .vfe.mean_vfe import finish_lazy_voxels
             finish_lazy_voxels(batch_dict)
             n_dev = None
-        voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
-        x = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords.int().contiguous(),
-                                    spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
+        x, pending = batch_dict.pop('_sparse_prefetch', (None, None))
+        if x is None or n_dev is None:
+            x, pending = self._input_tensor(batch_dict), None
         if PLAN_INDICES:
             # all rulebooks first: one host read-back for the four strided output sets instead of a sync per strided layer (and
-            # for the voxel count of a lazily voxelized batch: x is cut to its rows by the plan)
+            # for the voxel count of a lazily voxelized batch: x is cut to its rows by the plan); a prefetched batch has its
+            # counts on the host already
             from crbhip import bnrelu
-            plan_indices([self.conv_input, self.conv1, self.conv2, self.conv3, self.conv4, self.conv_out], x,
-                         with_frame_offsets=bnrelu.active_groups() is not None, n_dev=n_dev)
+            plan_indices(self._chain(), x, with_frame_offsets=bnrelu.active_groups() is not None, n_dev=n_dev, pending=pending)
             if n_dev is not None:
                 from .vfe.mean_vfe import finish_lazy_voxels
                 finish_lazy_voxels(batch_dict, x.indices.shape[0])

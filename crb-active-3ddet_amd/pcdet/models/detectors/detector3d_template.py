@@ -45,8 +45,34 @@ class Detector3DTemplate(nn.Module):
             pfe_mod.prefetch_keypoints(batch_dict)             # FPS on a side stream, joined inside the PFE
         if getattr(getattr(self, 'backbone_3d', None), 'ACCEPTS_LAZY_VOXELS', False) and 'voxels' not in batch_dict:
             batch_dict['_lazy_voxel_count'] = True             # one read-back for the voxel count + the table plan (mean_vfe.py)
+        vfe_done = batch_dict.pop('_vfe_done', False)           # prefetch_sparse() ran the voxel generator for this batch
         for stage in self.scheduled_modules():
+            if vfe_done and stage is getattr(self, 'vfe', None):
+                continue
             batch_dict = stage(batch_dict)
+        return batch_dict
+
+    def prefetch_sparse(self, batch_dict):
+        """Software pipelining of the loader side of the step (the reference voxelizes in its DataLoader workers, ahead of the GPU
+        step: pcdet/datasets/processor/data_processor.py:44-60): call with the NEXT batch right after this batch's forward pass has
+        been enqueued (before backward()). The voxel generator and the marking half of the 3-D backbone's table plan run on the
+        current stream without any host synchronisation, their counts travel to pinned memory; forward(batch_dict) of the next step
+        picks them up (same dict object). Without it every forward pass reads the counts back in the middle of its sparse phase: the
+        host waits for the device to drain and the device then waits for the host to refill the launch queue. Results are identical
+        (same kernels on the same inputs). No-op for batches that carry loader-side voxels."""
+        bb, vfe = getattr(self, 'backbone_3d', None), getattr(self, 'vfe', None)
+        if bb is None or vfe is None or not getattr(bb, 'ACCEPTS_LAZY_VOXELS', False) or not hasattr(bb, 'prefetch') or \
+                'voxels' in batch_dict or 'voxel_coords' in batch_dict or '_vfe_done' in batch_dict:
+            return batch_dict
+        import torch
+        with torch.no_grad():
+            batch_dict['_lazy_voxel_count'] = True
+            vfe(batch_dict)
+            if batch_dict.get('voxel_count_dev', None) is None:   # the generator answered with cut tensors: nothing to pipeline
+                batch_dict['_vfe_done'] = True
+                return batch_dict
+            bb.prefetch(batch_dict)
+        batch_dict['_vfe_done'] = True
         return batch_dict
 
     DENSE_BEFORE_PFE = True

@@ -199,18 +199,9 @@ def set_arithmetic(module, arithmetic):
     return n
 
 
-def plan_indices(modules, input, with_frame_offsets=False, n_dev=None):
-    """Build the rulebooks of every (non 1x1, non inverse) SparseConvolution found in `modules` (in module order, as the
-    forward pass will meet them) BEFORE the first feature kernel runs, and leave them in input.indice_dict under their
-    indice_key: crbhip.sparse.build_rulebooks takes the whole chain — the output sets of all strided layers are marked and
-    counted with ONE host read-back, every table costs one launch and all of them are finished (kernel order, compact
-    tables, tile order, wgrad pair lists) by two more — instead of ~30 launches and a synchronisation per layer in the
-    middle of the forward pass.
-    Precondition (checked): the convs that carry a new indice_key form one linear chain starting at `input` — every strided
-    conv consumes the output set of the strided conv before it. A tensor on which some of the strided keys already exist
-    is left alone: the forward pass then builds what is missing layer by layer.
-    n_dev (1,) i32 cuda: input.features / input.indices are the voxel generator's capacity buffers and the row count is still on
-    the device; the chain's read-back returns it and the tensor is cut to its rows here (input.indices.shape[0] afterwards)."""
+def _chain_specs(modules, input):
+    """the convs of `modules` that need a rulebook, in forward order, and the chain description build_rulebooks takes
+    -> (convs, have flags of the strided keys, specs, keys to fill)"""
     convs = []
     for root in modules:
         for m in root.modules():
@@ -218,16 +209,6 @@ def plan_indices(modules, input, with_frame_offsets=False, n_dev=None):
                     m.indice_key is not None:
                 convs.append(m)
     have = [m.indice_key in input.indice_dict for m in convs if not m.subm]
-
-    def cut(n):
-        input.indices = input.indices[:n]
-        input.features = input.features[:n]
-        return n
-    if any(have) and not all(have):
-        # partially planned tensor: no assumption about where the chain stands
-        if n_dev is not None:
-            cut(int(n_dev.cpu()[0]))
-        return input
     specs, todo, seen = [], [], set(input.indice_dict.keys())
     shape = list(input.spatial_shape)
     geom_of = {}
@@ -248,11 +229,48 @@ def plan_indices(modules, input, with_frame_offsets=False, n_dev=None):
                 todo.append(key)
         if not m.subm:
             shape = _sp.conv_out_shape(shape, g[1], g[2], g[3])
+    return convs, have, specs, todo
+
+
+def plan_begin(modules, input, n_dev):
+    """The device-only first half of plan_indices(..., n_dev=...) for a lazily voxelized tensor, issued ahead of time with no host
+    synchronisation (crbhip.sparse.begin_rulebooks): the strided levels are marked and counted, the counts travel to pinned host
+    memory behind an event. -> PendingChain to pass as plan_indices(..., pending=...) before the forward pass, or None when the
+    tensor is not a fresh unplanned chain (plan_indices then does everything itself)."""
+    convs, have, specs, todo = _chain_specs(modules, input)
+    if any(have) or not specs or not any(s[0] == 'spconv' for s in specs):
+        return None
+    return _sp.begin_rulebooks(input.indices, list(input.spatial_shape), input.batch_size, specs, n_dev)
+
+
+def plan_indices(modules, input, with_frame_offsets=False, n_dev=None, pending=None):
+    """Build the rulebooks of every (non 1x1, non inverse) SparseConvolution found in `modules` (in module order, as the
+    forward pass will meet them) BEFORE the first feature kernel runs, and leave them in input.indice_dict under their
+    indice_key: crbhip.sparse.build_rulebooks takes the whole chain — the output sets of all strided layers are marked and
+    counted with ONE host read-back, every table costs one launch and all of them are finished (kernel order, compact
+    tables, tile order, wgrad pair lists) by two more — instead of ~30 launches and a synchronisation per layer in the
+    middle of the forward pass.
+    Precondition (checked): the convs that carry a new indice_key form one linear chain starting at `input` — every strided
+    conv consumes the output set of the strided conv before it. A tensor on which some of the strided keys already exist
+    is left alone: the forward pass then builds what is missing layer by layer.
+    n_dev (1,) i32 cuda: input.features / input.indices are the voxel generator's capacity buffers and the row count is still on
+    the device; the chain's read-back returns it and the tensor is cut to its rows here (input.indices.shape[0] afterwards)."""
+    convs, have, specs, todo = _chain_specs(modules, input)
+
+    def cut(n):
+        input.indices = input.indices[:n]
+        input.features = input.features[:n]
+        return n
+    if any(have) and not all(have):
+        # partially planned tensor: no assumption about where the chain stands
+        if n_dev is not None:
+            cut(int(n_dev.cpu()[0]))
+        return input
     n_rows = None
     if specs and not (have and all(have)):
         books = _sp.build_rulebooks(input.indices, list(input.spatial_shape), input.batch_size, specs,
-                                    want_grad=torch.is_grad_enabled(), n_dev=n_dev)
-        if n_dev is not None:
+                                    want_grad=torch.is_grad_enabled(), n_dev=n_dev, pending=pending)
+        if n_dev is not None or pending is not None:
             books, n_rows = books
             cut(n_rows)
         for key, rb in zip(todo, books):

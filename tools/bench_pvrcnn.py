@@ -37,9 +37,15 @@ def main():
                         'point_frame_offsets': torch.from_numpy(off).to(dev), 'gt_boxes': torch.from_numpy(gt).to(dev),
                         'batch_size': a.batch, 'point_frame_counts_host': np.diff(off).tolist()})
 
+    ahead = {}
+    prefetch = os.environ.get('CRB_SPARSE_PREFETCH', '1') == '1'
+
     def step(i):
         opt.zero_grad(set_to_none=True)
-        ret, tb, _ = model(dict(batches[i % 2]))
+        ret, tb, _ = model(ahead.pop(i, None) or dict(batches[i % 2]))
+        if prefetch:
+            ahead.clear()
+            ahead[i + 1] = model.prefetch_sparse(dict(batches[(i + 1) % 2]))
         ret['loss'].backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
         opt.step()
