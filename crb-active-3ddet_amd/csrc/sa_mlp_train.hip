@@ -545,21 +545,25 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
   }
 }
 
-// out[e] = sum over k of part[k][e] in double: 8 slices of the part range per column, each in index order, then the slices in order
-__global__ __launch_bounds__(256) void sa_reduce_parts_kernel(const float* __restrict__ part, int64_t nparts, int count,
-                                                              float* __restrict__ out) {
-  __shared__ double red[8][32];
-  const int c = threadIdx.x & 31, s = threadIdx.x >> 5;
-  const int e = blockIdx.x * 32 + c;
-  const int64_t per = (nparts + 7) / 8, k0 = s * per, k1 = k0 + per < nparts ? k0 + per : nparts;
+// out[e] = sum over k of part[k][e] in double: 16 slices of the part range per column, each in index order, then the slices in
+// order. Two jobs per launch (the BatchNorm-1 sums and dW2 of one backward): blocks [0, blocksA) serve job A, the rest job B.
+struct SaReduceJob { const float* part; int64_t nparts; int count; float* out; };
+__global__ __launch_bounds__(256) void sa_reduce_parts_kernel(SaReduceJob ja, int blocksA, SaReduceJob jb) {
+  __shared__ double red[16][16];
+  const bool first = (int)blockIdx.x < blocksA;
+  const SaReduceJob j = first ? ja : jb;
+  const int blk = first ? blockIdx.x : blockIdx.x - blocksA;
+  const int c = threadIdx.x & 15, s = threadIdx.x >> 4;
+  const int e = blk * 16 + c;
+  const int64_t per = (j.nparts + 15) / 16, k0 = s * per, k1 = k0 + per < j.nparts ? k0 + per : j.nparts;
   double acc = 0.0;
-  if (e < count)
-    for (int64_t k = k0; k < k1; ++k) acc += (double)part[k * count + e];
+  if (e < j.count)
+    for (int64_t k = k0; k < k1; ++k) acc += (double)j.part[k * j.count + e];
   red[s][c] = acc;
   __syncthreads();
-  if (s == 0 && e < count) {
-    for (int k = 1; k < 8; ++k) acc += red[k][c];
-    out[e] = (float)acc;
+  if (s == 0 && e < j.count) {
+    for (int k = 1; k < 16; ++k) acc += red[k][c];
+    j.out[e] = (float)acc;
   }
 }
 
@@ -688,8 +692,9 @@ extern "C" int crb_sa_mlp2_train_backward(int B, int64_t M, int nsample, int h1,
   a.partW = workspace + (int64_t)grid * 4 * 2 * h1;
   const int rc = dispatch_sat<2>(h1, h2, a, grid, st);
   if (rc != CRB_OK) return rc;
-  hipLaunchKernelGGL(sa_reduce_parts_kernel, dim3(crb_cdiv(2 * h1, 32)), dim3(256), 0, st, a.part1, (int64_t)grid * 4, 2 * h1, dsums1);
-  hipLaunchKernelGGL(sa_reduce_parts_kernel, dim3(crb_cdiv(h1 * h2, 32)), dim3(256), 0, st, a.partW, (int64_t)grid, h1 * h2, dW2);
+  const SaReduceJob ja{a.part1, (int64_t)grid * 4, 2 * h1, dsums1}, jb{a.partW, (int64_t)grid, h1 * h2, dW2};
+  const int blocksA = crb_cdiv(2 * h1, 16), blocksB = crb_cdiv(h1 * h2, 16);
+  hipLaunchKernelGGL(sa_reduce_parts_kernel, dim3(blocksA + blocksB), dim3(256), 0, st, ja, blocksA, jb);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

@@ -32,6 +32,8 @@ def bilinear_interpolate_torch(im, x, y):
 BEV_INTERP_KERNEL = True   # crb_bev_interpolate_forward / _backward (one launch each) instead of the torch expression below
 
 
+CU_RESERVATION = __import__('os').environ.get('CRB_CU_RESERVATION', '1') == '1'    # A/B: announce the CUs the sampling holds (crb_cu_reservation)
+
 class _BevInterpolate(torch.autograd.Function):
     """bilinear lookup of the channels_last BEV map at the keypoints: same operations in the same order as the torch expression of
     interpolate_from_bev_features (bit-identical forward); backward adds the four weighted copies of the gradient into the map
@@ -202,7 +204,7 @@ class VoxelSetAbstraction(nn.Module):
             # 0.78 ms per convolution while the sampling runs)
             # (only the farthest-point sampler holds CUs for milliseconds; at most a quarter of the device is announced - the kernel
             # itself lets at most half of a launch's workgroups give way)
-            fps = self.model_cfg.get('SAMPLE_METHOD', 'FPS') == 'FPS'
+            fps = self.model_cfg.get('SAMPLE_METHOD', 'FPS') == 'FPS' and CU_RESERVATION
             held = min(int(batch_dict['batch_size']), torch.cuda.get_device_properties(pts.device).multi_processor_count // 4)
             if fps:
                 check(lib.crb_cu_reservation(held, cur_stream(pts.device)), 'crb_cu_reservation')

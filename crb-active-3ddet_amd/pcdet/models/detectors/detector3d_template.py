@@ -37,11 +37,14 @@ class Detector3DTemplate(nn.Module):
     def update_global_step(self):
         self.global_step += 1
 
-    def run_modules(self, batch_dict):
+    def run_modules(self, batch_dict, before_pfe=None):
         """the detector's module chain on one batch (what every reference detector's forward() starts with); a PFE that can
-        sample its keypoints ahead of time is told to start as soon as the points are known"""
+        sample its keypoints ahead of time is told to start as soon as the points are known.
+        before_pfe: optional callable run once between the dense half and the PFE (end of the chain without a PFE) - the place
+        where a caller that pipelines batches enqueues the NEXT batch's prologue (prefetch_sparse): its farthest-point sampling then
+        runs beside this batch's set-abstraction / RoI-head kernels instead of beside the persistent convolution kernels."""
         pfe_mod = getattr(self, 'pfe', None)
-        if pfe_mod is not None and hasattr(pfe_mod, 'prefetch_keypoints'):
+        if pfe_mod is not None and hasattr(pfe_mod, 'prefetch_keypoints') and '_keypoints_prefetched' not in batch_dict:
             pfe_mod.prefetch_keypoints(batch_dict)             # FPS on a side stream, joined inside the PFE
         if getattr(getattr(self, 'backbone_3d', None), 'ACCEPTS_LAZY_VOXELS', False) and 'voxels' not in batch_dict:
             batch_dict['_lazy_voxel_count'] = True             # one read-back for the voxel count + the table plan (mean_vfe.py)
@@ -49,7 +52,12 @@ class Detector3DTemplate(nn.Module):
         for stage in self.scheduled_modules():
             if vfe_done and stage is getattr(self, 'vfe', None):
                 continue
+            if before_pfe is not None and stage is pfe_mod:
+                before_pfe()
+                before_pfe = None
             batch_dict = stage(batch_dict)
+        if before_pfe is not None:
+            before_pfe()
         return batch_dict
 
     def prefetch_sparse(self, batch_dict):
@@ -72,6 +80,13 @@ class Detector3DTemplate(nn.Module):
                 batch_dict['_vfe_done'] = True
                 return batch_dict
             bb.prefetch(batch_dict)
+            # the keypoint sampling of that batch (5 ms of sequential rounds, one workgroup per frame on a side stream) starts here
+            # too: behind this batch's forward pass it runs beside the RoI-head / set-abstraction part of the backward pass. Started
+            # with its own forward pass it ran beside the first persistent one-workgroup-per-CU convolution launches, and the one
+            # that overlapped it took 2.7 ms instead of 0.73 (profiles/r05_pvrcnn_..._v3.csv launch list)
+            pfe_mod = getattr(self, 'pfe', None)
+            if pfe_mod is not None and hasattr(pfe_mod, 'prefetch_keypoints') and '_keypoints_prefetched' not in batch_dict:
+                pfe_mod.prefetch_keypoints(batch_dict)
         batch_dict['_vfe_done'] = True
         return batch_dict
 

@@ -62,20 +62,33 @@ class CRBSampling(Strategy):
         model.eval()
         self.enable_dropout(model)
         rows = []
-        for batch in batches:
-            batch = dict(batch)
-            if getattr(model, 'pfe', None) is not None and hasattr(model.pfe, 'prefetch_keypoints'):
-                model.pfe.prefetch_keypoints(batch)          # FPS on a side stream, as PVRCNN.forward does
+        pipelined = self.PIPELINE_BATCHES and hasattr(model, 'prefetch_sparse') and hasattr(model, 'run_modules')
+        it = iter(batches)
+        batch = next(it, None)
+        batch = dict(batch) if batch is not None else None
+        while batch is not None:
+            nxt = next(it, None)
+            nxt = dict(nxt) if nxt is not None else None
             valid = batch.pop('_valid_frames', None)
-            for mod in _chain(model):
-                batch = mod(batch)
+            if pipelined:
+                # one batch of look-ahead: the next batch's voxel generator, table-plan marks and keypoint sampling are enqueued
+                # between this batch's dense half and its PFE (Detector3DTemplate.prefetch_sparse) - no read-back stall in the next
+                # sparse phase, and the sampling runs beside set-abstraction kernels, not beside the persistent convolutions
+                batch = model.run_modules(batch, before_pfe=(lambda n=nxt: model.prefetch_sparse(n)) if nxt is not None else None)
+            else:
+                if getattr(model, 'pfe', None) is not None and hasattr(model.pfe, 'prefetch_keypoints'):
+                    model.pfe.prefetch_keypoints(batch)          # FPS on a side stream, as PVRCNN.forward does
+                for mod in _chain(model):
+                    batch = mod(batch)
             rec = scoring.pack_records(crb_frame_records(model, batch), self.layout)
             rows.append(rec if valid is None else rec[:valid])          # a padded tail batch: its repeats are dropped
+            batch = nxt
         if not rows:
             return torch.zeros((0, self.layout.stride), dtype=torch.float32, device=next(model.parameters()).device)
         return torch.cat(rows, 0)
 
     PAD_TAIL_BATCH = True
+    PIPELINE_BATCHES = __import__('os').environ.get('CRB_PIPELINE_BATCHES', '1') == '1'    # stage-1 pass: one batch of look-ahead (A/B)
 
     def upload_pool_batches(self, frame_indices, batch_size):
         """host batches of the given pool frames (read ahead by the loader's workers) -> device batches, one at a time.
