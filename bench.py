@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--kind', default='kitti', choices=['kitti', 'waymo'])
     ap.add_argument('--pool', type=int, default=2, help='distinct resident batches cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--n1-value', type=float, default=0.0, help='frames/s of the 1-GPU run of the same code: fills summary.scaling_efficiency '
+                                                                'of an N > 1 line (value / (N x this))')
     ap.add_argument('--no-sparse-prefetch', action='store_true',
                     help='A/B: do not software-pipeline the next batch\'s voxel generator + table-plan marks behind this batch\'s forward '
                          'pass (Detector3DTemplate.prefetch_sparse); every step then reads the counts back in its sparse phase')
@@ -791,6 +793,9 @@ def main():
         headline = {
             'second_frames_per_s': out['value'], 'second_ms_per_step': out['ms_per_step'],
             'frames_per_s_per_gpu': round(out['value'] / world, 3),
+            # value / (N x the 1-GPU value): needs the N = 1 number of the same code on the same node (--n1-value, e.g. from the
+            # N = 1 line of the driver's scaling sweep); null otherwise - the driver computes the curve from the per-N lines itself
+            'scaling_efficiency': None if not args.n1_value else round(out['value'] / (world * args.n1_value), 4),
             'crb_scoring_frames_per_s': None if score is None else score['value'],
             'crb_scoring_frames_per_batch': None if score is None else score['config']['frames_per_batch'],
             'crb_scoring_at_reference_batch': None if score is None or not score.get('at_reference_batch') else score['at_reference_batch']['value'],

@@ -192,7 +192,7 @@ def test_bench_two_rank_dry_run_prints_the_contract_line(tmp_path):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29541', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
            '--scoring-pool', str(pool), '--scoring-repeats', '1', '--pvrcnn-steps', '0', '--bf16x3-steps', '0',
-           '--no-cpu-baseline']
+           '--no-cpu-baseline', '--n1-value', '100.0']
     r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
@@ -206,6 +206,7 @@ def test_bench_two_rank_dry_run_prints_the_contract_line(tmp_path):
     # the headline numbers sit at the head of the line and again at its very end (a log tail keeps the end)
     assert list(d.keys())[-1] == 'summary' and d['summary'] == d['headline']
     assert d['summary']['second_frames_per_s'] == d['value'] and abs(d['summary']['frames_per_s_per_gpu'] * 2 - d['value']) < 1e-2
+    assert abs(d['summary']['scaling_efficiency'] - d['value'] / (2 * 100.0)) < 1e-3       # (--n1-value 100)
     assert d['summary']['crb_scoring_frames_per_s'] == d['crb_scoring']['value']
     sc = d['crb_scoring']
     assert sc['config']['frames_per_gpu'] == pool // 2 and sc['config']['pool_frames'] == pool and sc['config']['n_gpus'] == 2
