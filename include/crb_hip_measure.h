@@ -87,6 +87,11 @@ int crb_winograd_weights(const float* g, float* U, int cin, int cout, void* stre
 int crb_conv3x3_winograd_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
                               const float* bias, int relu, void* stream);
 
+/* latency-floor probes of the low-channel subm layers (csrc/probe_floor.hip): the memory side of the gather chain on 16-channel rows,
+ * no weights / MFMA. variant 0 = copy y[i] = x[i]; 1 = two dependent round trips (ell (n,8) fixed-stride neighbour list, -1 = none,
+ * rows summed); 2 = three (cmask / cbase -> packed -> rows: the compact table's chain). y (n,16). */
+int crb_probe_gather_chain(int variant, const float* x, int64_t n, const uint32_t* cmask, const int32_t* cbase,
+                           const int32_t* packed, const int32_t* ell, float* y, void* stream);
 #ifdef __cplusplus
 }
 #endif
