@@ -199,7 +199,11 @@ def dominant_roofline(prof, overhead_ms, gather_roof, gather_table):
     for pmc in ('r05_pmc_winograd2.json', 'r04_pmc_winograd2.json'):          # newest committed PMC summary of this kernel
         try:
             pm = json.load(open(os.path.join(ROOT, 'profiles', pmc)))
-            if pm.get('shape') and ('_'.join(str(x) for x in pm['shape'])) in name:
+            hit = next((e for key, e in pm.get('shapes', {}).items() if name.endswith('conv_' + key)), None)   # (forward / input-gradient instances)
+            if hit is not None:
+                traffic, traffic_src = hit['traffic_bytes_per_launch'], pm['source']
+                break
+            if pm.get('shape') and name.endswith('conv_' + '_'.join(str(x) for x in pm['shape'])):
                 traffic, traffic_src = pm['traffic_bytes_per_launch'], pm['source']
                 break
         except (OSError, ValueError, KeyError):

@@ -230,6 +230,7 @@ class _Conv3x3Stats(torch.autograd.Function):
                                                    cur_stream(x.device)), 'crb_conv3x3_winograd2_stats_nhwc')
         _prof_end(e0, 'wino_conv', cin, cout, N, H, W)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)          # (no zero tensor for the statistics output's gradient in every backward call)
         return y, stats
 
     @staticmethod

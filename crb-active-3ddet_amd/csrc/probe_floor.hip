@@ -49,7 +49,41 @@ __global__ __launch_bounds__(256) void probe_chain_kernel(const float* __restric
   }
   *reinterpret_cast<pf4*>(y + (int64_t)i * 16 + 4 * q) = acc;
 }
+// ---- calibration of rocprofv3's FETCH_SIZE on the Winograd forward kernel's access pattern: LDS-DMA reads of
+// KNOWN bytes. Every lane issues global_load_lds_dwordx4 (16 bytes); a wave instruction covers 32 pieces of 32 bytes (two lanes per
+// piece), the pieces `stride` bytes apart - stride 32: a dense streaming read; stride 512: the 8-channel pieces of adjacent pixels
+// of a 128-channel NHWC map (what the raw-block DMA of winograd2_kernel reads). pass_mask bit p: also read the p-th 32-byte piece of
+// every line in a later sweep (bits 0..3: all four 8-channel chunks of a 128-byte line, as the kernel's chunk loop does over time).
+// Every requested byte is requested exactly once per set bit. The landed data is summed into one float per workgroup (kept alive).
+__global__ __launch_bounds__(256) void probe_lds_dma_kernel(const float* __restrict__ src, int64_t pieces, int stride_floats,
+                                                             int pass_mask, float* __restrict__ sink) {
+  __shared__ __attribute__((aligned(16))) float buf[4][256];            // 1 KiB per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t nwave = (int64_t)gridDim.x * 4, w = (int64_t)blockIdx.x * 4 + wave;
+  float acc = 0.f;
+  for (int p = 0; p < 4; ++p) {
+    if (!((pass_mask >> p) & 1)) continue;
+    for (int64_t g = w; g * 32 < pieces; g += nwave) {                   // 32 pieces per wave instruction
+      const int64_t piece = g * 32 + (lane >> 1);
+      const float* a = src + (piece < pieces ? piece : 0) * stride_floats + p * 8 + (lane & 1) * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a,
+                                       (__attribute__((address_space(3))) void*)buf[wave], 16, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      acc += buf[wave][lane * 4];
+    }
+  }
+  acc = crb_wave_sum(acc);
+  if (lane == 0) atomicAdd(&sink[blockIdx.x & 255], acc);
+}
 }  // namespace
+
+extern "C" int crb_probe_lds_dma(const float* src, int64_t pieces, int stride_bytes, int pass_mask, float* sink256, void* stream) {
+  if (!src || !sink256 || pieces <= 0 || stride_bytes < 32 || (stride_bytes & 15) || !(pass_mask & 15)) return CRB_ERR_ARG;
+  hipLaunchKernelGGL(probe_lds_dma_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, src, pieces, stride_bytes / 4, pass_mask,
+                     sink256);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
 
 extern "C" int crb_probe_gather_chain(int variant, const float* x, int64_t n, const uint32_t* cmask, const int32_t* cbase,
                                       const int32_t* packed, const int32_t* ell, float* y, void* stream) {

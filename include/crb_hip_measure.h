@@ -87,6 +87,10 @@ int crb_winograd_weights(const float* g, float* U, int cin, int cout, void* stre
 int crb_conv3x3_winograd_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
                               const float* bias, int relu, void* stream);
 
+/* FETCH_SIZE calibration on the Winograd forward kernel's access pattern: LDS-DMA (global_load_lds_dwordx4) reads of `pieces` pieces of
+ * 32 bytes, `stride_bytes` apart (32 = dense, 512 = the 8-channel pieces of adjacent pixels of a 128-channel NHWC map); pass_mask bit p
+ * = a sweep over the p-th 32-byte piece of every stride (p < 4). Requested bytes = pieces * 32 * popcount(pass_mask). sink256: 256 floats. */
+int crb_probe_lds_dma(const float* src, int64_t pieces, int stride_bytes, int pass_mask, float* sink256, void* stream);
 /* latency-floor probes of the low-channel subm layers (csrc/probe_floor.hip): the memory side of the gather chain on 16-channel rows,
  * no weights / MFMA. variant 0 = copy y[i] = x[i]; 1 = two dependent round trips (ell (n,8) fixed-stride neighbour list, -1 = none,
  * rows summed); 2 = three (cmask / cbase -> packed -> rows: the compact table's chain). y (n,16). */
