@@ -99,8 +99,9 @@ struct SaLds {
   static constexpr int HP1 = H1 + 4, HP2 = H2 + 4;
   static constexpr int TR = PAR + PAR_FLOATS;                     // MODE 2: per wave [16][HP2] dy2 | [16][HP1] z1
   static constexpr int TR_WAVE = 16 * (HP1 + HP2);
-  static constexpr int CON = TR + (MODE == 2 ? 4 * TR_WAVE : 0);  // MODE 1: the two constant rows of an empty ball
-  static constexpr int TOTAL = CON + (MODE == 1 ? 2 * H2 : MODE == 2 ? 4 * H2 : 0);   // MODE 2: vsum of every wave
+  static constexpr int CON = TR + (MODE == 2 ? 4 * TR_WAVE : 0);  // MODE >= 1: the two constant rows of an empty ball (y2, relu(bn2(y2)))
+  static constexpr int VS = CON + (MODE >= 1 ? 2 * H2 : 0);       // MODE 2: vsum of every wave
+  static constexpr int TOTAL = VS + (MODE == 2 ? 4 * H2 : 0);
 };
 
 template <int N>
@@ -153,22 +154,23 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
   const int ns = a.ns, T = ns >> 4;                    // ns is a multiple of 16 (host check)
   const int M = (int)a.M, nw = (int)gridDim.x * 4, w0 = (int)blockIdx.x * 4 + wave;     // M * ns < 2^31 (host check)
 
-  // software pipeline over this wave's tiles (query w0 + k nw, row tile t): the cursor two tiles ahead ISSUES the loads of the
-  // sample index, the empty flag and the query centre (stage A: nothing it loads is looked at in the same iteration - a wait there
-  // would also wait for the P rows just requested), one tile ahead the source row is formed from them and the P row slice and the
-  // point are requested (stage B). The query index is wave-uniform (scalar register); a wave's queries ascend, so the frame of
-  // the cursor advances with it (first source row of the frame: `start`) instead of being searched per tile.
+  // Work distribution: chunks of 16 consecutive queries, chunk c of wave w0 = w0 + k nw (round-robin over the waves of the launch).
+  // A wave looks at FOUR chunks at a time (a "group"): one coalesced byte load gives the 64 empty flags, two ballots give the live
+  // and the empty queries as bit masks. Only live queries enter the tile pipeline; an empty ball costs a set bit in a mask (forward:
+  // its constant rows, backward: one row of gout), not a pipeline iteration with an exposed load (first version: 0.6 ms of the
+  // RoI-grid passes went into iterations over the 84 % empty queries at r = 0.8).
+  // Tile pipeline over the live queries (in ascending order): the cursor two tiles ahead ISSUES the loads of the sample index and
+  // the query centre (stage A: nothing it loads is looked at in the same iteration - a wait there would also wait for the P rows
+  // just requested), one tile ahead the source row is formed and the P row slice and the point are requested (stage B). The query
+  // index is wave-uniform (scalar register); the frame of the cursor advances with it (first source row of the frame: `start`).
   struct Cur { int q, t, b, fend, start; };
-  auto advance = [&](Cur& c) {
-    if (++c.t == T) { c.t = 0; c.q += nw; }
-  };
-  struct StA { int idxv, emp, start; float cx, cy, cz; bool valid; };
+  struct StA { int idxv, start; float cx, cy, cz; bool valid; };
   struct StB { f4 p[MB]; float px, py, pz, cx, cy, cz; int row; };   // the offset px - cx is formed where it is used
   auto load_a = [&](Cur& c) {
     StA s;
-    s.idxv = 0; s.emp = 1; s.start = 0; s.cx = s.cy = s.cz = 0.f;
+    s.idxv = 0; s.start = 0; s.cx = s.cy = s.cz = 0.f;
     const int q = __builtin_amdgcn_readfirstlane(c.q);
-    s.valid = q < M;
+    s.valid = q >= 0;
     if (s.valid) {
       int bb = __builtin_amdgcn_readfirstlane(c.b), fe = __builtin_amdgcn_readfirstlane(c.fend),
           st = __builtin_amdgcn_readfirstlane(c.start);
@@ -179,7 +181,6 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
       }
       c.b = bb; c.fend = fe; c.start = st;
       s.start = st;
-      s.emp = a.empty[q];
       s.idxv = a.idx[(int64_t)q * ns + 16 * c.t + r];
       s.cx = a.new_xyz[(int64_t)q * 3 + 0]; s.cy = a.new_xyz[(int64_t)q * 3 + 1]; s.cz = a.new_xyz[(int64_t)q * 3 + 2];
     }
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
   };
   auto load_b = [&](const StA& s) {
     StB b;
-    b.row = (s.valid && !s.emp) ? s.start + s.idxv : -1;
+    b.row = s.valid ? s.start + s.idxv : -1;
     b.px = b.py = b.pz = 0.f;
     b.cx = s.cx; b.cy = s.cy; b.cz = s.cz;
 #pragma unroll
@@ -257,9 +258,8 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
   i4 abest[NB];
   f4 sdb[MB], sdg[MB];                     // MODE 2
   f4 accW[NB][MB];
-  // MODE 2: vsum (LDS, H2 floats per wave) = sum over this wave's EMPTY queries of k2 * gout [z2 > 0]
-  unsigned posmask = 0;                    // MODE 2: channels of this lane with relu'(z2) = 1 on an empty ball's rows
-  int64_t n_empty = 0;                     // empty queries (MODE 2) / empty tiles (MODE 0) of this wave
+  float vs = 0.f, k2pos = 0.f;             // MODE 2, lane = channel: sum over this wave's EMPTY queries of k2 gout [z2 > 0]; k2 [z2 > 0]
+  int64_t n_empty = 0;                     // empty queries of this wave
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     s1[nb] = s2[nb] = f4{0.f, 0.f, 0.f, 0.f};
@@ -273,13 +273,8 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
   for (int mb = 0; mb < MB; ++mb) sdb[mb] = sdg[mb] = f4{0.f, 0.f, 0.f, 0.f};
   float* trD = smem + L::TR + wave * L::TR_WAVE;       // [16][HP2]
   float* trZ = trD + 16 * L::HP2;                      // [16][HP1]
-  float* sCon = smem + L::CON;                         // MODE 1: [y2 of an empty ball's rows (H2)][relu(bn2(.)) of it (H2)]
-  float* sVsum = smem + L::CON + wave * H2;            // MODE 2
-  if constexpr (MODE == 2) {
-    if (r == 0)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) *reinterpret_cast<f4*>(sVsum + 16 * nb + 4 * g) = f4{0.f, 0.f, 0.f, 0.f};
-  }
+  float* sCon = smem + L::CON;                         // MODE >= 1: [y2 of an empty ball's rows (H2)][relu(bn2(.)) of it (H2)]
+  float* sVsum = smem + L::VS + wave * H2;             // MODE 2
 
   // MODE 2, one tile: dz1^T = W2^T dy2^T (dy2 in the accumulator layout IS the B operand), masked by z1 > 0 -> gz1 row (optional),
   // the sums of BatchNorm 1's backward, and dW2 += dy2^T z1 with both tiles read back from LDS with the samples as k
@@ -347,62 +342,80 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (z2c[nb][j] > 0.f) posmask |= 1u << (nb * 4 + j);
-        if constexpr (MODE == 1) {
-          if (wave == 0 && r == 0) {
-            sCon[16 * nb + 4 * g + j] = accc[nb][j];
-            sCon[H2 + 16 * nb + 4 * g + j] = z2c[nb][j] > 0.f ? z2c[nb][j] : 0.f;
+        if (wave == 0 && r == 0) {
+          sCon[16 * nb + 4 * g + j] = accc[nb][j];
+          sCon[H2 + 16 * nb + 4 * g + j] = z2c[nb][j] > 0.f ? z2c[nb][j] : 0.f;
+        }
+      }
+    __syncthreads();
+    if constexpr (MODE == 2) {
+      if (lane < H2) k2pos = sCon[H2 + lane] > 0.f ? sBn2[2 * H2 + lane] * sBn2[H2 + lane] : 0.f;      // gamma * invstd where relu' = 1
+    }
+  }
+
+  // ---- the live-query iterator
+  auto load_flags = [&](int gq) -> int {
+    const int c = w0 + (4 * gq + (lane >> 4)) * nw;
+    const int64_t q = (int64_t)c * 16 + (lane & 15);
+    return q < M ? (int)a.empty[q] : 2;
+  };
+  auto query_of = [&](int gq, int bit) { return 16 * (w0 + (4 * gq + (bit >> 4)) * nw) + (bit & 15); };
+  int grp = 0;
+  int f_cur = load_flags(0), f_nxt = load_flags(1);
+  unsigned long long live_bits = 0;
+  auto enter_group = [&]() {               // f_cur = the flags of group grp
+    live_bits = __ballot(f_cur == 0);
+    unsigned long long emp = __ballot(f_cur == 1);
+    n_empty += __popcll(emp);
+    if constexpr (MODE >= 1) {
+      while (emp) {
+        const int q = query_of(grp, __builtin_ctzll(emp));
+        emp &= emp - 1;
+        if (lane < H2) {
+          if constexpr (MODE == 1) {       // the constant rows of an empty ball: 64 lanes, one row each of out / arg / y_sel
+            a.out[(int64_t)q * a.ld_out + lane] = sCon[H2 + lane];
+            a.arg[(int64_t)q * H2 + lane] = 0;
+            a.ysel[(int64_t)q * H2 + lane] = sCon[lane];
+          } else {                         // the max of equal rows sits at sample 0 (arg = 0): the only row with a gradient
+            vs += k2pos * a.gout[(int64_t)q * a.ld_g + lane];
           }
         }
       }
-    if constexpr (MODE == 1) __syncthreads();
-  }
+    }
+  };
+  enter_group();
+  auto next_live = [&]() -> int {
+    while (live_bits == 0) {
+      if ((int64_t)(w0 + 4 * (grp + 1) * nw) * 16 >= M) return -1;       // the next group's first chunk is past the end
+      ++grp;
+      f_cur = f_nxt;
+      f_nxt = load_flags(grp + 1);
+      enter_group();
+    }
+    const int bit = __builtin_ctzll(live_bits);
+    live_bits &= live_bits - 1;
+    return query_of(grp, bit);
+  };
+  auto advance = [&](Cur& c) {
+    if (c.q >= 0 && ++c.t == T) { c.t = 0; c.q = next_live(); }
+  };
 
-  Cur cur{w0, 0, 0, a.new_cnt[0], 0};
+  Cur cur{next_live(), 0, 0, a.new_cnt[0], 0};
+  int q = cur.q, t = 0;                    // the tile being computed
   StA a_nxt = load_a(cur);
   StB b_cur = load_b(a_nxt);
   advance(cur);
+  int q1 = cur.q, t1 = cur.t;
   a_nxt = load_a(cur);
-  for (int q = w0; q < M; q += nw) {
-    for (int t = 0; t < T; ++t) {
+  while (q >= 0) {
+    {
       StB b_nxt = load_b(a_nxt);
       advance(cur);
+      const int q2 = cur.q, t2 = cur.t;
       a_nxt = load_a(cur);
       // MODE 1 carries 48 registers of running maxima: keep the loop-invariant LDS reads (operand image, parameters) inside the
       // loop instead of hoisted into registers (78 spills otherwise)
       if constexpr (MODE == 1) asm volatile("" ::: "memory");
-      const bool live = __builtin_amdgcn_readfirstlane(b_cur.row) >= 0;     // empty[q] is per query: wave-uniform
-      if (!live) {
-        if constexpr (MODE == 0) ++n_empty;
-        if constexpr (MODE == 1) {
-          if (t == T - 1 && r == 0) {
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-              const int c = 16 * nb + 4 * g;
-              *reinterpret_cast<f4*>(a.out + (int64_t)q * a.ld_out + c) = *reinterpret_cast<const f4*>(sCon + H2 + c);
-              *reinterpret_cast<i4*>(a.arg + (int64_t)q * H2 + c) = i4{0, 0, 0, 0};
-              *reinterpret_cast<f4*>(a.ysel + (int64_t)q * H2 + c) = *reinterpret_cast<const f4*>(sCon + c);
-            }
-          }
-        }
-        if constexpr (MODE == 2) {
-          if (t == 0) {                      // the max of equal rows sits at sample 0 (arg = 0): the only row with a gradient
-            ++n_empty;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-              const int c = 16 * nb + 4 * g;
-              const f4 gs = *reinterpret_cast<const f4*>(a.gout + (int64_t)q * a.ld_g + c);
-              const f4 is = *reinterpret_cast<const f4*>(sBn2 + H2 + c), ga = *reinterpret_cast<const f4*>(sBn2 + 2 * H2 + c);
-              f4 d;
-#pragma unroll
-              for (int k = 0; k < 4; ++k) d[k] = (posmask >> (nb * 4 + k)) & 1u ? gs[k] : 0.f;
-              if (r == 0) *reinterpret_cast<f4*>(sVsum + c) += ga * is * d;
-            }
-          }
-        }
-        b_cur = b_nxt;
-        continue;
-      }
       f4 z1[MB], xh1[MB], acc[NB];
       layer1(b_cur, b_cur.row >= 0, z1, xh1);
       gemm2(z1, acc);
@@ -467,6 +480,8 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
         }
       }
       b_cur = b_nxt;
+      q = q1; t = t1;
+      q1 = q2; t1 = t2;
     }
   }
 
@@ -475,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
     f4 z1c[MB], xh1c[MB], accc[NB];
     layer1(b_zero, false, z1c, xh1c);
     gemm2(z1c, accc);
-    const float ne = (float)n_empty;       // every lane is one of the 16 equal rows of each empty tile
+    const float ne = (float)(n_empty * T);  // empty tiles of this wave; every lane is one of the 16 equal rows of each
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -497,6 +512,10 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
       layer1(b_zero, false, z1c, xh1c);
       gemm2(z1c, accc);
       bn2(accc, xh2c, z2c);
+      if (lane < H2) sVsum[lane] = vs;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const float cnt = (float)n_empty * (float)ns;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {

@@ -101,6 +101,49 @@ def test_ticket_finalize_is_bit_identical_to_the_separate_finalize_launch(dev, n
         assert int(t.abs().sum()) == 0
 
 
+def test_ticket_hand_off_under_load_two_streams_many_shapes(dev):
+    """The ordering the ticket finalize relies on (write-through partials acknowledged before the block's ticket, L1-bypassing reads
+    by the last block; VERDICT r04: "nothing tests the ordering"): 240 forward + backward calls of mixed shapes issued back to back
+    on TWO streams at once (each stream has its own ticket area; the device is oversubscribed, blocks of different launches and
+    XCDs interleave) - every result bit-identical to the three-launch form computed afterwards on one stream, every ticket area
+    zero at the end."""
+    from crbhip import bnrelu
+    shapes = [(563200, 128), (70001, 16), (4097, 256), (190000, 64), (33, 32), (140800, 256), (9000, 128), (250007, 16)]
+    g = torch.Generator(device=dev).manual_seed(11)
+    data = [(torch.randn(n, C, device=dev, generator=g) * 1.3 + 0.2, torch.randn(n, C, device=dev, generator=g)) for n, C in shapes]
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    torch.cuda.synchronize()
+    got = [[], []]
+    old = bnrelu.TICKETS
+    try:
+        bnrelu.TICKETS = True
+        for rep in range(15):
+            for k, (x, dz) in enumerate(data):
+                for si, st in enumerate(streams):
+                    with torch.cuda.stream(st):
+                        bn = _bn(x.shape[1], dev, 5 + k)
+                        xl = x.detach().requires_grad_(True)
+                        z = bnrelu.bn_relu(xl, bn, True)
+                        z.backward(dz)
+                        if rep == 14:
+                            got[si].append((z.detach(), xl.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var))
+        torch.cuda.synchronize()
+        for t in bnrelu._ticket_areas.values():
+            assert int(t.abs().sum()) == 0
+        bnrelu.TICKETS = False
+        for k, (x, dz) in enumerate(data):
+            bn = _bn(x.shape[1], dev, 5 + k)
+            xl = x.detach().requires_grad_(True)
+            z = bnrelu.bn_relu(xl, bn, True)
+            z.backward(dz)
+            ref = (z.detach(), xl.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var)
+            for si in range(2):
+                for a, b in zip(got[si][k], ref):
+                    assert torch.equal(a, b), (k, si)
+    finally:
+        bnrelu.TICKETS = old
+
+
 def test_kernel_side_updates_of_the_running_statistics_invalidate_the_eval_caches(dev):
     """the running statistics and the batch counter are written by the kernels through raw pointers; their version counters are
     bumped like an in-place torch op would, so what is cached for eval mode on (address, version) — rsqrt(running_var + eps),

@@ -49,6 +49,7 @@ if __name__ == '__main__':
     native = lambda n: ('at::native' in n) or ('rocclr' in n) or n.startswith('Memcpy') or n.startswith('Memset')
     by_site = collections.defaultdict(lambda: [0, 0.0, collections.Counter()])
     total = [0, 0.0]
+    heavy = collections.defaultdict(lambda: [0, 0.0])
     for e in prof.events():
         ks = [k for k in getattr(e, 'kernels', []) if native(k.name)]
         if not ks or any(getattr(c, 'kernels', None) for c in e.cpu_children):
@@ -57,6 +58,8 @@ if __name__ == '__main__':
         while p is not None and not p.name.startswith('mod:'):
             p = p.cpu_parent
         site = ('in ' + p.name[4:]) if p is not None else 'outside the modules'
+        heavy[(site, e.name.replace('aten::', ''))][0] += len(ks)
+        heavy[(site, e.name.replace('aten::', ''))][1] += sum(k.duration for k in ks)
         rec = by_site[site]
         rec[0] += len(ks)
         rec[1] += sum(k.duration for k in ks)
@@ -66,3 +69,6 @@ if __name__ == '__main__':
     print('scoring pass of %d frames: %d torch-native kernel launches, %.2f ms of device time' % (B, total[0], total[1] / 1e3))
     for site, (n, us, ops) in sorted(by_site.items(), key=lambda kv: -kv[1][0])[:top]:
         print('%4d launches %7.1f us  %-46s [%s]' % (n, us, site[:46], ', '.join('%s x%d' % (k, v) for k, v in ops.most_common(9))))
+    print('heaviest (site, op) pairs by device time:')
+    for (site, op), (n, us) in sorted(heavy.items(), key=lambda kv: -kv[1][1])[:25]:
+        print('  %7.1f us  x%-3d %-14s %s' % (us, n, op, site))
