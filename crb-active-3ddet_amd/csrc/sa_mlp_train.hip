@@ -68,7 +68,14 @@ struct SaTrainArgs {
   float* gz1;              // (M*ns, H1): dz1 [z1 > 0]
   float* part1;            // (waves, 2, H1): sums of d, d * xhat1
   float* partW;            // (blocks, H2, H1)
+  int skip;                // measurement builds (wrong results): bit 0 = no MFMAs of the forward GEMM, bit 1 = every P row is row 0
+                           // (no gather misses), bit 2 = no layer 1 (z1 = the P slice); 0 in the product library
 };
+#ifdef CRB_MEASURE
+int g_sat_skip = 0;
+#else
+constexpr int g_sat_skip = 0;
+#endif
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
@@ -118,7 +125,7 @@ __device__ __forceinline__ void lds_read_vec(const float* p, float (&v)[N]) {
 }
 
 template <int H1, int H2, int MODE>
-__global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
+__global__ __launch_bounds__(256, MODE == 0 ? 4 : MODE == 1 ? 3 : 2) void sa_train_kernel(SaTrainArgs a) {
   constexpr int MB = H1 / 16, NB = H2 / 16;
   using L = SaLds<H1, H2, MODE>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -188,25 +195,27 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
   };
   auto load_b = [&](const StA& s) {
     StB b;
-    b.row = s.valid ? s.start + s.idxv : -1;
-    b.px = b.py = b.pz = 0.f;
+    // (only live queries get here; past the end of the wave's work the cursor is invalid and row 0 is read and never used: no
+    // branch around the loads, no zero-initialised operand set)
+    b.row = s.valid ? s.start + s.idxv : 0;
     b.cx = s.cx; b.cy = s.cy; b.cz = s.cz;
+    const float* src = a.P + (int64_t)((a.skip & 2) ? 0 : b.row) * H1 + 4 * g;
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) b.p[mb] = f4{0.f, 0.f, 0.f, 0.f};
-    if (b.row >= 0) {
-      const float* src = a.P + (int64_t)b.row * H1 + 4 * g;
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) b.p[mb] = *reinterpret_cast<const f4*>(src + 16 * mb);
-      b.px = a.xyz[(int64_t)b.row * 3 + 0];
-      b.py = a.xyz[(int64_t)b.row * 3 + 1];
-      b.pz = a.xyz[(int64_t)b.row * 3 + 2];
-    }
+    for (int mb = 0; mb < MB; ++mb) b.p[mb] = *reinterpret_cast<const f4*>(src + 16 * mb);
+    b.px = a.xyz[(int64_t)b.row * 3 + 0];
+    b.py = a.xyz[(int64_t)b.row * 3 + 1];
+    b.pz = a.xyz[(int64_t)b.row * 3 + 2];
     return b;
   };
 
   // ---- the tile's arithmetic, shared by the modes
   // layer 1: y1 -> xhat1 -> z1 in the (sample r, channels 16 mb + 4 g + j) layout; live = false: the zero grouped row of an empty ball
   auto layer1 = [&](const StB& b, bool live, f4 (&z1)[MB], f4 (&xh1)[MB]) {
+    if (a.skip & 4) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) z1[mb] = xh1[mb] = b.p[mb];
+      return;
+    }
     const float dx = b.px - b.cx, dy = b.py - b.cy, dz = b.pz - b.cz;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
@@ -231,6 +240,11 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
   auto gemm2 = [&](const f4 (&z1)[MB], f4 (&acc)[NB]) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
+    if (a.skip & 1) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = z1[nb % MB];
+      return;
+    }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -400,24 +414,13 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
     if (c.q >= 0 && ++c.t == T) { c.t = 0; c.q = next_live(); }
   };
 
-  Cur cur{next_live(), 0, 0, a.new_cnt[0], 0};
-  int q = cur.q, t = 0;                    // the tile being computed
-  StA a_nxt = load_a(cur);
-  StB b_cur = load_b(a_nxt);
-  advance(cur);
-  int q1 = cur.q, t1 = cur.t;
-  a_nxt = load_a(cur);
-  while (q >= 0) {
-    {
-      StB b_nxt = load_b(a_nxt);
-      advance(cur);
-      const int q2 = cur.q, t2 = cur.t;
-      a_nxt = load_a(cur);
+  // one tile: query q, row tile t, operands b_cur
+  auto compute = [&](const StB& b_cur, const int q, const int t) {
       // MODE 1 carries 48 registers of running maxima: keep the loop-invariant LDS reads (operand image, parameters) inside the
-      // loop instead of hoisted into registers (78 spills otherwise)
+      // loop instead of hoisted into registers (78 spills otherwise); MODE 0: the registers go to the second prefetch stage
       if constexpr (MODE == 1) asm volatile("" ::: "memory");
       f4 z1[MB], xh1[MB], acc[NB];
-      layer1(b_cur, b_cur.row >= 0, z1, xh1);
+      layer1(b_cur, true, z1, xh1);
       gemm2(z1, acc);
       if constexpr (MODE == 0) {
 #pragma unroll
@@ -479,10 +482,27 @@ __global__ __launch_bounds__(256, 2) void sa_train_kernel(SaTrainArgs a) {
           bwd_tile(dy2, z1, xh1, grow);
         }
       }
-      b_cur = b_nxt;
-      q = q1; t = t1;
-      q1 = q2; t1 = t2;
-    }
+  };
+
+  Cur cur{next_live(), 0, 0, a.new_cnt[0], 0};
+  int q = cur.q, t = 0;                    // the tile being computed
+  StA a_nxt = load_a(cur);
+  // one tile of look-ahead for the P rows (two tiles, with three operand sets in rotation, measured the same: the gathers are not
+  // what a tile waits for - profiles/r05_sa_train_skip_work.txt)
+  StB b_cur = load_b(a_nxt);
+  advance(cur);
+  int q1 = cur.q, t1 = cur.t;
+  a_nxt = load_a(cur);
+  // (two operand sets used alternately with the loop unrolled by two - no copies - measured slower: the doubled body spills)
+  while (q >= 0) {
+    StB b_nxt = load_b(a_nxt);
+    advance(cur);
+    const int q2 = cur.q, t2 = cur.t;
+    a_nxt = load_a(cur);
+    compute(b_cur, q, t);
+    b_cur = b_nxt;
+    q = q1; t = t1;
+    q1 = q2; t1 = t2;
   }
 
   const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
@@ -588,7 +608,10 @@ __global__ __launch_bounds__(256) void sa_reduce_parts_kernel(SaReduceJob ja, in
 
 int g_sat_cus[64];                          // compute units per device (0 = not asked yet)
 
-int sat_grid(int64_t M) {
+// workgroups per CU by pass: the statistics pass fits 128 registers (4 waves per SIMD), the max pass 168 (3), the backward pass 256 (2)
+constexpr int SAT_PER_CU[3] = {4, 3, 2};
+
+int sat_grid(int64_t M, int mode) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   int n = __atomic_load_n(&g_sat_cus[dev], __ATOMIC_RELAXED);
@@ -597,8 +620,8 @@ int sat_grid(int64_t M) {
     n = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     __atomic_store_n(&g_sat_cus[dev], n, __ATOMIC_RELAXED);
   }
-  const int64_t want = (M + 3) / 4;
-  return (int)(want < 2 * n ? want : 2 * n);
+  const int64_t want = (M + 3) / 4, cap = (int64_t)SAT_PER_CU[mode] * n;
+  return (int)(want < cap ? want : cap);
 }
 
 template <int H1, int H2, int MODE>
@@ -640,7 +663,7 @@ extern "C" int crb_sa_mlp2_train_supported(int h1, int h2, int nsample) {
   return (h1 == 16 || h1 == 32 || h1 == 64) && (h2 == 16 || h2 == 32 || h2 == 64) && nsample >= 16 && nsample % 16 == 0;
 }
 
-extern "C" int64_t crb_sa_mlp2_train_waves(int64_t M) { return (int64_t)sat_grid(M < 1 ? 1 : M) * 4; }
+extern "C" int64_t crb_sa_mlp2_train_waves(int64_t M) { return (int64_t)sat_grid(M < 1 ? 1 : M, 0) * 4; }
 
 extern "C" int crb_sa_mlp2_train_stats(int B, int64_t M, int nsample, int h1, int h2, const float* xyz,
                                        const int32_t* xyz_batch_cnt, const float* P, const float* new_xyz,
@@ -649,11 +672,12 @@ extern "C" int crb_sa_mlp2_train_stats(int B, int64_t M, int nsample, int h1, in
                                        const float* beta1, const float* W2, float* wave_sums, void* stream) {
   if (!sat_common_ok(B, M, nsample, h1, h2) || !wave_sums) return CRB_ERR_ARG;
   SaTrainArgs a{};
+  a.skip = g_sat_skip;
   a.B = B; a.M = M; a.ns = nsample; a.xyz = xyz; a.xyz_cnt = xyz_batch_cnt; a.P = P; a.new_xyz = new_xyz;
   a.new_cnt = new_xyz_batch_cnt; a.idx = idx; a.empty = empty_mask; a.W1x = W1x; a.W2 = W2;
   a.bn1[0] = mean1; a.bn1[1] = invstd1; a.bn1[2] = gamma1; a.bn1[3] = beta1;
   a.stat = wave_sums;
-  const int rc = dispatch_sat<0>(h1, h2, a, sat_grid(M), (hipStream_t)stream);
+  const int rc = dispatch_sat<0>(h1, h2, a, sat_grid(M, 0), (hipStream_t)stream);
   if (rc != CRB_OK) return rc;
   CRB_CHECK_LAUNCH();
   return CRB_OK;
@@ -668,19 +692,20 @@ extern "C" int crb_sa_mlp2_train_max(int B, int64_t M, int nsample, int h1, int 
                                      float* y_sel, void* stream) {
   if (!sat_common_ok(B, M, nsample, h1, h2) || !out || !arg || !y_sel || out_row_stride < h2) return CRB_ERR_ARG;
   SaTrainArgs a{};
+  a.skip = g_sat_skip;
   a.B = B; a.M = M; a.ns = nsample; a.xyz = xyz; a.xyz_cnt = xyz_batch_cnt; a.P = P; a.new_xyz = new_xyz;
   a.new_cnt = new_xyz_batch_cnt; a.idx = idx; a.empty = empty_mask; a.W1x = W1x; a.W2 = W2;
   a.bn1[0] = mean1; a.bn1[1] = invstd1; a.bn1[2] = gamma1; a.bn1[3] = beta1;
   a.bn2[0] = mean2; a.bn2[1] = invstd2; a.bn2[2] = gamma2; a.bn2[3] = beta2;
   a.out = out; a.ld_out = out_row_stride; a.arg = arg; a.ysel = y_sel;
-  const int rc = dispatch_sat<1>(h1, h2, a, sat_grid(M), (hipStream_t)stream);
+  const int rc = dispatch_sat<1>(h1, h2, a, sat_grid(M, 1), (hipStream_t)stream);
   if (rc != CRB_OK) return rc;
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
 
 extern "C" int64_t crb_sa_mlp2_train_backward_workspace_floats(int64_t M, int h1, int h2) {
-  const int64_t grid = sat_grid(M < 1 ? 1 : M);
+  const int64_t grid = sat_grid(M < 1 ? 1 : M, 2);
   return grid * 4 * 2 * h1 + grid * (int64_t)h1 * h2;
 }
 
@@ -698,8 +723,9 @@ extern "C" int crb_sa_mlp2_train_backward(int B, int64_t M, int nsample, int h1,
     return CRB_ERR_ARG;
   if (!workspace || workspace_floats < crb_sa_mlp2_train_backward_workspace_floats(M, h1, h2)) return CRB_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  const int grid = sat_grid(M);
+  const int grid = sat_grid(M, 2);
   SaTrainArgs a{};
+  a.skip = g_sat_skip;
   a.B = B; a.M = M; a.ns = nsample; a.xyz = xyz; a.xyz_cnt = xyz_batch_cnt; a.P = P; a.new_xyz = new_xyz;
   a.new_cnt = new_xyz_batch_cnt; a.idx = idx; a.empty = empty_mask; a.W1x = W1x; a.W2 = W2;
   a.bn1[0] = mean1; a.bn1[1] = invstd1; a.bn1[2] = gamma1; a.bn1[3] = beta1;
@@ -717,3 +743,10 @@ extern "C" int crb_sa_mlp2_train_backward(int B, int64_t M, int nsample, int h1,
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
+
+#ifdef CRB_MEASURE
+extern "C" int crb_sa_mlp2_train_set_skip(int bits) {
+  g_sat_skip = bits;
+  return CRB_OK;
+}
+#endif

@@ -87,6 +87,9 @@ int crb_winograd_weights(const float* g, float* U, int cin, int cout, void* stre
 int crb_conv3x3_winograd_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
                               const float* bias, int relu, void* stream);
 
+/* measurement builds of the training set-abstraction passes (wrong results): bit 0 = no MFMAs in the forward GEMM, bit 1 = every P row is
+ * row 0 (no gather misses), bit 2 = no first layer */
+int crb_sa_mlp2_train_set_skip(int bits);
 /* FETCH_SIZE calibration on the Winograd forward kernel's access pattern: LDS-DMA (global_load_lds_dwordx4) reads of `pieces` pieces of
  * 32 bytes, `stride_bytes` apart (32 = dense, 512 = the 8-channel pieces of adjacent pixels of a 128-channel NHWC map); pass_mask bit p
  * = a sweep over the p-th 32-byte piece of every stride (p < 4). Requested bytes = pieces * 32 * popcount(pass_mask). sink256: 256 floats. */

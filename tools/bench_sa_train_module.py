@@ -53,6 +53,24 @@ def fwd_bwd():
     return torch.autograd.grad(out, params, go)
 
 
+if os.environ.get('CRB_MEASURE_LIB') == '1' and os.environ.get('SAT_SKIP'):
+    # skip-work builds of the recompute passes (measurement library): where a pass spends its time
+    from crbhip import lib
+    for bits in [int(v) for v in os.environ['SAT_SKIP'].split(',')]:
+        lib.crb_sa_mlp2_train_set_skip(bits)
+        M.FUSED_TRAIN = True
+        with torch.no_grad():
+            pass
+        from torch.profiler import profile, ProfilerActivity
+        fwd_bwd()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            fwd_bwd()
+            torch.cuda.synchronize()
+        evs = sorted([e for e in prof.events() if e.device_time_total > 0 and 'sa_train' in e.name], key=lambda e: e.time_range.start)
+        print('skip bits %d (1 = no forward-GEMM MFMAs, 2 = P row 0 for every sample, 4 = no first layer): sa_train launches in order (us): %s'
+              % (bits, ', '.join('%.0f' % e.device_time_total for e in evs)))
+    lib.crb_sa_mlp2_train_set_skip(0)
+    sys.exit(0)
 res = {}
 for tag, flag in (('recompute node', True), ('rows path', False)):
     M.FUSED_TRAIN = flag
