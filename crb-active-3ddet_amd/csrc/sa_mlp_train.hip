@@ -79,7 +79,7 @@ constexpr int g_sat_skip = 0;
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 // reductions over the 16 lanes of a DPP row (= the 16 samples of a tile); every lane ends with the result
 __device__ __forceinline__ float row_max16(float v) {
@@ -88,6 +88,20 @@ __device__ __forceinline__ float row_max16(float v) {
   v = fmaxf(v, dpp_f<0x141>(v));     // row_half_mirror
   v = fmaxf(v, dpp_f<0x140>(v));     // row_mirror
   return v;
+}
+// the same for NON-NEGATIVE finite floats (relu outputs): their bit patterns order like integers, and an integer maximum needs no
+// NaN canonicalisation of its operands (fmaxf costs a v_max v, v, v per step on top of the DPP move)
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ float row_max16_nonneg(float f) {
+  int v = __builtin_bit_cast(int, f);
+  v = max(v, dpp_i<0xB1>(v));
+  v = max(v, dpp_i<0x4E>(v));
+  v = max(v, dpp_i<0x141>(v));
+  v = max(v, dpp_i<0x140>(v));
+  return __builtin_bit_cast(float, v);
 }
 __device__ __forceinline__ float row_sum16(float v) {
   v += dpp_f<0xB1>(v);
@@ -438,7 +452,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 4 : MODE == 1 ? 3 : 2) void sa_tra
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const float z = z2[nb][j] > 0.f ? z2[nb][j] : 0.f;
-              const float zm = row_max16(z);
+              const float zm = row_max16_nonneg(z);
               const unsigned long long bal = __ballot(z == zm);
               const unsigned rowbits = (unsigned)(bal >> (16 * g)) & 0xffffu;
               const int first = __ffs((int)rowbits) - 1;                 // lowest sample of the tile that attains the maximum
