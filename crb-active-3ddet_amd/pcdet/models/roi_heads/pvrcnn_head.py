@@ -92,6 +92,28 @@ class PVRCNNHead(RoIHeadTemplate):
         size = rois.view(batch_size_rcnn, -1)[:, 3:6].unsqueeze(1)
         return (dense_idx + 0.5) / grid_size * size - size / 2
 
+    # training / grad path: the reference flattens the pooled tensor channel-major (pvrcnn_head.py:172-176: permute(0, 2, 1) +
+    # contiguous of a 226 MB tensor, and the same copy for its gradient). Re-ordering the COLUMNS of the first FC weight instead
+    # (28 MB, differentiable) leaves the pooled rows where the pooling wrote them: same products, another K order in the GEMM.
+    WEIGHT_SIDE_FLATTEN = __import__('os').environ.get('CRB_ROI_WEIGHT_SIDE_FLATTEN', '1') == '1'
+
+    def _heads_pooled(self, pooled):
+        """pooled (BN, G^3, C) -> shared, rcnn_cls, rcnn_reg without the channel-major copy of the pooled tensor"""
+        mods = list(self.shared_fc_layer)
+        n, g3, c = pooled.shape
+        conv0 = mods[0]
+        if not (self.WEIGHT_SIDE_FLATTEN and isinstance(conv0, nn.Conv1d) and conv0.kernel_size == (1,) and
+                conv0.in_channels == g3 * c):
+            return self._heads(pooled.permute(0, 2, 1).contiguous().view(n, -1, 1))
+        w = conv0.weight.view(conv0.out_channels, c, g3).permute(0, 2, 1).reshape(conv0.out_channels, g3 * c)
+        x = torch.nn.functional.linear(pooled.reshape(n, g3 * c), w, conv0.bias).unsqueeze(-1)     # (BN, 256, 1)
+        for m in mods[1:]:
+            x = m(x)
+        shared = x
+        rcnn_cls = self.cls_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
+        rcnn_reg = self.reg_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
+        return shared, rcnn_cls, rcnn_reg
+
     def _heads(self, pooled_flat):
         shared = self.shared_fc_layer(pooled_flat)
         rcnn_cls = self.cls_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
@@ -154,12 +176,15 @@ class PVRCNNHead(RoIHeadTemplate):
         fast = (not self.training) and (not torch.is_grad_enabled()) and \
             not any(m.training for m in self.modules() if isinstance(m, nn.BatchNorm1d))
         # the reference's channel-major flattening (a 226 MB copy at bs=16) is only needed off the fast path
-        pooled_flat = None if fast else pooled.permute(0, 2, 1).contiguous().view(n, -1, 1)          # (BN, C*G^3, 1)
+        pooled_flat = None
         if fast:
             rounds = self.model_cfg.get('SAMPLING_ROUND', None) or 1
             passes = self._heads_eval(pooled, rounds)
             shared, rcnn_cls, rcnn_reg = passes[-1]
+        elif self.training:
+            shared, rcnn_cls, rcnn_reg = self._heads_pooled(pooled)
         else:
+            pooled_flat = pooled.permute(0, 2, 1).contiguous().view(n, -1, 1)                        # (BN, C*G^3, 1)
             shared, rcnn_cls, rcnn_reg = self._heads(pooled_flat)
         if not self.training:
             rounds = self.model_cfg.get('SAMPLING_ROUND', None)
