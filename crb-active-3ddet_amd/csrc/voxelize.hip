@@ -67,6 +67,19 @@ __global__ __launch_bounds__(256) void vox_insert(const float* __restrict__ pts,
   pt_slot[i] = slot;
 }
 
+// all four fills of a call in one launch (round 5; they were four hipMemsetAsync launches): site keys = -1 (empty), first-point index
+// per site = CRB_IDX_EMPTY, per-row point count = 0, per-row slot list = CRB_IDX_EMPTY
+__global__ __launch_bounds__(256) void vox_clear(long long* __restrict__ hkeys, int* __restrict__ hval, int64_t H, int* __restrict__ cnt,
+                                                 int64_t cap, int* __restrict__ pidx, int64_t slots) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < H) {
+    hkeys[t] = -1LL;
+    hval[t] = CRB_IDX_EMPTY;
+  }
+  if (t < cap) cnt[t] = 0;
+  if (t < slots) pidx[t] = CRB_IDX_EMPTY;
+}
+
 struct FirstFlag {
   const uint32_t* pt_slot;
   const int* hval;
@@ -107,11 +120,41 @@ struct RankWriteAll {
   __device__ void operator()(int64_t i, int ex, int v) const { rank_first[i] = v ? ex : -1; rank_all[i] = ex; }
 };
 
+// FUSED_BASES (B <= VOX_MAX_FUSED_FRAMES): every workgroup forms the per-frame first rank / output base itself from the scan (B + 1
+// loads, a serial pass over the frames by one thread) instead of reading them from a one-thread launch of vox_frame_bases; workgroup 0
+// also writes num_voxels_out
+constexpr int VOX_MAX_FUSED_FRAMES = 256;
+template <bool FUSED_BASES>
 __global__ __launch_bounds__(256) void vox_assign(const float* __restrict__ pts, int n, VoxParams p,
                                                   const int* __restrict__ frame_off, const uint32_t* __restrict__ pt_slot,
                                                   const int* __restrict__ rank_first, const int* __restrict__ frame_S,
                                                   const int* __restrict__ frame_base, int* __restrict__ hval,
-                                                  int* __restrict__ coords /* (cap,4) b,z,y,x */) {
+                                                  int* __restrict__ coords /* (cap,4) b,z,y,x */,
+                                                  const int* __restrict__ rank_excl_all = nullptr,
+                                                  const int* __restrict__ total_first_ptr = nullptr,
+                                                  int* __restrict__ num_voxels_out = nullptr) {
+  __shared__ int sS[FUSED_BASES ? VOX_MAX_FUSED_FRAMES + 1 : 1], sBase[FUSED_BASES ? VOX_MAX_FUSED_FRAMES : 1];
+  if constexpr (FUSED_BASES) {
+    const int total_first = *total_first_ptr, n_total = frame_off[p.B];
+    for (int b = threadIdx.x; b <= p.B; b += 256) {
+      const int s0 = frame_off[b];
+      sS[b] = s0 < n_total ? rank_excl_all[s0] : total_first;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int base = 0;
+      for (int b = 0; b < p.B; ++b) {
+        const int c = sS[b + 1] - sS[b], kept = c < p.max_voxels ? c : p.max_voxels;
+        sBase[b] = base;
+        if (blockIdx.x == 0) num_voxels_out[b] = kept;
+        base += kept;
+      }
+      if (blockIdx.x == 0) num_voxels_out[p.B] = base;
+    }
+    __syncthreads();
+    frame_S = sS;
+    frame_base = sBase;
+  }
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   int r = rank_first[i];
@@ -230,9 +273,8 @@ extern "C" int crb_voxelize(const float* points, int64_t n_points, int num_featu
   p.gx = grid_xyz[0]; p.gy = grid_xyz[1]; p.gz = grid_xyz[2];
   p.max_voxels = max_voxels; p.max_points = max_points; p.C = num_features; p.B = B;
 
-  CRB_HIP(hipMemsetAsync(hkeys, 0xff, (size_t)H * 8, st));
-  CRB_HIP(hipMemsetAsync(hval, 0x7f, (size_t)H * 4, st));          // 0x7f7f7f7f > any index
-  CRB_HIP(hipMemsetAsync(cnt, 0, (size_t)cap * 4, st));
+  const int64_t slots = cap * max_points, clear_n = H > slots ? H : slots;      // (cap <= slots)
+  hipLaunchKernelGGL(vox_clear, dim3(crb_cdiv(clear_n, 256)), dim3(256), 0, st, hkeys, hval, H, cnt, cap, pidx, slots);
   const int blocks = crb_cdiv(n, 256);
   hipLaunchKernelGGL(vox_insert, dim3(blocks), dim3(256), 0, st, points, n, p, frame_offsets, hkeys, hval,
                      (uint32_t)(H - 1), pt_slot);
@@ -240,11 +282,15 @@ extern "C" int crb_voxelize(const float* points, int64_t n_points, int num_featu
   RankWriteAll rw{rank_first, rank_all};
   int rc = crb_device_excl_scan(ff, rw, (int64_t)n, tile_sums, total_first, st);
   if (rc != CRB_OK) return rc;
-  hipLaunchKernelGGL(vox_frame_bases, dim3(1), dim3(64), 0, st, frame_offsets, B, rank_all, total_first, max_voxels,
-                     frame_S, frame_base, num_voxels_out);
-  hipLaunchKernelGGL(vox_assign, dim3(blocks), dim3(256), 0, st, points, n, p, frame_offsets, pt_slot, rank_first,
-                     frame_S, frame_base, hval, coords);
-  CRB_HIP(hipMemsetAsync(pidx, 0x7f, (size_t)cap * max_points * 4, st));
+  if (B <= VOX_MAX_FUSED_FRAMES) {
+    hipLaunchKernelGGL(vox_assign<true>, dim3(blocks), dim3(256), 0, st, points, n, p, frame_offsets, pt_slot, rank_first,
+                       (const int*)nullptr, (const int*)nullptr, hval, coords, rank_all, total_first, num_voxels_out);
+  } else {
+    hipLaunchKernelGGL(vox_frame_bases, dim3(1), dim3(64), 0, st, frame_offsets, B, rank_all, total_first, max_voxels,
+                       frame_S, frame_base, num_voxels_out);
+    hipLaunchKernelGGL(vox_assign<false>, dim3(blocks), dim3(256), 0, st, points, n, p, frame_offsets, pt_slot, rank_first,
+                       frame_S, frame_base, hval, coords);
+  }
   hipLaunchKernelGGL(vox_collect, dim3(blocks), dim3(256), 0, st, n, max_points, pt_slot, hval, cnt, pidx);
   const int64_t gthreads = cap * num_features;
   hipLaunchKernelGGL(vox_gather, dim3(crb_cdiv(gthreads, 256)), dim3(256), 0, st, points, num_features, max_points,
