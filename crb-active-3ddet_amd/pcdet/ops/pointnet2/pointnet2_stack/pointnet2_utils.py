@@ -8,6 +8,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from crbhip import lib, check, ptr, cur_stream, require_cuda
+from ....utils.linear_rows import tall_t_matmul as _tall_t_matmul
 
 
 def _i32(t):
@@ -222,7 +223,7 @@ class GroupedFirstLayerRows(Function):
         gf = gP @ w1f if ctx.needs_input_grad[4] else None
         gw = None
         if ctx.needs_input_grad[7]:
-            gw = torch.cat([part.sum(0).t(), gP.t() @ feats], dim=1)           # (H, 3+C)
+            gw = torch.cat([part.sum(0).t(), _tall_t_matmul(gP, feats)], dim=1)           # (H, 3+C)
         return None, None, None, None, gf, None, None, gw
 
 
@@ -304,7 +305,7 @@ class GroupedFirstLayerBNReLU(Function):
                                                       ptr(mean), ptr(invstd), ptr(g), ptr(b), ptr(dbeta), ptr(dgamma), ptr(gP),
                                                       ptr(part), cur_stream(dev)), 'crb_group_affine_rows_grad_bn_stack')
         gf = gP @ w1f if ctx.needs_input_grad[4] else None
-        gw = torch.cat([part.sum(0).t(), gP.t() @ feats], dim=1) if ctx.needs_input_grad[7] else None
+        gw = torch.cat([part.sum(0).t(), _tall_t_matmul(gP, feats)], dim=1) if ctx.needs_input_grad[7] else None
         return None, None, None, None, gf, None, None, gw, dgamma, dbeta, None, None, None, None, None
 
 
@@ -451,7 +452,7 @@ class SAMlp2TrainConcat(Function):
             if ctx.needs_input_grad[4]:
                 gf = gP @ w1f
                 gfeat = gf if gfeat is None else gfeat + gf
-            gW1 = torch.cat([part.sum(0).t(), gP.t() @ feats], dim=1)           # (h1, 3+C)
+            gW1 = torch.cat([part.sum(0).t(), _tall_t_matmul(gP, feats)], dim=1)           # (h1, 3+C)
             grads += [None, None, gW1, d1[1], d1[0], None, None, None, None, None,
                       dW2, d2[1], d2[0], None, None, None, None, None]
         return (None, None, None, None, gfeat) + tuple(grads)
