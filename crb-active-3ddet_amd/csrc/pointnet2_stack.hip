@@ -17,6 +17,7 @@
 //    reference's tie rule exactly (first max per strided thread, then the lower-position operand of its LDS tree).
 //  * grouping: one workgroup per centre tile, rows read coalesced along C, the (C,nsample) slab transposed through LDS
 //    so the (M,C,nsample) output is written contiguously; the gradient scatters with channel-contiguous atomics.
+#include <hipcub/hipcub.hpp>
 #include "crb_common.h"
 #include "../../include/crb_hip.h"
 
@@ -746,6 +747,13 @@ struct GroupBn {
   const float* new_xyz;
   const float* P;
   const float* W1x;
+  // RECOMP instances, optional: the pairs in SOURCE-ROW order (crb_pair_sort_by_source: sorted_pair[k] = pair index, sorted_row[k] =
+  // its source row, n_src for the pairs of empty balls, which sort to the end). A slab then holds runs of pairs with one target: the
+  // fold below adds a run in LDS and issues ONE row of atomics per (16-pair segment, run) - at the voxel levels of the VSA module,
+  // where every sample of a ball is a different row and many balls share a voxel, 5 - 8 x fewer atomics than in pair order
+  const int* sorted_pair;
+  const int* sorted_row;
+  int n_src;
   const float* y_rows;
   const float* mean;
   const float* invstd;
@@ -774,11 +782,29 @@ __global__ __launch_bounds__(256) void group_affine_rows_grad_kernel(int B, int6
   __shared__ float sd[64][3];
   const int64_t p0 = (int64_t)blockIdx.x * 64;
   int myrow = -1;
+  __shared__ int spair[64];                                  // pair index of slot pl (identity order: p0 + pl)
+  const bool sorted = RECOMP && bn.sorted_pair != nullptr;
   if (threadIdx.x < 64) {
-    const int64_t p = p0 + threadIdx.x;
+    const int64_t k = p0 + threadIdx.x;
+    int64_t p = k;
     int row = -1;
     float dx = 0.f, dy = 0.f, dz = 0.f;
-    if (p < MP) {
+    if (sorted) {
+      if (k < MP) {
+        p = bn.sorted_pair[k];
+        const int rr = bn.sorted_row[k];
+        if (rr < bn.n_src) {
+          row = rr;
+          myrow = row;
+          const int m = (int)(p / ns);
+          dx = bn.xyz[(int64_t)row * 3 + 0] - bn.new_xyz[(int64_t)m * 3 + 0];
+          dy = bn.xyz[(int64_t)row * 3 + 1] - bn.new_xyz[(int64_t)m * 3 + 1];
+          dz = bn.xyz[(int64_t)row * 3 + 2] - bn.new_xyz[(int64_t)m * 3 + 2];
+        }
+      }
+      spair[threadIdx.x] = (int)p;
+    } else if (p < MP) {
+      spair[threadIdx.x] = (int)p;
       const int m = (int)(p / ns);
       if (!empty[m]) {
         int start;
@@ -824,7 +850,8 @@ __global__ __launch_bounds__(256) void group_affine_rows_grad_kernel(int B, int6
     const int pl = plane + i * NPLANE;
     bool have = pl < npl;
     if constexpr (RECOMP) have = have && srow[pl] >= 0;      // rows of empty balls were not written by the producer
-    v[i] = have ? src[pl * H4 + c4] : (gf4){0.f, 0.f, 0.f, 0.f};
+    if (sorted) v[i] = have ? reinterpret_cast<const gf4*>(grad_out + (int64_t)spair[pl] * H)[c4] : (gf4){0.f, 0.f, 0.f, 0.f};
+    else v[i] = have ? src[pl * H4 + c4] : (gf4){0.f, 0.f, 0.f, 0.f};
     if constexpr (BN) {
       if (have) {
         gf4 yv;
@@ -887,9 +914,16 @@ __global__ __launch_bounds__(256) void group_affine_rows_grad_kernel(int B, int6
   if (threadIdx.x < 64) {                                    // first occurrence of this pair's row in its 16-pair segment
     const int row = srow[threadIdx.x];
     int f = threadIdx.x;
-    if (row >= 0)
+    if (sorted) {
+      // source-row order: equal rows are adjacent, the first of a run inside the segment = the highest run start at or below me
+      const bool startrun = (threadIdx.x & 15) == 0 || srow[threadIdx.x - 1] != row;
+      const unsigned long long starts = __ballot(startrun);              // (threads 0..63 = wave 0)
+      const unsigned long long below = starts & ((2ULL << threadIdx.x) - 1ULL);
+      f = 63 - __builtin_clzll(below);
+    } else if (row >= 0) {
       for (int q = threadIdx.x & ~15; q < (int)threadIdx.x; ++q)
         if (srow[q] == row) { f = q; break; }
+    }
     first[threadIdx.x] = f;
   }
   __syncthreads();
@@ -930,11 +964,26 @@ __global__ __launch_bounds__(256) void group_affine_rows_grad_kernel(int B, int6
     if (cur >= 0) slab[cur * H + c] += acc;
   }
   __syncthreads();
-  // one source row per H consecutive lanes
   const int c = threadIdx.x % H, r0 = threadIdx.x / H;
+  if (sorted) {
+    // source-row order: a run goes on across the segment borders (a keypoint of the RoI-grid scales has hundreds of pairs). The
+    // head of a segment whose row continues the previous segment's last run is added to that run's head, last segment first, so a
+    // run over several whole segments arrives at its first head
+    if (threadIdx.x < H) {
+#pragma unroll
+      for (int seg = 3; seg >= 1; --seg) {
+        const int h = 16 * seg, row = srow[h];
+        if (row >= 0 && srow[h - 1] == row) slab[first[h - 1] * H + c] += slab[h * H + c];
+      }
+    }
+    __syncthreads();
+  }
+  // one source row per H consecutive lanes
   for (int pl = r0; pl < 64; pl += NROW) {
     const int row = srow[pl];
-    if (row >= 0 && first[pl] == pl) atomicAdd(&grad_P[(int64_t)row * H + c], slab[pl * H + c]);
+    bool head = row >= 0 && first[pl] == pl;
+    if (sorted && pl > 0 && (pl & 15) == 0 && srow[pl - 1] == row) head = false;
+    if (head) atomicAdd(&grad_P[(int64_t)row * H + c], slab[pl * H + c]);
   }
 }
 
@@ -1317,7 +1366,7 @@ extern "C" int crb_group_affine_rows_grad_bn_stack(int B, int64_t M, int H, int 
   const int64_t MP = M * nsample;
   const dim3 grid(crb_cdiv(MP, 64));
   hipStream_t st = (hipStream_t)stream;
-  const GroupBn bn{nullptr, nullptr, nullptr, nullptr, y, mean, invstd, gamma, beta, dbeta, dgamma, 1.0f / (float)MP};
+  const GroupBn bn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, y, mean, invstd, gamma, beta, dbeta, dgamma, 1.0f / (float)MP};
 #define CRB_GA_CASE(HH)                                                                                              \
   if (H == HH)                                                                                                       \
     hipLaunchKernelGGL((group_affine_rows_grad_kernel<HH, true>), grid, dim3(256), 0, st, B, MP, nsample, xyz_batch_cnt, \
@@ -1335,22 +1384,85 @@ extern "C" int crb_group_affine_rows_grad_bn_recompute_stack(int B, int64_t M, i
                                                              const uint8_t* empty_mask, const float* W1x, const float* grad_z,
                                                              const float* mean, const float* invstd, const float* gamma,
                                                              const float* beta, const float* dbeta, const float* dgamma,
+                                                             const int32_t* sorted_pair, const int32_t* sorted_row, int64_t n_src,
                                                              float* grad_P /* pre-zeroed */, float* part, void* stream) {
   if (B <= 0 || M < 0 || H <= 0 || nsample <= 0 || !xyz || !P || !new_xyz || !W1x || !mean || !invstd || !gamma || !beta ||
       !dbeta || !dgamma)
     return CRB_ERR_ARG;
+  if ((sorted_pair == nullptr) != (sorted_row == nullptr) || (sorted_pair && (n_src <= 0 || n_src >= (1LL << 31)))) return CRB_ERR_ARG;
   if (H != 16 && H != 32 && H != 64 && H != 128) return CRB_ERR_UNSUPPORTED;
   if (M == 0) return CRB_OK;
   const int64_t MP = M * nsample;
   const dim3 grid(crb_cdiv(MP, 64));
   hipStream_t st = (hipStream_t)stream;
-  const GroupBn bn{xyz, new_xyz, P, W1x, nullptr, mean, invstd, gamma, beta, dbeta, dgamma, 1.0f / (float)MP};
+  const GroupBn bn{xyz, new_xyz, P, W1x, sorted_pair, sorted_row, (int)n_src, nullptr, mean, invstd, gamma, beta, dbeta, dgamma,
+                   1.0f / (float)MP};
 #define CRB_GA_CASE(HH)                                                                                                    \
   if (H == HH)                                                                                                             \
     hipLaunchKernelGGL((group_affine_rows_grad_kernel<HH, true, true>), grid, dim3(256), 0, st, B, MP, nsample, xyz_batch_cnt, \
                        new_xyz_batch_cnt, idx, empty_mask, (const float*)nullptr, grad_z, grad_P, part, bn);
   CRB_GA_CASE(16) CRB_GA_CASE(32) CRB_GA_CASE(64) CRB_GA_CASE(128)
 #undef CRB_GA_CASE
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+// ---- pairs in source-row order (for the sorted form of the scatter above) ---------------------------------------------------------
+// key[p] = source row of pair p (start of its frame + idx[p]), n_src for the pairs of an empty ball; a stable device radix sort
+// (hipCUB) of (key, p) over the bits n_src needs: sorted_row / sorted_pair. Stable = pairs of one source row stay in pair order.
+__global__ __launch_bounds__(256) void pair_source_keys_kernel(int B, int64_t MP, int ns, const int* __restrict__ xyz_cnt,
+                                                               const int* __restrict__ new_cnt, const int* __restrict__ idx,
+                                                               const unsigned char* __restrict__ empty, int n_src,
+                                                               int* __restrict__ key, int* __restrict__ val) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= MP) return;
+  const int m = (int)(p / ns);
+  int k = n_src;
+  if (!empty[m]) {
+    int start;
+    locate_batch(new_cnt, B, m, xyz_cnt, &start);
+    k = start + idx[p];
+  }
+  key[p] = k;
+  val[p] = (int)p;
+}
+
+static size_t pair_sort_temp_bytes(int64_t n) {
+  size_t b = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const int*)nullptr, (int*)nullptr, (const int*)nullptr, (int*)nullptr, (int)n,
+                                           0, 32, (hipStream_t)0);
+  return b;
+}
+
+extern "C" int64_t crb_pair_sort_workspace_bytes(int64_t M, int nsample) {
+  const int64_t n = M * nsample;
+  if (n <= 0) return 256;
+  return 2 * crb_align_up(4 * n, 256) + crb_align_up((int64_t)pair_sort_temp_bytes(n), 256) + 256;
+}
+
+extern "C" int crb_pair_sort_by_source(int B, int64_t M, int nsample, const int32_t* xyz_batch_cnt, const int32_t* new_xyz_batch_cnt,
+                                       const int32_t* idx, const uint8_t* empty_mask, int64_t n_src, int32_t* sorted_pair,
+                                       int32_t* sorted_row, void* workspace, int64_t workspace_bytes, void* stream) {
+  const int64_t n = M * nsample;
+  if (B <= 0 || M < 0 || nsample <= 0 || n >= (1LL << 31) || n_src <= 0 || n_src >= (1LL << 31) - 1 || !sorted_pair || !sorted_row)
+    return CRB_ERR_ARG;
+  if (n == 0) return CRB_OK;
+  if (!workspace || workspace_bytes < crb_pair_sort_workspace_bytes(M, nsample)) return CRB_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  CrbArena ar(workspace, (size_t)workspace_bytes);
+  int* kin = ar.take<int>(n);
+  int* vin = ar.take<int>(n);
+  const size_t tb = pair_sort_temp_bytes(n);
+  char* temp = ar.take<char>((int64_t)tb);
+  if (!ar.ok) return CRB_ERR_WORKSPACE;
+  hipLaunchKernelGGL(pair_source_keys_kernel, dim3(crb_cdiv(n, 256)), dim3(256), 0, st, B, n, nsample, xyz_batch_cnt,
+                     new_xyz_batch_cnt, idx, empty_mask, (int)n_src, kin, vin);
+  int bits = 1;
+  while ((1LL << bits) <= n_src) ++bits;                     // keys 0 .. n_src
+  size_t tbytes = tb;
+  if (hipcub::DeviceRadixSort::SortPairs(temp, tbytes, (const int*)kin, sorted_row, (const int*)vin, sorted_pair, (int)n, 0, bits, st) !=
+      hipSuccess)
+    return CRB_ERR_LAUNCH;
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

@@ -324,6 +324,14 @@ def grouped_first_layer_rows(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_x
     return GroupedFirstLayerRows.apply(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx, empty, weight)
 
 
+# SAMlp2TrainConcat backward: scatter of the first layer's gradient in source-row order (crb_pair_sort_by_source) for layers of at least
+# this many (query, sample) pairs - the RoI-grid scales: 7 M pairs onto 32 k keypoints, where the real step's scatter takes 0.7 / 1.9 ms
+# in pair order (hot keypoints shared by thousands of grid points). Below it the device sort (a merge sort of ~19 launches for
+# n < 2 M) costs more than the kernel gains (139 -> 69 us at the voxel levels). CRB_SA_SORTED_SCATTER=0 = always pair order (A/B)
+SORTED_SCATTER = __import__('os').environ.get('CRB_SA_SORTED_SCATTER', '1') == '1'
+SORTED_SCATTER_MIN_PAIRS = 2 * 1024 * 1024
+
+
 def sa_mlp2_train_supported(h1, h2, nsample):
     return bool(lib.crb_sa_mlp2_train_supported(int(h1), int(h2), int(nsample)))
 
@@ -441,12 +449,24 @@ class SAMlp2TrainConcat(Function):
                                                  ptr(w1x), ptr(mean1), ptr(invstd1), ptr(g1c), ptr(b1c), ptr(W2c), ptr(mean2),
                                                  ptr(invstd2), ptr(g2c), ptr(b2c), gp, total, ptr(arg), ptr(d2[0]), ptr(d2[1]),
                                                  ptr(gz1), ptr(d1), ptr(dW2), ptr(wsp), wsf, st), 'crb_sa_mlp2_train_backward')
-            # pass D: BatchNorm 1 backward inside the scatter kernel of the first layer
+            # pass D: BatchNorm 1 backward inside the scatter kernel of the first layer. Large layers (the RoI-grid scales) scatter in
+            # source-row order: a stable device sort of the pairs, then runs of equal rows are added in LDS and cost one row of
+            # atomics per 16-pair segment
             gP = torch.zeros((feats.shape[0], h1), dtype=torch.float32, device=dev)
             part = torch.empty((int(lib.crb_group_affine_rows_grad_blocks(M, ns)), 3, h1), dtype=torch.float32, device=dev)
+            sp = sr = None
+            n_src = feats.shape[0]
+            if SORTED_SCATTER and n >= SORTED_SCATTER_MIN_PAIRS:
+                sp = torch.empty((n,), dtype=torch.int32, device=dev)
+                sr = torch.empty((n,), dtype=torch.int32, device=dev)
+                wsb = int(lib.crb_pair_sort_workspace_bytes(M, ns))
+                wss = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+                check(lib.crb_pair_sort_by_source(B, M, ns, ptr(xc), ptr(nc), ptr(idx), ptr(em), n_src, ptr(sp), ptr(sr), ptr(wss), wsb, st),
+                      'crb_pair_sort_by_source')
             check(lib.crb_group_affine_rows_grad_bn_recompute_stack(B, M, h1, ns, ptr(xyz_c), ptr(xc), ptr(P), ptr(new_c), ptr(nc),
                                                                     ptr(idx), ptr(em), ptr(w1x), ptr(gz1), ptr(mean1), ptr(invstd1),
-                                                                    ptr(g1c), ptr(b1c), ptr(d1[0]), ptr(d1[1]), ptr(gP), ptr(part), st),
+                                                                    ptr(g1c), ptr(b1c), ptr(d1[0]), ptr(d1[1]), ptr(sp), ptr(sr), n_src,
+                                                                    ptr(gP), ptr(part), st),
                   'crb_group_affine_rows_grad_bn_recompute_stack')
             del gz1
             if ctx.needs_input_grad[4]:

@@ -397,8 +397,18 @@ int crb_group_affine_rows_grad_bn_recompute_stack(int B, int64_t M, int H, int n
                                                   const int32_t* new_xyz_batch_cnt, const int32_t* idx,
                                                   const uint8_t* empty_mask, const float* W1x, const float* grad_z,
                                                   const float* mean, const float* invstd, const float* gamma,
-                                                  const float* beta, const float* dbeta, const float* dgamma, float* grad_P,
-                                                  float* part, void* stream);
+                                                  const float* beta, const float* dbeta, const float* dgamma,
+                                                  const int32_t* sorted_pair, const int32_t* sorted_row, int64_t n_src,
+                                                  float* grad_P, float* part, void* stream);
+/* optional operand of the call above (sorted_pair / sorted_row, NULL = pair order): the (query, sample) pairs in SOURCE-ROW order,
+ * stable (pairs of one row keep their order), pairs of empty balls last with sorted_row = n_src (the number of source rows). With it
+ * the kernel adds the pairs of a row inside LDS and issues one row of atomics per run instead of one per pair: for layers where
+ * every sample of a ball is a different row and many balls share a row (the voxel levels of VoxelSetAbstraction). Same sums, another
+ * order of the float additions into grad_P. workspace: crb_pair_sort_workspace_bytes(M, nsample). */
+int64_t crb_pair_sort_workspace_bytes(int64_t M, int nsample);
+int crb_pair_sort_by_source(int B, int64_t M, int nsample, const int32_t* xyz_batch_cnt, const int32_t* new_xyz_batch_cnt,
+                            const int32_t* idx, const uint8_t* empty_mask, int64_t n_src, int32_t* sorted_pair,
+                            int32_t* sorted_row, void* workspace, int64_t workspace_bytes, void* stream);
 /* xyz (B,n,3) -> out_idx (B,m); first pick is index 0; ties resolved like the reference kernel (see source).
  * temp: (B,n) f32 scratch for the running distances (the reference's `temp` argument); only needed for n > 40960
  * (below that the distances stay in registers) and may be NULL otherwise. */

@@ -329,8 +329,15 @@ def test_sa_module_fused_training_node_equals_module_and_rows_paths(dev, mlps, n
     _, a = layer(xyz, xc, new, nc, feats[0])
     assert type(a.grad_fn).__name__ == 'SAMlp2TrainConcatBackward'
     a.backward(go)
-    _, a2 = again(xyz, xc, new, nc, feats[3])
-    a2.backward(go)
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as U
+    floor = U.SORTED_SCATTER_MIN_PAIRS
+    try:                                                    # the second run scatters in source-row order (the large layers' path)
+        U.SORTED_SCATTER_MIN_PAIRS = 0
+        assert U.SORTED_SCATTER
+        _, a2 = again(xyz, xc, new, nc, feats[3])
+        a2.backward(go)
+    finally:
+        U.SORTED_SCATTER_MIN_PAIRS = floor
     try:
         M.FUSED_TRAIN = False
         _, r = rows(xyz, xc, new, nc, feats[2])

@@ -162,13 +162,34 @@ def test_entry_points_against_the_float64_restatement(dev, h1, h2, ns, counts, e
     db1f, dg1f = db1.float().contiguous(), dg1.float().contiguous()
     check(lib.crb_group_affine_rows_grad_bn_recompute_stack(B, M, h1, ns, ptr(xyz), ptr(xc), ptr(P), ptr(new), ptr(nc), ptr(idx), ptr(emu),
                                                             ptr(w1x), ptr(gz1), ptr(mean1), ptr(invstd1), ptr(g1), ptr(b1), ptr(db1f),
-                                                            ptr(dg1f), ptr(gP), ptr(part), st), 'pass D')
+                                                            ptr(dg1f), None, None, 0, ptr(gP), ptr(part), st), 'pass D')
     assert bool(torch.isfinite(part).all()) and bool(torch.isfinite(gP).all())
     gW1 = torch.cat([part.sum(0).t(), gP.t() @ feat], 1)
     if bool((~em).any()):
         assert _rel(gW1, dW1_ref) <= 10 * TOL and _rel(gP @ w1f, gfeat_ref) <= 10 * TOL
     else:
         assert float(gW1.abs().max()) == 0.0 and float(gP.abs().max()) == 0.0
+    # the same scatter in SOURCE-ROW order (crb_pair_sort_by_source): a stable sort of the pairs, pairs of empty balls last
+    sp = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    sr = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    wsb = int(lib.crb_pair_sort_workspace_bytes(M, ns))
+    wss = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    check(lib.crb_pair_sort_by_source(B, M, ns, ptr(xc), ptr(nc), ptr(idx), ptr(emu), 12000, ptr(sp), ptr(sr), ptr(wss), wsb, st), 'sort')
+    key = torch.where(em[:, None].expand(M, ns), torch.full_like(rows, 12000), rows).reshape(-1)
+    order = torch.sort(key, stable=True)[1]
+    assert torch.equal(sp.long(), order) and torch.equal(sr.long(), key[order])
+    gP2 = torch.zeros((12000, h1), device=dev)
+    part2 = torch.full((nslab, 3, h1), float('nan'), device=dev)
+    check(lib.crb_group_affine_rows_grad_bn_recompute_stack(B, M, h1, ns, ptr(xyz), ptr(xc), ptr(P), ptr(new), ptr(nc), ptr(idx), ptr(emu),
+                                                            ptr(w1x), ptr(gz1), ptr(mean1), ptr(invstd1), ptr(g1), ptr(b1), ptr(db1f),
+                                                            ptr(dg1f), ptr(sp), ptr(sr), 12000, ptr(gP2), ptr(part2), st), 'pass D, sorted')
+    assert bool(torch.isfinite(part2).all())
+    gW1s = torch.cat([part2.sum(0).t(), gP2.t() @ feat], 1)
+    if bool((~em).any()):
+        assert _rel(gW1s, dW1_ref) <= 10 * TOL and _rel(gP2 @ w1f, gfeat_ref) <= 10 * TOL
+        assert float((gP2 - gP).abs().max()) <= 1e-5 * max(1.0, float(gP.abs().max()))
+    else:
+        assert float(gW1s.abs().max()) == 0.0 and float(gP2.abs().max()) == 0.0
 
 
 def test_unsupported_shapes_say_so_and_the_module_keeps_the_rows_path(dev):

@@ -15,16 +15,28 @@ from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_modules as M  # noqa: 
 
 dev = torch.device('cuda', 0)
 torch.manual_seed(0)
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-NK, R, G3, C = 2048, 128, 216, 128
-xyz = (torch.rand(B * NK, 3, device=dev) * torch.tensor([70.0, 80.0, 4.0], device=dev)).contiguous()
-xc = torch.full((B,), NK, dtype=torch.int32, device=dev)
-centres = xyz.view(B, NK, 3)[:, torch.randint(0, NK, (R,), device=dev)]
-new = (centres[:, :, None, :] + (torch.rand(B, R, G3, 3, device=dev) - 0.5) * 4.0).reshape(-1, 3).contiguous()
-nc = torch.full((B,), R * G3, dtype=torch.int32, device=dev)
-feat = torch.randn(B * NK, C, device=dev, requires_grad=True)
-layer, c_out = M.build_local_aggregation_module(C, EasyDict({'MLPS': [[64, 64], [64, 64]], 'POOL_RADIUS': [0.8, 1.6],
-                                                            'NSAMPLE': [16, 16]}))
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16
+if os.environ.get('SA_BENCH', 'roi') == 'vsa':
+    # a voxel level of VoxelSetAbstraction (x_conv3-like): 6,500 source voxels per frame on a thin slab (lidar surfaces), 2,048
+    # keypoints per frame drawn from them, radii 1.2 / 2.4 m, nsample 16 / 32, 64 channels: every ball full of different rows
+    NK, R, G3, C = 6500, 2048, 1, 64
+    xyz = (torch.rand(B * NK, 3, device=dev) * torch.tensor([70.0, 80.0, 1.0], device=dev)).contiguous()
+    xc = torch.full((B,), NK, dtype=torch.int32, device=dev)
+    new = xyz.view(B, NK, 3)[:, torch.randperm(NK, device=dev)[:R]].reshape(-1, 3).contiguous()
+    nc = torch.full((B,), R, dtype=torch.int32, device=dev)
+    feat = torch.randn(B * NK, C, device=dev, requires_grad=True)
+    layer, c_out = M.build_local_aggregation_module(C, EasyDict({'MLPS': [[64, 64], [64, 64]], 'POOL_RADIUS': [1.2, 2.4],
+                                                                'NSAMPLE': [16, 32]}))
+else:
+    NK, R, G3, C = 2048, 128, 216, 128
+    xyz = (torch.rand(B * NK, 3, device=dev) * torch.tensor([70.0, 80.0, 4.0], device=dev)).contiguous()
+    xc = torch.full((B,), NK, dtype=torch.int32, device=dev)
+    centres = xyz.view(B, NK, 3)[:, torch.randint(0, NK, (R,), device=dev)]
+    new = (centres[:, :, None, :] + (torch.rand(B, R, G3, 3, device=dev) - 0.5) * 4.0).reshape(-1, 3).contiguous()
+    nc = torch.full((B,), R * G3, dtype=torch.int32, device=dev)
+    feat = torch.randn(B * NK, C, device=dev, requires_grad=True)
+    layer, c_out = M.build_local_aggregation_module(C, EasyDict({'MLPS': [[64, 64], [64, 64]], 'POOL_RADIUS': [0.8, 1.6],
+                                                                'NSAMPLE': [16, 16]}))
 layer = layer.to(dev).train()
 go = torch.randn(new.shape[0], c_out, device=dev)
 params = [feat] + list(layer.parameters())
@@ -45,7 +57,7 @@ def timeit(fn, n=10):
 
 
 def fwd():
-    return layer(xyz, xc, new, nc, feat, query_group=G3)[1]
+    return layer(xyz, xc, new, nc, feat, query_group=G3 if G3 > 1 else None)[1]
 
 
 def fwd_bwd():
@@ -98,11 +110,11 @@ with profile(activities=[ProfilerActivity.CUDA]) as prof:
     fwd_bwd()
     torch.cuda.synchronize()
 print('recompute node, launches of one forward+backward in order (us):')
-evs = sorted([e for e in prof.events() if e.device_time_total > 0 and ('sa_train' in e.name or 'group_affine' in e.name)], key=lambda e: e.time_range.start)
+evs = sorted([e for e in prof.events() if e.device_time_total > 0 and ('sa_train' in e.name or 'group_affine' in e.name or 'Radix' in e.name or 'radix' in e.name or 'pair_source' in e.name)], key=lambda e: e.time_range.start)
 print('   ' + ', '.join('%s %.0f' % (e.name.split('(')[0].split('::')[-1][:34], e.device_time_total) for e in evs))
-print('empty balls: %s of the queries at r = 0.8 / 1.6' % ', '.join('%.3f' % float(bl[1].float().mean()) for bl in layer._balls(xyz, xc, new, nc, G3)))
+print('empty balls: %s of the queries at r = 0.8 / 1.6' % ', '.join('%.3f' % float(bl[1].float().mean()) for bl in layer._balls(xyz, xc, new, nc, G3 if G3 > 1 else None)))
 a, b = res['recompute node'], res['rows path']
 print('recompute vs rows: output max |diff| %.2e (scale %.2e)' % (float((a[0] - b[0]).abs().max()), float(b[0].abs().max())))
 for k, (x, y) in enumerate(zip(a[1], b[1])):
     print('   grad %d %s: rel L2 %.2e' % (k, tuple(x.shape), float((x - y).norm() / y.norm().clamp_min(1e-20))))
-print('empty balls: %.3f of the queries at r = 0.8' % float(layer._balls(xyz, xc, new, nc, G3)[0][1].float().mean()))
+print('empty balls: %.3f of the queries at r = 0.8' % float(layer._balls(xyz, xc, new, nc, G3 if G3 > 1 else None)[0][1].float().mean()))

@@ -139,6 +139,6 @@ part = torch.empty((nslab, 3, h1), device=dev)
 db1f, dg1f = db1.float().contiguous(), dg1.float().contiguous()
 check(lib.crb_group_affine_rows_grad_bn_recompute_stack(B, M, h1, ns, ptr(xyz), ptr(xcn), ptr(P), ptr(new), ptr(ncn), ptr(idx), ptr(emu),
                                                         ptr(w1x), ptr(gz1), ptr(mean1), ptr(invstd1), ptr(g1), ptr(b1), ptr(db1f),
-                                                        ptr(dg1f), ptr(gP), ptr(part), st), 'passD')
+                                                        ptr(dg1f), None, None, 0, ptr(gP), ptr(part), st), 'passD')
 gW1 = torch.cat([part.sum(0).t(), gP.t() @ feat], 1)
 print('pass D: dW1 %.2e, dfeatures %.2e' % (rel_err(gW1, dW1_ref), rel_err(gP @ w1f, gfeat_ref)))
