@@ -1467,6 +1467,48 @@ extern "C" int crb_pair_sort_by_source(int B, int64_t M, int nsample, const int3
   return CRB_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ rows per frame
+// The stacked layout keeps the rows of a frame together, frames in order (that is what xyz_batch_cnt means to every kernel of this
+// file), so the frame-index column is non-decreasing and the rows of frame b are [lower_bound(b), lower_bound(b + 1)). One wave per
+// frame, 64-ary search: 64 probes per round, 4 rounds for 320 k rows. (The module-level form of the reference,
+// voxel_set_abstraction.py:321-323 `(xyz_bs_idxs == bs_idx).sum()` per frame, is B reductions over the column; a scatter_add of
+// ones is B hot atomics: 46 us for 320 k rows.)
+template <typename T>
+__device__ int sorted_lower_bound_wave(const T* __restrict__ key, int64_t stride, int n, int target) {
+  const int lane = threadIdx.x & 63;
+  int lo = 0, hi = n;                                        // the answer is in [lo, hi]
+  while (hi > lo) {
+    const int step = (hi - lo + 63) / 64;
+    const int64_t i = (int64_t)lo + (int64_t)lane * step;
+    const bool ge = i >= hi || (int)key[i * stride] >= target;
+    const unsigned long long m = __ballot(ge);
+    if (m & 1ULL) return lo;                                 // key[lo] >= target
+    const int f = m ? __ffsll((long long)m) - 1 : 64;       // lane f - 1 is below the target, lane f is not (or past hi)
+    const int64_t nhi = (int64_t)lo + (int64_t)f * step;
+    lo = lo + (f - 1) * step + 1;
+    hi = (f == 64 || nhi > hi) ? hi : (int)nhi;
+  }
+  return lo;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void sorted_key_counts_kernel(const T* __restrict__ key, int64_t stride, int n, int* __restrict__ counts) {
+  const int b = blockIdx.x;
+  const int lo = sorted_lower_bound_wave(key, stride, n, b), hi = sorted_lower_bound_wave(key, stride, n, b + 1);
+  if (threadIdx.x == 0) counts[b] = hi - lo;
+}
+
+extern "C" int crb_sorted_key_counts(const void* key, int key_is_float, int64_t stride, int64_t n, int B, int32_t* counts, void* stream) {
+  if (B <= 0 || n < 0 || n >= (1LL << 31) || stride <= 0 || !counts || (n > 0 && !key)) return CRB_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (key_is_float)
+    hipLaunchKernelGGL(sorted_key_counts_kernel<float>, dim3(B), dim3(64), 0, st, (const float*)key, stride, (int)n, counts);
+  else
+    hipLaunchKernelGGL(sorted_key_counts_kernel<int>, dim3(B), dim3(64), 0, st, (const int*)key, stride, (int)n, counts);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
 extern "C" int crb_group_affine_rows_grad_stack(int B, int64_t M, int H, int nsample, const int32_t* xyz_batch_cnt,
                                                 const int32_t* new_xyz_batch_cnt, const int32_t* idx,
                                                 const uint8_t* empty_mask, const float* rel, const float* grad_out,

@@ -91,8 +91,21 @@ def device_constant(values, device):
 
 
 def batch_counts(bs_idx, batch_size):
-    """rows per frame of a stacked tensor whose batch index column is bs_idx -> (B) int32. scatter_add instead of
-    torch.bincount: bincount reads back the maximum to size its output, a device->host sync per call."""
+    """rows per frame of a stacked tensor whose frame-index column is bs_idx -> (B) int32 (the reference's per-frame
+    `(bs_idxs == k).sum()` loops: voxel_set_abstraction.py:321-323, pvrcnn_head.py:96-98). On the device: crb_sorted_key_counts, one
+    launch of B waves that search the NON-DECREASING column (rows of a frame together, frames in order - what the counts mean to
+    every stacked op). Host tensors: a scatter_add (torch.bincount would read back the maximum to size its output)."""
+    if bs_idx.is_cuda:
+        from crbhip import lib, check, ptr, cur_stream
+        if bs_idx.dtype not in (torch.float32, torch.int32):
+            bs_idx = bs_idx.to(torch.int32)
+        out = torch.empty((batch_size,), dtype=torch.int32, device=bs_idx.device)
+        n = bs_idx.shape[0]
+        import ctypes
+        key = ctypes.c_void_p(bs_idx.data_ptr()) if n else None          # (a strided column: no copy)
+        check(lib.crb_sorted_key_counts(key, int(bs_idx.dtype == torch.float32), max(1, bs_idx.stride(0)), n,
+                                        int(batch_size), ptr(out), cur_stream(bs_idx.device)), 'crb_sorted_key_counts')
+        return out
     out = torch.zeros((batch_size,), dtype=torch.int32, device=bs_idx.device)
     return out.scatter_add_(0, bs_idx.long(), torch.ones_like(bs_idx, dtype=torch.int32))
 

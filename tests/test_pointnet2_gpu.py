@@ -667,3 +667,31 @@ def test_bev_interpolation_ignores_rows_of_no_frame_and_honours_deterministic_mo
     finally:
         torch.use_deterministic_algorithms(False)
     assert torch.equal(grads[0], grads[1])
+
+
+def test_rows_per_frame_from_the_sorted_frame_column(dev):
+    """crb_sorted_key_counts (common_utils.batch_counts on device tensors) against numpy's bincount: frames without rows at the
+    start, in the middle and at the end, a float column of a wider row-major tensor (strided, as points[:, 0]), an int32 column of
+    voxel coordinates, int64 keys, one row, no rows, counts above 64^3 rows"""
+    from pcdet.utils import common_utils
+    rng = np.random.default_rng(11)
+    cases = [[0, 5, 0, 0, 7, 1, 0], [3], [0], [0, 0, 0], [1, 0, 0, 0], [0, 0, 0, 1], [20000] * 16,
+             [int(v) for v in rng.integers(0, 40000, size=16)], [300000, 0, 1], [64, 64, 63, 65, 4096, 4097, 1, 0, 262144, 262145]]
+    for counts in cases:
+        B, n = len(counts), int(sum(counts))
+        key = np.repeat(np.arange(B), counts)
+        want = np.asarray(counts, dtype=np.int32)
+        pts = torch.zeros((n, 5), device=dev)
+        pts[:, 0] = torch.from_numpy(key).to(dev).float()
+        got = common_utils.batch_counts(pts[:, 0], B)
+        assert got.dtype == torch.int32 and np.array_equal(got.cpu().numpy(), want), counts
+        coords = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+        coords[:, 0] = torch.from_numpy(key).to(dev).int()
+        assert np.array_equal(common_utils.batch_counts(coords[:, 0], B).cpu().numpy(), want), counts
+        assert np.array_equal(common_utils.batch_counts(torch.from_numpy(key).to(dev), B).cpu().numpy(), want), counts
+        # the host form (not the device path) gives the same counts
+        assert np.array_equal(common_utils.batch_counts(torch.from_numpy(key), B).numpy(), want), counts
+    # frames beyond B are not counted; B larger than the keys present
+    key = torch.tensor([0, 0, 1, 3, 3, 3, 5], dtype=torch.int32, device=dev)
+    assert common_utils.batch_counts(key, 4).cpu().tolist() == [2, 1, 0, 3]
+    assert common_utils.batch_counts(key, 8).cpu().tolist() == [2, 1, 0, 3, 0, 1, 0, 0]
