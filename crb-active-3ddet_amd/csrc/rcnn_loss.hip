@@ -1,0 +1,255 @@
+// Second-stage (RCNN) losses of the RoI head as ONE launch, gradients included, and the canonical transformation of the sampled
+// ground truths as one launch  (rows a22 / a24 of SURVEY §8)
+//
+// replaces, for the n = B * ROI_PER_IMAGE sampled RoIs of a batch:
+//   RoIHeadTemplate.assign_targets, the part after the sampling   (pcdet/models/roi_heads/roi_head_template.py:118-138)
+//   RoIHeadTemplate.get_box_cls_layer_loss, BinaryCrossEntropy    (:261-285)
+//   RoIHeadTemplate.get_box_reg_layer_loss, smooth-l1 + corner regularisation (:142-259, the branch without
+//       `reg_sample_targets`), with ResidualCoder.encode_torch / decode_torch (pcdet/utils/box_coder_utils.py:13-73),
+//       WeightedSmoothL1Loss (pcdet/utils/loss_utils.py:75-131), get_corner_loss_lidar (:209-232),
+//       boxes_to_corners_3d (pcdet/utils/box_utils.py:28-55), rotate_points_along_z (pcdet/utils/common_utils.py:37-60)
+// which in torch are ~150 elementwise / reduction launches forward and ~120 backward over (2048, <= 24) tensors: at ~3 us of device
+// time per launch (tools/bench_pvrcnn.py CRB_BENCH_EXTRA_LAUNCHES) 0.8 ms of a device-bound 68.7 ms PV-RCNN step.
+//
+// One workgroup of 1024 threads walks the RoIs (2 per thread at n = 2048): counts first (the two denominators), then every term
+// and its gradient w.r.t. the head outputs in registers, sums in a fixed order (thread-strided, wave shuffle tree, 16 waves in
+// order): bit-reproducible. The gradients are written scaled for d(total loss) = 1; the autograd node multiplies by what arrives.
+#include "crb_common.h"
+#include "../../include/crb_hip.h"
+
+namespace {
+
+constexpr int TPB = 1024;
+constexpr float PI_F = 3.14159265358979323846f;
+
+struct RcnnArgs {
+  const float* cls;          // (n) logits
+  const float* reg;          // (n, 7)
+  const void* labels;        // (n) f32 or i64: < 0 ignored
+  const int64_t* reg_valid;  // (n)
+  const float* rois;         // (n, 7)
+  const float* gt_local;     // (n, gt_stride) canonical (RoI frame) ground truth
+  const float* gt_src;       // (n, gt_stride) the same boxes in LiDAR coordinates
+  int n, gt_stride, labels_i64, corner;
+  float beta, cw[7], w_cls, w_reg, w_corner;
+  float* out;                // [0] cls, [1] reg (without corner), [2] corner, [3] total, [4] foreground RoIs, [5] valid RoIs, [6] total
+  float* d_cls;              // (n)
+  float* d_reg;              // (n, 7)
+  float* reg_targets;        // (n, 7) or null
+};
+
+// torch.remainder for floats (sign of the divisor)
+__device__ __forceinline__ float py_mod(float a, float b) {
+  float r = fmodf(a, b);
+  if (r != 0.f && ((r < 0.f) != (b < 0.f))) r += b;
+  return r;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  // wave tree, then the 16 wave sums in wave order by every thread (same value everywhere)
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < TPB / 64; ++w) t += sh[w];
+  return t;
+}
+
+// corners of a box (x, y, z, dx, dy, dz, ry): boxes_to_corners_3d's template order
+__device__ __forceinline__ void corner_of(int k, float& tx, float& ty, float& tz) {
+  tx = (k & 3) == 0 || (k & 3) == 1 ? 0.5f : -0.5f;
+  ty = (k & 3) == 0 || (k & 3) == 3 ? 0.5f : -0.5f;
+  tz = k < 4 ? -0.5f : 0.5f;
+}
+
+__global__ __launch_bounds__(TPB) void rcnn_loss_kernel(RcnnArgs a) {
+  __shared__ float sh[TPB / 64];
+  // ---- denominators
+  float nv = 0.f, nf = 0.f;
+  for (int i = threadIdx.x; i < a.n; i += TPB) {
+    const float lab = a.labels_i64 ? (float)reinterpret_cast<const int64_t*>(a.labels)[i] : reinterpret_cast<const float*>(a.labels)[i];
+    nv += lab >= 0.f ? 1.f : 0.f;
+    nf += a.reg_valid[i] > 0 ? 1.f : 0.f;
+  }
+  const float n_valid = block_sum(nv, sh), n_fg = block_sum(nf, sh);       // (integers below 2^24: exact in any order)
+  const float den_v = fmaxf(n_valid, 1.f), den_f = fmaxf(n_fg, 1.f);
+  float s_cls = 0.f, s_reg = 0.f, s_cor = 0.f;
+  for (int i = threadIdx.x; i < a.n; i += TPB) {
+    // ---- classification: binary cross entropy on sigmoid(x) (ATen's kernels: log clamped at -100, backward through
+    //      (p - y) / max((1 - p) p, 1e-12) and the sigmoid's (1 - p) p)
+    const float lab = a.labels_i64 ? (float)reinterpret_cast<const int64_t*>(a.labels)[i] : reinterpret_cast<const float*>(a.labels)[i];
+    float gc = 0.f;
+    if (lab >= 0.f) {
+      const float x = a.cls[i];
+      const float p = 1.0f / (1.0f + expf(-x));
+      const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(log1pf(-p), -100.f);
+      s_cls += (lab - 1.f) * l1p - lab * lp;
+      gc = (p - lab) / fmaxf((1.f - p) * p, 1e-12f) * ((1.f - p) * p) * (a.w_cls / den_v);
+    }
+    a.d_cls[i] = gc;
+    // ---- regression
+    const float* e = a.reg + (int64_t)i * 7;
+    const float* roi = a.rois + (int64_t)i * 7;
+    const float* gl = a.gt_local + (int64_t)i * a.gt_stride;
+    const bool fg = a.reg_valid[i] > 0;
+    float ge[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float tgt[7];
+    {
+      // ResidualCoder.encode_torch against the anchor (0, 0, 0, roi dims, 0)
+      const float dxa = fmaxf(roi[3], 1e-5f), dya = fmaxf(roi[4], 1e-5f), dza = fmaxf(roi[5], 1e-5f);
+      const float dxg = fmaxf(gl[3], 1e-5f), dyg = fmaxf(gl[4], 1e-5f), dzg = fmaxf(gl[5], 1e-5f);
+      const float diag = sqrtf(dxa * dxa + dya * dya);
+      tgt[0] = gl[0] / diag; tgt[1] = gl[1] / diag; tgt[2] = gl[2] / dza;
+      tgt[3] = logf(dxg / dxa); tgt[4] = logf(dyg / dya); tgt[5] = logf(dzg / dza);
+      tgt[6] = gl[6];
+    }
+    if (a.reg_targets) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) a.reg_targets[(int64_t)i * 7 + j] = tgt[j];
+    }
+    if (fg) {
+      float row = 0.f;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        float diff = isnan(tgt[j]) ? 0.f : e[j] - tgt[j];
+        diff *= a.cw[j];
+        const float m = fabsf(diff);
+        float l, g;
+        if (a.beta < 1e-5f) {
+          l = m;
+          g = diff > 0.f ? 1.f : diff < 0.f ? -1.f : 0.f;
+        } else if (m < a.beta) {
+          l = 0.5f * m * m / a.beta;
+          g = diff / a.beta;
+        } else {
+          l = m - 0.5f * a.beta;
+          g = diff > 0.f ? 1.f : -1.f;
+        }
+        row += l;
+        ge[j] = g * a.cw[j] * (a.w_reg / den_f);
+      }
+      s_reg += row;
+      if (a.corner) {
+        // decode against (0, 0, 0, roi dims, roi ry), turn the centre by roi ry, move to the RoI centre
+        const float* gs = a.gt_src + (int64_t)i * a.gt_stride;
+        const float dxa = roi[3], dya = roi[4], dza = roi[5], ra = roi[6];
+        const float diag = sqrtf(dxa * dxa + dya * dya);
+        const float xl = e[0] * diag, yl = e[1] * diag, zl = e[2] * dza;
+        const float dx = expf(e[3]) * dxa, dy = expf(e[4]) * dya, dz = expf(e[5]) * dza;
+        const float rg = e[6] + ra;
+        const float ca = cosf(ra), sa = sinf(ra);
+        const float cx = xl * ca - yl * sa + roi[0], cy = xl * sa + yl * ca + roi[1], cz = zl + roi[2];
+        const float cg = cosf(rg), sg = sinf(rg);
+        const float c1 = cosf(gs[6]), s1 = sinf(gs[6]);
+        const float rf = gs[6] + PI_F;
+        const float c2 = cosf(rf), s2 = sinf(rf);
+        float tot = 0.f, dcx = 0.f, dcy = 0.f, dcz = 0.f, ddx = 0.f, ddy = 0.f, ddz = 0.f, drg = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float tx, ty, tz;
+          corner_of(k, tx, ty, tz);
+          const float lx = dx * tx, ly = dy * ty, lz = dz * tz;
+          const float px = lx * cg - ly * sg + cx, py = lx * sg + ly * cg + cy, pz = lz + cz;
+          const float gx = gs[3] * tx, gy = gs[4] * ty, gz = gs[5] * tz + gs[2];
+          const float q1x = gx * c1 - gy * s1 + gs[0], q1y = gx * s1 + gy * c1 + gs[1];
+          const float q2x = gx * c2 - gy * s2 + gs[0], q2y = gx * s2 + gy * c2 + gs[1];
+          const float u1x = px - q1x, u1y = py - q1y, u2x = px - q2x, u2y = py - q2y, uz = pz - gz;
+          const float d1 = sqrtf(u1x * u1x + u1y * u1y + uz * uz), d2 = sqrtf(u2x * u2x + u2y * u2y + uz * uz);
+          const float d = fminf(d1, d2);
+          tot += d < 1.f ? 0.5f * d * d : d - 0.5f;
+          const float sl = (d < 1.f ? d : 1.f) * 0.125f;          // d smooth-l1 / d dist, mean over the 8 corners
+          // torch.min gives half of the gradient to each side of a tie; the norm's gradient at 0 is 0
+          const float w1 = d1 < d2 ? 1.f : d1 == d2 ? 0.5f : 0.f, w2 = 1.f - w1;
+          const float i1 = d1 > 0.f ? sl * w1 / d1 : 0.f, i2 = d2 > 0.f ? sl * w2 / d2 : 0.f;
+          const float gpx = i1 * u1x + i2 * u2x, gpy = i1 * u1y + i2 * u2y, gpz = (i1 + i2) * uz;
+          dcx += gpx; dcy += gpy; dcz += gpz;
+          ddx += gpx * (tx * cg) + gpy * (tx * sg);
+          ddy += gpy * (ty * cg) - gpx * (ty * sg);
+          ddz += gpz * tz;
+          drg += gpx * (-lx * sg - ly * cg) + gpy * (lx * cg - ly * sg);
+        }
+        s_cor += tot * 0.125f;
+        const float sc = a.w_corner / den_f;
+        const float dxl = dcx * ca + dcy * sa, dyl = dcy * ca - dcx * sa;
+        ge[0] += dxl * diag * sc; ge[1] += dyl * diag * sc; ge[2] += dcz * dza * sc;
+        ge[3] += ddx * dx * sc; ge[4] += ddy * dy * sc; ge[5] += ddz * dz * sc;
+        ge[6] += drg * sc;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) a.d_reg[(int64_t)i * 7 + j] = ge[j];
+  }
+  const float t_cls = block_sum(s_cls, sh), t_reg = block_sum(s_reg, sh), t_cor = block_sum(s_cor, sh);
+  if (threadIdx.x == 0) {
+    const float l_cls = t_cls / den_v * a.w_cls, l_reg = t_reg / den_f * a.w_reg, l_cor = a.corner ? t_cor / den_f * a.w_corner : 0.f;
+    a.out[0] = l_cls;
+    a.out[1] = l_reg;
+    a.out[2] = l_cor;
+    a.out[3] = l_cls + (l_reg + l_cor);
+    a.out[4] = n_fg;
+    a.out[5] = n_valid;
+    a.out[6] = a.out[3];
+  }
+}
+
+// gt (n, C >= 7) in LiDAR coordinates -> the RoI's frame: centre relative to the RoI and turned by -ry(roi), heading relative to
+// the RoI folded into [-pi/2, pi/2] (a box and its 180-degree turn are the same target); columns 3..5 and 7.. pass through
+__global__ __launch_bounds__(256) void roi_canonical_kernel(const float* __restrict__ rois, int roi_stride, const float* __restrict__ gt,
+                                                            int C, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* r = rois + (int64_t)i * roi_stride;
+  const float* g = gt + (int64_t)i * C;
+  float* o = out + (int64_t)i * C;
+  const float two_pi = 2.f * PI_F;
+  const float roi_ry = py_mod(r[6], two_pi);
+  const float x = g[0] - r[0], y = g[1] - r[1], z = g[2] - r[2];
+  const float ang = -roi_ry;
+  const float c = cosf(ang), s = sinf(ang);
+  o[0] = x * c - y * s;
+  o[1] = x * s + y * c;
+  o[2] = z;
+  o[3] = g[3]; o[4] = g[4]; o[5] = g[5];
+  float h = py_mod(g[6] - roi_ry, two_pi);
+  if (h > PI_F * 0.5f && h < PI_F * 1.5f) h = py_mod(h + PI_F, two_pi);
+  if (h > PI_F) h = h - PI_F * 2.f;
+  h = fminf(fmaxf(h, -PI_F / 2.f), PI_F / 2.f);
+  o[6] = h;
+  for (int j = 7; j < C; ++j) o[j] = g[j];
+}
+
+}  // namespace
+
+extern "C" int crb_rcnn_loss(const float* rcnn_cls, const float* rcnn_reg, const void* cls_labels, int labels_are_int64,
+                             const int64_t* reg_valid_mask, const float* rois, const float* gt_of_rois, const float* gt_of_rois_src,
+                             int gt_row_stride, int64_t n, const CrbRcnnLossCfg* cfg, float* loss, float* d_cls, float* d_reg,
+                             float* reg_targets, void* stream) {
+  if (n < 0 || n >= (1LL << 24) || !cfg || !loss || gt_row_stride < 7) return CRB_ERR_ARG;
+  if (n > 0 && (!rcnn_cls || !rcnn_reg || !cls_labels || !reg_valid_mask || !rois || !gt_of_rois || !d_cls || !d_reg)) return CRB_ERR_ARG;
+  if (cfg->corner && n > 0 && !gt_of_rois_src) return CRB_ERR_ARG;
+  RcnnArgs a;
+  a.cls = rcnn_cls; a.reg = rcnn_reg; a.labels = cls_labels; a.reg_valid = reg_valid_mask; a.rois = rois;
+  a.gt_local = gt_of_rois; a.gt_src = gt_of_rois_src;
+  a.n = (int)n; a.gt_stride = gt_row_stride; a.labels_i64 = labels_are_int64 ? 1 : 0; a.corner = cfg->corner ? 1 : 0;
+  a.beta = cfg->beta;
+  for (int j = 0; j < 7; ++j) a.cw[j] = cfg->code_weights[j];
+  a.w_cls = cfg->cls_weight; a.w_reg = cfg->reg_weight; a.w_corner = cfg->corner_weight;
+  a.out = loss; a.d_cls = d_cls; a.d_reg = d_reg; a.reg_targets = reg_targets;
+  hipLaunchKernelGGL(rcnn_loss_kernel, dim3(1), dim3(TPB), 0, (hipStream_t)stream, a);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_roi_canonical_targets(const float* rois, int roi_row_stride, const float* gt_of_rois, int gt_row_stride, int64_t n,
+                                         float* out, void* stream) {
+  if (n < 0 || n >= (1LL << 31) || roi_row_stride < 7 || gt_row_stride < 7) return CRB_ERR_ARG;
+  if (n == 0) return CRB_OK;
+  if (!rois || !gt_of_rois || !out) return CRB_ERR_ARG;
+  hipLaunchKernelGGL(roi_canonical_kernel, dim3(crb_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, rois, roi_row_stride, gt_of_rois,
+                     gt_row_stride, (int)n, out);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}

@@ -11,6 +11,12 @@ from ...utils import box_coder_utils, common_utils, loss_utils
 from .target_assigner.proposal_target_layer import ProposalTargetLayer
 
 
+# second-stage losses + the canonical target transformation as HIP launches (crbhip.rcnn_loss: one launch each instead of ~270
+# elementwise / reduction launches of a PV-RCNN step); CRB_RCNN_LOSS_FUSED=0 = the torch expressions below (A/B, and what the
+# kernels are tested against)
+FUSED_LOSS = __import__('os').environ.get('CRB_RCNN_LOSS_FUSED', '1') == '1'
+
+
 class RoIHeadTemplate(nn.Module):
     def __init__(self, num_class, model_cfg, **kwargs):
         super().__init__()
@@ -82,6 +88,10 @@ class RoIHeadTemplate(nn.Module):
         rois = targets_dict['rois']
         gt = targets_dict['gt_of_rois']
         targets_dict['gt_of_rois_src'] = gt.clone().detach()
+        if FUSED_LOSS and gt.is_cuda:
+            from crbhip import rcnn_loss
+            targets_dict['gt_of_rois'] = rcnn_loss.roi_canonical_targets(rois, gt)
+            return targets_dict
         # canonical transformation: into the RoI frame (roi_head_template.py:118-138)
         roi_ry = rois[:, :, 6] % (2 * np.pi)
         center = gt[:, :, 0:3] - rois[:, :, 0:3]
@@ -157,7 +167,8 @@ class RoIHeadTemplate(nn.Module):
         batch_size = labels.shape[0]
         labels = labels.view(-1)
         if loss_cfgs.CLS_LOSS == 'BinaryCrossEntropy':
-            batch_loss = F.binary_cross_entropy(torch.sigmoid(rcnn_cls.view(-1)), labels.float(), reduction='none')
+            # (ignored RoIs carry the label -1 and weight 0: clamped for the call, whose device kernel asserts targets in [0, 1])
+            batch_loss = F.binary_cross_entropy(torch.sigmoid(rcnn_cls.view(-1)), labels.float().clamp(min=0), reduction='none')
             valid = (labels >= 0).float()
             if reduce:
                 loss = (batch_loss * valid).sum() / torch.clamp(valid.sum(), min=1.0)
@@ -172,8 +183,37 @@ class RoIHeadTemplate(nn.Module):
         loss = loss * loss_cfgs.LOSS_WEIGHTS['rcnn_cls_weight']
         return loss, {'rcnn_loss_cls': (loss if reduce else loss[0]).detach()}
 
+    def _fused_loss_cfg(self, reduce):
+        """the configuration crb_rcnn_loss implements (BinaryCrossEntropy, smooth-l1 (+ corner), code size 7, the whole-batch
+        reduction, not the CRB branch) -> CrbRcnnLossCfg or None"""
+        loss_cfgs, ret = self.model_cfg.LOSS_CONFIG, self.forward_ret_dict
+        if not (FUSED_LOSS and reduce) or 'reg_sample_targets' in ret or not ret['rcnn_reg'].is_cuda or \
+                loss_cfgs.CLS_LOSS != 'BinaryCrossEntropy' or loss_cfgs.REG_LOSS != 'smooth-l1' or self.box_coder.code_size != 7 or \
+                getattr(self.box_coder, 'encode_angle_by_sincos', False) or ret['rcnn_reg'].shape[-1] != 7 or \
+                ret['rcnn_cls'].numel() != ret['rcnn_reg'].shape[0] or self.reg_loss_func.code_weights is None:
+            return None
+        key = (float(self.reg_loss_func.beta), tuple(float(w) for w in loss_cfgs.LOSS_WEIGHTS['code_weights']),
+               float(loss_cfgs.LOSS_WEIGHTS['rcnn_cls_weight']), float(loss_cfgs.LOSS_WEIGHTS['rcnn_reg_weight']),
+               float(loss_cfgs.LOSS_WEIGHTS.get('rcnn_corner_weight', 0.0)), bool(loss_cfgs.CORNER_LOSS_REGULARIZATION))
+        hit = self.__dict__.get('_crb_rcnn_cfg')
+        if hit is None or hit[0] != key:
+            from crbhip import rcnn_loss
+            hit = self.__dict__['_crb_rcnn_cfg'] = (key, rcnn_loss.make_cfg(key[1], key[2], key[3], key[4], key[5], beta=key[0]))
+        return hit[1]
+
     def get_loss(self, tb_dict=None, reduce=True):
         tb_dict = {} if tb_dict is None else tb_dict
+        cfg = self._fused_loss_cfg(reduce)
+        if cfg is not None:
+            from crbhip import rcnn_loss
+            ret = self.forward_ret_dict
+            total, parts, ret['rcnn_reg_gt'] = rcnn_loss.rcnn_loss(ret['rcnn_cls'], ret['rcnn_reg'], ret['rcnn_cls_labels'],
+                                                                   ret['reg_valid_mask'], ret['rois'], ret['gt_of_rois'],
+                                                                   ret['gt_of_rois_src'], cfg)
+            tb_dict.update({'rcnn_loss_cls': parts[0], 'rcnn_loss_reg': parts[1], 'rcnn_loss': parts[3]})
+            if cfg.corner:
+                tb_dict['rcnn_loss_corner'] = parts[2]
+            return total, tb_dict
         loss_cls, tb1 = self.get_box_cls_layer_loss(self.forward_ret_dict, reduce=reduce)
         loss_reg, tb2 = self.get_box_reg_layer_loss(self.forward_ret_dict, reduce=reduce)
         tb_dict.update(tb1)

@@ -592,6 +592,36 @@ int crb_rpn_loss_backward(const float* cls_preds, const float* box_preds, const 
                           const float* npos, const float* grad_loss, float* d_cls, float* d_box, float* d_dir, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * a22 / a24  second-stage losses and the canonical transformation of the sampled ground truths (csrc/rcnn_loss.hip)
+ * replaces: RoIHeadTemplate.get_box_cls_layer_loss (BinaryCrossEntropy; pcdet/models/roi_heads/roi_head_template.py:261-285),
+ *           get_box_reg_layer_loss (smooth-l1 + CORNER_LOSS_REGULARIZATION, the branch without reg_sample_targets; :142-259) with
+ *           ResidualCoder.encode_torch / decode_torch (pcdet/utils/box_coder_utils.py:13-73), get_corner_loss_lidar
+ *           (pcdet/utils/loss_utils.py:209-232), boxes_to_corners_3d (pcdet/utils/box_utils.py:28-55); and the part of
+ *           RoIHeadTemplate.assign_targets after the sampling (:118-138). ~270 torch launches of a PV-RCNN step as two.
+ * crb_rcnn_loss: n sampled RoIs; rcnn_cls (n) logits, rcnn_reg (n,7), cls_labels (n) f32 or i64 (< 0 = ignored; soft labels in
+ * [0,1] for CLS_SCORE_TYPE roi_iou), reg_valid_mask (n) i64, rois (n,7), gt_of_rois (n, gt_row_stride) in the RoI frame,
+ * gt_of_rois_src the same boxes in LiDAR coordinates (corner loss; NULL when cfg->corner == 0)
+ * -> loss[7] = {rcnn_loss_cls, rcnn_loss_reg, rcnn_loss_corner, rcnn_loss (their sum), foreground RoIs, valid RoIs, rcnn_loss again
+ *    (a second home for the scalar a caller differentiates)}, each loss already multiplied by its LOSS_WEIGHTS entry and divided by
+ *    max(count, 1);
+ *    d_cls (n), d_reg (n,7) = d rcnn_loss / d (rcnn_cls, rcnn_reg); reg_targets (n,7) (forward_ret_dict['rcnn_reg_gt']) or NULL.
+ * One workgroup, sums in a fixed order: bit-reproducible. code size 7 only.
+ * crb_roi_canonical_targets: rois (n, roi_row_stride >= 7), gt_of_rois (n, gt_row_stride >= 7) -> out (n, gt_row_stride).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct CrbRcnnLossCfg {
+  float beta;                    /* smooth-L1 knee of the regression loss (1/9); the corner loss uses 1 */
+  float code_weights[7];         /* LOSS_CONFIG.LOSS_WEIGHTS.code_weights */
+  float cls_weight, reg_weight, corner_weight;   /* rcnn_cls_weight, rcnn_reg_weight, rcnn_corner_weight */
+  int32_t corner;                /* CORNER_LOSS_REGULARIZATION */
+} CrbRcnnLossCfg;
+int crb_rcnn_loss(const float* rcnn_cls, const float* rcnn_reg, const void* cls_labels, int labels_are_int64,
+                  const int64_t* reg_valid_mask, const float* rois, const float* gt_of_rois, const float* gt_of_rois_src,
+                  int gt_row_stride, int64_t n, const CrbRcnnLossCfg* cfg, float* loss, float* d_cls, float* d_reg,
+                  float* reg_targets, void* stream);
+int crb_roi_canonical_targets(const float* rois, int roi_row_stride, const float* gt_of_rois, int gt_row_stride, int64_t n,
+                              float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a7  3x3 stride-1 pad-1 convolution on channels_last maps as Winograd F(2x2,3x3) on the f32 MFMA (csrc/winograd_conv2.hip)
  * replaces: torch.nn.Conv2d(C, C, 3, padding=1) of the BEV backbone (pcdet/models/backbones_2d/base_bev_backbone.py:24-41;
  *           MIOpen's f32 implicit GEMM on this stack). 2.25x fewer multiplications than the direct convolution, results equal to

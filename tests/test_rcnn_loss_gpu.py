@@ -1,0 +1,159 @@
+"""GPU: csrc/rcnn_loss.hip (second-stage losses with their gradients in one launch, canonical transformation of the sampled ground
+truths in one launch) against the torch expressions of the mirror's RoIHeadTemplate (the restatement of
+pcdet/models/roi_heads/roi_head_template.py:118-138, :142-285 that the detector-level goldens pin) and their autograd:
+loss values and tb_dict entries 2e-6 relative, gradients 2e-5 of the largest entry, canonical targets 2e-6 absolute, bit-equal re-runs.
+Cases: the PV-RCNN shape (16 x 128 RoIs), RoI counts that are not multiples of the workgroup, no foreground RoI, no valid RoI,
+hard labels (CLS_SCORE_TYPE cls: int64 with -1), saturated logits (the -100 clamp and the 1e-12 floor of ATen's BCE), a prediction
+equal to its ground truth (corner distances 0: zero gradient), code weights and loss weights away from 1, corner loss off."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _head(dev, **loss_over):
+    from pcdet.model_cfgs import pv_rcnn_cfg
+    from pcdet.models.roi_heads.roi_head_template import RoIHeadTemplate
+    cfg = copy.deepcopy(pv_rcnn_cfg().MODEL.ROI_HEAD)
+    for k, v in loss_over.items():
+        if k in ('CLS_LOSS', 'REG_LOSS', 'CORNER_LOSS_REGULARIZATION'):
+            cfg.LOSS_CONFIG[k] = v
+        else:
+            cfg.LOSS_CONFIG.LOSS_WEIGHTS[k] = v
+    return RoIHeadTemplate(num_class=3, model_cfg=cfg).to(dev)
+
+
+def _boxes(rng, n, dev, centre=20.0):
+    b = np.concatenate([rng.uniform(-centre, centre, (n, 2)), rng.uniform(-2, 1, (n, 1)), rng.uniform(0.5, 4.5, (n, 3)),
+                        rng.uniform(-7, 7, (n, 1))], 1).astype(np.float32)
+    return torch.from_numpy(b).to(dev)
+
+
+def _case(dev, B, P, seed, fg='some', labels='soft', sat=False, exact=False):
+    rng = np.random.default_rng(seed)
+    n = B * P
+    rois = _boxes(rng, n, dev)
+    gt = rois + torch.from_numpy(rng.normal(0, 0.4, (n, 7)).astype(np.float32)).to(dev)
+    gt[:, 3:6] = gt[:, 3:6].abs() + 0.3
+    gt = torch.cat([gt, torch.from_numpy(rng.integers(1, 4, (n, 1)).astype(np.float32)).to(dev)], 1)
+    iou = torch.from_numpy(rng.uniform(0, 1, n).astype(np.float32)).to(dev)
+    if fg == 'none':
+        valid = torch.zeros(n, dtype=torch.int64, device=dev)
+    else:
+        valid = (iou > 0.55).long()
+    if labels == 'soft':
+        lab = torch.where(iou > 0.75, torch.ones_like(iou), torch.where(iou < 0.25, torch.zeros_like(iou), (iou - 0.25) / 0.5))
+    elif labels == 'hard':
+        lab = (iou > 0.6).long()
+        lab = torch.where((iou > 0.45) & (iou < 0.6), torch.full_like(lab, -1), lab)
+    else:                                                   # no valid RoI
+        lab = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    cls = torch.from_numpy(rng.normal(0, 2, (n, 1)).astype(np.float32)).to(dev)
+    if sat:
+        cls[::5] = 60.0
+        cls[1::5] = -60.0
+        cls[2::7] = 110.0
+    reg = torch.from_numpy(rng.normal(0, 0.3, (n, 7)).astype(np.float32)).to(dev)
+    return {'rois': rois.view(B, P, 7), 'gt_raw': gt.view(B, P, 8), 'reg_valid_mask': valid.view(B, P), 'rcnn_cls_labels': lab.view(B, P),
+            'rcnn_cls': cls, 'rcnn_reg': reg, 'exact': exact}
+
+
+def _run(head, case, fused):
+    from pcdet.models.roi_heads import roi_head_template as T
+    T.FUSED_LOSS, keep = fused, T.FUSED_LOSS
+    try:
+        head.proposal_target_layer.forward = lambda batch_dict, uniforms=None: {
+            'rois': case['rois'], 'gt_of_rois': case['gt_raw'].clone(), 'reg_valid_mask': case['reg_valid_mask'],
+            'rcnn_cls_labels': case['rcnn_cls_labels']}
+        targets = head.assign_targets({'batch_size': case['rois'].shape[0]})
+        cls = case['rcnn_cls'].clone().requires_grad_(True)
+        reg = case['rcnn_reg'].clone()
+        if case['exact']:                                    # prediction == ground truth for a few foreground RoIs
+            with torch.no_grad():
+                n = reg.shape[0]
+                anchors = torch.cat([torch.zeros(n, 3, device=reg.device), case['rois'].view(n, 7)[:, 3:6],
+                                     torch.zeros(n, 1, device=reg.device)], 1)
+                enc = head.box_coder.encode_torch(targets['gt_of_rois'].view(n, -1)[:, :7], anchors)
+                reg[::3] = enc[::3]
+        reg.requires_grad_(True)
+        head.forward_ret_dict = dict(targets, rcnn_cls=cls, rcnn_reg=reg)
+        loss, tb = head.get_loss()
+        (loss * 1.7).backward()
+        return loss.detach(), {k: v.detach().clone() for k, v in tb.items()}, cls.grad, reg.grad, targets['gt_of_rois'], \
+            head.forward_ret_dict['rcnn_reg_gt']
+    finally:
+        T.FUSED_LOSS = keep
+
+
+CASES = [
+    dict(B=16, P=128, seed=1),
+    dict(B=3, P=37, seed=2),
+    dict(B=1, P=1, seed=3),
+    dict(B=5, P=413, seed=4, labels='hard'),
+    dict(B=2, P=128, seed=5, fg='none'),
+    dict(B=2, P=64, seed=6, labels='none'),
+    dict(B=4, P=128, seed=7, sat=True),
+    dict(B=4, P=100, seed=8, exact=True),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'B%d_P%d_%s' % (c['B'], c['P'], '_'.join(k for k in c if k not in ('B', 'P', 'seed'))))
+def test_fused_losses_and_gradients_equal_the_torch_expressions(dev, case):
+    head = _head(dev)
+    c = _case(dev, **case)
+    loss_f, tb_f, gc_f, gr_f, ct_f, tgt_f = _run(head, c, True)
+    loss_t, tb_t, gc_t, gr_t, ct_t, tgt_t = _run(head, c, False)
+    assert type(loss_f) is torch.Tensor and set(tb_f) == set(tb_t) == {'rcnn_loss_cls', 'rcnn_loss_reg', 'rcnn_loss_corner', 'rcnn_loss'}
+    torch.testing.assert_close(ct_f, ct_t, rtol=0, atol=2e-6)
+    torch.testing.assert_close(tgt_f, tgt_t, rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(loss_f, loss_t, rtol=2e-6, atol=1e-7)
+    for k in tb_t:
+        torch.testing.assert_close(tb_f[k], tb_t[k], rtol=2e-6, atol=1e-7, msg=lambda m, k=k: k + ': ' + m)
+    for gf, gt, what in ((gc_f, gc_t, 'd rcnn_cls'), (gr_f, gr_t, 'd rcnn_reg')):
+        assert gf.shape == gt.shape and torch.isfinite(gf).all()
+        scale = float(gt.abs().max())
+        assert float((gf - gt).abs().max()) <= 2e-5 * max(scale, 1e-6), what
+    if case.get('exact'):
+        assert float(gr_f[::3].abs().max()) >= 0.0 and torch.isfinite(gr_f).all()
+    # the same launch again: bit-equal
+    loss_2, tb_2, gc_2, gr_2, _, _ = _run(head, c, True)
+    assert torch.equal(loss_f, loss_2) and torch.equal(gc_f, gc_2) and torch.equal(gr_f, gr_2)
+
+
+def test_weights_and_corner_switch(dev):
+    """code weights / loss weights away from 1; the corner term switched off (no rcnn_loss_corner entry, as in the reference)"""
+    c = _case(dev, B=4, P=128, seed=11)
+    head = _head(dev, code_weights=[1.0, 0.5, 2.0, 1.5, 1.0, 0.25, 3.0], rcnn_cls_weight=0.7, rcnn_reg_weight=1.3, rcnn_corner_weight=0.4)
+    f, t = _run(head, c, True), _run(head, c, False)
+    torch.testing.assert_close(f[0], t[0], rtol=2e-6, atol=1e-7)
+    for a, b in ((f[2], t[2]), (f[3], t[3])):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    head = _head(dev, CORNER_LOSS_REGULARIZATION=False)
+    f, t = _run(head, c, True), _run(head, c, False)
+    assert set(f[1]) == set(t[1]) == {'rcnn_loss_cls', 'rcnn_loss_reg', 'rcnn_loss'}
+    torch.testing.assert_close(f[0], t[0], rtol=2e-6, atol=1e-7)
+    assert float((f[3] - t[3]).abs().max()) <= 2e-5 * float(t[3].abs().max())
+
+
+def test_other_configurations_keep_the_torch_expressions(dev):
+    """reduce=False (per-frame losses of CRB stage 2), the CRB branch (reg_sample_targets) and CrossEntropy are not what the kernel
+    implements: the head says so by taking the torch path (no crb_rcnn_loss call)"""
+    from crbhip import rcnn_loss
+    head = _head(dev)
+    c = _case(dev, B=2, P=16, seed=12)
+    _run(head, c, True)
+    calls = []
+    orig = rcnn_loss.rcnn_loss
+    rcnn_loss.rcnn_loss = lambda *a, **k: calls.append(1) or orig(*a, **k)
+    try:
+        head.get_loss(reduce=True)
+        assert len(calls) == 1
+        loss, tb = head.get_loss(reduce=False)
+        assert loss.shape == (2,) and len(calls) == 1
+        head.forward_ret_dict['reg_sample_targets'] = torch.zeros_like(head.forward_ret_dict['rcnn_reg'])
+        assert head._fused_loss_cfg(True) is None
+    finally:
+        rcnn_loss.rcnn_loss = orig

@@ -40,9 +40,15 @@ def main():
     ahead = {}
     prefetch = os.environ.get('CRB_SPARSE_PREFETCH', '1') == '1'
 
+    # measurement knob: N extra one-element kernels after the forward pass (what does a tiny launch cost a device-bound step?)
+    extra = int(os.environ.get('CRB_BENCH_EXTRA_LAUNCHES', '0'))
+    tick = torch.zeros((1,), device=dev)
+
     def step(i):
         opt.zero_grad(set_to_none=True)
         ret, tb, _ = model(ahead.pop(i, None) or dict(batches[i % 2]))
+        for _ in range(extra):
+            tick.add_(1.0)
         if prefetch:
             ahead.clear()
             ahead[i + 1] = model.prefetch_sparse(dict(batches[(i + 1) % 2]))
