@@ -84,3 +84,43 @@ def roi_canonical_targets(rois, gt_of_rois):
     check(lib.crb_roi_canonical_targets(ptr(rois), int(rois.shape[-1]), ptr(gt), int(gt.shape[-1]), n, ptr(out), cur_stream(gt.device)),
           'crb_roi_canonical_targets')
     return out
+
+
+class RoiSamplerCfg(ctypes.Structure):
+    """CrbRoiSamplerCfg of include/crb_hip.h"""
+    _fields_ = [('roi_per_image', ctypes.c_int32), ('fg_quota', ctypes.c_int32), ('by_class', ctypes.c_int32),
+                ('score_type', ctypes.c_int32), ('fg_thresh', ctypes.c_float), ('reg_fg_thresh', ctypes.c_float),
+                ('cls_fg_thresh', ctypes.c_float), ('cls_bg_thresh', ctypes.c_float), ('cls_bg_thresh_lo', ctypes.c_float),
+                ('hard_bg_ratio', ctypes.c_float), ('soft_den', ctypes.c_float)]
+
+
+MAX_PROPOSALS = 1024            # one workgroup per frame, one thread per proposal
+
+
+@torch.no_grad()
+def roi_sample_targets(rois, roi_scores, roi_labels, gt_boxes, iou, u_perm, u_slot, cfg):
+    """rois (B,R,7+), roi_scores (B,R), roi_labels (B,R) i64, gt_boxes (B,G,8+), iou (B*R, B*G), u_perm (B,R), u_slot (B,P)
+    -> dict(sampled, rois, gt_of_rois, gt_iou_of_rois, roi_scores, roi_labels, reg_valid_mask, rcnn_cls_labels) of
+    ProposalTargetLayer.forward (proposal_target_layer.py:15-61)"""
+    require_cuda(rois, roi_scores, roi_labels, gt_boxes, iou, u_perm, u_slot)
+    B, R, G, P = int(rois.shape[0]), int(rois.shape[1]), int(gt_boxes.shape[1]), int(cfg.roi_per_image)
+    if roi_scores.shape != (B, R) or roi_labels.shape != (B, R) or iou.shape != (B * R, B * G) or u_perm.shape != (B, R) or \
+            u_slot.shape != (B, P) or roi_labels.dtype != torch.int64:
+        raise CrbHipError('crb_roi_sample_targets: shapes do not match (B, R, G, P) = (%d, %d, %d, %d)' % (B, R, G, P))
+    dev = rois.device
+    f = lambda t: t.contiguous().float()
+    rois, gt = f(rois), f(gt_boxes)
+    sampled = torch.empty((B, P), dtype=torch.int64, device=dev)
+    o_rois = torch.empty((B, P, rois.shape[-1]), dtype=torch.float32, device=dev)
+    o_gt = torch.empty((B, P, gt.shape[-1]), dtype=torch.float32, device=dev)
+    o_iou = torch.empty((B, P), dtype=torch.float32, device=dev)
+    o_scores = torch.empty((B, P), dtype=torch.float32, device=dev)
+    o_labels = torch.empty((B, P), dtype=torch.int64, device=dev)
+    valid = torch.empty((B, P), dtype=torch.int64, device=dev)
+    cls = torch.empty((B, P), dtype=torch.float32 if cfg.score_type == 0 else torch.int64, device=dev)
+    check(lib.crb_roi_sample_targets(ptr(rois), int(rois.shape[-1]), ptr(f(roi_scores)), ptr(roi_labels.contiguous()), ptr(gt),
+                                     int(gt.shape[-1]), ptr(f(iou)), ptr(f(u_perm)), ptr(f(u_slot)), B, R, G, ctypes.byref(cfg),
+                                     ptr(sampled), ptr(o_rois), ptr(o_gt), ptr(o_iou), ptr(o_scores), ptr(o_labels), ptr(valid),
+                                     ptr(cls), cur_stream(dev)), 'crb_roi_sample_targets')
+    return {'sampled': sampled, 'rois': o_rois, 'gt_of_rois': o_gt, 'gt_iou_of_rois': o_iou, 'roi_scores': o_scores,
+            'roi_labels': o_labels, 'reg_valid_mask': valid, 'rcnn_cls_labels': cls}

@@ -221,7 +221,165 @@ __global__ __launch_bounds__(256) void roi_canonical_kernel(const float* __restr
   for (int j = 7; j < C; ++j) o[j] = g[j];
 }
 
+// ---- ProposalTargetLayer: RoI sampling of one frame per workgroup (thread r = proposal r) ------------------------------------------
+// The batched, synchronisation-free form of the mirror (pcdet/models/roi_heads/target_assigner/proposal_target_layer.py here; the
+// reference's per-frame loop with np.random / torch.randint: proposal_target_layer.py:93-228 there) as one launch: same-class maximum
+// IoU, the three sets (foreground / hard / easy background), quotas, the draws from the given uniforms, every gather, the regression
+// mask and the classification labels. ~135 torch launches of a PV-RCNN step.
+struct RoiSampleArgs {
+  const float* rois; const float* scores; const int64_t* labels; const float* gt; const float* iou;
+  const float* u_perm; const float* u_slot;
+  int B, R, G, P, roi_c, gt_c;
+  CrbRoiSamplerCfg cfg;
+  int64_t* sampled; float* o_rois; float* o_gt; float* o_iou; float* o_scores; int64_t* o_labels; int64_t* reg_valid; void* cls_labels;
+};
+
+constexpr int RS_MAX_R = 1024;
+
+__device__ __forceinline__ int block_count(bool flag, int* sh) {
+  const unsigned long long m = __ballot(flag);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  int t = 0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+  return t;
+}
+
+__global__ __launch_bounds__(RS_MAX_R) void roi_sample_kernel(RoiSampleArgs a) {
+  __shared__ float s_mx[RS_MAX_R], s_u[RS_MAX_R];
+  __shared__ int s_arg[RS_MAX_R], s_fg[RS_MAX_R], s_hard[RS_MAX_R], s_easy[RS_MAX_R];
+  __shared__ unsigned char s_set[RS_MAX_R];                 // bit 0 fg, 1 hard, 2 easy
+  __shared__ int s_cnt[RS_MAX_R / 64];
+  __shared__ int s_last, s_umin;
+  const int b = blockIdx.x, r = threadIdx.x;
+  const CrbRoiSamplerCfg& c = a.cfg;
+  const bool live = r < a.R;
+  // last ground truth of the frame that is not a padding row (every row up to it counts, as in the mirror)
+  if (r == 0) s_last = 0;
+  __syncthreads();
+  if (c.by_class) {
+    for (int g = r; g < a.G; g += blockDim.x) {
+      const float* row = a.gt + ((int64_t)b * a.G + g) * a.gt_c;
+      float sum = 0.f;
+      for (int j = 0; j < a.gt_c - 1; ++j) sum += row[j];
+      if (sum != 0.f) atomicMax(&s_last, g);
+    }
+  }
+  __syncthreads();
+  float mx = 0.f;
+  int arg = 0;
+  if (live) {
+    const float* irow = a.iou + ((int64_t)b * a.R + r) * ((int64_t)a.B * a.G) + (int64_t)b * a.G;
+    if (c.by_class) {
+      const int64_t lab = a.labels[(int64_t)b * a.R + r];
+      float best = -1.f;
+      for (int g = 0; g <= s_last && g < a.G; ++g) {
+        const bool same = lab == (int64_t)a.gt[((int64_t)b * a.G + g) * a.gt_c + a.gt_c - 1];
+        const float v = same ? irow[g] : -1.f;
+        if (v > best) { best = v; arg = g; }
+      }
+      if (best < 0.f) { best = 0.f; arg = 0; }
+      mx = best;
+    } else {
+      mx = irow[0];
+      for (int g = 1; g < a.G; ++g)
+        if (irow[g] > mx) { mx = irow[g]; arg = g; }
+    }
+    s_mx[r] = mx;
+    s_arg[r] = arg;
+    s_u[r] = a.u_perm[(int64_t)b * a.R + r];
+  }
+  const bool fg = live && mx >= c.fg_thresh;
+  const bool easy = live && mx < c.cls_bg_thresh_lo;
+  const bool hard = live && mx < c.reg_fg_thresh && mx >= c.cls_bg_thresh_lo;
+  if (live) s_set[r] = (fg ? 1 : 0) | (hard ? 2 : 0) | (easy ? 4 : 0);
+  const int n_fg = block_count(fg, s_cnt), n_hard = block_count(hard, s_cnt), n_easy = block_count(easy, s_cnt);
+  // (after the counts' barriers s_set / s_u / s_mx are visible)
+  if (live) {
+    // foreground in the order of its uniforms (a random permutation), background sets in proposal order
+    int rk_fg = 0, rk_hard = 0, rk_easy = 0, lower = 0;
+    const float u = s_u[r];
+    for (int q = 0; q < a.R; ++q) {
+      const unsigned char sq = s_set[q];
+      const float uq = s_u[q];
+      const bool before = uq < u || (uq == u && q < r);
+      rk_fg += (sq & 1) && before;
+      rk_hard += (sq & 2) && q < r;
+      rk_easy += (sq & 4) && q < r;
+      lower += before;
+    }
+    if (fg) s_fg[rk_fg] = r;
+    if (hard) s_hard[rk_hard] = r;
+    if (easy) s_easy[rk_easy] = r;
+    if (lower == 0) s_umin = r;
+  }
+  __syncthreads();
+  const int n_bg = n_hard + n_easy, P = a.P;
+  int fg_take = n_bg > 0 ? min(n_fg, c.fg_quota) : P;
+  if (n_fg == 0) fg_take = 0;
+  const int bg_take = P - fg_take;
+  int hard_take = n_easy > 0 ? min((int)((float)bg_take * c.hard_bg_ratio), n_hard) : bg_take;
+  if (n_hard == 0) hard_take = 0;
+  for (int s = r; s < P; s += blockDim.x) {
+    const float us = a.u_slot[(int64_t)b * P + s];
+    int pick;
+    if (s < fg_take) {
+      int pos = n_bg > 0 ? s : (int)floorf(us * (float)max(n_fg, 1));
+      pos = min(min(pos, a.R - 1), max(n_fg, 1) - 1);
+      pick = n_fg > 0 ? s_fg[pos] : s_umin;
+    } else if (s < fg_take + hard_take) {
+      const int pos = min((int)floorf(us * (float)max(n_hard, 1)), max(n_hard, 1) - 1);
+      pick = n_hard > 0 ? s_hard[pos] : 0;
+    } else {
+      const int pos = min((int)floorf(us * (float)max(n_easy, 1)), max(n_easy, 1) - 1);
+      pick = n_easy > 0 ? s_easy[pos] : 0;
+    }
+    const int64_t o = (int64_t)b * P + s, src = (int64_t)b * a.R + pick;
+    a.sampled[o] = pick;
+    for (int j = 0; j < a.roi_c; ++j) a.o_rois[o * a.roi_c + j] = a.rois[src * a.roi_c + j];
+    const float* grow = a.gt + ((int64_t)b * a.G + s_arg[pick]) * a.gt_c;
+    for (int j = 0; j < a.gt_c; ++j) a.o_gt[o * a.gt_c + j] = grow[j];
+    const float iou = s_mx[pick];
+    a.o_iou[o] = iou;
+    a.o_scores[o] = a.scores[src];
+    a.o_labels[o] = a.labels[src];
+    a.reg_valid[o] = iou > c.reg_fg_thresh ? 1 : 0;
+    if (c.score_type == 0) {                                // roi_iou: soft labels
+      float v = (iou - c.cls_bg_thresh) / c.soft_den;
+      if (iou < c.cls_bg_thresh) v = 0.f;
+      if (iou > c.cls_fg_thresh) v = 1.f;
+      reinterpret_cast<float*>(a.cls_labels)[o] = v;
+    } else {                                                // cls: 1 / 0, -1 between the two thresholds
+      int64_t v = iou > c.cls_fg_thresh ? 1 : 0;
+      if (iou > c.cls_bg_thresh && iou < c.cls_fg_thresh) v = -1;
+      reinterpret_cast<int64_t*>(a.cls_labels)[o] = v;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int crb_roi_sample_targets(const float* rois, int roi_row_stride, const float* roi_scores, const int64_t* roi_labels,
+                                      const float* gt_boxes, int gt_row_stride, const float* iou, const float* u_perm, const float* u_slot,
+                                      int B, int R, int G, const CrbRoiSamplerCfg* cfg, int64_t* sampled, float* out_rois, float* out_gt,
+                                      float* out_iou, float* out_scores, int64_t* out_labels, int64_t* reg_valid_mask, void* cls_labels,
+                                      void* stream) {
+  if (!cfg || B <= 0 || R <= 0 || G <= 0 || roi_row_stride < 7 || gt_row_stride < 8 || cfg->roi_per_image <= 0) return CRB_ERR_ARG;
+  if (R > RS_MAX_R) return CRB_ERR_UNSUPPORTED;
+  if (!rois || !roi_scores || !roi_labels || !gt_boxes || !iou || !u_perm || !u_slot || !sampled || !out_rois || !out_gt || !out_iou ||
+      !out_scores || !out_labels || !reg_valid_mask || !cls_labels)
+    return CRB_ERR_ARG;
+  RoiSampleArgs a;
+  a.rois = rois; a.scores = roi_scores; a.labels = roi_labels; a.gt = gt_boxes; a.iou = iou; a.u_perm = u_perm; a.u_slot = u_slot;
+  a.B = B; a.R = R; a.G = G; a.P = cfg->roi_per_image; a.roi_c = roi_row_stride; a.gt_c = gt_row_stride; a.cfg = *cfg;
+  a.sampled = sampled; a.o_rois = out_rois; a.o_gt = out_gt; a.o_iou = out_iou; a.o_scores = out_scores; a.o_labels = out_labels;
+  a.reg_valid = reg_valid_mask; a.cls_labels = cls_labels;
+  const int threads = (int)crb_align_up(R, 64);
+  hipLaunchKernelGGL(roi_sample_kernel, dim3(B), dim3(threads), 0, (hipStream_t)stream, a);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
 
 extern "C" int crb_rcnn_loss(const float* rcnn_cls, const float* rcnn_reg, const void* cls_labels, int labels_are_int64,
                              const int64_t* reg_valid_mask, const float* rois, const float* gt_of_rois, const float* gt_of_rois_src,

@@ -12,6 +12,11 @@ import torch.nn as nn
 from ....ops.iou3d_nms import iou3d_nms_utils
 
 
+# the whole layer after the IoU matrix as one launch (crbhip.rcnn_loss.roi_sample_targets: ~135 elementwise / sort / gather launches of
+# a PV-RCNN step); CRB_ROI_SAMPLER_FUSED=0 = the torch expressions below (A/B, and what the kernel is tested against)
+FUSED_SAMPLER = __import__('os').environ.get('CRB_ROI_SAMPLER_FUSED', '1') == '1'
+
+
 class ProposalTargetLayer(nn.Module):
     def __init__(self, roi_sampler_cfg):
         super().__init__()
@@ -23,7 +28,46 @@ class ProposalTargetLayer(nn.Module):
         self.injected_indices = None
         self.injected_rois = None
 
+    def _fused_cfg(self):
+        cfg = self.roi_sampler_cfg
+        if cfg.CLS_SCORE_TYPE not in ('roi_iou', 'cls'):
+            return None
+        key = (int(cfg.ROI_PER_IMAGE), float(cfg.FG_RATIO), bool(cfg.get('SAMPLE_ROI_BY_EACH_CLASS', False)), cfg.CLS_SCORE_TYPE,
+               float(cfg.REG_FG_THRESH), float(cfg.CLS_FG_THRESH), float(cfg.CLS_BG_THRESH), float(cfg.CLS_BG_THRESH_LO),
+               float(cfg.HARD_BG_RATIO))
+        hit = self.__dict__.get('_crb_sampler_cfg')
+        if hit is None or hit[0] != key:
+            from crbhip import rcnn_loss
+            c = rcnn_loss.RoiSamplerCfg(key[0], int(np.round(key[1] * key[0])), int(key[2]), 0 if key[3] == 'roi_iou' else 1,
+                                        min(key[4], key[5]), key[4], key[5], key[6], key[7], key[8], key[5] - key[6])
+            hit = self.__dict__['_crb_sampler_cfg'] = (key, c)
+        return hit[1]
+
+    def forward_fused(self, batch_dict, uniforms=None):
+        """the layer as one launch behind the IoU matrix; None when this call is not what the kernel implements (injected RoIs of the
+        parity tests, more than 1024 proposals per frame, host tensors)"""
+        from crbhip import rcnn_loss
+        rois, gt_boxes = batch_dict['rois'], batch_dict['gt_boxes']
+        c = self._fused_cfg()
+        if c is None or not rois.is_cuda or self.injected_rois is not None or self.injected_indices is not None or \
+                rois.shape[1] > rcnn_loss.MAX_PROPOSALS or gt_boxes.shape[1] == 0 or gt_boxes.shape[-1] < 8:
+            return None
+        B, R, G = rois.shape[0], rois.shape[1], gt_boxes.shape[1]
+        iou = iou3d_nms_utils.boxes_iou3d_gpu(rois.reshape(B * R, rois.shape[-1])[:, 0:7], gt_boxes.reshape(B * G, -1)[:, 0:7])
+        if uniforms is None:
+            u_perm = torch.rand((B, R), device=rois.device, generator=self.generator)
+            u_slot = torch.rand((B, c.roi_per_image), device=rois.device, generator=self.generator)
+        else:
+            u_perm, u_slot = uniforms
+        out = rcnn_loss.roi_sample_targets(rois, batch_dict['roi_scores'], batch_dict['roi_labels'], gt_boxes, iou, u_perm, u_slot, c)
+        out.pop('sampled')
+        return out
+
     def forward(self, batch_dict, uniforms=None):
+        if FUSED_SAMPLER:
+            out = self.forward_fused(batch_dict, uniforms)
+            if out is not None:
+                return out
         cfg = self.roi_sampler_cfg
         rois, gt_of_rois, ious, scores, labels = self.sample_rois_for_rcnn(batch_dict, uniforms)
         reg_valid_mask = (ious > cfg.REG_FG_THRESH).long()

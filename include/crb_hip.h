@@ -620,6 +620,32 @@ int crb_rcnn_loss(const float* rcnn_cls, const float* rcnn_reg, const void* cls_
                   float* reg_targets, void* stream);
 int crb_roi_canonical_targets(const float* rois, int roi_row_stride, const float* gt_of_rois, int gt_row_stride, int64_t n,
                               float* out, void* stream);
+/* RoI sampling for the second stage: one workgroup per frame (csrc/rcnn_loss.hip)
+ * replaces: ProposalTargetLayer.forward / sample_rois_for_rcnn / subsample_rois / get_max_iou_with_same_class
+ *           (pcdet/models/roi_heads/target_assigner/proposal_target_layer.py:15-228): per frame the (same-class) maximum IoU of every
+ *           proposal, foreground / hard / easy background sets, FG_RATIO and HARD_BG_RATIO quotas, foreground without replacement in
+ *           random order, background with replacement, the gathers, reg_valid_mask and rcnn_cls_labels. The random numbers are
+ *           INPUTS: u_perm (B,R) orders the foreground, u_slot (B,P) draws with replacement (floor(u * n)) - the reference's
+ *           np.random / torch.randint stream is not reproduced.
+ * rois (B,R,roi_row_stride >= 7), roi_scores (B,R), roi_labels (B,R) i64, gt_boxes (B,G,gt_row_stride >= 8, class in the last column,
+ * zero rows = padding), iou (B*R, B*G) = crb_boxes_iou3d of all proposals against all ground truths (frame b uses its diagonal block)
+ * -> sampled (B,P) i64 proposal indices, out_rois (B,P,roi_row_stride), out_gt (B,P,gt_row_stride), out_iou / out_scores (B,P),
+ *    out_labels (B,P) i64, reg_valid_mask (B,P) i64, cls_labels (B,P) f32 (score_type 0 = roi_iou) or i64 (1 = cls, -1 ignored).
+ * R <= 1024, else CRB_ERR_UNSUPPORTED. */
+typedef struct CrbRoiSamplerCfg {
+  int32_t roi_per_image;         /* ROI_PER_IMAGE = P */
+  int32_t fg_quota;              /* round(FG_RATIO * P) */
+  int32_t by_class;              /* SAMPLE_ROI_BY_EACH_CLASS */
+  int32_t score_type;            /* CLS_SCORE_TYPE: 0 roi_iou, 1 cls */
+  float fg_thresh;               /* min(REG_FG_THRESH, CLS_FG_THRESH) */
+  float reg_fg_thresh, cls_fg_thresh, cls_bg_thresh, cls_bg_thresh_lo, hard_bg_ratio;
+  float soft_den;                /* CLS_FG_THRESH - CLS_BG_THRESH */
+} CrbRoiSamplerCfg;
+int crb_roi_sample_targets(const float* rois, int roi_row_stride, const float* roi_scores, const int64_t* roi_labels,
+                           const float* gt_boxes, int gt_row_stride, const float* iou, const float* u_perm, const float* u_slot,
+                           int B, int R, int G, const CrbRoiSamplerCfg* cfg, int64_t* sampled, float* out_rois, float* out_gt,
+                           float* out_iou, float* out_scores, int64_t* out_labels, int64_t* reg_valid_mask, void* cls_labels,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a7  3x3 stride-1 pad-1 convolution on channels_last maps as Winograd F(2x2,3x3) on the f32 MFMA (csrc/winograd_conv2.hip)

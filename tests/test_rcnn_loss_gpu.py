@@ -157,3 +157,93 @@ def test_other_configurations_keep_the_torch_expressions(dev):
         assert head._fused_loss_cfg(True) is None
     finally:
         rcnn_loss.rcnn_loss = orig
+
+
+def _sampler_case(dev, B, R, G, seed, mode):
+    """proposals around the ground truths: `mode` shapes the three sets of each frame (mixed / all foreground / no foreground /
+    no hard background / no easy background / no ground truth in frame 0)"""
+    rng = np.random.default_rng(seed)
+    gt = np.zeros((B, G, 8), np.float32)
+    rois = np.zeros((B, R, 7), np.float32)
+    labels = np.zeros((B, R), np.int64)
+    for b in range(B):
+        ng = int(rng.integers(1, G + 1))
+        if mode == 'no_gt' and b == 0:
+            ng = 0
+        g = np.concatenate([rng.uniform(-30, 30, (ng, 2)), rng.uniform(-1.5, 0, (ng, 1)), rng.uniform(1.2, 4.5, (ng, 3)),
+                            rng.uniform(-3.1, 3.1, (ng, 1)), rng.integers(1, 4, (ng, 1))], 1).astype(np.float32)
+        gt[b, :ng] = g
+        for r in range(R):
+            kind = {'mixed': rng.integers(0, 4), 'all_fg': 0, 'no_fg': rng.integers(1, 4), 'no_hard': rng.choice([0, 3]),
+                    'no_easy': rng.integers(0, 2), 'no_gt': rng.integers(0, 4)}[mode]
+            if ng == 0 or kind == 3:                          # far from everything: easy background
+                rois[b, r] = [rng.uniform(40, 60), rng.uniform(40, 60), -1, 3.9, 1.6, 1.5, rng.uniform(-3, 3)]
+                labels[b, r] = rng.integers(1, 4)
+                continue
+            k = int(rng.integers(0, ng))
+            jitter = {0: 0.01 if mode == 'all_fg' else 0.03, 1: 0.35, 2: 0.2}[int(kind)]
+            box = g[k, :7].copy()
+            if mode == 'no_fg':                               # half a box away along both axes: IoU 0.14 (hard background)
+                box[:2] += rng.choice([-1.0, 1.0], 2) * 0.5 * box[3:5]
+            else:
+                box[:2] += rng.normal(0, jitter * box[3:5])
+                box[6] += rng.normal(0, jitter * 0.3)
+            rois[b, r] = box
+            labels[b, r] = int(g[k, 7]) if (mode == 'all_fg' or rng.uniform() < 0.9) else int(g[k, 7]) % 3 + 1
+    t = lambda a: torch.from_numpy(a).to(dev)
+    return {'rois': t(rois), 'roi_scores': t(rng.uniform(0, 1, (B, R)).astype(np.float32)), 'roi_labels': t(labels), 'gt_boxes': t(gt),
+            'batch_size': B}
+
+
+@pytest.mark.parametrize('B,R,G,mode,by_class,score_type', [
+    (16, 512, 12, 'mixed', True, 'roi_iou'), (3, 100, 5, 'mixed', True, 'roi_iou'), (2, 512, 9, 'all_fg', True, 'roi_iou'),
+    (2, 300, 7, 'no_fg', True, 'cls'), (2, 512, 6, 'no_hard', True, 'roi_iou'), (2, 257, 6, 'no_easy', True, 'roi_iou'),
+    (3, 512, 4, 'no_gt', True, 'roi_iou'), (4, 512, 1, 'mixed', False, 'cls'), (1, 1024, 20, 'mixed', True, 'roi_iou')])
+def test_roi_sampling_kernel_equals_the_torch_layer(dev, B, R, G, mode, by_class, score_type):
+    """crb_roi_sample_targets against the mirror's batched torch layer on the same uniforms: every output EQUAL (indices, gathers,
+    masks, labels), drawn uniforms as well as injected ones; frames without foreground / background sets / ground truths, fewer
+    proposals than ROI_PER_IMAGE, the 1024-proposal limit, both CLS_SCORE_TYPEs, with and without SAMPLE_ROI_BY_EACH_CLASS"""
+    from pcdet.models.roi_heads.target_assigner import proposal_target_layer as L
+    head = _head(dev)
+    layer = head.proposal_target_layer
+    layer.roi_sampler_cfg.SAMPLE_ROI_BY_EACH_CLASS = by_class
+    layer.roi_sampler_cfg.CLS_SCORE_TYPE = score_type
+    bd = _sampler_case(dev, B, R, G, seed=B * 1000 + R + G, mode=mode)
+    P = layer.roi_sampler_cfg.ROI_PER_IMAGE
+    keep = L.FUSED_SAMPLER
+    try:
+        outs = []
+        for fused in (True, False):
+            L.FUSED_SAMPLER = fused
+            g = torch.Generator(device=dev)
+            g.manual_seed(5)
+            layer.generator = g
+            drawn = layer.forward(bd)
+            gi = torch.Generator(device=dev)
+            gi.manual_seed(6)
+            uni = (torch.rand((B, R), device=dev, generator=gi), torch.rand((B, P), device=dev, generator=gi))
+            outs.append((drawn, layer.forward(bd, uni)))
+        assert layer.forward_fused(bd) is not None
+    finally:
+        L.FUSED_SAMPLER = keep
+        layer.generator = None
+    for (f, t) in zip(outs[0], outs[1]):
+        assert set(f) == set(t)
+        for k in t:
+            assert f[k].dtype == t[k].dtype and f[k].shape == t[k].shape, k
+            assert torch.equal(f[k], t[k]), (k, mode)
+    fgs = outs[0][0]['reg_valid_mask'].sum(1)
+    if mode == 'all_fg':
+        assert int(fgs.min()) == P
+    if mode == 'no_fg':
+        assert int(fgs.max()) == 0
+
+
+def test_roi_sampling_falls_back_outside_its_limits(dev):
+    from pcdet.models.roi_heads.target_assigner import proposal_target_layer as L
+    layer = _head(dev).proposal_target_layer
+    bd = _sampler_case(dev, 1, 1100, 3, seed=3, mode='mixed')
+    assert layer.forward_fused(bd) is None and layer.forward(bd)['rois'].shape == (1, 128, 7)
+    bd = _sampler_case(dev, 2, 64, 3, seed=4, mode='mixed')
+    layer.injected_indices = torch.zeros((2, 128), dtype=torch.long, device=dev)
+    assert layer.forward_fused(bd) is None

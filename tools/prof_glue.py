@@ -62,6 +62,22 @@ def main():
         if name:
             m.register_forward_pre_hook(pre(name))
             m.register_forward_hook(post)
+    # finer scopes than the modules where one module launches hundreds of small kernels: methods of the RoI head / its target layer
+    def scope_method(obj, meth, tag):
+        fn = getattr(obj, meth)
+
+        def wrapped(*args, **kw):
+            with torch.autograd.profiler.record_function('mod:' + tag):
+                return fn(*args, **kw)
+        setattr(obj, meth, wrapped)
+    rh = getattr(model, 'roi_head', None)
+    if rh is not None:
+        for meth in ('proposal_layer', 'assign_targets', 'roi_grid_pool', 'get_global_grid_points_of_roi', 'get_loss'):
+            if hasattr(rh, meth):
+                scope_method(rh, meth, 'roi_head.' + meth)
+        ptl = rh.proposal_target_layer
+        for meth in ('sample_rois_for_rcnn', 'subsample_rois_batched', 'max_iou_with_same_class_batched'):
+            scope_method(ptl, meth, 'roi_head.target_layer.' + meth)
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
         step()
         torch.cuda.synchronize()
