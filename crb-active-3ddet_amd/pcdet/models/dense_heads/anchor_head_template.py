@@ -14,6 +14,10 @@ from .target_assigner.axis_aligned_target_assigner import AxisAlignedTargetAssig
 FUSED_LOSS = True     # RPN losses through crb_rpn_loss_forward / _backward for device tensors; False = the torch restatement
 
 
+# decode of the proposal layer's top-k anchors as one launch (CRB_PROPOSAL_FUSED=0: the torch expressions, A/B and test reference)
+FUSED_DECODE = __import__('os').environ.get('CRB_PROPOSAL_FUSED', '1') == '1'
+
+
 class AnchorHeadTemplate(nn.Module):
     def __init__(self, model_cfg, num_class, class_names, grid_size, point_cloud_range, predict_boxes_when_training):
         super().__init__()
@@ -69,7 +73,11 @@ class AnchorHeadTemplate(nn.Module):
         return self.target_assigner.assign_targets(self.anchors, gt_boxes)
 
     def _flat_anchors(self):
-        return torch.cat(self.anchors, dim=-3)
+        """the per-class anchor maps side by side (anchor_head_template.py:245); constants of the head: built once per device"""
+        hit = self.__dict__.get('_crb_flat_anchors')
+        if hit is None or hit[0] is not self.anchors or hit[1].device != self.anchors[0].device:
+            hit = self.__dict__['_crb_flat_anchors'] = (self.anchors, torch.cat(self.anchors, dim=-3))
+        return hit[1]
 
     def get_cls_layer_loss(self, new_data=None, reduce=True):
         src = self.forward_ret_dict if new_data is None else new_data
@@ -224,6 +232,18 @@ class AnchorHeadTemplate(nn.Module):
         batch_cls_preds = cls_preds.view(batch_size, A, -1).float()
         raw = box_preds.view(batch_size, A, -1)
         dirs = dir_cls_preds.view(batch_size, A, -1) if dir_cls_preds is not None else None
+        if anchor_idx is not None and FUSED_DECODE and raw.is_cuda and raw.shape[-1] == 7 and anchors.shape[-1] == 7 and \
+                type(self.box_coder).__name__ == 'ResidualCoder' and not getattr(self.box_coder, 'encode_angle_by_sincos', False):
+            # the top-k anchors of the proposal layer: gather + decode + direction bins as one launch (csrc/proposal_layer.hip)
+            from crbhip import lib, check, ptr, cur_stream
+            k = int(anchor_idx.shape[1])
+            out = torch.empty((batch_size, k, 7), dtype=torch.float32, device=raw.device)
+            check(lib.crb_decode_selected_anchors(ptr(raw.contiguous().float()), ptr(None if dirs is None else dirs.contiguous().float()),
+                                                  ptr(anchors.view(-1, 7).contiguous().float()), ptr(anchor_idx.contiguous()), batch_size,
+                                                  A, k, 0 if dirs is None else int(dirs.shape[-1]), float(self.model_cfg.get('DIR_OFFSET', 0.0)),
+                                                  float(self.model_cfg.get('DIR_LIMIT_OFFSET', 0.0)), ptr(out), cur_stream(raw.device)),
+                  'crb_decode_selected_anchors')
+            return batch_cls_preds, out
         if anchor_idx is None:
             batch_anchors = anchors.view(1, -1, anchors.shape[-1]).expand(batch_size, -1, -1)
         else:

@@ -15,6 +15,8 @@ from .target_assigner.proposal_target_layer import ProposalTargetLayer
 # elementwise / reduction launches of a PV-RCNN step); CRB_RCNN_LOSS_FUSED=0 = the torch expressions below (A/B, and what the
 # kernels are tested against)
 FUSED_LOSS = __import__('os').environ.get('CRB_RCNN_LOSS_FUSED', '1') == '1'
+# gathers of the proposal layer behind its NMS as one launch (csrc/proposal_layer.hip); CRB_PROPOSAL_FUSED=0 = torch expressions
+FUSED_PROPOSAL = __import__('os').environ.get('CRB_PROPOSAL_FUSED', '1') == '1'
 
 
 class RoIHeadTemplate(nn.Module):
@@ -64,6 +66,21 @@ class RoIHeadTemplate(nn.Module):
             top_boxes = torch.gather(box_preds, 1, top_idx[..., None].expand(-1, -1, box_preds.shape[-1]))
         keep, _ = iou3d_nms_utils.nms_batched(top_boxes[..., 0:7].contiguous(), None, nms_config.NMS_THRESH, post,
                                               rotated=(nms_config.NMS_TYPE == 'nms_gpu'))
+        if FUSED_PROPOSAL and cls_preds.is_cuda and top_idx.dtype == torch.int64:
+            from crbhip import lib, check, ptr, cur_stream
+            C, bc, dev = int(cls_preds.shape[-1]), int(top_boxes.shape[-1]), cls_preds.device
+            rois = torch.empty((B, post, bc), dtype=torch.float32, device=dev)
+            roi_scores = torch.empty((B, post), dtype=torch.float32, device=dev)
+            roi_labels = torch.empty((B, post), dtype=torch.int64, device=dev)
+            full = torch.empty((B, post, C), dtype=torch.float32, device=dev)
+            check(lib.crb_proposal_finish(ptr(keep), ptr(top_idx.contiguous()), ptr(top_boxes.contiguous().float()),
+                                          ptr(scores.contiguous().float()), ptr(labels.contiguous()), ptr(cls_preds.contiguous().float()),
+                                          B, A, k, post, bc, C, ptr(rois), ptr(roi_scores), ptr(roi_labels), ptr(full), cur_stream(dev)),
+                  'crb_proposal_finish')
+            batch_dict.update(rois=rois, roi_scores=roi_scores, roi_labels=roi_labels, full_cls_scores=full,
+                              has_class_labels=True if C > 1 else False)
+            batch_dict.pop('batch_index', None)
+            return batch_dict
         valid = keep >= 0
         kept = keep.clamp(min=0).long()
         sel = torch.gather(top_idx, 1, kept)                                       # indices into the anchors

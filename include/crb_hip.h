@@ -592,6 +592,24 @@ int crb_rpn_loss_backward(const float* cls_preds, const float* box_preds, const 
                           const float* npos, const float* grad_loss, float* d_cls, float* d_box, float* d_dir, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * a21  proposal layer around its NMS (csrc/proposal_layer.hip)
+ * crb_decode_selected_anchors replaces AnchorHeadTemplate.generate_predicted_boxes for the anchors the proposal layer keeps
+ *   (pcdet/models/dense_heads/anchor_head_template.py:238-285 with ResidualCoder.decode_torch, pcdet/utils/box_coder_utils.py:45-73,
+ *   and the direction-bin correction through common_utils.limit_period): box_preds (B,A,7), dir_preds (B,A,num_dir_bins) or NULL,
+ *   anchors (A,7), anchor_idx (B,k) i64 -> out (B,k,7) = the rows the full decode holds at those indices, bit for bit.
+ * crb_proposal_finish replaces the gathers of RoIHeadTemplate.proposal_layer behind the class-agnostic NMS
+ *   (pcdet/models/roi_heads/roi_head_template.py:73-108): keep (B,post) i32 (-1 = padding, positions in the top-k order), top_idx (B,k)
+ *   i64 anchor indices, top_boxes (B,k,box_row_stride), scores (B,A), labels (B,A) i64 (0-based argmax), cls_preds (B,A,num_class)
+ *   -> rois (B,post,box_row_stride) zero padded, roi_scores (B,post), roi_labels (B,post) i64 (1-based; padding = 1 as in the
+ *   reference), full_cls_scores (B,post,num_class).
+ * ---------------------------------------------------------------------------------------------- */
+int crb_decode_selected_anchors(const float* box_preds, const float* dir_preds, const float* anchors, const int64_t* anchor_idx, int B,
+                                int64_t A, int k, int num_dir_bins, float dir_offset, float dir_limit_offset, float* out, void* stream);
+int crb_proposal_finish(const int32_t* keep, const int64_t* top_idx, const float* top_boxes, const float* scores, const int64_t* labels,
+                        const float* cls_preds, int B, int64_t A, int k, int post, int box_row_stride, int num_class, float* rois,
+                        float* roi_scores, int64_t* roi_labels, float* full_cls_scores, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a22 / a24  second-stage losses and the canonical transformation of the sampled ground truths (csrc/rcnn_loss.hip)
  * replaces: RoIHeadTemplate.get_box_cls_layer_loss (BinaryCrossEntropy; pcdet/models/roi_heads/roi_head_template.py:261-285),
  *           get_box_reg_layer_loss (smooth-l1 + CORNER_LOSS_REGULARIZATION, the branch without reg_sample_targets; :142-259) with

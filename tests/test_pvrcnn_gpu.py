@@ -116,6 +116,21 @@ def test_proposal_layer_matches_oracle_nms(model, dev):
         assert torch.equal(b['batch_box_decoder'](probe), torch.gather(box, 1, probe[..., None].expand(-1, -1, 7)))
         cfg = model.roi_head.model_cfg.NMS_CONFIG['TEST']
         out = model.roi_head.proposal_layer(dict(b), cfg)
+        # the two launches of csrc/proposal_layer.hip (decode of the kept anchors, gathers behind the NMS) against the torch
+        # expressions they replace: every output equal, test and training NMS configurations
+        from pcdet.models.dense_heads import anchor_head_template as AH
+        from pcdet.models.roi_heads import roi_head_template as RH
+        assert AH.FUSED_DECODE and RH.FUSED_PROPOSAL
+        for nms_cfg in (cfg, model.roi_head.model_cfg.NMS_CONFIG['TRAIN']):
+            fused = model.roi_head.proposal_layer(dict(b), nms_cfg)
+            try:
+                AH.FUSED_DECODE = RH.FUSED_PROPOSAL = False
+                plain = model.roi_head.proposal_layer(dict(b), nms_cfg)
+            finally:
+                AH.FUSED_DECODE = RH.FUSED_PROPOSAL = True
+            for key in ('rois', 'roi_scores', 'roi_labels', 'full_cls_scores'):
+                assert fused[key].dtype == plain[key].dtype and torch.equal(fused[key], plain[key]), key
+            assert fused['has_class_labels'] == plain['has_class_labels']
     for f in range(2):
         s, lab = cls[f].max(1)
         top_s, top_i = torch.topk(s, 1024)
