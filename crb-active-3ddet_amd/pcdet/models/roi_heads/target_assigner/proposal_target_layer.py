@@ -46,10 +46,14 @@ class ProposalTargetLayer(nn.Module):
     def forward_fused(self, batch_dict, uniforms=None):
         """the layer as one launch behind the IoU matrix; None when this call is not what the kernel implements (injected RoIs of the
         parity tests, more than 1024 proposals per frame, host tensors)"""
+        rois, gt_boxes = batch_dict.get('rois', None), batch_dict.get('gt_boxes', None)
+        # (an instance whose sampling methods were replaced - the golden tests feed recorded draws that way - keeps the torch layer)
+        if rois is None or gt_boxes is None or not rois.is_cuda or 'sample_rois_for_rcnn' in self.__dict__ or \
+                'subsample_rois_batched' in self.__dict__:
+            return None
         from crbhip import rcnn_loss
-        rois, gt_boxes = batch_dict['rois'], batch_dict['gt_boxes']
         c = self._fused_cfg()
-        if c is None or not rois.is_cuda or self.injected_rois is not None or self.injected_indices is not None or \
+        if c is None or self.injected_rois is not None or self.injected_indices is not None or \
                 rois.shape[1] > rcnn_loss.MAX_PROPOSALS or gt_boxes.shape[1] == 0 or gt_boxes.shape[-1] < 8:
             return None
         B, R, G = rois.shape[0], rois.shape[1], gt_boxes.shape[1]
