@@ -685,6 +685,36 @@ extern "C" int crb_bn_relu_backward(const float* x, const float* dz, int64_t dz_
   return CRB_OK;
 }
 
+#ifdef CRB_MEASURE
+// (measurement library only: the consumer side of crb_conv3x3_winograd2_bnbwd_nhwc, VERDICT r04 item 6a - measured, not adopted)
+// backward with the reduction already done by the producer of dz: slab_sums (n_slabs, 2, C) = column sums of dz [z > 0] and
+// dz [z > 0] xhat over disjoint row sets (crb_conv3x3_winograd2_bnbwd_nhwc) -> dbeta, dgamma by the ordered slab reduction + ticket
+// finalize of crb_bn_relu_forward_partials, then the apply pass of crb_bn_relu_backward
+extern "C" int crb_bn_relu_backward_partials(const float* x, const float* dz, int64_t dz_row_stride, int64_t n, int C,
+                                             const float* slab_sums, int64_t n_slabs, const float* mean, const float* invstd,
+                                             const float* gamma, const float* beta, int relu, float* dx, float* dgamma, float* dbeta,
+                                             void* workspace, int64_t workspace_bytes, int32_t* tickets, void* stream) {
+  if (n <= 0 || C <= 0 || (C & 3) || C > 1024 || (256 % (C >> 2) && (C >> 2) < 256) || !slab_sums || n_slabs <= 0) return CRB_ERR_ARG;
+  if (workspace_bytes < crb_bn_workspace_bytes(n, C) - 256 || !workspace) return CRB_ERR_WORKSPACE;
+  const int64_t ld_dz = dz_row_stride > 0 ? dz_row_stride : C;
+  if (ld_dz < C || (ld_dz & 3)) return CRB_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)(n_slabs < bn_blocks(n) ? n_slabs : bn_blocks(n));
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL(bn_slab_partial_kernel, dim3(nblk), dim3(256), 0, st, slab_sums, n_slabs, C, partial,
+                     bn_final(tickets, workspace, n, C, 1, dbeta, dgamma, nullptr, nullptr, nullptr, 0.f, 0.f));
+  if (!tickets)
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(crb_cdiv(C, 8)), dim3(256), 0, st, partial, nblk, C, n, 0.f, 1, dbeta, dgamma,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f);
+  const int64_t total4 = n * C / 4;
+  if (dx)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(crb_cdiv(total4, 256)), dim3(256), 0, st, x, dz, mean, invstd, gamma, beta,
+                       dbeta, dgamma, dx, total4, C, 1.0f / (float)n, relu, ld_dz, (g_bn_order >> 1) & 1);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+#endif
+
 // training BatchNorm + ReLU over all groups*ns rows, then max over each group of ns consecutive rows.
 // zmax (groups, out_row_stride >= C) may be a column slice of a wider buffer; arg (groups, C) = first row of the group
 // attaining the max. workspace: crb_bn_workspace_bytes(groups * ns, C).

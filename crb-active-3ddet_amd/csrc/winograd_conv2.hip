@@ -45,7 +45,6 @@
 // The kernel below is the round-4 kernel; round 5 changed its host side only (per-device launch state, atomic launch sequence,
 // reservation honoured by full-size launches only and clamped to half of the CUs, BatchNorm-apply instances removed).
 #include <atomic>
-#include <type_traits>
 #include "crb_common.h"
 #include "../../include/crb_hip.h"
 
@@ -159,6 +158,11 @@ struct Wino2Args {
   float* stats;        // null, or (2 * spatial blocks, 2, Cout): per (spatial block, half of its 64 tiles) the column sums of y and y^2
                        // over the outputs inside the map - the slab sums crb_bn_relu_forward_partials takes (training: the following
                        // BatchNorm's statistics pass over y disappears)
+  // BNB instances (input-gradient launches whose output dz is the gradient w.r.t. relu(batchnorm(bn_y))): a.stats receives the slab sums
+  // of dz [z > 0] and dz [z > 0] xhat instead of those of y and y^2 - the BatchNorm backward's reduction pass (bn_partial_kernel<true>,
+  // same expressions) rides in this epilogue; bn_y (N,H,W,Cout) is the BatchNorm's input, the four vectors its saved statistics / affine
+  const float* bn_y; const float* bn_mean; const float* bn_invstd; const float* bn_gamma; const float* bn_beta;
+  int bn_relu;
   const float* affine; // AFFINE instances: (Cin, 2) = per input channel (scale, shift): the kernel convolves relu(scale * x + shift)
   int N, H, W, cin, cout, relu;
   int th, tw;          // tile rows per image rounded UP TO EVEN (a wave's two tile rows never straddle two images; the phantom
@@ -212,7 +216,7 @@ __device__ __forceinline__ void unit_next(UnitPos& u, const Wino2Args& a) {
 // memory), zero outside the map like any padded input: applied by the input transform to the 16 values it reads, times a 0 / 1
 // mask of the patch positions inside the map. The 8 (scale, shift) pairs of a chunk travel in four of the eight junk slots of the
 // wave's second raw DMA instruction: no extra instruction, no extra counter to wait for.
-template <int MODE, bool AFFINE = false>
+template <int MODE, bool AFFINE = false, bool BNB = false>
 __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const Vb = lds;
@@ -412,16 +416,39 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   //      the wave's block, 4 consecutive output channels; then the accumulators start the next unit at zero
   UnitPos eu = first;
   int ec = 0;
-  auto unit_epilogue = [&]() {
+  auto unit_epilogue = [&]() __attribute__((always_inline)) {
     const int k = eu.cb * WG_K + wk * 16 + 4 * kq;
     f32x4 bias = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (a.bias) {
+    if (!BNB && a.bias) {
       const float* bp = a.bias + eu.cb * WG_K + __builtin_amdgcn_readfirstlane(wk) * 16;
       const f32x4 b0 = sload4(bp), b1 = sload4(bp + 4), b2 = sload4(bp + 8), b3 = sload4(bp + 12);
 #pragma unroll
       for (int e = 0; e < 4; ++e) bias[e] = kq == 0 ? b0[e] : kq == 1 ? b1[e] : kq == 2 ? b2[e] : b3[e];
     }
     f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = (f32x4){0.f, 0.f, 0.f, 0.f};     // a.stats: this lane's sums over its 8 outputs
+    f32x4 bmu, bis, bga, bbe, bv[2][4];
+    if constexpr (BNB) {
+      // the BatchNorm's input at this lane's 8 output positions: requested before the output transform, used after its stores
+      bmu = *reinterpret_cast<const f32x4*>(a.bn_mean + k); bis = *reinterpret_cast<const f32x4*>(a.bn_invstd + k);
+      bga = *reinterpret_cast<const f32x4*>(a.bn_gamma + k); bbe = *reinterpret_cast<const f32x4*>(a.bn_beta + k);
+#pragma unroll
+      for (int tbk = 0; tbk < 2; ++tbk) {
+        const int tile = wt * 32 + tbk * 16 + l15;
+        const int Rg = eu.R0 + (tile >> 2);
+        const int tx = eu.bc * TB_COLS + (tile & 3);
+        int n2, ty2;
+        row_of(eu, tile >> 2, n2, ty2);
+        const int oy = 2 * ty2, ox = 2 * tx;
+        const bool in = Rg < a.RT && tx < a.tw && oy < a.H;
+        const bool x1 = ox + 1 < a.W, y1 = oy + 1 < a.H;
+        const float* yp = a.bn_y + (((int64_t)n2 * a.H + oy) * a.W + ox) * a.cout + k;
+        const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bv[tbk][0] = in ? *reinterpret_cast<const f32x4*>(yp) : zero4;
+        bv[tbk][1] = (in && x1) ? *reinterpret_cast<const f32x4*>(yp + a.cout) : zero4;
+        bv[tbk][2] = (in && y1) ? *reinterpret_cast<const f32x4*>(yp + (int64_t)a.W * a.cout) : zero4;
+        bv[tbk][3] = (in && x1 && y1) ? *reinterpret_cast<const f32x4*>(yp + (int64_t)a.W * a.cout + a.cout) : zero4;
+      }
+    }
 #pragma unroll
     for (int tbk = 0; tbk < 2; ++tbk) {
       const int tile = wt * 32 + tbk * 16 + l15;
@@ -452,7 +479,24 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
         if (x1) *reinterpret_cast<f32x4*>(yo + a.cout) = y01;
         if (y1) *reinterpret_cast<f32x4*>(yo + (int64_t)a.W * a.cout) = y10;
         if (x1 && y1) *reinterpret_cast<f32x4*>(yo + (int64_t)a.W * a.cout + a.cout) = y11;
-        if (a.stats) {                                                // fixed order: (0,0), (0,1), (1,0), (1,1) of tile block 0, then 1
+        if constexpr (BNB) {
+          // BatchNorm backward sums of the positions just written, bn_partial_kernel<true>'s expressions: xhat = (y - mean) invstd,
+          // d = dz [gamma xhat + beta > 0], sums of d and d xhat; positions outside the map contribute nothing
+          const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+          const f32x4 v00 = bv[tbk][0], v01 = bv[tbk][1], v10 = bv[tbk][2], v11 = bv[tbk][3];
+          auto term = [&](const f32x4 v, f32x4 d, bool in) __attribute__((always_inline)) {
+            const f32x4 xh = (v - bmu) * bis;
+            if (a.bn_relu) {
+              const f32x4 z = bga * xh + bbe;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) d[e] = z[e] > 0.f ? d[e] : 0.f;
+            }
+            if (!in) d = zero4;
+            s1 = s1 + d;
+            s2 = s2 + d * xh;
+          };
+          term(v00, y00, true); term(v01, y01, x1); term(v10, y10, y1); term(v11, y11, x1 && y1);
+        } else if (a.stats) {                                         // fixed order: (0,0), (0,1), (1,0), (1,1) of tile block 0, then 1
           const float m01 = x1 ? 1.f : 0.f, m10 = y1 ? 1.f : 0.f, m11 = (x1 && y1) ? 1.f : 0.f;
           s1 = s1 + y00; s2 = s2 + y00 * y00;
           s1 = s1 + y01 * m01; s2 = s2 + (y01 * y01) * m01;
@@ -729,12 +773,19 @@ int device_cus(int* dev_out) {
 }
 }  // namespace
 
+struct Wino2Bnb { const float* y; const float* mean; const float* invstd; const float* gamma; const float* beta; int relu; };
+
 static int winograd2_launch(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout, const float* bias,
-                            int relu, void* stream, float* stats = nullptr) {
+                            int relu, void* stream, float* stats = nullptr, const Wino2Bnb* bnb = nullptr) {
   if (N <= 0 || H <= 0 || W <= 0) return CRB_ERR_ARG;
   if (!crb_winograd2_supported(cin, cout, H, W)) return CRB_ERR_UNSUPPORTED;
   Wino2Args a;
   a.x = x; a.U = U; a.y = y; a.bias = bias; a.affine = nullptr; a.stats = stats;
+  a.bn_y = a.bn_mean = a.bn_invstd = a.bn_gamma = a.bn_beta = nullptr; a.bn_relu = 0;
+  if (bnb) {
+    a.bn_y = bnb->y; a.bn_mean = bnb->mean; a.bn_invstd = bnb->invstd; a.bn_gamma = bnb->gamma; a.bn_beta = bnb->beta;
+    a.bn_relu = bnb->relu;
+  }
   a.N = N; a.H = H; a.W = W; a.cin = cin; a.cout = cout; a.relu = relu;
   a.th = (((H + 1) / 2) + 1) & ~1; a.tw = (W + 1) / 2;
   const int64_t rt = (int64_t)N * a.th;
@@ -763,6 +814,15 @@ static int winograd2_launch(const float* x, const float* U, float* y, int N, int
   if (mode == 11) kern = winograd2_kernel<11>;
   if (mode == 12) kern = winograd2_kernel<12>;
   if (mode == 13) kern = winograd2_kernel<13>;
+#endif
+#ifdef CRB_MEASURE
+  if (bnb) {
+    if (mode != 0) return CRB_ERR_UNSUPPORTED;
+    kern = winograd2_kernel<0, false, true>;
+    mode = 14;                                                // (attribute bit of this instance)
+  }
+#else
+  if (bnb) return CRB_ERR_UNSUPPORTED;                        // (the BNB instance lives in the measurement library only)
 #endif
   int dev = 0;
   const int n_cu = device_cus(&dev);
@@ -798,6 +858,22 @@ extern "C" int64_t crb_winograd2_stats_slabs(int N, int H, int W) {
   const int64_t th = (((H + 1) / 2) + 1) & ~1, tw4 = ((W + 1) / 2 + TB_COLS - 1) / TB_COLS;
   return 2 * ((N * th + TB_ROWS - 1) / TB_ROWS) * tw4;
 }
+
+#ifdef CRB_MEASURE
+// VERDICT r04 item 6a, measured (tools/time_wino_bnbwd.py, profiles/r05_time_wino_bnbwd.txt) and NOT adopted: the epilogue costs +52 us
+// per 128-channel launch at 16 x 200 x 176 (the reduction pass it replaces: 105 us, the slab reduction 16 us: net 38 us) and +85 us per
+// 256-channel launch at 100 x 88 (reduction pass 55 us: a loss) - with the matrix pipe idle, every epilogue instruction is serial time.
+// input-gradient launch whose output dz is the gradient w.r.t. relu(batchnorm(bn_y)) of the previous layer: besides dz it writes the
+// slab sums (crb_winograd2_stats_slabs, 2, Cout) of dz [z > 0] and dz [z > 0] xhat -> crb_bn_relu_backward_partials(bn_y, dz, ...):
+// that BatchNorm's backward launches no reduction pass over (bn_y, dz)
+extern "C" int crb_conv3x3_winograd2_bnbwd_nhwc(const float* x, const float* U, float* y, float* stats, int N, int H, int W, int cin,
+                                                int cout, const float* bn_y, const float* mean, const float* invstd, const float* gamma,
+                                                const float* beta, int relu, void* stream) {
+  if (!stats || !bn_y || !mean || !invstd || !gamma || !beta) return CRB_ERR_ARG;
+  const Wino2Bnb b{bn_y, mean, invstd, gamma, beta, relu ? 1 : 0};
+  return winograd2_launch(x, U, y, N, H, W, cin, cout, nullptr, 0, stream, stats, &b);
+}
+#endif
 
 extern "C" int crb_conv3x3_winograd2_stats_nhwc(const float* x, const float* U, float* y, float* stats, int N, int H, int W, int cin,
                                                 int cout, void* stream) {

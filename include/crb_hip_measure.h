@@ -99,6 +99,23 @@ int crb_probe_lds_dma(const float* src, int64_t pieces, int stride_bytes, int pa
  * rows summed); 2 = three (cmask / cbase -> packed -> rows: the compact table's chain). y (n,16). */
 int crb_probe_gather_chain(int variant, const float* x, int64_t n, const uint32_t* cmask, const int32_t* cbase,
                            const int32_t* packed, const int32_t* ell, float* y, void* stream);
+/* VERDICT r04 item 6a, measured and NOT adopted (profiles/r05_time_wino_bnbwd.txt, tools/time_wino_bnbwd.py): the BatchNorm
+ * backward's reduction pass inside the Winograd input-gradient kernel's epilogue. */
+/* the input-gradient launch of layer L+1 when its output dz is the gradient w.r.t. relu(batchnorm_L(bn_y)): the same kernel with an
+ * epilogue that also writes the slab sums (crb_winograd2_stats_slabs, 2, Cout) of dz [z > 0] and dz [z > 0] xhat (xhat = (bn_y - mean)
+ * invstd, z = gamma xhat + beta; relu = 0: no mask) -> crb_bn_relu_backward_partials: the reduction pass of that BatchNorm's backward
+ * over (bn_y, dz) is not launched (base_bev_backbone.py:31-41 in training; autograd's native_batch_norm_backward in the reference).
+ * x = dy of layer L+1, U = its input-gradient weight image, y = dz (N,H,W,Cout), bn_y (N,H,W,Cout). */
+int crb_conv3x3_winograd2_bnbwd_nhwc(const float* x, const float* U, float* y, float* stats, int N, int H, int W, int cin, int cout,
+                                     const float* bn_y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                     int relu, void* stream);
+/* crb_bn_relu_backward with the reduction done by the producer of dz: slab_sums (n_slabs, 2, C) = column sums of dz [z > 0] and
+ * dz [z > 0] xhat over disjoint sets of rows that cover all n (crb_conv3x3_winograd2_bnbwd_nhwc) */
+int crb_bn_relu_backward_partials(const float* x, const float* dz, int64_t dz_row_stride, int64_t n, int C, const float* slab_sums,
+                                  int64_t n_slabs, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                  int relu, float* dx, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
+                                  int32_t* tickets, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
