@@ -75,9 +75,55 @@ def transform_weights2(g):
     return U
 
 
+# images made ahead by prepare_weights2 (one launch for all layers of a step): key -> image. A key names the weight's memory, its
+# autograd version (an optimizer step bumps it) and the mode: a stale image cannot be returned
+_PREPARED = {}
+PREPARE = __import__('os').environ.get('CRB_WINOGRAD_PREPARE', '1') == '1'
+
+
+def _prep_key(w, mode):
+    return (w.data_ptr(), w._version, tuple(w.shape), tuple(w.stride()), w.device.index, int(mode))
+
+
+def prepare_weights2(weights, input_grad=True):
+    """the forward (and input-gradient) images of all `weights` (nn.Conv2d weights (Cout,Cin,3,3) f32 on one device) in ONE launch
+    (crb_winograd2_weights_conv_multi) instead of one ~10 us launch per image; weights_forward2 / weights_input_grad2 of the same
+    tensors (same memory, same version) then return the prepared images"""
+    import ctypes
+    _PREPARED.clear()
+    jobs = []
+    for w in weights:
+        if not (PREPARE and w.is_cuda and w.dtype == torch.float32 and w.dim() == 4 and w.shape[2:] == (3, 3)):
+            continue
+        for mode in ((0, 1) if input_grad else (0,)):
+            cout, cin = w.shape[0], w.shape[1]
+            if lib.crb_winograd2_supported(int(cout if mode else cin), int(cin if mode else cout), 5, 1):
+                jobs.append((w.detach(), mode))
+    for lo in range(0, len(jobs), 32):
+        part = jobs[lo:lo + 32]
+        n = len(part)
+        Us = [torch.empty((16 * w.shape[0] * w.shape[1],), dtype=torch.float32, device=w.device) for w, _ in part]
+        wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w, _ in part])
+        up = (ctypes.c_void_p * n)(*[u.data_ptr() for u in Us])
+        st = (ctypes.c_int64 * (4 * n))(*[v for w, _ in part for v in w.stride()])
+        ci = (ctypes.c_int32 * n)(*[w.shape[1] for w, _ in part])
+        co = (ctypes.c_int32 * n)(*[w.shape[0] for w, _ in part])
+        md = (ctypes.c_int32 * n)(*[m for _, m in part])
+        check(lib.crb_winograd2_weights_conv_multi(n, wp, st, up, ci, co, md, cur_stream(part[0][0].device)),
+              'crb_winograd2_weights_conv_multi')
+        for (w, mode), U in zip(part, Us):
+            U.wino2_shape = (w.shape[0], w.shape[1]) if mode else (w.shape[1], w.shape[0])
+            _PREPARED[_prep_key(w, mode)] = U
+    return len(jobs)
+
+
 def _weights_conv2(weight, mode):
     """nn.Conv2d weight (Cout,Cin,3,3), any strides -> image of the forward (mode 0) / input-gradient (mode 1) convolution"""
     require_cuda(weight)
+    if _PREPARED:
+        hit = _PREPARED.get(_prep_key(weight, mode))
+        if hit is not None:
+            return hit
     w = weight.detach()
     if w.dtype != torch.float32:
         w = w.float()

@@ -118,10 +118,8 @@ __global__ __launch_bounds__(256) void winograd2_weights_kernel(const float* __r
 // the same image straight from an nn.Conv2d weight (Cout,Cin,3,3) with arbitrary element strides (contiguous or channels_last):
 // mode 0 = forward (kernel input channels = Cin), mode 1 = input gradient: the convolution dy -> dx has the flipped, transposed
 // weights g'[ky][kx][co][ci] = w[co][ci][2-ky][2-kx] (kernel input channels = Cout, output channels = Cin)
-__global__ __launch_bounds__(256) void winograd2_weights_conv_kernel(const float* __restrict__ w, int64_t so, int64_t si,
-                                                                     int64_t sky, int64_t skx, float* __restrict__ U,
-                                                                     int kin, int kout, int mode) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void weights_conv_one(const float* __restrict__ w, int64_t so, int64_t si, int64_t sky, int64_t skx,
+                                                 float* __restrict__ U, int kin, int kout, int mode, int64_t t) {
   if (t >= (int64_t)kin * kout) return;
   const int ci = (int)(t / kout), co = (int)(t - (int64_t)ci * kout);      // kernel-side input / output channel
   float g[3][3];
@@ -148,6 +146,25 @@ __global__ __launch_bounds__(256) void winograd2_weights_conv_kernel(const float
     dst[img_index(r * 4 + 2, col, ci & 7)] = 0.5f * (tmp[r][0] - tmp[r][1] + tmp[r][2]);
     dst[img_index(r * 4 + 3, col, ci & 7)] = tmp[r][2];
   }
+}
+
+__global__ __launch_bounds__(256) void winograd2_weights_conv_kernel(const float* __restrict__ w, int64_t so, int64_t si,
+                                                                     int64_t sky, int64_t skx, float* __restrict__ U,
+                                                                     int kin, int kout, int mode) {
+  weights_conv_one(w, so, si, sky, skx, U, kin, kout, mode, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+// the images of MANY layers in one launch (a training step of the BEV backbone transforms 22 weight tensors, ~10 us per launch each
+// for 0.6 - 2.4 MB of output: launch-bound). Block b belongs to the job whose block range holds it.
+constexpr int WJ_MAX = 32;
+struct Wino2WJob { const float* w; float* U; int64_t so, si, sky, skx; int kin, kout, mode, first_block; };
+struct Wino2WJobs { int n; Wino2WJob job[WJ_MAX]; };
+
+__global__ __launch_bounds__(256) void winograd2_weights_conv_multi_kernel(Wino2WJobs jobs) {
+  int j = 0;
+  while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.job[j + 1].first_block) ++j;       // (wave-uniform, <= 31 steps)
+  const Wino2WJob& q = jobs.job[j];
+  weights_conv_one(q.w, q.so, q.si, q.sky, q.skx, q.U, q.kin, q.kout, q.mode, (int64_t)(blockIdx.x - q.first_block) * 256 + threadIdx.x);
 }
 
 struct Wino2Args {
@@ -748,6 +765,29 @@ extern "C" int crb_winograd2_weights_conv(const float* w, int64_t so, int64_t si
   const int64_t per = (int64_t)kin * kout;
   hipLaunchKernelGGL(winograd2_weights_conv_kernel, dim3(crb_cdiv(per, 256)), dim3(256), 0, (hipStream_t)stream, w, so, si, sky, skx,
                      U, kin, kout, mode ? 1 : 0);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+// n weight tensors in one launch: w[j] (Cout_j, Cin_j, 3, 3) with element strides strides[4 j .. 4 j + 3] = (so, si, sky, skx), U[j] its
+// image for mode[j] (0 forward, 1 input gradient). n <= 32.
+extern "C" int crb_winograd2_weights_conv_multi(int n, const float* const* w, const int64_t* strides, float* const* U,
+                                                const int32_t* conv_cin, const int32_t* conv_cout, const int32_t* mode, void* stream) {
+  if (n < 0 || n > WJ_MAX || (n > 0 && (!w || !strides || !U || !conv_cin || !conv_cout || !mode))) return CRB_ERR_ARG;
+  if (n == 0) return CRB_OK;
+  Wino2WJobs jobs;
+  jobs.n = n;
+  int64_t blocks = 0;
+  for (int j = 0; j < n; ++j) {
+    const int kin = mode[j] ? conv_cout[j] : conv_cin[j], kout = mode[j] ? conv_cin[j] : conv_cout[j];
+    if (!w[j] || !U[j]) return CRB_ERR_ARG;
+    if (!crb_winograd2_supported(kin, kout, 5, 1)) return CRB_ERR_UNSUPPORTED;
+    jobs.job[j] = Wino2WJob{w[j], U[j], strides[4 * j], strides[4 * j + 1], strides[4 * j + 2], strides[4 * j + 3], kin, kout,
+                            mode[j] ? 1 : 0, (int)blocks};
+    blocks += crb_cdiv((int64_t)kin * kout, 256);
+    if (blocks >= (1LL << 30)) return CRB_ERR_ARG;
+  }
+  hipLaunchKernelGGL(winograd2_weights_conv_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, jobs);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

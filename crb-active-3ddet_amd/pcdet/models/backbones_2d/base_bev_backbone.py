@@ -258,6 +258,13 @@ class BaseBEVBackbone(nn.Module):
             return data_dict
         run = self._run_rows_train if (ROWS_TRAIN and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last)) \
             else (lambda seq, t: seq(t))
+        if run == self._run_rows_train and torch.is_grad_enabled():
+            # the Winograd weight images of all stride-1 3x3 layers of this step (forward + input gradient) in one launch
+            from crbhip import winograd
+            if winograd.PREPARE:
+                winograd.prepare_weights2([m.weight for blk in self.blocks for m in blk
+                                           if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1)
+                                           and m.weight.is_cuda])
         fuse_cat = ROWS_TRAIN and x.is_cuda and self._can_fuse_concat(x)
         pre = []                                         # deblock conv outputs awaiting their joint BN+ReLU+concat
         for i, blk in enumerate(self.blocks):

@@ -685,6 +685,11 @@ int crb_winograd2_weights(const float* g, float* U, int cin, int cout, void* str
  * flipped, transposed weights: Cout -> Cin) */
 int crb_winograd2_weights_conv(const float* w, int64_t so, int64_t si, int64_t sky, int64_t skx, float* U, int conv_cin,
                                int conv_cout, int mode, void* stream);
+/* the same for n <= 32 weight tensors in ONE launch (the 11 stride-1 layers of the BEV backbone need 22 images per training step, each
+ * launch-bound at ~10 us): w[j] (Cout_j, Cin_j, 3, 3) with element strides strides[4 j .. 4 j + 3], U[j] its image for mode[j].
+ * w, U, conv_cin, conv_cout, mode, strides are HOST arrays. */
+int crb_winograd2_weights_conv_multi(int n, const float* const* w, const int64_t* strides, float* const* U, const int32_t* conv_cin,
+                                     const int32_t* conv_cout, const int32_t* mode, void* stream);
 int crb_conv3x3_winograd2_nhwc(const float* x, const float* U, float* y, int N, int H, int W, int cin, int cout,
                                const float* bias, int relu, void* stream);
 /* training forward that also hands the following BatchNorm its statistics: stats (crb_winograd2_stats_slabs(N,H,W), 2, Cout) f32 =

@@ -327,3 +327,25 @@ def test_results_do_not_depend_on_the_cu_reservation(dev, shape):
     finally:
         check(lib.crb_cu_reservation(0, cur_stream(dev)), 'crb_cu_reservation')
     assert torch.equal(winograd.conv3x3(x, w), ref)
+
+
+def test_prepared_weight_images_equal_the_single_launches(dev):
+    """crb_winograd2_weights_conv_multi (all layers of a step in one launch) against one crb_winograd2_weights_conv per image:
+    bit-equal, contiguous and channels_last weights, 128 / 256 channel pairs; the prepared image is handed out only for the same
+    memory at the same autograd version"""
+    from crbhip import winograd
+    torch.manual_seed(3)
+    ws = [torch.randn(co, ci, 3, 3, device=dev) for co, ci in ((128, 256), (128, 128), (256, 128), (256, 256), (64, 64))]
+    ws[1] = ws[1].contiguous(memory_format=torch.channels_last)
+    ws += [torch.randn(128, 128, 3, 3, device=dev) for _ in range(14)]              # 19 tensors x 2 modes: two launches of <= 32 jobs
+    winograd._PREPARED.clear()
+    single = [(winograd.weights_forward2(w), winograd.weights_input_grad2(w)) for w in ws]
+    assert winograd.prepare_weights2(ws) == 2 * len(ws)
+    for w, (uf, ug) in zip(ws, single):
+        pf, pg = winograd.weights_forward2(w), winograd.weights_input_grad2(w)
+        assert pf is winograd._PREPARED[winograd._prep_key(w, 0)] and pg is winograd._PREPARED[winograd._prep_key(w, 1)]
+        assert torch.equal(pf, uf) and torch.equal(pg, ug) and pf.wino2_shape == uf.wino2_shape and pg.wino2_shape == ug.wino2_shape
+    ws[0].add_(1.0)                                                                  # an optimizer step: new version, no stale image
+    fresh = winograd.weights_forward2(ws[0])
+    assert fresh is not winograd._PREPARED.get(winograd._prep_key(ws[0], 0)) and not torch.equal(fresh, single[0][0])
+    winograd._PREPARED.clear()
