@@ -584,6 +584,78 @@ def _conv_wgrad_raw(x, dy, pairs, K, kind='wgrad'):
     return dw
 
 
+# weight layouts made ahead for all layers of a step (crb_sparse_weights_multi): parameter key -> (w_kio, w_dgrad, flip), and the same
+# record under w_kio's address for the backward. Keys carry the parameter's autograd version: no stale layout is handed out.
+_PREP_W = {}
+_PREP_WD = {}
+PREPARE_WEIGHTS = __import__('os').environ.get('CRB_SPARSE_PREPARE', '1') == '1'
+
+
+def _wkey(w):
+    return (w.data_ptr(), w._version, tuple(w.shape), w.device.index)
+
+
+def prepare_weights(convs):
+    """convs: spconv layers (weight (Cout, k.., Cin) contiguous f32, .subm) -> their (K,Cin,Cout) forward operands and (K,Cout,Cin)
+    input-gradient operands in ONE launch instead of three launch-bound launches per layer; weight_kio / SparseConvFunction.backward
+    pick them up"""
+    import ctypes
+    _PREP_W.clear()
+    _PREP_WD.clear()
+    jobs = [c for c in convs if PREPARE_WEIGHTS and c.weight.is_cuda and c.weight.dtype == torch.float32 and c.weight.is_contiguous()]
+    for lo in range(0, len(jobs), 32):
+        part = jobs[lo:lo + 32]
+        n = len(part)
+        dims = []
+        for c in part:
+            w = c.weight
+            cout, cin = int(w.shape[0]), int(w.shape[-1])
+            dims.append((w.numel() // (cout * cin), cin, cout))
+        kio = [torch.empty(d, dtype=torch.float32, device=c.weight.device) for c, d in zip(part, dims)]
+        wd = [torch.empty((d[0], d[2], d[1]), dtype=torch.float32, device=c.weight.device) for c, d in zip(part, dims)]
+        A = lambda t, v: (t * n)(*v)
+        check(lib.crb_sparse_weights_multi(n, A(ctypes.c_void_p, [c.weight.data_ptr() for c in part]), A(ctypes.c_int32, [d[0] for d in dims]),
+                                           A(ctypes.c_int32, [d[1] for d in dims]), A(ctypes.c_int32, [d[2] for d in dims]),
+                                           A(ctypes.c_int32, [int(bool(c.subm)) for c in part]),
+                                           A(ctypes.c_void_p, [t.data_ptr() for t in kio]), A(ctypes.c_void_p, [t.data_ptr() for t in wd]),
+                                           cur_stream(part[0].weight.device)), 'crb_sparse_weights_multi')
+        for c, a, b in zip(part, kio, wd):
+            # (the record keeps the parameter's storage alive: while it exists no other tensor can sit at that address, so address +
+            #  version + shape name THIS parameter's values and nothing else)
+            rec = (a, b, bool(c.subm), c.weight.detach())
+            _PREP_W[_wkey(c.weight)] = rec
+            _PREP_WD[a.data_ptr()] = rec
+    return len(jobs)
+
+
+class _WeightKIO(torch.autograd.Function):
+    """(Cout, k.., Cin) parameter -> (K, Cin, Cout) contiguous forward operand; the prepared copy when there is one"""
+
+    @staticmethod
+    def forward(ctx, weight, K):
+        ctx.wshape = weight.shape
+        hit = _PREP_W.get(_wkey(weight)) if _PREP_W else None
+        if hit is not None:
+            return hit[0]
+        return weight.reshape(weight.shape[0], K, weight.shape[-1]).permute(1, 2, 0).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.permute(2, 0, 1).reshape(ctx.wshape), None
+
+
+def weight_kio(weight, K):
+    return _WeightKIO.apply(weight, K)
+
+
+def _dgrad_weights(w, subm):
+    """W[o]^T (at K-1-o for submanifold layers) of a (K,Cin,Cout) forward operand: prepared or formed here"""
+    hit = _PREP_WD.get(w.data_ptr()) if _PREP_WD else None
+    if hit is not None and hit[0].data_ptr() == w.data_ptr() and hit[0].shape == w.shape and hit[2] == bool(subm):
+        return hit[1]
+    return (w.flip(0) if subm else w).transpose(1, 2).contiguous()
+
+
 class SparseConvFunction(torch.autograd.Function):
     """y = sum_o x[nbr[:,o]] @ w[o]   (w in (K,Cin,Cout) layout; `inverse` runs the transposed rulebook)"""
 
@@ -611,11 +683,11 @@ class SparseConvFunction(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if rb.subm:
-                wd = w.flip(0).transpose(1, 2).contiguous()      # Wd[o] = W[K-1-o]^T
+                wd = _dgrad_weights(w, True)                     # Wd[o] = W[K-1-o]^T
                 dx = _conv_forward_raw(dy, wd, rb.table_for('nbr', wd.shape[1], wd.shape[2], ar), rb.n_in, 'subm_dgrad',
                                        arithmetic=ar)
             else:
-                wd = w.transpose(1, 2).contiguous()
+                wd = _dgrad_weights(w, False)
                 table, n_in = (rb.table_for('nbr', wd.shape[1], wd.shape[2], ar), rb.n_out) if inverse else \
                     (rb.table_for('nbr_t', wd.shape[1], wd.shape[2], ar), rb.n_in)
                 dx = _conv_forward_raw(dy, wd, table, n_in, 'spconv_dgrad', arithmetic=ar)

@@ -113,8 +113,16 @@ def prepare_weights2(weights, input_grad=True):
               'crb_winograd2_weights_conv_multi')
         for (w, mode), U in zip(part, Us):
             U.wino2_shape = (w.shape[0], w.shape[1]) if mode else (w.shape[1], w.shape[0])
+            U._crb_src = w              # (keeps the weight's storage alive: no other tensor can take the key's address meanwhile)
             _PREPARED[_prep_key(w, mode)] = U
     return len(jobs)
+
+
+def forget_prepared_forward():
+    """the forward images were for the pass that prepared them; the input-gradient images stay for its backward (autograd refuses a
+    backward whose saved weight changed version)"""
+    for k in [k for k in _PREPARED if k[-1] == 0]:
+        del _PREPARED[k]
 
 
 def _weights_conv2(weight, mode):

@@ -2010,3 +2010,46 @@ extern "C" int crb_sparse_conv_wgrad(const float* X, const float* dY, const int3
 #undef X_
   return CRB_ERR_UNSUPPORTED;
 }
+
+// ---- weight layouts of all layers of a step in one launch -----------------------------------------------------------------------
+// spconv keeps a layer's weight as (Cout, K, Cin) (the checkpoint layout); the gather-GEMM multiplies by W[o] (Cin, Cout) forward and
+// by W[o]^T (flipped over o for submanifold layers) in the input gradient. Per layer that is a permuted copy forward and a flip + a
+// transposed copy backward: three launch-bound launches of < 0.5 MB each, 31 per SECOND step. One launch writes all of them.
+namespace {
+constexpr int SWJ_MAX = 32;
+struct SparseWJob { const float* w; float* kio; float* wd; int K, cin, cout, flip, first_block; };
+struct SparseWJobs { int n; SparseWJob job[SWJ_MAX]; };
+
+__global__ __launch_bounds__(256) void sparse_weights_multi_kernel(SparseWJobs jobs) {
+  int j = 0;
+  while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.job[j + 1].first_block) ++j;
+  const SparseWJob& q = jobs.job[j];
+  const int64_t t = (int64_t)(blockIdx.x - q.first_block) * 256 + threadIdx.x;      // index into kio: ((k, i), o)
+  const int64_t total = (int64_t)q.K * q.cin * q.cout;
+  if (t >= total) return;
+  const int o = (int)(t % q.cout);
+  const int i = (int)((t / q.cout) % q.cin);
+  const int k = (int)(t / ((int64_t)q.cout * q.cin));
+  const float v = q.w[((int64_t)o * q.K + k) * q.cin + i];
+  q.kio[t] = v;                                                                     // W[k][i][o]
+  if (q.wd) q.wd[((int64_t)(q.flip ? q.K - 1 - k : k) * q.cout + o) * q.cin + i] = v;   // Wd[k'][o][i] = W[k][i][o], k' = K-1-k if flip
+}
+}  // namespace
+
+extern "C" int crb_sparse_weights_multi(int n, const float* const* w, const int32_t* K, const int32_t* cin, const int32_t* cout,
+                                        const int32_t* flip, float* const* w_kio, float* const* w_dgrad, void* stream) {
+  if (n < 0 || n > SWJ_MAX || (n > 0 && (!w || !K || !cin || !cout || !flip || !w_kio || !w_dgrad))) return CRB_ERR_ARG;
+  if (n == 0) return CRB_OK;
+  SparseWJobs jobs;
+  jobs.n = n;
+  int64_t blocks = 0;
+  for (int j = 0; j < n; ++j) {
+    if (!w[j] || !w_kio[j] || K[j] <= 0 || cin[j] <= 0 || cout[j] <= 0) return CRB_ERR_ARG;
+    jobs.job[j] = SparseWJob{w[j], w_kio[j], w_dgrad[j], K[j], cin[j], cout[j], flip[j] ? 1 : 0, (int)blocks};
+    blocks += crb_cdiv((int64_t)K[j] * cin[j] * cout[j], 256);
+    if (blocks >= (1LL << 30)) return CRB_ERR_ARG;
+  }
+  hipLaunchKernelGGL(sparse_weights_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, jobs);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}

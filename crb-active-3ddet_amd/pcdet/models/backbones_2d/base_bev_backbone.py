@@ -287,4 +287,7 @@ class BaseBEVBackbone(nn.Module):
         if len(self.deblocks) > len(self.blocks):
             x = self.deblocks[-1](x)
         data_dict['spatial_features_2d'] = x
+        if x.is_cuda:
+            from crbhip import winograd
+            winograd.forget_prepared_forward()
         return data_dict

@@ -2,6 +2,7 @@
 kernels. Module / parameter names match the reference so its checkpoints load unchanged."""
 from functools import partial
 
+import torch
 import torch.nn as nn
 
 from ...utils.spconv_utils import replace_feature, spconv
@@ -102,12 +103,20 @@ class _Backbone8xBase(nn.Module):
             if n_dev is not None:
                 from .vfe.mean_vfe import finish_lazy_voxels
                 finish_lazy_voxels(batch_dict, x.indices.shape[0])
+        if torch.is_grad_enabled() and x.features.is_cuda:
+            # forward and input-gradient weight layouts of every sparse layer of this step in one launch
+            from crbhip import sparse as _sp
+            if _sp.PREPARE_WEIGHTS:
+                _sp.prepare_weights([m for m in self.modules() if isinstance(m, spconv.SparseConvolution) and not m.conv1x1])
         x = self.conv_input(x)
         x1 = self.conv1(x)
         x2 = self.conv2(x1)
         x3 = self.conv3(x2)
         x4 = self.conv4(x3)
         out = self.conv_out(x4)
+        if torch.is_grad_enabled() and x.features.is_cuda:
+            from crbhip import sparse as _sp
+            _sp._PREP_W.clear()          # the forward operands were for THIS pass (the backward finds its operands by their own address)
         return self._finish(batch_dict, out, (x1, x2, x3, x4))
 
 

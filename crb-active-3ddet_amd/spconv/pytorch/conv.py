@@ -81,6 +81,8 @@ class SparseConvolution(SparseModule):
         K = 1
         for k in self.kernel_size:
             K *= k
+        if w.is_cuda:
+            return _sp.weight_kio(w, K)          # (the copy made ahead for all layers of the step, when there is one)
         return w.reshape(self.out_channels, K, self.in_channels).permute(1, 2, 0).contiguous()
 
     def forward(self, input, epilogue=None):

@@ -193,6 +193,12 @@ int crb_sparse_conv_forward_compact_bn(const float* X, const float* W, const uin
                                        const float* running_mean, const float* running_var, float eps, int relu,
                                        void* stream);
 
+/* the weight layouts of n <= 32 layers in one launch: w[j] = a spconv layer's parameter (Cout_j, K_j, Cin_j) contiguous (spconv 2.x
+ * checkpoint layout, spconv/pytorch/conv.py) -> w_kio[j] (K, Cin, Cout) = the forward operand W[o] of crb_sparse_conv_forward*, and
+ * w_dgrad[j] (K, Cout, Cin) (NULL = not wanted) = the input gradient's operand: W[o]^T, at K-1-o when flip[j] (submanifold layers).
+ * Replaces a permuted copy per layer forward and a flip + transposed copy per layer backward. Host arrays of pointers / ints. */
+int crb_sparse_weights_multi(int n, const float* const* w, const int32_t* K, const int32_t* cin, const int32_t* cout,
+                             const int32_t* flip, float* const* w_kio, float* const* w_dgrad, void* stream);
 int crb_sparse_conv_forward(const float* X, const float* W, const int32_t* nbr, const int32_t* perm, float* Y,
                             int64_t n_out, int K, int cin, int cout, void* stream);
 /* dW (K,cin,cout) = sum over pairs X[pin]^T dY[pout] */

@@ -897,3 +897,42 @@ def test_2d_sparse_convs_match_the_oracle_on_a_one_slice_volume(dev, strided):
     _close(conv.bias.grad.cpu().numpy(), dY.sum(0), rtol=2e-4)
     d = y.dense()
     assert d.shape == (2, 32) + tuple(y.spatial_shape)
+
+
+def test_prepared_weight_layouts_equal_the_per_layer_copies(dev):
+    """crb_sparse_weights_multi (forward and input-gradient operands of all layers of a step in one launch) against the per-layer
+    permute / flip / transpose copies: bit-equal, submanifold and strided layers, kernel sizes 3 and (3,1,1), 40 layers = two launches;
+    an updated parameter (new autograd version) is not served from the prepared set"""
+    import spconv.pytorch as spconv
+    from crbhip import sparse as S
+    torch.manual_seed(5)
+    convs = [spconv.SubMConv3d(4, 16, 3, bias=False, indice_key='a'), spconv.SubMConv3d(16, 16, 3, bias=False, indice_key='a'),
+             spconv.SparseConv3d(16, 32, 3, stride=2, padding=1, bias=False, indice_key='b'),
+             spconv.SparseConv3d(64, 128, (3, 1, 1), stride=(2, 1, 1), bias=False, indice_key='c')]
+    convs += [spconv.SubMConv3d(32, 32, 3, bias=False, indice_key='d%d' % k) for k in range(36)]
+    convs = [c.to(dev) for c in convs]
+    S._PREP_W.clear()
+    S._PREP_WD.clear()
+    plain = []
+    for c in convs:
+        K = c.weight.numel() // (c.out_channels * c.in_channels)
+        kio = c.weight.detach().reshape(c.out_channels, K, c.in_channels).permute(1, 2, 0).contiguous()
+        plain.append((kio, (kio.flip(0) if c.subm else kio).transpose(1, 2).contiguous()))
+    assert S.prepare_weights(convs) == len(convs)
+    for c, (kio, wd) in zip(convs, plain):
+        got = c.weight_kio()
+        assert got.data_ptr() == S._PREP_W[S._wkey(c.weight)][0].data_ptr() and torch.equal(got, kio)
+        assert torch.equal(S._dgrad_weights(got.detach(), c.subm), wd)
+        assert S._dgrad_weights(got.detach(), not c.subm).data_ptr() != S._PREP_WD[got.data_ptr()][1].data_ptr()
+    # gradient of the layout op: the (K,Cin,Cout) gradient back in the parameter's layout
+    g = torch.randn_like(plain[2][0])
+    w = convs[2].weight
+    w.grad = None
+    convs[2].weight_kio().backward(g)
+    assert torch.equal(w.grad, g.permute(2, 0, 1).reshape(w.shape))
+    with torch.no_grad():
+        convs[0].weight.add_(1.0)
+    fresh = convs[0].weight_kio()
+    assert S._wkey(convs[0].weight) not in S._PREP_W and not torch.equal(fresh, plain[0][0])
+    S._PREP_W.clear()
+    S._PREP_WD.clear()

@@ -345,6 +345,18 @@ def test_prepared_weight_images_equal_the_single_launches(dev):
         pf, pg = winograd.weights_forward2(w), winograd.weights_input_grad2(w)
         assert pf is winograd._PREPARED[winograd._prep_key(w, 0)] and pg is winograd._PREPARED[winograd._prep_key(w, 1)]
         assert torch.equal(pf, uf) and torch.equal(pg, ug) and pf.wino2_shape == uf.wino2_shape and pg.wino2_shape == ug.wino2_shape
+    # a weight that is freed while its image is still in the prepared set: a NEW tensor of the same shape must not be served the old
+    # image (the set keeps the source alive, so the allocator cannot hand its address out again) - found by a stage-2 test that
+    # failed only in the full suite order
+    old = torch.randn(128, 128, 3, 3, device=dev)
+    winograd.prepare_weights2([old])
+    old_img = winograd.weights_forward2(old).clone()
+    del old
+    new = torch.randn(128, 128, 3, 3, device=dev)
+    img = winograd.weights_forward2(new)
+    winograd._PREPARED.clear()
+    assert torch.equal(img, winograd.weights_forward2(new)) and not torch.equal(img, old_img)
+    winograd.prepare_weights2(ws)
     ws[0].add_(1.0)                                                                  # an optimizer step: new version, no stale image
     fresh = winograd.weights_forward2(ws[0])
     assert fresh is not winograd._PREPARED.get(winograd._prep_key(ws[0], 0)) and not torch.equal(fresh, single[0][0])
