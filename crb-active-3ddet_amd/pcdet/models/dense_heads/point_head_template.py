@@ -8,6 +8,36 @@ from ...ops.roiaware_pool3d import roiaware_pool3d_utils
 from ...utils import loss_utils
 
 
+# point labels and the focal classification loss (+ gradient) as HIP launches (csrc/point_head.hip); CRB_POINT_HEAD_FUSED=0 = the torch
+# expressions below (A/B, and what the kernels are tested against)
+FUSED = __import__('os').environ.get('CRB_POINT_HEAD_FUSED', '1') == '1'
+
+
+class _PointFocalLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, preds, labels, alpha, gamma, weight):
+        from crbhip import lib, check, ptr, cur_stream
+        p = preds.contiguous().float()
+        n, C = p.shape
+        buf = torch.empty((3,), dtype=torch.float32, device=p.device)
+        d = torch.empty_like(p)
+        check(lib.crb_point_focal_loss(ptr(p), ptr(labels.contiguous()), n, C, alpha, gamma, weight, ptr(buf), ptr(d), cur_stream(p.device)),
+              'crb_point_focal_loss')
+        ctx.save_for_backward(d)
+        ctx.pshape = preds.shape
+        pos = buf[1]
+        ctx.mark_non_differentiable(pos)
+        ctx.set_materialize_grads(False)
+        return buf[2], pos
+
+    @staticmethod
+    def backward(ctx, g, _gp):
+        if g is None:
+            return None, None, None, None, None
+        (d,) = ctx.saved_tensors
+        return (d * g).view(ctx.pshape), None, None, None, None
+
+
 class PointHeadTemplate(nn.Module):
     def __init__(self, model_cfg, num_class):
         super().__init__()
@@ -49,6 +79,16 @@ class PointHeadTemplate(nn.Module):
         if points.shape[0] != M * B:
             raise NotImplementedError('ragged keypoint counts: pad to a dense (B,M,3) tensor first')
         pts = points[:, 1:4].reshape(B, M, 3).contiguous()
+        if FUSED and pts.is_cuda and gt_boxes.shape[1] > 0:
+            # the label arithmetic behind the two point-in-box queries as one launch (csrc/point_head.hip)
+            from crbhip import lib, check, ptr, cur_stream
+            inner = roiaware_pool3d_utils.points_in_boxes_gpu(pts, gt_boxes[:, :, 0:7].contiguous())
+            outer = roiaware_pool3d_utils.points_in_boxes_gpu(pts, extend_gt_boxes[:, :, 0:7].contiguous())
+            labels = torch.empty((B * M,), dtype=torch.int64, device=pts.device)
+            gt = gt_boxes.contiguous().float()
+            check(lib.crb_point_labels(ptr(inner), ptr(outer), ptr(gt), B, M, int(gt.shape[1]), int(gt.shape[2]), int(self.num_class),
+                                       ptr(labels), cur_stream(pts.device)), 'crb_point_labels')
+            return {'point_cls_labels': labels, 'point_box_labels': None, 'point_part_labels': None}
         inner = roiaware_pool3d_utils.points_in_boxes_gpu(pts, gt_boxes[:, :, 0:7].contiguous()).long().view(-1)
         outer = roiaware_pool3d_utils.points_in_boxes_gpu(pts, extend_gt_boxes[:, :, 0:7].contiguous()).view(-1)
         fg = inner >= 0
@@ -65,6 +105,14 @@ class PointHeadTemplate(nn.Module):
     def get_cls_layer_loss(self, tb_dict=None, reduce=True):
         labels = self.forward_ret_dict['point_cls_labels'].view(-1)
         preds = self.forward_ret_dict['point_cls_preds'].view(-1, self.num_class)
+        if FUSED and reduce and preds.is_cuda and type(self.cls_loss_func).__name__ == 'SigmoidFocalClassificationLoss' and \
+                labels.dtype == torch.int64:
+            # focal loss + its gradient as one launch (csrc/point_head.hip)
+            loss, pos = _PointFocalLoss.apply(preds, labels, float(self.cls_loss_func.alpha), float(self.cls_loss_func.gamma),
+                                              float(self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS['point_cls_weight']))
+            tb_dict = {} if tb_dict is None else tb_dict
+            tb_dict.update({'point_loss_cls': loss.detach(), 'point_pos_num': pos})
+            return loss, tb_dict
         positives = labels > 0
         cls_weights = ((labels == 0) * 1.0 + 1.0 * positives).float()
         pos_normalizer = positives.sum(dim=0).float()

@@ -616,6 +616,22 @@ int crb_proposal_finish(const int32_t* keep, const int64_t* top_idx, const float
                         float* roi_scores, int64_t* roi_labels, float* full_cls_scores, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * a20  point head in training (csrc/point_head.hip)
+ * crb_point_labels replaces the label arithmetic of PointHeadTemplate.assign_stack_targets behind its two points_in_boxes_gpu calls
+ *   (pcdet/models/dense_heads/point_head_template.py:49-129, set_ignore_flag mode of PointHeadSimple): inner / outer (B*M) i32 = first
+ *   containing ground truth / enlarged ground truth of every point or -1, gt_boxes (B,G,gt_row_stride >= 8, class last)
+ *   -> labels (B*M) i64: the box's class (1 when num_class == 1) inside a box, -1 in the enlarged shell only, 0 elsewhere.
+ * crb_point_focal_loss replaces PointHeadTemplate.get_cls_layer_loss with SigmoidFocalClassificationLoss (:131-155,
+ *   pcdet/utils/loss_utils.py:9-72) and its autograd: preds (n, num_class) logits, labels (n) i64 -> loss[3] = {point_loss_cls
+ *   (x loss_weight, normalised by max(positives, 1)), positives, point_loss_cls again (the scalar a caller differentiates)},
+ *   d_preds (n, num_class) = d loss / d preds. One workgroup, sums in a fixed order.
+ * ---------------------------------------------------------------------------------------------- */
+int crb_point_labels(const int32_t* inner, const int32_t* outer, const float* gt_boxes, int B, int64_t M, int G, int gt_row_stride,
+                     int num_class, int64_t* labels, void* stream);
+int crb_point_focal_loss(const float* preds, const int64_t* labels, int64_t n, int num_class, float alpha, float gamma,
+                         float loss_weight, float* loss, float* d_preds, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a22 / a24  second-stage losses and the canonical transformation of the sampled ground truths (csrc/rcnn_loss.hip)
  * replaces: RoIHeadTemplate.get_box_cls_layer_loss (BinaryCrossEntropy; pcdet/models/roi_heads/roi_head_template.py:261-285),
  *           get_box_reg_layer_loss (smooth-l1 + CORNER_LOSS_REGULARIZATION, the branch without reg_sample_targets; :142-259) with

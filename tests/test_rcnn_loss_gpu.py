@@ -247,3 +247,62 @@ def test_roi_sampling_falls_back_outside_its_limits(dev):
     bd = _sampler_case(dev, 2, 64, 3, seed=4, mode='mixed')
     layer.injected_indices = torch.zeros((2, 128), dtype=torch.long, device=dev)
     assert layer.forward_fused(bd) is None
+
+
+@pytest.mark.parametrize('num_class,B,M,mode', [(1, 16, 2048, 'mixed'), (3, 2, 333, 'mixed'), (1, 2, 2048, 'no_positive'), (3, 1, 1, 'mixed')])
+def test_point_head_labels_and_focal_loss_equal_the_torch_expressions(dev, num_class, B, M, mode):
+    """csrc/point_head.hip against the mirror's torch expressions (point_head_template.py assign_stack_targets / get_cls_layer_loss):
+    labels EQUAL; loss 2e-6, positives equal, gradient 2e-5 of its largest entry; bit-equal re-run; class-agnostic and three-class heads,
+    a batch without any point inside a box, saturated logits"""
+    import copy
+    from pcdet.model_cfgs import pv_rcnn_cfg
+    from pcdet.models.dense_heads import point_head_template as PT
+    from pcdet.models.dense_heads.point_head_simple import PointHeadSimple
+    cfg = copy.deepcopy(pv_rcnn_cfg().MODEL.POINT_HEAD)
+    cfg.LOSS_CONFIG.LOSS_WEIGHTS['point_cls_weight'] = 0.7
+    head = PointHeadSimple(num_class=num_class, input_channels=32, model_cfg=cfg).to(dev).train()
+    rng = np.random.default_rng(B * 100 + M)
+    G = 7
+    gt = np.zeros((B, G, 8), np.float32)
+    for b in range(B):
+        ng = int(rng.integers(1, G + 1))
+        gt[b, :ng] = np.concatenate([rng.uniform(-20, 20, (ng, 2)), rng.uniform(-1.5, 0, (ng, 1)), rng.uniform(1.5, 4.5, (ng, 3)),
+                                     rng.uniform(-3, 3, (ng, 1)), rng.integers(1, 4, (ng, 1))], 1)
+    pts = np.zeros((B, M, 4), np.float32)
+    for b in range(B):
+        pts[b, :, 0] = b
+        ng = int((gt[b, :, 3] > 0).sum())
+        k = rng.integers(0, ng, M)
+        spread = {'mixed': 0.75, 'no_positive': 0.0}[mode]
+        pts[b, :, 1:4] = gt[b, k, 0:3] + rng.uniform(-1, 1, (M, 3)) * gt[b, k, 3:6] * spread
+        if mode == 'no_positive':
+            pts[b, :, 1:3] += 100.0
+    batch = {'gt_boxes': torch.from_numpy(gt).to(dev), 'point_coords': torch.from_numpy(pts.reshape(-1, 4)).to(dev)}
+    preds = torch.from_numpy(rng.normal(0, 2, (B * M, num_class)).astype(np.float32)).to(dev)
+    preds[::7] = 40.0
+    preds[1::7] = -40.0
+    out = []
+    keep = PT.FUSED
+    try:
+        for fused in (True, False, True):
+            PT.FUSED = fused
+            labels = head.assign_targets(batch)['point_cls_labels']
+            p = preds.clone().requires_grad_(True)
+            head.forward_ret_dict = {'point_cls_preds': p, 'point_cls_labels': labels}
+            loss, tb = head.get_loss()
+            (loss * 1.3).backward()
+            out.append((labels, loss.detach(), tb['point_pos_num'].detach().clone(), tb['point_loss_cls'].clone(), p.grad))
+    finally:
+        PT.FUSED = keep
+    f, t, f2 = out
+    assert f[0].dtype == t[0].dtype == torch.int64 and torch.equal(f[0], t[0])
+    if mode == 'mixed' and M > 1:
+        assert int((t[0] > 0).sum()) > 0 and int((t[0] == 0).sum()) > 0
+        assert num_class == 1 or int(t[0].max()) > 1
+    if mode == 'no_positive':
+        assert int((t[0] > 0).sum()) == 0
+    torch.testing.assert_close(f[1], t[1], rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(f[3], t[3], rtol=2e-6, atol=1e-7)
+    assert float(f[2]) == float(t[2])
+    assert f[4].shape == t[4].shape and float((f[4] - t[4]).abs().max()) <= 2e-5 * max(float(t[4].abs().max()), 1e-9)
+    assert torch.equal(f[1], f2[1]) and torch.equal(f[4], f2[4])

@@ -75,9 +75,9 @@ def main():
         for meth in ('proposal_layer', 'assign_targets', 'roi_grid_pool', 'get_global_grid_points_of_roi', 'get_loss'):
             if hasattr(rh, meth):
                 scope_method(rh, meth, 'roi_head.' + meth)
-        ptl = rh.proposal_target_layer
-        for meth in ('sample_rois_for_rcnn', 'subsample_rois_batched', 'max_iou_with_same_class_batched'):
-            scope_method(ptl, meth, 'roi_head.target_layer.' + meth)
+        # (the target layer's sampling methods are not wrapped: an instance with replaced sampling methods keeps the torch layer,
+        #  proposal_target_layer.forward_fused - the listing would show launches the product path does not make)
+        scope_method(rh.proposal_target_layer, 'forward', 'roi_head.target_layer.forward')
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
         step()
         torch.cuda.synchronize()
