@@ -411,3 +411,38 @@ extern "C" int crb_roi_canonical_targets(const float* rois, int roi_row_stride, 
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
+
+// ---- grid points of the RoI-grid pooling (PVRCNNHead.get_global_grid_points_of_roi / get_dense_grid_points, pvrcnn_head.py:116-141):
+//      G^3 points per RoI, ((i + 0.5) / G) * size - size / 2 per axis (index order x slowest, z fastest), turned by the RoI's heading
+//      about z, moved to its centre. ~17 torch launches as one.
+namespace {
+__global__ __launch_bounds__(256) void roi_grid_points_kernel(const float* __restrict__ rois, int roi_c, int64_t n, int G,
+                                                              float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int g3 = G * G * G;
+  if (t >= n * g3) return;
+  const int64_t r = t / g3;
+  const int q = (int)(t - r * g3);
+  const int ix = q / (G * G), iy = (q / G) % G, iz = q % G;
+  const float* b = rois + r * roi_c;
+  const float gf = (float)G;
+  const float lx = ((float)ix + 0.5f) / gf * b[3] - b[3] / 2.f;
+  const float ly = ((float)iy + 0.5f) / gf * b[4] - b[4] / 2.f;
+  const float lz = ((float)iz + 0.5f) / gf * b[5] - b[5] / 2.f;
+  const float c = cosf(b[6]), s = sinf(b[6]);
+  out[t * 3 + 0] = lx * c - ly * s + b[0];
+  out[t * 3 + 1] = lx * s + ly * c + b[1];
+  out[t * 3 + 2] = lz + b[2];
+}
+}  // namespace
+
+extern "C" int crb_roi_grid_points(const float* rois, int roi_row_stride, int64_t n, int grid_size, float* out, void* stream) {
+  if (n < 0 || roi_row_stride < 7 || grid_size <= 0 || grid_size > 64 || n * grid_size * grid_size * grid_size >= (1LL << 40)) return CRB_ERR_ARG;
+  if (n == 0) return CRB_OK;
+  if (!rois || !out) return CRB_ERR_ARG;
+  const int64_t total = n * grid_size * grid_size * grid_size;
+  hipLaunchKernelGGL(roi_grid_points_kernel, dim3(crb_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, rois, roi_row_stride, n,
+                     grid_size, out);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}

@@ -23,6 +23,10 @@ def _gc_order(c, g3):
     return _GC_ORDER[key]
 
 
+# grid points of the RoI-grid pooling as one launch; CRB_ROI_GRID_POINTS_FUSED=0 = the torch expressions (A/B, test reference)
+FUSED_GRID_POINTS = __import__('os').environ.get('CRB_ROI_GRID_POINTS_FUSED', '1') == '1'
+
+
 class PVRCNNHead(RoIHeadTemplate):
     def __init__(self, input_channels, model_cfg, num_class=1, **kwargs):
         super().__init__(num_class=num_class, model_cfg=model_cfg)
@@ -80,6 +84,13 @@ class PVRCNNHead(RoIHeadTemplate):
     def get_global_grid_points_of_roi(self, rois, grid_size):
         rois = rois.view(-1, rois.shape[-1])
         n = rois.shape[0]
+        if FUSED_GRID_POINTS and rois.is_cuda and not rois.requires_grad:
+            # one launch (csrc/rcnn_loss.hip crb_roi_grid_points); the local points are not formed (no caller reads them)
+            from crbhip import lib, check, ptr, cur_stream
+            r = rois.detach().contiguous().float()
+            glob = torch.empty((n, grid_size ** 3, 3), dtype=torch.float32, device=r.device)
+            check(lib.crb_roi_grid_points(ptr(r), int(r.shape[1]), n, int(grid_size), ptr(glob), cur_stream(r.device)), 'crb_roi_grid_points')
+            return glob, None
         local = self.get_dense_grid_points(rois, n, grid_size)
         glob = common_utils.rotate_points_along_z(local.clone(), rois[:, 6]).squeeze(dim=1)
         glob = glob + rois[:, 0:3].unsqueeze(dim=1)

@@ -660,6 +660,10 @@ int crb_rcnn_loss(const float* rcnn_cls, const float* rcnn_reg, const void* cls_
                   float* reg_targets, void* stream);
 int crb_roi_canonical_targets(const float* rois, int roi_row_stride, const float* gt_of_rois, int gt_row_stride, int64_t n,
                               float* out, void* stream);
+/* grid points of the RoI-grid pooling (PVRCNNHead.get_global_grid_points_of_roi + get_dense_grid_points, pvrcnn_head.py:116-141):
+ * rois (n, roi_row_stride >= 7) -> out (n, grid_size^3, 3): ((i + 0.5) / G) * size - size / 2 per axis (x slowest, z fastest), turned by
+ * the heading about z, moved to the centre. */
+int crb_roi_grid_points(const float* rois, int roi_row_stride, int64_t n, int grid_size, float* out, void* stream);
 /* RoI sampling for the second stage: one workgroup per frame (csrc/rcnn_loss.hip)
  * replaces: ProposalTargetLayer.forward / sample_rois_for_rcnn / subsample_rois / get_max_iou_with_same_class
  *           (pcdet/models/roi_heads/target_assigner/proposal_target_layer.py:15-228): per frame the (same-class) maximum IoU of every

@@ -306,3 +306,24 @@ def test_point_head_labels_and_focal_loss_equal_the_torch_expressions(dev, num_c
     assert float(f[2]) == float(t[2])
     assert f[4].shape == t[4].shape and float((f[4] - t[4]).abs().max()) <= 2e-5 * max(float(t[4].abs().max()), 1e-9)
     assert torch.equal(f[1], f2[1]) and torch.equal(f[4], f2[4])
+
+
+def test_roi_grid_points_kernel_equals_the_torch_expressions(dev):
+    """crb_roi_grid_points against get_dense_grid_points + rotate_points_along_z + centre (the mirror of pvrcnn_head.py:116-141):
+    1e-6 relative / 4e-6 absolute (one f32 rounding of a 60 m coordinate; the torch path multiplies by a 3x3 matrix), grid sizes 6 and 2,
+    rows wider than 7"""
+    from pcdet.models.roi_heads import pvrcnn_head as PH
+    rng = np.random.default_rng(9)
+    rois = torch.cat([_boxes(rng, 517, dev, centre=60.0), torch.zeros(517, 2, device=dev)], 1).view(11, 47, 9)
+    head = PH.PVRCNNHead.__new__(PH.PVRCNNHead)
+    for G in (6, 2):
+        fused, none = PH.PVRCNNHead.get_global_grid_points_of_roi(head, rois, G)
+        assert none is None
+        keep = PH.FUSED_GRID_POINTS
+        try:
+            PH.FUSED_GRID_POINTS = False
+            plain, _ = PH.PVRCNNHead.get_global_grid_points_of_roi(head, rois, G)
+        finally:
+            PH.FUSED_GRID_POINTS = keep
+        assert fused.shape == plain.shape == (517, G ** 3, 3)
+        torch.testing.assert_close(fused, plain, rtol=1e-6, atol=4e-6)
