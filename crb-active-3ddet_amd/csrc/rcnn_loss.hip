@@ -446,3 +446,133 @@ extern "C" int crb_roi_grid_points(const float* rois, int roi_row_stride, int64_
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
+
+// ---- second-stage box decode (RoIHeadTemplate.generate_predicted_boxes, roi_head_template.py:335-359): residuals against the RoI as
+//      anchor (centre 0, its dims, its heading), the decoded centre turned by the RoI's heading about z and moved to the RoI's centre.
+//      The operations of ResidualCoder.decode_torch / rotate_points_along_z in their order; ~20 torch launches as one.
+namespace {
+__global__ __launch_bounds__(256) void rcnn_decode_kernel(const float* __restrict__ rois, int roi_c, const float* __restrict__ reg, int64_t n,
+                                                          float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* r = rois + i * roi_c;
+  const float* e = reg + i * 7;
+  const float dxa = r[3], dya = r[4], dza = r[5], ra = r[6];
+  const float diag = sqrtf(dxa * dxa + dya * dya);
+  const float xl = e[0] * diag + 0.f, yl = e[1] * diag + 0.f, zl = e[2] * dza + 0.f;
+  const float c = cosf(ra), s = sinf(ra);
+  float* o = out + i * 7;
+  o[0] = xl * c - yl * s + r[0];
+  o[1] = xl * s + yl * c + r[1];
+  o[2] = zl + r[2];
+  o[3] = expf(e[3]) * dxa;
+  o[4] = expf(e[4]) * dya;
+  o[5] = expf(e[5]) * dza;
+  o[6] = e[6] + ra;
+}
+
+// ---- CRB stage-1 records behind the final NMS (crb_frame_records of the mirror = Detector3DTemplate.post_processing's per-frame
+//      selection, detector3d_template.py:190-234, + the label entropy of crb_sampling.py:86-94): gathers of the kept boxes / scores /
+//      labels / logits with zero padding, and the Shannon entropy of the predicted-label histogram. One workgroup per frame.
+constexpr int REC_MAX_CLASS = 16;
+__global__ __launch_bounds__(256) void record_rows_kernel(const int64_t* __restrict__ sel, const uint8_t* __restrict__ valid,
+                                                          const float* __restrict__ boxes, int box_c, const float* __restrict__ conf,
+                                                          const int64_t* __restrict__ labels, const float* __restrict__ full, int nc_full,
+                                                          int N, int P, int num_class, float* __restrict__ o_boxes,
+                                                          float* __restrict__ o_scores, int64_t* __restrict__ o_labels,
+                                                          float* __restrict__ o_logits, float* __restrict__ o_entropy) {
+  __shared__ int cnt[REC_MAX_CLASS];
+  __shared__ int nvalid;
+  const int b = blockIdx.x;
+  if (threadIdx.x < REC_MAX_CLASS) cnt[threadIdx.x] = 0;
+  if (threadIdx.x == 0) nvalid = 0;
+  __syncthreads();
+  for (int j = threadIdx.x; j < P; j += 256) {
+    const int64_t o = (int64_t)b * P + j;
+    const bool v = valid[o] != 0;
+    const float vf = v ? 1.f : 0.f;
+    const int64_t src = (int64_t)b * N + sel[o];
+    for (int k = 0; k < box_c; ++k) o_boxes[o * box_c + k] = boxes[src * box_c + k] * vf;
+    o_scores[o] = conf[src] * vf;
+    const int64_t lab = labels[src] * (v ? 1 : 0);
+    o_labels[o] = lab;
+    if (full)
+      for (int k = 0; k < nc_full; ++k) o_logits[o * nc_full + k] = full[src * nc_full + k] * vf;
+    if (v) {
+      int c = (int)(lab - 1);
+      c = c < 0 ? 0 : c;
+      if (c < num_class) atomicAdd(&cnt[c], 1);
+      atomicAdd(&nvalid, 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // absent classes count as 1; proportions over the number of boxes, renormalised (torch.distributions.Categorical)
+    const float n = (float)nvalid, den = fmaxf(n, 1.f);
+    float props[REC_MAX_CLASS], tot = 0.f;
+    for (int c = 0; c < num_class; ++c) {
+      props[c] = (cnt[c] > 0 ? (float)cnt[c] : 1.f) / den;
+      tot += props[c];
+    }
+    float ent = 0.f;
+    for (int c = 0; c < num_class; ++c) {
+      const float p = props[c] / tot;
+      ent += p * logf(p);
+    }
+    o_entropy[b] = nvalid > 0 ? -ent : 0.f;
+  }
+}
+
+// ---- predicted-box point density: points whose FIRST containing box is k (idx from crb_points_in_boxes) over the box volume
+constexpr int DEN_MAX_P = 2048;
+__global__ __launch_bounds__(1024) void box_density_kernel(const int32_t* __restrict__ idx, const float* __restrict__ boxes, int box_c,
+                                                           const uint8_t* __restrict__ valid, int M, int P, float* __restrict__ density) {
+  __shared__ int cnt[DEN_MAX_P];
+  const int b = blockIdx.x;
+  for (int k = threadIdx.x; k < P; k += 1024) cnt[k] = 0;
+  __syncthreads();
+  for (int m = threadIdx.x; m < M; m += 1024) {
+    const int k = idx[(int64_t)b * M + m];
+    if (k >= 0 && k < P) atomicAdd(&cnt[k], 1);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < P; k += 1024) {
+    const float* bx = boxes + ((int64_t)b * P + k) * box_c;
+    const float vol = bx[3] * bx[4] * bx[5];
+    density[(int64_t)b * P + k] = valid[(int64_t)b * P + k] ? (float)cnt[k] / fmaxf(vol, 1e-12f) : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int crb_rcnn_decode_boxes(const float* rois, int roi_row_stride, const float* box_preds, int64_t n, float* out, void* stream) {
+  if (n < 0 || n >= (1LL << 31) || roi_row_stride < 7) return CRB_ERR_ARG;
+  if (n == 0) return CRB_OK;
+  if (!rois || !box_preds || !out) return CRB_ERR_ARG;
+  hipLaunchKernelGGL(rcnn_decode_kernel, dim3(crb_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, rois, roi_row_stride, box_preds, n, out);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_record_rows(const int64_t* sel, const uint8_t* valid, const float* box_preds, int box_row_stride, const float* cls_confs,
+                               const int64_t* label_preds, const float* full_cls_scores, int full_classes, int B, int N, int P,
+                               int num_class, float* pred_boxes, float* pred_scores, int64_t* pred_labels, float* pred_logits,
+                               float* entropy, void* stream) {
+  if (B <= 0 || N <= 0 || P <= 0 || box_row_stride < 7 || num_class <= 0 || num_class > REC_MAX_CLASS) return CRB_ERR_ARG;
+  if (!sel || !valid || !box_preds || !cls_confs || !label_preds || !pred_boxes || !pred_scores || !pred_labels || !entropy) return CRB_ERR_ARG;
+  if (full_cls_scores && (full_classes <= 0 || !pred_logits)) return CRB_ERR_ARG;
+  hipLaunchKernelGGL(record_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, sel, valid, box_preds, box_row_stride, cls_confs,
+                     label_preds, full_cls_scores, full_classes, N, P, num_class, pred_boxes, pred_scores, pred_labels, pred_logits, entropy);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_box_point_density(const int32_t* first_box, const float* pred_boxes, int box_row_stride, const uint8_t* valid, int B,
+                                     int M, int P, float* density, void* stream) {
+  if (B <= 0 || M < 0 || P <= 0 || box_row_stride < 7) return CRB_ERR_ARG;
+  if (P > DEN_MAX_P) return CRB_ERR_UNSUPPORTED;
+  if ((M > 0 && !first_box) || !pred_boxes || !valid || !density) return CRB_ERR_ARG;
+  hipLaunchKernelGGL(box_density_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, first_box, pred_boxes, box_row_stride, valid, M, P,
+                     density);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}

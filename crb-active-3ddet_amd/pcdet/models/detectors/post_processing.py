@@ -15,6 +15,10 @@ from ...utils import common_utils
 from ...ops.roiaware_pool3d import roiaware_pool3d_utils
 
 
+# the record rows behind the final NMS as two launches (CRB_RECORDS_FUSED=0: the torch expressions, A/B and test reference)
+FUSED_RECORDS = __import__('os').environ.get('CRB_RECORDS_FUSED', '1') == '1'
+
+
 def _frame_points(batch_dict, batch_size):
     """points (N,1+C) frame-sorted -> dense (B,M,3) with far-away padding, counts (B)"""
     pts = batch_dict['points']
@@ -80,6 +84,39 @@ def crb_frame_records(model, batch_dict):
     else:
         label_preds = label_preds + 1
     sel, valid, num = final_nms_batched(cls_confs, box_preds, cfg.NMS_CONFIG, cfg.SCORE_THRESH)
+    num_class = len(model.model_cfg.DENSE_HEAD.ANCHOR_GENERATOR_CONFIG)
+    full = batch_dict.get('full_cls_scores', None)
+    if FUSED_RECORDS and box_preds.is_cuda and not cfg.OUTPUT_RAW_SCORE and num_class <= 16 and sel.shape[1] <= 2048 and \
+            label_preds.dtype == torch.int64:
+        # the gathers of the kept boxes, the label entropy and the point density as two launches (csrc/rcnn_loss.hip)
+        from crbhip import lib, check, ptr, cur_stream
+        dev, P, N = box_preds.device, int(sel.shape[1]), int(box_preds.shape[1])
+        bp, cc, lp = box_preds.contiguous().float(), cls_confs.contiguous().float(), label_preds.contiguous()
+        fc = full.contiguous().float() if full is not None else None
+        vu = valid.contiguous().view(torch.uint8)
+        pred_boxes = torch.empty((B, P, bp.shape[-1]), dtype=torch.float32, device=dev)
+        pred_scores = torch.empty((B, P), dtype=torch.float32, device=dev)
+        pred_labels = torch.empty((B, P), dtype=torch.int64, device=dev)
+        pred_logits = torch.empty((B, P, fc.shape[-1]), dtype=torch.float32, device=dev) if fc is not None else None
+        ent = torch.empty((B,), dtype=torch.float32, device=dev)
+        check(lib.crb_record_rows(ptr(sel.contiguous()), ptr(vu), ptr(bp), int(bp.shape[-1]), ptr(cc), ptr(lp), ptr(fc),
+                                  int(fc.shape[-1]) if fc is not None else 0, B, N, P, num_class, ptr(pred_boxes), ptr(pred_scores),
+                                  ptr(pred_labels), ptr(pred_logits), ptr(ent), cur_stream(dev)), 'crb_record_rows')
+        pts, _ = _frame_points(batch_dict, B)
+        far = pred_boxes.clone()
+        far[..., 0:3] = torch.where(valid[..., None], pred_boxes[..., 0:3], pred_boxes.new_full((), 1e7))
+        idx = roiaware_pool3d_utils.points_in_boxes_gpu(pts, far[..., 0:7].contiguous())               # (B,M) i32
+        density = torch.empty((B, P), dtype=torch.float32, device=dev)
+        check(lib.crb_box_point_density(ptr(idx), ptr(pred_boxes), int(pred_boxes.shape[-1]), ptr(vu), B, int(idx.shape[1]), P,
+                                        ptr(density), cur_stream(dev)), 'crb_box_point_density')
+        rcnn_cls = rcnn_reg = None
+        if 'rcnn_cls' in batch_dict and batch_dict['rcnn_cls'].dim() > 2:
+            rcnn_cls = torch.mean(torch.sigmoid(batch_dict['rcnn_cls']), 0).view(B, -1, 1)
+            rcnn_reg = torch.mean(batch_dict['rcnn_reg'], 0).view(B, -1, 7)
+        gt_stats = gt_point_stats_device(batch_dict, num_class)[0] if 'gt_boxes' in batch_dict else None
+        return {'sel': sel, 'valid': valid, 'num': num, 'pred_boxes': pred_boxes, 'pred_scores': pred_scores,
+                'pred_labels': pred_labels, 'pred_logits': pred_logits, 'density': density, 'entropy': ent,
+                'batch_rcnn_cls': rcnn_cls, 'batch_rcnn_reg': rcnn_reg, 'confidence': cls_preds, 'gt_stats': gt_stats}
     vf = valid[..., None].to(box_preds.dtype)
     pred_boxes = torch.gather(box_preds, 1, sel[..., None].expand(-1, -1, box_preds.shape[-1])) * vf
     pred_scores = torch.gather(cls_confs, 1, sel) * valid.to(cls_confs.dtype)

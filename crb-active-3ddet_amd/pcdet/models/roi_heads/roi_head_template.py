@@ -243,6 +243,15 @@ class RoIHeadTemplate(nn.Module):
         """rois (B,N,7), cls (BN,C), box (BN,code) -> (B,N,C), (B,N,code) in LiDAR coordinates"""
         code_size = self.box_coder.code_size
         batch_cls_preds = cls_preds.view(batch_size, -1, cls_preds.shape[-1])
+        if FUSED_PROPOSAL and box_preds.is_cuda and code_size == 7 and not torch.is_grad_enabled() and \
+                not getattr(self.box_coder, 'encode_angle_by_sincos', False) and box_preds.shape[-1] == 7:
+            from crbhip import lib, check, ptr, cur_stream
+            r = rois.contiguous().float()
+            n = box_preds.numel() // 7
+            out = torch.empty((batch_size, n // batch_size, 7), dtype=torch.float32, device=box_preds.device)
+            check(lib.crb_rcnn_decode_boxes(ptr(r), int(r.shape[-1]), ptr(box_preds.contiguous().float()), n, ptr(out),
+                                            cur_stream(box_preds.device)), 'crb_rcnn_decode_boxes')
+            return batch_cls_preds, out
         local_rois = torch.cat([torch.zeros_like(rois[:, :, 0:3]), rois[:, :, 3:]], dim=-1).detach()
         boxes = self.box_coder.decode_torch(box_preds.view(batch_size, -1, code_size), local_rois).view(-1, code_size)
         boxes = common_utils.rotate_points_along_z(boxes.unsqueeze(1), rois[:, :, 6].reshape(-1)).squeeze(1)

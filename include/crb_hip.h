@@ -664,6 +664,22 @@ int crb_roi_canonical_targets(const float* rois, int roi_row_stride, const float
  * rois (n, roi_row_stride >= 7) -> out (n, grid_size^3, 3): ((i + 0.5) / G) * size - size / 2 per axis (x slowest, z fastest), turned by
  * the heading about z, moved to the centre. */
 int crb_roi_grid_points(const float* rois, int roi_row_stride, int64_t n, int grid_size, float* out, void* stream);
+/* second-stage box decode (RoIHeadTemplate.generate_predicted_boxes, roi_head_template.py:335-359): rois (n, roi_row_stride >= 7),
+ * box_preds (n,7) residuals -> out (n,7) boxes in LiDAR coordinates (ResidualCoder.decode_torch against the RoI as anchor with centre
+ * 0, the centre turned by the RoI's heading and moved to the RoI's centre). */
+int crb_rcnn_decode_boxes(const float* rois, int roi_row_stride, const float* box_preds, int64_t n, float* out, void* stream);
+/* CRB stage-1 records behind the final NMS (Detector3DTemplate.post_processing's per-frame selection, detector3d_template.py:186-234,
+ * and the label entropy of crb_sampling.py:86-94), one workgroup per frame: sel (B,P) i64 indices into the N boxes of the frame, valid
+ * (B,P) u8, box_preds (B,N,box_row_stride), cls_confs (B,N), label_preds (B,N) i64 (1-based), full_cls_scores (B,N,full_classes) or
+ * NULL -> pred_boxes (B,P,box_row_stride), pred_scores (B,P), pred_labels (B,P) i64, pred_logits (B,P,full_classes), all zero where
+ * not valid; entropy (B) = Shannon entropy of the label histogram of the valid boxes, absent classes counted as 1, 0 without boxes.
+ * crb_box_point_density: first_box (B,M) i32 = first containing predicted box of every point (crb_points_in_boxes) -> density (B,P) =
+ * points / max(volume, 1e-12) of the valid boxes, 0 elsewhere (P <= 2048). */
+int crb_record_rows(const int64_t* sel, const uint8_t* valid, const float* box_preds, int box_row_stride, const float* cls_confs,
+                    const int64_t* label_preds, const float* full_cls_scores, int full_classes, int B, int N, int P, int num_class,
+                    float* pred_boxes, float* pred_scores, int64_t* pred_labels, float* pred_logits, float* entropy, void* stream);
+int crb_box_point_density(const int32_t* first_box, const float* pred_boxes, int box_row_stride, const uint8_t* valid, int B, int M, int P,
+                          float* density, void* stream);
 /* RoI sampling for the second stage: one workgroup per frame (csrc/rcnn_loss.hip)
  * replaces: ProposalTargetLayer.forward / sample_rois_for_rcnn / subsample_rois / get_max_iou_with_same_class
  *           (pcdet/models/roi_heads/target_assigner/proposal_target_layer.py:15-228): per frame the (same-class) maximum IoU of every

@@ -59,6 +59,28 @@ def test_eval_records_and_parity(model, dev):
         scores, labels = torch.max(b['rpn_preds'].view(3, -1, 3) if False else None or
                                    model.dense_head.forward_ret_dict['cls_preds'].view(3, -1, 3), dim=2)
         rec = crb_frame_records(model, b)
+        # the fused record rows (crb_record_rows + crb_box_point_density) and the fused second-stage decode (crb_rcnn_decode_boxes)
+        # against the torch expressions they replace, on this batch
+        from pcdet.models.detectors import post_processing as PP
+        from pcdet.models.roi_heads import roi_head_template as RH
+        assert PP.FUSED_RECORDS and RH.FUSED_PROPOSAL
+        try:
+            PP.FUSED_RECORDS = False
+            plain = crb_frame_records(model, b)
+            RH.FUSED_PROPOSAL = False
+            _, boxes_plain = model.roi_head.generate_predicted_boxes(batch_size=3, rois=b['rois'], cls_preds=b['rcnn_cls'][-1],
+                                                                     box_preds=b['rcnn_reg'][-1])
+        finally:
+            PP.FUSED_RECORDS = RH.FUSED_PROPOSAL = True
+        _, boxes_fused = model.roi_head.generate_predicted_boxes(batch_size=3, rois=b['rois'], cls_preds=b['rcnn_cls'][-1],
+                                                                 box_preds=b['rcnn_reg'][-1])
+        torch.testing.assert_close(boxes_fused, boxes_plain, rtol=1e-6, atol=4e-6)
+        assert int(rec['valid'].sum()) > 0
+        for k in ('sel', 'valid', 'num', 'pred_boxes', 'pred_scores', 'pred_labels', 'pred_logits', 'density'):
+            assert (rec[k] is None) == (plain[k] is None), k
+            if rec[k] is not None:
+                assert rec[k].dtype == plain[k].dtype and torch.equal(rec[k], plain[k]), k
+        torch.testing.assert_close(rec['entropy'], plain['entropy'], rtol=1e-6, atol=1e-7)
         pred_dicts, recall = model.post_processing(b)
     assert len(pred_dicts) == 3
     keys = {'confidence', 'rpn_preds', 'num_bbox', 'mean_points', 'median_points', 'variance_points',

@@ -42,6 +42,25 @@ if __name__ == '__main__':
         if name:
             m.register_forward_pre_hook(pre(name))
             m.register_forward_hook(post)
+    # functions outside the modules that launch many small kernels, as scopes of their own (module globals: looked up at call time)
+    def scope_fn(mod, fname, tag):
+        fn = getattr(mod, fname)
+
+        def wrapped(*a, **k):
+            with torch.autograd.profiler.record_function('mod:' + tag):
+                return fn(*a, **k)
+        setattr(mod, fname, wrapped)
+    from pcdet.models.detectors import post_processing as pp
+    from pcdet.query_strategies import scoring as sc
+    for fname in ('final_nms_batched', 'label_entropy', '_first_hit_counts', '_frame_points', 'gt_point_stats_device'):
+        scope_fn(pp, fname, 'records.' + fname)
+    scope_fn(sc, 'pack_records', 'records.pack_records')
+    rh = getattr(model, 'roi_head', None)
+    if rh is not None:
+        for meth in ('proposal_layer', 'roi_grid_pool'):
+            fn = getattr(rh, meth)
+            setattr(rh, meth, (lambda f, t: (lambda *a, **k: (lambda rf: (rf.__enter__(), f(*a, **k), rf.__exit__(None, None, None))[1])(
+                torch.autograd.profiler.record_function('mod:' + t))))(fn, 'roi_head.' + meth))
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         strat.score_device_batches(batches[2:3])
