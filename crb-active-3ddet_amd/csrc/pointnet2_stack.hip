@@ -1579,3 +1579,29 @@ extern "C" int crb_three_interpolate_grad_stack(int64_t N, int C, const float* g
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
+
+// ---- voxel centres (common_utils.get_voxel_centers, pcdet/utils/common_utils.py:63-80): coords (n, 3) [z, y, x] integers with a row
+//      stride (a column slice of the (n, 4) [b, z, y, x] index tensor) -> (n, 3) xyz = (coord + 0.5) * (voxel_size * downsample) + range
+//      minimum, the torch expression's operations in its order. flip + cast + four elementwise launches per VSA level as one.
+namespace {
+__global__ __launch_bounds__(256) void voxel_centers_kernel(const int32_t* __restrict__ coords, int64_t row_stride, int64_t n, float sx,
+                                                            float sy, float sz, float mx, float my, float mz, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int32_t* c = coords + i * row_stride;
+  out[i * 3 + 0] = ((float)c[2] + 0.5f) * sx + mx;
+  out[i * 3 + 1] = ((float)c[1] + 0.5f) * sy + my;
+  out[i * 3 + 2] = ((float)c[0] + 0.5f) * sz + mz;
+}
+}  // namespace
+
+extern "C" int crb_voxel_centers(const int32_t* coords_zyx, int64_t row_stride, int64_t n, const float* scaled_voxel_size,
+                                 const float* range_min, float* out, void* stream) {
+  if (n < 0 || row_stride < 3 || !scaled_voxel_size || !range_min) return CRB_ERR_ARG;
+  if (n == 0) return CRB_OK;
+  if (!coords_zyx || !out) return CRB_ERR_ARG;
+  hipLaunchKernelGGL(voxel_centers_kernel, dim3(crb_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, coords_zyx, row_stride, n,
+                     scaled_voxel_size[0], scaled_voxel_size[1], scaled_voxel_size[2], range_min[0], range_min[1], range_min[2], out);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}

@@ -69,6 +69,18 @@ def mask_points_by_range(points, limit_range):
 def get_voxel_centers(voxel_coords, downsample_times, voxel_size, point_cloud_range):
     """voxel_coords (N,3) [z,y,x] -> centers (N,3) xyz (common_utils.py:63-80)"""
     assert voxel_coords.shape[1] == 3
+    if voxel_coords.is_cuda and voxel_coords.dtype == torch.int32 and voxel_coords.stride(1) == 1:
+        # one launch (crb_voxel_centers) on the column slice itself; the scaled voxel size is the same f32 product as below
+        import ctypes
+        from crbhip import lib, check, ptr, cur_stream
+        n = voxel_coords.shape[0]
+        vs = (np.asarray(voxel_size, dtype=np.float32) * np.float32(downsample_times)).astype(np.float32)
+        lo = np.asarray(point_cloud_range[0:3], dtype=np.float32)
+        out = torch.empty((n, 3), dtype=torch.float32, device=voxel_coords.device)
+        check(lib.crb_voxel_centers(ctypes.c_void_p(voxel_coords.data_ptr()) if n else None, max(3, voxel_coords.stride(0)), n,
+                                    vs.ctypes.data_as(ctypes.c_void_p), lo.ctypes.data_as(ctypes.c_void_p), ptr(out),
+                                    cur_stream(voxel_coords.device)), 'crb_voxel_centers')
+        return out
     centers = voxel_coords.flip(1).float()          # (a python index list would be uploaded per call: a host sync)
     vs = device_constant(voxel_size, centers.device) * downsample_times
     pc_min = device_constant(point_cloud_range[0:3], centers.device)

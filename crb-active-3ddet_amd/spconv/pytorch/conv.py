@@ -81,6 +81,15 @@ class SparseConvolution(SparseModule):
         K = 1
         for k in self.kernel_size:
             K *= k
+        if w.is_cuda and not torch.is_grad_enabled():
+            # inference: the layout is a function of the parameter alone - kept on the module until the parameter changes (address /
+            # autograd version, as fold_conv_bn keys its folded weights): no permuted copy per layer per batch of a scoring pass
+            key = (w.data_ptr(), w._version, tuple(w.shape))
+            hit = self.__dict__.get('_crb_kio')
+            if hit is None or hit[0] != key:
+                hit = self.__dict__['_crb_kio'] = (key, w.detach().reshape(self.out_channels, K, self.in_channels).permute(1, 2, 0)
+                                                   .contiguous())
+            return hit[1]
         if w.is_cuda:
             return _sp.weight_kio(w, K)          # (the copy made ahead for all layers of the step, when there is one)
         return w.reshape(self.out_channels, K, self.in_channels).permute(1, 2, 0).contiguous()

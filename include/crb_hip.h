@@ -421,6 +421,11 @@ int crb_pair_sort_by_source(int B, int64_t M, int nsample, const int32_t* xyz_ba
  * from row to row, n rows, NON-DECREASING (the stacked layout: rows of a frame together, frames in order) -> counts (B) i32.
  * Values outside [0, B) are not counted. One launch, no atomics. */
 int crb_sorted_key_counts(const void* key, int key_is_float, int64_t stride, int64_t n, int B, int32_t* counts, void* stream);
+/* voxel centres (common_utils.get_voxel_centers, pcdet/utils/common_utils.py:63-80): coords_zyx (n rows of 3 i32 [z,y,x], row_stride
+ * elements apart: columns 1..3 of the (n,4) index tensor) -> out (n,3) xyz = (coord + 0.5) * scaled_voxel_size + range_min;
+ * scaled_voxel_size[3] = voxel size x downsample factor (f32 product), range_min[3]: HOST arrays. */
+int crb_voxel_centers(const int32_t* coords_zyx, int64_t row_stride, int64_t n, const float* scaled_voxel_size, const float* range_min,
+                      float* out, void* stream);
 /* xyz (B,n,3) -> out_idx (B,m); first pick is index 0; ties resolved like the reference kernel (see source).
  * temp: (B,n) f32 scratch for the running distances (the reference's `temp` argument); only needed for n > 40960
  * (below that the distances stay in registers) and may be NULL otherwise. */

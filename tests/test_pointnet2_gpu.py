@@ -695,3 +695,20 @@ def test_rows_per_frame_from_the_sorted_frame_column(dev):
     key = torch.tensor([0, 0, 1, 3, 3, 3, 5], dtype=torch.int32, device=dev)
     assert common_utils.batch_counts(key, 4).cpu().tolist() == [2, 1, 0, 3]
     assert common_utils.batch_counts(key, 8).cpu().tolist() == [2, 1, 0, 3, 0, 1, 0, 0]
+
+
+def test_voxel_centers_kernel_equals_the_torch_expression(dev):
+    """crb_voxel_centers on the column slice of an (n,4) index tensor against flip + cast + (c + 0.5) * (voxel_size * stride) + minimum:
+    bit-equal for every level's stride, n = 0, contiguous (n,3) input"""
+    from pcdet.utils import common_utils as CU
+    rng = np.random.default_rng(2)
+    vs, rng_pc = [0.05, 0.05, 0.1], [0, -40, -3, 70.4, 40, 1]
+    for n in (0, 1, 70001):
+        idx = torch.from_numpy(np.concatenate([rng.integers(0, 16, (n, 1)), rng.integers(0, 41, (n, 1)), rng.integers(0, 1600, (n, 1)),
+                                               rng.integers(0, 1408, (n, 1))], 1).astype(np.int32)).to(dev)
+        for times in (1, 2, 4, 8):
+            got = CU.get_voxel_centers(idx[:, 1:4], times, vs, rng_pc)
+            c = idx[:, 1:4].flip(1).float()
+            want = (c + 0.5) * (CU.device_constant(vs, dev) * times) + CU.device_constant(rng_pc[0:3], dev)
+            assert got.shape == (n, 3) and torch.equal(got, want)
+            assert torch.equal(CU.get_voxel_centers(idx[:, 1:4].contiguous(), times, vs, rng_pc), want)
