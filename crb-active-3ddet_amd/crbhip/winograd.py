@@ -169,6 +169,70 @@ def conv3x3_U2(x, U, bias=None, relu=False):
     return y
 
 
+# ---- round 6: the same convolution on the bf16 matrix pipe through an exact three-way split of the f32 operands
+#      (csrc/winograd_conv4.hip, crb_conv3x3_winograd4_nhwc): f32 in, f32 out, errors against f64 at the level of the f32-MFMA kernel
+
+def supported4(cin, cout, H, W):
+    return bool(lib.crb_winograd4_supported(int(cin), int(cout), int(H), int(W)))
+
+
+def _weights_conv4(weight, mode):
+    """nn.Conv2d weight (Cout,Cin,3,3), any strides -> split-bf16 image of the forward (mode 0) / input-gradient (mode 1) convolution"""
+    require_cuda(weight)
+    w = weight.detach()
+    if w.dtype != torch.float32:
+        w = w.float()
+    cout, cin = w.shape[0], w.shape[1]
+    U = torch.empty((int(lib.crb_winograd4_weights_bytes(cin, cout)),), dtype=torch.uint8, device=w.device)
+    so, si, sky, skx = w.stride()
+    check(lib.crb_winograd4_weights_conv(w.data_ptr(), so, si, sky, skx, ptr(U), cin, cout, mode, cur_stream(w.device)),
+          'crb_winograd4_weights_conv')
+    U.wino4_shape = (cout, cin) if mode else (cin, cout)
+    return U
+
+
+def weights_forward4(weight):
+    return _weights_conv4(weight, 0)
+
+
+def weights_input_grad4(weight):
+    return _weights_conv4(weight, 1)
+
+
+def conv3x3_U4(x, U, bias=None, relu=False):
+    """x (N,Cin,H,W) f32 channels_last, U = weights_forward4(...) -> y (N,Cout,H,W) channels_last"""
+    require_cuda(x, U)
+    xv = _nhwc(x.float())
+    N, H, W, cin = xv.shape
+    ucin, cout = U.wino4_shape
+    if ucin != cin or not supported4(cin, cout, H, W):
+        raise CrbHipError('no Winograd (4) instance for %d -> %d channels on a %d x %d map' % (cin, cout, H, W))
+    y = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    e0 = _prof_begin()
+    check(lib.crb_conv3x3_winograd4_nhwc(xv.data_ptr(), ptr(U), y.data_ptr(), N, H, W, cin, cout,
+                                         ptr(bias.contiguous().float()) if bias is not None else None, int(bool(relu)),
+                                         cur_stream(x.device)), 'crb_conv3x3_winograd4_nhwc')
+    _prof_end(e0, 'wino_conv', cin, cout, N, H, W)
+    return y
+
+
+def conv3x3_stats_U4(x, U):
+    """(y, slab sums of y and y^2) of the bias-free convolution (crb_conv3x3_winograd4_stats_nhwc)"""
+    require_cuda(x, U)
+    xv = _nhwc(x.float())
+    N, H, W, cin = xv.shape
+    ucin, cout = U.wino4_shape
+    if ucin != cin or not supported4(cin, cout, H, W):
+        raise CrbHipError('no Winograd (4) instance for %d -> %d channels on a %d x %d map' % (cin, cout, H, W))
+    y = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    stats = torch.empty((int(lib.crb_winograd4_stats_slabs(N, H, W)), 2, cout), dtype=torch.float32, device=x.device)
+    e0 = _prof_begin()
+    check(lib.crb_conv3x3_winograd4_stats_nhwc(xv.data_ptr(), ptr(U), y.data_ptr(), ptr(stats), N, H, W, cin, cout,
+                                               cur_stream(x.device)), 'crb_conv3x3_winograd4_stats_nhwc')
+    _prof_end(e0, 'wino_conv', cin, cout, N, H, W)
+    return y, stats
+
+
 def _nhwc(x):
     """(N,C,H,W) tensor in channels_last memory -> its (N,H,W,C) view (no copy); other layouts are converted"""
     if not x.is_contiguous(memory_format=torch.channels_last):

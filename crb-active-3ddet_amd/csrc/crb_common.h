@@ -260,3 +260,6 @@ static inline int64_t crb_hash_capacity(int64_t n) {
 #else
 #define CRB_KNOB static constexpr int
 #endif
+
+// winograd_conv4.hip: sets ITS copy of the busy-CU word (device variables are per translation unit); crb_cu_reservation calls it
+int crbhip_wino4_cu_busy_set(int cus, hipStream_t stream);

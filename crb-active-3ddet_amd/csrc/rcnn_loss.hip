@@ -262,7 +262,7 @@ __global__ __launch_bounds__(RS_MAX_R) void roi_sample_kernel(RoiSampleArgs a) {
     for (int g = r; g < a.G; g += blockDim.x) {
       const float* row = a.gt + ((int64_t)b * a.G + g) * a.gt_c;
       float sum = 0.f;
-      for (int j = 0; j < a.gt_c - 1; ++j) sum += row[j];
+      for (int j = 0; j < a.gt_c; ++j) sum += row[j];       // the whole row, class label included (proposal_target_layer.py:93)
       if (sum != 0.f) atomicMax(&s_last, g);
     }
   }

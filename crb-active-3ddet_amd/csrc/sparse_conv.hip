@@ -429,11 +429,12 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_fwd2_kernel(const float* _
     auto x2 = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true)); };
     // every exchange is evaluated by ALL lanes before the selects (a DPP read under a lane-dependent branch would see its
     // source lanes switched off)
-    const float p0 = x1(v[0][t]), p1 = x1(v[1][t]), p2 = x1(v[2][t]), p3 = x1(v[3][t]);
+    constexpr int i1 = KS > 1 ? 1 : 0, i2 = KS > 2 ? 2 : 0, i3 = KS > 3 ? 3 : 0;      // (only instantiated paths with KS = 4 call this)
+    const float p0 = x1(v[0][t]), p1 = x1(v[i1][t]), p2 = x1(v[i2][t]), p3 = x1(v[i3][t]);
     const float n0 = odd ? p1 : v[0][t];
-    const float n1 = odd ? v[1][t] : p0;
-    const float n2 = odd ? p3 : v[2][t];
-    const float n3 = odd ? v[3][t] : p2;
+    const float n1 = odd ? v[i1][t] : p0;
+    const float n2 = odd ? p3 : v[i2][t];
+    const float n3 = odd ? v[i3][t] : p2;
     const float q0 = x2(n0), q1 = x2(n1), q2 = x2(n2), q3 = x2(n3);
     m[0] = hi ? q2 : n0;
     m[1] = hi ? q3 : n1;

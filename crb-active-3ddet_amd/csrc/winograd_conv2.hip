@@ -797,7 +797,8 @@ namespace {
 constexpr int MAX_DEV = 64;
 std::atomic<int> g_dev_cus[MAX_DEV];
 std::atomic<unsigned> g_dev_attr[MAX_DEV];                    // bit m: hipFuncSetAttribute done for kernel instance m on this device
-std::atomic<unsigned> g_launch_seq{0};
+std::atomic<unsigned> g_dev_seq[MAX_DEV];                     // launch sequence PER DEVICE: the latch ring (64 slots) lives in that device's memory,
+                                                             // two launches share a slot only if 64 launches to the SAME device lie between them
 
 int device_cus(int* dev_out) {
   int dev = 0;
@@ -876,9 +877,9 @@ static int winograd2_launch(const float* x, const float* U, float* y, int N, int
   a.persistent = g_wino2_persistent;
   const int64_t grid = a.persistent ? (units < n_cu ? units : n_cu) : ((nb + 7) / 8) * 8 * a.ncb;
   // the busy-CU latch (crb_cu_reservation) is for launches that put a workgroup on EVERY CU: a smaller launch leaves CUs free
-  // anyway, and giving up workgroups there would funnel it into a few. The sequence number is process-wide and
+  // anyway, and giving up workgroups there would funnel it into a few. The sequence number is per device and
   // atomic (launches from several host threads / to several devices); slot = seq mod 64 of the device's latch ring.
-  unsigned seq = (g_launch_seq.fetch_add(1, std::memory_order_relaxed) + 1) & 0xffffffu;
+  unsigned seq = (g_dev_seq[dev].fetch_add(1, std::memory_order_relaxed) + 1) & 0xffffffu;
   a.seq = (a.persistent && grid == n_cu) ? (seq ? seq : 1) : 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, (hipStream_t)stream, a);
   CRB_CHECK_LAUNCH();
@@ -931,5 +932,5 @@ extern "C" int crb_cu_reservation(int cus, void* stream) {
   if (n_cu > 0 && cus > n_cu / 2) cus = n_cu / 2;             // at most half of the device is announced as taken
   hipLaunchKernelGGL(cu_busy_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, cus);
   CRB_CHECK_LAUNCH();
-  return CRB_OK;
+  return crbhip_wino4_cu_busy_set(cus, (hipStream_t)stream);
 }

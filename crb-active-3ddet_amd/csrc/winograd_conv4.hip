@@ -1,0 +1,734 @@
+// 3x3 stride-1 pad-1 convolution on channels_last (NHWC) f32 maps as Winograd F(2x2, 3x3) with the 16 GEMMs on the bf16 matrix
+// pipe through an EXACT three-way split of every f32 operand (round 6; row a7 of SURVEY §8: the BEV backbone's 3x3 convolutions,
+// pcdet/models/backbones_2d/base_bev_backbone.py:24-41).
+//
+// Why: on gfx950 the exact-f32 MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2) runs at the f32 VECTOR rate, 1/16 of the bf16 matrix rate.
+// winograd_conv2.hip sits at 0.65 of that roof for two rounds with every ingredient priced at 2-5 %. An f32
+// value is the exact sum of three bf16 values
+//     x = x1 + x2 + x3,  x1 = x & 0xffff0000, x2 = (x - x1) & 0xffff0000, x3 = x - x1 - x2      (both subtractions exact, x3 has
+//                                                                                               <= 8 significant bits: no rounding)
+// and a product of two such sums has nine exact partial products of which the six with i + j <= 4 carry everything above
+// 2^-24 |x w| (the three dropped ones are bounded by 2^-16 * 2^-8 * 2 + 2^-32 < 2^-23 |x w|, the size of ONE f32 rounding of the
+// product): six v_mfma_f32_32x32x16_bf16 passes, f32 accumulation in the matrix pipe, give the f32 GEMM at 16 / 6 = 2.67 x the
+// f32 MFMA rate. Measured against f64 convolutions the results are as close as the f32-MFMA kernel's (tests/test_winograd_gpu.py,
+// tests/test_insitu_gpu.py: same bars). The weights are split once per step by the weight-image kernel; V = B^T d B is split by the
+// lanes that form it (and / subtract / v_perm: no rounding instruction), so the MFMA waves read ready bf16 fragments.
+//
+// With the matrix pipe 2.67 x faster the kernel is bound by LDS traffic and VALU issue, and the design follows from that:
+//   * workgroup = 256 threads = ONE wave per SIMD with up to 512 registers: wave = 32 tiles x 32 output channels x all 16 xi
+//     (256 accumulators), workgroup = 64 tiles (16 tile rows x 4 tile columns of one spatial block, tile rows running over the
+//     whole batch) x 64 output channels. All xi of a tile live in one lane: Y = A^T M A happens in registers, 16-byte stores.
+//   * chunk = 16 input channels = the K of one MFMA; a chunk runs as FOUR phases, one xi row (4 xi) each: per phase and wave 24
+//     MFMAs (768 matrix-pipe cycles) on 12 A + 12 B fragments (ds_read_b128). LDS holds two V phase images (26 KB each, written by
+//     the transform), three U phase images (24 KB each, LDS-DMA two phases ahead) and ONE raw block (24 KB) = 147 KB.
+//   * the raw block is shared by the whole workgroup: 36 pixel rows x 10 pixels x 16 channels (halo rows fetched once; a block
+//     that straddles two images keeps a 2-row gap between them), DMA'd once per chunk right after its last reader and read in ONE
+//     phase: thread (tile, channel quad) reads its 4 x 4 patch (16 ds_read_b128, conflict-free through an even/odd pixel-column
+//     order of the LDS image), does the column pass t = B^T d and keeps t (64 registers) for the four row passes of the next
+//     four phases.
+//   * one barrier per phase: [wait own V stores + the DMA that has to have landed | barrier | DMA of raw(c+1) / U(f+2) | row pass +
+//     split + stores of V(f+1) interleaved with the 24 MFMAs of phase f].
+//   * persistent workgroups (one per CU), contiguous unit ranges, busy-CU latch as in winograd_conv2.hip.
+#include <atomic>
+#include <type_traits>
+#include "crb_common.h"
+#include "../../include/crb_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TB_ROWS = 16, TB_COLS = 4;     // tile block: 16 tile rows x 4 tile columns
+constexpr int WG_K = 64;                     // output channels per workgroup
+constexpr int CC = 16;                       // input channels per chunk
+constexpr int NT = 256;
+// byte sizes of the LDS images
+constexpr int U_XP = 2 * 64 * 16;            // one (xi, piece): [k group 2][row 64][8 bf16] = 2048
+constexpr int U_PHASE = 12 * U_XP;           // 4 xi x 3 pieces = 24576
+constexpr int V_REGION = 64 * 16 + 64;       // [tile 64][8 bf16] + 64 bytes: the two k groups of a b64 store land in different banks
+constexpr int V_XP = 2 * V_REGION;           // 2176
+constexpr int V_PHASE = 12 * V_XP;           // 26112
+constexpr int RAW_ROWS = 36, RAW_PX = 10;
+constexpr int RAW_SLOTS = 6 * NT;            // 1536 slots of 16 bytes (1440 used: 36 rows x 10 pixels x 4 channel quads)
+constexpr int RAW_BYTES = RAW_SLOTS * 16;    // 24576
+constexpr int LDS_V = 0, LDS_U = 2 * V_PHASE, LDS_RAW = LDS_U + 3 * U_PHASE, LDS_BYTES = LDS_RAW + RAW_BYTES;   // 150528
+
+__device__ float g_wino4_zero_page[64];      // source of out-of-map pixels (zero-initialised, never written)
+__device__ int g_cu_busy4 = 0;               // see winograd_conv2.hip (crb_cu_reservation sets both)
+__device__ unsigned g_cu_latch4[64];
+__global__ void cu_busy4_set_kernel(int v) { __hip_atomic_store(&g_cu_busy4, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// exact three-way split: the bf16 bit patterns (high halves) of x1, x2, x3
+__device__ __forceinline__ void split3(float x, unsigned& h1, unsigned& h2, unsigned& h3) {
+  const unsigned b = __float_as_uint(x);
+  const float r1 = x - __uint_as_float(b & 0xffff0000u);
+  const unsigned b1 = __float_as_uint(r1);
+  const float r2 = r1 - __uint_as_float(b1 & 0xffff0000u);
+  h1 = b >> 16;
+  h2 = b1 >> 16;
+  h3 = __float_as_uint(r2) >> 16;
+}
+
+// ---- weight image. Byte offset of (xi = 4 i + jx, piece p, kernel input channel ci, kernel output channel co):
+//      [co / 64][ci / 16][i][jx][p][k group (ci % 16) / 8][row co % 64][element ci % 8] bf16  - a phase image is one linear 24 KB copy
+__device__ __forceinline__ void weights_octet(const float* __restrict__ w, int64_t so, int64_t si, int64_t sky, int64_t skx,
+                                              unsigned char* __restrict__ U, int kin, int kout, int mode, int64_t t) {
+  if (t >= (int64_t)(kin / 8) * kout) return;
+  const int cg = (int)(t / kout), co = (int)(t - (int64_t)cg * kout);     // channel octet, kernel-side output channel
+  u32x4 out[16][3];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ci = cg * 8 + e;
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        g[a][b] = mode == 0 ? w[co * so + ci * si + a * sky + b * skx] : w[ci * so + co * si + (2 - a) * sky + (2 - b) * skx];
+    float tmp[4][3];                 // G g (the expressions of winograd_conv2.hip: the f32 U is the same number)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      tmp[0][b] = g[0][b];
+      tmp[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+      tmp[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+      tmp[3][b] = g[2][b];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float u[4] = {tmp[r][0], 0.5f * (tmp[r][0] + tmp[r][1] + tmp[r][2]), 0.5f * (tmp[r][0] - tmp[r][1] + tmp[r][2]), tmp[r][2]};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        unsigned h[3];
+        split3(u[c], h[0], h[1], h[2]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const unsigned d = out[r * 4 + c][p][e >> 1];
+          out[r * 4 + c][p][e >> 1] = (e & 1) ? (d | (h[p] << 16)) : h[p];
+        }
+      }
+    }
+  }
+  const int nch = kin / CC;
+  const int cb = co / WG_K, row = co - cb * WG_K, chunk = cg >> 1, kg = cg & 1;
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const int64_t off = ((int64_t)(cb * nch + chunk) * 4 + (xi >> 2)) * U_PHASE + (((xi & 3) * 3 + p) * 2 + kg) * (64 * 16) + row * 16;
+      *reinterpret_cast<u32x4*>(U + off) = out[xi][p];
+    }
+}
+
+__global__ __launch_bounds__(256) void winograd4_weights_conv_kernel(const float* __restrict__ w, int64_t so, int64_t si, int64_t sky,
+                                                                     int64_t skx, unsigned char* __restrict__ U, int kin, int kout,
+                                                                     int mode) {
+  weights_octet(w, so, si, sky, skx, U, kin, kout, mode, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+constexpr int WJ_MAX = 32;
+struct Wino4WJob { const float* w; unsigned char* U; int64_t so, si, sky, skx; int kin, kout, mode, first_block; };
+struct Wino4WJobs { int n; Wino4WJob job[WJ_MAX]; };
+
+__global__ __launch_bounds__(256) void winograd4_weights_conv_multi_kernel(Wino4WJobs jobs) {
+  int j = 0;
+  while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.job[j + 1].first_block) ++j;       // (wave-uniform, <= 31 steps)
+  const Wino4WJob& q = jobs.job[j];
+  weights_octet(q.w, q.so, q.si, q.sky, q.skx, q.U, q.kin, q.kout, q.mode, (int64_t)(blockIdx.x - q.first_block) * 256 + threadIdx.x);
+}
+
+struct Wino4Args {
+  const float* x;            // (N,H,W,Cin)
+  const unsigned char* U;    // crb_winograd4_weights_conv image
+  float* y;                  // (N,H,W,Cout)
+  const float* bias;         // (Cout) or null
+  float* stats;              // null, or (2 * spatial blocks, 2, Cout): per (spatial block, half of its 64 tiles) the column sums of y and
+                             // y^2 over the outputs inside the map (crb_bn_relu_forward_partials takes them)
+  int N, H, W, cin, cout, relu;
+  int th, tw;                // tile rows per image = ceil(H / 2), tiles per row = ceil(W / 2)
+  int RT;                    // tile rows over the batch = N * th
+  int tw4;                   // tile-column blocks = ceil(tw / 4)
+  int nblocks;               // spatial blocks = ceil(RT / 16) * tw4
+  int ncb;                   // cout / 64
+  unsigned seq;              // launch sequence number for the busy-CU latch; 0 = ignore g_cu_busy4
+};
+
+template <int AUX = 0>
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
+}
+
+__device__ __forceinline__ f32x4 sload4(const float* p) {
+  f32x4 r;
+  asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+  return r;
+}
+
+struct UnitPos {
+  int cb, bc, R0, n0, ty0;     // channel block, tile-column block, first tile row over the batch = image n0, row ty0 of it
+};
+__device__ __forceinline__ UnitPos unit_at(int u, const Wino4Args& a) {       // units are numbered with the channel block fastest
+  UnitPos p;
+  const int tb = u / a.ncb;
+  p.cb = u - tb * a.ncb;
+  const int br = tb / a.tw4;
+  p.bc = tb - br * a.tw4;
+  p.R0 = br * TB_ROWS;
+  p.n0 = p.R0 / a.th;
+  p.ty0 = p.R0 - p.n0 * a.th;
+  return p;
+}
+
+// The 256 accumulators are the AGPRs a0 .. a255 BY NAME (xi -> a[16 xi : 16 xi + 15]): as C++ values the register allocator
+// parks some of the sixteen 512-bit tuples in VGPRs and copies them to AGPRs around every MFMA (first build of this file: 240 +
+// 268 copies and 455 spilled registers in the loop). The compiler sees these registers through the clobber list at the head of
+// the kernel only, so nothing here may spill (it would spill into "free" AGPRs): the build checks for zero scratch.
+// Hazards the compiler cannot see inside asm: MFMA -> MFMA on the same accumulator needs no wait states (srcC = vDst, same
+// opcode); MFMA -> v_accvgpr_read needs the MFMA's passes + wait states: acc_settle() in front of the output transform.
+template <int XI>
+__device__ __forceinline__ void mfma_acc(const bf16x8& A, const bf16x8& B) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%2:%3], %0, %1, a[%2:%3]" : : "v"(A), "v"(B), "n"(XI * 16), "n"(XI * 16 + 15));
+}
+template <int R>
+__device__ __forceinline__ float acc_read() {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(x) : "n"(R));
+  return x;
+}
+template <int R>
+__device__ __forceinline__ void acc_zero() {
+  asm volatile("v_accvgpr_write_b32 a[%0], 0" : : "n"(R));
+}
+template <int R0, int N>
+__device__ __forceinline__ void acc_zero_range() {
+  if constexpr (N > 0) {
+    acc_zero<R0>();
+    acc_zero_range<R0 + 1, N - 1>();
+  }
+}
+__device__ __forceinline__ void acc_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
+// MODE (measurement builds): 1 = no MFMAs, 2 = no transform (V never written), 3 = no DMA after the prologue (all wrong results)
+template <int MODE>
+__global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* const Vb = lds + LDS_V;
+  unsigned char* const Ub = lds + LDS_U;
+  unsigned char* const Rb = lds + LDS_RAW;
+  const int T = threadIdx.x, lane = T & 63, wave = __builtin_amdgcn_readfirstlane(T >> 6);
+  asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17",
+               "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35",
+               "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53",
+               "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71",
+               "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89",
+               "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106",
+               "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121",
+               "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136",
+               "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151",
+               "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166",
+               "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181",
+               "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196",
+               "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211",
+               "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226",
+               "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241",
+               "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
+
+  // ---- the unit range of this workgroup
+  const int nunits = a.nblocks * a.ncb;
+  int G = gridDim.x;
+  if (a.seq) {
+    if (T == 0) {
+      unsigned* L = g_cu_latch4 + (a.seq & 63u);
+      unsigned v = __hip_atomic_load(L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), mine;
+      for (;;) {
+        if ((v >> 8) == a.seq) { mine = v & 255u; break; }
+        const int b = __hip_atomic_load(&g_cu_busy4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned busy = (unsigned)min(max(b, 0), 255);
+        const unsigned seen = atomicCAS(L, v, (a.seq << 8) | busy);
+        if (seen == v) { mine = busy; break; }
+        v = seen;
+      }
+      *reinterpret_cast<unsigned*>(Rb) = mine;
+    }
+    __syncthreads();
+    const int busy = (int)*reinterpret_cast<const unsigned*>(Rb);
+    __syncthreads();
+    G = max(1, (int)gridDim.x - __builtin_amdgcn_readfirstlane(busy));
+    if ((int)blockIdx.x >= G) return;
+  }
+  const int u_first = (int)((int64_t)blockIdx.x * nunits / G);
+  const int u_end = (int)((int64_t)(blockIdx.x + 1) * nunits / G);
+  if (u_first >= u_end) return;
+  const int nch = a.cin / CC;
+  const int total_chunks = (u_end - u_first) * nch;
+
+  // ---- transform role: thread = (tile, channel quad)
+  const int t_tile = T >> 2, t_q = T & 3, t_tr = t_tile >> 2, t_tc = t_tile & 3;
+  // V store: [xi][piece][k group = quad >> 1][tile][half = quad & 1] -> byte offset inside a phase image (+ (jx * 3 + p) * V_XP)
+  const int v_wr = (t_q >> 1) * V_REGION + t_tile * 16 + (t_q & 1) * 8;
+  int t_unit = u_first, tcnt = 0;                   // unit and chunk of it that the NEXT t_load reads
+  // raw read base of the thread's patch: local pixel row 2 tr (+ 2 behind an image boundary), pixel column order (even | odd)
+  auto raw_base = [&](int u) {
+    const UnitPos p = unit_at(u, a);
+    const int rows_a = min(TB_ROWS, a.th - p.ty0);           // tile rows of the block that belong to its first image
+    const int lr = 2 * t_tr + (t_tr >= rows_a ? 2 : 0);
+    return 16 * (4 * (lr * RAW_PX + t_tc) + t_q);
+  };
+  int raw_rd = raw_base(t_unit);
+
+  // ---- DMA role. raw: slots s = T + 256 j (16 bytes each): s -> (pixel position P = s >> 2, channel quad s & 3), P = local
+  //      row * 10 + column order (x >> 1) + 5 (x & 1). U: 6 x 16 bytes per thread and phase.
+  int r_unit = u_first, rc = 0;                     // unit / chunk of it the next raw copy fetches
+  const float* rsrc[6];
+  unsigned rstep = 0;                               // bit j: slot j moves on by a chunk per issue (in-map pixel)
+  auto raw_sources = [&](int u) {
+    const UnitPos p = unit_at(u, a);
+    const int rows_a = min(TB_ROWS, a.th - p.ty0);
+    const int limit_a = 2 * rows_a + 2;
+    rstep = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int s = T + NT * j;
+      const int P = s >> 2, q = s & 3;
+      const int lr = P / RAW_PX, rem = P - lr * RAW_PX;
+      const int xx = rem < 5 ? 2 * rem : 2 * (rem - 5) + 1;
+      const bool in_a = lr < limit_a;
+      const int n = in_a ? p.n0 : p.n0 + 1;
+      const int py = in_a ? 2 * p.ty0 - 1 + lr : lr - limit_a - 1;
+      const int px = 8 * p.bc - 1 + xx;
+      const bool ok = lr < RAW_ROWS && (in_a || (rows_a < TB_ROWS && (lr - limit_a) < 2 * (TB_ROWS - rows_a) + 2)) && n < a.N &&
+                      py >= 0 && py < a.H && px >= 0 && px < a.W;
+      const int64_t off = (((int64_t)n * a.H + py) * a.W + px) * a.cin + q * 4;
+      rsrc[j] = ok ? a.x + off : g_wino4_zero_page;
+      rstep |= ok ? (1u << j) : 0u;
+    }
+  };
+  raw_sources(r_unit);
+  auto issue_raw = [&]() {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) glds16(rsrc[j], Rb + (NT * j + wave * 64) * 16);
+  };
+  auto r_advance = [&]() {                                    // after issue_raw: move the sources to the next chunk
+    if (++rc < nch) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) rsrc[j] += (rstep >> j & 1u) ? CC : 0;
+      return;
+    }
+    rc = 0;
+    ++r_unit;
+    if (r_unit % a.ncb == 0) raw_sources(r_unit);            // next spatial block (channel block 0 again)
+    else {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) rsrc[j] -= (rstep >> j & 1u) ? (nch - 1) * CC : 0;
+    }
+  };
+  int u_cb = u_first % a.ncb, upc = 0;              // channel block / phase of its unit the next U copy fetches
+  const unsigned char* usrc = a.U + (int64_t)u_cb * nch * 4 * U_PHASE + T * 16;
+  auto issue_u = [&](int ub) {                                // one phase image -> U buffer at byte offset ub
+#pragma unroll
+    for (int k = 0; k < 6; ++k) glds16(usrc + k * (NT * 16), Ub + ub + (k * NT + wave * 64) * 16);
+  };
+  auto u_advance = [&]() {
+    if (++upc < nch * 4) { usrc += U_PHASE; return; }
+    upc = 0;
+    if (++u_cb == a.ncb) u_cb = 0;
+    usrc = a.U + (int64_t)u_cb * nch * 4 * U_PHASE + T * 16;
+  };
+
+  // ---- MFMA role: wave = tile half (wave & 1) x channel half (wave >> 1)
+  const int w_th = wave & 1, w_kh = wave >> 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int a_rd = lhi * (64 * 16) + (w_kh * 32 + l31) * 16;       // U image: A operand, rows = output channels
+  const int b_rd = lhi * V_REGION + (w_th * 32 + l31) * 16;        // V image: B operand, columns = tiles
+  acc_zero_range<0, 256>();
+
+  // ---- output transform of a finished unit: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]. Lane = tile l31 of the wave's half, channels
+  //      cb * 64 + 32 kh + 8 j + 4 lhi + (0..3) for register group j (accumulator register 4 j + e of every xi)
+  int e_unit = u_first, ec = 0;
+  auto epilogue_group = [&](auto jc, const UnitPos& eu, float* yo, bool in, bool x1, bool y1) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;
+    const int kbase = eu.cb * WG_K + w_kh * 32 + 4 * lhi + 8 * j;
+    f32x4 bias = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+      const float* bp = a.bias + eu.cb * WG_K + __builtin_amdgcn_readfirstlane(w_kh) * 32 + 8 * j;
+      const f32x4 b0 = sload4(bp), b1 = sload4(bp + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bias[e] = lhi ? b1[e] : b0[e];
+    }
+    f32x4 M[16];
+#define CRB_ACC4(XI) M[XI] = (f32x4){acc_read<XI * 16 + 4 * j>(), acc_read<XI * 16 + 4 * j + 1>(), acc_read<XI * 16 + 4 * j + 2>(), acc_read<XI * 16 + 4 * j + 3>()}
+    CRB_ACC4(0); CRB_ACC4(1); CRB_ACC4(2); CRB_ACC4(3); CRB_ACC4(4); CRB_ACC4(5); CRB_ACC4(6); CRB_ACC4(7);
+    CRB_ACC4(8); CRB_ACC4(9); CRB_ACC4(10); CRB_ACC4(11); CRB_ACC4(12); CRB_ACC4(13); CRB_ACC4(14); CRB_ACC4(15);
+#undef CRB_ACC4
+    f32x4 t0[4], t1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      t0[s] = M[0 * 4 + s] + M[1 * 4 + s] + M[2 * 4 + s];
+      t1[s] = M[1 * 4 + s] - M[2 * 4 + s] - M[3 * 4 + s];
+    }
+    f32x4 y00 = t0[0] + t0[1] + t0[2] + bias, y01 = t0[1] - t0[2] - t0[3] + bias;
+    f32x4 y10 = t1[0] + t1[1] + t1[2] + bias, y11 = t1[1] - t1[2] - t1[3] + bias;
+    if (a.relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        y00[e] = fmaxf(y00[e], 0.f); y01[e] = fmaxf(y01[e], 0.f);
+        y10[e] = fmaxf(y10[e], 0.f); y11[e] = fmaxf(y11[e], 0.f);
+      }
+    }
+    f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (in) {
+      float* o = yo + 8 * j;
+      *reinterpret_cast<f32x4*>(o) = y00;
+      if (x1) *reinterpret_cast<f32x4*>(o + a.cout) = y01;
+      if (y1) *reinterpret_cast<f32x4*>(o + (int64_t)a.W * a.cout) = y10;
+      if (x1 && y1) *reinterpret_cast<f32x4*>(o + (int64_t)a.W * a.cout + a.cout) = y11;
+      if (a.stats) {                                          // fixed order: (0,0), (0,1), (1,0), (1,1)
+        const float m01 = x1 ? 1.f : 0.f, m10 = y1 ? 1.f : 0.f, m11 = (x1 && y1) ? 1.f : 0.f;
+        s1 = y00; s2 = y00 * y00;
+        s1 = s1 + y01 * m01; s2 = s2 + (y01 * y01) * m01;
+        s1 = s1 + y10 * m10; s2 = s2 + (y10 * y10) * m10;
+        s1 = s1 + y11 * m11; s2 = s2 + (y11 * y11) * m11;
+      }
+    }
+    if (a.stats) {
+      // sum over the 32 tiles of the lane half (rotations inside the 16-lane rows, then the two rows of the half: fixed order), lanes
+      // 0 and 32 write their four channels: slab = (spatial block, tile half)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float u = s1[e], v = s2[e];
+#define CRB_ROW_ROR_ADD(x, ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false))
+        CRB_ROW_ROR_ADD(u, 0x128); CRB_ROW_ROR_ADD(v, 0x128);       // row_ror:8
+        CRB_ROW_ROR_ADD(u, 0x124); CRB_ROW_ROR_ADD(v, 0x124);
+        CRB_ROW_ROR_ADD(u, 0x122); CRB_ROW_ROR_ADD(v, 0x122);
+        CRB_ROW_ROR_ADD(u, 0x121); CRB_ROW_ROR_ADD(v, 0x121);
+#undef CRB_ROW_ROR_ADD
+        u += __shfl_xor(u, 16, 64);
+        v += __shfl_xor(v, 16, 64);
+        s1[e] = u;
+        s2[e] = v;
+      }
+      if (l31 == 0) {
+        const int64_t blk = (int64_t)(eu.R0 / TB_ROWS) * a.tw4 + eu.bc;
+        float* so = a.stats + ((blk * 2 + w_th) * 2) * a.cout + kbase;
+        *reinterpret_cast<f32x4*>(so) = s1;
+        *reinterpret_cast<f32x4*>(so + a.cout) = s2;
+      }
+    }
+  };
+  auto unit_epilogue = [&]() __attribute__((always_inline)) {
+    const UnitPos eu = unit_at(e_unit, a);
+    const int tile = w_th * 32 + l31;
+    const int tr = tile >> 2, tc = tile & 3;
+    const int Rg = eu.R0 + tr;
+    const int tx = eu.bc * TB_COLS + tc;
+    int n2 = eu.n0, ty2 = eu.ty0 + tr;
+    while (ty2 >= a.th) { ty2 -= a.th; ++n2; }
+    const int oy = 2 * ty2, ox = 2 * tx;
+    const bool in = Rg < a.RT && tx < a.tw;
+    const bool x1 = ox + 1 < a.W, y1 = oy + 1 < a.H;
+    float* const yo = a.y + (((int64_t)n2 * a.H + oy) * a.W + ox) * a.cout + eu.cb * WG_K + w_kh * 32 + 4 * lhi;
+    acc_settle();
+    epilogue_group(std::integral_constant<int, 0>{}, eu, yo, in, x1, y1);
+    epilogue_group(std::integral_constant<int, 1>{}, eu, yo, in, x1, y1);
+    epilogue_group(std::integral_constant<int, 2>{}, eu, yo, in, x1, y1);
+    epilogue_group(std::integral_constant<int, 3>{}, eu, yo, in, x1, y1);
+    acc_zero_range<0, 256>();
+    ++e_unit;
+  };
+
+  // ---- input transform, cut into pieces that the phase places one behind each MFMA (one wave per SIMD: what is issued between
+  //      two MFMAs runs under the first one; MFMAs back to back make the wave wait for the matrix pipe):
+  //      col<b>: column b of the thread's 4 x 4 patch of 4 channels from the raw block, tp[.][b] = B^T d,
+  //              B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1];
+  //      xi<r, jx, s>: element jx of row r of tp B in five steps: value + first piece, second piece, third piece, pack + store of
+  //              piece 0, pack + store of pieces 1 and 2 (3 ds_write_b64)
+  f32x4 tp[4][4];
+  f32x4 sv, sr1, sr2;                                 // value, first and second remainder of the element being split
+  auto t_read = [&](f32x4 (&d)[4][4]) {
+    const unsigned char* p = Rb + raw_rd;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)          // pixel column b of the patch: position t_tc + (b >> 1) + 5 (b & 1) of the row
+        d[i][b] = *reinterpret_cast<const f32x4*>(p + (i * RAW_PX + (b >> 1) + 5 * (b & 1)) * 64);
+  };
+  auto t_col = [&](const f32x4 (&d)[4][4], int b) __attribute__((always_inline)) {
+    tp[0][b] = d[0][b] - d[2][b];
+    tp[1][b] = d[1][b] + d[2][b];
+    tp[2][b] = d[2][b] - d[1][b];
+    tp[3][b] = d[1][b] - d[3][b];
+    // (anchors: volatile asm statements keep their order, so the values exist HERE, between the two MFMAs around this piece - the
+    // optimizer otherwise sinks pure arithmetic to its first use, across sched_barrier)
+    asm volatile("" : "+v"(tp[0][b]), "+v"(tp[1][b]), "+v"(tp[2][b]), "+v"(tp[3][b]));
+  };
+  auto trunc16 = [](float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); };
+  auto pack_hi = [](const f32x4& x) {
+    u32x2 o;
+    o[0] = (__float_as_uint(x[0]) >> 16) | (__float_as_uint(x[1]) & 0xffff0000u);
+    o[1] = (__float_as_uint(x[2]) >> 16) | (__float_as_uint(x[3]) & 0xffff0000u);
+    return o;
+  };
+  auto t_xi = [&](unsigned char* V, auto rcst, auto jcst, auto scst) __attribute__((always_inline)) {
+    constexpr int r = decltype(rcst)::value, jx = decltype(jcst)::value, s = decltype(scst)::value;
+    if (MODE == 2) return;
+    if constexpr (s == 0) {
+      if constexpr (jx == 0) sv = tp[r][0] - tp[r][2];
+      else if constexpr (jx == 1) sv = tp[r][1] + tp[r][2];
+      else if constexpr (jx == 2) sv = tp[r][2] - tp[r][1];
+      else sv = tp[r][1] - tp[r][3];
+      asm volatile("" : "+v"(sv));
+    } else if constexpr (s == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sr1[e] = sv[e] - trunc16(sv[e]);
+      asm volatile("" : "+v"(sr1));
+    } else if constexpr (s == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sr2[e] = sr1[e] - trunc16(sr1[e]);
+      asm volatile("" : "+v"(sr2));
+    } else if constexpr (s == 3) {
+      *reinterpret_cast<u32x2*>(V + v_wr + (jx * 3 + 0) * V_XP) = pack_hi(sv);
+    } else {
+      *reinterpret_cast<u32x2*>(V + v_wr + (jx * 3 + 1) * V_XP) = pack_hi(sr1);
+      *reinterpret_cast<u32x2*>(V + v_wr + (jx * 3 + 2) * V_XP) = pack_hi(sr2);
+    }
+  };
+  auto t_advance = [&]() {                           // after a t_read: the next one reads the next chunk's block
+    if (++tcnt < nch) return;
+    tcnt = 0;
+    ++t_unit;
+    if (t_unit % a.ncb == 0) raw_rd = raw_base(t_unit);
+  };
+
+  // ---- phases. f = 4 chunk + i: MFMAs of xi row i on V[f & 1], U[f % 3]; V(f + 1) formed meanwhile; U(f + 2) and, in phase 0,
+  //      raw(chunk + 1) requested right behind the barrier. Every phase requests its copies unconditionally (past the end of the
+  //      workgroup's range they fetch a valid U image and zero-page / in-map pixels that nobody reads): the counts below hold in
+  //      every phase.
+  int ub_cur = 0, ub_nxt = U_PHASE, ub_nn = 2 * U_PHASE;
+  auto phase = [&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int rn = (i + 1) & 3;
+    // DMA that may stay in flight: what phase f - 1 requested (U(f + 1); in phase 1 also raw(chunk + 1), requested before it)
+    if (i == 1) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    unsigned char* const Vn = Vb + ((i + 1) & 1) * V_PHASE;
+    const unsigned char* const Vc = Vb + (i & 1) * V_PHASE + b_rd;
+    const unsigned char* const Uc = Ub + ub_cur + a_rd;
+    bf16x8 A[2][3], B[2][3];
+    auto op_read = [&](int jx, int slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        A[slot][p] = *reinterpret_cast<const bf16x8*>(Uc + (jx * 3 + p) * U_XP);
+        B[slot][p] = *reinterpret_cast<const bf16x8*>(Vc + (jx * 3 + p) * V_XP);
+      }
+    };
+    op_read(0, 0);
+    f32x4 d[4][4];
+    if (i == 3) { t_read(d); t_advance(); }
+    if (MODE != 3) {
+      if (i == 0) { issue_raw(); r_advance(); }
+      issue_u(ub_nn); u_advance();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // piece k (behind MFMA k of the phase). Phase 3 starts with the four column passes (columns 0, 2 first: xi 0 needs them)
+    auto piece = [&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
+      constexpr int k0 = (i == 3) ? k - 4 : k;
+      if constexpr (i == 3 && k < 4) {
+        t_col(d, k == 0 ? 0 : k == 1 ? 2 : k == 2 ? 1 : 3);
+      } else if constexpr (k0 >= 0 && k0 < 20) {
+        t_xi(Vn, std::integral_constant<int, rn>{}, std::integral_constant<int, k0 / 5>{}, std::integral_constant<int, k0 % 5>{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stage = [&](auto jc) __attribute__((always_inline)) {
+      constexpr int jx = decltype(jc)::value;
+      constexpr int s = jx & 1;
+      if (MODE != 1) mfma_acc<4 * i + jx>(A[s][0], B[s][2]);
+      if (jx < 3) op_read(jx + 1, s ^ 1);
+      piece(std::integral_constant<int, 6 * jx + 0>{});
+      if (MODE != 1) mfma_acc<4 * i + jx>(A[s][2], B[s][0]);
+      piece(std::integral_constant<int, 6 * jx + 1>{});
+      if (MODE != 1) mfma_acc<4 * i + jx>(A[s][1], B[s][1]);
+      piece(std::integral_constant<int, 6 * jx + 2>{});
+      if (MODE != 1) mfma_acc<4 * i + jx>(A[s][0], B[s][1]);
+      piece(std::integral_constant<int, 6 * jx + 3>{});
+      if (MODE != 1) mfma_acc<4 * i + jx>(A[s][1], B[s][0]);
+      piece(std::integral_constant<int, 6 * jx + 4>{});
+      if (MODE != 1) mfma_acc<4 * i + jx>(A[s][0], B[s][0]);
+      piece(std::integral_constant<int, 6 * jx + 5>{});
+    };
+    stage(std::integral_constant<int, 0>{});
+    stage(std::integral_constant<int, 1>{});
+    stage(std::integral_constant<int, 2>{});
+    stage(std::integral_constant<int, 3>{});
+    const int t = ub_cur; ub_cur = ub_nxt; ub_nxt = ub_nn; ub_nn = t;
+  };
+
+  // ---- prologue: raw(0), U(0), U(1) in one round trip, raw(0) -> tp -> V(0)
+  issue_raw(); r_advance();
+  issue_u(0); u_advance();
+  issue_u(U_PHASE); u_advance();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  {
+    f32x4 d[4][4];
+    t_read(d); t_advance();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) t_col(d, b);
+  }
+#define CRB_T_XI_ALL(JX)                                                                                                      \
+  t_xi(Vb, std::integral_constant<int, 0>{}, std::integral_constant<int, JX>{}, std::integral_constant<int, 0>{});            \
+  t_xi(Vb, std::integral_constant<int, 0>{}, std::integral_constant<int, JX>{}, std::integral_constant<int, 1>{});            \
+  t_xi(Vb, std::integral_constant<int, 0>{}, std::integral_constant<int, JX>{}, std::integral_constant<int, 2>{});            \
+  t_xi(Vb, std::integral_constant<int, 0>{}, std::integral_constant<int, JX>{}, std::integral_constant<int, 3>{});            \
+  t_xi(Vb, std::integral_constant<int, 0>{}, std::integral_constant<int, JX>{}, std::integral_constant<int, 4>{})
+  CRB_T_XI_ALL(0); CRB_T_XI_ALL(1); CRB_T_XI_ALL(2); CRB_T_XI_ALL(3);
+#undef CRB_T_XI_ALL
+
+  for (int cg = 0; cg < total_chunks; ++cg) {
+    phase(std::integral_constant<int, 0>{});
+    phase(std::integral_constant<int, 1>{});
+    phase(std::integral_constant<int, 2>{});
+    phase(std::integral_constant<int, 3>{});
+    if (++ec == nch) { ec = 0; unit_epilogue(); }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (copies requested past the end of the range)
+}
+
+}  // namespace
+
+CRB_KNOB g_wino4_mode = 0;      // measurement builds: 1 = no MFMAs, 2 = no transform, 3 = no DMA in the loop
+#ifdef CRB_MEASURE
+extern "C" int crb_winograd4_set_mode(int mode) { g_wino4_mode = (mode >= 1 && mode <= 3) ? mode : 0; return CRB_OK; }
+#endif
+
+// ceil(H / 2) >= 16: a block of 16 tile rows touches at most two images (the raw block keeps ONE gap)
+extern "C" int crb_winograd4_supported(int cin, int cout, int H, int W) {
+  return (cin > 0 && cout > 0 && cin % CC == 0 && cout % WG_K == 0 && H >= 31 && W >= 1) ? 1 : 0;
+}
+
+extern "C" int64_t crb_winograd4_weights_bytes(int cin, int cout) { return (int64_t)16 * cin * cout * 6; }
+
+// w = nn.Conv2d weight (Cout,Cin,3,3) f32 with element strides (so, si, sky, skx); mode 0: image of the forward convolution
+// (Cin -> Cout), mode 1: image of the input-gradient convolution (Cout -> Cin, flipped / transposed weights)
+extern "C" int crb_winograd4_weights_conv(const float* w, int64_t so, int64_t si, int64_t sky, int64_t skx, void* U, int conv_cin,
+                                          int conv_cout, int mode, void* stream) {
+  const int kin = mode ? conv_cout : conv_cin, kout = mode ? conv_cin : conv_cout;
+  if (!crb_winograd4_supported(kin, kout, 31, 1)) return CRB_ERR_UNSUPPORTED;
+  const int64_t per = (int64_t)(kin / 8) * kout;
+  hipLaunchKernelGGL(winograd4_weights_conv_kernel, dim3(crb_cdiv(per, 256)), dim3(256), 0, (hipStream_t)stream, w, so, si, sky, skx,
+                     (unsigned char*)U, kin, kout, mode ? 1 : 0);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_winograd4_weights_conv_multi(int n, const float* const* w, const int64_t* strides, void* const* U,
+                                                const int32_t* conv_cin, const int32_t* conv_cout, const int32_t* mode, void* stream) {
+  if (n < 0 || n > WJ_MAX || (n > 0 && (!w || !strides || !U || !conv_cin || !conv_cout || !mode))) return CRB_ERR_ARG;
+  if (n == 0) return CRB_OK;
+  Wino4WJobs jobs;
+  jobs.n = n;
+  int64_t blocks = 0;
+  for (int j = 0; j < n; ++j) {
+    const int kin = mode[j] ? conv_cout[j] : conv_cin[j], kout = mode[j] ? conv_cin[j] : conv_cout[j];
+    if (!w[j] || !U[j]) return CRB_ERR_ARG;
+    if (!crb_winograd4_supported(kin, kout, 31, 1)) return CRB_ERR_UNSUPPORTED;
+    jobs.job[j] = Wino4WJob{w[j], (unsigned char*)U[j], strides[4 * j], strides[4 * j + 1], strides[4 * j + 2], strides[4 * j + 3], kin,
+                            kout, mode[j] ? 1 : 0, (int)blocks};
+    blocks += crb_cdiv((int64_t)(kin / 8) * kout, 256);
+    if (blocks >= (1LL << 30)) return CRB_ERR_ARG;
+  }
+  hipLaunchKernelGGL(winograd4_weights_conv_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, jobs);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+namespace {
+constexpr int MAX_DEV = 64;
+std::atomic<int> g_dev_cus4[MAX_DEV];
+std::atomic<unsigned> g_dev_attr4[MAX_DEV];
+std::atomic<unsigned> g_dev_seq4[MAX_DEV];                     // launch sequence PER DEVICE: the latch ring (64 slots) lives in that device's memory,
+                                                             // two launches share a slot only if 64 launches to the SAME device lie between them
+
+int device_cus4(int* dev_out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return -1;
+  *dev_out = dev;
+  int n = g_dev_cus4[dev].load(std::memory_order_relaxed);
+  if (n > 0) return n;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+  n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  g_dev_cus4[dev].store(n, std::memory_order_relaxed);
+  return n;
+}
+}  // namespace
+
+// (called by crb_cu_reservation in winograd_conv2.hip: every persistent Winograd kernel sees the announcement)
+int crbhip_wino4_cu_busy_set(int cus, hipStream_t stream) {
+  hipLaunchKernelGGL(cu_busy4_set_kernel, dim3(1), dim3(1), 0, stream, cus);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+static int winograd4_launch(const float* x, const void* U, float* y, int N, int H, int W, int cin, int cout, const float* bias, int relu,
+                            void* stream, float* stats) {
+  if (N <= 0 || H <= 0 || W <= 0) return CRB_ERR_ARG;
+  if (!crb_winograd4_supported(cin, cout, H, W)) return CRB_ERR_UNSUPPORTED;
+  Wino4Args a;
+  a.x = x; a.U = (const unsigned char*)U; a.y = y; a.bias = bias; a.stats = stats;
+  a.N = N; a.H = H; a.W = W; a.cin = cin; a.cout = cout; a.relu = relu;
+  a.th = (H + 1) / 2; a.tw = (W + 1) / 2;
+  const int64_t rt = (int64_t)N * a.th;
+  if (rt >= (1LL << 30) || (int64_t)N * H * W * (cin > cout ? cin : cout) >= (1LL << 40)) return CRB_ERR_ARG;
+  a.RT = (int)rt;
+  a.tw4 = (a.tw + TB_COLS - 1) / TB_COLS;
+  const int64_t nb = (int64_t)((rt + TB_ROWS - 1) / TB_ROWS) * a.tw4;
+  if (nb >= (1LL << 26)) return CRB_ERR_ARG;
+  a.nblocks = (int)nb;
+  a.ncb = cout / WG_K;
+  int mode = 0;
+  auto kern = winograd4_kernel<0>;
+#ifdef CRB_MEASURE
+  mode = g_wino4_mode;
+  if (mode == 1) kern = winograd4_kernel<1>;
+  if (mode == 2) kern = winograd4_kernel<2>;
+  if (mode == 3) kern = winograd4_kernel<3>;
+#endif
+  int dev = 0;
+  const int n_cu = device_cus4(&dev);
+  if (n_cu <= 0) return CRB_ERR_LAUNCH;
+  if (!(g_dev_attr4[dev].load(std::memory_order_acquire) & (1u << mode))) {
+    CRB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    g_dev_attr4[dev].fetch_or(1u << mode, std::memory_order_release);
+  }
+  const int64_t units = nb * a.ncb;
+  const int64_t grid = units < n_cu ? units : n_cu;
+  unsigned seq = (g_dev_seq4[dev].fetch_add(1, std::memory_order_relaxed) + 1) & 0xffffffu;
+  a.seq = (grid == n_cu) ? (seq ? seq : 1) : 0;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_conv3x3_winograd4_nhwc(const float* x, const void* U, float* y, int N, int H, int W, int cin, int cout,
+                                          const float* bias, int relu, void* stream) {
+  return winograd4_launch(x, U, y, N, H, W, cin, cout, bias, relu, stream, nullptr);
+}
+
+extern "C" int64_t crb_winograd4_stats_slabs(int N, int H, int W) {
+  if (N <= 0 || H <= 0 || W <= 0) return 0;
+  const int64_t th = (H + 1) / 2, tw4 = ((W + 1) / 2 + TB_COLS - 1) / TB_COLS;
+  return 2 * ((N * th + TB_ROWS - 1) / TB_ROWS) * tw4;
+}
+
+extern "C" int crb_conv3x3_winograd4_stats_nhwc(const float* x, const void* U, float* y, float* stats, int N, int H, int W, int cin,
+                                                int cout, void* stream) {
+  if (!stats) return CRB_ERR_ARG;
+  return winograd4_launch(x, U, y, N, H, W, cin, cout, nullptr, 0, stream, stats);
+}

@@ -233,8 +233,11 @@ class VoxelSetAbstraction(nn.Module):
             feats.append(self.interpolate_from_bev_features(keypoints, batch_dict['spatial_features'], batch_size,
                                                             bev_stride=batch_dict['spatial_features_stride']))
         new_xyz = keypoints[:, 1:4].contiguous()
-        # (get_sampled_points returns exactly NUM_KEYPOINTS rows per frame, frames in order)
-        new_xyz_batch_cnt = torch.full((batch_size,), keypoints.shape[0] // batch_size, dtype=torch.int32, device=keypoints.device)
+        # (get_sampled_points returns exactly NUM_KEYPOINTS rows per frame, frames in order; any other keypoint source is counted)
+        if keypoints.shape[0] == batch_size * self.model_cfg.NUM_KEYPOINTS:
+            new_xyz_batch_cnt = torch.full((batch_size,), self.model_cfg.NUM_KEYPOINTS, dtype=torch.int32, device=keypoints.device)
+        else:
+            new_xyz_batch_cnt = _batch_counts(keypoints[:, 0], batch_size)
         if 'raw_points' in self.model_cfg.FEATURES_SOURCE:
             raw = batch_dict['points']
             feats.append(self.aggregate_keypoint_features_from_one_source(

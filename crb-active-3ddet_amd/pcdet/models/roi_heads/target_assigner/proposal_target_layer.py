@@ -97,7 +97,7 @@ class ProposalTargetLayer(nn.Module):
         of the RoI's own class; RoIs without a same-class gt get overlap 0 and assignment 0."""
         B, R, _ = rois.shape
         G = gt_boxes.shape[1]
-        nonzero = gt_boxes[..., :-1].sum(-1) != 0
+        nonzero = gt_boxes.sum(-1) != 0           # the whole row, class label included (reference :93 `cur_gt[k].sum() == 0`)
         idx = torch.arange(G, device=rois.device).view(1, G)
         last = torch.where(nonzero, idx, torch.zeros_like(idx)).max(dim=1, keepdim=True)[0]
         valid = idx <= last

@@ -102,6 +102,9 @@ def device_constant(values, device):
     return t
 
 
+_CHECK_SORTED = __import__('os').environ.get('CRB_CHECK_SORTED', '0') == '1'      # debug: one read-back per call
+
+
 def batch_counts(bs_idx, batch_size):
     """rows per frame of a stacked tensor whose frame-index column is bs_idx -> (B) int32 (the reference's per-frame
     `(bs_idxs == k).sum()` loops: voxel_set_abstraction.py:321-323, pvrcnn_head.py:96-98). On the device: crb_sorted_key_counts, one
@@ -109,6 +112,8 @@ def batch_counts(bs_idx, batch_size):
     every stacked op). Host tensors: a scatter_add (torch.bincount would read back the maximum to size its output)."""
     if bs_idx.is_cuda:
         from crbhip import lib, check, ptr, cur_stream
+        if _CHECK_SORTED and bs_idx.shape[0] > 1:          # CRB_CHECK_SORTED=1: an unsorted column would count wrong on the device only
+            assert bool((bs_idx[1:] >= bs_idx[:-1]).all()), 'batch_counts: the frame-index column must be non-decreasing'
         if bs_idx.dtype not in (torch.float32, torch.int32):
             bs_idx = bs_idx.to(torch.int32)
         out = torch.empty((batch_size,), dtype=torch.int32, device=bs_idx.device)
@@ -118,6 +123,8 @@ def batch_counts(bs_idx, batch_size):
         check(lib.crb_sorted_key_counts(key, int(bs_idx.dtype == torch.float32), max(1, bs_idx.stride(0)), n,
                                         int(batch_size), ptr(out), cur_stream(bs_idx.device)), 'crb_sorted_key_counts')
         return out
+    if bs_idx.shape[0] > 1:      # host: the same contract as the device path, checked (free here), so the two cannot diverge silently
+        assert bool((bs_idx[1:] >= bs_idx[:-1]).all()), 'batch_counts: the frame-index column must be non-decreasing'
     out = torch.zeros((batch_size,), dtype=torch.int32, device=bs_idx.device)
     return out.scatter_add_(0, bs_idx.long(), torch.ones_like(bs_idx, dtype=torch.int32))
 

@@ -75,8 +75,21 @@ class SparseConvolution(SparseModule):
         return (not self.inverse and not self.conv1x1 and feats.is_cuda and feats.shape[0] > 0 and
                 self.arithmetic == 'f32' and _sp.epilogue_supported(self.in_channels, self.out_channels))
 
+    def train(self, mode=True):
+        # the inference layout cache (weight_kio) is keyed on the parameter's address and autograd version; writes through `.data`
+        # (the reference OptimWrapper's weight decay, an fp16 master copy, EMA updates) bump neither: the cache does not outlive a
+        # switch between training and evaluation, nor a load_state_dict
+        self.__dict__.pop('_crb_kio', None)
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.__dict__.pop('_crb_kio', None)
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def weight_kio(self):
-        """(Cout,k..,Cin) -> (K,Cin,Cout) contiguous; differentiable"""
+        """(Cout,k..,Cin) -> (K,Cin,Cout) contiguous; differentiable. Inference keeps the layout on the module until the parameter's
+        address / autograd version changes or the module changes mode; in-place writes through `.data` while the module STAYS in
+        eval mode are not detected (call module.train(False) again, or drop `_crb_kio`)."""
         w = self.weight
         K = 1
         for k in self.kernel_size:

@@ -748,6 +748,31 @@ int64_t crb_winograd2_stats_slabs(int N, int H, int W);
 int crb_conv3x3_winograd2_stats_nhwc(const float* x, const float* U, float* y, float* stats, int N, int H, int W, int cin, int cout,
                                      void* stream);
 
+/* a7, round 6: the same convolution with the 16 Winograd GEMMs on the bf16 matrix pipe through an EXACT three-way split of every
+ * f32 operand (csrc/winograd_conv4.hip). replaces: the same torch.nn.Conv2d(C, C, 3, padding=1) of
+ * pcdet/models/backbones_2d/base_bev_backbone.py:24-41 as crb_conv3x3_winograd2_nhwc. x = x1 + x2 + x3 with x1 = x & 0xffff0000,
+ * x2 = (x - x1) & 0xffff0000, x3 = x - x1 - x2 (no rounding: an f32 significand is three bf16 significands); of the nine exact
+ * partial products of x * w the six with i + j <= 4 are accumulated in f32 by v_mfma_f32_32x32x16_bf16 (the three dropped ones are
+ * below 2^-23 |x w|, one f32 rounding of the product): f32 in, f32 out, errors against an f64 convolution at the level of the f32-MFMA
+ * kernel's (tests/test_winograd_gpu.py holds both to the same bars), at 16 / 6 of the f32 MFMA rate. Inf / NaN inputs give NaN (inf -
+ * inf in the split), values below 2^-110 lose their low pieces to flushing.
+ * Same arguments as the *2 entry points; the weight image is bf16 pieces in LDS order ([Cout/64][Cin/16][xi row][xi][piece][k
+ * group][64 rows][8]), crb_winograd4_weights_bytes bytes. crb_winograd4_supported: Cin % 16 == 0, Cout % 64 == 0, H >= 31 (a block of
+ * 16 tile rows touches at most two images). One wave per SIMD with all 16 xi of a 32 x 32 block (256 accumulators), raw block shared
+ * by the workgroup (halo rows fetched once), four xi-row phases per 16-channel chunk. Stats slabs as crb_winograd2_stats_slabs but
+ * with the tile rows per image NOT rounded up to even: crb_winograd4_stats_slabs. */
+int crb_winograd4_supported(int cin, int cout, int H, int W);
+int64_t crb_winograd4_weights_bytes(int cin, int cout);
+int crb_winograd4_weights_conv(const float* w, int64_t so, int64_t si, int64_t sky, int64_t skx, void* U, int conv_cin, int conv_cout,
+                               int mode, void* stream);
+int crb_winograd4_weights_conv_multi(int n, const float* const* w, const int64_t* strides, void* const* U, const int32_t* conv_cin,
+                                     const int32_t* conv_cout, const int32_t* mode, void* stream);
+int crb_conv3x3_winograd4_nhwc(const float* x, const void* U, float* y, int N, int H, int W, int cin, int cout, const float* bias,
+                               int relu, void* stream);
+int64_t crb_winograd4_stats_slabs(int N, int H, int W);
+int crb_conv3x3_winograd4_stats_nhwc(const float* x, const void* U, float* y, float* stats, int N, int H, int W, int cin, int cout,
+                                     void* stream);
+
 /* a7 backward: weight gradient of the same convolution in the Winograd domain (csrc/winograd_wgrad.hip):
  * dU[xi][ci][co] = sum over tiles of (B^T d B)[xi][ci] * (A dY A^T)[xi][co] as 16 MFMA GEMMs whose two operands are both
  * produced by transforms inside the kernel, partial sums per range of tiles in the workspace, then dW = G^T dU G added up in
