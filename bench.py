@@ -36,6 +36,9 @@ MFMA_BF16_PEAK_TF = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 # start after the last backward kernel; 4 MB buckets go out while the BEV backbone's backward is still running (xGMI ring:
 # ~30-50 us of latency per call, hidden) and leave only the sparse backbone's ~3 MB for the end of the step
 DDP_BUCKET_MB = 4
+# CRB_FORCE_DIST=1: run the N > 1 code (process group, DDP wrapper, barriers, score / embedding all-gathers) at world size 1 too:
+# `torchrun --nproc-per-node 1 bench.py --gpus 1` then loads RCCL and executes every collective on the one GPU of a test box
+FORCE_DIST = os.environ.get('CRB_FORCE_DIST', '0') == '1'
 
 
 def parse():
@@ -386,7 +389,7 @@ def _pctl(xs):
 
 def _all_ranks(x, world, device):
     """the value of every rank, in rank order (diagnostics of the first multi-GPU runs: which rank is slow)"""
-    if world == 1:
+    if world == 1 and not FORCE_DIST:
         return [float(x)]
     t = torch.tensor([float(x)], dtype=torch.float64, device='cpu' if dist.get_backend() == 'gloo' else device)
     out = [torch.zeros_like(t) for _ in range(world)]
@@ -395,7 +398,7 @@ def _all_ranks(x, world, device):
 
 
 def _max_over_ranks(dt, world, device):
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -435,13 +438,13 @@ def crb_scoring_bench(args, rank, world, device):
 
     def timed(fn):
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or FORCE_DIST:
             dist.barrier()
         t0 = time.perf_counter()
         out = fn()
         torch.cuda.synchronize()
         mine_s = time.perf_counter() - t0                     # this rank alone, before it waits for the others
-        if world > 1:
+        if world > 1 or FORCE_DIST:
             dist.barrier()
         dt = _max_over_ranks(time.perf_counter() - t0, world, device)
         rank_seconds.append([round(v, 4) for v in _all_ranks(mine_s, world, device)])
@@ -548,7 +551,7 @@ def pvrcnn_bench(args, rank, world, device):
     model.train()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01, fused=True)
     net = model
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=True,
                                                         bucket_cap_mb=DDP_BUCKET_MB)
     batches = make_batches(args, rank, device, first=20000)
@@ -575,13 +578,13 @@ def pvrcnn_bench(args, rank, world, device):
     torch.cuda.reset_peak_memory_stats()         # (after the warm-up: MIOpen's solver search allocates workspaces the steps never see again)
     gc.collect()
     gc.freeze()
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.pvrcnn_steps):
         loss = step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         dist.barrier()
     dt = _max_over_ranks(time.perf_counter() - t0, world, device)
     out = {'metric': 'frames/s PV-RCNN fwd+bwd+AdamW, KITTI 20k-pt clouds', 'unit': 'frames/s',
@@ -621,7 +624,7 @@ def main():
     dev_idx = local_rank % ndev          # one process per GPU; the modulo only matters for the single-GPU gloo dry run
     torch.cuda.set_device(dev_idx)
     device = torch.device('cuda', dev_idx)
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = os.environ.get('CRB_DIST_BACKEND', 'nccl')          # 'nccl' = RCCL over xGMI
         if backend == 'nccl':
@@ -646,7 +649,7 @@ def main():
     model.train()
     opt = torch.optim.AdamW(model.parameters(), lr=3e-3, weight_decay=0.01, betas=(0.9, 0.99), fused=True)   # one multi-tensor kernel (0.23 vs 0.42 ms for the 84 tensors)
     net = model
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_idx], gradient_as_bucket_view=True,
                                                         bucket_cap_mb=DDP_BUCKET_MB)
     batches = make_batches(args, rank, device)
@@ -677,7 +680,7 @@ def main():
         """-> wall seconds for EXACTLY args.steps steps (barrier + synchronize on both sides, max over ranks) and the
         per-step device-timeline durations (events at the step boundaries on the compute stream, no host sync inside)"""
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or FORCE_DIST:
             dist.barrier()
         torch.cuda.synchronize()
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -691,7 +694,7 @@ def main():
             marks[i + 1].record()
         torch.cuda.synchronize()
         own = time.perf_counter() - t0                                  # this rank's own steps, before it waits for the others
-        if world > 1:
+        if world > 1 or FORCE_DIST:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -840,7 +843,7 @@ def main():
                                      'split-bf16 contract (wgrad, BEV backbone and heads unchanged, f32)'}
         out['summary'] = headline
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         dist.destroy_process_group()
 
 

@@ -34,6 +34,7 @@
 #include "crb_common.h"
 #include "../../include/crb_hip.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -60,6 +61,7 @@ constexpr int LDS_V = 0, LDS_U = 2 * V_PHASE, LDS_RAW = LDS_U + 3 * U_PHASE, LDS
 __device__ float g_wino4_zero_page[64];      // source of out-of-map pixels (zero-initialised, never written)
 __device__ int g_cu_busy4 = 0;               // see winograd_conv2.hip (crb_cu_reservation sets both)
 __device__ unsigned g_cu_latch4[64];
+__device__ unsigned long long* g_wino4_dbg = nullptr;      // measurement mode 9: 8 uint64 per (workgroup, wave)
 __global__ void cu_busy4_set_kernel(int v) { __hip_atomic_store(&g_cu_busy4, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // exact three-way split: the bf16 bit patterns (high halves) of x1, x2, x3
@@ -212,7 +214,9 @@ __device__ __forceinline__ void acc_zero_range() {
 }
 __device__ __forceinline__ void acc_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
-// MODE (measurement builds): 1 = no MFMAs, 2 = no transform (V never written), 3 = no DMA after the prologue (all wrong results)
+#ifdef CRB_MEASURE   // the first form: A/B in the measurement library
+// MODE (measurement builds, wrong results): 1 = no MFMAs, 2 = no transform (V never written), 3 = no DMA after the prologue, 4 = no
+// operand reads, 5 = no U copies, 6 = no raw copies, 7 = no V stores (values formed), 8 = no epilogue stores
 template <int MODE>
 __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
       }
     }
     f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (in) {
+    if (in && MODE != 8) {
       float* o = yo + 8 * j;
       *reinterpret_cast<f32x4*>(o) = y00;
       if (x1) *reinterpret_cast<f32x4*>(o + a.cout) = y01;
@@ -490,8 +494,10 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
       for (int e = 0; e < 4; ++e) sr2[e] = sr1[e] - trunc16(sr1[e]);
       asm volatile("" : "+v"(sr2));
     } else if constexpr (s == 3) {
+      if (MODE == 7) { asm volatile("" :: "v"(pack_hi(sv))); return; }          // measurement: no V stores
       *reinterpret_cast<u32x2*>(V + v_wr + (jx * 3 + 0) * V_XP) = pack_hi(sv);
     } else {
+      if (MODE == 7) { asm volatile("" :: "v"(pack_hi(sr1)), "v"(pack_hi(sr2))); return; }
       *reinterpret_cast<u32x2*>(V + v_wr + (jx * 3 + 1) * V_XP) = pack_hi(sr1);
       *reinterpret_cast<u32x2*>(V + v_wr + (jx * 3 + 2) * V_XP) = pack_hi(sr2);
     }
@@ -522,6 +528,10 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
     auto op_read = [&](int jx, int slot) __attribute__((always_inline)) {
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
+        if (MODE == 4) {                    // measurement: no operand reads
+          asm volatile("" : "=v"(A[slot][p]), "=v"(B[slot][p]));
+          continue;
+        }
         A[slot][p] = *reinterpret_cast<const bf16x8*>(Uc + (jx * 3 + p) * U_XP);
         B[slot][p] = *reinterpret_cast<const bf16x8*>(Vc + (jx * 3 + p) * V_XP);
       }
@@ -530,8 +540,8 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
     f32x4 d[4][4];
     if (i == 3) { t_read(d); t_advance(); }
     if (MODE != 3) {
-      if (i == 0) { issue_raw(); r_advance(); }
-      issue_u(ub_nn); u_advance();
+      if (i == 0 && MODE != 6) { issue_raw(); r_advance(); }
+      if (MODE != 5) { issue_u(ub_nn); u_advance(); }
     }
     __builtin_amdgcn_sched_barrier(0);
     // piece k (behind MFMA k of the phase). Phase 3 starts with the four column passes (columns 0, 2 first: xi 0 needs them)
@@ -600,11 +610,430 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (copies requested past the end of the range)
 }
 
+
+#endif
+
+// ================================================================================================================================
+// Second form (the default): the same pipeline with TWO waves per SIMD. Measured on the first form above (one 512-register wave
+// per SIMD, profiles/r06_time_winograd4_v1_skip_work_modes.txt): the skip-work builds add up - MFMAs 140 us, LDS-DMA 130 us,
+// operand reads 90 us, transform 75 us, V stores 50 us, output stores 45 us of 635 us: with one in-order wave per SIMD nothing
+// runs under anything else. Here a workgroup is 512 threads = 8 waves of 128 accumulators + 128 registers: wave = 32 tiles x 32
+// output channels x HALF of the xi (columns 2 xh, 2 xh + 1 of every xi row), so each SIMD has a second wave to issue from while
+// one waits for LDS, for the matrix pipe or at a counter. Price: the output transform needs both halves. Y = A^T M A splits as
+// Y = Q(xh = 0) + Q(xh = 1) with Q = A^T (M_half A_half) formed by each wave on its own accumulators; wave xh keeps output row xh
+// of its Q and hands the other row to its partner (wave ^ 4) through LDS (the raw block and the V image that are idle between
+// two units: 2 rounds x 32 KB, three extra barriers per unit).
+constexpr int NT2 = 512;
+// The 128 accumulators are a8 .. a135 (xi (row i, column 2 xh + jj) -> a[8 + 16 (2 i + jj) ..]); a0 .. a7 are left to the compiler, which
+// parks a handful of loop-invariant values there when the 120 VGPRs it is given run out (amdgpu_num_vgpr: 120 + 136 = 256 = two waves
+// per SIMD). tools/check_wino4_isa.py fails the build if it ever writes a VGPR into a8 or above.
+constexpr int ACC0 = 8;
+template <int XI>
+__device__ __forceinline__ void mfma_acc8(const bf16x8& A, const bf16x8& B) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%2:%3], %0, %1, a[%2:%3]" : : "v"(A), "v"(B), "n"(ACC0 + XI * 16), "n"(ACC0 + XI * 16 + 15));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(120))) void winograd4b_kernel(Wino4Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* const Vb = lds + LDS_V;
+  unsigned char* const Ub = lds + LDS_U;
+  unsigned char* const Rb = lds + LDS_RAW;
+  const int T = threadIdx.x, lane = T & 63, wave = __builtin_amdgcn_readfirstlane(T >> 6);
+  asm volatile("" ::: "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135");
+
+  // ---- the unit range of this workgroup
+  const int nunits = a.nblocks * a.ncb;
+  int G = gridDim.x;
+  if (a.seq) {
+    if (T == 0) {
+      unsigned* L = g_cu_latch4 + (a.seq & 63u);
+      unsigned v = __hip_atomic_load(L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), mine;
+      for (;;) {
+        if ((v >> 8) == a.seq) { mine = v & 255u; break; }
+        const int b = __hip_atomic_load(&g_cu_busy4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned busy = (unsigned)min(max(b, 0), 255);
+        const unsigned seen = atomicCAS(L, v, (a.seq << 8) | busy);
+        if (seen == v) { mine = busy; break; }
+        v = seen;
+      }
+      *reinterpret_cast<unsigned*>(Rb) = mine;
+    }
+    __syncthreads();
+    const int busy = (int)*reinterpret_cast<const unsigned*>(Rb);
+    __syncthreads();
+    G = max(1, (int)gridDim.x - __builtin_amdgcn_readfirstlane(busy));
+    if ((int)blockIdx.x >= G) return;
+  }
+  const int u_first = (int)((int64_t)blockIdx.x * nunits / G);
+  const int u_end = (int)((int64_t)(blockIdx.x + 1) * nunits / G);
+  if (u_first >= u_end) return;
+  const int nch = a.cin / CC;
+  const int total_chunks = (u_end - u_first) * nch;
+
+  // ---- transform role: thread = (tile, channel pair)
+  const int t_tile = T >> 3, t_cp = T & 7, t_tr = t_tile >> 2, t_tc = t_tile & 3;
+  // V store (4 bytes = the pair's two bf16): [xi][piece][k group = pair >> 2][tile][pair & 3] (+ (jx * 3 + p) * V_XP)
+  const int v_wr = (t_cp >> 2) * V_REGION + t_tile * 16 + (t_cp & 3) * 4;
+  int t_unit = u_first, tcnt = 0;                   // unit and chunk of it that the NEXT t_read reads
+  auto raw_base = [&](int u) {
+    const UnitPos p = unit_at(u, a);
+    const int rows_a = min(TB_ROWS, a.th - p.ty0);           // tile rows of the block that belong to its first image
+    const int lr = 2 * t_tr + (t_tr >= rows_a ? 2 : 0);
+    return 64 * (lr * RAW_PX + t_tc) + 8 * t_cp;
+  };
+  int raw_rd = raw_base(t_unit);
+
+  // ---- DMA role. raw: slots s = T + 512 j (16 bytes each): s -> (pixel position P = s >> 2, channel quad s & 3), P = local
+  //      row * 10 + column order (x >> 1) + 5 (x & 1). U: 3 x 16 bytes per thread and phase.
+  int r_unit = u_first, rc = 0;
+  const float* rsrc[3];
+  unsigned rstep = 0;
+  auto raw_sources = [&](int u) {
+    const UnitPos p = unit_at(u, a);
+    const int rows_a = min(TB_ROWS, a.th - p.ty0);
+    const int limit_a = 2 * rows_a + 2;
+    rstep = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int s = T + NT2 * j;
+      const int P = s >> 2, q = s & 3;
+      const int lr = P / RAW_PX, rem = P - lr * RAW_PX;
+      const int xx = rem < 5 ? 2 * rem : 2 * (rem - 5) + 1;
+      const bool in_a = lr < limit_a;
+      const int n = in_a ? p.n0 : p.n0 + 1;
+      const int py = in_a ? 2 * p.ty0 - 1 + lr : lr - limit_a - 1;
+      const int px = 8 * p.bc - 1 + xx;
+      const bool ok = lr < RAW_ROWS && (in_a || (rows_a < TB_ROWS && (lr - limit_a) < 2 * (TB_ROWS - rows_a) + 2)) && n < a.N &&
+                      py >= 0 && py < a.H && px >= 0 && px < a.W;
+      const int64_t off = (((int64_t)n * a.H + py) * a.W + px) * a.cin + q * 4;
+      rsrc[j] = ok ? a.x + off : g_wino4_zero_page;
+      rstep |= ok ? (1u << j) : 0u;
+    }
+  };
+  raw_sources(r_unit);
+  auto issue_raw = [&]() {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) glds16(rsrc[j], Rb + (NT2 * j + wave * 64) * 16);
+  };
+  auto r_advance = [&]() {
+    if (++rc < nch) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) rsrc[j] += (rstep >> j & 1u) ? CC : 0;
+      return;
+    }
+    rc = 0;
+    ++r_unit;
+    if (r_unit % a.ncb == 0) raw_sources(r_unit);            // next spatial block (channel block 0 again)
+    else {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) rsrc[j] -= (rstep >> j & 1u) ? (nch - 1) * CC : 0;
+    }
+  };
+  int u_cb = u_first % a.ncb, upc = 0;
+  const unsigned char* usrc = a.U + (int64_t)u_cb * nch * 4 * U_PHASE + T * 16;
+  auto issue_u = [&](int ub) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) glds16(usrc + k * (NT2 * 16), Ub + ub + (k * NT2 + wave * 64) * 16);
+  };
+  auto u_advance = [&]() {
+    if (++upc < nch * 4) { usrc += U_PHASE; return; }
+    upc = 0;
+    if (++u_cb == a.ncb) u_cb = 0;
+    usrc = a.U + (int64_t)u_cb * nch * 4 * U_PHASE + T * 16;
+  };
+
+  // ---- MFMA role: wave = tile half (wave & 1) x channel half ((wave >> 1) & 1) x xi-column half (wave >> 2)
+  const int w_th = wave & 1, w_kh = (wave >> 1) & 1, w_xh = wave >> 2;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int a_rd = w_xh * 6 * U_XP + lhi * (64 * 16) + (w_kh * 32 + l31) * 16;       // U image: A operand, rows = output channels
+  const int b_rd = w_xh * 6 * V_XP + lhi * V_REGION + (w_th * 32 + l31) * 16;        // V image: B operand, columns = tiles
+  acc_zero_range<ACC0, 128>();
+
+  // ---- output transform of a finished unit (see the head of this kernel). Accumulator of xi (row i, column 2 xh + jj): a[(2 i + jj)
+  //      * 16 ..]; lane = tile l31 of the wave's tile half, channels cb * 64 + 32 kh + 8 j + 4 lhi + (0..3) for register group j
+  int e_unit = u_first, ec = 0;
+  auto unit_epilogue = [&]() __attribute__((always_inline)) {
+    const UnitPos eu = unit_at(e_unit, a);
+    const int tile = w_th * 32 + l31;
+    const int tr = tile >> 2, tc = tile & 3;
+    const int Rg = eu.R0 + tr;
+    const int tx = eu.bc * TB_COLS + tc;
+    int n2 = eu.n0, ty2 = eu.ty0 + tr;
+    while (ty2 >= a.th) { ty2 -= a.th; ++n2; }
+    const int oy = 2 * ty2 + w_xh, ox = 2 * tx;                   // this wave finalises output row xh of the 2 x 2
+    const bool in = Rg < a.RT && tx < a.tw && oy < a.H;
+    const bool x1 = ox + 1 < a.W;
+    const int kb = eu.cb * WG_K + w_kh * 32 + 4 * lhi;
+    float* const yo = a.y + (((int64_t)n2 * a.H + oy) * a.W + ox) * a.cout + kb;
+    unsigned char* const X0 = Rb;                                 // exchange areas: [column 2][wave 8][lane 64] 16 bytes = 16 KB each
+    unsigned char* const X1 = Vb + V_PHASE;                       // (V[1]: read by phase 3, rewritten in the next phase 0)
+    const int x_wr = wave * 1024 + lane * 16, x_rd = (wave ^ 4) * 1024 + lane * 16;
+    acc_settle();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                 // every wave is done with the raw block and V[1]
+    auto group_q = [&](auto jc, f32x4 (&keep)[2], unsigned char* X) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      // rows first, streaming over the accumulators: S0[x] = M[0][x] + M[1][x] + M[2][x], S1[x] = M[1][x] - M[2][x] - M[3][x] for the
+      // wave's two columns x (A^T = [1 1 1 0; 0 1 -1 -1] from the left), then the columns: xh = 0 holds columns 0, 1 of M
+      // (Q[.][0] = S[0] + S[1], Q[.][1] = S[1]), xh = 1 columns 2, 3 (Q[.][0] = S[0], Q[.][1] = -S[0] - S[1])
+#define CRB_ACC4(I, JJ) ((f32x4){acc_read<ACC0 + (2 * I + JJ) * 16 + 4 * j>(), acc_read<ACC0 + (2 * I + JJ) * 16 + 4 * j + 1>(), \
+                                 acc_read<ACC0 + (2 * I + JJ) * 16 + 4 * j + 2>(), acc_read<ACC0 + (2 * I + JJ) * 16 + 4 * j + 3>()})
+      f32x4 S0[2], S1[2];
+      {
+        const f32x4 m00 = CRB_ACC4(0, 0), m01 = CRB_ACC4(0, 1), m10 = CRB_ACC4(1, 0), m11 = CRB_ACC4(1, 1);
+        S0[0] = m00 + m10; S0[1] = m01 + m11;
+        S1[0] = m10; S1[1] = m11;
+      }
+      {
+        const f32x4 m20 = CRB_ACC4(2, 0), m21 = CRB_ACC4(2, 1), m30 = CRB_ACC4(3, 0), m31 = CRB_ACC4(3, 1);
+        S0[0] = S0[0] + m20; S0[1] = S0[1] + m21;
+        S1[0] = S1[0] - m20 - m30; S1[1] = S1[1] - m21 - m31;
+      }
+#undef CRB_ACC4
+      const f32x4 q00 = w_xh ? S0[0] : S0[0] + S0[1], q01 = w_xh ? -S0[0] - S0[1] : S0[1];
+      const f32x4 q10 = w_xh ? S1[0] : S1[0] + S1[1], q11 = w_xh ? -S1[0] - S1[1] : S1[1];
+      keep[0] = w_xh ? q10 : q00;
+      keep[1] = w_xh ? q11 : q01;
+      *reinterpret_cast<f32x4*>(X + x_wr) = w_xh ? q00 : q10;              // the partner's row
+      *reinterpret_cast<f32x4*>(X + 8 * 1024 + x_wr) = w_xh ? q01 : q11;
+    };
+    auto group_out = [&](auto jc, const f32x4 (&keep)[2], const unsigned char* X) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      const f32x4 o0 = *reinterpret_cast<const f32x4*>(X + x_rd), o1 = *reinterpret_cast<const f32x4*>(X + 8 * 1024 + x_rd);
+      f32x4 bias = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (a.bias) {
+        const float* bp = a.bias + eu.cb * WG_K + __builtin_amdgcn_readfirstlane(w_kh) * 32 + 8 * j;
+        const f32x4 b0 = sload4(bp), b1 = sload4(bp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias[e] = lhi ? b1[e] : b0[e];
+      }
+      // (xi-column half 0 first in both waves: the two rows of an output are formed by the same expression)
+      f32x4 y0 = (w_xh ? o0 + keep[0] : keep[0] + o0) + bias, y1 = (w_xh ? o1 + keep[1] : keep[1] + o1) + bias;
+      if (a.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y0[e] = fmaxf(y0[e], 0.f); y1[e] = fmaxf(y1[e], 0.f); }
+      }
+      f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (in && MODE != 8) {
+        float* o = yo + 8 * j;
+        *reinterpret_cast<f32x4*>(o) = y0;
+        if (x1) *reinterpret_cast<f32x4*>(o + a.cout) = y1;
+      }
+      if (a.stats) {
+        if (in) {
+          const float m1 = x1 ? 1.f : 0.f;
+          s1 = y0 + y1 * m1;
+          s2 = y0 * y0 + (y1 * y1) * m1;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float u = s1[e], v = s2[e];
+#define CRB_ROW_ROR_ADD(x, ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false))
+          CRB_ROW_ROR_ADD(u, 0x128); CRB_ROW_ROR_ADD(v, 0x128);       // row_ror:8
+          CRB_ROW_ROR_ADD(u, 0x124); CRB_ROW_ROR_ADD(v, 0x124);
+          CRB_ROW_ROR_ADD(u, 0x122); CRB_ROW_ROR_ADD(v, 0x122);
+          CRB_ROW_ROR_ADD(u, 0x121); CRB_ROW_ROR_ADD(v, 0x121);
+#undef CRB_ROW_ROR_ADD
+          u += __shfl_xor(u, 16, 64);
+          v += __shfl_xor(v, 16, 64);
+          s1[e] = u;
+          s2[e] = v;
+        }
+        if (l31 == 0) {                      // slab = (spatial block, tile half, output row)
+          const int64_t blk = (int64_t)(eu.R0 / TB_ROWS) * a.tw4 + eu.bc;
+          float* so = a.stats + (((blk * 2 + w_th) * 2 + w_xh) * 2) * a.cout + kb + 8 * j;
+          *reinterpret_cast<f32x4*>(so) = s1;
+          *reinterpret_cast<f32x4*>(so + a.cout) = s2;
+        }
+      }
+    };
+    f32x4 k0[2], k1[2];
+    group_q(std::integral_constant<int, 0>{}, k0, X0);
+    group_q(std::integral_constant<int, 1>{}, k1, X1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    group_out(std::integral_constant<int, 0>{}, k0, X0);
+    group_out(std::integral_constant<int, 1>{}, k1, X1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                 // the partners have read round 0
+    group_q(std::integral_constant<int, 2>{}, k0, X0);
+    group_q(std::integral_constant<int, 3>{}, k1, X1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    group_out(std::integral_constant<int, 2>{}, k0, X0);
+    group_out(std::integral_constant<int, 3>{}, k1, X1);
+    acc_zero_range<ACC0, 128>();
+    ++e_unit;
+    // (the next phase's barrier orders these exchange reads in front of the raw copy and the V stores that reuse the areas)
+  };
+
+  // ---- input transform pieces (see the first form): col<b>, and per xi two steps: [value, remainders] and [packs + 3 stores]
+  f32x2 tp[4][4];
+  f32x2 sv, sr1, sr2;
+  auto t_read = [&](f32x2 (&d)[4][4]) {
+    const unsigned char* p = Rb + raw_rd;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        d[i][b] = *reinterpret_cast<const f32x2*>(p + (i * RAW_PX + (b >> 1) + 5 * (b & 1)) * 64);
+  };
+  auto t_col = [&](const f32x2 (&d)[4][4], int b) __attribute__((always_inline)) {
+    tp[0][b] = d[0][b] - d[2][b];
+    tp[1][b] = d[1][b] + d[2][b];
+    tp[2][b] = d[2][b] - d[1][b];
+    tp[3][b] = d[1][b] - d[3][b];
+    asm volatile("" : "+v"(tp[0][b]), "+v"(tp[1][b]), "+v"(tp[2][b]), "+v"(tp[3][b]));
+  };
+  auto trunc16 = [](float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); };
+  auto pack_hi = [](const f32x2& x) { return (__float_as_uint(x[0]) >> 16) | (__float_as_uint(x[1]) & 0xffff0000u); };
+  auto t_xi = [&](unsigned char* V, auto rcst, auto jcst, auto scst) __attribute__((always_inline)) {
+    constexpr int r = decltype(rcst)::value, jx = decltype(jcst)::value, s = decltype(scst)::value;
+    if (MODE == 2) return;
+    if constexpr (s == 0) {
+      if constexpr (jx == 0) sv = tp[r][0] - tp[r][2];
+      else if constexpr (jx == 1) sv = tp[r][1] + tp[r][2];
+      else if constexpr (jx == 2) sv = tp[r][2] - tp[r][1];
+      else sv = tp[r][1] - tp[r][3];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) sr1[e] = sv[e] - trunc16(sv[e]);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) sr2[e] = sr1[e] - trunc16(sr1[e]);
+      asm volatile("" : "+v"(sv), "+v"(sr1), "+v"(sr2));
+    } else {
+      if (MODE == 7) { asm volatile("" :: "v"(pack_hi(sv)), "v"(pack_hi(sr1)), "v"(pack_hi(sr2))); return; }
+      *reinterpret_cast<unsigned*>(V + v_wr + (jx * 3 + 0) * V_XP) = pack_hi(sv);
+      *reinterpret_cast<unsigned*>(V + v_wr + (jx * 3 + 1) * V_XP) = pack_hi(sr1);
+      *reinterpret_cast<unsigned*>(V + v_wr + (jx * 3 + 2) * V_XP) = pack_hi(sr2);
+    }
+  };
+  auto t_advance = [&]() {
+    if (++tcnt < nch) return;
+    tcnt = 0;
+    ++t_unit;
+    if (t_unit % a.ncb == 0) raw_rd = raw_base(t_unit);
+  };
+
+  // ---- phases (as in the first form; per wave 2 xi = 12 MFMAs that alternate between the two accumulators)
+  unsigned long long st_wait = 0, st_bar = 0, st_head = 0, st_body = 0, st_epi = 0, st_start = 0;      // MODE 9: s_memtime sums
+  int ub_cur = 0, ub_nxt = U_PHASE, ub_nn = 2 * U_PHASE;
+  auto phase = [&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int rn = (i + 1) & 3;
+    unsigned long long tm0 = 0, tm1 = 0, tm2 = 0;
+    if (MODE == 9) tm0 = __builtin_amdgcn_s_memtime();
+    if (i == 1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    if (MODE == 9) tm1 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_barrier();
+    if (MODE == 9) { tm2 = __builtin_amdgcn_s_memtime(); st_wait += tm1 - tm0; st_bar += tm2 - tm1; }
+    unsigned char* const Vn = Vb + ((i + 1) & 1) * V_PHASE;
+    const unsigned char* const Vc = Vb + (i & 1) * V_PHASE + b_rd;
+    const unsigned char* const Uc = Ub + ub_cur + a_rd;
+    // pieces 0 and 2 of both xi first (8 fragments); the two middle pieces take the registers of the spent (piece 2) fragments
+    // behind the fourth MFMA: 32 fragment registers instead of 48 (the wave has 120 + what the compiler parks in a0 .. a7)
+    bf16x8 A[2][3], B[2][3];
+    auto op_read = [&](int p) __attribute__((always_inline)) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        if (MODE == 4) { asm volatile("" : "=v"(A[jj][p]), "=v"(B[jj][p])); continue; }
+        A[jj][p] = *reinterpret_cast<const bf16x8*>(Uc + (jj * 3 + p) * U_XP);
+        B[jj][p] = *reinterpret_cast<const bf16x8*>(Vc + (jj * 3 + p) * V_XP);
+      }
+    };
+    op_read(0);
+    op_read(2);
+    f32x2 d[4][4];
+    if (i == 3) { t_read(d); t_advance(); }
+    if (MODE != 3) {
+      if (i == 0 && MODE != 6) { issue_raw(); r_advance(); }
+      if (MODE != 5) { issue_u(ub_nn); u_advance(); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE == 9) { tm0 = __builtin_amdgcn_s_memtime(); st_head += tm0 - tm2; }
+    // piece k (behind MFMA k of the phase): phase 3 starts with the four column passes (columns 0, 2 first: xi 0 needs them)
+    auto piece = [&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
+      constexpr int k0 = (i == 3) ? k - 4 : k;
+      if constexpr (i == 3 && k < 4) {
+        t_col(d, k == 0 ? 0 : k == 1 ? 2 : k == 2 ? 1 : 3);
+      } else if constexpr (k0 >= 0 && k0 < 8) {
+        t_xi(Vn, std::integral_constant<int, rn>{}, std::integral_constant<int, k0 / 2>{}, std::integral_constant<int, k0 % 2>{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto pair = [&](auto cc, int pa, int pb) __attribute__((always_inline)) {      // product (piece pa of U) x (piece pb of V) for both xi
+      constexpr int c = decltype(cc)::value;
+      if (MODE != 1) mfma_acc8<2 * i + 0>(A[0][pa], B[0][pb]);
+      piece(std::integral_constant<int, 2 * c>{});
+      if (MODE != 1) mfma_acc8<2 * i + 1>(A[1][pa], B[1][pb]);
+      piece(std::integral_constant<int, 2 * c + 1>{});
+    };
+    pair(std::integral_constant<int, 0>{}, 0, 2);
+    pair(std::integral_constant<int, 1>{}, 2, 0);
+    op_read(1);
+    __builtin_amdgcn_sched_barrier(0);
+    pair(std::integral_constant<int, 2>{}, 0, 0);
+    pair(std::integral_constant<int, 3>{}, 1, 1);
+    pair(std::integral_constant<int, 4>{}, 0, 1);
+    pair(std::integral_constant<int, 5>{}, 1, 0);
+    if (MODE == 9) st_body += __builtin_amdgcn_s_memtime() - tm0;
+    const int t = ub_cur; ub_cur = ub_nxt; ub_nxt = ub_nn; ub_nn = t;
+  };
+
+  // ---- prologue: raw(0), U(0), U(1) in one round trip, raw(0) -> tp -> V(0)
+  if (MODE == 9) st_start = __builtin_amdgcn_s_memtime();
+  issue_raw(); r_advance();
+  issue_u(0); u_advance();
+  issue_u(U_PHASE); u_advance();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  {
+    f32x2 d[4][4];
+    t_read(d); t_advance();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) t_col(d, b);
+  }
+#define CRB_T_XI_ALL(JX)                                                                                                      \
+  t_xi(Vb, std::integral_constant<int, 0>{}, std::integral_constant<int, JX>{}, std::integral_constant<int, 0>{});            \
+  t_xi(Vb, std::integral_constant<int, 0>{}, std::integral_constant<int, JX>{}, std::integral_constant<int, 1>{})
+  CRB_T_XI_ALL(0); CRB_T_XI_ALL(1); CRB_T_XI_ALL(2); CRB_T_XI_ALL(3);
+#undef CRB_T_XI_ALL
+
+  for (int cg = 0; cg < total_chunks; ++cg) {
+    phase(std::integral_constant<int, 0>{});
+    phase(std::integral_constant<int, 1>{});
+    phase(std::integral_constant<int, 2>{});
+    phase(std::integral_constant<int, 3>{});
+    if (++ec == nch) {
+      ec = 0;
+      unsigned long long te = 0;
+      if (MODE == 9) te = __builtin_amdgcn_s_memtime();
+      unit_epilogue();
+      if (MODE == 9) st_epi += __builtin_amdgcn_s_memtime() - te;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (copies requested past the end of the range)
+  if (MODE == 9 && g_wino4_dbg && lane == 0) {
+    unsigned long long* o = g_wino4_dbg + ((int64_t)blockIdx.x * 8 + wave) * 8;
+    o[0] = st_wait; o[1] = st_bar; o[2] = st_head; o[3] = st_body; o[4] = st_epi; o[5] = __builtin_amdgcn_s_memtime() - st_start;
+    o[6] = (unsigned long long)total_chunks; o[7] = (unsigned long long)(u_end - u_first);
+  }
+}
+
 }  // namespace
 
-CRB_KNOB g_wino4_mode = 0;      // measurement builds: 1 = no MFMAs, 2 = no transform, 3 = no DMA in the loop
+CRB_KNOB g_wino4_mode [[maybe_unused]] = 0;      // measurement builds: see MODE
+CRB_KNOB g_wino4_variant [[maybe_unused]] = 2;   // 2 = two waves per SIMD (the product kernel), 1 = the first form (measurement library)
 #ifdef CRB_MEASURE
-extern "C" int crb_winograd4_set_mode(int mode) { g_wino4_mode = (mode >= 1 && mode <= 3) ? mode : 0; return CRB_OK; }
+extern "C" int crb_winograd4_set_debug(void* dev_buf) {
+  unsigned long long* p = (unsigned long long*)dev_buf;
+  CRB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wino4_dbg), &p, sizeof(p)));
+  return CRB_OK;
+}
+extern "C" int crb_winograd4_set_variant(int v) { g_wino4_variant = v == 1 ? 1 : 2; return CRB_OK; }
+extern "C" int crb_winograd4_set_mode(int mode) { g_wino4_mode = (mode >= 1 && mode <= 9) ? mode : 0; return CRB_OK; }
 #endif
 
 // ceil(H / 2) >= 16: a block of 16 tile rows touches at most two images (the raw block keeps ONE gap)
@@ -692,13 +1121,32 @@ static int winograd4_launch(const float* x, const void* U, float* y, int N, int 
   if (nb >= (1LL << 26)) return CRB_ERR_ARG;
   a.nblocks = (int)nb;
   a.ncb = cout / WG_K;
-  int mode = 0;
-  auto kern = winograd4_kernel<0>;
+  int mode = 0, nt = NT2;
+  auto kern = winograd4b_kernel<0>;
 #ifdef CRB_MEASURE
   mode = g_wino4_mode;
-  if (mode == 1) kern = winograd4_kernel<1>;
-  if (mode == 2) kern = winograd4_kernel<2>;
-  if (mode == 3) kern = winograd4_kernel<3>;
+  if (mode == 1) kern = winograd4b_kernel<1>;
+  if (mode == 2) kern = winograd4b_kernel<2>;
+  if (mode == 3) kern = winograd4b_kernel<3>;
+  if (mode == 4) kern = winograd4b_kernel<4>;
+  if (mode == 5) kern = winograd4b_kernel<5>;
+  if (mode == 6) kern = winograd4b_kernel<6>;
+  if (mode == 7) kern = winograd4b_kernel<7>;
+  if (mode == 8) kern = winograd4b_kernel<8>;
+  if (mode == 9) kern = winograd4b_kernel<9>;
+  if (g_wino4_variant == 1) {              // first form (one wave per SIMD): A/B only
+    nt = NT;
+    kern = winograd4_kernel<0>;
+    if (mode == 1) kern = winograd4_kernel<1>;
+    if (mode == 2) kern = winograd4_kernel<2>;
+    if (mode == 3) kern = winograd4_kernel<3>;
+    if (mode == 4) kern = winograd4_kernel<4>;
+    if (mode == 5) kern = winograd4_kernel<5>;
+    if (mode == 6) kern = winograd4_kernel<6>;
+    if (mode == 7) kern = winograd4_kernel<7>;
+    if (mode == 8) kern = winograd4_kernel<8>;
+    mode += 16;                            // (attribute bit of the instance)
+  }
 #endif
   int dev = 0;
   const int n_cu = device_cus4(&dev);
@@ -711,7 +1159,7 @@ static int winograd4_launch(const float* x, const void* U, float* y, int N, int 
   const int64_t grid = units < n_cu ? units : n_cu;
   unsigned seq = (g_dev_seq4[dev].fetch_add(1, std::memory_order_relaxed) + 1) & 0xffffffu;
   a.seq = (grid == n_cu) ? (seq ? seq : 1) : 0;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nt), LDS_BYTES, (hipStream_t)stream, a);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
@@ -724,7 +1172,7 @@ extern "C" int crb_conv3x3_winograd4_nhwc(const float* x, const void* U, float* 
 extern "C" int64_t crb_winograd4_stats_slabs(int N, int H, int W) {
   if (N <= 0 || H <= 0 || W <= 0) return 0;
   const int64_t th = (H + 1) / 2, tw4 = ((W + 1) / 2 + TB_COLS - 1) / TB_COLS;
-  return 2 * ((N * th + TB_ROWS - 1) / TB_ROWS) * tw4;
+  return (g_wino4_variant == 1 ? 2 : 4) * ((N * th + TB_ROWS - 1) / TB_ROWS) * tw4;       // (spatial block, tile half, output row)
 }
 
 extern "C" int crb_conv3x3_winograd4_stats_nhwc(const float* x, const void* U, float* y, float* stats, int N, int H, int W, int cin,

@@ -65,7 +65,7 @@ class PoolEvalStrategy(Strategy):
         rank, world = self._world()
         gts = getattr(self, '_local_gt_stats', None)
         widen = gts is not None and gts.shape[0] == local_rows.shape[0]
-        if world > 1:
+        if world > 1 or scoring.FORCE_COLLECTIVE:
             # the row width of the collective must be the same on every rank: widen only if EVERY rank collected the
             # statistics of all of its frames (a rank whose frames carry no gt_boxes would otherwise send narrower rows
             # and the all-gather would hang or corrupt)

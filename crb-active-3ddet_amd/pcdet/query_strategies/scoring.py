@@ -101,10 +101,15 @@ def shard_indices(n, rank, world):
 COLLECTIVE_LOG = None
 
 
+# CRB_FORCE_DIST=1: the collectives run at world size 1 too (a world-size-1 `nccl` group on one GPU loads RCCL and executes them:
+# tests/test_multirank_gpu.py); results are the same rows
+FORCE_COLLECTIVE = __import__('os').environ.get('CRB_FORCE_DIST', '0') == '1'
+
+
 def all_gather_rows(local, n_total, world, backend_device=None):
     """local (per, S) rows of this rank (rank-strided shard) -> (n_total, S) rows in dataset order, on every rank.
     One all_gather_into_tensor (RCCL over xGMI on the GPU node; gloo in the CPU tests)."""
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVE:
         return local[:n_total]
     per = local.shape[0]
     log = COLLECTIVE_LOG

@@ -18,6 +18,13 @@ int crb_mask_sort_set_rank_bits(int mode);
 int crb_winograd_set_mode(int mode);
 /* measurement builds of the second Winograd design (wrong results): 1 = no MFMAs, 2 = no input transform, 3 = no LDS-DMA in the loop; 5 .. 13: see csrc/winograd_conv2.hip; 4 below */
 int crb_winograd2_set_mode(int mode);
+/* measurement builds of the split-bf16 Winograd kernel (wrong results): 1 = no MFMAs, 2 = no input transform, 3 = no LDS-DMA in the loop,
+ * 4 = no operand reads, 5 = no U copies, 6 = no raw copies, 7 = no V stores, 8 = no output stores, 9 = stamps (csrc/winograd_conv4.hip) */
+int crb_winograd4_set_mode(int mode);
+/* A/B: 2 = the product kernel (two waves per SIMD, xi split over wave pairs), 1 = the first form (one 512-register wave per SIMD) */
+int crb_winograd4_set_variant(int v);
+/* mode 9 (correct results + s_memtime sums per (workgroup, wave): {counter wait, barrier, phase head, phase body, epilogue, total, chunks, units}): 8 uint64 per wave, 8 waves per workgroup; NULL = off */
+int crb_winograd4_set_debug(void* dev_buf_u64x64_per_wg);
 /* mode 4 (correct results + stamps) writes 16 uint64 per workgroup {s_memtime: start, after prologue, after chunks, cycles parked at the chunk barriers; wall_clock64 (100 MHz): start, end; XCC id; units; per-stage cycle sums}. NULL = off */
 int crb_winograd2_set_debug(void* dev_buf_u64x16_per_wg);
 /* A/B: 1 = persistent workgroups (one per CU, contiguous unit ranges, one pipeline; default), 0 = one unit per workgroup */

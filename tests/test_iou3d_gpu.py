@@ -183,3 +183,52 @@ def test_model_nms_utils_contract(dev):
     np.testing.assert_array_equal(pl.cpu().numpy(), np.r_[np.zeros(len(w0), np.int64), np.ones(len(w1), np.int64)])
     np.testing.assert_array_equal(ps.cpu().numpy(), np.r_[cls[w0, 0], cls[w1, 1]])
     np.testing.assert_array_equal(pb.cpu().numpy(), np.r_[b[w0], b[w1]])
+
+
+def _oracle_nms_first(b, thresh, keep_n):
+    """the oracle's greedy NMS stopped after keep_n picks (pairwise IoU from the pinned oracle, one candidate against the kept set)"""
+    kept = []
+    for i in range(len(b)):
+        if kept and (oracle.boxes_pairwise(b[i:i + 1], b[kept], 1)[0] > thresh).any():
+            continue
+        kept.append(i)
+        if len(kept) == keep_n:
+            break
+    return np.asarray(kept, np.int64)
+
+
+def test_nms_picks_on_unfiltered_training_size_proposal_sets_counted(dev):
+    """how often do the picks differ from the oracle's when NOTHING is filtered? 100 seeded sets of 9,000
+    score-sorted proposals (the training NMS: threshold 0.8, 512 kept) straight from the box generator - 80 sets of loosely
+    scattered boxes (most survive) and 20 of tight clusters around 60 objects (half of the candidates are suppressed, IoUs inside
+    a cluster lie around the threshold). The first 512 picks are compared as they are; every difference has to be explained by a pair of
+    boxes whose IoU lies within 1e-4 of the threshold (f32 sin / cos of a different libm on the two sides). The test prints how
+    many sets and boxes differ - the number README / DESIGN section 4 quote next to "bit-exact on margin-safe inputs"."""
+    from pcdet.ops.iou3d_nms import iou3d_nms_utils as U
+    thresh, keep_n, n = 0.8, 512, 9000
+    differing, boxes_diff = 0, 0
+    for seed in range(100):
+        rng = np.random.default_rng(70000 + seed)
+        if seed < 80:
+            b, s = detection_boxes(rng, n, n_obj=n // 12)
+        else:             # proposal-like: 150 near-copies of each of 60 boxes (IoU around the threshold inside a cluster)
+            c, _ = detection_boxes(rng, 60, n_obj=60)
+            b = np.repeat(c, n // 60, axis=0).copy()
+            b[:, :2] += rng.normal(0, 0.12, (n, 2)).astype(np.float32)
+            b[:, 3:6] *= rng.uniform(0.95, 1.05, (n, 3)).astype(np.float32)
+            b[:, 6] += rng.normal(0, 0.03, n).astype(np.float32)
+            s = rng.uniform(0, 1, n).astype(np.float32)
+        b = b[np.argsort(-s, kind='stable')]
+        keep, _ = U.nms_gpu(_t(b, dev), torch.arange(n, 0, -1, device=dev).float(), thresh)
+        k = keep.cpu().numpy()[:keep_n]
+        ref = _oracle_nms_first(b, thresh, keep_n)
+        if not np.array_equal(k, ref):
+            differing += 1
+            sym = np.setxor1d(k, ref)
+            boxes_diff += len(sym)
+            first = int(min(sym))                        # the first box the two sides disagree on: one of its pairs is in the margin
+            iou = oracle.boxes_pairwise(b[first:first + 1], b[:first], 1)[0]
+            assert (np.abs(iou - thresh) < 1e-4).any(), (seed, first)
+    print('NMS picks, 100 unfiltered sets of %d proposals (threshold %.1f, first %d picks): %d sets differ from the oracle, %d '
+          'boxes in the symmetric difference in total' % (n, thresh, keep_n, differing, boxes_diff))
+    assert differing <= 10

@@ -220,3 +220,89 @@ def test_bench_two_rank_dry_run_prints_the_contract_line(tmp_path):
     # first-real-run hygiene: every rank searched MIOpen solvers in its own user db, warm-up time is reported per rank
     assert len(d['warmup_seconds_per_rank']) == 2 and all(v > 0 for v in d['warmup_seconds_per_rank'])
     assert d['miopen_user_db'] == 'per rank'
+
+
+# ---- RCCL on the one GPU of this box: a world-size-1 `nccl` process group loads librccl and executes the
+#      collectives of the N > 1 code before the driver's 8-GPU node ever sees them
+
+def _nccl1_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    for p in (ROOT, os.path.join(ROOT, 'crb-active-3ddet_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['CRB_FORCE_DIST'] = '1'                  # (read at import: the collectives run at world size 1 too)
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    assert dist.get_backend() == 'nccl'
+    from pcdet.query_strategies import scoring
+    assert scoring.FORCE_COLLECTIVE
+    # (a) the records all-gather: same rows back, through all_gather_into_tensor on RCCL
+    scoring.COLLECTIVE_LOG = []
+    local = torch.randn(7, 1287, device=dev)
+    got = scoring.all_gather_rows(local, 5, 1)
+    assert torch.equal(got, local[:5])
+    emb = torch.randn(3, 65536, device=dev)
+    assert torch.equal(scoring.all_gather_rows(emb, 3, 1), emb)
+    log = scoring.COLLECTIVE_LOG
+    assert len(log) == 2 and all(c['backend'] == 'nccl' for c in log) and log[1]['bytes_per_rank'] == 3 * 65536 * 4
+    # all-reduce / barrier / all_gather list (what bench.py's timing brackets use)
+    t = torch.tensor([3.5], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    assert float(t) == 3.5
+    # (b) one DDP step of SECOND over RCCL = the same step without the wrapper (one rank: the average of one gradient)
+    from pcdet.datasets import SyntheticDataset
+    from pcdet.datasets.synthetic import kitti_batch
+    from pcdet.model_cfgs import second_cfg
+    from pcdet.models import build_network
+    torch.manual_seed(0)
+    model = build_network(second_cfg().MODEL, 3, SyntheticDataset(num_frames=2)).to(dev)
+    model.train()
+    pts, off, gt = kitti_batch(3000, 2, 6000)
+    bidx = np.repeat(np.arange(2, dtype=np.float32), np.diff(off))
+
+    def batch():
+        return {'points': torch.from_numpy(np.concatenate([bidx[:, None], pts], 1)).to(dev),
+                'point_frame_offsets': torch.from_numpy(off).to(dev), 'gt_boxes': torch.from_numpy(gt).to(dev), 'batch_size': 2}
+    grads = []
+    for net in (model, torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], gradient_as_bucket_view=True, bucket_cap_mb=4)):
+        model.zero_grad(set_to_none=True)
+        ret, _, _ = net(batch())
+        ret['loss'].mean().backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None]).double().cpu())
+    torch.save({'plain': grads[0], 'ddp': grads[1]}, os.path.join(out_dir, 'nccl1.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_world_size_one_group_runs_the_collectives_and_a_ddp_step(tmp_path):
+    out = str(tmp_path)
+    _run(_nccl1_worker, 1, (out,))
+    g = torch.load(os.path.join(out, 'nccl1.pt'))
+    rel = float((g['plain'] - g['ddp']).norm() / g['plain'].norm())
+    assert torch.isfinite(g['ddp']).all() and rel < 2e-3, rel           # (MIOpen's weight-gradient kernels use atomics: not bit-equal)
+
+
+def test_bench_one_rank_over_rccl_prints_the_contract_line():
+    """`torchrun --nproc-per-node 1 bench.py --gpus 1` with CRB_FORCE_DIST=1: the process group is `nccl` (RCCL), the model is
+    DDP-wrapped, the barriers / max-over-ranks reductions and the two scoring all-gathers execute on the GPU - the code the
+    driver's N = 2, 4, 8 runs will execute, minus the second device."""
+    import json
+    import subprocess
+    env = dict(os.environ, CRB_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('CRB_DIST_BACKEND', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29547', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+           '--scoring-pool', '32', '--scoring-repeats', '1', '--pvrcnn-steps', '0', '--bf16x3-steps', '0', '--no-cpu-baseline']
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['value'] > 0
+    coll = d['crb_scoring']['collectives']
+    assert len(coll) >= 2 and all(c['backend'] == 'nccl' for c in coll)
+    assert 4 * 65536 in {c['bytes_per_rank'] // c['rows_per_rank'] for c in coll}

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from oracle import anchor_head_oracle as aho
-from golden.make_goldens import small_head_cfg
+from golden._constants import small_head_cfg
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 

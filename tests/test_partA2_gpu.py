@@ -18,7 +18,7 @@ def _close(got, ref, rel):
 
 
 def _head_and_batch(dev):
-    from golden.make_goldens import parta2_cfg, parta2_inputs, seeded_state
+    from golden._constants import parta2_cfg, parta2_inputs, seeded_state
     from pcdet.models.roi_heads import PartA2FCHead
     head = PartA2FCHead(input_channels=32, model_cfg=parta2_cfg(), num_class=1)
     g = np.load(os.path.join(GOLD, 'ref_partA2.npz'))

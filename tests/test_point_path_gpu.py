@@ -34,7 +34,7 @@ class _Level:
 
 
 def _build(dev):
-    from golden.make_goldens import PP_KEYPOINTS, PP_PCR, PP_VOXEL, point_path_inputs, seeded_state
+    from golden._constants import PP_KEYPOINTS, PP_PCR, PP_VOXEL, point_path_inputs, seeded_state
     from pcdet.model_cfgs import pv_rcnn_cfg
     from pcdet.models.backbones_3d.pfe.voxel_set_abstraction import VoxelSetAbstraction
     from pcdet.models.roi_heads.pvrcnn_head import PVRCNNHead
@@ -129,7 +129,7 @@ def test_point_path_train_matches_reference_classes_and_gradients(dev):
 
 def test_stack_sa_module_alone_with_ragged_counts_matches_reference(dev):
     """StackSAModuleMSG.forward (pointnet2_modules.py:78-112) on the x_conv2 source: 40 queries in frame 0, 7 in frame 1"""
-    from golden.make_goldens import PP_PCR, PP_VOXEL
+    from golden._constants import PP_PCR, PP_VOXEL
     from pcdet.utils import common_utils
     vsa, head, batch, inp, g = _build(dev)
     sa = vsa.SA_layers[1].eval()

@@ -123,7 +123,7 @@ def _device_batch(g, dev):
 
 def _fake_model():
     from pcdet.config import EasyDict
-    from golden.make_goldens import POST_CFG
+    from golden._constants import POST_CFG
     return types.SimpleNamespace(model_cfg=EasyDict({
         'POST_PROCESSING': POST_CFG, 'DENSE_HEAD': {'ANCHOR_GENERATOR_CONFIG': [{'class_name': n} for n in NAMES]}}))
 

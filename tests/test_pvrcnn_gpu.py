@@ -289,7 +289,7 @@ def test_train_step_matches_the_reference_detector(dev, kind):
     largest entry (the backward through the BEV backbone's 11 train-mode BatchNorm layers amplifies f32 rounding to several
     1e-3 at B = 2 on any implementation: tests/test_winograd_gpu.py)."""
     import os
-    from golden.make_goldens import PV_FIRST_FRAME, PV_KEYPOINTS, PV_KINDS, pv_grads, pv_seeded_state
+    from golden._constants import PV_FIRST_FRAME, PV_KEYPOINTS, PV_KINDS, pv_grads, pv_seeded_state
     from pcdet.datasets import SyntheticDataset
     from pcdet.model_cfgs import pv_rcnn_cfg
     from pcdet.models import build_network
