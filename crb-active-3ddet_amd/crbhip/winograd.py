@@ -2,8 +2,9 @@
 than the direct convolution, results equal to it up to f32 rounding of the transforms (4e-7 of the output scale against an f64
 convolution; MIOpen's implicit GEMM: 1.2e-6).
 
-Two kernels: the round-4 design (crb_conv3x3_winograd2_nhwc, `*2` functions; 0.77 ms per 128->128 @ 16x200x176 call against
-MIOpen's 1.41) is what the BEV backbone runs by default — `conv3x3` (training: forward + input gradient) and `fold` / `conv3x3_U2`
+Kernels: forward and input gradient run on the round-6 split-bf16 kernel (crb_conv3x3_winograd4_nhwc; KERNEL below) where it has
+an instance, otherwise on the round-4 f32-MFMA design (crb_conv3x3_winograd2_nhwc; 0.71 ms per 128->128 @ 16x200x176 call against
+MIOpen's 1.41), which also is what the `*2` names meant before round 6; the BEV backbone calls — `conv3x3` (training: forward + input gradient) and `fold` / `conv3x3_U2`
 (inference: BatchNorm folded, bias + ReLU in the epilogue); the round-3 kernel (crb_conv3x3_winograd_nhwc, 1.15 ms) stays for
 A/B runs in tools/."""
 import torch
@@ -75,6 +76,17 @@ def transform_weights2(g):
     return U
 
 
+# Which kernel runs the forward / input-gradient convolutions: 'x6' = csrc/winograd_conv4.hip (the 16 GEMMs as six bf16 MFMA passes over an
+# exact three-way split of the f32 operands: f32 in, f32 out, errors against f64 at the f32-MFMA kernel's level, ~11 % faster), 'f32' =
+# csrc/winograd_conv2.hip (exact-f32 MFMA). 'x6' needs Cin % 16 == 0, Cout % 64 == 0 and maps of at least 31 rows; everything else
+# (and everything under CRB_WINOGRAD_KERNEL=f32) runs on the f32-MFMA kernel. The weight gradient is the f32-MFMA kernel's either way.
+KERNEL = __import__('os').environ.get('CRB_WINOGRAD_KERNEL', 'x6')
+
+
+def _use4(kin, kout):
+    return KERNEL == 'x6' and bool(lib.crb_winograd4_supported(int(kin), int(kout), 31, 1))
+
+
 # images made ahead by prepare_weights2 (one launch for all layers of a step): key -> image. A key names the weight's memory, its
 # autograd version (an optimizer step bumps it) and the mode: a stale image cannot be returned
 _PREPARED = {}
@@ -82,7 +94,7 @@ PREPARE = __import__('os').environ.get('CRB_WINOGRAD_PREPARE', '1') == '1'
 
 
 def _prep_key(w, mode):
-    return (w.data_ptr(), w._version, tuple(w.shape), tuple(w.stride()), w.device.index, int(mode))
+    return (w.data_ptr(), w._version, tuple(w.shape), tuple(w.stride()), w.device.index, KERNEL, int(mode))
 
 
 def prepare_weights2(weights, input_grad=True):
@@ -99,22 +111,36 @@ def prepare_weights2(weights, input_grad=True):
             cout, cin = w.shape[0], w.shape[1]
             if lib.crb_winograd2_supported(int(cout if mode else cin), int(cin if mode else cout), 5, 1):
                 jobs.append((w.detach(), mode))
-    for lo in range(0, len(jobs), 32):
-        part = jobs[lo:lo + 32]
-        n = len(part)
-        Us = [torch.empty((16 * w.shape[0] * w.shape[1],), dtype=torch.float32, device=w.device) for w, _ in part]
-        wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w, _ in part])
-        up = (ctypes.c_void_p * n)(*[u.data_ptr() for u in Us])
-        st = (ctypes.c_int64 * (4 * n))(*[v for w, _ in part for v in w.stride()])
-        ci = (ctypes.c_int32 * n)(*[w.shape[1] for w, _ in part])
-        co = (ctypes.c_int32 * n)(*[w.shape[0] for w, _ in part])
-        md = (ctypes.c_int32 * n)(*[m for _, m in part])
-        check(lib.crb_winograd2_weights_conv_multi(n, wp, st, up, ci, co, md, cur_stream(part[0][0].device)),
-              'crb_winograd2_weights_conv_multi')
-        for (w, mode), U in zip(part, Us):
-            U.wino2_shape = (w.shape[0], w.shape[1]) if mode else (w.shape[1], w.shape[0])
-            U._crb_src = w              # (keeps the weight's storage alive: no other tensor can take the key's address meanwhile)
-            _PREPARED[_prep_key(w, mode)] = U
+    def kshape(w, mode):
+        return (w.shape[0], w.shape[1]) if mode else (w.shape[1], w.shape[0])
+    jobs4 = [(w, m) for w, m in jobs if _use4(*kshape(w, m))]
+    jobs2 = [(w, m) for w, m in jobs if not _use4(*kshape(w, m))]
+    for four, todo in ((True, jobs4), (False, jobs2)):
+        for lo in range(0, len(todo), 32):
+            part = todo[lo:lo + 32]
+            n = len(part)
+            if four:
+                Us = [torch.empty((int(lib.crb_winograd4_weights_bytes(w.shape[1], w.shape[0])),), dtype=torch.uint8, device=w.device)
+                      for w, _ in part]
+            else:
+                Us = [torch.empty((16 * w.shape[0] * w.shape[1],), dtype=torch.float32, device=w.device) for w, _ in part]
+            wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w, _ in part])
+            up = (ctypes.c_void_p * n)(*[u.data_ptr() for u in Us])
+            st = (ctypes.c_int64 * (4 * n))(*[v for w, _ in part for v in w.stride()])
+            ci = (ctypes.c_int32 * n)(*[w.shape[1] for w, _ in part])
+            co = (ctypes.c_int32 * n)(*[w.shape[0] for w, _ in part])
+            md = (ctypes.c_int32 * n)(*[m for _, m in part])
+            fn = lib.crb_winograd4_weights_conv_multi if four else lib.crb_winograd2_weights_conv_multi
+            check(fn(n, wp, st, up, ci, co, md, cur_stream(part[0][0].device)),
+                  'crb_winograd4_weights_conv_multi' if four else 'crb_winograd2_weights_conv_multi')
+            for (w, mode), U in zip(part, Us):
+                if four:
+                    U.wino4_shape = kshape(w, mode)
+                    U._crb_mode = mode
+                else:
+                    U.wino2_shape = kshape(w, mode)
+                U._crb_src = w              # (keeps the weight's storage alive: no other tensor can take the key's address meanwhile)
+                _PREPARED[_prep_key(w, mode)] = U
     return len(jobs)
 
 
@@ -132,6 +158,14 @@ def _weights_conv2(weight, mode):
         hit = _PREPARED.get(_prep_key(weight, mode))
         if hit is not None:
             return hit
+    cout, cin = weight.shape[0], weight.shape[1]
+    if _use4(cout if mode else cin, cin if mode else cout):
+        return _weights_conv4(weight, mode)
+    return _weights_conv2_f32(weight, mode)
+
+
+def _weights_conv2_f32(weight, mode):
+    """the f32-MFMA kernel's image (crb_winograd2_weights_conv)"""
     w = weight.detach()
     if w.dtype != torch.float32:
         w = w.float()
@@ -142,6 +176,14 @@ def _weights_conv2(weight, mode):
           'crb_winograd2_weights_conv')
     U.wino2_shape = (cout, cin) if mode else (cin, cout)
     return U
+
+
+def _f32_image_of(U):
+    """the f32-MFMA kernel's image of the weight a split-bf16 image was made from (maps with fewer than 31 rows), kept on the image"""
+    U2 = getattr(U, '_crb_f32', None)
+    if U2 is None:
+        U2 = U._crb_f32 = _weights_conv2_f32(U._crb_src, U._crb_mode)
+    return U2
 
 
 def weights_forward2(weight):
@@ -155,6 +197,10 @@ def weights_input_grad2(weight):
 def conv3x3_U2(x, U, bias=None, relu=False):
     """x (N,Cin,H,W) f32 channels_last, U = weights_forward2(...) -> y (N,Cout,H,W) channels_last (second kernel)"""
     require_cuda(x, U)
+    if hasattr(U, 'wino4_shape'):
+        if supported4(U.wino4_shape[0], U.wino4_shape[1], x.shape[2], x.shape[3]):
+            return conv3x3_U4(x, U, bias, relu)
+        U = _f32_image_of(U)
     xv = _nhwc(x.float())
     N, H, W, cin = xv.shape
     ucin, cout = U.wino2_shape
@@ -188,6 +234,7 @@ def _weights_conv4(weight, mode):
     check(lib.crb_winograd4_weights_conv(w.data_ptr(), so, si, sky, skx, ptr(U), cin, cout, mode, cur_stream(w.device)),
           'crb_winograd4_weights_conv')
     U.wino4_shape = (cout, cin) if mode else (cin, cout)
+    U._crb_src, U._crb_mode = w, mode
     return U
 
 
@@ -341,12 +388,17 @@ class _Conv3x3Stats(torch.autograd.Function):
         N, H, W, cin = xv.shape
         cout = weight.shape[0]
         U = weights_forward2(weight)
-        y = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-        stats = torch.empty((int(lib.crb_winograd2_stats_slabs(N, H, W)), 2, cout), dtype=torch.float32, device=x.device)
-        e0 = _prof_begin()
-        check(lib.crb_conv3x3_winograd2_stats_nhwc(xv.data_ptr(), ptr(U), y.data_ptr(), ptr(stats), N, H, W, cin, cout,
-                                                   cur_stream(x.device)), 'crb_conv3x3_winograd2_stats_nhwc')
-        _prof_end(e0, 'wino_conv', cin, cout, N, H, W)
+        if hasattr(U, 'wino4_shape') and supported4(cin, cout, H, W):
+            y, stats = conv3x3_stats_U4(x, U)
+        else:
+            if hasattr(U, 'wino4_shape'):
+                U = _f32_image_of(U)
+            y = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+            stats = torch.empty((int(lib.crb_winograd2_stats_slabs(N, H, W)), 2, cout), dtype=torch.float32, device=x.device)
+            e0 = _prof_begin()
+            check(lib.crb_conv3x3_winograd2_stats_nhwc(xv.data_ptr(), ptr(U), y.data_ptr(), ptr(stats), N, H, W, cin, cout,
+                                                       cur_stream(x.device)), 'crb_conv3x3_winograd2_stats_nhwc')
+            _prof_end(e0, 'wino_conv', cin, cout, N, H, W)
         ctx.mark_non_differentiable(stats)
         ctx.set_materialize_grads(False)          # (no zero tensor for the statistics output's gradient in every backward call)
         return y, stats

@@ -75,7 +75,58 @@ __global__ __launch_bounds__(256) void probe_lds_dma_kernel(const float* __restr
   acc = crb_wave_sum(acc);
   if (lane == 0) atomicAdd(&sink[blockIdx.x & 255], acc);
 }
+
+// ---- how fast can ONE workgroup per CU stream an L2-resident image into LDS? (round 6: the split-bf16 Winograd kernel asks for 30 KB
+// per ~1,000 cycles and CU.) Every workgroup walks the same `bytes`-long image `iters` times, 16 bytes per lane and instruction,
+// DEPTH instructions in flight per wave. VARIANT 0: LDS-DMA (global_load_lds_dwordx4); 1: global_load_dwordx4 into registers, then
+// ds_write_b128 (register staging). The landed data is never read (the write into LDS is what is timed).
+template <int VARIANT, int DEPTH>
+__global__ __launch_bounds__(512) void probe_stream_kernel(const float* __restrict__ src, int64_t bytes, int iters, float* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(16))) float sbuf[];            // DEPTH KiB per wave
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = blockDim.x >> 6;
+  float* my = sbuf + wave * DEPTH * 256;
+  const int64_t per_sweep = bytes / (1024 * (int64_t)nw * DEPTH);         // groups of DEPTH KiB per wave and sweep
+  pf4 keep = (pf4){0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+    for (int64_t g = 0; g < per_sweep; ++g) {
+      const float* base = src + ((g * nw + wave) * DEPTH) * 256 + lane * 4;
+      if (VARIANT == 0) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + d * 256),
+                                           (__attribute__((address_space(3))) void*)(my + d * 256), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DEPTH / 2) : "memory");      // half of them stay in flight across the loop edge
+      } else {
+        pf4 v[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) v[d] = *reinterpret_cast<const pf4*>(base + d * 256);
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) *reinterpret_cast<pf4*>(my + d * 256 + lane * 4) = v[d];
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  keep = *reinterpret_cast<const pf4*>(my + lane * 4);
+  if (keep[0] == 123.456f) sink[0] = keep[1];
+}
 }  // namespace
+
+// variant 0 LDS-DMA / 1 register staging; threads 256 or 512 per workgroup, one workgroup per CU (grid = cus); depth 4 or 8
+extern "C" int crb_probe_stream(int variant, int threads, int depth, int cus, const float* src, int64_t bytes, int iters, float* sink,
+                                void* stream) {
+  if (!src || !sink || bytes <= 0 || iters <= 0 || cus <= 0 || (threads != 256 && threads != 512) || (depth != 4 && depth != 8)) return CRB_ERR_ARG;
+  const size_t lds = (size_t)(threads / 64) * depth * 1024;
+  hipStream_t st = (hipStream_t)stream;
+#define CRB_PS(V, D) hipLaunchKernelGGL((probe_stream_kernel<V, D>), dim3(cus), dim3(threads), lds, st, src, bytes, iters, sink)
+  if (variant == 0 && depth == 4) CRB_PS(0, 4);
+  else if (variant == 0) CRB_PS(0, 8);
+  else if (depth == 4) CRB_PS(1, 4);
+  else CRB_PS(1, 8);
+#undef CRB_PS
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
 
 extern "C" int crb_probe_lds_dma(const float* src, int64_t pieces, int stride_bytes, int pass_mask, float* sink256, void* stream) {
   if (!src || !sink256 || pieces <= 0 || stride_bytes < 32 || (stride_bytes & 15) || !(pass_mask & 15)) return CRB_ERR_ARG;

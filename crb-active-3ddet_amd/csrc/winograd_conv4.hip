@@ -61,7 +61,9 @@ constexpr int LDS_V = 0, LDS_U = 2 * V_PHASE, LDS_RAW = LDS_U + 3 * U_PHASE, LDS
 __device__ float g_wino4_zero_page[64];      // source of out-of-map pixels (zero-initialised, never written)
 __device__ int g_cu_busy4 = 0;               // see winograd_conv2.hip (crb_cu_reservation sets both)
 __device__ unsigned g_cu_latch4[64];
+#ifdef CRB_MEASURE
 __device__ unsigned long long* g_wino4_dbg = nullptr;      // measurement mode 9: 8 uint64 per (workgroup, wave)
+#endif
 __global__ void cu_busy4_set_kernel(int v) { __hip_atomic_store(&g_cu_busy4, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // exact three-way split: the bf16 bit patterns (high halves) of x1, x2, x3
@@ -214,7 +216,6 @@ __device__ __forceinline__ void acc_zero_range() {
 }
 __device__ __forceinline__ void acc_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
-#ifdef CRB_MEASURE   // the first form: A/B in the measurement library
 // MODE (measurement builds, wrong results): 1 = no MFMAs, 2 = no transform (V never written), 3 = no DMA after the prologue, 4 = no
 // operand reads, 5 = no U copies, 6 = no raw copies, 7 = no V stores (values formed), 8 = no epilogue stores
 template <int MODE>
@@ -611,10 +612,9 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
 }
 
 
-#endif
-
+#ifdef CRB_MEASURE   // the second form: A/B in the measurement library (it is not faster: see its header)
 // ================================================================================================================================
-// Second form (the default): the same pipeline with TWO waves per SIMD. Measured on the first form above (one 512-register wave
+// Second form (measurement library, crb_winograd4_set_variant(2)): the same pipeline with TWO waves per SIMD. Measured on the first form above (one 512-register wave
 // per SIMD, profiles/r06_time_winograd4_v1_skip_work_modes.txt): the skip-work builds add up - MFMAs 140 us, LDS-DMA 130 us,
 // operand reads 90 us, transform 75 us, V stores 50 us, output stores 45 us of 635 us: with one in-order wave per SIMD nothing
 // runs under anything else. Here a workgroup is 512 threads = 8 waves of 128 accumulators + 128 registers: wave = 32 tiles x 32
@@ -624,23 +624,28 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
 // of its Q and hands the other row to its partner (wave ^ 4) through LDS (the raw block and the V image that are idle between
 // two units: 2 rounds x 32 KB, three extra barriers per unit).
 constexpr int NT2 = 512;
-// The 128 accumulators are a8 .. a135 (xi (row i, column 2 xh + jj) -> a[8 + 16 (2 i + jj) ..]); a0 .. a7 are left to the compiler, which
-// parks a handful of loop-invariant values there when the 120 VGPRs it is given run out (amdgpu_num_vgpr: 120 + 136 = 256 = two waves
-// per SIMD). tools/check_wino4_isa.py fails the build if it ever writes a VGPR into a8 or above.
-constexpr int ACC0 = 8;
+// The 128 accumulators are a16 .. a143 (xi (row i, column 2 xh + jj) -> a[16 + 16 (2 i + jj) ..]); a0 .. a15 are left to the compiler, which
+// parks values there (mostly the address arithmetic of raw_sources, once per spatial block) when the 112 VGPRs it is given run out
+// (amdgpu_num_vgpr: 112 + 144 = 256 = two waves per SIMD). tools/check_wino4_isa.py fails the build if it ever writes a VGPR into a16 or above.
+constexpr int ACC0 = 16;
 template <int XI>
 __device__ __forceinline__ void mfma_acc8(const bf16x8& A, const bf16x8& B) {
   asm volatile("v_mfma_f32_32x32x16_bf16 a[%2:%3], %0, %1, a[%2:%3]" : : "v"(A), "v"(B), "n"(ACC0 + XI * 16), "n"(ACC0 + XI * 16 + 15));
 }
 
 template <int MODE>
-__global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(120))) void winograd4b_kernel(Wino4Args a) {
+__global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(112))) void winograd4b_kernel(Wino4Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const Vb = lds + LDS_V;
   unsigned char* const Ub = lds + LDS_U;
   unsigned char* const Rb = lds + LDS_RAW;
+  // measurement builds: MODE 1 .. 9 as listed above; MODE >= 64: a bit mask of what is LEFT OUT (1 MFMAs, 2 transform, 4 copies, 8 operand
+  // reads, 16 output stores) - "what does this ingredient cost beside the MFMAs alone"
+  constexpr int FL = MODE >= 64 ? MODE - 64 : 0;
+  constexpr bool NO_MFMA = MODE == 1 || (FL & 1), NO_T = MODE == 2 || (FL & 2), NO_DMA = MODE == 3 || (FL & 4), NO_OPR = MODE == 4 || (FL & 8),
+                 NO_OUT = MODE == 8 || (FL & 16);
   const int T = threadIdx.x, lane = T & 63, wave = __builtin_amdgcn_readfirstlane(T >> 6);
-  asm volatile("" ::: "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135");
+  asm volatile("" ::: "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143");
 
   // ---- the unit range of this workgroup
   const int nunits = a.nblocks * a.ncb;
@@ -694,9 +699,12 @@ __global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(120))) void 
     const int rows_a = min(TB_ROWS, a.th - p.ty0);
     const int limit_a = 2 * rows_a + 2;
     rstep = 0;
+    int Tq = T;
+    asm volatile("" : "+v"(Tq));        // (opaque: the slot arithmetic below is redone per spatial block instead of living in registers
+                                        // across the chunk loop, where the wave has none to spare)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int s = T + NT2 * j;
+      const int s = Tq + NT2 * j;
       const int P = s >> 2, q = s & 3;
       const int lr = P / RAW_PX, rem = P - lr * RAW_PX;
       const int xx = rem < 5 ? 2 * rem : 2 * (rem - 5) + 1;
@@ -767,11 +775,11 @@ __global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(120))) void 
     const int kb = eu.cb * WG_K + w_kh * 32 + 4 * lhi;
     float* const yo = a.y + (((int64_t)n2 * a.H + oy) * a.W + ox) * a.cout + kb;
     unsigned char* const X0 = Rb;                                 // exchange areas: [column 2][wave 8][lane 64] 16 bytes = 16 KB each
-    unsigned char* const X1 = Vb + V_PHASE;                       // (V[1]: read by phase 3, rewritten in the next phase 0)
+    unsigned char* const X1 = Ub + 2 * U_PHASE;                   // (the third U image of the first form: this pipeline runs on two)
     const int x_wr = wave * 1024 + lane * 16, x_rd = (wave ^ 4) * 1024 + lane * 16;
     acc_settle();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                 // every wave is done with the raw block and V[1]
+    __builtin_amdgcn_s_barrier();                                 // every wave is done with the raw block
     auto group_q = [&](auto jc, f32x4 (&keep)[2], unsigned char* X) __attribute__((always_inline)) {
       constexpr int j = decltype(jc)::value;
       // rows first, streaming over the accumulators: S0[x] = M[0][x] + M[1][x] + M[2][x], S1[x] = M[1][x] - M[2][x] - M[3][x] for the
@@ -815,7 +823,7 @@ __global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(120))) void 
         for (int e = 0; e < 4; ++e) { y0[e] = fmaxf(y0[e], 0.f); y1[e] = fmaxf(y1[e], 0.f); }
       }
       f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (in && MODE != 8) {
+      if (in && !NO_OUT) {
         float* o = yo + 8 * j;
         *reinterpret_cast<f32x4*>(o) = y0;
         if (x1) *reinterpret_cast<f32x4*>(o + a.cout) = y1;
@@ -868,29 +876,28 @@ __global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(120))) void 
     // (the next phase's barrier orders these exchange reads in front of the raw copy and the V stores that reuse the areas)
   };
 
-  // ---- input transform pieces (see the first form): col<b>, and per xi two steps: [value, remainders] and [packs + 3 stores]
+  unsigned long long st_wait = 0, st_bar = 0, st_head = 0, st_body = 0, st_epi = 0, st_start = 0;      // MODE 9: s_memtime sums
+  // ---- input transform pieces (see the first form): col<b> (its four raw values are read one piece earlier), and per xi two steps:
+  //      [value, remainders] and [packs + 3 stores]
   f32x2 tp[4][4];
   f32x2 sv, sr1, sr2;
-  auto t_read = [&](f32x2 (&d)[4][4]) {
-    const unsigned char* p = Rb + raw_rd;
+  auto t_col = [&](int b) __attribute__((always_inline)) {       // column b of the patch: 4 raw values -> tp[.][b] (the SIMD's other wave covers the read)
+    if (NO_T) return;
+    const unsigned char* p = Rb + raw_rd + ((b >> 1) + 5 * (b & 1)) * 64;      // pixel column b: position t_tc + (b >> 1) + 5 (b & 1)
+    f32x2 d[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-        d[i][b] = *reinterpret_cast<const f32x2*>(p + (i * RAW_PX + (b >> 1) + 5 * (b & 1)) * 64);
-  };
-  auto t_col = [&](const f32x2 (&d)[4][4], int b) __attribute__((always_inline)) {
-    tp[0][b] = d[0][b] - d[2][b];
-    tp[1][b] = d[1][b] + d[2][b];
-    tp[2][b] = d[2][b] - d[1][b];
-    tp[3][b] = d[1][b] - d[3][b];
+    for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const f32x2*>(p + i * RAW_PX * 64);
+    tp[0][b] = d[0] - d[2];
+    tp[1][b] = d[1] + d[2];
+    tp[2][b] = d[2] - d[1];
+    tp[3][b] = d[1] - d[3];
     asm volatile("" : "+v"(tp[0][b]), "+v"(tp[1][b]), "+v"(tp[2][b]), "+v"(tp[3][b]));
   };
   auto trunc16 = [](float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); };
   auto pack_hi = [](const f32x2& x) { return (__float_as_uint(x[0]) >> 16) | (__float_as_uint(x[1]) & 0xffff0000u); };
   auto t_xi = [&](unsigned char* V, auto rcst, auto jcst, auto scst) __attribute__((always_inline)) {
     constexpr int r = decltype(rcst)::value, jx = decltype(jcst)::value, s = decltype(scst)::value;
-    if (MODE == 2) return;
+    if (NO_T) return;
     if constexpr (s == 0) {
       if constexpr (jx == 0) sv = tp[r][0] - tp[r][2];
       else if constexpr (jx == 1) sv = tp[r][1] + tp[r][2];
@@ -915,91 +922,109 @@ __global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(120))) void 
     if (t_unit % a.ncb == 0) raw_rd = raw_base(t_unit);
   };
 
-  // ---- phases (as in the first form; per wave 2 xi = 12 MFMAs that alternate between the two accumulators)
-  unsigned long long st_wait = 0, st_bar = 0, st_head = 0, st_body = 0, st_epi = 0, st_start = 0;      // MODE 9: s_memtime sums
-  int ub_cur = 0, ub_nxt = U_PHASE, ub_nn = 2 * U_PHASE;
+  // ---- phases, software-pipelined so that NOTHING but the counter wait and the barrier stands between two phases' MFMAs (the second
+  //      form's first build read its operands and issued its copies between the barrier and the first MFMA, in all eight waves at
+  //      once: matrix pipe 23 % busy). Phase f = 4 chunk + i runs the 12 MFMAs of xi row i on operands that are ALREADY in registers
+  //      and, one piece behind every MFMA: requests U(f + 2) -> U[f & 1] (and raw(chunk + 1) in phase 0), forms row (i + 2) & 3 of
+  //      V(f + 2) -> V[f & 1] (phase 2 first reads the new raw block and does the column pass), and reads the operands of phase f + 1
+  //      from V[(f + 1) & 1], U[(f + 1) & 1] into the registers the MFMAs have just released. The barrier at the head of phase f
+  //      certifies V(f + 1), U(f + 1) and that every wave is done reading V(f), U(f).
+  bf16x8 A[2][3], B[2][3];                           // operands of the running phase: [xi jj][piece]
+  auto op_read = [&](int f1, int p, bool is_a) __attribute__((always_inline)) {      // piece p of both xi of the phase with parity f1
+    if (NO_OPR) return;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      if (is_a) A[jj][p] = *reinterpret_cast<const bf16x8*>(Ub + f1 * U_PHASE + a_rd + (jj * 3 + p) * U_XP);
+      else B[jj][p] = *reinterpret_cast<const bf16x8*>(Vb + f1 * V_PHASE + b_rd + (jj * 3 + p) * V_XP);
+    }
+  };
   auto phase = [&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
-    constexpr int rn = (i + 1) & 3;
+    constexpr int rn = (i + 2) & 3;
+    constexpr int f0 = i & 1, f1 = f0 ^ 1;             // parity of f (buffers being refilled) and of f + 1 (buffers being read)
     unsigned long long tm0 = 0, tm1 = 0, tm2 = 0;
     if (MODE == 9) tm0 = __builtin_amdgcn_s_memtime();
-    if (i == 1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    // copies that may stay in flight: raw(chunk + 1), requested in phase 0 behind U(f + 2) and read in phase 2
+    if (i == 1) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (MODE == 9) tm1 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_barrier();
     if (MODE == 9) { tm2 = __builtin_amdgcn_s_memtime(); st_wait += tm1 - tm0; st_bar += tm2 - tm1; }
-    unsigned char* const Vn = Vb + ((i + 1) & 1) * V_PHASE;
-    const unsigned char* const Vc = Vb + (i & 1) * V_PHASE + b_rd;
-    const unsigned char* const Uc = Ub + ub_cur + a_rd;
-    // pieces 0 and 2 of both xi first (8 fragments); the two middle pieces take the registers of the spent (piece 2) fragments
-    // behind the fourth MFMA: 32 fragment registers instead of 48 (the wave has 120 + what the compiler parks in a0 .. a7)
-    bf16x8 A[2][3], B[2][3];
-    auto op_read = [&](int p) __attribute__((always_inline)) {
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        if (MODE == 4) { asm volatile("" : "=v"(A[jj][p]), "=v"(B[jj][p])); continue; }
-        A[jj][p] = *reinterpret_cast<const bf16x8*>(Uc + (jj * 3 + p) * U_XP);
-        B[jj][p] = *reinterpret_cast<const bf16x8*>(Vc + (jj * 3 + p) * V_XP);
+    unsigned char* const Vn = Vb + f0 * V_PHASE;
+    // transform piece t of the phase (phase 2: the column passes first, columns 0, 2 first: xi 0 needs them)
+    auto tpiece = [&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int t0 = (i == 2) ? t - 4 : t;
+      if constexpr (i == 2 && t < 4) {
+        constexpr int order[4] = {0, 2, 1, 3};
+        t_col(order[t]);
+        if constexpr (t == 3) t_advance();
+      } else if constexpr (t0 >= 0 && t0 < 8) {
+        t_xi(Vn, std::integral_constant<int, rn>{}, std::integral_constant<int, t0 / 2>{}, std::integral_constant<int, t0 % 2>{});
       }
     };
-    op_read(0);
-    op_read(2);
-    f32x2 d[4][4];
-    if (i == 3) { t_read(d); t_advance(); }
-    if (MODE != 3) {
-      if (i == 0 && MODE != 6) { issue_raw(); r_advance(); }
-      if (MODE != 5) { issue_u(ub_nn); u_advance(); }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (MODE == 9) { tm0 = __builtin_amdgcn_s_memtime(); st_head += tm0 - tm2; }
-    // piece k (behind MFMA k of the phase): phase 3 starts with the four column passes (columns 0, 2 first: xi 0 needs them)
-    auto piece = [&](auto kc) __attribute__((always_inline)) {
+    // slot k: the work placed behind MFMA k
+    auto slot = [&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value;
-      constexpr int k0 = (i == 3) ? k - 4 : k;
-      if constexpr (i == 3 && k < 4) {
-        t_col(d, k == 0 ? 0 : k == 1 ? 2 : k == 2 ? 1 : 3);
-      } else if constexpr (k0 >= 0 && k0 < 8) {
-        t_xi(Vn, std::integral_constant<int, rn>{}, std::integral_constant<int, k0 / 2>{}, std::integral_constant<int, k0 % 2>{});
+      if constexpr (k == 0) {
+        if (!NO_DMA) {
+          if (MODE != 5) { issue_u(f0 * U_PHASE); u_advance(); }
+          if (i == 0 && MODE != 6) { issue_raw(); r_advance(); }
+        }
+      }
+      if constexpr (k == 1) op_read(f1, 2, false);       // B piece 2 was used by MFMAs 0, 1
+      if constexpr (k == 5) op_read(f1, 1, false);       // B piece 1: MFMAs 2 .. 5
+      if constexpr (k == 7) op_read(f1, 0, true);        // A piece 0: MFMAs 0 .. 3, 6, 7
+      if constexpr (k == 9) op_read(f1, 1, true);        // A piece 1: MFMAs 4, 5, 8, 9
+      if constexpr (k == 11) { op_read(f1, 2, true); op_read(f1, 0, false); }
+      if constexpr (i == 2) {                            // 12 transform pieces over 12 slots
+        tpiece(std::integral_constant<int, k>{});
+      } else if constexpr (k >= 1 && k <= 8) {
+        tpiece(std::integral_constant<int, k - 1>{});
       }
       __builtin_amdgcn_sched_barrier(0);
     };
-    auto pair = [&](auto cc, int pa, int pb) __attribute__((always_inline)) {      // product (piece pa of U) x (piece pb of V) for both xi
-      constexpr int c = decltype(cc)::value;
-      if (MODE != 1) mfma_acc8<2 * i + 0>(A[0][pa], B[0][pb]);
-      piece(std::integral_constant<int, 2 * c>{});
-      if (MODE != 1) mfma_acc8<2 * i + 1>(A[1][pa], B[1][pb]);
-      piece(std::integral_constant<int, 2 * c + 1>{});
-    };
-    pair(std::integral_constant<int, 0>{}, 0, 2);
-    pair(std::integral_constant<int, 1>{}, 2, 0);
-    op_read(1);
     __builtin_amdgcn_sched_barrier(0);
-    pair(std::integral_constant<int, 2>{}, 0, 0);
-    pair(std::integral_constant<int, 3>{}, 1, 1);
-    pair(std::integral_constant<int, 4>{}, 0, 1);
-    pair(std::integral_constant<int, 5>{}, 1, 0);
+    if (MODE == 9) { tm0 = __builtin_amdgcn_s_memtime(); st_head += tm0 - tm2; }
+#define CRB_MM(K, JJ, PA, PB)                                      \
+    if (!NO_MFMA) mfma_acc8<2 * i + JJ>(A[JJ][PA], B[JJ][PB]);    \
+    slot(std::integral_constant<int, K>{})
+    CRB_MM(0, 0, 0, 2); CRB_MM(1, 1, 0, 2);
+    CRB_MM(2, 0, 0, 1); CRB_MM(3, 1, 0, 1);
+    CRB_MM(4, 0, 1, 1); CRB_MM(5, 1, 1, 1);
+    CRB_MM(6, 0, 0, 0); CRB_MM(7, 1, 0, 0);
+    CRB_MM(8, 0, 1, 0); CRB_MM(9, 1, 1, 0);
+    CRB_MM(10, 0, 2, 0); CRB_MM(11, 1, 2, 0);
+#undef CRB_MM
     if (MODE == 9) st_body += __builtin_amdgcn_s_memtime() - tm0;
-    const int t = ub_cur; ub_cur = ub_nxt; ub_nxt = ub_nn; ub_nn = t;
   };
 
-  // ---- prologue: raw(0), U(0), U(1) in one round trip, raw(0) -> tp -> V(0)
+  // ---- prologue: raw(0), U(0), U(1) in one round trip; raw(0) -> tp -> rows 0, 1 = V(0), V(1); operands of phase 0
   if (MODE == 9) st_start = __builtin_amdgcn_s_memtime();
   issue_raw(); r_advance();
   issue_u(0); u_advance();
   issue_u(U_PHASE); u_advance();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  {
-    f32x2 d[4][4];
-    t_read(d); t_advance();
 #pragma unroll
-    for (int b = 0; b < 4; ++b) t_col(d, b);
-  }
-#define CRB_T_XI_ALL(JX)                                                                                                      \
-  t_xi(Vb, std::integral_constant<int, 0>{}, std::integral_constant<int, JX>{}, std::integral_constant<int, 0>{});            \
-  t_xi(Vb, std::integral_constant<int, 0>{}, std::integral_constant<int, JX>{}, std::integral_constant<int, 1>{})
-  CRB_T_XI_ALL(0); CRB_T_XI_ALL(1); CRB_T_XI_ALL(2); CRB_T_XI_ALL(3);
+  for (int b = 0; b < 4; ++b) t_col(b);
+  t_advance();
+#define CRB_T_XI_ALL(V, R, JX)                                                                                                \
+  t_xi(V, std::integral_constant<int, R>{}, std::integral_constant<int, JX>{}, std::integral_constant<int, 0>{});             \
+  t_xi(V, std::integral_constant<int, R>{}, std::integral_constant<int, JX>{}, std::integral_constant<int, 1>{})
+  CRB_T_XI_ALL(Vb, 0, 0); CRB_T_XI_ALL(Vb, 0, 1); CRB_T_XI_ALL(Vb, 0, 2); CRB_T_XI_ALL(Vb, 0, 3);
+  CRB_T_XI_ALL(Vb + V_PHASE, 1, 0); CRB_T_XI_ALL(Vb + V_PHASE, 1, 1); CRB_T_XI_ALL(Vb + V_PHASE, 1, 2); CRB_T_XI_ALL(Vb + V_PHASE, 1, 3);
 #undef CRB_T_XI_ALL
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int p = 0; p < 3; ++p) { op_read(0, p, true); op_read(0, p, false); }
+  if (NO_OPR) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) asm volatile("" : "=v"(A[jj][p]), "=v"(B[jj][p]));
+  }
 
   for (int cg = 0; cg < total_chunks; ++cg) {
     phase(std::integral_constant<int, 0>{});
@@ -1011,6 +1036,9 @@ __global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(120))) void 
       unsigned long long te = 0;
       if (MODE == 9) te = __builtin_amdgcn_s_memtime();
       unit_epilogue();
+      // the operands of the next phase, read during phase 3, were not kept across the output transform (48 registers): again
+#pragma unroll
+      for (int p = 0; p < 3; ++p) { op_read(0, p, true); op_read(0, p, false); }
       if (MODE == 9) st_epi += __builtin_amdgcn_s_memtime() - te;
     }
   }
@@ -1022,18 +1050,20 @@ __global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(120))) void 
   }
 }
 
+#endif  // CRB_MEASURE (second form)
+
 }  // namespace
 
 CRB_KNOB g_wino4_mode [[maybe_unused]] = 0;      // measurement builds: see MODE
-CRB_KNOB g_wino4_variant [[maybe_unused]] = 2;   // 2 = two waves per SIMD (the product kernel), 1 = the first form (measurement library)
+CRB_KNOB g_wino4_variant [[maybe_unused]] = 1;   // 1 = one 512-register wave per SIMD (the product kernel), 2 = the second form (measurement library)
 #ifdef CRB_MEASURE
 extern "C" int crb_winograd4_set_debug(void* dev_buf) {
   unsigned long long* p = (unsigned long long*)dev_buf;
   CRB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wino4_dbg), &p, sizeof(p)));
   return CRB_OK;
 }
-extern "C" int crb_winograd4_set_variant(int v) { g_wino4_variant = v == 1 ? 1 : 2; return CRB_OK; }
-extern "C" int crb_winograd4_set_mode(int mode) { g_wino4_mode = (mode >= 1 && mode <= 9) ? mode : 0; return CRB_OK; }
+extern "C" int crb_winograd4_set_variant(int v) { g_wino4_variant = v == 2 ? 2 : 1; return CRB_OK; }
+extern "C" int crb_winograd4_set_mode(int mode) { g_wino4_mode = ((mode >= 1 && mode <= 9) || (mode >= 64 && mode < 96)) ? mode : 0; return CRB_OK; }
 #endif
 
 // ceil(H / 2) >= 16: a block of 16 tile rows touches at most two images (the raw block keeps ONE gap)
@@ -1121,22 +1151,26 @@ static int winograd4_launch(const float* x, const void* U, float* y, int N, int 
   if (nb >= (1LL << 26)) return CRB_ERR_ARG;
   a.nblocks = (int)nb;
   a.ncb = cout / WG_K;
-  int mode = 0, nt = NT2;
-  auto kern = winograd4b_kernel<0>;
+  int mode = 0, nt = NT;
+  auto kern = winograd4_kernel<0>;
 #ifdef CRB_MEASURE
   mode = g_wino4_mode;
-  if (mode == 1) kern = winograd4b_kernel<1>;
-  if (mode == 2) kern = winograd4b_kernel<2>;
-  if (mode == 3) kern = winograd4b_kernel<3>;
-  if (mode == 4) kern = winograd4b_kernel<4>;
-  if (mode == 5) kern = winograd4b_kernel<5>;
-  if (mode == 6) kern = winograd4b_kernel<6>;
-  if (mode == 7) kern = winograd4b_kernel<7>;
-  if (mode == 8) kern = winograd4b_kernel<8>;
-  if (mode == 9) kern = winograd4b_kernel<9>;
-  if (g_wino4_variant == 1) {              // first form (one wave per SIMD): A/B only
-    nt = NT;
-    kern = winograd4_kernel<0>;
+  if (g_wino4_variant == 2) {              // second form (two waves per SIMD): A/B only
+    nt = NT2;
+    kern = winograd4b_kernel<0>;
+    if (mode == 1) kern = winograd4b_kernel<1>;
+    if (mode == 2) kern = winograd4b_kernel<2>;
+    if (mode == 3) kern = winograd4b_kernel<3>;
+    if (mode == 5) kern = winograd4b_kernel<5>;
+    if (mode == 6) kern = winograd4b_kernel<6>;
+    if (mode == 7) kern = winograd4b_kernel<7>;
+    if (mode == 8) kern = winograd4b_kernel<8>;
+    if (mode == 64 + 30) kern = winograd4b_kernel<64 + 30>;       // MFMAs (+ counters, barriers) only
+    if (mode == 64 + 22) kern = winograd4b_kernel<64 + 22>;       // MFMAs + operand reads
+    if (mode == 64 + 31) kern = winograd4b_kernel<64 + 31>;       // counters and barriers only
+    if (mode == 64 + 29) kern = winograd4b_kernel<64 + 29>;       // transform only
+    mode = 32;                             // (no attribute bit: set every time)
+  } else {
     if (mode == 1) kern = winograd4_kernel<1>;
     if (mode == 2) kern = winograd4_kernel<2>;
     if (mode == 3) kern = winograd4_kernel<3>;
@@ -1145,15 +1179,15 @@ static int winograd4_launch(const float* x, const void* U, float* y, int N, int 
     if (mode == 6) kern = winograd4_kernel<6>;
     if (mode == 7) kern = winograd4_kernel<7>;
     if (mode == 8) kern = winograd4_kernel<8>;
-    mode += 16;                            // (attribute bit of the instance)
+    if (mode > 8) mode = 0;
   }
 #endif
   int dev = 0;
   const int n_cu = device_cus4(&dev);
   if (n_cu <= 0) return CRB_ERR_LAUNCH;
-  if (!(g_dev_attr4[dev].load(std::memory_order_acquire) & (1u << mode))) {
+  if (mode >= 32 || !(g_dev_attr4[dev].load(std::memory_order_acquire) & (1u << mode))) {
     CRB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    g_dev_attr4[dev].fetch_or(1u << mode, std::memory_order_release);
+    if (mode < 32) g_dev_attr4[dev].fetch_or(1u << mode, std::memory_order_release);
   }
   const int64_t units = nb * a.ncb;
   const int64_t grid = units < n_cu ? units : n_cu;
@@ -1172,7 +1206,7 @@ extern "C" int crb_conv3x3_winograd4_nhwc(const float* x, const void* U, float* 
 extern "C" int64_t crb_winograd4_stats_slabs(int N, int H, int W) {
   if (N <= 0 || H <= 0 || W <= 0) return 0;
   const int64_t th = (H + 1) / 2, tw4 = ((W + 1) / 2 + TB_COLS - 1) / TB_COLS;
-  return (g_wino4_variant == 1 ? 2 : 4) * ((N * th + TB_ROWS - 1) / TB_ROWS) * tw4;       // (spatial block, tile half, output row)
+  return (g_wino4_variant == 2 ? 4 : 2) * ((N * th + TB_ROWS - 1) / TB_ROWS) * tw4;       // (spatial block, tile half[, output row: second form])
 }
 
 extern "C" int crb_conv3x3_winograd4_stats_nhwc(const float* x, const void* U, float* y, float* stats, int N, int H, int W, int cin,

@@ -760,7 +760,7 @@ int crb_conv3x3_winograd2_stats_nhwc(const float* x, const float* U, float* y, f
  * group][64 rows][8]), crb_winograd4_weights_bytes bytes. crb_winograd4_supported: Cin % 16 == 0, Cout % 64 == 0, H >= 31 (a block of
  * 16 tile rows touches at most two images). One wave per SIMD with all 16 xi of a 32 x 32 block (256 accumulators), raw block shared
  * by the workgroup (halo rows fetched once), four xi-row phases per 16-channel chunk. Stats: crb_winograd4_stats_slabs slabs (one per
- * spatial block, tile half and output row of the 2 x 2), same meaning as crb_winograd2_stats_slabs' otherwise. */
+ * spatial block and tile half; tile rows per image NOT rounded up to even), same meaning as crb_winograd2_stats_slabs' otherwise. */
 int crb_winograd4_supported(int cin, int cout, int H, int W);
 int64_t crb_winograd4_weights_bytes(int cin, int cout);
 int crb_winograd4_weights_conv(const float* w, int64_t so, int64_t si, int64_t sky, int64_t skx, void* U, int conv_cin, int conv_cout,

@@ -21,7 +21,7 @@ int crb_winograd2_set_mode(int mode);
 /* measurement builds of the split-bf16 Winograd kernel (wrong results): 1 = no MFMAs, 2 = no input transform, 3 = no LDS-DMA in the loop,
  * 4 = no operand reads, 5 = no U copies, 6 = no raw copies, 7 = no V stores, 8 = no output stores, 9 = stamps (csrc/winograd_conv4.hip) */
 int crb_winograd4_set_mode(int mode);
-/* A/B: 2 = the product kernel (two waves per SIMD, xi split over wave pairs), 1 = the first form (one 512-register wave per SIMD) */
+/* A/B: 1 = the product kernel (one 512-register wave per SIMD), 2 = the second form (two waves per SIMD, xi split over wave pairs, pipelined) */
 int crb_winograd4_set_variant(int v);
 /* mode 9 (correct results + s_memtime sums per (workgroup, wave): {counter wait, barrier, phase head, phase body, epilogue, total, chunks, units}): 8 uint64 per wave, 8 waves per workgroup; NULL = off */
 int crb_winograd4_set_debug(void* dev_buf_u64x64_per_wg);
@@ -101,6 +101,9 @@ int crb_sa_mlp2_train_set_skip(int bits);
  * 32 bytes, `stride_bytes` apart (32 = dense, 512 = the 8-channel pieces of adjacent pixels of a 128-channel NHWC map); pass_mask bit p
  * = a sweep over the p-th 32-byte piece of every stride (p < 4). Requested bytes = pieces * 32 * popcount(pass_mask). sink256: 256 floats. */
 int crb_probe_lds_dma(const float* src, int64_t pieces, int stride_bytes, int pass_mask, float* sink256, void* stream);
+/* one workgroup per CU streams an L2-resident image into LDS `iters` times: variant 0 = LDS-DMA, 1 = global_load_dwordx4 + ds_write_b128;
+ * threads 256 | 512, depth 4 | 8 instructions in flight per wave (csrc/probe_floor.hip) */
+int crb_probe_stream(int variant, int threads, int depth, int cus, const float* src, int64_t bytes, int iters, float* sink, void* stream);
 /* latency-floor probes of the low-channel subm layers (csrc/probe_floor.hip): the memory side of the gather chain on 16-channel rows,
  * no weights / MFMA. variant 0 = copy y[i] = x[i]; 1 = two dependent round trips (ell (n,8) fixed-stride neighbour list, -1 = none,
  * rows summed); 2 = three (cmask / cbase -> packed -> rows: the compact table's chain). y (n,16). */

@@ -43,24 +43,40 @@ def test_first_winograd_kernel_matches_direct_convolution(dev, N, C, K, H, W):
 # 192 (three channel blocks); more units than CUs (persistent ranges of several units) and fewer
 W2_SHAPES = [(2, 128, 128, 50, 44), (1, 256, 256, 25, 22), (3, 64, 64, 7, 9), (20, 24, 64, 5, 9), (2, 8, 192, 33, 17),
              (1, 256, 128, 40, 31), (16, 16, 64, 50, 44)]
+# the split-bf16 kernel (csrc/winograd_conv4.hip; the default where it has an instance: Cin % 16 == 0, Cout % 64 == 0, H >= 31).
+# Shapes: the BEV shapes scaled down; blocks of 16 tile rows that straddle two images (N * ceil(H/2) not a multiple of 16: the raw
+# block's 2-row gap), the smallest map (H = 31: 16 tile rows = one image per block), partial tile columns and odd sizes (W = 9, 5,
+# 17, 31: ceil(W/2) not a multiple of 4; H = 33, 37, 63: half tiles), Cin = 16 (ONE chunk) and 48 (three), Cout = 192 (three channel
+# blocks), more units than CUs and fewer; (3, 64, 64, 7, 9) and (1, 256, 256, 25, 22): maps below 31 rows - the same calls fall back
+# to the f32-MFMA kernel
+W4_SHAPES = [(2, 128, 128, 50, 44), (1, 256, 256, 33, 22), (3, 64, 64, 31, 9), (2, 16, 192, 33, 17), (1, 256, 128, 40, 31),
+             (16, 16, 64, 50, 44), (5, 32, 64, 37, 5), (3, 48, 128, 63, 70), (3, 64, 64, 7, 9), (1, 256, 256, 25, 22)]
 
 
-@pytest.mark.parametrize('N,C,K,H,W', W2_SHAPES)
-def test_winograd_conv_matches_direct_convolution(dev, N, C, K, H, W):
+@pytest.mark.parametrize('kernel,N,C,K,H,W', [('f32',) + s for s in W2_SHAPES] + [('x6',) + s for s in W4_SHAPES])
+def test_winograd_conv_matches_direct_convolution(dev, monkeypatch, kernel, N, C, K, H, W):
     """forward (+ bias, + ReLU epilogue), the input gradient as the same kernel on dy with the flipped / transposed weight
     image, and the autograd node (dw, db on MIOpen) against an f64 convolution: <= 1e-5 of the output scale forward, <= 2e-5
-    of the largest gradient entry; run-to-run bit equality"""
+    of the largest gradient entry; run-to-run bit equality. Both kernels to the same bars: 'f32' = exact-f32 MFMA
+    (winograd_conv2.hip), 'x6' = six bf16 MFMA passes over the exact three-way split of the operands (winograd_conv4.hip)"""
     from crbhip import winograd
+    monkeypatch.setattr(winograd, 'KERNEL', kernel)
     torch.manual_seed(N * 1000 + C + K + H)
     assert winograd.supported2(C, K, H, W)
+    if kernel == 'x6':
+        assert winograd._use4(C, K) and hasattr(winograd.weights_forward2(torch.zeros(K, C, 3, 3, device=dev)), 'wino4_shape')
     x = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
     w = (torch.randn(K, C, 3, 3, device=dev) / np.sqrt(9 * C))
     b = torch.randn(K, device=dev)
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     scale = float(ref.abs().max())
+    imgs = []
     for wt in (w, w.contiguous(memory_format=torch.channels_last)):                     # both weight layouts: same image
         U = winograd.weights_forward2(wt)
-        assert torch.equal(U, winograd.transform_weights2(w.permute(2, 3, 1, 0).contiguous()))
+        imgs.append(U)
+        if kernel == 'f32':
+            assert torch.equal(U, winograd.transform_weights2(w.permute(2, 3, 1, 0).contiguous()))
+    assert torch.equal(imgs[0], imgs[1])
     y = winograd.conv3x3_U2(x, U, b)
     assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
     assert float((y.double() - ref).abs().max()) <= 1e-5 * scale
@@ -72,7 +88,8 @@ def test_winograd_conv_matches_direct_convolution(dev, N, C, K, H, W):
     x64, w64, b64 = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
     F.conv2d(x64, w64, b64, padding=1).backward(dy.double())
     if winograd.supported2(K, C, H, W):
-        assert torch.equal(winograd.weights_input_grad2(w), winograd.transform_weights2(w.flip(2, 3).permute(2, 3, 0, 1).contiguous()))
+        if kernel == 'f32':
+            assert torch.equal(winograd.weights_input_grad2(w), winograd.transform_weights2(w.flip(2, 3).permute(2, 3, 0, 1).contiguous()))
         xg = x.clone().requires_grad_(True)
         wg = w.clone().requires_grad_(True)
         bg = b.clone().requires_grad_(True)
@@ -254,11 +271,14 @@ def test_bev_backbone_gradients_at_a_bench_like_shape_against_f64(dev, monkeypat
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('shape', [(2, 64, 64, 37, 29), (3, 16, 128, 12, 21), (16, 128, 128, 40, 36)])
-def test_forward_kernel_writes_the_slab_sums_of_its_output(dev, shape):
-    """crb_conv3x3_winograd2_stats_nhwc: same output as the plain kernel (bit-equal), and the slab sums add up to the column sums
-    of y and y^2 over the map (odd sizes: outputs of border tiles outside the map are not counted); bit-equal on a rerun"""
+@pytest.mark.parametrize('kernel', ['f32', 'x6'])
+@pytest.mark.parametrize('shape', [(2, 64, 64, 37, 29), (3, 16, 128, 12, 21), (16, 128, 128, 40, 36), (5, 32, 64, 33, 7)])
+def test_forward_kernel_writes_the_slab_sums_of_its_output(dev, monkeypatch, kernel, shape):
+    """crb_conv3x3_winograd2_stats_nhwc / crb_conv3x3_winograd4_stats_nhwc: same output as the plain kernel (bit-equal), and the slab
+    sums add up to the column sums of y and y^2 over the map (odd sizes: outputs of border tiles outside the map are not counted);
+    bit-equal on a rerun"""
     from crbhip import winograd
+    monkeypatch.setattr(winograd, 'KERNEL', kernel)
     N, C, K, H, W = shape
     torch.manual_seed(11)
     x = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
@@ -306,13 +326,15 @@ def test_bev_backbone_statistics_from_the_epilogue_match_the_statistics_pass(dev
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('kernel', ['f32', 'x6'])
 @pytest.mark.parametrize('shape', [(4, 64, 128, 60, 44), (6, 128, 256, 100, 88)])
-def test_results_do_not_depend_on_the_cu_reservation(dev, shape):
+def test_results_do_not_depend_on_the_cu_reservation(dev, monkeypatch, kernel, shape):
     """crb_cu_reservation(n): a persistent forward launch that puts a workgroup on every CU spreads its units over (CUs - n)
     workgroups (n is clamped to half of the CUs; smaller launches ignore it); outputs are bit-equal for any n (every unit is
     computed by exactly one workgroup, whichever). First shape: 96 units (fewer than CUs: the reservation is not looked at);
     second: 836 units on 256 workgroups."""
     from crbhip import winograd, lib, check, cur_stream
+    monkeypatch.setattr(winograd, 'KERNEL', kernel)
     N, C, K, H, W = shape
     torch.manual_seed(17)
     x = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
@@ -329,11 +351,14 @@ def test_results_do_not_depend_on_the_cu_reservation(dev, shape):
     assert torch.equal(winograd.conv3x3(x, w), ref)
 
 
-def test_prepared_weight_images_equal_the_single_launches(dev):
-    """crb_winograd2_weights_conv_multi (all layers of a step in one launch) against one crb_winograd2_weights_conv per image:
-    bit-equal, contiguous and channels_last weights, 128 / 256 channel pairs; the prepared image is handed out only for the same
-    memory at the same autograd version"""
+@pytest.mark.parametrize('kernel', ['f32', 'x6'])
+def test_prepared_weight_images_equal_the_single_launches(dev, monkeypatch, kernel):
+    """crb_winograd2 / 4_weights_conv_multi (all layers of a step in one launch) against one crb_winograd2 / 4_weights_conv per
+    image: bit-equal, contiguous and channels_last weights, 128 / 256 channel pairs; the prepared image is handed out only for the
+    same memory at the same autograd version"""
     from crbhip import winograd
+    monkeypatch.setattr(winograd, 'KERNEL', kernel)
+    shp = 'wino2_shape' if kernel == 'f32' else 'wino4_shape'
     torch.manual_seed(3)
     ws = [torch.randn(co, ci, 3, 3, device=dev) for co, ci in ((128, 256), (128, 128), (256, 128), (256, 256), (64, 64))]
     ws[1] = ws[1].contiguous(memory_format=torch.channels_last)
@@ -344,7 +369,7 @@ def test_prepared_weight_images_equal_the_single_launches(dev):
     for w, (uf, ug) in zip(ws, single):
         pf, pg = winograd.weights_forward2(w), winograd.weights_input_grad2(w)
         assert pf is winograd._PREPARED[winograd._prep_key(w, 0)] and pg is winograd._PREPARED[winograd._prep_key(w, 1)]
-        assert torch.equal(pf, uf) and torch.equal(pg, ug) and pf.wino2_shape == uf.wino2_shape and pg.wino2_shape == ug.wino2_shape
+        assert torch.equal(pf, uf) and torch.equal(pg, ug) and getattr(pf, shp) == getattr(uf, shp) and getattr(pg, shp) == getattr(ug, shp)
     # a weight that is freed while its image is still in the prepared set: a NEW tensor of the same shape must not be served the old
     # image (the set keeps the source alive, so the allocator cannot hand its address out again) - found by a stage-2 test that
     # failed only in the full suite order

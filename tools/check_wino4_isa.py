@@ -23,7 +23,7 @@ def main(measure=False):
         name, body, second = m.group(1), m.group(0), m.group(2) == 'b'
         if 'ILi9E' in name:           # the stamp build (mode 9) may clobber accumulators: timing only
             continue
-        first_acc = 8 if second else 0
+        first_acc = 16 if second else 0
         for w in re.finditer(r'v_accvgpr_write_b32 a(\d+), v\d+', body):
             if int(w.group(1)) >= first_acc:
                 bad.append('%s: %s' % (name, w.group(0)))
