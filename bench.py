@@ -29,6 +29,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense f32-input MFMA (exact f32), the dtype this path computes in
+MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
 MFMA_BF16_PEAK_TF = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
@@ -199,7 +200,9 @@ def dominant_roofline(prof, overhead_ms, gather_roof, gather_table):
         return gather_roof, None, table
     name, r, v = best
     traffic, traffic_src = None, 'no committed PMC summary for this kernel instance'
-    for pmc in ('r05_pmc_winograd2.json', 'r04_pmc_winograd2.json'):          # newest committed PMC summary of this kernel
+    from crbhip import winograd as _w
+    x6 = _w.KERNEL == 'x6' and name.startswith('winograd_conv')                # (the forward / input-gradient kernel of this run)
+    for pmc in (('r06_pmc_winograd4.json',) if x6 else ('r05_pmc_winograd2.json', 'r04_pmc_winograd2.json')):   # newest committed PMC summary of this kernel
         try:
             pm = json.load(open(os.path.join(ROOT, 'profiles', pmc)))
             hit = next((e for key, e in pm.get('shapes', {}).items() if name.endswith('conv_' + key)), None)   # (forward / input-gradient instances)
@@ -211,7 +214,10 @@ def dominant_roofline(prof, overhead_ms, gather_roof, gather_table):
                 break
         except (OSError, ValueError, KeyError):
             continue
-    roof = {'bound': 'mfma', 'kernel': 'winograd2_kernel / winograd2_wgrad_kernel: %s (F(2x2,3x3) f32 MFMA, BEV backbone 3x3 convolutions)' % name,
+    kname = ('winograd4_kernel: %s (F(2x2,3x3), f32 in / f32 out, every product as six bf16 MFMA passes over an exact three-way split of '
+             'the f32 operands, f32 accumulate; BEV backbone 3x3 convolutions)' if x6 else
+             'winograd2_kernel / winograd2_wgrad_kernel: %s (F(2x2,3x3) f32 MFMA, BEV backbone 3x3 convolutions)') % name
+    roof = {'bound': 'mfma', 'kernel': kname,
             'achieved': r['TFLOPs'], 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s', 'frac': r['mfma_f32_frac'],
             'traffic': traffic, 'traffic_source': traffic_src,
             'avg_launch_us': r['avg_us'], 'launches': r['launches'], 'event_pair_overhead_us': round(1e3 * overhead_ms, 2),
@@ -221,6 +227,13 @@ def dominant_roofline(prof, overhead_ms, gather_roof, gather_table):
                         'mfma_f32': round(1e6 * v['flops'] / v['n'] / (MFMA_F32_PEAK_TF * 1e12), 2)},
             'note': 'flops = the MFMA work of the Winograd algorithm (16 GEMMs over 2x2-output tiles); the direct convolution it replaces '
                     'has 2.25x the flops (direct_equivalent_TFLOPs may exceed the MFMA peak: fewer multiplications, not a faster pipe)'}
+    if x6:
+        roof['bf16_mfma_TFLOPs_issued'] = round(6.0 * r['TFLOPs'], 1)
+        roof['bf16_mfma_frac'] = round(6.0 * r['TFLOPs'] / MFMA_BF16_PEAK_TF, 4)
+        roof['note'] += ('; achieved / peak / frac price the ALGORITHMIC f32 flops of the 16 GEMMs against the f32-input MFMA peak (the dtype of '
+                         'the path: f32 operands, f32 results, errors against f64 at the f32-MFMA kernel\'s level); the matrix pipe issues six '
+                         'bf16 passes per product: bf16_mfma_TFLOPs_issued against the 2,500 TFLOP/s dense bf16 peak = bf16_mfma_frac. The '
+                         'kernel is bound by LDS traffic, not by the matrix pipe (DESIGN section 6)')
     return roof, gather_roof, table
 
 
