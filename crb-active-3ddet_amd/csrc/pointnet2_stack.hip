@@ -1115,6 +1115,129 @@ __global__ __launch_bounds__(256) void three_interp_grad_kernel(int N, int C, co
   atomicAdd(&grad_feat[(int64_t)id[2] * C + c], g * ww[2]);
 }
 
+// ---- round 6: the in-register sampling kernel again, built for fewer vector instructions and ONE barrier per
+// round. fps_kernel spends a round (2.6 us at 20,000 points) on ~240 vector instructions per wave for the 20 distance updates with
+// their running (distance, index) pair, a 64-bit butterfly through ds_bpermute (20 of them), two barriers and a dependent global
+// load of the winner's coordinates by thread 0. Here:
+//   * the update runs on PAIRS of points in packed f32 (v_pk_add / v_pk_mul: the same IEEE operations in the
+//     same order, two points per instruction; min / max have no packed form) and keeps only the running maximum; the index of a lane's maximum is found
+//     afterwards (first t with dist[t] == maximum: the strided thread's first maximum, as before);
+//   * wave level: maximum distance by DPP row shifts + row broadcasts (6 steps, no LDS), lanes that hold it offer the tie key
+//     ((bit-reversed index bits << 20) | index, smallest wins: the order of the 64-bit keys of fps_kernel), minimum by DPP again;
+//     the winning lane fetches its point's coordinates with one 12-byte load (the cloud is L2-resident: 16 loads per round in
+//     parallel, one per wave, instead of thread 0's load behind the second barrier);
+//   * workgroup level: the winner lane of every wave writes {distance, key, x, y, z} into a double-buffered slot, ONE barrier, every
+//     wave reduces the 16 slots inside a DPP row and reads the winner's coordinates from the slot: no second barrier.
+// Picks are the picks of fps_kernel (tests/test_pointnet2_gpu.py: bit-exact against oracle_fps incl. the tie rule).
+typedef float fps_f2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float fps_dpp_f(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ unsigned fps_dpp_u(unsigned old, unsigned src) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xf, false);
+}
+// maximum over the wave (lane 63 holds it after the two broadcasts; returned as a uniform value)
+__device__ __forceinline__ float fps_wave_max(float v) {
+  v = fmaxf(v, fps_dpp_f<0x111>(v, v));          // row_shr:1
+  v = fmaxf(v, fps_dpp_f<0x112>(v, v));          // row_shr:2
+  v = fmaxf(v, fps_dpp_f<0x114>(v, v));          // row_shr:4
+  v = fmaxf(v, fps_dpp_f<0x118>(v, v));          // row_shr:8   -> lane 15 of every row: the row's maximum
+  v = fmaxf(v, fps_dpp_f<0x142, 0xa>(v, v));     // row_bcast:15 into rows 1, 3
+  v = fmaxf(v, fps_dpp_f<0x143, 0xc>(v, v));     // row_bcast:31 into rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ unsigned fps_wave_min_u(unsigned v) {
+  v = min(v, fps_dpp_u<0x111>(v, v));
+  v = min(v, fps_dpp_u<0x112>(v, v));
+  v = min(v, fps_dpp_u<0x114>(v, v));
+  v = min(v, fps_dpp_u<0x118>(v, v));
+  v = min(v, fps_dpp_u<0x142, 0xa>(v, v));
+  v = min(v, fps_dpp_u<0x143, 0xc>(v, v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+template <int PPT>      // points per thread, even
+__global__ __launch_bounds__(FPS_THREADS) void fps2_kernel(int n, int m, int log2bs, const float* __restrict__ xyz_all,
+                                                           int* __restrict__ out_all) {
+  __shared__ float slot[2][16][8];                 // [buffer][wave]: distance, key (bits), x, y, z
+  const float* xyz = xyz_all + (int64_t)blockIdx.x * n * 3;
+  int* out = out_all + (int64_t)blockIdx.x * m;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  fps_f2 px[PPT / 2], py[PPT / 2], pz[PPT / 2], dist[PPT / 2];      // element e of pair h: point tid + (2 h + e) * 1024
+  const unsigned bsmask = (1u << log2bs) - 1u;
+#pragma unroll
+  for (int h = 0; h < PPT / 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int k = tid + (2 * h + e) * FPS_THREADS;
+      const bool in = k < n;
+      px[h][e] = in ? xyz[k * 3 + 0] : 0.f; py[h][e] = in ? xyz[k * 3 + 1] : 0.f; pz[h][e] = in ? xyz[k * 3 + 2] : 0.f;
+      dist[h][e] = in ? 1e10f : -1.f;              // a slot past the end never wins: min(d, -1) = -1 < every real distance
+    }
+  float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
+  if (tid == 0) out[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    const fps_f2 X1 = (fps_f2){x1, x1}, Y1 = (fps_f2){y1, y1}, Z1 = (fps_f2){z1, z1};
+    float lmax = -1.f;
+#pragma unroll
+    for (int h = 0; h < PPT / 2; ++h) {
+      const fps_f2 dx = px[h] - X1, dy = py[h] - Y1, dz = pz[h] - Z1;
+      const fps_f2 d = dx * dx + dy * dy + dz * dz;
+      // (no NaNs here: fminf / fmaxf add a canonicalising v_max x, x, x per operand; gfx950 has no packed f32 min / max)
+      float d0, d1;
+      asm("v_min_f32 %0, %1, %2" : "=v"(d0) : "v"(d[0]), "v"(dist[h][0]));
+      asm("v_min_f32 %0, %1, %2" : "=v"(d1) : "v"(d[1]), "v"(dist[h][1]));
+      dist[h] = (fps_f2){d0, d1};
+      asm("v_max3_f32 %0, %1, %2, %3" : "=v"(lmax) : "v"(lmax), "v"(d0), "v"(d1));
+    }
+    const float bestd = lmax;
+    const float M = fps_wave_max(bestd);
+    // the lane's first maximum (descending scan: the smallest t is written last)
+    int bestt = 0;
+#pragma unroll
+    for (int t = PPT - 1; t >= 0; --t) bestt = dist[t >> 1][t & 1] == bestd ? t : bestt;
+    const int bestk = tid + bestt * FPS_THREADS;
+    const unsigned v = (unsigned)bestk & bsmask;
+    const unsigned br = log2bs ? (__brev(v) >> (32 - log2bs)) : 0u;
+    const unsigned key = (bestd == M && bestd >= 0.f) ? ((br << 20) | (unsigned)bestk) : 0xffffffffu;
+    const unsigned K = fps_wave_min_u(key);
+    // the wave's winner lane fetches its point (one 12-byte load, L2-resident cloud) and fills the wave's slot
+    float* sl = slot[j & 1][0];
+    if (key == K && K != 0xffffffffu) {
+      const float* p = xyz + (int64_t)bestk * 3;
+      float* o = sl + wave * 8;
+      o[0] = M; o[1] = __uint_as_float(K); o[2] = p[0]; o[3] = p[1]; o[4] = p[2];
+    } else if (K == 0xffffffffu && lane == 0) {
+      float* o = sl + wave * 8;
+      o[0] = -1.f; o[1] = __uint_as_float(K);
+    }
+    __syncthreads();
+    // every wave: the best of the 16 slots (inside one DPP row), then the winner's coordinates from its slot
+    const int w16 = lane & 15;
+    const float sd = sl[w16 * 8];
+    const unsigned sk = __float_as_uint(sl[w16 * 8 + 1]);
+    float gm = sd;
+    gm = fmaxf(gm, fps_dpp_f<0x111>(gm, gm));
+    gm = fmaxf(gm, fps_dpp_f<0x112>(gm, gm));
+    gm = fmaxf(gm, fps_dpp_f<0x114>(gm, gm));
+    gm = fmaxf(gm, fps_dpp_f<0x118>(gm, gm));
+    const float GM = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gm), 15));
+    unsigned gk = sd == GM ? sk : 0xffffffffu;
+    gk = min(gk, fps_dpp_u<0x111>(gk, gk));
+    gk = min(gk, fps_dpp_u<0x112>(gk, gk));
+    gk = min(gk, fps_dpp_u<0x114>(gk, gk));
+    gk = min(gk, fps_dpp_u<0x118>(gk, gk));
+    const unsigned GK = (unsigned)__builtin_amdgcn_readlane((int)gk, 15);
+    const unsigned long long wb = __ballot(sd == GM && sk == GK) & 0xffffULL;
+    const int ww = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(wb ? wb : 1ULL));
+    x1 = sl[ww * 8 + 2]; y1 = sl[ww * 8 + 3]; z1 = sl[ww * 8 + 4];
+    if (tid == 0) out[j] = (int)(GK & 0xfffffu);
+  }
+}
+
 // any n: running distances in a caller-provided (B,n) buffer, coordinates re-read every round
 __global__ __launch_bounds__(FPS_THREADS) void fps_large_kernel(int n, int m, int log2bs, const float* __restrict__ xyz_all,
                                                                 float* __restrict__ temp_all, int* __restrict__ out_all) {
@@ -1166,12 +1289,18 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_large_kernel(int n, int m, in
   }
 }
 
+CRB_KNOB g_fps_variant = 2;      // 2 = fps2_kernel for the in-register sizes (default), 1 = fps_kernel (measurement library: A/B)
 template <int PPT, bool REGS>
 void launch_fps(int B, int n, int m, int log2bs, const float* xyz, int* out, hipStream_t st) {
-  hipLaunchKernelGGL((fps_kernel<PPT, REGS>), dim3(B), dim3(FPS_THREADS), 0, st, n, m, log2bs, xyz, out);
+  if (REGS && g_fps_variant == 2) hipLaunchKernelGGL((fps2_kernel<PPT>), dim3(B), dim3(FPS_THREADS), 0, st, n, m, log2bs, xyz, out);
+  else hipLaunchKernelGGL((fps_kernel<PPT, REGS>), dim3(B), dim3(FPS_THREADS), 0, st, n, m, log2bs, xyz, out);
 }
 
 }  // namespace
+
+#ifdef CRB_MEASURE
+extern "C" int crb_fps_set_variant(int v) { g_fps_variant = v == 1 ? 1 : 2; return CRB_OK; }
+#endif
 
 extern "C" int crb_ball_query_stack(int B, int64_t M, float radius, int nsample, const float* new_xyz,
                                     const int32_t* new_xyz_batch_cnt, const float* xyz, const int32_t* xyz_batch_cnt,

@@ -23,6 +23,9 @@ int crb_winograd2_set_mode(int mode);
 int crb_winograd4_set_mode(int mode);
 /* A/B: 1 = the product kernel (one 512-register wave per SIMD), 2 = the second form (two waves per SIMD, xi split over wave pairs, pipelined) */
 int crb_winograd4_set_variant(int v);
+/* A/B of the farthest-point sampling kernel for the in-register sizes: 2 = fps2_kernel (packed updates, DPP reductions, one barrier per
+ * round; default), 1 = fps_kernel (round 2) */
+int crb_fps_set_variant(int v);
 /* mode 9 (correct results + s_memtime sums per (workgroup, wave): {counter wait, barrier, phase head, phase body, epilogue, total, chunks, units}): 8 uint64 per wave, 8 waves per workgroup; NULL = off */
 int crb_winograd4_set_debug(void* dev_buf_u64x64_per_wg);
 /* mode 4 (correct results + stamps) writes 16 uint64 per workgroup {s_memtime: start, after prologue, after chunks, cycles parked at the chunk barriers; wall_clock64 (100 MHz): start, end; XCC id; units; per-stage cycle sums}. NULL = off */
