@@ -52,6 +52,7 @@ def parse():
     ap.add_argument('--kind', default='kitti', choices=['kitti', 'waymo'])
     ap.add_argument('--pool', type=int, default=2, help='distinct resident batches cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-leg-tables', action='store_true', help='skip the per-launch kernel tables of the PV-RCNN and scoring legs')
     ap.add_argument('--n1-value', type=float, default=0.0, help='frames/s of the 1-GPU run of the same code: fills summary.scaling_efficiency '
                                                                 'of an N > 1 line (value / (N x this))')
     ap.add_argument('--no-sparse-prefetch', action='store_true',
@@ -418,6 +419,119 @@ def _max_over_ranks(dt, world, device):
     return dt
 
 
+class CallProfiler:
+    """HIP-event pairs around EVERY launch that goes through the C-ABI while it is active (the PV-RCNN and scoring
+    legs on the driver's roofline). `lib.crb_*` attributes are replaced by wrappers that record an event on torch's current stream
+    (= the stream handed to the call) before and after; run OUTSIDE the timed regions. Rows: per entry point and shape key - launches
+    per unit (step / pass), average microseconds, and for the kernels with a work formula the algorithmic flops over LIVE rows
+    (queries whose ball is not empty: read from the call's own empty mask) against the f32-MFMA peak, or the algorithmic bytes
+     against HBM."""
+
+    @staticmethod
+    def _live(ptr_value, count):
+        if not ptr_value or count <= 0:
+            return None
+
+        class _V:
+            __cuda_array_interface__ = {'data': (int(ptr_value), False), 'shape': (int(count),), 'typestr': '|u1', 'version': 2}
+        return (torch.as_tensor(_V(), device='cuda') == 0).sum()
+
+    WORK = {
+        # name: args -> (shape key, flops over all rows, bytes, (empty-mask pointer, rows) or None, extra)
+        'crb_sa_mlp2_train_stats': lambda a: ((a[3], a[4], a[2]), 2.0 * a[1] * a[2] * a[3] * a[4], 0.0, (a[11], a[1]), {}),
+        'crb_sa_mlp2_train_max': lambda a: ((a[3], a[4], a[2]), 2.0 * a[1] * a[2] * a[3] * a[4], 0.0, (a[11], a[1]), {}),
+        'crb_sa_mlp2_train_backward': lambda a: ((a[3], a[4], a[2]), 6.0 * a[1] * a[2] * a[3] * a[4], 0.0, (a[11], a[1]), {}),
+        'crb_sa_mlp2_max_stack': lambda a: ((a[3], a[4], a[2]), 2.0 * a[1] * a[2] * a[3] * a[4], 0.0, (a[11], a[1]), {}),
+        'crb_group_affine_rows_stats_stack': lambda a: ((a[2], a[3]), 0.0, 4.0 * a[1] * a[3] * (1 + a[2]), (a[10], a[1]), {}),
+        'crb_group_affine_rows_grad_bn_recompute_stack': lambda a: ((a[2], a[3]), 0.0, 4.0 * a[1] * a[3] * (1 + 2 * a[2]), (a[10], a[1]), {}),
+        'crb_group_affine_rows_grad_stack': lambda a: ((a[2], a[3]), 0.0, 4.0 * a[1] * a[3] * (1 + 2 * a[2]), (a[7], a[1]), {}),
+        'crb_farthest_point_sample': lambda a: ((a[1], a[2]), 0.0, 0.0, None, {'rounds': float(a[0]) * 0 + float(a[2] - 1), 'frames': a[0]}),
+        'crb_ball_query2_stack': lambda a: ((a[3], a[5]), 0.0, 0.0, None, {'queries': float(a[1])}),
+        'crb_ball_query2_grouped_stack': lambda a: ((a[2], a[4], a[6]), 0.0, 0.0, None, {'queries': float(a[1])}),
+        'crb_nms_batched': lambda a: ((a[3], a[6]), 0.0, float(a[2]) * (28.0 * a[3] + 8.0 * a[3] * ((a[3] + 63) // 64)), None, {}),
+    }
+
+    def __init__(self):
+        self.records = []
+        self._saved = {}
+
+    def __enter__(self):
+        from crbhip import _lib
+        L = _lib.lib
+        for name in _lib.parse_header():
+            fn = getattr(L, name, None)
+            if fn is None or not fn.argtypes or name.endswith(('_bytes', '_supported', '_floats', '_waves', '_slabs')):
+                continue
+            self._saved[name] = fn
+
+            def wrap(*args, _fn=fn, _name=name):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = _fn(*args)
+                e1.record()
+                work = self.WORK.get(_name)
+                key, fl, by, live, extra = (None, 0.0, 0.0, None, {})
+                if work is not None:
+                    vals = [getattr(v, 'value', v) for v in args]
+                    key, fl, by, live, extra = work(vals)
+                    if live is not None:
+                        live = (self._live(live[0], live[1]), live[1])
+                self.records.append((_name, key, fl, by, live, extra, e0, e1))
+                return rc
+            setattr(L, name, wrap)
+        return self
+
+    def __exit__(self, *exc):
+        from crbhip import _lib
+        for name, fn in self._saved.items():
+            setattr(_lib.lib, name, fn)
+        return False
+
+    def rows(self, units, overhead_ms=0.0):
+        """-> ({row name: row}, roofline of the row with the most time among the kernels that have a work formula)"""
+        torch.cuda.synchronize()
+        agg = {}
+        for name, key, fl, by, live, extra, e0, e1 in self.records:
+            ms = max(e0.elapsed_time(e1) - overhead_ms, 1e-4)
+            frac = 1.0
+            if live is not None and live[0] is not None:
+                frac = float(live[0].item()) / max(1, live[1])
+            k = name[4:] + ('' if key is None else '_' + '_'.join(str(x) for x in key))
+            a = agg.setdefault(k, {'ms': 0.0, 'n': 0, 'flops': 0.0, 'bytes': 0.0, 'live': 0.0, 'rounds': 0.0, 'queries': 0.0})
+            a['ms'] += ms; a['n'] += 1; a['flops'] += fl * frac; a['bytes'] += by * frac; a['live'] += frac
+            a['rounds'] += extra.get('rounds', 0.0); a['queries'] += extra.get('queries', 0.0)
+        rows, best = {}, None
+        for k, a in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):
+            r = {'launches_per_unit': round(a['n'] / units, 2), 'avg_us': round(1e3 * a['ms'] / a['n'], 2), 'ms_per_unit': round(a['ms'] / units, 3)}
+            if a['flops'] > 0:
+                tf = a['flops'] / (a['ms'] * 1e-3) / 1e12
+                r.update({'TFLOPs_live_rows': round(tf, 2), 'mfma_f32_frac': round(tf / MFMA_F32_PEAK_TF, 4), 'live_fraction': round(a['live'] / a['n'], 3)})
+            if a['bytes'] > 0:
+                gb = a['bytes'] / (a['ms'] * 1e-3) / 1e9
+                r.update({'GBps_alg': round(gb, 1), 'hbm_frac': round(gb / HBM_PEAK_GBS, 4), 'live_fraction': round(a['live'] / a['n'], 3)})
+            if a['rounds'] > 0:
+                r['us_per_round'] = round(1e3 * a['ms'] / a['rounds'], 3)
+            if a['queries'] > 0:
+                r['Mqueries_per_s'] = round(a['queries'] / (a['ms'] * 1e-3) / 1e6, 1)
+            rows[k] = r
+            if (a['flops'] > 0 or a['bytes'] > 0) and (best is None or a['ms'] > best[1]['ms']):
+                best = (k, a, r)
+        roof = None
+        if best is not None:
+            k, a, r = best
+            if a['flops'] > 0:
+                roof = {'bound': 'mfma', 'kernel': k, 'achieved': r['TFLOPs_live_rows'], 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
+                        'frac': r['mfma_f32_frac'], 'traffic': None, 'avg_launch_us': r['avg_us'], 'launches_per_unit': r['launches_per_unit'],
+                        'alg_flops_per_launch': round(a['flops'] / a['n']), 'live_fraction': r['live_fraction'],
+                        'note': 'the leg\'s own kernel with the most time; flops over live rows (queries with a non-empty ball)'}
+            else:
+                roof = {'bound': 'hbm', 'kernel': k, 'achieved': r['GBps_alg'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': r['hbm_frac'],
+                        'traffic': None, 'avg_launch_us': r['avg_us'], 'launches_per_unit': r['launches_per_unit'],
+                        'alg_bytes_per_launch': round(a['bytes'] / a['n'])}
+        return rows, roof
+
+
 def crb_scoring_bench(args, rank, world, device):
     """CRB stage-1 acquisition scoring over the BASELINE configs[3] pool (3,000 synthetic KITTI frames): every rank scores
     its rank-strided shard with the PV-RCNN eval forward + 5 MC-dropout head passes and the batched post-processing records
@@ -495,6 +609,12 @@ def crb_scoring_bench(args, rank, world, device):
                   'note': 'resident passes at the reference\'s evaluation batch size; `value` above uses --scoring-batch frames per '
                           'batch (an eval-mode pass scores every frame on its own: the batch size is the caller\'s loader setting)'}
         del kept_ref
+    # kernel table of one scoring batch (event pairs around every C-ABI launch, outside the timed passes)
+    ktable = kroof = None
+    if not getattr(args, 'no_leg_tables', False):
+        with CallProfiler() as cp:
+            strat.score_device_batches(kept[:2])
+        ktable, kroof = cp.rows(2.0, event_pair_overhead_ms())
     miopen_s = None
     if getattr(args, 'miopen_steps', 0) > 0:
         from pcdet.models.backbones_2d import base_bev_backbone as bev
@@ -550,6 +670,7 @@ def crb_scoring_bench(args, rank, world, device):
             'per_rank_seconds': {'loader_pass': rank_seconds[0], 'resident_passes': rank_seconds[1:1 + len(times)],
                                  'note': 'each rank\'s own time for the pass (its scoring + the all-gather it waits in), before the closing barrier'},
             'collectives': [dict(c, seconds=round(c['seconds'], 5)) for c in coll],
+            'roofline': kroof, 'kernel_table': ktable, 'kernel_table_unit': 'one batch of %d frames' % bs,
             'record_bytes_per_frame': 4 * strat.layout.stride, 'boxes_kept_total': int(rec[:, 1].sum().item())}
 
 
@@ -600,7 +721,16 @@ def pvrcnn_bench(args, rank, world, device):
     if world > 1 or FORCE_DIST:
         dist.barrier()
     dt = _max_over_ranks(time.perf_counter() - t0, world, device)
+    ktable = kroof = None
+    if not getattr(args, 'no_leg_tables', False) and rank == 0:
+        with CallProfiler() as cp:                      # two more steps with an event pair around every C-ABI launch (not timed)
+            for i in range(2):
+                step(args.pvrcnn_steps + i)
+        ktable, kroof = cp.rows(2.0, event_pair_overhead_ms())
     out = {'metric': 'frames/s PV-RCNN fwd+bwd+AdamW, KITTI 20k-pt clouds', 'unit': 'frames/s',
+           'roofline': kroof, 'kernel_table': ktable, 'kernel_table_unit': 'one training step',
+           'kernel_table_note': 'HIP-event pairs around every launch of libcrbhip.so during two extra steps (launches on the side stream '
+                                'overlap the main stream: the rows do not add up to the step); Winograd rows: see the top-level kernel_table',
            'value': round(args.batch * world * args.pvrcnn_steps / dt, 3), 'ms_per_step': round(1e3 * dt / args.pvrcnn_steps, 3),
            'steps': args.pvrcnn_steps, 'warmup': 3, 'dtype': 'f32',
            'config': {'workload': 'BASELINE configs[2]: PV-RCNN (VoxelBackBone8x + VSA + PointHeadSimple + PVRCNNHead) on '
