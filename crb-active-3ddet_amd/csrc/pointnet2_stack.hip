@@ -1115,6 +1115,233 @@ __global__ __launch_bounds__(256) void three_interp_grad_kernel(int N, int C, co
   atomicAdd(&grad_feat[(int64_t)id[2] * C + c], g * ww[2]);
 }
 
+
+// ------------------------------------------------------------------------------------------------ ball query on a cell grid
+// (round 6) The scans above test every point of the frame against every query
+// (ball_query_gpu.cu:47-66 does the same per thread). Here the points of one call are put into a hashed grid of cells of edge
+// 1.001 r_b by a counting sort of the call's own (histogram with atomics, exclusive scan, cursor fill: 5 launches, no library
+// sort), a query reads the 27 cells around its own (distinct hash buckets only), tests those candidates with the SAME distance
+// expression, and keeps the nsample SMALLEST point indices of each radius in ascending order: the list a scan in index order would
+// have produced (ball_query_gpu.cu:49-64: hits in scan order, first nsample, padded with the first hit), index-exact. A bucket may
+// hold points of other cells or frames (hash collisions): they fail the frame or the distance test like any other point. Queries
+// with more than BQG_MAX_CAND candidates or BQG_MAX_HITS hits in r_b (dense balls) are answered by the scan, which ends early there.
+// Why 1.001: a point with |dx| < r_b has to lie in a neighbouring cell; floor(x / c) of the two sides is computed in f32 (error <= 3e-5
+// cells at 250 cells from the origin), the margin keeps the difference of the floors <= 1.
+constexpr int BQG_MAX_CAND = 4096, BQG_MAX_HITS = 1024;
+
+struct BqGrid {
+  float inv_cell;
+  unsigned mask;       // buckets - 1 (power of two)
+};
+__device__ __forceinline__ unsigned bqg_bucket(const BqGrid& g, int b, int ix, int iy, int iz) {
+  unsigned h = (unsigned)ix * 73856093u ^ (unsigned)iy * 19349663u ^ (unsigned)iz * 83492791u ^ (unsigned)b * 2654435761u;
+  h ^= h >> 15;
+  return h & g.mask;
+}
+// exclusive prefixes of the two count vectors, B + 1 entries each (one wave; B is a batch size)
+__global__ __launch_bounds__(64) void bqg_prefix_kernel(int B, const int* __restrict__ xyz_cnt, const int* __restrict__ new_cnt,
+                                                        int* __restrict__ xyz_pref, int* __restrict__ new_pref) {
+  int ax = 0, an = 0;
+  for (int k0 = 0; k0 < B; k0 += 64) {
+    const int k = k0 + (int)threadIdx.x;
+    const int cx = k < B ? xyz_cnt[k] : 0, cn = k < B ? new_cnt[k] : 0;
+    const int ix = crb_wave_incl_scan(cx), in = crb_wave_incl_scan(cn);
+    if (k < B) { xyz_pref[k] = ax + ix - cx; new_pref[k] = an + in - cn; }
+    ax += __shfl(ix, 63, 64);
+    an += __shfl(in, 63, 64);
+  }
+  if (threadIdx.x == 0) { xyz_pref[B] = ax; new_pref[B] = an; }
+}
+// frame of row i: the last b with pref[b] <= i (rows past the end: the last frame)
+__device__ __forceinline__ int bqg_frame_of(const int* __restrict__ pref, int B, int i) {
+  int lo = 0, hi = B - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (pref[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+__global__ __launch_bounds__(256) void bqg_hist_kernel(BqGrid g, int B, int n, const float* __restrict__ xyz, const int* __restrict__ xyz_pref,
+                                                       int* __restrict__ count, int* __restrict__ bucket_of) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int b = bqg_frame_of(xyz_pref, B, i);
+  const unsigned h = bqg_bucket(g, b, (int)floorf(xyz[(int64_t)i * 3] * g.inv_cell), (int)floorf(xyz[(int64_t)i * 3 + 1] * g.inv_cell),
+                                (int)floorf(xyz[(int64_t)i * 3 + 2] * g.inv_cell));
+  bucket_of[i] = (int)h;
+  atomicAdd(&count[h], 1);
+}
+__global__ __launch_bounds__(256) void bqg_fill_kernel(int n, const int* __restrict__ bucket_of, int* __restrict__ cursor, int* __restrict__ sorted) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  sorted[atomicAdd(&cursor[bucket_of[i]], 1)] = i;      // (order inside a bucket: arbitrary; the query kernel orders its hits by index)
+}
+
+__global__ __launch_bounds__(256) void ball_query2_grid_kernel(BqGrid g, int B, int M, float ra, int nsa, float rb, int nsb,
+                                                               const float* __restrict__ new_xyz, const int* __restrict__ new_cnt,
+                                                               const float* __restrict__ xyz, const int* __restrict__ xyz_cnt,
+                                                               const int* __restrict__ xyz_pref, const int* __restrict__ new_pref,
+                                                               const int* __restrict__ bstart, const int* __restrict__ sorted,
+                                                               int* __restrict__ idx_a, int* __restrict__ idx_b,
+                                                               unsigned char* __restrict__ empty_a, unsigned char* __restrict__ empty_b) {
+  __shared__ int s_pref[4][64], s_beg[4][32];           // (s_pref doubles as the selection scratch: nsample <= 64)
+  __shared__ int s_hit[4][BQG_MAX_HITS];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + wave;
+  if (q >= M) return;
+  const int b = bqg_frame_of(new_pref, B, q);               // (log2 B cached loads: locate_batch's B dependent loads per wave cost more than the query)
+  const int start = xyz_pref[b];
+  const int n = xyz_pref[b + 1] - start;
+  const float* p = xyz + (int64_t)start * 3;
+  const float qx = new_xyz[(int64_t)q * 3 + 0], qy = new_xyz[(int64_t)q * 3 + 1], qz = new_xyz[(int64_t)q * 3 + 2];
+  const float ra2 = ra * ra, rb2 = rb * rb;
+  const unsigned long long below = (1ULL << lane) - 1ULL;
+  int* oa = idx_a + (int64_t)q * nsa;
+  int* ob = idx_b + (int64_t)q * nsb;
+  // ---- the 27 buckets around the query's cell, duplicates dropped
+  const int cx = (int)floorf(qx * g.inv_cell), cy = (int)floorf(qy * g.inv_cell), cz = (int)floorf(qz * g.inv_cell);
+  int hb = -1, beg = 0, len = 0;
+  if (lane < 27) {
+    hb = (int)bqg_bucket(g, b, cx + lane % 3 - 1, cy + (lane / 3) % 3 - 1, cz + lane / 9 - 1);
+    beg = bstart[hb];
+    len = bstart[hb + 1] - beg;
+  }
+  for (int j = 0; j < 26; ++j) {
+    const int hj = __builtin_amdgcn_readlane(hb, j);
+    if (lane > j && lane < 27 && hb == hj) len = 0;
+  }
+  const int pref = crb_wave_incl_scan(len) - len;                          // candidates in front of this lane's bucket
+  const int T = __builtin_amdgcn_readlane(pref + len, 63);
+  bool scan = T > BQG_MAX_CAND;
+  int H = 0;
+  if (!scan) {
+    if (lane < 32) { s_pref[wave][lane] = lane < 27 ? pref : 0x7fffffff; s_beg[wave][lane] = beg; }
+    __builtin_amdgcn_wave_barrier();
+    // (wave-private LDS, in-order LDS pipe: the stores above are visible to this wave's reads below)
+    for (int c0 = 0; c0 < T; c0 += 256) {                                  // four candidates per lane and step: four load chains in flight
+      int k[4];
+      float d2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = c0 + u * 64 + lane;
+        k[u] = -1;
+        if (t < T) {
+          int lo = 0;                                                      // last bucket whose prefix is <= t (empty buckets share a prefix: take the last)
+#pragma unroll
+          for (int s = 16; s > 0; s >>= 1)
+            if (lo + s < 27 && s_pref[wave][lo + s] <= t) lo += s;
+          k[u] = sorted[s_beg[wave][lo] + (t - s_pref[wave][lo])] - start;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        d2[u] = __builtin_inff();
+        if (k[u] >= 0 && k[u] < n) {
+          const float x = p[k[u] * 3 + 0], y = p[k[u] * 3 + 1], z = p[k[u] * 3 + 2];
+          d2[u] = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool hit_b = d2[u] < rb2, hit_a = d2[u] < ra2;
+        const unsigned long long mb = __ballot(hit_b);
+        if (mb != 0ULL) {
+          const int pos = H + __popcll(mb & below);
+          if (hit_b && pos < BQG_MAX_HITS) s_hit[wave][pos] = k[u] | (hit_a ? (int)0x80000000 : 0);
+          H += __popcll(mb);
+        }
+      }
+    }
+    scan = H > BQG_MAX_HITS;
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (scan) {                                                               // dense ball: the scan in index order ends after a few points
+    int ca = 0, cb = 0, fa = -1, fb = -1;
+    for (int k0 = 0; k0 < n && (ca < nsa || cb < nsb); k0 += 64) {
+      const int k = k0 + lane;
+      bool ha = false, hbb = false;
+      if (k < n) {
+        const float x = p[k * 3 + 0], y = p[k * 3 + 1], z = p[k * 3 + 2];
+        const float d2 = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z);
+        ha = d2 < ra2;
+        hbb = d2 < rb2;
+      }
+      const unsigned long long ma = __ballot(ha), mb = __ballot(hbb);
+      if (ma != 0ULL && ca < nsa) {
+        if (fa < 0) fa = k0 + (__ffsll((long long)ma) - 1);
+        const int pos = ca + __popcll(ma & below);
+        if (ha && pos < nsa) oa[pos] = k;
+        ca += __popcll(ma);
+      }
+      if (mb != 0ULL && cb < nsb) {
+        if (fb < 0) fb = k0 + (__ffsll((long long)mb) - 1);
+        const int pos = cb + __popcll(mb & below);
+        if (hbb && pos < nsb) ob[pos] = k;
+        cb += __popcll(mb);
+      }
+    }
+    ca = ca > nsa ? nsa : ca;
+    cb = cb > nsb ? nsb : cb;
+    for (int l = ca + lane; l < nsa; l += 64) oa[l] = (fa >= 0) ? fa : 0;
+    for (int l = cb + lane; l < nsb; l += 64) ob[l] = (fb >= 0) ? fb : 0;
+    if (lane == 0) { empty_a[q] = fa < 0; empty_b[q] = fb < 0; }
+    return;
+  }
+  // ---- the nsample smallest indices of each radius, in ascending order (H <= BQG_MAX_HITS hits in s_hit, bit 31: inside r_a too)
+  auto emit = [&](bool want_a, int ns, int* out, unsigned char* empty_flag) {
+    // count of the radius, and the largest index that is still among the ns smallest (threshold search over the index range)
+    int cnt = 0;
+    for (int i0 = 0; i0 < H; i0 += 64) {
+      const int i = i0 + lane;
+      const bool in = i < H && (!want_a || s_hit[wave][i] < 0);
+      cnt += __popcll(__ballot(in));
+    }
+    int thr = 0x7fffffff;
+    if (cnt > ns) {
+      int lo = 0, hi = n - 1;                                               // smallest v with #(k <= v) >= ns
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        int c = 0;
+        for (int i0 = 0; i0 < H; i0 += 64) {
+          const int i = i0 + lane;
+          const int v = i < H ? s_hit[wave][i] : 0;
+          c += __popcll(__ballot(i < H && (!want_a || v < 0) && (v & 0x7fffffff) <= mid));
+        }
+        if (c >= ns) hi = mid; else lo = mid + 1;
+      }
+      thr = lo;
+    }
+    const int total = cnt < ns ? cnt : ns;
+    // the selected hits (at most ns <= 64 of them) compacted into the wave's bucket scratch, then ranked among themselves
+    int* sel = s_pref[wave];                                                // (s_pref / s_beg: 64 ints, done with)
+    int at = 0;
+    for (int i0 = 0; i0 < H; i0 += 64) {
+      const int i = i0 + lane;
+      const int v = i < H ? s_hit[wave][i] : 0;
+      const bool pick = i < H && (!want_a || v < 0) && (v & 0x7fffffff) <= thr;
+      const unsigned long long m = __ballot(pick);
+      if (pick) sel[at + __popcll(m & below)] = v & 0x7fffffff;
+      at += __popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    int mine = 0x7fffffff, rank = 0;
+    if (lane < total) {
+      mine = sel[lane];
+      for (int j = 0; j < total; ++j) rank += sel[j] < mine ? 1 : 0;
+      out[rank] = mine;
+    }
+    int first = mine;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) first = min(first, __shfl_xor(first, s, 64));
+    for (int l = total + lane; l < ns; l += 64) out[l] = total > 0 ? first : 0;
+    if (lane == 0) *empty_flag = total == 0;
+    __builtin_amdgcn_wave_barrier();
+  };
+  emit(true, nsa, oa, empty_a + q);
+  emit(false, nsb, ob, empty_b + q);
+}
+
 // ---- round 6: the in-register sampling kernel again, built for fewer vector instructions and ONE barrier per
 // round. fps_kernel spends a round (2.6 us at 20,000 points) on ~240 vector instructions per wave for the 20 distance updates with
 // their running (distance, index) pair, a 64-bit butterfly through ds_bpermute (20 of them), two barriers and a dependent global
@@ -1329,6 +1556,58 @@ extern "C" int crb_ball_query2_stack(int B, int64_t M, float radius_a, int nsamp
                        nsample_a, radius_b, nsample_b, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx_a, idx_b,
                        empty_a, empty_b);
   }
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+// workspace of crb_ball_query2_grid_stack for n_total source points: bucket counts / starts, cursors, bucket of every point, the
+// sorted point list, scan tile sums
+static inline int64_t bqg_buckets(int64_t n_total) {
+  int64_t nb = 1024;
+  while (nb < 2 * n_total && nb < (1LL << 24)) nb <<= 1;
+  return nb;
+}
+extern "C" int64_t crb_ball_query2_grid_workspace_bytes(int64_t n_total) {
+  if (n_total <= 0) return 256;
+  const int64_t nb = bqg_buckets(n_total);
+  return 4 * (crb_align_up(nb + 1, 64) + crb_align_up(nb, 64) + 2 * crb_align_up(n_total, 64) + crb_align_up(crb_scan_num_tiles(nb + 1), 64) + 2 * 4096 + 128) + 1024;
+}
+
+struct BqgCount { const int* c; int64_t nb; __device__ int operator()(int64_t i) const { return i < nb ? c[i] : 0; } };
+struct BqgWrite { int* start; int* cursor; int64_t nb; __device__ void operator()(int64_t i, int ex, int) const { start[i] = ex; if (i < nb) cursor[i] = ex; } };
+
+extern "C" int crb_ball_query2_grid_stack(int B, int64_t M, float radius_a, int nsample_a, float radius_b, int nsample_b,
+                                          const float* new_xyz, const int32_t* new_xyz_batch_cnt, const float* xyz,
+                                          const int32_t* xyz_batch_cnt, int64_t n_total, int32_t* idx_a, int32_t* idx_b,
+                                          uint8_t* empty_a, uint8_t* empty_b, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (B <= 0 || M < 0 || nsample_a <= 0 || nsample_b <= 0 || M >= (1LL << 31) || n_total < 0 || n_total >= (1LL << 30)) return CRB_ERR_ARG;
+  if (!(radius_a <= radius_b) || !(radius_b > 0.f) || nsample_a > 64 || nsample_b > 64) return CRB_ERR_UNSUPPORTED;
+  if (M == 0) return CRB_OK;
+  if (workspace_bytes < crb_ball_query2_grid_workspace_bytes(n_total) || !workspace) return CRB_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nb = bqg_buckets(n_total);
+  int* count = (int*)workspace;                                   // nb + 1 (the scan's input; starts after it: in place is not possible)
+  int* startv = count;                                            // (exclusive scan written over the counts: the apply pass reads a tile before it writes it)
+  int* cursor = count + crb_align_up(nb + 1, 64);
+  int* bucket_of = cursor + crb_align_up(nb, 64);
+  int* sorted = bucket_of + crb_align_up(n_total, 64);
+  int* tiles = sorted + crb_align_up(n_total, 64);
+  int* xyz_pref = tiles + crb_align_up(crb_scan_num_tiles(nb + 1), 64);      // B + 1 each (B <= 4095)
+  int* new_pref = xyz_pref + 4096 + 64;
+  if (B >= 4096) return CRB_ERR_ARG;
+  BqGrid g;
+  g.inv_cell = 1.0f / (radius_b * 1.001f);
+  g.mask = (unsigned)(nb - 1);
+  CRB_HIP(hipMemsetAsync(count, 0, (size_t)(nb + 1) * sizeof(int), st));
+  hipLaunchKernelGGL(bqg_prefix_kernel, dim3(1), dim3(64), 0, st, B, xyz_batch_cnt, new_xyz_batch_cnt, xyz_pref, new_pref);
+  if (n_total > 0)
+    hipLaunchKernelGGL(bqg_hist_kernel, dim3(crb_cdiv(n_total, 256)), dim3(256), 0, st, g, B, (int)n_total, xyz, xyz_pref, count, bucket_of);
+  const int rc = crb_device_excl_scan(BqgCount{count, nb}, BqgWrite{startv, cursor, nb}, nb + 1, tiles, nullptr, st);
+  if (rc != CRB_OK) return rc;
+  if (n_total > 0)
+    hipLaunchKernelGGL(bqg_fill_kernel, dim3(crb_cdiv(n_total, 256)), dim3(256), 0, st, (int)n_total, bucket_of, cursor, sorted);
+  hipLaunchKernelGGL(ball_query2_grid_kernel, dim3(crb_cdiv(M, 4)), dim3(256), 0, st, g, B, (int)M, radius_a, nsample_a, radius_b,
+                     nsample_b, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, xyz_pref, new_pref, startv, sorted, idx_a, idx_b, empty_a, empty_b);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }

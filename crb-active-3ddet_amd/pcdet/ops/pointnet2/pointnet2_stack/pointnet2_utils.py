@@ -39,6 +39,16 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+# CRB_BALL_QUERY_GRID=1 (opt-in): the ball queries of the set-abstraction layers on a per-call cell grid (crb_ball_query2_grid_stack)
+# instead of a scan of the whole frame. Index-exact (tests), but measured SLOWER than the 8-queries-per-wave scans at 20,000 points per
+# frame on every source of the PV-RCNN set abstraction (tools/time_ball_query.py: 198-371 us against 51-293 us per call at 16 frames,
+# 661-1,222 against 143-891 at 64): one query per wave pays two dependent random loads per candidate and a selection pass, the scan
+# streams coalesced points for eight queries at once and ends early. Frames with fewer points than the threshold are always scanned
+BALL_QUERY_GRID = __import__('os').environ.get('CRB_BALL_QUERY_GRID', '0') == '1'
+BALL_QUERY_GRID_MIN_POINTS = int(__import__('os').environ.get('CRB_BALL_QUERY_GRID_MIN_POINTS', '2048'))
+_BQ_WS = {}
+
+
 @torch.no_grad()
 def ball_query_pair(radius_a, nsample_a, radius_b, nsample_b, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, group=None):
     """both radii of a StackSAModuleMSG in one scan -> ((idx_a, empty_a), (idx_b, empty_b)), the same values as two
@@ -57,6 +67,18 @@ def ball_query_pair(radius_a, nsample_a, radius_b, nsample_b, xyz, xyz_batch_cnt
                                                 int(nsample_b), ptr(new_xyz), ptr(_i32(new_xyz_batch_cnt)), ptr(xyz),
                                                 ptr(_i32(xyz_batch_cnt)), ptr(ia), ptr(ib), ptr(ea), ptr(eb),
                                                 cur_stream(dev)), 'crb_ball_query2_grouped_stack')
+        return (ia, ea), (ib, eb)
+    N = xyz.shape[0]
+    if BALL_QUERY_GRID and radius_a <= radius_b and N >= B * BALL_QUERY_GRID_MIN_POINTS and max(nsample_a, nsample_b) <= 64:
+        # the call's points counting-sorted into cells of the larger radius, 27 cells per query: the same lists, index for index
+        nbytes = int(lib.crb_ball_query2_grid_workspace_bytes(N))
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+        ws = _BQ_WS.get(key)                      # one per (device, stream): every call on a stream is ordered behind the last
+        if ws is None or ws.numel() * 4 < nbytes:
+            ws = _BQ_WS[key] = torch.empty((nbytes // 4 + 64,), dtype=torch.int32, device=dev)
+        check(lib.crb_ball_query2_grid_stack(B, M, float(radius_a), int(nsample_a), float(radius_b), int(nsample_b), ptr(new_xyz),
+                                             ptr(_i32(new_xyz_batch_cnt)), ptr(xyz), ptr(_i32(xyz_batch_cnt)), N, ptr(ia), ptr(ib),
+                                             ptr(ea), ptr(eb), ptr(ws), ws.numel() * 4, cur_stream(dev)), 'crb_ball_query2_grid_stack')
         return (ia, ea), (ib, eb)
     check(lib.crb_ball_query2_stack(B, M, float(radius_a), int(nsample_a), float(radius_b), int(nsample_b), ptr(new_xyz),
                                     ptr(_i32(new_xyz_batch_cnt)), ptr(xyz), ptr(_i32(xyz_batch_cnt)), ptr(ia), ptr(ib),

@@ -279,6 +279,16 @@ int crb_ball_query2_stack(int B, int64_t M, float radius_a, int nsample_a, float
                           const float* new_xyz, const int32_t* new_xyz_batch_cnt, const float* xyz,
                           const int32_t* xyz_batch_cnt, int32_t* idx_a, int32_t* idx_b, uint8_t* empty_a,
                           uint8_t* empty_b, void* stream);
+/* crb_ball_query2_stack on a per-call cell grid (round 6): the call's source points are counting-sorted into a hashed grid of cells
+ * of edge 1.001 radius_b (histogram, exclusive scan, cursor fill), a query tests the points of the 27 cells around its own and
+ * keeps the nsample smallest indices of each radius in ascending order - the lists of crb_ball_query2_stack, index for index
+ * (replaces the same ball_query_wrapper calls, pointnet2_utils.py:31-38 / ball_query_gpu.cu:47-66: hits in scan order, first
+ * nsample, padded with the first hit). radius_a <= radius_b. n_total = rows of xyz. workspace: crb_ball_query2_grid_workspace_bytes. */
+int64_t crb_ball_query2_grid_workspace_bytes(int64_t n_total);
+int crb_ball_query2_grid_stack(int B, int64_t M, float radius_a, int nsample_a, float radius_b, int nsample_b,
+                               const float* new_xyz, const int32_t* new_xyz_batch_cnt, const float* xyz,
+                               const int32_t* xyz_batch_cnt, int64_t n_total, int32_t* idx_a, int32_t* idx_b, uint8_t* empty_a,
+                               uint8_t* empty_b, void* workspace, int64_t workspace_bytes, void* stream);
 /* crb_ball_query2_stack for queries that come in spatially compact groups of `group` consecutive rows inside one frame
  * (every new_xyz_batch_cnt[b] a multiple of `group` for the fast path; a group that straddles two frames is still answered
  * correctly, by a per-query scan; the 216 grid points of one RoI in PVRCNNHead.roi_grid_pool,

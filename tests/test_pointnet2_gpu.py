@@ -81,6 +81,33 @@ def _check_ball_query_pair(dev, xyz, xc, off, rng, counts):
             np.testing.assert_array_equal(got_e.cpu().numpy().astype(bool), ref_empty)
 
 
+@pytest.mark.parametrize('radii', [(0.4, 16, 0.8, 16), (0.8, 16, 1.2, 32), (1.2, 16, 2.4, 32), (0.05, 4, 0.1, 8), (0.8, 16, 0.8, 16)])
+def test_grid_ball_query_equals_the_scan_at_the_bench_size(dev, monkeypatch, radii):
+    """crb_ball_query2_grid_stack (counting sort of the call's points into cells of the larger radius, 27 cells per query, the
+    nsample smallest indices kept in ascending order) against crb_ball_query2_stack (scan of the whole frame) on 4 frames of
+    20,000 lidar points with 2,048 sampled + 200 far-away queries per frame, duplicated points included: index lists and empty
+    flags equal. Dense balls (near the sensor: hundreds of hits, more than 1,024 candidates at the large radii) take the kernel's
+    scan fallback, sparse ones the selection path; both are compared here, and against the oracle in the test above."""
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as U
+    ra, na, rb, nb = radii
+    B, n = 4, 20000
+    pts, off, _ = kitti_batch(11, B, n_points=n)
+    xyz_np = np.ascontiguousarray(pts[:, :3]).copy()
+    xyz_np[5:4000:7] = xyz_np[4:3999:7]                                   # exact duplicates (equal distances, different indices)
+    xyz = _t(xyz_np, dev)
+    xc = _t(np.diff(off).astype(np.int32), dev)
+    rng = np.random.default_rng(5)
+    new = torch.cat([torch.cat([xyz[off[b]:off[b + 1]][torch.from_numpy(rng.choice(n, 2048, replace=False)).to(dev)],
+                                xyz[off[b]:off[b] + 200] + 300.0]) for b in range(B)]).contiguous()
+    nc = torch.full((B,), 2248, dtype=torch.int32, device=dev)
+    monkeypatch.setattr(U, 'BALL_QUERY_GRID', True)
+    (ia, ea), (ib, eb) = U.ball_query_pair(ra, na, rb, nb, xyz, xc, new, nc)
+    monkeypatch.setattr(U, 'BALL_QUERY_GRID', False)
+    (ja, fa), (jb, fb) = U.ball_query_pair(ra, na, rb, nb, xyz, xc, new, nc)
+    assert torch.equal(ea, fa) and torch.equal(eb, fb) and int(fb.sum()) >= 200 * B
+    assert torch.equal(ia, ja) and torch.equal(ib, jb)
+
+
 @pytest.mark.parametrize('n,m', [(20000, 2048), (4096, 512), (1000, 100), (777, 64), (37, 10), (30000, 300), (50000, 200)])
 def test_fps(dev, n, m):
     from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as U

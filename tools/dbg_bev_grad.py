@@ -36,10 +36,11 @@ if __name__ == '__main__':
     n64 = copy.deepcopy(net).double()
     ref = run(n64, x0.double(), gout.double())
     res = {}
-    for tag, wino, wg in (('MIOpen', False, False), ('Winograd fwd+dgrad, MIOpen wgrad', True, False), ('Winograd fwd+dgrad+wgrad', True, True),
-                          ('MIOpen again', False, False)):
-        bb.WINOGRAD, winograd.WGRAD = wino, wg
+    for tag, wino, wg, kern in (('MIOpen', False, False, 'f32'), ('Winograd f32-MFMA fwd+dgrad, MIOpen wgrad', True, False, 'f32'),
+                                ('Winograd f32-MFMA fwd+dgrad+wgrad', True, True, 'f32'), ('Winograd split-bf16 fwd+dgrad, MIOpen wgrad', True, False, 'x6'),
+                                ('Winograd split-bf16 fwd+dgrad, wgrad f32', True, True, 'x6'), ('MIOpen again', False, False, 'f32')):
+        bb.WINOGRAD, winograd.WGRAD, winograd.KERNEL = wino, wg, kern
         got = run(copy.deepcopy(net), x0, gout)
         res[tag] = got
         errs = [float((a.double() - r).norm() / r.norm()) for a, r in zip(got, ref)]
-        print('%-36s out %.2e  dx %.2e  ' % (tag, errs[0], errs[1]) + '  '.join('%s %.2e' % (n, e) for n, e in zip(names, errs[2:])), flush=True)
+        print('%-46s out %.2e  dx %.2e  ' % (tag, errs[0], errs[1]) + '  '.join('%s %.2e' % (n, e) for n, e in zip(names, errs[2:])), flush=True)
