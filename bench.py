@@ -341,9 +341,10 @@ def cpu_baseline(args):
     dt = time.time() - t0
     crb = cpu_baseline_crb(cores) if args.kind == 'kitti' else None
     return {'value': round(args.cpu_frames / dt, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port', 'crb': crb,
-            'threads_note': 'capped at 32 host threads: the oracle\'s OpenMP loops and torch\'s CPU convolutions of this '
-                            '16-frame problem get slower beyond that (first bench of r01: 152 s for 2 frames on 256 threads, '
-                            '8 s per frame on 8)',
+            'threads_note': 'cores = the threads actually used = min(CPUs this process may use (cgroup quota / affinity: %d here), 32); '
+                            'the cap of 32 exists because the oracle\'s OpenMP loops and torch\'s CPU convolutions of this 16-frame '
+                            'problem get slower beyond that (first bench of r01: 152 s for 2 frames on 256 threads, 8 s per frame '
+                            'on 8)' % effective_cpu_count(),
             'sample': '%d synthetic %s frames x %d pts (BASELINE configs[0]), one SECOND fwd+bwd step (oracle C voxelizer + '
                       'sparse conv fwd/dgrad/wgrad with OpenMP, functional torch CPU for BEV/head/targets/loss), %.1f s' %
                       (args.cpu_frames, args.kind, args.points, dt)}
