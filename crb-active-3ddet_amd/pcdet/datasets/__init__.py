@@ -80,10 +80,51 @@ def _samplers(dist, training, *datasets):
     return [DistributedSampler(d, world_size, rank, shuffle=False) for d in datasets]
 
 
+class LookaheadLoader:
+    """A DataLoader whose batches know their successor. Iterating yields the loader's own batch dicts, one
+    step behind: every batch carries `batch['_crb_next']` = the NEXT batch dict (None for the last), which the loader workers have
+    produced by then anyway. `Detector3DTemplate.forward` takes it as the cue to enqueue the next batch's voxel generator, table
+    marks and keypoint sampling behind this batch's dense half (`prefetch_sparse`): the reference's unmodified `train_one_epoch`
+    (`batch = next(dataloader_iter); model_func(model, batch)`, tools/train_utils/train_utils.py:26-44) then runs without the
+    per-step read-back, like a caller that pipelines by hand. Everything else (len, dataset, batch_size, num_workers, sampler, ...)
+    is the wrapped loader's. CRB_LOADER_LOOKAHEAD=0 hands out plain DataLoaders."""
+
+    def __init__(self, loader):
+        self.__dict__['_loader'] = loader
+
+    def __getattr__(self, name):
+        return getattr(self.__dict__['_loader'], name)
+
+    def __setattr__(self, name, value):
+        setattr(self.__dict__['_loader'], name, value)
+
+    def __len__(self):
+        return len(self.__dict__['_loader'])
+
+    def __iter__(self):
+        it = iter(self.__dict__['_loader'])
+        try:
+            cur = next(it)
+        except StopIteration:
+            return
+        for nxt in it:
+            if isinstance(cur, dict):
+                cur['_crb_next'] = nxt if isinstance(nxt, dict) else None
+            yield cur
+            cur = nxt
+        if isinstance(cur, dict):
+            cur['_crb_next'] = None
+        yield cur
+
+
+LOOKAHEAD = __import__('os').environ.get('CRB_LOADER_LOOKAHEAD', '1') == '1'
+
+
 def _loader(dataset, batch_size, workers, sampler, training):
-    return DataLoader(dataset, batch_size=batch_size, pin_memory=True, num_workers=workers,
-                      shuffle=(sampler is None) and training, collate_fn=dataset.collate_batch, drop_last=False,
-                      sampler=sampler, timeout=0)
+    dl = DataLoader(dataset, batch_size=batch_size, pin_memory=True, num_workers=workers,
+                    shuffle=(sampler is None) and training, collate_fn=dataset.collate_batch, drop_last=False,
+                    sampler=sampler, timeout=0)
+    return LookaheadLoader(dl) if (LOOKAHEAD and training) else dl
 
 
 def build_dataloader(dataset_cfg, class_names, batch_size, dist, root_path=None, workers=4, logger=None, training=True,
