@@ -57,6 +57,7 @@ constexpr int RAW_ROWS = 36, RAW_PX = 10;
 constexpr int RAW_SLOTS = 6 * NT;            // 1536 slots of 16 bytes (1440 used: 36 rows x 10 pixels x 4 channel quads)
 constexpr int RAW_BYTES = RAW_SLOTS * 16;    // 24576
 constexpr int LDS_V = 0, LDS_U = 2 * V_PHASE, LDS_RAW = LDS_U + 3 * U_PHASE, LDS_BYTES = LDS_RAW + RAW_BYTES;   // 150528
+constexpr int LDS_RAW_R = 2 * V_PHASE, LDS_BYTES_R = LDS_RAW_R + RAW_BYTES;                                     // 76800 (U in registers)
 
 __device__ float g_wino4_zero_page[64];      // source of out-of-map pixels (zero-initialised, never written)
 __device__ int g_cu_busy4 = 0;               // see winograd_conv2.hip (crb_cu_reservation sets both)
@@ -166,6 +167,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
 }
 
+// 16 bytes per lane from a uniform base + a lane offset, issued HERE and waited for by hand (s_waitcnt vmcnt(n) before the first use:
+// the compiler does not know this is a memory operation - with LDS-DMA copies in flight beside ordinary loads its own bookkeeping
+// falls back to vmcnt(0), which would wait for the copy that was just requested)
+template <int OFF>
+__device__ __forceinline__ bf16x8 gload16(const unsigned char* sbase, unsigned voff) {
+  bf16x8 r;
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(OFF));
+  return r;
+}
+
 __device__ __forceinline__ f32x4 sload4(const float* p) {
   f32x4 r;
   asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
@@ -218,12 +229,16 @@ __device__ __forceinline__ void acc_settle() { asm volatile("s_nop 15\n\ts_nop 1
 
 // MODE (measurement builds, wrong results): 1 = no MFMAs, 2 = no transform (V never written), 3 = no DMA after the prologue, 4 = no
 // operand reads, 5 = no U copies, 6 = no raw copies, 7 = no V stores (values formed), 8 = no epilogue stores
-template <int MODE>
+// UR = 1: the U fragments go from L2 straight to the registers of the MFMA lanes (global_load_dwordx4, one phase ahead, into the
+// registers the previous phase's MFMAs of the same xi just released) instead of LDS-DMA + ds_read: the copy engine delivers 45-60
+// B/clk per CU (profiles/r06_probe_lds_dma_stream_rate.txt) where a phase wants 24 KB of U in ~800 cycles, and the A operand reads
+// were half of the LDS read traffic. LDS: two V images + the raw block = 76.8 KB.
+template <int MODE, int UR>
 __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const Vb = lds + LDS_V;
   unsigned char* const Ub = lds + LDS_U;
-  unsigned char* const Rb = lds + LDS_RAW;
+  unsigned char* const Rb = lds + (UR ? LDS_RAW_R : LDS_RAW);
   const int T = threadIdx.x, lane = T & 63, wave = __builtin_amdgcn_readfirstlane(T >> 6);
   asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17",
                "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35",
@@ -270,6 +285,12 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
   if (u_first >= u_end) return;
   const int nch = a.cin / CC;
   const int total_chunks = (u_end - u_first) * nch;
+
+  // ---- MFMA role: wave = tile half (wave & 1) x channel half (wave >> 1)
+  const int w_th = wave & 1, w_kh = wave >> 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int a_rd = lhi * (64 * 16) + (w_kh * 32 + l31) * 16;       // U image: A operand, rows = output channels
+  const int b_rd = lhi * V_REGION + (w_th * 32 + l31) * 16;        // V image: B operand, columns = tiles
 
   // ---- transform role: thread = (tile, channel quad)
   const int t_tile = T >> 2, t_q = T & 3, t_tr = t_tile >> 2, t_tc = t_tile & 3;
@@ -332,7 +353,8 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
     }
   };
   int u_cb = u_first % a.ncb, upc = 0;              // channel block / phase of its unit the next U copy fetches
-  const unsigned char* usrc = a.U + (int64_t)u_cb * nch * 4 * U_PHASE + T * 16;
+  const int u_lane = UR ? 0 : T * 16;               // (UR: usrc stays uniform, the lane part is a_rd in the load's offset register)
+  const unsigned char* usrc = a.U + (int64_t)u_cb * nch * 4 * U_PHASE + u_lane;
   auto issue_u = [&](int ub) {                                // one phase image -> U buffer at byte offset ub
 #pragma unroll
     for (int k = 0; k < 6; ++k) glds16(usrc + k * (NT * 16), Ub + ub + (k * NT + wave * 64) * 16);
@@ -341,14 +363,21 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
     if (++upc < nch * 4) { usrc += U_PHASE; return; }
     upc = 0;
     if (++u_cb == a.ncb) u_cb = 0;
-    usrc = a.U + (int64_t)u_cb * nch * 4 * U_PHASE + T * 16;
+    usrc = a.U + (int64_t)u_cb * nch * 4 * U_PHASE + u_lane;
+  };
+  bf16x8 Ar[4][3];                                   // UR: the A fragments of the phase about to run
+  auto a_load = [&](auto jc) __attribute__((always_inline)) {    // fragments of xi jx of the image at usrc
+    constexpr int jx = decltype(jc)::value;
+    if (MODE == 5 || MODE == 3) {
+      asm volatile("" : "=v"(Ar[jx][0]), "=v"(Ar[jx][1]), "=v"(Ar[jx][2]));
+      return;
+    }
+    const unsigned voff = (unsigned)a_rd + (jx * 3 + 1) * U_XP;
+    Ar[jx][0] = gload16<-U_XP>(usrc, voff);
+    Ar[jx][1] = gload16<0>(usrc, voff);
+    Ar[jx][2] = gload16<U_XP>(usrc, voff);
   };
 
-  // ---- MFMA role: wave = tile half (wave & 1) x channel half (wave >> 1)
-  const int w_th = wave & 1, w_kh = wave >> 1;
-  const int l31 = lane & 31, lhi = lane >> 5;
-  const int a_rd = lhi * (64 * 16) + (w_kh * 32 + l31) * 16;       // U image: A operand, rows = output channels
-  const int b_rd = lhi * V_REGION + (w_th * 32 + l31) * 16;        // V image: B operand, columns = tiles
   acc_zero_range<0, 256>();
 
   // ---- output transform of a finished unit: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]. Lane = tile l31 of the wave's half, channels
@@ -519,7 +548,11 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
     constexpr int i = decltype(ic)::value;
     constexpr int rn = (i + 1) & 3;
     // DMA that may stay in flight: what phase f - 1 requested (U(f + 1); in phase 1 also raw(chunk + 1), requested before it)
-    if (i == 1) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    if (UR) {     // (register loads are waited for where they are used; raw(chunk + 1) of phase 0 has to be in LDS for phase 3: only
+                  // what phase 2 requested may be in flight)
+      if (i == 3) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if (i == 1) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     unsigned char* const Vn = Vb + ((i + 1) & 1) * V_PHASE;
@@ -533,7 +566,7 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
           asm volatile("" : "=v"(A[slot][p]), "=v"(B[slot][p]));
           continue;
         }
-        A[slot][p] = *reinterpret_cast<const bf16x8*>(Uc + (jx * 3 + p) * U_XP);
+        if (!UR) A[slot][p] = *reinterpret_cast<const bf16x8*>(Uc + (jx * 3 + p) * U_XP);
         B[slot][p] = *reinterpret_cast<const bf16x8*>(Vc + (jx * 3 + p) * V_XP);
       }
     };
@@ -541,8 +574,8 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
     f32x4 d[4][4];
     if (i == 3) { t_read(d); t_advance(); }
     if (MODE != 3) {
-      if (i == 0 && MODE != 6) { issue_raw(); r_advance(); }
-      if (MODE != 5) { issue_u(ub_nn); u_advance(); }
+      if (i == 0 && MODE != 6) { issue_raw(); if (!UR) r_advance(); }
+      if (MODE != 5 && !UR) { issue_u(ub_nn); u_advance(); }
     }
     __builtin_amdgcn_sched_barrier(0);
     // piece k (behind MFMA k of the phase). Phase 3 starts with the four column passes (columns 0, 2 first: xi 0 needs them)
@@ -559,18 +592,27 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
     auto stage = [&](auto jc) __attribute__((always_inline)) {
       constexpr int jx = decltype(jc)::value;
       constexpr int s = jx & 1;
-      if (MODE != 1) mfma_acc<4 * i + jx>(A[s][0], B[s][2]);
+      const bf16x8 &A0 = UR ? Ar[jx][0] : A[s][0], &A1 = UR ? Ar[jx][1] : A[s][1], &A2 = UR ? Ar[jx][2] : A[s][2];
+      // register loads in flight behind the fragments of (this phase, xi jx): the other xi of the previous phase's requests, this
+      // phase's requests so far, and in phase 0 the six raw copies
+      if (UR) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(i == 0 ? 15 : 9) : "memory");
+      if (MODE != 1) mfma_acc<4 * i + jx>(A0, B[s][2]);
       if (jx < 3) op_read(jx + 1, s ^ 1);
       piece(std::integral_constant<int, 6 * jx + 0>{});
-      if (MODE != 1) mfma_acc<4 * i + jx>(A[s][2], B[s][0]);
+      if (MODE != 1) mfma_acc<4 * i + jx>(A2, B[s][0]);
       piece(std::integral_constant<int, 6 * jx + 1>{});
-      if (MODE != 1) mfma_acc<4 * i + jx>(A[s][1], B[s][1]);
+      if (MODE != 1) mfma_acc<4 * i + jx>(A1, B[s][1]);
       piece(std::integral_constant<int, 6 * jx + 2>{});
-      if (MODE != 1) mfma_acc<4 * i + jx>(A[s][0], B[s][1]);
+      if (MODE != 1) mfma_acc<4 * i + jx>(A0, B[s][1]);
       piece(std::integral_constant<int, 6 * jx + 3>{});
-      if (MODE != 1) mfma_acc<4 * i + jx>(A[s][1], B[s][0]);
+      if (MODE != 1) mfma_acc<4 * i + jx>(A1, B[s][0]);
       piece(std::integral_constant<int, 6 * jx + 4>{});
-      if (MODE != 1) mfma_acc<4 * i + jx>(A[s][0], B[s][0]);
+      if (MODE != 1) mfma_acc<4 * i + jx>(A0, B[s][0]);
+      if (UR) {                                  // the next phase's fragments of this xi, into the registers just released
+        if (MODE == 1) asm volatile("" :: "v"(Ar[jx][0]), "v"(Ar[jx][1]), "v"(Ar[jx][2]));
+        a_load(jc);
+        if (jx == 3) u_advance();
+      }
       piece(std::integral_constant<int, 6 * jx + 5>{});
     };
     stage(std::integral_constant<int, 0>{});
@@ -578,12 +620,20 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
     stage(std::integral_constant<int, 2>{});
     stage(std::integral_constant<int, 3>{});
     const int t = ub_cur; ub_cur = ub_nxt; ub_nxt = ub_nn; ub_nn = t;
+    if (UR && i == 0 && MODE != 3 && MODE != 6) r_advance();      // (its branches behind the MFMAs: the compiler's vmcnt bookkeeping
+                                                                  // of the register loads gives up at control-flow joins)
   };
 
   // ---- prologue: raw(0), U(0), U(1) in one round trip, raw(0) -> tp -> V(0)
   issue_raw(); r_advance();
-  issue_u(0); u_advance();
-  issue_u(U_PHASE); u_advance();
+  if (UR) {
+    a_load(std::integral_constant<int, 0>{}); a_load(std::integral_constant<int, 1>{});
+    a_load(std::integral_constant<int, 2>{}); a_load(std::integral_constant<int, 3>{});
+    u_advance();
+  } else {
+    issue_u(0); u_advance();
+    issue_u(U_PHASE); u_advance();
+  }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   {
@@ -1055,14 +1105,14 @@ __global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(112))) void 
 }  // namespace
 
 CRB_KNOB g_wino4_mode [[maybe_unused]] = 0;      // measurement builds: see MODE
-CRB_KNOB g_wino4_variant [[maybe_unused]] = 1;   // 1 = one 512-register wave per SIMD (the product kernel), 2 = the second form (measurement library)
+CRB_KNOB g_wino4_variant [[maybe_unused]] = 1;   // 1 = one 512-register wave per SIMD, U in registers (the product kernel), 2 = the second form, 3 = the first form with U through LDS-DMA (measurement library)
 #ifdef CRB_MEASURE
 extern "C" int crb_winograd4_set_debug(void* dev_buf) {
   unsigned long long* p = (unsigned long long*)dev_buf;
   CRB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wino4_dbg), &p, sizeof(p)));
   return CRB_OK;
 }
-extern "C" int crb_winograd4_set_variant(int v) { g_wino4_variant = v == 2 ? 2 : 1; return CRB_OK; }
+extern "C" int crb_winograd4_set_variant(int v) { g_wino4_variant = (v == 2 || v == 3) ? v : 1; return CRB_OK; }
 extern "C" int crb_winograd4_set_mode(int mode) { g_wino4_mode = ((mode >= 1 && mode <= 9) || (mode >= 64 && mode < 96)) ? mode : 0; return CRB_OK; }
 #endif
 
@@ -1152,12 +1202,14 @@ static int winograd4_launch(const float* x, const void* U, float* y, int N, int 
   a.nblocks = (int)nb;
   a.ncb = cout / WG_K;
   int mode = 0, nt = NT;
-  auto kern = winograd4_kernel<0>;
+  auto kern = winograd4_kernel<0, 1>;
+  int lds_bytes = LDS_BYTES_R;
 #ifdef CRB_MEASURE
   mode = g_wino4_mode;
   if (g_wino4_variant == 2) {              // second form (two waves per SIMD): A/B only
     nt = NT2;
     kern = winograd4b_kernel<0>;
+    lds_bytes = LDS_BYTES;
     if (mode == 1) kern = winograd4b_kernel<1>;
     if (mode == 2) kern = winograd4b_kernel<2>;
     if (mode == 3) kern = winograd4b_kernel<3>;
@@ -1171,29 +1223,33 @@ static int winograd4_launch(const float* x, const void* U, float* y, int N, int 
     if (mode == 64 + 29) kern = winograd4b_kernel<64 + 29>;       // transform only
     mode = 32;                             // (no attribute bit: set every time)
   } else {
-    if (mode == 1) kern = winograd4_kernel<1>;
-    if (mode == 2) kern = winograd4_kernel<2>;
-    if (mode == 3) kern = winograd4_kernel<3>;
-    if (mode == 4) kern = winograd4_kernel<4>;
-    if (mode == 5) kern = winograd4_kernel<5>;
-    if (mode == 6) kern = winograd4_kernel<6>;
-    if (mode == 7) kern = winograd4_kernel<7>;
-    if (mode == 8) kern = winograd4_kernel<8>;
+    const bool ur = g_wino4_variant != 3;      // variant 3: the first form with U through LDS-DMA (the round's first product kernel)
+    if (!ur) lds_bytes = LDS_BYTES;
+    if (mode == 0 && !ur) kern = winograd4_kernel<0, 0>;
+    if (mode == 1) kern = ur ? winograd4_kernel<1, 1> : winograd4_kernel<1, 0>;
+    if (mode == 2) kern = ur ? winograd4_kernel<2, 1> : winograd4_kernel<2, 0>;
+    if (mode == 3) kern = ur ? winograd4_kernel<3, 1> : winograd4_kernel<3, 0>;
+    if (mode == 4) kern = ur ? winograd4_kernel<4, 1> : winograd4_kernel<4, 0>;
+    if (mode == 5) kern = ur ? winograd4_kernel<5, 1> : winograd4_kernel<5, 0>;
+    if (mode == 6) kern = ur ? winograd4_kernel<6, 1> : winograd4_kernel<6, 0>;
+    if (mode == 7) kern = ur ? winograd4_kernel<7, 1> : winograd4_kernel<7, 0>;
+    if (mode == 8) kern = ur ? winograd4_kernel<8, 1> : winograd4_kernel<8, 0>;
     if (mode > 8) mode = 0;
+    if (!ur || mode) mode = 32;            // (measurement instances: attribute set every time)
   }
 #endif
   int dev = 0;
   const int n_cu = device_cus4(&dev);
   if (n_cu <= 0) return CRB_ERR_LAUNCH;
   if (mode >= 32 || !(g_dev_attr4[dev].load(std::memory_order_acquire) & (1u << mode))) {
-    CRB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    CRB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     if (mode < 32) g_dev_attr4[dev].fetch_or(1u << mode, std::memory_order_release);
   }
   const int64_t units = nb * a.ncb;
   const int64_t grid = units < n_cu ? units : n_cu;
   unsigned seq = (g_dev_seq4[dev].fetch_add(1, std::memory_order_relaxed) + 1) & 0xffffffu;
   a.seq = (grid == n_cu) ? (seq ? seq : 1) : 0;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nt), LDS_BYTES, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nt), lds_bytes, (hipStream_t)stream, a);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
