@@ -58,11 +58,6 @@ constexpr int RAW_SLOTS = 6 * NT;            // 1536 slots of 16 bytes (1440 use
 constexpr int RAW_BYTES = RAW_SLOTS * 16;    // 24576
 constexpr int LDS_V = 0, LDS_U = 2 * V_PHASE, LDS_RAW = LDS_U + 3 * U_PHASE, LDS_BYTES = LDS_RAW + RAW_BYTES;   // 150528
 constexpr int LDS_RAW_R = 2 * V_PHASE, LDS_BYTES_R = LDS_RAW_R + RAW_BYTES;                                     // 76800 (U in registers)
-// UR = 1: a finished unit's 64 tiles x 4 pixels x 64 channels wait in LDS ([pixel of the tile 4][tile 64][64 + 4 floats], + one 16-byte
-// record per tile: address of its first pixel, inside-the-map flags) and leave during the next unit's phases as full 256-byte rows
-constexpr int O_TILE = 272, O_SUB = 64 * O_TILE, O_BYTES = 4 * O_SUB, O_REC = 64 * 16;
-constexpr int LDS_O = LDS_BYTES_R, LDS_BYTES_R1 = LDS_O + O_BYTES + O_REC;                                           // 147456
-constexpr int LDS_RAW_R2 = 3 * V_PHASE, LDS_BYTES_R2 = LDS_RAW_R2 + 2 * RAW_BYTES;                               // 127488 (three V images, two raw blocks)
 
 __device__ float g_wino4_zero_page[64];      // source of out-of-map pixels (zero-initialised, never written)
 __device__ int g_cu_busy4 = 0;               // see winograd_conv2.hip (crb_cu_reservation sets both)
@@ -164,7 +159,6 @@ struct Wino4Args {
   int nblocks;               // spatial blocks = ceil(RT / 16) * tw4
   int ncb;                   // cout / 64
   unsigned seq;              // launch sequence number for the busy-CU latch; 0 = ignore g_cu_busy4
-  int stagger;               // measurement: workgroup b sleeps (b & 7) * stagger * 8128 cycles before its first unit
 };
 
 template <int AUX = 0>
@@ -174,10 +168,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 }
 
 // 16 bytes per lane from a uniform base + a lane offset, issued HERE and waited for by hand (s_waitcnt vmcnt(n) before the first use:
-// the compiler does not know this is a memory operation). Ordinary loads were tried twice: with the LDS-DMA builtin beside them the
-// compiler's vmcnt bookkeeping falls back to vmcnt(0) in front of the first MFMA behind a copy request (it waits for the copy just
-// requested); with the copies hidden in inline asm instead (M0 set by hand) the counts come out right and the LDS waits are counted
-// (lgkmcnt(3..7) instead of 0) - and the kernel is 3 % slower (601 vs 584 us at 128 -> 128, 200 x 176).
+// the compiler does not know this is a memory operation - with LDS-DMA copies in flight beside ordinary loads its own bookkeeping
+// falls back to vmcnt(0), which would wait for the copy that was just requested)
 template <int OFF>
 __device__ __forceinline__ bf16x8 gload16(const unsigned char* sbase, unsigned voff) {
   bf16x8 r;
@@ -187,10 +179,6 @@ __device__ __forceinline__ bf16x8 gload16(const unsigned char* sbase, unsigned v
 
 __device__ __forceinline__ f32x4 sload4(const float* p) {
   f32x4 r;
-  // (a uniform address, but under register pressure the compiler may hold it in VGPRs and print those for the "s" operand)
-  const uint64_t pv = (uint64_t)p;
-  p = (const float*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) |
-                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pv));
   asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
   return r;
 }
@@ -241,19 +229,21 @@ __device__ __forceinline__ void acc_settle() { asm volatile("s_nop 15\n\ts_nop 1
 
 // MODE (measurement builds, wrong results): 1 = no MFMAs, 2 = no transform (V never written), 3 = no DMA after the prologue, 4 = no
 // operand reads, 5 = no U copies, 6 = no raw copies, 7 = no V stores (values formed), 8 = no epilogue stores
-// UR = 1, 2: the U fragments go from L2 straight to the registers of the MFMA lanes (global_load_dwordx4, one phase ahead, into the
+// UR = 1: the U fragments go from L2 straight to the registers of the MFMA lanes (global_load_dwordx4, one phase ahead, into the
 // registers the previous phase's MFMAs of the same xi just released) instead of LDS-DMA + ds_read: the copy engine delivers 45-60
 // B/clk per CU (profiles/r06_probe_lds_dma_stream_rate.txt) where a phase wants 24 KB of U in ~800 cycles, and the A operand reads
 // were half of the LDS read traffic. LDS: two V images + the raw block = 76.8 KB.
+// Tried on top of this form and not faster (all bit-equal; commit 1c6ae13, profiles/r06_time_winograd4_v5_experiments_not_faster.txt):
+// fragments two phases ahead (row pass formed per phase from two raw rows to pay for the registers, two raw blocks); V formed two
+// phases ahead with the next phase's first B fragments read before the barrier; finished units leaving through an LDS staging block
+// as full 256-byte rows during the next unit; workgroups staggered against synchronised store bursts (-5 us for a 27 us delay);
+// ordinary (compiler-tracked) fragment loads with the raw copies hidden in inline asm (counted lgkmcnt waits, 3 % slower).
 template <int MODE, int UR>
 __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const Vb = lds + LDS_V;
   unsigned char* const Ub = lds + LDS_U;
-  unsigned char* const Rb = lds + (UR == 2 ? LDS_RAW_R2 : UR ? LDS_RAW_R : LDS_RAW);         // (UR = 2: two blocks)
-  constexpr bool DS = (UR == 1);                    // outputs leave through LDS (deferred, full rows)
-  unsigned char* const Ob = lds + LDS_O;
-  unsigned char* const Tb = Ob + O_BYTES;
+  unsigned char* const Rb = lds + (UR ? LDS_RAW_R : LDS_RAW);
   const int T = threadIdx.x, lane = T & 63, wave = __builtin_amdgcn_readfirstlane(T >> 6);
   asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17",
                "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35",
@@ -300,7 +290,6 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
   if (u_first >= u_end) return;
   const int nch = a.cin / CC;
   const int total_chunks = (u_end - u_first) * nch;
-  for (int k = (int)(blockIdx.x & 7u) * a.stagger; k > 0; --k) __builtin_amdgcn_s_sleep(127);
 
   // ---- MFMA role: wave = tile half (wave & 1) x channel half (wave >> 1)
   const int w_th = wave & 1, w_kh = wave >> 1;
@@ -350,12 +339,9 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
     }
   };
   raw_sources(r_unit);
-  int r_par = 0, t_par = 0;                         // UR = 2: raw block (of two) the next copy fills / the transform reads
   auto issue_raw = [&]() {
-    unsigned char* const dst = Rb + (UR == 2 ? r_par * RAW_BYTES : 0);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) glds16(rsrc[j], dst + (NT * j + wave * 64) * 16);
-    r_par ^= 1;
+    for (int j = 0; j < 6; ++j) glds16(rsrc[j], Rb + (NT * j + wave * 64) * 16);
   };
   auto r_advance = [&]() {                                    // after issue_raw: move the sources to the next chunk
     if (++rc < nch) {
@@ -384,42 +370,20 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
     if (++u_cb == a.ncb) u_cb = 0;
     usrc = a.U + (int64_t)u_cb * nch * 4 * U_PHASE + u_lane;
   };
-  bf16x8 Ar[2][4][3];                                // UR: the A fragments of the next UR phases (set = phase parity when UR = 2)
-  auto a_load = [&](auto sc, auto jc) __attribute__((always_inline)) {    // fragments of xi jx of the image at usrc -> set st
-    constexpr int st = decltype(sc)::value, jx = decltype(jc)::value;
+  bf16x8 Ar[4][3];                                   // UR: the A fragments of the phase about to run
+  auto a_load = [&](auto jc) __attribute__((always_inline)) {    // fragments of xi jx of the image at usrc
+    constexpr int jx = decltype(jc)::value;
     if (MODE == 5 || MODE == 3) {
-      asm volatile("" : "=v"(Ar[st][jx][0]), "=v"(Ar[st][jx][1]), "=v"(Ar[st][jx][2]));
+      asm volatile("" : "=v"(Ar[jx][0]), "=v"(Ar[jx][1]), "=v"(Ar[jx][2]));
       return;
     }
     const unsigned voff = (unsigned)a_rd + (jx * 3 + 1) * U_XP;
-    Ar[st][jx][0] = gload16<-U_XP>(usrc, voff);
-    Ar[st][jx][1] = gload16<0>(usrc, voff);
-    Ar[st][jx][2] = gload16<U_XP>(usrc, voff);
+    Ar[jx][0] = gload16<-U_XP>(usrc, voff);
+    Ar[jx][1] = gload16<0>(usrc, voff);
+    Ar[jx][2] = gload16<U_XP>(usrc, voff);
   };
 
   acc_zero_range<0, 256>();
-
-  // ---- UR = 1: rows of the finished unit leave LDS during the next unit's phases. Wave w owns tiles 16 w .. 16 w + 15; step k of
-  //      its 16 moves pixel k >> 2 of tiles 16 w + 4 (k & 3) + (lane >> 4): 16 lanes x 16 bytes = the 64 channels of one pixel
-  int drain_left = 0;
-  f32x4 drain_v;
-  u32x4 drain_rec;
-  auto drain_read = [&]() __attribute__((always_inline)) {
-    const int k = 16 - drain_left;
-    const int tile = 16 * wave + 4 * (k & 3) + (lane >> 4);
-    drain_rec = *reinterpret_cast<const u32x4*>(Tb + tile * 16);
-    drain_v = *reinterpret_cast<const f32x4*>(Ob + (k >> 2) * O_SUB + tile * O_TILE + (lane & 15) * 16);
-  };
-  auto drain_store = [&]() __attribute__((always_inline)) {
-    typedef __attribute__((address_space(1))) float gfloat;      // (a global pointer: a generic one would make the store a flat one)
-    typedef __attribute__((address_space(1))) f32x4 gf32x4;
-    const int k = 16 - drain_left;
-    const unsigned sx = (k >> 2) & 1, sy = (k >> 3) & 1;
-    const unsigned need = 1u | (sx << 1) | (sy << 2);
-    gfloat* const row = (gfloat*)(((uint64_t)drain_rec[1] << 32) | drain_rec[0]) + ((int64_t)sy * a.W + sx) * a.cout + (lane & 15) * 4;
-    if ((drain_rec[2] & need) == need && MODE != 8) *(gf32x4*)row = drain_v;
-    --drain_left;
-  };
 
   // ---- output transform of a finished unit: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]. Lane = tile l31 of the wave's half, channels
   //      cb * 64 + 32 kh + 8 j + 4 lhi + (0..3) for register group j (accumulator register 4 j + e of every xi)
@@ -455,21 +419,12 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
       }
     }
     f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (DS) {
-      unsigned char* o = Ob + (w_th * 32 + l31) * O_TILE + (w_kh * 32 + 8 * j + 4 * lhi) * 4;
-      *reinterpret_cast<f32x4*>(o) = y00;
-      *reinterpret_cast<f32x4*>(o + O_SUB) = y01;
-      *reinterpret_cast<f32x4*>(o + 2 * O_SUB) = y10;
-      *reinterpret_cast<f32x4*>(o + 3 * O_SUB) = y11;
-    }
     if (in && MODE != 8) {
-      if (!DS) {
-        float* o = yo + 8 * j;
-        *reinterpret_cast<f32x4*>(o) = y00;
-        if (x1) *reinterpret_cast<f32x4*>(o + a.cout) = y01;
-        if (y1) *reinterpret_cast<f32x4*>(o + (int64_t)a.W * a.cout) = y10;
-        if (x1 && y1) *reinterpret_cast<f32x4*>(o + (int64_t)a.W * a.cout + a.cout) = y11;
-      }
+      float* o = yo + 8 * j;
+      *reinterpret_cast<f32x4*>(o) = y00;
+      if (x1) *reinterpret_cast<f32x4*>(o + a.cout) = y01;
+      if (y1) *reinterpret_cast<f32x4*>(o + (int64_t)a.W * a.cout) = y10;
+      if (x1 && y1) *reinterpret_cast<f32x4*>(o + (int64_t)a.W * a.cout + a.cout) = y11;
       if (a.stats) {                                          // fixed order: (0,0), (0,1), (1,0), (1,1)
         const float m01 = x1 ? 1.f : 0.f, m10 = y1 ? 1.f : 0.f, m11 = (x1 && y1) ? 1.f : 0.f;
         s1 = y00; s2 = y00 * y00;
@@ -515,20 +470,6 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
     const bool in = Rg < a.RT && tx < a.tw;
     const bool x1 = ox + 1 < a.W, y1 = oy + 1 < a.H;
     float* const yo = a.y + (((int64_t)n2 * a.H + oy) * a.W + ox) * a.cout + eu.cb * WG_K + w_kh * 32 + 4 * lhi;
-    if (DS) {
-      // (the previous unit's rows have left: the last of them were read at the start of a phase every wave has since finished
-      // issuing - wait for this wave's reads and meet the others before the block is overwritten)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (w_kh == 0 && lhi == 0) {
-        const uint64_t base = (uint64_t)(a.y + (((int64_t)n2 * a.H + oy) * a.W + ox) * a.cout + eu.cb * WG_K);
-        u32x4 rec;
-        rec[0] = (unsigned)base; rec[1] = (unsigned)(base >> 32);
-        rec[2] = (in ? 1u : 0u) | (x1 ? 2u : 0u) | (y1 ? 4u : 0u); rec[3] = 0u;
-        *reinterpret_cast<u32x4*>(Tb + tile * 16) = rec;
-      }
-      drain_left = 16;
-    }
     acc_settle();
     epilogue_group(std::integral_constant<int, 0>{}, eu, yo, in, x1, y1);
     epilogue_group(std::integral_constant<int, 1>{}, eu, yo, in, x1, y1);
@@ -536,11 +477,6 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
     epilogue_group(std::integral_constant<int, 3>{}, eu, yo, in, x1, y1);
     acc_zero_range<0, 256>();
     ++e_unit;
-    if (DS && nch < 4) {                   // a unit shorter than 16 phases: its rows leave at once
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      while (drain_left > 0) { drain_read(); drain_store(); }
-    }
   };
 
   // ---- input transform, cut into pieces that the phase places one behind each MFMA (one wave per SIMD: what is issued between
@@ -558,24 +494,6 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
 #pragma unroll
       for (int b = 0; b < 4; ++b)          // pixel column b of the patch: position t_tc + (b >> 1) + 5 (b & 1) of the row
         d[i][b] = *reinterpret_cast<const f32x4*>(p + (i * RAW_PX + (b >> 1) + 5 * (b & 1)) * 64);
-  };
-  // UR = 2: no tp. Row r of B^T d is formed from the two raw rows it needs in the phase that splits it (8 ds_read_b128 per phase
-  // instead of 16 per chunk, 48 registers less): r -> rows (ra, rb) = (0,2) (1,2) (1,2) (1,3), value da - db, da + db, db - da, da - db
-  f32x4 tr[4], dd[2][4];
-  auto t_rows_read = [&](const unsigned char* p, auto rcst, int bA, int bB) __attribute__((always_inline)) {
-    constexpr int r = decltype(rcst)::value;
-    constexpr int ra = r == 0 ? 0 : 1, rb = r == 3 ? 3 : 2;
-    dd[0][bA] = *reinterpret_cast<const f32x4*>(p + (ra * RAW_PX + (bA >> 1) + 5 * (bA & 1)) * 64);
-    dd[1][bA] = *reinterpret_cast<const f32x4*>(p + (rb * RAW_PX + (bA >> 1) + 5 * (bA & 1)) * 64);
-    dd[0][bB] = *reinterpret_cast<const f32x4*>(p + (ra * RAW_PX + (bB >> 1) + 5 * (bB & 1)) * 64);
-    dd[1][bB] = *reinterpret_cast<const f32x4*>(p + (rb * RAW_PX + (bB >> 1) + 5 * (bB & 1)) * 64);
-  };
-  auto t_row_form = [&](auto rcst, int b) __attribute__((always_inline)) {
-    constexpr int r = decltype(rcst)::value;
-    if constexpr (r == 1) tr[b] = dd[0][b] + dd[1][b];
-    else if constexpr (r == 2) tr[b] = dd[1][b] - dd[0][b];
-    else tr[b] = dd[0][b] - dd[1][b];
-    asm volatile("" : "+v"(tr[b]));
   };
   auto t_col = [&](const f32x4 (&d)[4][4], int b) __attribute__((always_inline)) {
     tp[0][b] = d[0][b] - d[2][b];
@@ -597,17 +515,10 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
     constexpr int r = decltype(rcst)::value, jx = decltype(jcst)::value, s = decltype(scst)::value;
     if (MODE == 2) return;
     if constexpr (s == 0) {
-      if (UR == 2) {
-        if constexpr (jx == 0) { t_row_form(rcst, 0); t_row_form(rcst, 2); }
-        else if constexpr (jx == 1) t_row_form(rcst, 1);
-        else if constexpr (jx == 3) t_row_form(rcst, 3);
-      }
-      const f32x4 &p0 = UR == 2 ? tr[0] : tp[r][0], &p1 = UR == 2 ? tr[1] : tp[r][1], &p2 = UR == 2 ? tr[2] : tp[r][2],
-                  &p3 = UR == 2 ? tr[3] : tp[r][3];
-      if constexpr (jx == 0) sv = p0 - p2;
-      else if constexpr (jx == 1) sv = p1 + p2;
-      else if constexpr (jx == 2) sv = p2 - p1;
-      else sv = p1 - p3;
+      if constexpr (jx == 0) sv = tp[r][0] - tp[r][2];
+      else if constexpr (jx == 1) sv = tp[r][1] + tp[r][2];
+      else if constexpr (jx == 2) sv = tp[r][2] - tp[r][1];
+      else sv = tp[r][1] - tp[r][3];
       asm volatile("" : "+v"(sv));
     } else if constexpr (s == 1) {
 #pragma unroll
@@ -638,23 +549,19 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
   //      workgroup's range they fetch a valid U image and zero-page / in-map pixels that nobody reads): the counts below hold in
   //      every phase.
   int ub_cur = 0, ub_nxt = U_PHASE, ub_nn = 2 * U_PHASE;
-  int vb_cur = 0, vb_nxt = V_PHASE, vb_nn = 2 * V_PHASE;        // UR = 2: V images of this phase, the next, the one being formed
-  bf16x8 Bpre[3];                                                // UR = 2: B fragments of xi 0 of the next phase
   auto phase = [&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
-    constexpr int rn = (i + (UR == 2 ? 2 : 1)) & 3;       // row of V formed in this phase (UR = 2: for the phase after the next)
+    constexpr int rn = (i + 1) & 3;
     // DMA that may stay in flight: what phase f - 1 requested (U(f + 1); in phase 1 also raw(chunk + 1), requested before it)
     if (UR) {     // (register loads are waited for where they are used; raw(chunk + 1) of phase 0 has to be in LDS for phase 3: only
-                  // what phase 2 (UR = 2: phases 1 and 2) requested may be in flight)
-      // UR = 2: phase 2 starts to read raw(chunk + 1), requested four phases ago, and requests raw(chunk + 2)
-      if (i == (UR == 2 ? 2 : 3)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(12 * UR) : "memory");
+                  // what phase 2 requested may be in flight)
+      if (i == 3) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     } else if (i == 1) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    unsigned char* const Vn = Vb + (UR == 2 ? vb_nn : ((i + 1) & 1) * V_PHASE);
-    const unsigned char* const Vc = Vb + (UR == 2 ? vb_cur : (i & 1) * V_PHASE) + b_rd;
-    const unsigned char* const Vx = Vb + vb_nxt + b_rd;                 // (UR = 2: the next phase's image, complete since this barrier)
+    unsigned char* const Vn = Vb + ((i + 1) & 1) * V_PHASE;
+    const unsigned char* const Vc = Vb + (i & 1) * V_PHASE + b_rd;
     const unsigned char* const Uc = Ub + ub_cur + a_rd;
     bf16x8 A[2][3], B[2][3];
     auto op_read = [&](int jx, int slot) __attribute__((always_inline)) {
@@ -668,32 +575,21 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
         B[slot][p] = *reinterpret_cast<const bf16x8*>(Vc + (jx * 3 + p) * V_XP);
       }
     };
-    if (UR == 2) {      // xi 0's fragments were read at the end of the previous phase: no LDS round trip between the barrier and MFMA 0
-#pragma unroll
-      for (int p = 0; p < 3; ++p) B[0][p] = Bpre[p];
-    } else op_read(0, 0);
+    op_read(0, 0);
     f32x4 d[4][4];
-    if (UR == 2 && i == 2) { t_advance(); t_par ^= 1; }
-    const unsigned char* const rawp = Rb + raw_rd + (UR == 2 ? t_par * RAW_BYTES : 0);
-    if (UR == 2) {
-      if (MODE != 2) t_rows_read(rawp, std::integral_constant<int, rn>{}, 0, 2);
-    } else if (i == 3) {
-      t_read(d);
-      t_advance();
-    }
+    if (i == 3) { t_read(d); t_advance(); }
     if (MODE != 3) {
-      if (i == (UR == 2 ? 2 : 0) && MODE != 6) { issue_raw(); if (!UR) r_advance(); }
+      if (i == 0 && MODE != 6) { issue_raw(); if (!UR) r_advance(); }
       if (MODE != 5 && !UR) { issue_u(ub_nn); u_advance(); }
     }
     __builtin_amdgcn_sched_barrier(0);
     // piece k (behind MFMA k of the phase). Phase 3 starts with the four column passes (columns 0, 2 first: xi 0 needs them)
     auto piece = [&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value;
-      constexpr int k0 = (i == 3 && UR != 2) ? k - 4 : k;
-      if constexpr (i == 3 && k < 4 && UR != 2) {
+      constexpr int k0 = (i == 3) ? k - 4 : k;
+      if constexpr (i == 3 && k < 4) {
         t_col(d, k == 0 ? 0 : k == 1 ? 2 : k == 2 ? 1 : 3);
       } else if constexpr (k0 >= 0 && k0 < 20) {
-        if (UR == 2 && k0 == 1 && MODE != 2) t_rows_read(rawp, std::integral_constant<int, rn>{}, 1, 3);
         t_xi(Vn, std::integral_constant<int, rn>{}, std::integral_constant<int, k0 / 5>{}, std::integral_constant<int, k0 % 5>{});
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -701,20 +597,12 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
     auto stage = [&](auto jc) __attribute__((always_inline)) {
       constexpr int jx = decltype(jc)::value;
       constexpr int s = jx & 1;
-      constexpr int cs = (UR == 2) ? (i & 1) : 0;
-      const bf16x8 &A0 = UR ? Ar[cs][jx][0] : A[s][0], &A1 = UR ? Ar[cs][jx][1] : A[s][1], &A2 = UR ? Ar[cs][jx][2] : A[s][2];
-      // register loads in flight behind the fragments of (this phase, xi jx): the other xi of the requests UR phases ago, everything
-      // requested since, and the six raw copies of phase 0 while they are younger than the fragments
-      if (UR) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(UR == 1 ? (i == 0 ? 15 : 9) : ((i == 2 || i == 3) ? 27 : 21)) : "memory");
+      const bf16x8 &A0 = UR ? Ar[jx][0] : A[s][0], &A1 = UR ? Ar[jx][1] : A[s][1], &A2 = UR ? Ar[jx][2] : A[s][2];
+      // register loads in flight behind the fragments of (this phase, xi jx): the other xi of the previous phase's requests, this
+      // phase's requests so far, and in phase 0 the six raw copies
+      if (UR) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(i == 0 ? 15 : 9) : "memory");
       if (MODE != 1) mfma_acc<4 * i + jx>(A0, B[s][2]);
       if (jx < 3) op_read(jx + 1, s ^ 1);
-      else if (UR == 2) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          if (MODE == 4) asm volatile("" : "=v"(Bpre[p]));
-          else Bpre[p] = *reinterpret_cast<const bf16x8*>(Vx + p * V_XP);
-        }
-      }
       piece(std::integral_constant<int, 6 * jx + 0>{});
       if (MODE != 1) mfma_acc<4 * i + jx>(A2, B[s][0]);
       piece(std::integral_constant<int, 6 * jx + 1>{});
@@ -726,8 +614,8 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
       piece(std::integral_constant<int, 6 * jx + 4>{});
       if (MODE != 1) mfma_acc<4 * i + jx>(A0, B[s][0]);
       if (UR) {                                  // the next phase's fragments of this xi, into the registers just released
-        if (MODE == 1) asm volatile("" :: "v"(Ar[cs][jx][0]), "v"(Ar[cs][jx][1]), "v"(Ar[cs][jx][2]));
-        a_load(std::integral_constant<int, cs>{}, jc);
+        if (MODE == 1) asm volatile("" :: "v"(Ar[jx][0]), "v"(Ar[jx][1]), "v"(Ar[jx][2]));
+        a_load(jc);
         if (jx == 3) u_advance();
       }
       piece(std::integral_constant<int, 6 * jx + 5>{});
@@ -736,38 +624,24 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
     stage(std::integral_constant<int, 1>{});
     stage(std::integral_constant<int, 2>{});
     stage(std::integral_constant<int, 3>{});
-    if (DS && drain_left > 0) {            // one step per phase, behind the last MFMAs (the operand registers are free here)
-      drain_read();
-      drain_store();
-    }
     const int t = ub_cur; ub_cur = ub_nxt; ub_nxt = ub_nn; ub_nn = t;
-    if (UR == 2) { const int t2 = vb_cur; vb_cur = vb_nxt; vb_nxt = vb_nn; vb_nn = t2; }
-    if (UR && i == (UR == 2 ? 2 : 0) && MODE != 3 && MODE != 6) r_advance();      // (its branches behind the MFMAs: the compiler's vmcnt bookkeeping
+    if (UR && i == 0 && MODE != 3 && MODE != 6) r_advance();      // (its branches behind the MFMAs: the compiler's vmcnt bookkeeping
                                                                   // of the register loads gives up at control-flow joins)
   };
 
   // ---- prologue: raw(0), U(0), U(1) in one round trip, raw(0) -> tp -> V(0)
   issue_raw(); r_advance();
-  if (UR == 2) { issue_raw(); r_advance(); }
   if (UR) {
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-    a_load(I0{}, I0{}); a_load(I0{}, I1{}); a_load(I0{}, I2{}); a_load(I0{}, I3{});
+    a_load(std::integral_constant<int, 0>{}); a_load(std::integral_constant<int, 1>{});
+    a_load(std::integral_constant<int, 2>{}); a_load(std::integral_constant<int, 3>{});
     u_advance();
-    if (UR == 2) {
-      a_load(I1{}, I0{}); a_load(I1{}, I1{}); a_load(I1{}, I2{}); a_load(I1{}, I3{});
-      u_advance();
-    }
   } else {
     issue_u(0); u_advance();
     issue_u(U_PHASE); u_advance();
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  if (UR == 2) {
-    t_rows_read(Rb + raw_rd, std::integral_constant<int, 0>{}, 0, 2);
-    t_rows_read(Rb + raw_rd, std::integral_constant<int, 0>{}, 1, 3);
-  } else {
+  {
     f32x4 d[4][4];
     t_read(d); t_advance();
 #pragma unroll
@@ -781,22 +655,6 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
   t_xi(Vb, std::integral_constant<int, 0>{}, std::integral_constant<int, JX>{}, std::integral_constant<int, 4>{})
   CRB_T_XI_ALL(0); CRB_T_XI_ALL(1); CRB_T_XI_ALL(2); CRB_T_XI_ALL(3);
 #undef CRB_T_XI_ALL
-  if (UR == 2) {          // V(1) as well, then the first phase's xi 0 fragments
-    t_rows_read(Rb + raw_rd, std::integral_constant<int, 1>{}, 0, 2);
-    t_rows_read(Rb + raw_rd, std::integral_constant<int, 1>{}, 1, 3);
-#define CRB_T_XI_ALL1(JX)                                                                                                              \
-  t_xi(Vb + V_PHASE, std::integral_constant<int, 1>{}, std::integral_constant<int, JX>{}, std::integral_constant<int, 0>{});            \
-  t_xi(Vb + V_PHASE, std::integral_constant<int, 1>{}, std::integral_constant<int, JX>{}, std::integral_constant<int, 1>{});            \
-  t_xi(Vb + V_PHASE, std::integral_constant<int, 1>{}, std::integral_constant<int, JX>{}, std::integral_constant<int, 2>{});            \
-  t_xi(Vb + V_PHASE, std::integral_constant<int, 1>{}, std::integral_constant<int, JX>{}, std::integral_constant<int, 3>{});            \
-  t_xi(Vb + V_PHASE, std::integral_constant<int, 1>{}, std::integral_constant<int, JX>{}, std::integral_constant<int, 4>{})
-    CRB_T_XI_ALL1(0); CRB_T_XI_ALL1(1); CRB_T_XI_ALL1(2); CRB_T_XI_ALL1(3);
-#undef CRB_T_XI_ALL1
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int p = 0; p < 3; ++p) Bpre[p] = *reinterpret_cast<const bf16x8*>(Vb + b_rd + p * V_XP);
-  }
 
   for (int cg = 0; cg < total_chunks; ++cg) {
     phase(std::integral_constant<int, 0>{});
@@ -804,11 +662,6 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
     phase(std::integral_constant<int, 2>{});
     phase(std::integral_constant<int, 3>{});
     if (++ec == nch) { ec = 0; unit_epilogue(); }
-  }
-  if (DS) {                                                         // the last unit's rows
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    while (drain_left > 0) { drain_read(); drain_store(); }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (copies requested past the end of the range)
 }
@@ -1264,7 +1117,7 @@ extern "C" int crb_winograd4_set_debug(void* dev_buf) {
   CRB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wino4_dbg), &p, sizeof(p)));
   return CRB_OK;
 }
-extern "C" int crb_winograd4_set_variant(int v) { g_wino4_variant = (v >= 2 && v <= 12) ? v : 1; return CRB_OK; }
+extern "C" int crb_winograd4_set_variant(int v) { g_wino4_variant = (v == 2 || v == 3) ? v : 1; return CRB_OK; }
 extern "C" int crb_winograd4_set_mode(int mode) { g_wino4_mode = ((mode >= 1 && mode <= 9) || (mode >= 64 && mode < 96)) ? mode : 0; return CRB_OK; }
 #endif
 
@@ -1353,10 +1206,9 @@ static int winograd4_launch(const float* x, const void* U, float* y, int N, int 
   if (nb >= (1LL << 26)) return CRB_ERR_ARG;
   a.nblocks = (int)nb;
   a.ncb = cout / WG_K;
-  a.stagger = 0;
   int mode = 0, nt = NT;
   auto kern = winograd4_kernel<0, 1>;
-  int lds_bytes = LDS_BYTES_R1;
+  int lds_bytes = LDS_BYTES_R;
 #ifdef CRB_MEASURE
   mode = g_wino4_mode;
   if (g_wino4_variant == 2) {              // second form (two waves per SIMD): A/B only
@@ -1376,11 +1228,9 @@ static int winograd4_launch(const float* x, const void* U, float* y, int N, int 
     if (mode == 64 + 29) kern = winograd4b_kernel<64 + 29>;       // transform only
     mode = 32;                             // (no attribute bit: set every time)
   } else {
-    if (g_wino4_variant >= 5) a.stagger = g_wino4_variant - 4;       // variants 5..: the product kernel with staggered workgroups
     const bool ur = g_wino4_variant != 3;      // variant 3: the first form with U through LDS-DMA (the round's first product kernel)
     if (!ur) lds_bytes = LDS_BYTES;
     if (mode == 0 && !ur) kern = winograd4_kernel<0, 0>;
-    const bool ur2 = g_wino4_variant == 4;     // variant 4: U fragments requested two phases ahead
     if (mode == 1) kern = ur ? winograd4_kernel<1, 1> : winograd4_kernel<1, 0>;
     if (mode == 2) kern = ur ? winograd4_kernel<2, 1> : winograd4_kernel<2, 0>;
     if (mode == 3) kern = ur ? winograd4_kernel<3, 1> : winograd4_kernel<3, 0>;
@@ -1390,14 +1240,7 @@ static int winograd4_launch(const float* x, const void* U, float* y, int N, int 
     if (mode == 7) kern = ur ? winograd4_kernel<7, 1> : winograd4_kernel<7, 0>;
     if (mode == 8) kern = ur ? winograd4_kernel<8, 1> : winograd4_kernel<8, 0>;
     if (mode > 8) mode = 0;
-    if (ur2) {
-      lds_bytes = LDS_BYTES_R2;
-      kern = winograd4_kernel<0, 2>;
-      if (mode == 1) kern = winograd4_kernel<1, 2>;
-      if (mode == 6) kern = winograd4_kernel<6, 2>;
-      if (mode == 8) kern = winograd4_kernel<8, 2>;
-    }
-    if (!ur || ur2 || mode) mode = 32;     // (measurement instances: attribute set every time)
+    if (!ur || mode) mode = 32;            // (measurement instances: attribute set every time)
   }
 #endif
   int dev = 0;
