@@ -230,9 +230,9 @@ __device__ __forceinline__ void acc_settle() { asm volatile("s_nop 15\n\ts_nop 1
 // MODE (measurement builds, wrong results): 1 = no MFMAs, 2 = no transform (V never written), 3 = no DMA after the prologue, 4 = no
 // operand reads, 5 = no U copies, 6 = no raw copies, 7 = no V stores (values formed), 8 = no epilogue stores
 // UR = 1: the U fragments go from L2 straight to the registers of the MFMA lanes (global_load_dwordx4, one phase ahead, into the
-// registers the previous phase's MFMAs of the same xi just released) instead of LDS-DMA + ds_read: the copy engine delivers 45-60
-// B/clk per CU (profiles/r06_probe_lds_dma_stream_rate.txt) where a phase wants 24 KB of U in ~800 cycles, and the A operand reads
-// were half of the LDS read traffic. LDS: two V images + the raw block = 76.8 KB.
+// registers the previous phase's MFMAs of the same xi just released) instead of LDS-DMA + ds_read: through LDS the A fragments
+// cost 24 KB of copies landing + 48 KB read back per phase (half of the operand reads) on a copy engine that tops out at 45-60
+// B/clk per CU (profiles/r06_probe_lds_dma_stream_rate.txt). LDS: two V images + the raw block = 76.8 KB.
 // Tried on top of this form and not faster (all bit-equal; commit 1c6ae13, profiles/r06_time_winograd4_v5_experiments_not_faster.txt):
 // fragments two phases ahead (row pass formed per phase from two raw rows to pay for the registers, two raw blocks); V formed two
 // phases ahead with the next phase's first B fragments read before the barrier; finished units leaving through an LDS staging block
