@@ -141,6 +141,10 @@ class BaseBEVBackbone(nn.Module):
                 if _wino_ok(c, x, (pd[2], pd[0])):
                     from crbhip import winograd
                     return BaseBEVBackbone._wino_conv(c, x, mods[i + 2] if i + 2 < len(mods) else None), 2
+                if torch.are_deterministic_algorithms_enabled() and torch.is_grad_enabled() and pd[0] == pd[2] and x.is_cuda:
+                    from crbhip import dense_strided       # (MIOpen's weight gradient of this layer adds split-K partials with atomics)
+                    if dense_strided.supported(c, x):
+                        return dense_strided.conv_det(c, x, (pd[2], pd[0])), 2
                 return torch.nn.functional.conv2d(x, c.weight, c.bias, c.stride, (pd[2], pd[0]), c.dilation, c.groups), 2
         return None, 0
 
@@ -201,6 +205,10 @@ class BaseBEVBackbone(nn.Module):
                 w2d = w2d.t() if isinstance(conv, nn.ConvTranspose2d) else w2d            # (Cout, Cin)
                 n, _, h, w_ = x.shape
                 return rows_to_nchw(LinearRows.apply(rows, w2d), n, h, w_)
+        if torch.are_deterministic_algorithms_enabled() and torch.is_grad_enabled() and x.is_cuda and isinstance(conv, nn.ConvTranspose2d):
+            from crbhip import dense_strided
+            if dense_strided.supported(conv, x):
+                return dense_strided.conv_det(conv, x)
         return conv(x)
 
     def _can_fuse_concat_eval(self, x):
