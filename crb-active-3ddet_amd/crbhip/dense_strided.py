@@ -90,14 +90,33 @@ def supported(conv, x):
     return ok(cin) and ok(cout) and bool(sparse.lib.crb_sparse_conv_supported(blk(cin), blk(cout)))
 
 
+class _vendor_default_solvers(object):
+    """the vendor forward / data-gradient kernels of these two layers give the same bits run to run in the default mode (only the weight
+    gradient did not: tools/dbg_determinism.py). Under the deterministic flag MIOpen falls back to its naive reference solver for them:
+    157 ms per call at 16 x 200 x 176 instead of 0.6 - so the flag is lowered around exactly these calls."""
+
+    def __enter__(self):
+        self.was = torch.are_deterministic_algorithms_enabled()
+        self.warn = torch.is_deterministic_algorithms_warn_only_enabled()
+        self.cudnn = torch.backends.cudnn.deterministic
+        torch.use_deterministic_algorithms(False)
+        torch.backends.cudnn.deterministic = False
+
+    def __exit__(self, *exc):
+        torch.backends.cudnn.deterministic = self.cudnn
+        torch.use_deterministic_algorithms(self.was, warn_only=self.warn)
+        return False
+
+
 class _StridedConvDet(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, kind, s, p):
         ctx.save_for_backward(x, w)
         ctx.kind, ctx.s, ctx.p = kind, s, p
-        if kind == 'conv':
-            return torch.nn.functional.conv2d(x, w, None, s, p)
-        return torch.nn.functional.conv_transpose2d(x, w, None, s, 0)
+        with _vendor_default_solvers():
+            if kind == 'conv':
+                return torch.nn.functional.conv2d(x, w, None, s, p)
+            return torch.nn.functional.conv_transpose2d(x, w, None, s, 0)
 
     @staticmethod
     def backward(ctx, dy):
@@ -106,8 +125,9 @@ class _StridedConvDet(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [p, p] if kind == 'conv' else [0, 0], [1, 1], kind == 'deconv',
-                                                     [0, 0], 1, [True, False, False])[0]
+            with _vendor_default_solvers():
+                dx = torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [p, p] if kind == 'conv' else [0, 0], [1, 1],
+                                                         kind == 'deconv', [0, 0], 1, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
             dw = weight_grad(kind, x, dy, w.shape[2], w.shape[3], s, p)
         return dx, dw, None, None, None

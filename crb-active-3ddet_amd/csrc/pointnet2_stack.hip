@@ -762,6 +762,10 @@ struct GroupBn {
   const float* dbeta;
   const float* dgamma;
   float inv_n;
+  // deterministic mode (crb_group_affine_rows_grad_bn_recompute_stack_fixed): the rows that leave a slab are added as 64-bit
+  // fixed-point numbers (value * fixed_scale, rounded to nearest) - integer addition does not depend on the order of arrival
+  unsigned long long* fixed;
+  float fixed_scale;
 };
 
 template <int H, bool BN = false, bool RECOMP = false>
@@ -983,7 +987,11 @@ __global__ __launch_bounds__(256) void group_affine_rows_grad_kernel(int B, int6
     const int row = srow[pl];
     bool head = row >= 0 && first[pl] == pl;
     if (sorted && pl > 0 && (pl & 15) == 0 && srow[pl - 1] == row) head = false;
-    if (head) atomicAdd(&grad_P[(int64_t)row * H + c], slab[pl * H + c]);
+    if (head) {
+      const float val = slab[pl * H + c];
+      if (bn.fixed) atomicAdd(&bn.fixed[(int64_t)row * H + c], (unsigned long long)__float2ll_rn(val * bn.fixed_scale));
+      else atomicAdd(&grad_P[(int64_t)row * H + c], val);
+    }
   }
 }
 
@@ -1786,14 +1794,15 @@ extern "C" int crb_group_affine_rows_grad_bn_stack(int B, int64_t M, int H, int 
 }
 
 // the same without the forward's saved tensors (sa_mlp_train.hip pass D): y and rel are formed again from xyz / new_xyz / P / W1x
-extern "C" int crb_group_affine_rows_grad_bn_recompute_stack(int B, int64_t M, int H, int nsample, const float* xyz,
+static int group_affine_rows_grad_bn_recompute(int B, int64_t M, int H, int nsample, const float* xyz,
                                                              const int32_t* xyz_batch_cnt, const float* P, const float* new_xyz,
                                                              const int32_t* new_xyz_batch_cnt, const int32_t* idx,
                                                              const uint8_t* empty_mask, const float* W1x, const float* grad_z,
                                                              const float* mean, const float* invstd, const float* gamma,
                                                              const float* beta, const float* dbeta, const float* dgamma,
                                                              const int32_t* sorted_pair, const int32_t* sorted_row, int64_t n_src,
-                                                             float* grad_P /* pre-zeroed */, float* part, void* stream) {
+                                                             float* grad_P /* pre-zeroed */, float* part, void* stream,
+                                                             int64_t* grad_P_fixed, float fixed_scale) {
   if (B <= 0 || M < 0 || H <= 0 || nsample <= 0 || !xyz || !P || !new_xyz || !W1x || !mean || !invstd || !gamma || !beta ||
       !dbeta || !dgamma)
     return CRB_ERR_ARG;
@@ -1804,7 +1813,7 @@ extern "C" int crb_group_affine_rows_grad_bn_recompute_stack(int B, int64_t M, i
   const dim3 grid(crb_cdiv(MP, 64));
   hipStream_t st = (hipStream_t)stream;
   const GroupBn bn{xyz, new_xyz, P, W1x, sorted_pair, sorted_row, (int)n_src, nullptr, mean, invstd, gamma, beta, dbeta, dgamma,
-                   1.0f / (float)MP};
+                   1.0f / (float)MP, (unsigned long long*)grad_P_fixed, fixed_scale};
 #define CRB_GA_CASE(HH)                                                                                                    \
   if (H == HH)                                                                                                             \
     hipLaunchKernelGGL((group_affine_rows_grad_kernel<HH, true, true>), grid, dim3(256), 0, st, B, MP, nsample, xyz_batch_cnt, \
@@ -1813,6 +1822,39 @@ extern "C" int crb_group_affine_rows_grad_bn_recompute_stack(int B, int64_t M, i
 #undef CRB_GA_CASE
   CRB_CHECK_LAUNCH();
   return CRB_OK;
+}
+
+extern "C" int crb_group_affine_rows_grad_bn_recompute_stack(int B, int64_t M, int H, int nsample, const float* xyz,
+                                                             const int32_t* xyz_batch_cnt, const float* P, const float* new_xyz,
+                                                             const int32_t* new_xyz_batch_cnt, const int32_t* idx,
+                                                             const uint8_t* empty_mask, const float* W1x, const float* grad_z,
+                                                             const float* mean, const float* invstd, const float* gamma,
+                                                             const float* beta, const float* dbeta, const float* dgamma,
+                                                             const int32_t* sorted_pair, const int32_t* sorted_row, int64_t n_src,
+                                                             float* grad_P /* pre-zeroed */, float* part, void* stream) {
+  if (!grad_P) return CRB_ERR_ARG;
+  return group_affine_rows_grad_bn_recompute(B, M, H, nsample, xyz, xyz_batch_cnt, P, new_xyz, new_xyz_batch_cnt, idx, empty_mask, W1x,
+                                             grad_z, mean, invstd, gamma, beta, dbeta, dgamma, sorted_pair, sorted_row, n_src, grad_P,
+                                             part, stream, nullptr, 0.f);
+}
+
+// deterministic form: the per-source-row sums are accumulated in grad_P_fixed (n_src, H) int64, pre-zeroed, as round(value * scale)
+// (integer atomics: the result does not depend on the order in which the slabs arrive); the caller converts back
+// (grad_P = grad_P_fixed / scale). scale is the caller's: 2^40 / (a power of two >= max |grad_z| * max |gamma invstd|) keeps 2^-40 of
+// that magnitude per addend and overflows only beyond 2^22 times it. `part` as above (it never went through atomics).
+extern "C" int crb_group_affine_rows_grad_bn_recompute_stack_fixed(int B, int64_t M, int H, int nsample, const float* xyz,
+                                                                   const int32_t* xyz_batch_cnt, const float* P, const float* new_xyz,
+                                                                   const int32_t* new_xyz_batch_cnt, const int32_t* idx,
+                                                                   const uint8_t* empty_mask, const float* W1x, const float* grad_z,
+                                                                   const float* mean, const float* invstd, const float* gamma,
+                                                                   const float* beta, const float* dbeta, const float* dgamma,
+                                                                   const int32_t* sorted_pair, const int32_t* sorted_row, int64_t n_src,
+                                                                   int64_t* grad_P_fixed /* pre-zeroed */, float scale, float* part,
+                                                                   void* stream) {
+  if (!grad_P_fixed || !(scale > 0.f)) return CRB_ERR_ARG;
+  return group_affine_rows_grad_bn_recompute(B, M, H, nsample, xyz, xyz_batch_cnt, P, new_xyz, new_xyz_batch_cnt, idx, empty_mask, W1x,
+                                             grad_z, mean, invstd, gamma, beta, dbeta, dgamma, sorted_pair, sorted_row, n_src, nullptr,
+                                             part, stream, grad_P_fixed, scale);
 }
 
 // ---- pairs in source-row order (for the sorted form of the scatter above) ---------------------------------------------------------

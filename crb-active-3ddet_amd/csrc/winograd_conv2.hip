@@ -316,8 +316,8 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
   int tc = 0;
   f32x2 mk[4][2];
   auto t_setup = [&]() {
-    int n = tu.n0, ty = tu.ty0 + t_tr;
-    while (ty >= a.th) { ty -= a.th; ++n; }
+    int ty = tu.ty0 + t_tr;
+    while (ty >= a.th) ty -= a.th;
     const int x0 = 2 * (tu.bc * TB_COLS + t_tc) - 1;
     float cv[4];
 #pragma unroll
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(NT, 2) void winograd2_kernel(Wino2Args a) {
 }  // namespace
 
 CRB_KNOB g_wino2_persistent = 1; // 1: one workgroup per CU over a range of units (measured 4 - 8 % faster); 0: one unit per workgroup
-CRB_KNOB g_wino2_mode = 0;      // measurement builds: 1 = no MFMAs, 2 = no transform, 3 = no DMA in the loop
+CRB_KNOB g_wino2_mode [[maybe_unused]] = 0;      // measurement builds: 1 = no MFMAs, 2 = no transform, 3 = no DMA in the loop
 #ifdef CRB_MEASURE
 extern "C" int crb_winograd2_set_mode(int mode) { g_wino2_mode = (mode >= 1 && mode <= 13) ? mode : 0; return CRB_OK; }
 extern "C" int crb_winograd2_set_persistent(int on) { g_wino2_persistent = on ? 1 : 0; return CRB_OK; }

@@ -56,7 +56,7 @@ constexpr int V_PHASE = 12 * V_XP;           // 26112
 constexpr int RAW_ROWS = 36, RAW_PX = 10;
 constexpr int RAW_SLOTS = 6 * NT;            // 1536 slots of 16 bytes (1440 used: 36 rows x 10 pixels x 4 channel quads)
 constexpr int RAW_BYTES = RAW_SLOTS * 16;    // 24576
-constexpr int LDS_V = 0, LDS_U = 2 * V_PHASE, LDS_RAW = LDS_U + 3 * U_PHASE, LDS_BYTES = LDS_RAW + RAW_BYTES;   // 150528
+constexpr int LDS_V = 0, LDS_U = 2 * V_PHASE, LDS_RAW = LDS_U + 3 * U_PHASE, LDS_BYTES [[maybe_unused]] = LDS_RAW + RAW_BYTES;   // 150528
 constexpr int LDS_RAW_R = 2 * V_PHASE, LDS_BYTES_R = LDS_RAW_R + RAW_BYTES;                                     // 76800 (U in registers)
 
 __device__ float g_wino4_zero_page[64];      // source of out-of-map pixels (zero-initialised, never written)

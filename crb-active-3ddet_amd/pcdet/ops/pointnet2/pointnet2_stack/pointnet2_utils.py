@@ -3,6 +3,7 @@ Same callables: ball_query, grouping_operation, QueryAndGroup, farthest_point_sa
 three_nn, three_interpolate."""
 import ctypes
 
+import math
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -485,11 +486,25 @@ class SAMlp2TrainConcat(Function):
                 wss = torch.empty((wsb,), dtype=torch.uint8, device=dev)
                 check(lib.crb_pair_sort_by_source(B, M, ns, ptr(xc), ptr(nc), ptr(idx), ptr(em), n_src, ptr(sp), ptr(sr), ptr(wss), wsb, st),
                       'crb_pair_sort_by_source')
-            check(lib.crb_group_affine_rows_grad_bn_recompute_stack(B, M, h1, ns, ptr(xyz_c), ptr(xc), ptr(P), ptr(new_c), ptr(nc),
-                                                                    ptr(idx), ptr(em), ptr(w1x), ptr(gz1), ptr(mean1), ptr(invstd1),
-                                                                    ptr(g1c), ptr(b1c), ptr(d1[0]), ptr(d1[1]), ptr(sp), ptr(sr), n_src,
-                                                                    ptr(gP), ptr(part), st),
-                  'crb_group_affine_rows_grad_bn_recompute_stack')
+            if torch.are_deterministic_algorithms_enabled():
+                # float atomics add in arrival order; 64-bit fixed point does not care: round(value * 2^40 / R) with R a power of two
+                # >= max |grad| * max |gamma invstd| (2^-40 R per addend, room for sums up to 2^22 R)
+                R = float(gz1.abs().max()) * float((g1c * invstd1).abs().max())
+                scale = 2.0 ** (40 - (math.frexp(R)[1] if R > 0.0 and math.isfinite(R) else 0))
+                gP64 = torch.zeros((feats.shape[0], h1), dtype=torch.int64, device=dev)
+                check(lib.crb_group_affine_rows_grad_bn_recompute_stack_fixed(B, M, h1, ns, ptr(xyz_c), ptr(xc), ptr(P), ptr(new_c), ptr(nc),
+                                                                              ptr(idx), ptr(em), ptr(w1x), ptr(gz1), ptr(mean1),
+                                                                              ptr(invstd1), ptr(g1c), ptr(b1c), ptr(d1[0]), ptr(d1[1]),
+                                                                              ptr(sp), ptr(sr), n_src, ptr(gP64), scale, ptr(part), st),
+                      'crb_group_affine_rows_grad_bn_recompute_stack_fixed')
+                gP = (gP64.double() * (1.0 / scale)).float()
+                del gP64
+            else:
+                check(lib.crb_group_affine_rows_grad_bn_recompute_stack(B, M, h1, ns, ptr(xyz_c), ptr(xc), ptr(P), ptr(new_c), ptr(nc),
+                                                                        ptr(idx), ptr(em), ptr(w1x), ptr(gz1), ptr(mean1), ptr(invstd1),
+                                                                        ptr(g1c), ptr(b1c), ptr(d1[0]), ptr(d1[1]), ptr(sp), ptr(sr), n_src,
+                                                                        ptr(gP), ptr(part), st),
+                      'crb_group_affine_rows_grad_bn_recompute_stack')
             del gz1
             if ctx.needs_input_grad[4]:
                 gf = gP @ w1f

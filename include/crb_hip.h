@@ -416,7 +416,19 @@ int crb_group_affine_rows_grad_bn_recompute_stack(int B, int64_t M, int H, int n
                                                   const float* beta, const float* dbeta, const float* dgamma,
                                                   const int32_t* sorted_pair, const int32_t* sorted_row, int64_t n_src,
                                                   float* grad_P, float* part, void* stream);
-/* optional operand of the call above (sorted_pair / sorted_row, NULL = pair order): the (query, sample) pairs in SOURCE-ROW order,
+/* deterministic form of the call above (torch.use_deterministic_algorithms in the host mirror): what leaves a slab is added into
+ * grad_P_fixed (n_src, H) int64, pre-zeroed, as round(value * scale) with 64-bit integer atomics - the sums do not depend on the
+ * order in which the slabs arrive; the caller converts back (grad_P = grad_P_fixed / scale). scale > 0: 2^40 / (a power of two >=
+ * max |grad_z| * max |gamma * invstd|) keeps 2^-40 of that magnitude per addend and overflows only past 2^22 times it. */
+int crb_group_affine_rows_grad_bn_recompute_stack_fixed(int B, int64_t M, int H, int nsample, const float* xyz,
+                                                        const int32_t* xyz_batch_cnt, const float* P, const float* new_xyz,
+                                                        const int32_t* new_xyz_batch_cnt, const int32_t* idx,
+                                                        const uint8_t* empty_mask, const float* W1x, const float* grad_z,
+                                                        const float* mean, const float* invstd, const float* gamma,
+                                                        const float* beta, const float* dbeta, const float* dgamma,
+                                                        const int32_t* sorted_pair, const int32_t* sorted_row, int64_t n_src,
+                                                        int64_t* grad_P_fixed, float scale, float* part, void* stream);
+/* optional operand of the calls above (sorted_pair / sorted_row, NULL = pair order): the (query, sample) pairs in SOURCE-ROW order,
  * stable (pairs of one row keep their order), pairs of empty balls last with sorted_row = n_src (the number of source rows). With it
  * the kernel adds the pairs of a row inside LDS and issues one row of atomics per run of a 64-pair slab instead of one per distinct
  * row of a 16-pair segment: for layers where many balls share a row (the RoI-grid scales of PV-RCNN: 7 M pairs onto 32 k keypoints,
