@@ -141,8 +141,19 @@ class PVRCNNHead(RoIHeadTemplate):
             m = mods[i]
             if isinstance(m, nn.Conv1d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d):
                 w, shift = fold_conv_bn(m, mods[i + 1])
-                x = torch.nn.functional.conv1d(x, w, shift)
+                if x.shape[-1] == 1 and m.kernel_size == (1,) and m.stride == (1,) and m.padding == (0,) and m.groups == 1:
+                    # a length-1 signal: the layer is rows @ W^T + shift. As a convolution it goes to MIOpen, whose solver choice for
+                    # these (rows, 256, 1) problems depends on process state (workspace it is offered, what ran before): the RoI
+                    # head's outputs came out 1.6e-8 apart between two schedules of the same forward pass inside the full test suite
+                    x = torch.addmm(shift, x.squeeze(-1), w.squeeze(-1).t()).unsqueeze(-1)
+                else:
+                    x = torch.nn.functional.conv1d(x, w, shift)
                 i += 2
+            elif isinstance(m, nn.Conv1d) and x.shape[-1] == 1 and m.kernel_size == (1,) and m.stride == (1,) and m.padding == (0,) and \
+                    m.groups == 1 and not torch.is_grad_enabled():
+                w2 = m.weight.squeeze(-1)
+                x = (x.squeeze(-1) @ w2.t() if m.bias is None else torch.addmm(m.bias, x.squeeze(-1), w2.t())).unsqueeze(-1)
+                i += 1
             else:
                 x = m(x)
                 i += 1

@@ -249,7 +249,7 @@ def test_ragged_batch_train_and_scoring(model, dev):
 def test_dense_half_before_pfe_schedule_gives_identical_outputs(model, dev):
     """Detector3DTemplate.scheduled_modules runs BACKBONE_2D + DENSE_HEAD before the PFE (they commute: the PFE reads the
     BEV input map, not their outputs) so that the keypoint FPS on the side stream is hidden: same module set, every output
-    of the chain equal to the reference order's (bit-identical up to the RoI head, 1e-6 for the RoI head's outputs), eval mode."""
+    of the chain bit-identical to the reference order's, eval mode."""
     order = [type(m).__name__ for m in model.scheduled_modules()]
     ref_order = [type(m).__name__ for m in model.module_list]
     assert sorted(order) == sorted(ref_order) and order != ref_order
@@ -268,10 +268,11 @@ def test_dense_half_before_pfe_schedule_gives_identical_outputs(model, dev):
             type(model).DENSE_BEFORE_PFE = True
     for k in outs[0]:
         a, b = outs[0][k], outs[1][k]
-        if k in ('rois', 'spatial_features_2d', 'point_features'):
-            assert torch.equal(a, b), (k, float((a - b).abs().max()))
-        else:       # RoI-head outputs: 1.6e-8 apart once in a full-suite run (equal when the test runs alone); cause not isolated
-            assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max())), (k, float((a - b).abs().max()))
+        # bit-identical, RoI head included (round 5 saw its outputs 1.6e-8 apart inside the full suite and equal alone: the
+        # head's Conv1d(k=1) layers on (rows, 256, 1) tensors went to MIOpen, whose solver choice for them depends on process
+        # state; they are row GEMMs now - pvrcnn_head.py:_run_folded; two strict full-suite runs failed before the change and
+        # passed after it, profiles/r06_schedule_equal_strict_runs.txt)
+        assert torch.equal(a, b), (k, float((a - b).abs().max()))
 
 
 @pytest.mark.parametrize('kind', ['kitti', 'waymo'])
