@@ -144,6 +144,10 @@ __global__ __launch_bounds__(256) void ball_query2_multi_kernel(int B, int M, fl
                                                                 int* __restrict__ idx_a, int* __restrict__ idx_b,
                                                                 unsigned char* __restrict__ empty_a,
                                                                 unsigned char* __restrict__ empty_b) {
+  // In the pipelined scoring pass these waves share the sampling kernel's 16 CUs with the NEXT batch's farthest-point sampling (off
+  // the critical path, a batch ahead). All workgroups of a call are resident at once, so the ones on those CUs set the kernel's
+  // time: beside fps2_kernel (few stalls) a call took 646 us instead of 244. Issue priority over the default-priority sampler:
+  __builtin_amdgcn_s_setprio(3);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int q0 = (blockIdx.x * 4 + wave) * Q;
@@ -280,6 +284,7 @@ __global__ __launch_bounds__(256) void ball_query2_grouped_kernel(int B, int M, 
   __shared__ int cidx[GQ_CAP];
   __shared__ float red[4][4];
   __shared__ int wcount[4];
+  __builtin_amdgcn_s_setprio(3);                             // (see ball_query2_multi_kernel)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int q0 = blockIdx.x * group;

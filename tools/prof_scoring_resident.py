@@ -14,6 +14,9 @@ if __name__ == '__main__':
     from pcdet.model_cfgs import pv_rcnn_cfg
     from pcdet.models import build_network
     from pcdet.query_strategies import build_strategy
+    if os.environ.get('CRB_FPS_VARIANT'):                 # measurement library (CRB_MEASURE_LIB=1): A/B of the sampling kernel
+        from crbhip import lib
+        lib.crb_fps_set_variant(int(os.environ['CRB_FPS_VARIANT']))
     dev = torch.device('cuda', 0)
     torch.manual_seed(0)
     cfg = pv_rcnn_cfg()

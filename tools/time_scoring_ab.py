@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """GPU, measurement library: the resident CRB stage-1 scoring pass (8 batches of B frames, argv[1], default 16) with the Winograd
-product kernel (variant 1: weight fragments in registers) against the LDS-DMA form (variant 3), interleaved, three rounds."""
+product kernel (variant 1: weight fragments in registers) against the LDS-DMA form (variant 3), interleaved, three rounds; third row: the product Winograd kernel with the round-2 farthest-point sampling kernel."""
 import os
 import sys
 import time
@@ -28,8 +28,9 @@ if __name__ == '__main__':
     strat.score_device_batches(batches[:2])
     torch.cuda.synchronize()
     for rep in range(3):
-        for v, name in ((1, 'U in registers'), (3, 'U through LDS-DMA')):
+        for v, fv, name in ((1, 2, 'U in registers'), (3, 2, 'U through LDS-DMA'), (1, 1, 'U in regs, old FPS')):
             lib.crb_winograd4_set_variant(v)
+            lib.crb_fps_set_variant(fv)
             strat.score_device_batches(batches[:2])
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -38,3 +39,4 @@ if __name__ == '__main__':
             dt = time.perf_counter() - t0
             print('%d frames per batch, %-18s %.1f frames/s (%.1f ms per batch)' % (B, name, 8 * B / dt, dt / 8 * 1e3), flush=True)
     lib.crb_winograd4_set_variant(1)
+    lib.crb_fps_set_variant(2)
