@@ -87,6 +87,15 @@ def _use4(kin, kout):
     return KERNEL == 'x6' and bool(lib.crb_winograd4_supported(int(kin), int(kout), 31, 1))
 
 
+# the split-bf16 kernel's third form (workgroup tile 32 tiles x 128 channels: crb_conv3x3_winograd4c_nhwc) where it has an instance
+# (Cout % 128 == 0); CRB_WINOGRAD_FORM_C=0: the 64 x 64 form everywhere (A/B). Same outputs, bit for bit; another image layout.
+FORM_C = __import__('os').environ.get('CRB_WINOGRAD_FORM_C', '1') == '1'
+
+
+def _use_c(kin, kout):
+    return FORM_C and _use4(kin, kout) and bool(lib.crb_winograd4c_supported(int(kin), int(kout), 31, 1))
+
+
 # images made ahead by prepare_weights2 (one launch for all layers of a step): key -> image. A key names the weight's memory, its
 # autograd version (an optimizer step bumps it) and the mode: a stale image cannot be returned
 _PREPARED = {}
@@ -94,7 +103,7 @@ PREPARE = __import__('os').environ.get('CRB_WINOGRAD_PREPARE', '1') == '1'
 
 
 def _prep_key(w, mode):
-    return (w.data_ptr(), w._version, tuple(w.shape), tuple(w.stride()), w.device.index, KERNEL, int(mode))
+    return (w.data_ptr(), w._version, tuple(w.shape), tuple(w.stride()), w.device.index, KERNEL, FORM_C, int(mode))
 
 
 def prepare_weights2(weights, input_grad=True):
@@ -129,7 +138,7 @@ def prepare_weights2(weights, input_grad=True):
             st = (ctypes.c_int64 * (4 * n))(*[v for w, _ in part for v in w.stride()])
             ci = (ctypes.c_int32 * n)(*[w.shape[1] for w, _ in part])
             co = (ctypes.c_int32 * n)(*[w.shape[0] for w, _ in part])
-            md = (ctypes.c_int32 * n)(*[m for _, m in part])
+            md = (ctypes.c_int32 * n)(*[(m + 2 if (four and _use_c(*kshape(w, m))) else m) for w, m in part])
             fn = lib.crb_winograd4_weights_conv_multi if four else lib.crb_winograd2_weights_conv_multi
             check(fn(n, wp, st, up, ci, co, md, cur_stream(part[0][0].device)),
                   'crb_winograd4_weights_conv_multi' if four else 'crb_winograd2_weights_conv_multi')
@@ -137,6 +146,7 @@ def prepare_weights2(weights, input_grad=True):
                 if four:
                     U.wino4_shape = kshape(w, mode)
                     U._crb_mode = mode
+                    U._crb_c = _use_c(*kshape(w, mode))
                 else:
                     U.wino2_shape = kshape(w, mode)
                 U._crb_src = w              # (keeps the weight's storage alive: no other tensor can take the key's address meanwhile)
@@ -231,10 +241,11 @@ def _weights_conv4(weight, mode):
     cout, cin = w.shape[0], w.shape[1]
     U = torch.empty((int(lib.crb_winograd4_weights_bytes(cin, cout)),), dtype=torch.uint8, device=w.device)
     so, si, sky, skx = w.stride()
-    check(lib.crb_winograd4_weights_conv(w.data_ptr(), so, si, sky, skx, ptr(U), cin, cout, mode, cur_stream(w.device)),
-          'crb_winograd4_weights_conv')
+    form_c = _use_c(cout if mode else cin, cin if mode else cout)
+    check(lib.crb_winograd4_weights_conv(w.data_ptr(), so, si, sky, skx, ptr(U), cin, cout, mode + (2 if form_c else 0),
+                                         cur_stream(w.device)), 'crb_winograd4_weights_conv')
     U.wino4_shape = (cout, cin) if mode else (cin, cout)
-    U._crb_src, U._crb_mode = w, mode
+    U._crb_src, U._crb_mode, U._crb_c = w, mode, form_c
     return U
 
 
@@ -256,9 +267,10 @@ def conv3x3_U4(x, U, bias=None, relu=False):
         raise CrbHipError('no Winograd (4) instance for %d -> %d channels on a %d x %d map' % (cin, cout, H, W))
     y = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     e0 = _prof_begin()
-    check(lib.crb_conv3x3_winograd4_nhwc(xv.data_ptr(), ptr(U), y.data_ptr(), N, H, W, cin, cout,
-                                         ptr(bias.contiguous().float()) if bias is not None else None, int(bool(relu)),
-                                         cur_stream(x.device)), 'crb_conv3x3_winograd4_nhwc')
+    fn = lib.crb_conv3x3_winograd4c_nhwc if getattr(U, '_crb_c', False) else lib.crb_conv3x3_winograd4_nhwc
+    check(fn(xv.data_ptr(), ptr(U), y.data_ptr(), N, H, W, cin, cout,
+             ptr(bias.contiguous().float()) if bias is not None else None, int(bool(relu)),
+             cur_stream(x.device)), 'crb_conv3x3_winograd4_nhwc')
     _prof_end(e0, 'wino_conv', cin, cout, N, H, W)
     return y
 
@@ -272,10 +284,13 @@ def conv3x3_stats_U4(x, U):
     if ucin != cin or not supported4(cin, cout, H, W):
         raise CrbHipError('no Winograd (4) instance for %d -> %d channels on a %d x %d map' % (cin, cout, H, W))
     y = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    stats = torch.empty((int(lib.crb_winograd4_stats_slabs(N, H, W)), 2, cout), dtype=torch.float32, device=x.device)
+    form_c = getattr(U, '_crb_c', False)
+    slabs = lib.crb_winograd4c_stats_slabs(N, H, W) if form_c else lib.crb_winograd4_stats_slabs(N, H, W)
+    stats = torch.empty((int(slabs), 2, cout), dtype=torch.float32, device=x.device)
     e0 = _prof_begin()
-    check(lib.crb_conv3x3_winograd4_stats_nhwc(xv.data_ptr(), ptr(U), y.data_ptr(), ptr(stats), N, H, W, cin, cout,
-                                               cur_stream(x.device)), 'crb_conv3x3_winograd4_stats_nhwc')
+    fn = lib.crb_conv3x3_winograd4c_stats_nhwc if form_c else lib.crb_conv3x3_winograd4_stats_nhwc
+    check(fn(xv.data_ptr(), ptr(U), y.data_ptr(), ptr(stats), N, H, W, cin, cout, cur_stream(x.device)),
+          'crb_conv3x3_winograd4_stats_nhwc')
     _prof_end(e0, 'wino_conv', cin, cout, N, H, W)
     return y, stats
 

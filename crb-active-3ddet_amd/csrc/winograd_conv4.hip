@@ -81,8 +81,10 @@ __device__ __forceinline__ void split3(float x, unsigned& h1, unsigned& h2, unsi
 // ---- weight image. Byte offset of (xi = 4 i + jx, piece p, kernel input channel ci, kernel output channel co):
 //      [co / 64][ci / 16][i][jx][p][k group (ci % 16) / 8][row co % 64][element ci % 8] bf16  - a phase image is one linear 24 KB copy
 __device__ __forceinline__ void weights_octet(const float* __restrict__ w, int64_t so, int64_t si, int64_t sky, int64_t skx,
-                                              unsigned char* __restrict__ U, int kin, int kout, int mode, int64_t t) {
+                                              unsigned char* __restrict__ U, int kin, int kout, int mode_, int64_t t) {
   if (t >= (int64_t)(kin / 8) * kout) return;
+  const int mode = mode_ & 1;                  // 0 = forward weights, 1 = input-gradient weights (transposed, rotated)
+  const bool layout_c = (mode_ & 2) != 0;      // image layout of the 32 x 128 form
   const int cg = (int)(t / kout), co = (int)(t - (int64_t)cg * kout);     // channel octet, kernel-side output channel
   u32x4 out[16][3];
 #pragma unroll
@@ -118,7 +120,19 @@ __device__ __forceinline__ void weights_octet(const float* __restrict__ w, int64
     }
   }
   const int nch = kin / CC;
-  const int cb = co / WG_K, row = co - cb * WG_K, chunk = cg >> 1, kg = cg & 1;
+  const int chunk = cg >> 1, kg = cg & 1;
+  if (layout_c) {      // [co / 128][ci / 16][i][jx][k group][row co % 128][p][element ci % 8]: the image of winograd4c_kernel
+    const int cb = co / 128, row = co - cb * 128;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const int64_t off = ((int64_t)(cb * nch + chunk) * 4 + (xi >> 2)) * (4 * 2 * 128 * 48) + (xi & 3) * (2 * 128 * 48) + (kg * 128 + row) * 48 + p * 16;
+        *reinterpret_cast<u32x4*>(U + off) = out[xi][p];
+      }
+    return;
+  }
+  const int cb = co / WG_K, row = co - cb * WG_K;
 #pragma unroll
   for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
@@ -667,6 +681,426 @@ __global__ __launch_bounds__(NT, 1) void winograd4_kernel(Wino4Args a) {
 }
 
 
+// ================================================================================================================================
+// Third form (round 6, "c"): workgroup tile = 32 tiles (8 tile rows x 4 tile columns) x 128 output channels instead of 64 x 64.
+// The product GEMM per phase is the same (four waves x one 32 x 32 block x 4 xi), but the input side halves: V of a spatial block is
+// formed ONCE per 128 output channels instead of once per 64 (the row pass, its split, the V stores and the raw copies were three of
+// the additive costs of the form above), every wave reads the same B fragments, and the four waves load four different channel
+// quarters of the weight image (no two waves ask for the same fragment any more). All 256 threads still share the transform: thread =
+// (tile, channel quad, xi pair), the xi pair {0,1} or {2,3} of a row - its three lane-local patch columns X0, X1, X2 are
+// (c0, c2, c1) or (c2, c1, -c3), so that both halves run the same instructions: xi_a = X0 - X1, xi_b = X1 + X2 (exact: a negation
+// and a commuted addition). Same arithmetic as the form above: the outputs are bit-equal.
+// Weight image "c": [Cout/128][Cin/16][xi row][xi][k group][row 128][piece 3][8 bf16] - a lane's three pieces are 48 contiguous bytes.
+namespace c4 {
+constexpr int TB_ROWS = 8, TB_COLS = 4;
+constexpr int WG_K = 128;
+constexpr int U_ROW = 48;
+constexpr int U_XI = 2 * WG_K * U_ROW;         // 12288
+constexpr int U_PHASE = 4 * U_XI;              // 49152
+constexpr int V_REGION = 32 * 16 + 64;         // [tile 32][8 bf16] + 64 bytes between the two k groups
+constexpr int V_XP = 2 * V_REGION + 16;        // 1168: + 16 so that the two xi pairs of a (tile, quad) store to different banks
+constexpr int V_PHASE = 12 * V_XP;             // 14016
+constexpr int RAW_ROWS = 20, RAW_PX = 10;
+constexpr int RAW_SLOTS = 4 * NT;              // 1024 slots of 16 bytes (800 used: 20 rows x 10 pixels x 4 channel quads)
+constexpr int RAW_BYTES = RAW_SLOTS * 16;      // 16384
+constexpr int LDS_V = 0, LDS_RAW = 2 * V_PHASE, LDS_BYTES = LDS_RAW + RAW_BYTES;   // 44416
+
+struct UnitPos { int cb, bc, R0, n0, ty0; };
+__device__ __forceinline__ UnitPos unit_at(int u, const Wino4Args& a) {
+  UnitPos p;
+  const int tb = u / a.ncb;
+  p.cb = u - tb * a.ncb;
+  const int br = tb / a.tw4;
+  p.bc = tb - br * a.tw4;
+  p.R0 = br * TB_ROWS;
+  p.n0 = p.R0 / a.th;
+  p.ty0 = p.R0 - p.n0 * a.th;
+  return p;
+}
+}  // namespace c4
+
+__global__ __launch_bounds__(NT, 1) void winograd4c_kernel(Wino4Args a) {
+  constexpr int TB_ROWS = c4::TB_ROWS, TB_COLS = c4::TB_COLS, WG_K = c4::WG_K, U_ROW = c4::U_ROW, U_XI = c4::U_XI, U_PHASE = c4::U_PHASE,
+                V_REGION = c4::V_REGION, V_XP = c4::V_XP, V_PHASE = c4::V_PHASE, RAW_ROWS = c4::RAW_ROWS, RAW_PX = c4::RAW_PX;
+  using UnitPos = c4::UnitPos;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* const Vb = lds + c4::LDS_V;
+  unsigned char* const Rb = lds + c4::LDS_RAW;
+  const int T = threadIdx.x, lane = T & 63, wave = __builtin_amdgcn_readfirstlane(T >> 6);
+  asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17",
+               "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35",
+               "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53",
+               "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71",
+               "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89",
+               "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106",
+               "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121",
+               "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136",
+               "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151",
+               "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166",
+               "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181",
+               "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196",
+               "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211",
+               "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226",
+               "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241",
+               "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
+
+  // ---- the unit range of this workgroup (busy-CU latch as in the forms above)
+  const int nunits = a.nblocks * a.ncb;
+  int G = gridDim.x;
+  if (a.seq) {
+    if (T == 0) {
+      unsigned* L = g_cu_latch4 + (a.seq & 63u);
+      unsigned v = __hip_atomic_load(L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), mine;
+      for (;;) {
+        if ((v >> 8) == a.seq) { mine = v & 255u; break; }
+        const int b = __hip_atomic_load(&g_cu_busy4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned busy = (unsigned)min(max(b, 0), 255);
+        const unsigned seen = atomicCAS(L, v, (a.seq << 8) | busy);
+        if (seen == v) { mine = busy; break; }
+        v = seen;
+      }
+      *reinterpret_cast<unsigned*>(Rb) = mine;
+    }
+    __syncthreads();
+    const int busy = (int)*reinterpret_cast<const unsigned*>(Rb);
+    __syncthreads();
+    G = max(1, (int)gridDim.x - __builtin_amdgcn_readfirstlane(busy));
+    if ((int)blockIdx.x >= G) return;
+  }
+  const int u_first = (int)((int64_t)blockIdx.x * nunits / G);
+  const int u_end = (int)((int64_t)(blockIdx.x + 1) * nunits / G);
+  if (u_first >= u_end) return;
+  const int nch = a.cin / CC;
+  const int total_chunks = (u_end - u_first) * nch;
+
+  // ---- MFMA role: wave = channel quarter, all 32 tiles
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int a_rd = (lhi * WG_K + wave * 32 + l31) * U_ROW;          // weight image: the lane's (k group, row), three pieces
+  const int b_rd = lhi * V_REGION + l31 * 16;                       // V image: B operand, columns = tiles
+
+  // ---- transform role: thread = (tile, channel quad, xi pair)
+  const int t_tile = T >> 3, t_q = (T >> 1) & 3, t_h = T & 1, t_tr = t_tile >> 2, t_tc = t_tile & 3;
+  const int v_wr = (t_q >> 1) * V_REGION + t_tile * 16 + (t_q & 1) * 8 + t_h * (6 * V_XP);
+  const float t_sg = t_h ? -1.f : 1.f;                              // X2 = -c3 for the pair {2, 3}
+  int t_unit = u_first, tcnt = 0;
+  // raw read offsets of the lane's three patch columns (pixel column b of the patch sits at position t_tc + (b >> 1) + 5 (b & 1) of its
+  // row): X0 = c0 | c2, X1 = c2 | c1, X2 = c1 | c3
+  int raw_rd[3];
+  auto raw_base = [&](int u) {
+    const UnitPos p = c4::unit_at(u, a);
+    const int rows_a = min(TB_ROWS, a.th - p.ty0);
+    const int lr = 2 * t_tr + (t_tr >= rows_a ? 2 : 0);
+    const int b0 = t_h ? 2 : 0, b1 = t_h ? 1 : 2, b2 = t_h ? 3 : 1;
+    raw_rd[0] = 16 * (4 * (lr * RAW_PX + t_tc + (b0 >> 1) + 5 * (b0 & 1)) + t_q);
+    raw_rd[1] = 16 * (4 * (lr * RAW_PX + t_tc + (b1 >> 1) + 5 * (b1 & 1)) + t_q);
+    raw_rd[2] = 16 * (4 * (lr * RAW_PX + t_tc + (b2 >> 1) + 5 * (b2 & 1)) + t_q);
+  };
+  raw_base(t_unit);
+
+  // ---- copy role. raw: slots s = T + 256 j (16 bytes each): s -> (pixel position P = s >> 2, channel quad s & 3), P = local
+  //      row * 10 + column order (x >> 1) + 5 (x & 1)
+  int r_unit = u_first, rc = 0;
+  const float* rsrc[4];
+  unsigned rstep = 0;
+  auto raw_sources = [&](int u) {
+    const UnitPos p = c4::unit_at(u, a);
+    const int rows_a = min(TB_ROWS, a.th - p.ty0);
+    const int limit_a = 2 * rows_a + 2;
+    rstep = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int s = T + NT * j;
+      const int P = s >> 2, q = s & 3;
+      const int lr = P / RAW_PX, rem = P - lr * RAW_PX;
+      const int xx = rem < 5 ? 2 * rem : 2 * (rem - 5) + 1;
+      const bool in_a = lr < limit_a;
+      const int n = in_a ? p.n0 : p.n0 + 1;
+      const int py = in_a ? 2 * p.ty0 - 1 + lr : lr - limit_a - 1;
+      const int px = 8 * p.bc - 1 + xx;
+      const bool ok = lr < RAW_ROWS && (in_a || (rows_a < TB_ROWS && (lr - limit_a) < 2 * (TB_ROWS - rows_a) + 2)) && n < a.N &&
+                      py >= 0 && py < a.H && px >= 0 && px < a.W;
+      const int64_t off = (((int64_t)n * a.H + py) * a.W + px) * a.cin + q * 4;
+      rsrc[j] = ok ? a.x + off : g_wino4_zero_page;
+      rstep |= ok ? (1u << j) : 0u;
+    }
+  };
+  raw_sources(r_unit);
+  auto issue_raw = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(rsrc[j], Rb + (NT * j + wave * 64) * 16);
+  };
+  auto r_advance = [&]() {
+    if (++rc < nch) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rsrc[j] += (rstep >> j & 1u) ? CC : 0;
+      return;
+    }
+    rc = 0;
+    ++r_unit;
+    if (r_unit % a.ncb == 0) raw_sources(r_unit);
+    else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rsrc[j] -= (rstep >> j & 1u) ? (nch - 1) * CC : 0;
+    }
+  };
+  int u_cb = u_first % a.ncb, upc = 0;              // channel block / phase of its unit the next fragment loads fetch
+  const unsigned char* usrc = a.U + (int64_t)u_cb * nch * 4 * U_PHASE;
+  auto u_advance = [&]() {
+    if (++upc < nch * 4) { usrc += U_PHASE; return; }
+    upc = 0;
+    if (++u_cb == a.ncb) u_cb = 0;
+    usrc = a.U + (int64_t)u_cb * nch * 4 * U_PHASE;
+  };
+  bf16x8 Ar[4][3];                                   // the A fragments of the phase about to run
+  auto a_load = [&](auto jc) __attribute__((always_inline)) {
+    constexpr int jx = decltype(jc)::value;
+    const unsigned voff = (unsigned)a_rd + jx * U_XI;
+    Ar[jx][0] = gload16<0>(usrc, voff);
+    Ar[jx][1] = gload16<16>(usrc, voff);
+    Ar[jx][2] = gload16<32>(usrc, voff);
+  };
+
+  acc_zero_range<0, 256>();
+
+  // ---- output transform of a finished unit: lane = tile l31, channels cb * 128 + 32 wave + 8 j + 4 lhi + (0..3) for register group j
+  int e_unit = u_first, ec = 0;
+  auto epilogue_group = [&](auto jc, const UnitPos& eu, float* yo, bool in, bool x1, bool y1) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;
+    const int kbase = eu.cb * WG_K + wave * 32 + 4 * lhi + 8 * j;
+    f32x4 bias = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+      const float* bp = a.bias + eu.cb * WG_K + wave * 32 + 8 * j;
+      const f32x4 b0 = sload4(bp), b1 = sload4(bp + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bias[e] = lhi ? b1[e] : b0[e];
+    }
+    f32x4 M[16];
+#define CRB_ACC4(XI) M[XI] = (f32x4){acc_read<XI * 16 + 4 * j>(), acc_read<XI * 16 + 4 * j + 1>(), acc_read<XI * 16 + 4 * j + 2>(), acc_read<XI * 16 + 4 * j + 3>()}
+    CRB_ACC4(0); CRB_ACC4(1); CRB_ACC4(2); CRB_ACC4(3); CRB_ACC4(4); CRB_ACC4(5); CRB_ACC4(6); CRB_ACC4(7);
+    CRB_ACC4(8); CRB_ACC4(9); CRB_ACC4(10); CRB_ACC4(11); CRB_ACC4(12); CRB_ACC4(13); CRB_ACC4(14); CRB_ACC4(15);
+#undef CRB_ACC4
+    f32x4 t0[4], t1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      t0[s] = M[0 * 4 + s] + M[1 * 4 + s] + M[2 * 4 + s];
+      t1[s] = M[1 * 4 + s] - M[2 * 4 + s] - M[3 * 4 + s];
+    }
+    f32x4 y00 = t0[0] + t0[1] + t0[2] + bias, y01 = t0[1] - t0[2] - t0[3] + bias;
+    f32x4 y10 = t1[0] + t1[1] + t1[2] + bias, y11 = t1[1] - t1[2] - t1[3] + bias;
+    if (a.relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        y00[e] = fmaxf(y00[e], 0.f); y01[e] = fmaxf(y01[e], 0.f);
+        y10[e] = fmaxf(y10[e], 0.f); y11[e] = fmaxf(y11[e], 0.f);
+      }
+    }
+    f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (in) {
+      float* o = yo + 8 * j;
+      *reinterpret_cast<f32x4*>(o) = y00;
+      if (x1) *reinterpret_cast<f32x4*>(o + a.cout) = y01;
+      if (y1) *reinterpret_cast<f32x4*>(o + (int64_t)a.W * a.cout) = y10;
+      if (x1 && y1) *reinterpret_cast<f32x4*>(o + (int64_t)a.W * a.cout + a.cout) = y11;
+      if (a.stats) {                                          // fixed order: (0,0), (0,1), (1,0), (1,1)
+        const float m01 = x1 ? 1.f : 0.f, m10 = y1 ? 1.f : 0.f, m11 = (x1 && y1) ? 1.f : 0.f;
+        s1 = y00; s2 = y00 * y00;
+        s1 = s1 + y01 * m01; s2 = s2 + (y01 * y01) * m01;
+        s1 = s1 + y10 * m10; s2 = s2 + (y10 * y10) * m10;
+        s1 = s1 + y11 * m11; s2 = s2 + (y11 * y11) * m11;
+      }
+    }
+    if (a.stats) {     // sum over the 32 tiles of the block (fixed order), lanes 0 and 32 write their four channels: slab = spatial block
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float u = s1[e], v = s2[e];
+#define CRB_ROW_ROR_ADD(x, ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false))
+        CRB_ROW_ROR_ADD(u, 0x128); CRB_ROW_ROR_ADD(v, 0x128);
+        CRB_ROW_ROR_ADD(u, 0x124); CRB_ROW_ROR_ADD(v, 0x124);
+        CRB_ROW_ROR_ADD(u, 0x122); CRB_ROW_ROR_ADD(v, 0x122);
+        CRB_ROW_ROR_ADD(u, 0x121); CRB_ROW_ROR_ADD(v, 0x121);
+#undef CRB_ROW_ROR_ADD
+        u += __shfl_xor(u, 16, 64);
+        v += __shfl_xor(v, 16, 64);
+        s1[e] = u;
+        s2[e] = v;
+      }
+      if (l31 == 0) {
+        const int64_t blk = (int64_t)(eu.R0 / TB_ROWS) * a.tw4 + eu.bc;
+        float* so = a.stats + (blk * 2) * a.cout + kbase;
+        *reinterpret_cast<f32x4*>(so) = s1;
+        *reinterpret_cast<f32x4*>(so + a.cout) = s2;
+      }
+    }
+  };
+  auto unit_epilogue = [&]() __attribute__((always_inline)) {
+    const UnitPos eu = c4::unit_at(e_unit, a);
+    const int tr = l31 >> 2, tc = l31 & 3;
+    const int Rg = eu.R0 + tr;
+    const int tx = eu.bc * TB_COLS + tc;
+    int n2 = eu.n0, ty2 = eu.ty0 + tr;
+    while (ty2 >= a.th) { ty2 -= a.th; ++n2; }
+    const int oy = 2 * ty2, ox = 2 * tx;
+    const bool in = Rg < a.RT && tx < a.tw;
+    const bool x1 = ox + 1 < a.W, y1 = oy + 1 < a.H;
+    float* const yo = a.y + (((int64_t)n2 * a.H + oy) * a.W + ox) * a.cout + eu.cb * WG_K + wave * 32 + 4 * lhi;
+    acc_settle();
+    epilogue_group(std::integral_constant<int, 0>{}, eu, yo, in, x1, y1);
+    epilogue_group(std::integral_constant<int, 1>{}, eu, yo, in, x1, y1);
+    epilogue_group(std::integral_constant<int, 2>{}, eu, yo, in, x1, y1);
+    epilogue_group(std::integral_constant<int, 3>{}, eu, yo, in, x1, y1);
+    acc_zero_range<0, 256>();
+    ++e_unit;
+  };
+
+  // ---- input transform in pieces placed behind the MFMAs. col<k>: lane-local column k (3 of them) of the 4 x 4 patch,
+  //      tp[.][k] = B^T d (the third column times t_sg); xi<r, jj, s>: element jj of the lane's xi pair of row r in five steps
+  f32x4 tp[4][3];
+  f32x4 sv, sr1, sr2;
+  auto t_read = [&](f32x4 (&d)[4][3]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) d[i][k] = *reinterpret_cast<const f32x4*>(Rb + raw_rd[k] + i * RAW_PX * 64);
+  };
+  auto t_col = [&](const f32x4 (&d)[4][3], int k) __attribute__((always_inline)) {
+    tp[0][k] = d[0][k] - d[2][k];
+    tp[1][k] = d[1][k] + d[2][k];
+    tp[2][k] = d[2][k] - d[1][k];
+    tp[3][k] = d[1][k] - d[3][k];
+    if (k == 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tp[r][2] = tp[r][2] * t_sg;
+    }
+    asm volatile("" : "+v"(tp[0][k]), "+v"(tp[1][k]), "+v"(tp[2][k]), "+v"(tp[3][k]));
+  };
+  auto trunc16 = [](float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); };
+  auto pack_hi = [](const f32x4& x) {
+    u32x2 o;
+    o[0] = (__float_as_uint(x[0]) >> 16) | (__float_as_uint(x[1]) & 0xffff0000u);
+    o[1] = (__float_as_uint(x[2]) >> 16) | (__float_as_uint(x[3]) & 0xffff0000u);
+    return o;
+  };
+  auto t_xi = [&](unsigned char* V, auto rcst, auto jcst, auto scst) __attribute__((always_inline)) {
+    constexpr int r = decltype(rcst)::value, jj = decltype(jcst)::value, s = decltype(scst)::value;
+    if constexpr (s == 0) {
+      if constexpr (jj == 0) sv = tp[r][0] - tp[r][1];
+      else sv = tp[r][1] + tp[r][2];
+      asm volatile("" : "+v"(sv));
+    } else if constexpr (s == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sr1[e] = sv[e] - trunc16(sv[e]);
+      asm volatile("" : "+v"(sr1));
+    } else if constexpr (s == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sr2[e] = sr1[e] - trunc16(sr1[e]);
+      asm volatile("" : "+v"(sr2));
+    } else if constexpr (s == 3) {
+      *reinterpret_cast<u32x2*>(V + v_wr + (jj * 3 + 0) * V_XP) = pack_hi(sv);
+    } else {
+      *reinterpret_cast<u32x2*>(V + v_wr + (jj * 3 + 1) * V_XP) = pack_hi(sr1);
+      *reinterpret_cast<u32x2*>(V + v_wr + (jj * 3 + 2) * V_XP) = pack_hi(sr2);
+    }
+  };
+  auto t_advance = [&]() {
+    if (++tcnt < nch) return;
+    tcnt = 0;
+    ++t_unit;
+    if (t_unit % a.ncb == 0) raw_base(t_unit);
+  };
+
+  // ---- phases. f = 4 chunk + i: MFMAs of xi row i on V[f & 1] and the fragments requested a phase ago; V(f + 1) formed meanwhile;
+  //      raw(chunk + 1) requested in phase 0, read in phase 3
+  auto phase = [&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int rn = (i + 1) & 3;
+    if (i == 3) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    unsigned char* const Vn = Vb + ((i + 1) & 1) * V_PHASE;
+    const unsigned char* const Vc = Vb + (i & 1) * V_PHASE + b_rd;
+    bf16x8 B[2][3];
+    auto op_read = [&](int jx, int slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) B[slot][p] = *reinterpret_cast<const bf16x8*>(Vc + (jx * 3 + p) * V_XP);
+    };
+    op_read(0, 0);
+    f32x4 d[4][3];
+    if (i == 3) { t_read(d); t_advance(); }
+    if (i == 0) issue_raw();
+    __builtin_amdgcn_sched_barrier(0);
+    // piece k behind MFMA k: the ten steps of the lane's two xi on every other MFMA (phase 3: the three column passes first)
+    auto piece = [&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (i == 3 && k < 3) {
+        t_col(d, k);
+      } else {
+        constexpr int k0 = (i == 3) ? k - 3 : k;
+        if constexpr (k0 >= 0 && k0 < 20 && (k0 & 1) == 0) {
+          t_xi(Vn, std::integral_constant<int, rn>{}, std::integral_constant<int, (k0 >> 1) / 5>{}, std::integral_constant<int, (k0 >> 1) % 5>{});
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stage = [&](auto jc) __attribute__((always_inline)) {
+      constexpr int jx = decltype(jc)::value;
+      constexpr int s = jx & 1;
+      const bf16x8 &A0 = Ar[jx][0], &A1 = Ar[jx][1], &A2 = Ar[jx][2];
+      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(i == 0 ? 13 : 9) : "memory");
+      mfma_acc<4 * i + jx>(A0, B[s][2]);
+      if (jx < 3) op_read(jx + 1, s ^ 1);
+      piece(std::integral_constant<int, 6 * jx + 0>{});
+      mfma_acc<4 * i + jx>(A2, B[s][0]);
+      piece(std::integral_constant<int, 6 * jx + 1>{});
+      mfma_acc<4 * i + jx>(A1, B[s][1]);
+      piece(std::integral_constant<int, 6 * jx + 2>{});
+      mfma_acc<4 * i + jx>(A0, B[s][1]);
+      piece(std::integral_constant<int, 6 * jx + 3>{});
+      mfma_acc<4 * i + jx>(A1, B[s][0]);
+      piece(std::integral_constant<int, 6 * jx + 4>{});
+      mfma_acc<4 * i + jx>(A0, B[s][0]);
+      a_load(jc);
+      if (jx == 3) u_advance();
+      piece(std::integral_constant<int, 6 * jx + 5>{});
+    };
+    stage(std::integral_constant<int, 0>{});
+    stage(std::integral_constant<int, 1>{});
+    stage(std::integral_constant<int, 2>{});
+    stage(std::integral_constant<int, 3>{});
+    if (i == 0) r_advance();
+  };
+
+  // ---- prologue: raw(0) and the fragments of phase 0 in one round trip, raw(0) -> tp -> V(0)
+  issue_raw(); r_advance();
+  a_load(std::integral_constant<int, 0>{}); a_load(std::integral_constant<int, 1>{});
+  a_load(std::integral_constant<int, 2>{}); a_load(std::integral_constant<int, 3>{});
+  u_advance();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  {
+    f32x4 d[4][3];
+    t_read(d); t_advance();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t_col(d, k);
+  }
+#define CRB_T_XI_ALL(JJ)                                                                                                      \
+  t_xi(Vb, std::integral_constant<int, 0>{}, std::integral_constant<int, JJ>{}, std::integral_constant<int, 0>{});            \
+  t_xi(Vb, std::integral_constant<int, 0>{}, std::integral_constant<int, JJ>{}, std::integral_constant<int, 1>{});            \
+  t_xi(Vb, std::integral_constant<int, 0>{}, std::integral_constant<int, JJ>{}, std::integral_constant<int, 2>{});            \
+  t_xi(Vb, std::integral_constant<int, 0>{}, std::integral_constant<int, JJ>{}, std::integral_constant<int, 3>{});            \
+  t_xi(Vb, std::integral_constant<int, 0>{}, std::integral_constant<int, JJ>{}, std::integral_constant<int, 4>{})
+  CRB_T_XI_ALL(0); CRB_T_XI_ALL(1);
+#undef CRB_T_XI_ALL
+
+  for (int cg = 0; cg < total_chunks; ++cg) {
+    phase(std::integral_constant<int, 0>{});
+    phase(std::integral_constant<int, 1>{});
+    phase(std::integral_constant<int, 2>{});
+    phase(std::integral_constant<int, 3>{});
+    if (++ec == nch) { ec = 0; unit_epilogue(); }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (fragments requested past the end of the range)
+}
+
 #ifdef CRB_MEASURE   // the second form: A/B in the measurement library (it is not faster: see its header)
 // ================================================================================================================================
 // Second form (measurement library, crb_winograd4_set_variant(2)): the same pipeline with TWO waves per SIMD. Measured on the first form above (one 512-register wave
@@ -1126,17 +1560,24 @@ extern "C" int crb_winograd4_supported(int cin, int cout, int H, int W) {
   return (cin > 0 && cout > 0 && cin % CC == 0 && cout % WG_K == 0 && H >= 31 && W >= 1) ? 1 : 0;
 }
 
+// the 32-tile x 128-channel form: ceil(H / 2) >= 8 keeps a block of 8 tile rows inside two images
+extern "C" int crb_winograd4c_supported(int cin, int cout, int H, int W) {
+  return (cin > 0 && cout > 0 && cin % CC == 0 && cout % c4::WG_K == 0 && H >= 31 && W >= 1) ? 1 : 0;
+}
+
 extern "C" int64_t crb_winograd4_weights_bytes(int cin, int cout) { return (int64_t)16 * cin * cout * 6; }
 
 // w = nn.Conv2d weight (Cout,Cin,3,3) f32 with element strides (so, si, sky, skx); mode 0: image of the forward convolution
 // (Cin -> Cout), mode 1: image of the input-gradient convolution (Cout -> Cin, flipped / transposed weights)
+// (mode + 2: the same image in the layout of the 32-tile x 128-channel form, crb_winograd4c_supported shapes)
 extern "C" int crb_winograd4_weights_conv(const float* w, int64_t so, int64_t si, int64_t sky, int64_t skx, void* U, int conv_cin,
                                           int conv_cout, int mode, void* stream) {
-  const int kin = mode ? conv_cout : conv_cin, kout = mode ? conv_cin : conv_cout;
-  if (!crb_winograd4_supported(kin, kout, 31, 1)) return CRB_ERR_UNSUPPORTED;
+  if (mode < 0 || mode > 3) return CRB_ERR_ARG;
+  const int kin = (mode & 1) ? conv_cout : conv_cin, kout = (mode & 1) ? conv_cin : conv_cout;
+  if (!((mode & 2) ? crb_winograd4c_supported(kin, kout, 31, 1) : crb_winograd4_supported(kin, kout, 31, 1))) return CRB_ERR_UNSUPPORTED;
   const int64_t per = (int64_t)(kin / 8) * kout;
   hipLaunchKernelGGL(winograd4_weights_conv_kernel, dim3(crb_cdiv(per, 256)), dim3(256), 0, (hipStream_t)stream, w, so, si, sky, skx,
-                     (unsigned char*)U, kin, kout, mode ? 1 : 0);
+                     (unsigned char*)U, kin, kout, mode);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
 }
@@ -1149,11 +1590,12 @@ extern "C" int crb_winograd4_weights_conv_multi(int n, const float* const* w, co
   jobs.n = n;
   int64_t blocks = 0;
   for (int j = 0; j < n; ++j) {
-    const int kin = mode[j] ? conv_cout[j] : conv_cin[j], kout = mode[j] ? conv_cin[j] : conv_cout[j];
+    if (mode[j] < 0 || mode[j] > 3) return CRB_ERR_ARG;
+    const int kin = (mode[j] & 1) ? conv_cout[j] : conv_cin[j], kout = (mode[j] & 1) ? conv_cin[j] : conv_cout[j];
     if (!w[j] || !U[j]) return CRB_ERR_ARG;
-    if (!crb_winograd4_supported(kin, kout, 31, 1)) return CRB_ERR_UNSUPPORTED;
+    if (!((mode[j] & 2) ? crb_winograd4c_supported(kin, kout, 31, 1) : crb_winograd4_supported(kin, kout, 31, 1))) return CRB_ERR_UNSUPPORTED;
     jobs.job[j] = Wino4WJob{w[j], (unsigned char*)U[j], strides[4 * j], strides[4 * j + 1], strides[4 * j + 2], strides[4 * j + 3], kin,
-                            kout, mode[j] ? 1 : 0, (int)blocks};
+                            kout, mode[j], (int)blocks};
     blocks += crb_cdiv((int64_t)(kin / 8) * kout, 256);
     if (blocks >= (1LL << 30)) return CRB_ERR_ARG;
   }
@@ -1188,6 +1630,55 @@ int crbhip_wino4_cu_busy_set(int cus, hipStream_t stream) {
   hipLaunchKernelGGL(cu_busy4_set_kernel, dim3(1), dim3(1), 0, stream, cus);
   CRB_CHECK_LAUNCH();
   return CRB_OK;
+}
+
+static int winograd4c_launch(const float* x, const void* U, float* y, int N, int H, int W, int cin, int cout, const float* bias, int relu,
+                             void* stream, float* stats) {
+  if (N <= 0 || H <= 0 || W <= 0) return CRB_ERR_ARG;
+  if (!crb_winograd4c_supported(cin, cout, H, W)) return CRB_ERR_UNSUPPORTED;
+  Wino4Args a;
+  a.x = x; a.U = (const unsigned char*)U; a.y = y; a.bias = bias; a.stats = stats;
+  a.N = N; a.H = H; a.W = W; a.cin = cin; a.cout = cout; a.relu = relu;
+  a.th = (H + 1) / 2; a.tw = (W + 1) / 2;
+  const int64_t rt = (int64_t)N * a.th;
+  if (rt >= (1LL << 30) || (int64_t)N * H * W * (cin > cout ? cin : cout) >= (1LL << 40)) return CRB_ERR_ARG;
+  a.RT = (int)rt;
+  a.tw4 = (a.tw + c4::TB_COLS - 1) / c4::TB_COLS;
+  const int64_t nb = (int64_t)((rt + c4::TB_ROWS - 1) / c4::TB_ROWS) * a.tw4;
+  if (nb >= (1LL << 26)) return CRB_ERR_ARG;
+  a.nblocks = (int)nb;
+  a.ncb = cout / c4::WG_K;
+  int dev = 0;
+  const int n_cu = device_cus4(&dev);
+  if (n_cu <= 0) return CRB_ERR_LAUNCH;
+  if (!(g_dev_attr4[dev].load(std::memory_order_acquire) & (1u << 31))) {
+    CRB_HIP(hipFuncSetAttribute((const void*)winograd4c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c4::LDS_BYTES));
+    g_dev_attr4[dev].fetch_or(1u << 31, std::memory_order_release);
+  }
+  const int64_t units = nb * a.ncb;
+  const int64_t grid = units < n_cu ? units : n_cu;
+  unsigned seq = (g_dev_seq4[dev].fetch_add(1, std::memory_order_relaxed) + 1) & 0xffffffu;
+  a.seq = (grid == n_cu) ? (seq ? seq : 1) : 0;
+  hipLaunchKernelGGL(winograd4c_kernel, dim3((unsigned)grid), dim3(NT), c4::LDS_BYTES, (hipStream_t)stream, a);
+  CRB_CHECK_LAUNCH();
+  return CRB_OK;
+}
+
+extern "C" int crb_conv3x3_winograd4c_nhwc(const float* x, const void* U, float* y, int N, int H, int W, int cin, int cout,
+                                           const float* bias, int relu, void* stream) {
+  return winograd4c_launch(x, U, y, N, H, W, cin, cout, bias, relu, stream, nullptr);
+}
+
+extern "C" int64_t crb_winograd4c_stats_slabs(int N, int H, int W) {
+  if (N <= 0 || H <= 0 || W <= 0) return 0;
+  const int64_t th = (H + 1) / 2, tw4 = ((W + 1) / 2 + c4::TB_COLS - 1) / c4::TB_COLS;
+  return ((N * th + c4::TB_ROWS - 1) / c4::TB_ROWS) * tw4;       // one slab per spatial block of 32 tiles
+}
+
+extern "C" int crb_conv3x3_winograd4c_stats_nhwc(const float* x, const void* U, float* y, float* stats, int N, int H, int W, int cin,
+                                                 int cout, void* stream) {
+  if (!stats) return CRB_ERR_ARG;
+  return winograd4c_launch(x, U, y, N, H, W, cin, cout, nullptr, 0, stream, stats);
 }
 
 static int winograd4_launch(const float* x, const void* U, float* y, int N, int H, int W, int cin, int cout, const float* bias, int relu,

@@ -794,6 +794,16 @@ int crb_conv3x3_winograd4_nhwc(const float* x, const void* U, float* y, int N, i
 int64_t crb_winograd4_stats_slabs(int N, int H, int W);
 int crb_conv3x3_winograd4_stats_nhwc(const float* x, const void* U, float* y, float* stats, int N, int H, int W, int cin, int cout,
                                      void* stream);
+/* The same convolution with a workgroup tile of 32 tiles x 128 output channels (round 6, third form): V of a spatial block is formed once
+ * per 128 output channels instead of once per 64. Cin % 16 == 0, Cout % 128 == 0; weight image: crb_winograd4_weights_conv(_multi) with
+ * mode + 2 (same bytes, other order); statistics slabs: crb_winograd4c_stats_slabs (one per block of 8 tile rows x 4 tile columns).
+ * Outputs bit-equal to crb_conv3x3_winograd4_nhwc. */
+int crb_winograd4c_supported(int cin, int cout, int H, int W);
+int crb_conv3x3_winograd4c_nhwc(const float* x, const void* U, float* y, int N, int H, int W, int cin, int cout,
+                                const float* bias, int relu, void* stream);
+int64_t crb_winograd4c_stats_slabs(int N, int H, int W);
+int crb_conv3x3_winograd4c_stats_nhwc(const float* x, const void* U, float* y, float* stats, int N, int H, int W, int cin,
+                                      int cout, void* stream);
 
 /* a7 backward: weight gradient of the same convolution in the Winograd domain (csrc/winograd_wgrad.hip):
  * dU[xi][ci][co] = sum over tiles of (B^T d B)[xi][ci] * (A dY A^T)[xi][co] as 16 MFMA GEMMs whose two operands are both

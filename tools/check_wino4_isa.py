@@ -19,7 +19,7 @@ def main(measure=False):
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
         text = open(out).read()
     bad = []
-    for m in re.finditer(r'^(_ZN\S*winograd4(b?)_kernel\S*):.*?s_endpgm', text, flags=re.S | re.M):
+    for m in re.finditer(r'^(_ZN\S*winograd4([bc]?)_kernel\S*):.*?s_endpgm', text, flags=re.S | re.M):
         name, body, second = m.group(1), m.group(0), m.group(2) == 'b'
         if 'ILi9E' in name:           # the stamp build (mode 9) may clobber accumulators: timing only
             continue
