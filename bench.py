@@ -215,7 +215,9 @@ def dominant_roofline(prof, overhead_ms, gather_roof, gather_table):
                 break
         except (OSError, ValueError, KeyError):
             continue
-    kname = ('winograd4_kernel: %s (F(2x2,3x3), f32 in / f32 out, every product as six bf16 MFMA passes over an exact three-way split of '
+    form_c = x6 and getattr(_w, 'FORM_C', False) and int(name.split('_')[3]) % 128 == 0       # winograd_conv_<cin>_<cout>_<H>_<W>
+    kname = (('winograd4c_kernel' if form_c else 'winograd4_kernel') +
+             ': %s (F(2x2,3x3), f32 in / f32 out, every product as six bf16 MFMA passes over an exact three-way split of '
              'the f32 operands, f32 accumulate; BEV backbone 3x3 convolutions)' if x6 else
              'winograd2_kernel / winograd2_wgrad_kernel: %s (F(2x2,3x3) f32 MFMA, BEV backbone 3x3 convolutions)') % name
     roof = {'bound': 'mfma', 'kernel': kname,
@@ -234,7 +236,7 @@ def dominant_roofline(prof, overhead_ms, gather_roof, gather_table):
         roof['note'] += ('; achieved / peak / frac price the ALGORITHMIC f32 flops of the 16 GEMMs against the f32-input MFMA peak (the dtype of '
                          'the path: f32 operands, f32 results, errors against f64 at the f32-MFMA kernel\'s level); the matrix pipe issues six '
                          'bf16 passes per product: bf16_mfma_TFLOPs_issued against the 2,500 TFLOP/s dense bf16 peak = bf16_mfma_frac. The '
-                         'kernel is bound by LDS traffic, not by the matrix pipe (DESIGN section 6)')
+                         'kernel is bound by the latency of its in-order loads and the input transform, not by the matrix pipe (DESIGN section 6)')
     return roof, gather_roof, table
 
 

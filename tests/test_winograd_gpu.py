@@ -386,3 +386,39 @@ def test_prepared_weight_images_equal_the_single_launches(dev, monkeypatch, kern
     fresh = winograd.weights_forward2(ws[0])
     assert fresh is not winograd._PREPARED.get(winograd._prep_key(ws[0], 0)) and not torch.equal(fresh, single[0][0])
     winograd._PREPARED.clear()
+
+
+@pytest.mark.parametrize('N,C,K,H,W', [(2, 128, 128, 50, 44), (1, 256, 256, 33, 22), (3, 64, 128, 31, 9), (2, 16, 384, 33, 17),
+                                       (1, 256, 128, 40, 31), (5, 32, 128, 37, 5), (3, 48, 128, 63, 70), (2, 128, 256, 47, 35)])
+def test_third_form_of_the_split_bf16_kernel_is_bit_equal_to_the_second(dev, monkeypatch, N, C, K, H, W):
+    """crb_conv3x3_winograd4c_nhwc (workgroup tile 32 tiles x 128 output channels, weight image in its own layout) against
+    crb_conv3x3_winograd4_nhwc (64 x 64): the same arithmetic in the same order - outputs with bias + ReLU, the statistics variant's
+    outputs and the column sums of its slabs (the slabs themselves cover other blocks), the input gradient: torch.equal. Ragged
+    shapes: blocks that straddle two images, partial tile rows / columns, fewer units than CUs."""
+    from crbhip import winograd, lib
+    monkeypatch.setattr(winograd, 'KERNEL', 'x6')
+    torch.manual_seed(N * 1000 + C)
+    x = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(K, C, 3, 3, device=dev) / np.sqrt(9 * C)
+    b = torch.randn(K, device=dev)
+    im = {}
+    for c in (False, True):
+        monkeypatch.setattr(winograd, 'FORM_C', c)
+        im[c] = winograd.weights_forward4(w)
+        assert bool(getattr(im[c], '_crb_c', False)) == c
+    assert im[True].numel() == im[False].numel() and not torch.equal(im[True], im[False])        # same bytes, another order
+    assert torch.equal(torch.sort(im[True].view(torch.int16)).values, torch.sort(im[False].view(torch.int16)).values)
+    ya, yc = winograd.conv3x3_U4(x, im[False], b, relu=True), winograd.conv3x3_U4(x, im[True], b, relu=True)
+    assert torch.equal(ya, yc)
+    (sa_y, sa), (sc_y, sc) = winograd.conv3x3_stats_U4(x, im[False]), winograd.conv3x3_stats_U4(x, im[True])
+    assert torch.equal(sa_y, sc_y) and sc.shape[0] == int(lib.crb_winograd4c_stats_slabs(N, H, W))
+    ref = torch.stack([sa_y.double().sum((0, 2, 3)), (sa_y.double() ** 2).sum((0, 2, 3))])
+    for s in (sa, sc):
+        assert float((s.double().sum(0) - ref).abs().max() / ref.abs().max()) <= 1e-6
+    if winograd.supported4(K, C, H, W) and C % 128 == 0:
+        dy = torch.randn(N, K, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+        g = {}
+        for c in (False, True):
+            monkeypatch.setattr(winograd, 'FORM_C', c)
+            g[c] = winograd.conv3x3_U4(dy, winograd.weights_input_grad4(w))
+        assert torch.equal(g[False], g[True])
