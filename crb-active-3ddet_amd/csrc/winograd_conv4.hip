@@ -783,22 +783,25 @@ __global__ __launch_bounds__(NT, 1) void winograd4c_kernel(Wino4Args a) {
   const int v_wr = (t_q >> 1) * V_REGION + t_tile * 16 + (t_q & 1) * 8 + t_h * (6 * V_XP);
   const float t_sg = t_h ? -1.f : 1.f;                              // X2 = -c3 for the pair {2, 3}
   int t_unit = u_first, tcnt = 0;
-  // raw read offsets of the lane's three patch columns (pixel column b of the patch sits at position t_tc + (b >> 1) + 5 (b & 1) of its
-  // row): X0 = c0 | c2, X1 = c2 | c1, X2 = c1 | c3
+  // raw read offsets of the lane's three patch columns: X0 = c0 | c2, X1 = c2 | c1, X2 = c1 | c3. Pixel x (0..9) of a block row sits at
+  // position pos(x) = x with 1 <-> 2 and 7 <-> 8 swapped: the order in which none of the three ds_read_b128 of a row has two lanes of
+  // a 16-lane group on one bank group with different addresses (found by enumeration for thread = (tile, quad, xi pair); the
+  // even | odd order of the 64 x 64 form gives 2-way conflicts here: SQ_LDS_BANK_CONFLICT 6.8 M cycles per launch)
+  auto px_pos = [](int x) { return (x == 1 || x == 2) ? 3 - x : (x == 7 || x == 8) ? 15 - x : x; };
   int raw_rd[3];
   auto raw_base = [&](int u) {
     const UnitPos p = c4::unit_at(u, a);
     const int rows_a = min(TB_ROWS, a.th - p.ty0);
     const int lr = 2 * t_tr + (t_tr >= rows_a ? 2 : 0);
     const int b0 = t_h ? 2 : 0, b1 = t_h ? 1 : 2, b2 = t_h ? 3 : 1;
-    raw_rd[0] = 16 * (4 * (lr * RAW_PX + t_tc + (b0 >> 1) + 5 * (b0 & 1)) + t_q);
-    raw_rd[1] = 16 * (4 * (lr * RAW_PX + t_tc + (b1 >> 1) + 5 * (b1 & 1)) + t_q);
-    raw_rd[2] = 16 * (4 * (lr * RAW_PX + t_tc + (b2 >> 1) + 5 * (b2 & 1)) + t_q);
+    raw_rd[0] = 16 * (4 * (lr * RAW_PX + px_pos(2 * t_tc + b0)) + t_q);
+    raw_rd[1] = 16 * (4 * (lr * RAW_PX + px_pos(2 * t_tc + b1)) + t_q);
+    raw_rd[2] = 16 * (4 * (lr * RAW_PX + px_pos(2 * t_tc + b2)) + t_q);
   };
   raw_base(t_unit);
 
   // ---- copy role. raw: slots s = T + 256 j (16 bytes each): s -> (pixel position P = s >> 2, channel quad s & 3), P = local
-  //      row * 10 + column order (x >> 1) + 5 (x & 1)
+  //      row * 10 + pos(x)
   int r_unit = u_first, rc = 0;
   const float* rsrc[4];
   unsigned rstep = 0;
@@ -812,7 +815,7 @@ __global__ __launch_bounds__(NT, 1) void winograd4c_kernel(Wino4Args a) {
       const int s = T + NT * j;
       const int P = s >> 2, q = s & 3;
       const int lr = P / RAW_PX, rem = P - lr * RAW_PX;
-      const int xx = rem < 5 ? 2 * rem : 2 * (rem - 5) + 1;
+      const int xx = px_pos(rem);                               // (pos is its own inverse)
       const bool in_a = lr < limit_a;
       const int n = in_a ? p.n0 : p.n0 + 1;
       const int py = in_a ? 2 * p.ty0 - 1 + lr : lr - limit_a - 1;

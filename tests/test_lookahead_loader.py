@@ -30,26 +30,30 @@ def test_training_loop_through_the_lookahead_loader_prefetches_and_gives_the_sam
     from pcdet.models import build_network, model_fn_decorator
     ds = SyntheticDataset(num_frames=8, n_points=6000)
     losses, hits = {}, {}
-    for look in (False, True):
-        torch.manual_seed(0)
-        model = build_network(second_cfg().MODEL, 3, ds).to(dev).train()
-        opt = torch.optim.SGD(model.parameters(), lr=1e-3)
-        loader = build_synthetic_dataloader(ds, 2)
-        if look:
-            loader = LookaheadLoader(loader)
-        fn = model_fn_decorator()
-        out = []
-        it = iter(loader)                                   # (the reference's loop: next(dataloader_iter), model_func(model, batch))
-        for _ in range(len(loader)):
-            batch = next(it)
-            opt.zero_grad()
-            loss, tb, _ = fn(model, batch)
-            loss.backward()
-            opt.step()
-            out.append(float(loss.detach()))
-        losses[look], hits[look] = out, model.__dict__.get('_crb_prefetch_hits', 0)
+    was = torch.are_deterministic_algorithms_enabled()
+    torch.use_deterministic_algorithms(True, warn_only=True)       # (bit-reproducible training steps: tests/test_determinism.py)
+    try:
+        for look in (False, True):
+            torch.manual_seed(0)
+            model = build_network(second_cfg().MODEL, 3, ds).to(dev).train()
+            opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+            loader = build_synthetic_dataloader(ds, 2)
+            if look:
+                loader = LookaheadLoader(loader)
+            fn = model_fn_decorator()
+            out = []
+            it = iter(loader)                                   # (the reference's loop: next(dataloader_iter), model_func(model, batch))
+            for _ in range(len(loader)):
+                batch = next(it)
+                opt.zero_grad()
+                loss, tb, _ = fn(model, batch)
+                loss.backward()
+                opt.step()
+                out.append(float(loss.detach()))
+            losses[look], hits[look] = out, model.__dict__.get('_crb_prefetch_hits', 0)
+    finally:
+        torch.use_deterministic_algorithms(was)
     assert hits[False] == 0 and hits[True] == len(losses[True]) - 1, hits
-    # same kernels on the same inputs, in another order of launches: the first forward is bit-equal; later steps carry the weight
-    # gradients' f32 atomic summation order, 1e-7 relative when measured
-    assert losses[True][0] == losses[False][0], (losses[True], losses[False])
-    np.testing.assert_allclose(losses[True], losses[False], rtol=2e-5)
+    # the same kernels on the same inputs in another order of launches, in the deterministic mode (the default mode's two atomically
+    # summed vendor weight gradients make the fourth loss of two runs differ by up to 1e-4 once a ReLU flips): equal, bit for bit
+    assert losses[True] == losses[False], (losses[True], losses[False])
