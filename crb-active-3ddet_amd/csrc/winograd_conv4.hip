@@ -703,7 +703,7 @@ constexpr int V_PHASE = 12 * V_XP;             // 14016
 constexpr int RAW_ROWS = 20, RAW_PX = 10;
 constexpr int RAW_SLOTS = 4 * NT;              // 1024 slots of 16 bytes (800 used: 20 rows x 10 pixels x 4 channel quads)
 constexpr int RAW_BYTES = RAW_SLOTS * 16;      // 16384
-constexpr int LDS_V = 0, LDS_RAW = 2 * V_PHASE, LDS_BYTES = LDS_RAW + RAW_BYTES;   // 44416
+constexpr int LDS_V = 0, LDS_RAW = 4 * V_PHASE, LDS_BYTES = LDS_RAW + 2 * RAW_BYTES;   // 88832: four V rows (two buffers of two xi rows), two raw blocks
 
 struct UnitPos { int cb, bc, R0, n0, ty0; };
 __device__ __forceinline__ UnitPos unit_at(int u, const Wino4Args& a) {
@@ -828,9 +828,12 @@ __global__ __launch_bounds__(NT, 1) void winograd4c_kernel(Wino4Args a) {
     }
   };
   raw_sources(r_unit);
+  int r_par = 0, t_par = 0;                         // raw block (of two) the next copy fills / the next transform read takes
   auto issue_raw = [&]() {
+    unsigned char* const dst = Rb + r_par * c4::RAW_BYTES;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(rsrc[j], Rb + (NT * j + wave * 64) * 16);
+    for (int j = 0; j < 4; ++j) glds16(rsrc[j], dst + (NT * j + wave * 64) * 16);
+    r_par ^= 1;
   };
   auto r_advance = [&]() {
     if (++rc < nch) {
@@ -963,7 +966,8 @@ __global__ __launch_bounds__(NT, 1) void winograd4c_kernel(Wino4Args a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) d[i][k] = *reinterpret_cast<const f32x4*>(Rb + raw_rd[k] + i * RAW_PX * 64);
+      for (int k = 0; k < 3; ++k) d[i][k] = *reinterpret_cast<const f32x4*>(Rb + t_par * c4::RAW_BYTES + raw_rd[k] + i * RAW_PX * 64);
+    t_par ^= 1;
   };
   auto t_col = [&](const f32x4 (&d)[4][3], int k) __attribute__((always_inline)) {
     tp[0][k] = d[0][k] - d[2][k];
@@ -1011,16 +1015,16 @@ __global__ __launch_bounds__(NT, 1) void winograd4c_kernel(Wino4Args a) {
     if (t_unit % a.ncb == 0) raw_base(t_unit);
   };
 
-  // ---- phases. f = 4 chunk + i: MFMAs of xi row i on V[f & 1] and the fragments requested a phase ago; V(f + 1) formed meanwhile;
-  //      raw(chunk + 1) requested in phase 0, read in phase 3
+  // ---- phases. f = 4 chunk + i: MFMAs of xi row i on V row i and the fragments requested a phase ago. ONE barrier per TWO xi rows:
+  //      rows (0, 1) and (2, 3) are the two V buffers; while the MFMAs run on one, the transform forms the other - row (i + 2) & 3, two
+  //      phases ahead, rows 0 and 1 for the next chunk from raw(chunk + 1) (two raw blocks: requested a chunk ahead in phase 2)
   auto phase = [&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
-    constexpr int rn = (i + 1) & 3;
-    if (i == 3) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    unsigned char* const Vn = Vb + ((i + 1) & 1) * V_PHASE;
-    const unsigned char* const Vc = Vb + (i & 1) * V_PHASE + b_rd;
+    constexpr int rn = (i + 2) & 3;
+    if (i == 2) { asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    else if (i == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    unsigned char* const Vn = Vb + rn * V_PHASE;
+    const unsigned char* const Vc = Vb + i * V_PHASE + b_rd;
     bf16x8 B[2][3];
     auto op_read = [&](int jx, int slot) __attribute__((always_inline)) {
 #pragma unroll
@@ -1028,16 +1032,15 @@ __global__ __launch_bounds__(NT, 1) void winograd4c_kernel(Wino4Args a) {
     };
     op_read(0, 0);
     f32x4 d[4][3];
-    if (i == 3) { t_read(d); t_advance(); }
-    if (i == 0) issue_raw();
+    if (i == 2) { t_read(d); t_advance(); issue_raw(); }
     __builtin_amdgcn_sched_barrier(0);
     // piece k behind MFMA k: the ten steps of the lane's two xi on every other MFMA (phase 3: the three column passes first)
     auto piece = [&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value;
-      if constexpr (i == 3 && k < 3) {
+      if constexpr (i == 2 && k < 3) {
         t_col(d, k);
       } else {
-        constexpr int k0 = (i == 3) ? k - 3 : k;
+        constexpr int k0 = (i == 2) ? k - 3 : k;
         if constexpr (k0 >= 0 && k0 < 20 && (k0 & 1) == 0) {
           t_xi(Vn, std::integral_constant<int, rn>{}, std::integral_constant<int, (k0 >> 1) / 5>{}, std::integral_constant<int, (k0 >> 1) % 5>{});
         }
@@ -1048,7 +1051,7 @@ __global__ __launch_bounds__(NT, 1) void winograd4c_kernel(Wino4Args a) {
       constexpr int jx = decltype(jc)::value;
       constexpr int s = jx & 1;
       const bf16x8 &A0 = Ar[jx][0], &A1 = Ar[jx][1], &A2 = Ar[jx][2];
-      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(i == 0 ? 13 : 9) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(i == 2 ? 13 : 9) : "memory");
       mfma_acc<4 * i + jx>(A0, B[s][2]);
       if (jx < 3) op_read(jx + 1, s ^ 1);
       piece(std::integral_constant<int, 6 * jx + 0>{});
@@ -1069,11 +1072,12 @@ __global__ __launch_bounds__(NT, 1) void winograd4c_kernel(Wino4Args a) {
     stage(std::integral_constant<int, 1>{});
     stage(std::integral_constant<int, 2>{});
     stage(std::integral_constant<int, 3>{});
-    if (i == 0) r_advance();
+    if (i == 2) r_advance();
   };
 
   // ---- prologue: raw(0) and the fragments of phase 0 in one round trip, raw(0) -> tp -> V(0)
   issue_raw(); r_advance();
+  issue_raw(); r_advance();                                       // raw(0), raw(1)
   a_load(std::integral_constant<int, 0>{}); a_load(std::integral_constant<int, 1>{});
   a_load(std::integral_constant<int, 2>{}); a_load(std::integral_constant<int, 3>{});
   u_advance();
@@ -1093,6 +1097,14 @@ __global__ __launch_bounds__(NT, 1) void winograd4c_kernel(Wino4Args a) {
   t_xi(Vb, std::integral_constant<int, 0>{}, std::integral_constant<int, JJ>{}, std::integral_constant<int, 4>{})
   CRB_T_XI_ALL(0); CRB_T_XI_ALL(1);
 #undef CRB_T_XI_ALL
+#define CRB_T_XI_ALL1(JJ)                                                                                                                 \
+  t_xi(Vb + V_PHASE, std::integral_constant<int, 1>{}, std::integral_constant<int, JJ>{}, std::integral_constant<int, 0>{});            \
+  t_xi(Vb + V_PHASE, std::integral_constant<int, 1>{}, std::integral_constant<int, JJ>{}, std::integral_constant<int, 1>{});            \
+  t_xi(Vb + V_PHASE, std::integral_constant<int, 1>{}, std::integral_constant<int, JJ>{}, std::integral_constant<int, 2>{});            \
+  t_xi(Vb + V_PHASE, std::integral_constant<int, 1>{}, std::integral_constant<int, JJ>{}, std::integral_constant<int, 3>{});            \
+  t_xi(Vb + V_PHASE, std::integral_constant<int, 1>{}, std::integral_constant<int, JJ>{}, std::integral_constant<int, 4>{})
+  CRB_T_XI_ALL1(0); CRB_T_XI_ALL1(1);
+#undef CRB_T_XI_ALL1
 
   for (int cg = 0; cg < total_chunks; ++cg) {
     phase(std::integral_constant<int, 0>{});
