@@ -857,13 +857,13 @@ __global__ __launch_bounds__(NT, 1) void winograd4c_kernel(Wino4Args a) {
     if (++u_cb == a.ncb) u_cb = 0;
     usrc = a.U + (int64_t)u_cb * nch * 4 * U_PHASE;
   };
-  bf16x8 Ar[4][3];                                   // the A fragments of the phase about to run
-  auto a_load = [&](auto jc) __attribute__((always_inline)) {
-    constexpr int jx = decltype(jc)::value;
+  bf16x8 Ar[2][4][3];                                // the A fragments of the next two phases (set = phase parity)
+  auto a_load = [&](auto sc, auto jc) __attribute__((always_inline)) {
+    constexpr int st = decltype(sc)::value, jx = decltype(jc)::value;
     const unsigned voff = (unsigned)a_rd + jx * U_XI;
-    Ar[jx][0] = gload16<0>(usrc, voff);
-    Ar[jx][1] = gload16<16>(usrc, voff);
-    Ar[jx][2] = gload16<32>(usrc, voff);
+    Ar[st][jx][0] = gload16<0>(usrc, voff);
+    Ar[st][jx][1] = gload16<16>(usrc, voff);
+    Ar[st][jx][2] = gload16<32>(usrc, voff);
   };
 
   acc_zero_range<0, 256>();
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(NT, 1) void winograd4c_kernel(Wino4Args a) {
   auto phase = [&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     constexpr int rn = (i + 2) & 3;
-    if (i == 2) { asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    if (i == 2) { asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
     else if (i == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
     unsigned char* const Vn = Vb + rn * V_PHASE;
     const unsigned char* const Vc = Vb + i * V_PHASE + b_rd;
@@ -1050,8 +1050,11 @@ __global__ __launch_bounds__(NT, 1) void winograd4c_kernel(Wino4Args a) {
     auto stage = [&](auto jc) __attribute__((always_inline)) {
       constexpr int jx = decltype(jc)::value;
       constexpr int s = jx & 1;
-      const bf16x8 &A0 = Ar[jx][0], &A1 = Ar[jx][1], &A2 = Ar[jx][2];
-      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(i == 2 ? 13 : 9) : "memory");
+      constexpr int cs = i & 1;
+      const bf16x8 &A0 = Ar[cs][jx][0], &A1 = Ar[cs][jx][1], &A2 = Ar[cs][jx][2];
+      // loads in flight behind the fragments of (this phase, xi jx), requested two phases ago: the other xi of that phase, the whole
+      // phase in between, this phase's requests so far, and the four raw copies of phase 2 while they are younger
+      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(i >= 2 ? 25 : 21) : "memory");
       mfma_acc<4 * i + jx>(A0, B[s][2]);
       if (jx < 3) op_read(jx + 1, s ^ 1);
       piece(std::integral_constant<int, 6 * jx + 0>{});
@@ -1064,7 +1067,7 @@ __global__ __launch_bounds__(NT, 1) void winograd4c_kernel(Wino4Args a) {
       mfma_acc<4 * i + jx>(A1, B[s][0]);
       piece(std::integral_constant<int, 6 * jx + 4>{});
       mfma_acc<4 * i + jx>(A0, B[s][0]);
-      a_load(jc);
+      a_load(std::integral_constant<int, cs>{}, jc);
       if (jx == 3) u_advance();
       piece(std::integral_constant<int, 6 * jx + 5>{});
     };
@@ -1078,9 +1081,14 @@ __global__ __launch_bounds__(NT, 1) void winograd4c_kernel(Wino4Args a) {
   // ---- prologue: raw(0) and the fragments of phase 0 in one round trip, raw(0) -> tp -> V(0)
   issue_raw(); r_advance();
   issue_raw(); r_advance();                                       // raw(0), raw(1)
-  a_load(std::integral_constant<int, 0>{}); a_load(std::integral_constant<int, 1>{});
-  a_load(std::integral_constant<int, 2>{}); a_load(std::integral_constant<int, 3>{});
-  u_advance();
+  {
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    a_load(I0{}, I0{}); a_load(I0{}, I1{}); a_load(I0{}, I2{}); a_load(I0{}, I3{});
+    u_advance();
+    a_load(I1{}, I0{}); a_load(I1{}, I1{}); a_load(I1{}, I2{}); a_load(I1{}, I3{});
+    u_advance();
+  }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   {
