@@ -5,6 +5,10 @@
 //   variant 0  copy              y[i] = x[i]                                             1 round trip
 //   variant 1  two round trips   fixed-stride neighbour list ell[i][0..7] -> rows x[ell] (summed) -> y[i]
 //   variant 2  three round trips cmask[i], cbase[i] -> packed[cbase[i] ..] -> rows (summed) -> y[i]   (the compact table's chain)
+//   variant 3  input-stationary  x[i] read ONCE, fixed-stride neighbour list ell[i][0..7] -> atomicAdd of the row into y[ell] (round 6,
+//              the formulation that moves the "algorithmic" bytes only - what does its scatter cost?); y pre-zeroed
+//   variant 4  the same with the rows of one workgroup (64 rows, consecutive in (b, z, y, x) order) first added into an LDS tile of
+//              the workgroup's own output rows when the neighbour falls into it (its x-neighbours), global atomics for the rest
 // One lane per (row, channel quad): a row of 16 floats is one 64-byte segment, read / written by 4 lanes of 16 bytes.
 #ifdef CRB_MEASURE
 #include "crb_common.h"
@@ -20,8 +24,40 @@ __global__ __launch_bounds__(256) void probe_chain_kernel(const float* __restric
                                                           const int* __restrict__ ell, float* __restrict__ y) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int i = t >> 2, q = t & 3;
-  if (i >= n) return;
   pf4 acc = (pf4){0.f, 0.f, 0.f, 0.f};
+  if (VARIANT == 3 || VARIANT == 4) {
+    const bool live = i < n;
+    __shared__ float tile[64 * 16];
+    const int row0 = blockIdx.x * 64;
+    if (VARIANT == 4) {
+      for (int e = threadIdx.x; e < 64 * 16; e += 256) tile[e] = 0.f;
+      __syncthreads();
+    }
+    const int ii = live ? i : 0;
+    const pf4 v = *reinterpret_cast<const pf4*>(x + (int64_t)ii * 16 + 4 * q);
+    const int4 e0 = *reinterpret_cast<const int4*>(ell + (int64_t)ii * 8), e1 = *reinterpret_cast<const int4*>(ell + (int64_t)ii * 8 + 4);
+    const int e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (e[k] < 0 || !live) continue;
+      if (VARIANT == 4 && e[k] >= row0 && e[k] < row0 + 64) {
+        float* t4 = tile + (e[k] - row0) * 16 + 4 * q;
+        atomicAdd(t4 + 0, v[0]); atomicAdd(t4 + 1, v[1]); atomicAdd(t4 + 2, v[2]); atomicAdd(t4 + 3, v[3]);
+      } else {
+        float* o = y + (int64_t)e[k] * 16 + 4 * q;
+        atomicAdd(o + 0, v[0]); atomicAdd(o + 1, v[1]); atomicAdd(o + 2, v[2]); atomicAdd(o + 3, v[3]);
+      }
+    }
+    if (VARIANT == 4) {
+      __syncthreads();
+      if (!live) return;
+      float* o = y + (int64_t)i * 16 + 4 * q;
+      const float* t4 = tile + (i - row0) * 16 + 4 * q;
+      atomicAdd(o + 0, t4[0]); atomicAdd(o + 1, t4[1]); atomicAdd(o + 2, t4[2]); atomicAdd(o + 3, t4[3]);
+    }
+    return;
+  }
+  if (i >= n) return;
   if (VARIANT == 0) {
     acc = *reinterpret_cast<const pf4*>(x + (int64_t)i * 16 + 4 * q);
   } else if (VARIANT == 1) {
@@ -144,6 +180,8 @@ extern "C" int crb_probe_gather_chain(int variant, const float* x, int64_t n, co
   if (variant == 0) hipLaunchKernelGGL(probe_chain_kernel<0>, grid, dim3(256), 0, st, x, (int)n, cmask, cbase, packed, ell, y);
   else if (variant == 1 && ell) hipLaunchKernelGGL(probe_chain_kernel<1>, grid, dim3(256), 0, st, x, (int)n, cmask, cbase, packed, ell, y);
   else if (variant == 2 && cmask && cbase && packed) hipLaunchKernelGGL(probe_chain_kernel<2>, grid, dim3(256), 0, st, x, (int)n, cmask, cbase, packed, ell, y);
+  else if (variant == 3 && ell) hipLaunchKernelGGL(probe_chain_kernel<3>, grid, dim3(256), 0, st, x, (int)n, cmask, cbase, packed, ell, y);
+  else if (variant == 4 && ell) hipLaunchKernelGGL(probe_chain_kernel<4>, grid, dim3(256), 0, st, x, (int)n, cmask, cbase, packed, ell, y);
   else return CRB_ERR_ARG;
   CRB_CHECK_LAUNCH();
   return CRB_OK;
